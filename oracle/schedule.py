@@ -1,0 +1,110 @@
+"""Noise-schedule tables and sampling-schedule matrices (oracle, CPU).
+
+Restates:
+  * cosine_simple_diffusion_schedule  -- algorithms/dfot/diffusion/noise_schedule.py:48-81
+  * make_beta_schedule (beta clip)    -- noise_schedule.py:6-33
+  * DiscreteDiffusion._build_buffer   -- algorithms/dfot/diffusion/discrete_diffusion.py:94-168
+  * ddim_idx_to_noise_level           -- discrete_diffusion.py:379-384
+  * _generate_scheduling_matrix       -- algorithms/common/base_pytorch_video_algo.py:877-913
+  * pyramid / interleaved variants    -- base_pytorch_video_algo.py:915-947
+  * CosineNoiseSchedule (training)    -- algorithms/dfot/diffusion/continuous_diffusion.py:46-92
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+
+
+@dataclass
+class ScheduleTables:
+    """fp32 lookup tables indexed by the integer noise level k in [0, timesteps)."""
+
+    alphas_cumprod: torch.Tensor
+    sqrt_alphas_cumprod: torch.Tensor
+    sqrt_one_minus_alphas_cumprod: torch.Tensor
+    logsnr: torch.Tensor
+    timesteps: int
+
+
+def _alphas_cumprod_cosine_simple(timesteps: int, logsnr_min: float, logsnr_max: float,
+                                  shifted: float, interpolated: bool) -> torch.Tensor:
+    f64 = torch.float64
+    lo = torch.atan(torch.exp(torch.tensor(-0.5 * logsnr_max, dtype=f64)))
+    hi = torch.atan(torch.exp(torch.tensor(-0.5 * logsnr_min, dtype=f64)))
+    u = torch.linspace(0, 1, timesteps, dtype=f64)
+    logsnr = -2.0 * torch.log(torch.tan(lo + u * (hi - lo)))
+    if shifted != 1.0:
+        moved = logsnr + 2.0 * math.log(shifted)
+        logsnr = u * logsnr + (1 - u) * moved if interpolated else moved
+    return torch.sigmoid(logsnr)
+
+
+def _alphas_cumprod_cosine(timesteps: int, s: float = 0.008) -> torch.Tensor:
+    # noise_schedule.py:36-45 (used by the discrete K600 configuration)
+    u = torch.linspace(0, timesteps, timesteps + 1, dtype=torch.float64) / timesteps
+    ac = torch.cos((u + s) / (1 + s) * math.pi * 0.5) ** 2
+    return (ac / ac[0])[1:]
+
+
+def build_tables(timesteps: int = 1000, beta_schedule: str = "cosine_simple_diffusion",
+                 shifted: float = 0.125, interpolated: bool = False,
+                 logsnr_min: float = -15.0, logsnr_max: float = 15.0,
+                 clip_min: float = 1e-9) -> ScheduleTables:
+    """alphas_cumprod is rebuilt from clipped betas exactly as the reference does
+    (schedule -> alpha ratios -> betas clipped to [1e-9, 1] -> cumprod), all in
+    float64, then cast to float32."""
+    if beta_schedule == "cosine_simple_diffusion":
+        ac = _alphas_cumprod_cosine_simple(timesteps, logsnr_min, logsnr_max, shifted, interpolated)
+    elif beta_schedule == "cosine":
+        ac = _alphas_cumprod_cosine(timesteps)
+    else:
+        raise ValueError(f"oracle: unsupported beta schedule {beta_schedule}")
+    ratio = torch.cat([ac[:1], ac[1:] / ac[:-1]])
+    betas = torch.clip(1.0 - ratio, clip_min, 1.0)
+    ac = torch.cumprod(1.0 - betas, dim=0)
+    snr = ac / (1.0 - ac)
+    f32 = torch.float32
+    return ScheduleTables(
+        alphas_cumprod=ac.to(f32),
+        sqrt_alphas_cumprod=torch.sqrt(ac).to(f32),
+        sqrt_one_minus_alphas_cumprod=torch.sqrt(1.0 - ac).to(f32),
+        logsnr=torch.log(snr).to(f32),
+        timesteps=timesteps,
+    )
+
+
+def ddim_levels(timesteps: int, sampling_timesteps: int) -> torch.Tensor:
+    """Table of sampling_timesteps+1 integer noise levels, entry 0 == -1 (clean)."""
+    return torch.linspace(-1, timesteps - 1, sampling_timesteps + 1).long()
+
+
+def scheduling_matrix(kind: str, horizon: int, padding: int, timesteps: int,
+                      sampling_timesteps: int) -> torch.Tensor:
+    """(M, horizon+padding) int64 noise levels; padded columns are pure noise."""
+    s = sampling_timesteps
+    if kind == "full_sequence":
+        idx = np.arange(s, -1, -1)[:, None].repeat(horizon, axis=1)
+    elif kind == "autoregressive":
+        rows = s + (horizon - 1) + 1
+        m = np.arange(rows)[:, None]
+        t = np.arange(horizon)[None, :]
+        idx = np.clip(s + t - m, 0, s)
+    else:
+        raise ValueError(f"oracle: unsupported scheduling matrix {kind}")
+    levels = ddim_levels(timesteps, s)[torch.from_numpy(idx).long()]
+    if padding > 0:
+        pad = torch.full((levels.shape[0], padding), timesteps - 1, dtype=torch.long)
+        levels = torch.cat([levels, pad], dim=1)
+    return levels
+
+
+def training_logsnr(t: torch.Tensor, shift: float = 0.125, logsnr_min: float = -15.0,
+                    logsnr_max: float = 15.0) -> torch.Tensor:
+    """Continuous-time cosine logSNR(t), t in [0,1] (fp32 like the reference buffers)."""
+    lo = torch.atan(torch.exp(-0.5 * torch.tensor(logsnr_max, dtype=torch.float32)))
+    hi = torch.atan(torch.exp(-0.5 * torch.tensor(logsnr_min, dtype=torch.float32)))
+    sh = 2 * torch.log(torch.tensor(shift, dtype=torch.float32))
+    return -2 * torch.log(torch.tan(lo + t * (hi - lo))) + sh
