@@ -1,0 +1,9 @@
+"""MI355X-native DFoT denoising engine (hot path only): HIP kernels behind a C ABI
+(``csrc/`` -> ``libdfot_hip.so``, ``include/dfot_hip.h``) plus the host-side mirror of the
+reference's backbone / sampler interfaces.  Importing it requires the built HIP library --
+there is no CPU fallback."""
+from . import capi  # noqa: F401  (raises ImportError when libdfot_hip.so is missing)
+from .backbone import UViT3DPose  # noqa: F401
+from .diffusion import DiffusionConfig, Schedule  # noqa: F401
+from .guidance import HistoryGuidance  # noqa: F401
+from .sampler import DFoTVideoPoseSampler, SamplerConfig, device_noise_fn  # noqa: F401

@@ -1,0 +1,193 @@
+"""Drop-in UViT3DPose backbone backed by libdfot_hip.so.
+
+Mirrors the reference's plugin contract for this path:
+  * constructor keywords of DiscreteDiffusion._build_model
+    (algorithms/dfot/diffusion/discrete_diffusion.py:84-92)
+  * ``forward(x, noise_levels, external_cond, external_cond_mask)`` of BaseBackbone
+    (algorithms/dfot/backbones/base_backbone.py:78-86, u_vit/u_vit3d_pose.py:63-131)
+  * state-dict key names / shapes, so reference checkpoints load with
+    ``load_state_dict``.
+Parameters live here as fp32 ``nn.Parameter``s (the reference layout); the C library keeps
+packed bf16 copies that are refreshed whenever a parameter changes.  Inference only
+(the engine has no backward yet): call under ``torch.no_grad()``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Dict, Optional, Sequence, Tuple
+
+import torch
+from torch import nn
+
+from . import capi
+
+
+def _get(cfg, key, default=None):
+    if isinstance(cfg, dict):
+        return cfg.get(key, default)
+    return getattr(cfg, key, default) if not hasattr(cfg, "get") else cfg.get(key, default)
+
+
+class _Node(nn.Module):
+    """Anonymous container so that dotted reference key names map onto a module tree."""
+
+
+class UViT3DPose(nn.Module):
+    def __init__(self, cfg, x_shape: Sequence[int], max_tokens: int, external_cond_dim: int = 0,
+                 external_cond_type: str = "action", external_cond_num_classes: Optional[int] = None,
+                 use_causal_mask: bool = False, **kwargs):
+        super().__init__()
+        block_types = list(_get(cfg, "block_types", ["ResBlock", "ResBlock", "TransformerBlock", "TransformerBlock"]))
+        if block_types != ["ResBlock", "ResBlock", "TransformerBlock", "TransformerBlock"]:
+            raise ValueError(f"unsupported block_types {block_types}")
+        if _get(cfg, "pos_emb_type", "rope") != "rope":
+            raise ValueError("only pos_emb_type='rope' is supported")
+        if not _get(cfg, "use_fourier_noise_embedding", True):
+            raise ValueError("only the Fourier noise-level embedding (continuous diffusion) is supported")
+        cond = _get(cfg, "conditioning", None)
+        cond_dim = _get(cond, "dim", None) if cond is not None else None
+        self.cfg = cfg
+        self.x_shape = tuple(x_shape)
+        self.max_tokens = self.temporal_length = int(max_tokens)
+        self.external_cond_dim = int(cond_dim or 180)
+        self.use_causal_mask = use_causal_mask
+        c = capi.UViTConfig()
+        c.channels[:] = list(_get(cfg, "channels"))
+        c.emb_channels = int(_get(cfg, "emb_channels"))
+        c.num_updown_blocks[:] = list(_get(cfg, "num_updown_blocks"))
+        c.num_mid_blocks = int(_get(cfg, "num_mid_blocks"))
+        c.num_heads = int(_get(cfg, "num_heads"))
+        c.in_channels = int(self.x_shape[0])
+        c.resolution = int(self.x_shape[-1])
+        c.max_tokens = self.max_tokens
+        c.cond_dim = self.external_cond_dim
+        c.noise_dim = 256
+        c.rope_theta = 10000.0
+        c.eps = 1e-6
+        if int(_get(cfg, "patch_size", 2)) != 2:
+            raise ValueError("only patch_size=2 is supported")
+        self._ccfg = c
+        self._handle = C.c_void_p()
+        capi.check(capi.lib.dfot_uvit_create(C.byref(c), C.byref(self._handle)))
+        self._names = []
+        self._persistent_buffers = {"noise_level_pos_embedding.timesteps.freqs",
+                                    "noise_level_pos_embedding.timesteps.phases"}
+        shape = (C.c_int64 * 4)()
+        ndim = C.c_int()
+        for i in range(capi.lib.dfot_uvit_num_params(self._handle)):
+            name = capi.lib.dfot_uvit_param_name(self._handle, i).decode()
+            capi.check(capi.lib.dfot_uvit_param_shape(self._handle, i, shape, C.byref(ndim)))
+            self._register(name, tuple(shape[k] for k in range(ndim.value)))
+            self._names.append(name)
+        self._synced: Optional[Tuple] = None
+        self._reserved = 0
+
+    # ------------------------------------------------------------------ module tree
+    def _register(self, name: str, shape: Tuple[int, ...]) -> None:
+        *path, leaf = name.split(".")
+        node: nn.Module = self
+        for part in path:
+            if part not in node._modules:
+                node.add_module(part, _Node())
+            node = node._modules[part]
+        t = torch.zeros(shape, dtype=torch.float32)
+        if name in self._persistent_buffers:
+            node.register_buffer(leaf, t, persistent=True)
+        else:
+            node.register_parameter(leaf, nn.Parameter(t))
+
+    def _tensors(self) -> Dict[str, torch.Tensor]:
+        sd = dict(self.named_parameters())
+        sd.update(dict(self.named_buffers()))
+        return sd
+
+    def reset_parameters(self, seed: int = 0) -> None:
+        """Reference-style default init (zero-initialised output projections included)."""
+        g = torch.Generator().manual_seed(seed)
+        with torch.no_grad():
+            for name, t in self._tensors().items():
+                leaf = name.rsplit(".", 1)[-1]
+                if leaf == "freqs":
+                    t.copy_(2 * math.pi * torch.randn(t.shape, generator=g))
+                elif leaf == "phases":
+                    t.copy_(2 * math.pi * torch.rand(t.shape, generator=g))
+                elif any(s in name for s in (".attn_out.", ".mlp_out.2.", ".out_rest.1.", "project_output")):
+                    t.zero_()
+                elif leaf == "bias":
+                    t.zero_()
+                elif t.ndim == 1:
+                    t.fill_(1.0)
+                else:
+                    fan_in = math.prod(t.shape[1:])
+                    bound = 1.0 / math.sqrt(fan_in)
+                    t.copy_((torch.rand(t.shape, generator=g) * 2 - 1) * bound)
+
+    # ------------------------------------------------------------------ weights -> engine
+    def _signature(self) -> Tuple:
+        return tuple((t.data_ptr(), t._version) for t in self._tensors().values())
+
+    def sync_weights(self, force: bool = False) -> None:
+        sig = self._signature()
+        if not force and sig == self._synced:
+            return
+        tensors = self._tensors()
+        s = capi.stream_ptr()
+        for name in self._names:
+            t = tensors[name]
+            if not t.is_cuda:
+                raise RuntimeError(f"parameter {name} is on {t.device}; move the module to the GPU first")
+            src = t.detach().to(torch.float32).contiguous()
+            shape = (C.c_int64 * src.ndim)(*src.shape)
+            capi.check(capi.lib.dfot_uvit_load_weight(self._handle, name.encode(), capi.ptr(src), shape, src.ndim, s))
+        capi.check(capi.lib.dfot_uvit_finalize(self._handle, s))
+        self._synced = sig
+
+    def set_option(self, key: str, value: int) -> None:
+        capi.check(capi.lib.dfot_uvit_set_option(self._handle, key.encode(), int(value)))
+
+    def reserve(self, batch: int) -> None:
+        if batch > self._reserved:
+            torch.cuda.synchronize()
+            capi.check(capi.lib.dfot_uvit_reserve(self._handle, int(batch)))
+            self._reserved = batch
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, x: torch.Tensor, noise_levels: torch.Tensor, external_cond: Optional[torch.Tensor] = None,
+                external_cond_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+        assert x.shape[1] == self.temporal_length, (
+            f"Temporal length of U-ViT is set to {self.temporal_length}, but input has temporal length {x.shape[1]}.")
+        assert external_cond is not None, "External condition (camera pose) is required for U-ViT3DPose model."
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()) and x.requires_grad:
+            raise RuntimeError("the HIP engine is inference-only; call under torch.no_grad()")
+        b = x.shape[0]
+        if tuple(x.shape[2:]) != self.x_shape:
+            raise ValueError(f"x has frame shape {tuple(x.shape[2:])}, expected {self.x_shape}")
+        if tuple(external_cond.shape) != (b, self.temporal_length, self.external_cond_dim, *self.x_shape[1:]):
+            raise ValueError(f"external_cond has shape {tuple(external_cond.shape)}")
+        if external_cond_mask is not None:
+            assert external_cond_mask.ndim == 1, "embedding mask should be of shape (B,)"
+        self.sync_weights()
+        self.reserve(b)
+        xf = x.detach().to(torch.float32).contiguous()
+        kf = noise_levels.detach().to(torch.float32).contiguous()
+        cf = external_cond.detach().to(torch.float32).contiguous()
+        mf = None if external_cond_mask is None else external_cond_mask.to(torch.uint8).contiguous()
+        out = torch.empty_like(xf)
+        capi.check(capi.lib.dfot_uvit_forward(self._handle, capi.ptr(xf), capi.ptr(kf), capi.ptr(cf), capi.ptr(mf),
+                                              capi.ptr(out), b, capi.stream_ptr()))
+        return out.to(x.dtype)
+
+    def read_tap(self, name: str, channels: int, level: int, batch: int) -> torch.Tensor:
+        r = self.x_shape[-1] // 2 // (2 ** level)
+        out = torch.empty(batch * self.temporal_length, channels, r, r, device="cuda", dtype=torch.float32)
+        capi.check(capi.lib.dfot_uvit_read_tap(self._handle, name.encode(), capi.ptr(out), out.numel(), capi.stream_ptr()))
+        return out
+
+    def __del__(self):
+        try:
+            if getattr(self, "_handle", None) and self._handle.value:
+                capi.lib.dfot_uvit_destroy(self._handle)
+                self._handle = C.c_void_p()
+        except Exception:
+            pass

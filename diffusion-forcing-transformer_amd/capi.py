@@ -1,0 +1,88 @@
+"""ctypes binding of libdfot_hip.so (include/dfot_hip.h).
+
+There is no CPU fallback: importing this module raises if the HIP library has not been
+built (``python -c "import __graft_entry__ as g; g.build()"``), and every call raises
+``DfotError`` with the library's message when a status code is non-zero.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdfot_hip.so")
+
+OK, ERR_ARG, ERR_SHAPE, ERR_HIP, ERR_STATE, ERR_NAME = range(6)
+
+
+class DfotError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__(f"libdfot_hip error {code}: {message}")
+        self.code = code
+
+
+class UViTConfig(C.Structure):
+    _fields_ = [
+        ("channels", C.c_int32 * 4), ("emb_channels", C.c_int32), ("num_updown_blocks", C.c_int32 * 3),
+        ("num_mid_blocks", C.c_int32), ("num_heads", C.c_int32), ("in_channels", C.c_int32),
+        ("resolution", C.c_int32), ("max_tokens", C.c_int32), ("cond_dim", C.c_int32), ("noise_dim", C.c_int32),
+        ("rope_theta", C.c_float), ("eps", C.c_float),
+    ]
+
+
+# name -> (restype, argtypes); every symbol include/dfot_hip.h declares
+_P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
+SIGNATURES = {
+    "dfot_last_error": (C.c_char_p, []),
+    "dfot_version": (_I, []),
+    "dfot_uvit_create": (_I, [C.POINTER(UViTConfig), C.POINTER(_P)]),
+    "dfot_uvit_destroy": (_I, [_P]),
+    "dfot_uvit_num_params": (_I, [_P]),
+    "dfot_uvit_param_name": (C.c_char_p, [_P, _I]),
+    "dfot_uvit_param_shape": (_I, [_P, _I, C.POINTER(_L), C.POINTER(_I)]),
+    "dfot_uvit_load_weight": (_I, [_P, C.c_char_p, _P, C.POINTER(_L), _I, _P]),
+    "dfot_uvit_finalize": (_I, [_P, _P]),
+    "dfot_uvit_reserve": (_I, [_P, _I]),
+    "dfot_uvit_workspace_bytes": (C.c_size_t, [_P]),
+    "dfot_uvit_set_option": (_I, [_P, C.c_char_p, _I]),
+    "dfot_uvit_forward": (_I, [_P, _P, _P, _P, _P, _P, _I, _P]),
+    "dfot_uvit_read_tap": (_I, [_P, C.c_char_p, _P, C.c_size_t, _P]),
+    "dfot_ray_encode": (_I, [_P, _P, _I, _I, _I, _P]),
+    "dfot_hg_prepare": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _L, _P]),
+    "dfot_ddim_compose": (_I, [_P] * 11 + [_I, _I, _I, _L, _P]),
+    "dfot_op_gemm": (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "dfot_op_conv3x3": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "dfot_op_attention": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "dfot_op_f32_to_bf16": (_I, [_P, _P, _L, _P]),
+    "dfot_op_bf16_to_f32": (_I, [_P, _P, _L, _P]),
+}
+
+
+def _load() -> C.CDLL:
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: the HIP extension has not been built. There is no CPU fallback; "
+            "run `python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc).")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
+        fn.restype, fn.argtypes = res, args
+    return lib
+
+
+lib = _load()
+
+
+def check(code: int) -> None:
+    if code != OK:
+        raise DfotError(code, (lib.dfot_last_error() or b"").decode())
+
+
+def ptr(t) -> C.c_void_p:
+    """Device pointer of a torch tensor (None -> NULL)."""
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+def stream_ptr() -> C.c_void_p:
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

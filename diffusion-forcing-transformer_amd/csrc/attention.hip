@@ -1,0 +1,220 @@
+// Flash-style non-causal self-attention forward for the DFoT transformer levels (gfx950).
+//   level 2: N = T*32*32 = 8192 tokens, d = 64 ; level 3: N = 2048, d = 128 ; 9 heads.
+//
+// One workgroup = 4 waves = 128 query rows of one (batch, head); each wave owns 32 query rows.
+// Both products are computed "transposed" so that the query index stays on the MFMA lane:
+//   S^T (keys x q)  = K  (A operand, LDS rows)        x Q^T (B operand, registers)
+//   O^T (dv   x q)  = V^T(A operand, LDS transposed read) x P^T (B operand = exp'd S^T registers)
+// With v_mfma_f32_32x32x16_bf16 the accumulator of S^T holds, per lane, 16 keys of ONE query
+// column, so the online-softmax statistics (running max m, sum l, rescale alpha) and the O^T
+// accumulator columns are all lane-local; the only cross-lane traffic is one exchange with lane^32.
+// The S^T accumulator registers are used directly as the B fragment of the second product; the
+// k (=key) order inside a 16-key step is then permuted (key = 16s + 8(j>>2) + 4h + (j&3)), and the
+// V^T fragment is fetched in that same order by two ds_read_b64_tr_b16 per step
+// (cdna_hip_programming.md section 3 "accumulator tile as the next MFMA's operand", T10).
+// Scores are in the exp2 domain: the caller folds log2(e)/sqrt(d) into q.
+#include "common.h"
+#include "dfot_hip.h"
+
+namespace dfot {
+
+template <int D>
+struct AttnCfg {
+  static constexpr int KV = 64;                  // keys per tile
+  static constexpr int ROWB = D * 2;             // bytes per K/V row in LDS
+  static constexpr int TILE = KV * ROWB;         // bytes of one K or V tile
+  static constexpr int CH = D / 8;               // 16-byte chunks per row
+  static constexpr int PER_THREAD = KV * CH / 256;
+  __device__ static int swz_k(int row, int c) { return D == 64 ? (c ^ ((row >> 1) & 7)) : (c ^ (row & 15)); }
+  __device__ static int swz_v(int row, int c) { return D == 64 ? (c ^ (((row >> 1) & 1) << 2)) : (c ^ ((row & 3) << 2)); }
+};
+
+template <int D, bool USE_TR>
+__global__ __launch_bounds__(256) void attn_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K,
+                                                   const bf16* __restrict__ V, bf16* __restrict__ O, long ldo,
+                                                   int N, int heads) {
+  using C = AttnCfg<D>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lq = lane & 31, lh = lane >> 5;
+  const int bh = blockIdx.y;
+  const long base = (long)bh * N * D;
+  const int q0 = blockIdx.x * 128 + wave * 32;
+  const bf16* Qb = Q + base;
+  const bf16* Kb = K + base;
+  const bf16* Vb = V + base;
+
+  // Q fragments: B operand, lane holds Q[q0+lq][16*ks + 8*lh + j]
+  bf16x8 qf[D / 16];
+#pragma unroll
+  for (int ks = 0; ks < D / 16; ++ks)
+    qf[ks] = *reinterpret_cast<const bf16x8*>(Qb + (long)(q0 + lq) * D + ks * 16 + lh * 8);
+
+  f32x16 oacc[D / 32];
+#pragma unroll
+  for (int i = 0; i < D / 32; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[i][r] = 0.f;
+  float m_i = -INFINITY, l_i = 0.f;
+
+  bf16x8 rk[C::PER_THREAD], rv[C::PER_THREAD];
+  auto load_tile = [&](int t) {
+#pragma unroll
+    for (int i = 0; i < C::PER_THREAD; ++i) {
+      const int e = tid + 256 * i;
+      const int row = e / C::CH, c = e % C::CH;
+      const long off = (long)(t * C::KV + row) * D + c * 8;
+      rk[i] = *reinterpret_cast<const bf16x8*>(Kb + off);
+      rv[i] = *reinterpret_cast<const bf16x8*>(Vb + off);
+    }
+  };
+  auto store_tile = [&](int stage) {
+    char* sk = smem + stage * 2 * C::TILE;
+    char* sv = sk + C::TILE;
+#pragma unroll
+    for (int i = 0; i < C::PER_THREAD; ++i) {
+      const int e = tid + 256 * i;
+      const int row = e / C::CH, c = e % C::CH;
+      *reinterpret_cast<bf16x8*>(sk + row * C::ROWB + C::swz_k(row, c) * 16) = rk[i];
+      *reinterpret_cast<bf16x8*>(sv + row * C::ROWB + C::swz_v(row, c) * 16) = rv[i];
+    }
+  };
+
+  const int nt = N / C::KV;
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+
+  for (int t = 0; t < nt; ++t) {
+    const int cur = t & 1;
+    const char* sk = smem + cur * 2 * C::TILE;
+    const char* sv = sk + C::TILE;
+    if (t + 1 < nt) load_tile(t + 1);
+
+    // ---- S^T = K Q^T : two 32-key sub-tiles ----
+    f32x16 sacc[2];
+#pragma unroll
+    for (int kt2 = 0; kt2 < 2; ++kt2) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sacc[kt2][r] = 0.f;
+      const int row = kt2 * 32 + lq;
+#pragma unroll
+      for (int ks = 0; ks < D / 16; ++ks) {
+        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sk + row * C::ROWB + C::swz_k(row, ks * 2 + lh) * 16);
+        sacc[kt2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sacc[kt2], 0, 0, 0);
+      }
+    }
+
+    // ---- online softmax (exp2 domain), statistics lane-local per query column ----
+    float mx = sacc[0][0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sacc[0][r]);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[1][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float m_new = fmaxf(m_i, mx);
+    const float alpha = __builtin_amdgcn_exp2f(m_i - m_new);
+    float rs = 0.f;
+    bf16x8 pf[2][2];
+#pragma unroll
+    for (int kt2 = 0; kt2 < 2; ++kt2)
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float p = __builtin_amdgcn_exp2f(sacc[kt2][8 * s + j] - m_new);
+          rs += p;
+          pf[kt2][s][j] = f2bf(p);
+        }
+    l_i = l_i * alpha + rs;
+    m_i = m_new;
+#pragma unroll
+    for (int i = 0; i < D / 32; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
+
+    // ---- O^T += V^T P^T ----
+#pragma unroll
+    for (int dvt = 0; dvt < D / 32; ++dvt) {
+#pragma unroll
+      for (int kt2 = 0; kt2 < 2; ++kt2) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          bf16x8 vf;
+          if constexpr (USE_TR) {
+            // 16-lane group gi=lane>>4 reads the 4x16 block rows kb+{0..3}, cols dvt*32 + 16*(gi&1) + {0..15};
+            // lane 4q+p of the group supplies row q, columns 4p..4p+3
+            const int kb = kt2 * 32 + 16 * s + 4 * lh;
+            const int q4 = (lane & 15) >> 2, p4 = lane & 3;
+            const int col = dvt * 32 + 16 * ((lane >> 4) & 1) + 4 * p4;
+            const int r0 = kb + q4, r1 = kb + 8 + q4;
+            const char* a0 = sv + r0 * C::ROWB + C::swz_v(r0, col >> 3) * 16 + (col & 7) * 2;
+            const char* a1 = sv + r1 * C::ROWB + C::swz_v(r1, col >> 3) * 16 + (col & 7) * 2;
+            const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                (bf16x4 __attribute__((address_space(3)))*)(a0));
+            const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                (bf16x4 __attribute__((address_space(3)))*)(a1));
+            vf = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          } else {
+            const int dv = dvt * 32 + lq;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              const int key = kt2 * 32 + 16 * s + 8 * (j >> 2) + 4 * lh + (j & 3);
+              vf[j] = *reinterpret_cast<const bf16*>(sv + key * C::ROWB + C::swz_v(key, dv >> 3) * 16 + (dv & 7) * 2);
+            }
+          }
+          oacc[dvt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[kt2][s], oacc[dvt], 0, 0, 0);
+        }
+      }
+    }
+
+    if (t + 1 < nt) store_tile(cur ^ 1);
+    __syncthreads();
+  }
+
+  // ---- normalise and store: lane holds O[q0+lq][dvt*32 + 8*g + 4*lh + {0..3}] in oacc[dvt][4g..4g+3] ----
+  const float l_tot = l_i + __shfl_xor(l_i, 32);
+  const float inv = 1.0f / l_tot;
+  const int b = bh / heads, hd = bh % heads;
+  bf16* orow = O + ((long)b * N + q0 + lq) * ldo + hd * D;
+#pragma unroll
+  for (int dvt = 0; dvt < D / 32; ++dvt)
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      bf16x4 o4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o4[j] = f2bf(oacc[dvt][4 * g4 + j] * inv);
+      *reinterpret_cast<bf16x4*>(orow + dvt * 32 + 8 * g4 + 4 * lh) = o4;
+    }
+}
+
+template <int D, bool TR>
+static int launch_attn_t(const bf16* q, const bf16* k, const bf16* v, bf16* o, long ldo, int batch, int heads, int n,
+                         hipStream_t stream) {
+  auto kern = attn_kernel<D, TR>;
+  const int lds = 4 * AttnCfg<D>::TILE;
+  static bool attr_set = false;
+  if (!attr_set) {
+    DFOT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(n / 128, batch * heads), dim3(256), lds, stream, q, k, v, o, ldo, n, heads);
+  DFOT_CHECK_HIP(hipGetLastError());
+  return DFOT_OK;
+}
+
+int launch_attention(const bf16* q, const bf16* k, const bf16* v, bf16* o, long ldo, int batch, int heads, int n, int d,
+                     int variant, hipStream_t stream) {
+  DFOT_REQUIRE(q && k && v && o, DFOT_ERR_ARG, "attention: null pointer");
+  DFOT_REQUIRE(d == 64 || d == 128, DFOT_ERR_SHAPE, "attention: head dim %d not in {64,128}", d);
+  DFOT_REQUIRE(n > 0 && n % 128 == 0, DFOT_ERR_SHAPE, "attention: N=%d must be a multiple of 128", n);
+  DFOT_REQUIRE(ldo % 4 == 0, DFOT_ERR_SHAPE, "attention: output row stride %ld must be a multiple of 4", ldo);
+  if (d == 64) {
+    return variant == 1 ? launch_attn_t<64, false>(q, k, v, o, ldo, batch, heads, n, stream)
+                        : launch_attn_t<64, true>(q, k, v, o, ldo, batch, heads, n, stream);
+  }
+  return variant == 1 ? launch_attn_t<128, false>(q, k, v, o, ldo, batch, heads, n, stream)
+                      : launch_attn_t<128, true>(q, k, v, o, ldo, batch, heads, n, stream);
+}
+
+}  // namespace dfot

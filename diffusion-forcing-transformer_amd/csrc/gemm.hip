@@ -1,0 +1,296 @@
+// bf16 MFMA GEMM (C = A * W^T) and implicit-GEMM 3x3 convolution for gfx950, with the DFoT
+// backbone's fused epilogues.
+//
+// Tile: 128x128x64 per 256-thread workgroup (4 waves as 2x2, each wave 64x64 = 4x4 MFMA
+// 16x16x32 bf16 tiles).  Both operands are K-major, so A and W fragments are read from LDS the
+// same way: one ds_read_b128 per lane = 8 consecutive k of one row.  LDS rows are 128 B (64 bf16);
+// the 16-byte chunk c of row r is stored at position c ^ ((r>>1)&7): any 16 consecutive rows
+// read at one logical chunk hit 16 distinct slots of the 256-B bank row (conflict-free
+// ds_read_b128, MI355X_MICROARCH.md LDS table).
+// Staging: global_load_lds_dwordx4 (LDS-DMA).  The LDS image of one wave instruction is linear
+// (8 rows x 128 B), so the swizzle is applied to the per-lane SOURCE address
+// (cdna_hip_programming.md rule 21); a register-staged path (DMA=false) is kept for A/B testing.
+// Two LDS stages; next tile's loads are issued before the current tile's MFMAs.
+#include "gemm.h"
+#include "dfot_hip.h"
+
+namespace dfot {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int STAGE_BYTES = (BM + BN) * BK * 2;  // 32 KiB
+constexpr int A_BYTES = BM * BK * 2;
+
+template <int AMODE>
+struct RowSrc {
+  const bf16* ptr[4];  // dense: row base (+swizzled chunk); conv: pixel base of the centre tap
+  int y[4], x[4];
+};
+
+template <int AMODE, int EPI, bool DMA>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int tiles_n = (g.N + BN - 1) / BN;
+  const int tn = blockIdx.x % tiles_n, tm = blockIdx.x / tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int nk = g.K / BK;
+
+  // ---- per-thread staging geometry: 4 A chunks + 4 W chunks of 16 B per k-tile ----
+  const int prow = lane >> 3;  // row within the 8-row group written by one wave instruction
+  const int ppos = lane & 7;   // 16-byte position within the 128-byte LDS row
+  const bf16* a_src[4];
+  int a_y[4], a_x[4];
+  const bf16* w_src[4];
+  int a_chunk[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = 8 * (4 * i + wave) + prow;
+    const int c = ppos ^ ((r >> 1) & 7);
+    a_chunk[i] = c;
+    const long m = (long)m0 + r;
+    if constexpr (AMODE == A_DENSE) {
+      a_src[i] = g.A + m * g.lda + c * 8;
+      a_y[i] = a_x[i] = 0;
+    } else {
+      const int xw = (int)(m % g.Wd);
+      const int yh = (int)((m / g.Wd) % g.H);
+      a_x[i] = xw;
+      a_y[i] = yh;
+      a_src[i] = g.A + m * (long)g.Cin + c * 8;
+    }
+    int n = n0 + r;
+    n = n < g.N ? n : g.N - 1;
+    w_src[i] = g.W + (long)n * g.K + c * 8;
+  }
+
+  auto a_addr = [&](int i, int kt) -> const bf16* {
+    if constexpr (AMODE == A_DENSE) {
+      return a_src[i] + (long)kt * BK;
+    } else {
+      const int kbase = kt * BK;
+      const int tap = kbase / g.Cin;
+      const int c0 = kbase - tap * g.Cin;
+      const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+      const int yy = a_y[i] + dy, xx = a_x[i] + dx;
+      const bool ok = (yy >= 0) && (yy < g.H) && (xx >= 0) && (xx < g.Wd);
+      const bf16* p = a_src[i] + ((long)dy * g.Wd + dx) * g.Cin + c0;
+      return ok ? p : g.zeros + a_chunk[i] * 8;
+    }
+  };
+
+  bf16x8 ra[4], rw[4];  // register staging (DMA=false)
+
+  auto issue = [&](int kt, int stage) {
+    char* sa = smem + stage * STAGE_BYTES;
+    char* sw = sa + A_BYTES;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const bf16* pa = a_addr(i, kt);
+      const bf16* pw = w_src[i] + (long)kt * BK;
+      if constexpr (DMA) {
+        __builtin_amdgcn_global_load_lds(DFOT_GLOBAL_PTR(pa), DFOT_LDS_PTR(sa + (4 * i + wave) * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(DFOT_GLOBAL_PTR(pw), DFOT_LDS_PTR(sw + (4 * i + wave) * 1024), 16, 0, 0);
+      } else {
+        ra[i] = *reinterpret_cast<const bf16x8*>(pa);
+        rw[i] = *reinterpret_cast<const bf16x8*>(pw);
+      }
+    }
+  };
+  auto commit = [&](int stage) {  // DMA=false only: registers -> LDS
+    char* sa = smem + stage * STAGE_BYTES;
+    char* sw = sa + A_BYTES;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int off = (4 * i + wave) * 1024 + lane * 16;
+      *reinterpret_cast<bf16x8*>(sa + off) = ra[i];
+      *reinterpret_cast<bf16x8*>(sw + off) = rw[i];
+    }
+  };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int frow = lane & 15, fk = lane >> 4;
+  auto compute = [&](int stage) {
+    const char* sa = smem + stage * STAGE_BYTES;
+    const char* sw = sa + A_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 af[4], wf[4];
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) {
+        const int r = wm * 64 + mi * 16 + frow;
+        const int pos = (ks * 4 + fk) ^ ((r >> 1) & 7);
+        af[mi] = *reinterpret_cast<const bf16x8*>(sa + r * 128 + pos * 16);
+      }
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) {
+        const int r = wn * 64 + ni * 16 + frow;
+        const int pos = (ks * 4 + fk) ^ ((r >> 1) & 7);
+        wf[ni] = *reinterpret_cast<const bf16x8*>(sw + r * 128 + pos * 16);
+      }
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mi], wf[ni], acc[mi][ni], 0, 0, 0);
+    }
+  };
+
+  // ---- main loop ----
+  issue(0, 0);
+  if constexpr (DMA) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  } else {
+    commit(0);
+  }
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) issue(kt + 1, cur ^ 1);
+    compute(cur);
+    if constexpr (DMA) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+      if (kt + 1 < nk) commit(cur ^ 1);
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue ----
+  const int colq = lane & 15, rowq = (lane >> 4) * 4;
+  if constexpr (EPI == E_FILM_GN || EPI == E_FILM_RMS) {
+    // columns of this wave: [scale ch 0..31 | shift ch 0..31] of channel group (n0 + wn*64)/64
+    const int cgrp = (n0 + wn * 64) >> 6;
+    if (n0 + wn * 64 < g.N) {
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) {
+        const int c = cgrp * 32 + ni * 16 + colq;
+        const int col_scale = n0 + wn * 64 + ni * 16 + colq;
+        const int col_shift = col_scale + 32;
+        const float b_scale = g.bias[col_scale], b_shift = g.bias[col_shift];
+        float na, nb;
+        if constexpr (EPI == E_FILM_GN) {
+          const int bt = m0 / g.rows_per_bt;
+          const int grp = c / (g.C / 32);
+          const float mean = g.gn_sums[(bt * 32 + grp) * 2 + 0], rs = g.gn_sums[(bt * 32 + grp) * 2 + 1];
+          na = rs * g.gamma[c];
+          nb = g.beta[c] - mean * na;
+        } else {
+          na = g.gamma[c];
+          nb = 0.f;
+        }
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const long m = (long)m0 + wm * 64 + mi * 16 + rowq + j;
+            const float scale = acc[mi][ni][j] + b_scale;
+            const float shift = acc[mi][ni + 2][j] + b_shift;
+            float y;
+            if constexpr (EPI == E_FILM_GN) {
+              const float hv = bf2f(g.h_bf16[m * g.ldh + c]);
+              y = silu_f((hv * na + nb) * (1.f + scale) + shift);
+            } else {
+              const float xv = g.x_f32[m * g.ldh + c];
+              // RMSNorm output is rounded to the activation dtype before the gain (normalization.py:52-53)
+              y = (xv * g.rstd[m]) * na * (1.f + scale) + shift;
+            }
+            g.out_bf16[m * g.ldo + c] = f2bf(y);
+          }
+        }
+      }
+    }
+  } else {
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+      const int col = n0 + wn * 64 + ni * 16 + colq;
+      if (col >= g.N) continue;
+      const float bv = g.bias ? g.bias[col] : 0.f;
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const long m = (long)m0 + wm * 64 + mi * 16 + rowq + j;
+          float v = acc[mi][ni][j] + bv;
+          if constexpr (EPI == E_F32) {
+            if (g.resid) v += g.resid[m * g.ldo + col];
+            g.out_f32[m * g.ldo + col] = v;
+          } else if constexpr (EPI == E_BF16) {
+            g.out_bf16[m * g.ldo + col] = f2bf(v);
+          } else if constexpr (EPI == E_QKV) {
+            if (col < g.split) {
+              g.out_bf16[m * g.ldo + col] = f2bf(v);
+            } else {
+              g.out2[m * g.ldo2 + (col - g.split)] = f2bf(silu_f(v));
+            }
+          } else if constexpr (EPI == E_POSE) {
+            const int bt = (int)(m / g.rows_per_bt);
+            const int b = (int)(m / g.rows_per_batch);
+            const float keep = (g.cond_mask && g.cond_mask[b]) ? 0.f : 1.f;
+            g.out_bf16[m * g.ldo + col] = f2bf(v * keep + g.nemb[(long)bt * g.N + col]);
+          }
+        }
+      }
+    }
+  }
+}
+
+template <int AMODE, int EPI, bool DMA>
+static int launch_t(const GemmArgs& g, hipStream_t stream) {
+  const int tiles = (g.M / BM) * ((g.N + BN - 1) / BN);
+  auto kern = gemm_kernel<AMODE, EPI, DMA>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    DFOT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       2 * STAGE_BYTES));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(tiles), dim3(256), 2 * STAGE_BYTES, stream, g);
+  DFOT_CHECK_HIP(hipGetLastError());
+  return DFOT_OK;
+}
+
+template <int AMODE, int EPI>
+static int launch_d(bool dma, const GemmArgs& g, hipStream_t s) {
+  return dma ? launch_t<AMODE, EPI, true>(g, s) : launch_t<AMODE, EPI, false>(g, s);
+}
+
+int launch_gemm(int amode, int epi, bool lds_dma, const GemmArgs& g, hipStream_t stream) {
+  DFOT_REQUIRE(g.A && g.W, DFOT_ERR_ARG, "gemm: null operand");
+  DFOT_REQUIRE(g.M > 0 && g.M % BM == 0, DFOT_ERR_SHAPE, "gemm: M=%d must be a positive multiple of %d", g.M, BM);
+  DFOT_REQUIRE(g.K > 0 && g.K % BK == 0, DFOT_ERR_SHAPE, "gemm: K=%d must be a positive multiple of %d", g.K, BK);
+  DFOT_REQUIRE(g.N > 0, DFOT_ERR_SHAPE, "gemm: N=%d", g.N);
+  if (amode == A_CONV3) {
+    DFOT_REQUIRE(g.Cin % BK == 0 && g.K == 9 * g.Cin, DFOT_ERR_SHAPE, "conv3x3: Cin=%d must be a multiple of %d", g.Cin, BK);
+    DFOT_REQUIRE(g.zeros != nullptr, DFOT_ERR_ARG, "conv3x3: zero page missing");
+    DFOT_REQUIRE(g.H > 0 && g.Wd > 0 && g.M % (g.H * g.Wd) == 0, DFOT_ERR_SHAPE, "conv3x3: M=%d not a whole number of %dx%d images", g.M, g.H, g.Wd);
+  }
+  if (epi == E_FILM_GN || epi == E_FILM_RMS) {
+    DFOT_REQUIRE(g.N == 2 * g.C && g.C % 32 == 0, DFOT_ERR_SHAPE, "film: N=%d must be 2*C, C=%d %% 32 == 0", g.N, g.C);
+    DFOT_REQUIRE(epi == E_FILM_RMS || (g.rows_per_bt % BM == 0), DFOT_ERR_SHAPE, "film: rows per image %d must be a multiple of %d", g.rows_per_bt, BM);
+  }
+  if (amode == A_DENSE) {
+    switch (epi) {
+      case E_F32: return launch_d<A_DENSE, E_F32>(lds_dma, g, stream);
+      case E_BF16: return launch_d<A_DENSE, E_BF16>(lds_dma, g, stream);
+      case E_QKV: return launch_d<A_DENSE, E_QKV>(lds_dma, g, stream);
+      case E_FILM_GN: return launch_d<A_DENSE, E_FILM_GN>(lds_dma, g, stream);
+      case E_FILM_RMS: return launch_d<A_DENSE, E_FILM_RMS>(lds_dma, g, stream);
+      case E_POSE: return launch_d<A_DENSE, E_POSE>(lds_dma, g, stream);
+    }
+  } else if (amode == A_CONV3) {
+    switch (epi) {
+      case E_F32: return launch_d<A_CONV3, E_F32>(lds_dma, g, stream);
+      case E_BF16: return launch_d<A_CONV3, E_BF16>(lds_dma, g, stream);
+    }
+  }
+  set_error("gemm: unsupported mode/epilogue combination %d/%d", amode, epi);
+  return DFOT_ERR_ARG;
+}
+
+}  // namespace dfot

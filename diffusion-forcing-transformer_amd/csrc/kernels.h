@@ -1,0 +1,54 @@
+// HBM-bound kernels of the DFoT backbone and sampler step (launch wrappers).
+#pragma once
+#include "common.h"
+
+namespace dfot {
+
+// ---- embeddings ----
+int launch_noise_emb(const float* k, const float* freqs, const float* phases, const float* w1, const float* b1,
+                     const float* w2, const float* b2, float* out, int bt, int ndim, int e, hipStream_t s);
+int launch_embed_input(const float* x, const float* w, const float* b, float* out, int bt, int res, int cin, int c0,
+                       hipStream_t s);
+int launch_cond_repack(const float* cond, bf16* a, int bt, int res, int cdim, int kpad, hipStream_t s);
+int launch_emb_pyramid(const bf16* emb0, bf16* emb1, bf16* emb2, bf16* emb3, int bt, int r0, int e, hipStream_t s);
+int launch_project_output(const float* x0, const float* w, const float* b, float* out, int bt, int res, int c0, int cout,
+                          hipStream_t s);
+// ---- norms ----
+// stats[bt][32][2] = (mean, rstd) over (pixels x channels-of-group); partial = scratch [bt][nblk][32][2]
+int launch_gn_stats_f32(const float* x, float* partial, float* stats, int bt, int pixels, int c, float eps, hipStream_t s);
+int launch_gn_stats_bf16(const bf16* x, float* partial, float* stats, int bt, int pixels, int c, float eps, hipStream_t s);
+int gn_partial_blocks(int pixels);
+int launch_gn_apply_silu(const float* x, const float* stats, const float* gamma, const float* beta, bf16* out, int bt,
+                         int pixels, int c, hipStream_t s);
+int launch_rms_stats(const float* x, float* rstd, long m, int c, float eps, hipStream_t s);
+int launch_qk_norm_rope(const bf16* qkv, const float* qw, const float* kw, const float* cs, bf16* q, bf16* k, bf16* v,
+                        int batch, int n, int heads, int d, float qscale, float eps, hipStream_t s);
+// ---- resampling / skips ----
+int launch_pool2_bf16(const float* x, bf16* out, int bt, int h, int w, int c, hipStream_t s);
+int launch_sub_bf16(const float* a, const float* b, bf16* out, long n, hipStream_t s);
+int launch_upsample_add(const float* t, const float* skip, float* out, int bt, int h, int w, int c, hipStream_t s);
+// ---- pose ----
+int launch_ray_encode(const float* poses, float* out, int b, int t, int res, hipStream_t s);
+// ---- sampler ----
+int launch_hg_prepare(const float* x, const float* noise, const float* qa, const float* qb, float* x_in, int batch,
+                      int nfe, int tokens, long f, hipStream_t s);
+int launch_ddim_compose(const float* x, const float* x_in, const float* v, const float* sa, const float* s1,
+                        const float* an, const float* cn, const float* keep, const float* weight, const uint8_t* gen,
+                        float* x_next, int batch, int nfe, int tokens, long f, hipStream_t s);
+// ---- casts / weight packing ----
+int launch_f32_to_bf16(const float* src, bf16* dst, long n, hipStream_t s);
+int launch_bf16_to_f32(const bf16* src, float* dst, long n, hipStream_t s);
+// dst[r][col0 + k] (row stride ldd) = src[map ? map[r] : r][k] for k < K ; zero for K <= k < kpad
+int launch_pack_rows(const float* src, bf16* dst, const int* map, int rows, int k, int kpad, long ldd, int col0,
+                     hipStream_t s);
+// conv weight [Co][Ci][3][3] fp32 -> [Co][(ky*3+kx)*Ci + ci] bf16
+int launch_pack_conv3(const float* src, bf16* dst, int co, int ci, hipStream_t s);
+int launch_gather_f32(const float* src, float* dst, const int* map, int n, hipStream_t s);
+// activation layout helpers for taps: [BT][P][C] fp32 -> [BT][C][P] fp32
+int launch_nhwc_to_nchw(const float* src, float* dst, int bt, int p, int c, hipStream_t s);
+int launch_bf16_nhwc_to_nchw(const bf16* src, float* dst, int bt, int p, int c, hipStream_t s);
+
+int launch_attention(const bf16* q, const bf16* k, const bf16* v, bf16* o, long ldo, int batch, int heads, int n, int d,
+                     int variant, hipStream_t stream);
+
+}  // namespace dfot

@@ -1,0 +1,708 @@
+// HBM-bound kernels of the DFoT backbone: embeddings, norms, resampling, weight packing (gfx950).
+// All activations are channels-last ("[frame][pixel][channel]"), so the reference's
+// "(b t) c h w -> b (t h w) c" rearranges at the transformer levels are no-ops here.
+#include "kernels.h"
+#include "dfot_hip.h"
+
+namespace dfot {
+
+typedef __attribute__((ext_vector_type(4))) float float4v;
+typedef __attribute__((ext_vector_type(2))) float float2v;
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// --------------------------------------------------------------------------------------------
+// noise-level embedding: Fourier features -> Linear -> SiLU -> Linear  (embeddings.py:67-110)
+// one workgroup per (video, token); a wave computes one output row at a time (coalesced weights)
+// --------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void noise_emb_kernel(const float* __restrict__ k, const float* __restrict__ freqs,
+                                                        const float* __restrict__ phases, const float* __restrict__ w1,
+                                                        const float* __restrict__ b1, const float* __restrict__ w2,
+                                                        const float* __restrict__ b2, float* __restrict__ out, int ndim,
+                                                        int e) {
+  extern __shared__ float sm[];  // [ndim] fourier, [e] hidden
+  float* f = sm;
+  float* h = sm + ndim;
+  const int bt = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float kv = k[bt];
+  for (int i = tid; i < ndim; i += 256) f[i] = cosf(__fadd_rn(__fmul_rn(kv, freqs[i]), phases[i])) * 1.41421356237309515f;
+  __syncthreads();
+  for (int row = wave; row < e; row += 4) {
+    float acc = 0.f;
+    for (int i = lane; i < ndim; i += 64) acc += w1[(long)row * ndim + i] * f[i];
+    acc = wave_sum(acc);
+    if (lane == 0) h[row] = silu_f(acc + b1[row]);
+  }
+  __syncthreads();
+  for (int row = wave; row < e; row += 4) {
+    float acc = 0.f;
+    for (int i = lane; i < e; i += 64) acc += w2[(long)row * e + i] * h[i];
+    acc = wave_sum(acc);
+    if (lane == 0) out[(long)bt * e + row] = acc + b2[row];
+  }
+}
+
+int launch_noise_emb(const float* k, const float* freqs, const float* phases, const float* w1, const float* b1,
+                     const float* w2, const float* b2, float* out, int bt, int ndim, int e, hipStream_t s) {
+  hipLaunchKernelGGL(noise_emb_kernel, dim3(bt), dim3(256), (ndim + e) * sizeof(float), s, k, freqs, phases, w1, b1, w2,
+                     b2, out, ndim, e);
+  DFOT_CHECK_HIP(hipGetLastError());
+  return DFOT_OK;
+}
+
+// --------------------------------------------------------------------------------------------
+// EmbedInput: conv k2 s2, Cin(3) -> C0, NCHW fp32 in, channels-last fp32 out (u_vit_blocks.py:16-30)
+// --------------------------------------------------------------------------------------------
+__global__ void embed_input_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
+                                   float* __restrict__ out, long total, int res, int cin, int c0) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int c = (int)(idx % c0);
+  const long pix = idx / c0;
+  const int r0 = res / 2;
+  const int px = (int)(pix % r0), py = (int)((pix / r0) % r0);
+  const long bt = pix / ((long)r0 * r0);
+  float acc = b[c];
+  for (int ci = 0; ci < cin; ++ci) {
+    const float* xp = x + ((bt * cin + ci) * res + 2 * py) * (long)res + 2 * px;
+    const float* wp = w + ((long)c * cin + ci) * 4;
+    acc += xp[0] * wp[0] + xp[1] * wp[1] + xp[res] * wp[2] + xp[res + 1] * wp[3];
+  }
+  out[idx] = acc;
+}
+
+int launch_embed_input(const float* x, const float* w, const float* b, float* out, int bt, int res, int cin, int c0,
+                       hipStream_t s) {
+  const long total = (long)bt * (res / 2) * (res / 2) * c0;
+  hipLaunchKernelGGL(embed_input_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, x, w, b, out, total, res, cin, c0);
+  DFOT_CHECK_HIP(hipGetLastError());
+  return DFOT_OK;
+}
+
+// --------------------------------------------------------------------------------------------
+// pose conditioning repack: cond [BT][cdim][res][res] fp32 -> patch rows A[(bt,py,px)][k] bf16,
+// k = c*4 + dy*2 + dx (the flatten order of the Conv2d weight), rows padded to kpad.
+// one workgroup = one patch row py and a chunk of CC channels; transposed through LDS
+// --------------------------------------------------------------------------------------------
+constexpr int RP_CC = 20;
+__global__ __launch_bounds__(256) void cond_repack_kernel(const float* __restrict__ cond, bf16* __restrict__ a, int res,
+                                                          int cdim, int kpad) {
+  extern __shared__ bf16 tile[];  // [r0][RP_CC*4 + 2]
+  const int r0 = res / 2;
+  const int ld = RP_CC * 4 + 2;
+  const int chunk = blockIdx.x, py = blockIdx.y, bt = blockIdx.z;
+  const int c0 = chunk * RP_CC;
+  for (int e = threadIdx.x; e < RP_CC * 2 * res; e += blockDim.x) {
+    const int xx = e % res;
+    const int dy = (e / res) & 1;
+    const int cc = e / (2 * res);
+    const float v = cond[(((long)bt * cdim + c0 + cc) * res + 2 * py + dy) * res + xx];
+    tile[(xx >> 1) * ld + cc * 4 + dy * 2 + (xx & 1)] = f2bf(v);
+  }
+  __syncthreads();
+  const int kk = RP_CC * 4;
+  for (int e = threadIdx.x; e < r0 * kk; e += blockDim.x) {
+    const int px = e / kk, k = e % kk;
+    a[((long)(bt * r0 + py) * r0 + px) * kpad + c0 * 4 + k] = tile[px * ld + k];
+  }
+}
+
+int launch_cond_repack(const float* cond, bf16* a, int bt, int res, int cdim, int kpad, hipStream_t s) {
+  DFOT_REQUIRE(cdim % RP_CC == 0, DFOT_ERR_SHAPE, "cond_repack: cond dim %d must be a multiple of %d", cdim, RP_CC);
+  const int r0 = res / 2;
+  const size_t lds = (size_t)r0 * (RP_CC * 4 + 2) * sizeof(bf16);
+  hipLaunchKernelGGL(cond_repack_kernel, dim3(cdim / RP_CC, r0, bt), dim3(256), lds, s, cond, a, res, cdim, kpad);
+  DFOT_CHECK_HIP(hipGetLastError());
+  return DFOT_OK;
+}
+
+// --------------------------------------------------------------------------------------------
+// embedding pyramid: avg_pool2d(emb, 2^l) for l = 1,2,3 from the level-0 map (u_vit3d_pose.py:99-107)
+// thread = (8x8 level-0 pixel block, 8 channels)
+// --------------------------------------------------------------------------------------------
+__global__ void emb_pyramid_kernel(const bf16* __restrict__ e0, bf16* __restrict__ e1, bf16* __restrict__ e2,
+                                   bf16* __restrict__ e3, long total, int r0, int e) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int ec = e / 8;
+  const int c8 = (int)(idx % ec);
+  const long blk = idx / ec;
+  const int r3 = r0 / 8;
+  const int bx = (int)(blk % r3), by = (int)((blk / r3) % r3);
+  const long bt = blk / ((long)r3 * r3);
+  float s3[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int qy = 0; qy < 2; ++qy)
+    for (int qx = 0; qx < 2; ++qx) {
+      float s2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      for (int hy = 0; hy < 2; ++hy)
+        for (int hx = 0; hx < 2; ++hx) {
+          float s1[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+          for (int py = 0; py < 2; ++py)
+            for (int px = 0; px < 2; ++px) {
+              const int y = by * 8 + qy * 4 + hy * 2 + py, x = bx * 8 + qx * 4 + hx * 2 + px;
+              const bf16x8 v = *reinterpret_cast<const bf16x8*>(e0 + ((bt * r0 + y) * r0 + x) * e + c8 * 8);
+#pragma unroll
+              for (int j = 0; j < 8; ++j) s1[j] += bf2f(v[j]);
+            }
+          bf16x8 o;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            o[j] = f2bf(s1[j] * 0.25f);
+            s2[j] += s1[j];
+          }
+          const int y1 = by * 4 + qy * 2 + hy, x1 = bx * 4 + qx * 2 + hx;
+          *reinterpret_cast<bf16x8*>(e1 + ((bt * (r0 / 2) + y1) * (r0 / 2) + x1) * e + c8 * 8) = o;
+        }
+      bf16x8 o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        o[j] = f2bf(s2[j] * (1.f / 16.f));
+        s3[j] += s2[j];
+      }
+      const int y2 = by * 2 + qy, x2 = bx * 2 + qx;
+      *reinterpret_cast<bf16x8*>(e2 + ((bt * (r0 / 4) + y2) * (r0 / 4) + x2) * e + c8 * 8) = o;
+    }
+  bf16x8 o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = f2bf(s3[j] * (1.f / 64.f));
+  *reinterpret_cast<bf16x8*>(e3 + ((bt * r3 + by) * r3 + bx) * e + c8 * 8) = o;
+}
+
+int launch_emb_pyramid(const bf16* emb0, bf16* emb1, bf16* emb2, bf16* emb3, int bt, int r0, int e, hipStream_t s) {
+  DFOT_REQUIRE(r0 % 8 == 0 && e % 8 == 0, DFOT_ERR_SHAPE, "emb_pyramid: level-0 size %d / emb %d must be multiples of 8", r0, e);
+  const long total = (long)bt * (r0 / 8) * (r0 / 8) * (e / 8);
+  hipLaunchKernelGGL(emb_pyramid_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, emb0, emb1, emb2, emb3, total, r0, e);
+  DFOT_CHECK_HIP(hipGetLastError());
+  return DFOT_OK;
+}
+
+// --------------------------------------------------------------------------------------------
+// ProjectOutput: conv_transpose k2 s2, C0 -> cout(3), channels-last in, NCHW out (u_vit_blocks.py:33-49)
+// weight layout [C0][cout][2][2]; thread = one level-0 pixel, 4*cout outputs
+// --------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void project_output_kernel(const float* __restrict__ x0, const float* __restrict__ w,
+                                                             const float* __restrict__ b, float* __restrict__ out,
+                                                             long npix, int res, int c0, int cout) {
+  extern __shared__ float wl[];  // [c0][cout*4]
+  const int nw = c0 * cout * 4;
+  for (int i = threadIdx.x; i < nw; i += blockDim.x) wl[i] = w[i];
+  __syncthreads();
+  const long pix = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (pix >= npix) return;
+  const int r0 = res / 2;
+  const int px = (int)(pix % r0), py = (int)((pix / r0) % r0);
+  const long bt = pix / ((long)r0 * r0);
+  float acc[12];
+  for (int o = 0; o < cout * 4; ++o) acc[o] = 0.f;
+  const float* xp = x0 + pix * c0;
+  for (int c = 0; c < c0; c += 4) {
+    const float4v xv = *reinterpret_cast<const float4v*>(xp + c);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      for (int o = 0; o < cout * 4; ++o) acc[o] += xv[j] * wl[(c + j) * cout * 4 + o];
+  }
+  for (int co = 0; co < cout; ++co)
+    for (int dy = 0; dy < 2; ++dy) {
+      float2v v;
+      v[0] = acc[co * 4 + dy * 2 + 0] + b[co];
+      v[1] = acc[co * 4 + dy * 2 + 1] + b[co];
+      *reinterpret_cast<float2v*>(out + ((bt * cout + co) * res + 2 * py + dy) * (long)res + 2 * px) = v;
+    }
+}
+
+int launch_project_output(const float* x0, const float* w, const float* b, float* out, int bt, int res, int c0, int cout,
+                          hipStream_t s) {
+  DFOT_REQUIRE(cout <= 3 && c0 % 4 == 0, DFOT_ERR_SHAPE, "project_output: cout=%d (<=3), c0=%d", cout, c0);
+  const long npix = (long)bt * (res / 2) * (res / 2);
+  hipLaunchKernelGGL(project_output_kernel, dim3(cdiv(npix, 256)), dim3(256), c0 * cout * 4 * sizeof(float), s, x0, w, b,
+                     out, npix, res, c0, cout);
+  DFOT_CHECK_HIP(hipGetLastError());
+  return DFOT_OK;
+}
+
+// --------------------------------------------------------------------------------------------
+// GroupNorm(32 groups) statistics over channels-last tensors, deterministic two-stage reduction
+// --------------------------------------------------------------------------------------------
+constexpr int GN_PIX_PER_BLOCK = 512;
+int gn_partial_blocks(int pixels) { return cdiv(pixels, GN_PIX_PER_BLOCK); }
+
+template <typename T>
+__global__ __launch_bounds__(256) void gn_partial_kernel(const T* __restrict__ x, float* __restrict__ partial,
+                                                         int pixels, int c) {
+  __shared__ float red_s[256], red_q[256];
+  const int bt = blockIdx.y, blk = blockIdx.x, nblk = gridDim.x;
+  const int quads = c / 4;                 // 4-channel quads per pixel
+  const int ppass = 256 / quads;           // pixels per pass
+  const int q = threadIdx.x % quads, pp = threadIdx.x / quads;
+  const int cpg = c / 32;                  // channels per group (>= 4)
+  const int p0 = blk * GN_PIX_PER_BLOCK;
+  const int p1 = min(p0 + GN_PIX_PER_BLOCK, pixels);
+  float s = 0.f, ss = 0.f;
+  {
+    for (int p = p0 + pp; p < p1; p += ppass) {
+      const T* src = x + ((long)bt * pixels + p) * c + q * 4;
+      float v[4];
+      if constexpr (sizeof(T) == 4) {
+        const float4v t = *reinterpret_cast<const float4v*>(src);
+        v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
+      } else {
+        const bf16x4 t = *reinterpret_cast<const bf16x4*>(src);
+        v[0] = bf2f(t[0]); v[1] = bf2f(t[1]); v[2] = bf2f(t[2]); v[3] = bf2f(t[3]);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        s += v[j];
+        ss += v[j] * v[j];
+      }
+    }
+  }
+  // deterministic in-block reduction: every group has exactly 8 contributing threads
+  // ((cpg/4) quads x ppass pixel-lanes); one thread per (group, moment) sums them in fixed order
+  red_s[threadIdx.x] = s;
+  red_q[threadIdx.x] = ss;
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const int g = threadIdx.x & 31, which = threadIdx.x >> 5;
+    const float* r = which ? red_q : red_s;
+    const int qpg = cpg / 4;  // quads per group
+    float t = 0.f;
+    for (int pl = 0; pl < ppass; ++pl)
+      for (int qq = 0; qq < qpg; ++qq) t += r[pl * quads + g * qpg + qq];
+    partial[(((long)bt * nblk + blk) * 32 + g) * 2 + which] = t;
+  }
+}
+
+__global__ void gn_finalize_kernel(const float* __restrict__ partial, float* __restrict__ stats, int nblk, float inv_count,
+                                   float eps) {
+  const int bt = blockIdx.x, g = threadIdx.x;
+  if (g >= 32) return;
+  float s = 0.f, ss = 0.f;
+  for (int b = 0; b < nblk; ++b) {
+    s += partial[(((long)bt * nblk + b) * 32 + g) * 2 + 0];
+    ss += partial[(((long)bt * nblk + b) * 32 + g) * 2 + 1];
+  }
+  const float mean = s * inv_count;
+  const float var = fmaxf(ss * inv_count - mean * mean, 0.f);
+  stats[(bt * 32 + g) * 2 + 0] = mean;
+  stats[(bt * 32 + g) * 2 + 1] = rsqrtf(var + eps);
+}
+
+template <typename T>
+static int launch_gn_stats_t(const T* x, float* partial, float* stats, int bt, int pixels, int c, float eps, hipStream_t s) {
+  DFOT_REQUIRE(c == 128 || c == 256 || c == 512 || c == 1024, DFOT_ERR_SHAPE, "group_norm: channels %d not in {128,256,512,1024}", c);
+  const int nblk = gn_partial_blocks(pixels);
+  hipLaunchKernelGGL(gn_partial_kernel<T>, dim3(nblk, bt), dim3(256), 0, s, x, partial, pixels, c);
+  DFOT_CHECK_HIP(hipGetLastError());
+  const float inv = 1.f / ((float)pixels * (float)(c / 32));
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(bt), dim3(64), 0, s, partial, stats, nblk, inv, eps);
+  DFOT_CHECK_HIP(hipGetLastError());
+  return DFOT_OK;
+}
+int launch_gn_stats_f32(const float* x, float* partial, float* stats, int bt, int pixels, int c, float eps, hipStream_t s) {
+  return launch_gn_stats_t<float>(x, partial, stats, bt, pixels, c, eps, s);
+}
+int launch_gn_stats_bf16(const bf16* x, float* partial, float* stats, int bt, int pixels, int c, float eps, hipStream_t s) {
+  return launch_gn_stats_t<bf16>(x, partial, stats, bt, pixels, c, eps, s);
+}
+
+// GroupNorm apply + SiLU, fp32 in -> bf16 out (feeds the 3x3 conv's A operand)
+__global__ void gn_apply_silu_kernel(const float* __restrict__ x, const float* __restrict__ stats,
+                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                     bf16* __restrict__ out, long total8, int pixels, int c) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total8) return;
+  const int c8 = (int)(idx % (c / 8));
+  const long pix = idx / (c / 8);
+  const int bt = (int)(pix / pixels);
+  const int cpg = c / 32;
+  const float* src = x + pix * c + c8 * 8;
+  const float4v a = *reinterpret_cast<const float4v*>(src);
+  const float4v b = *reinterpret_cast<const float4v*>(src + 4);
+  float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+  bf16x8 o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int ch = c8 * 8 + j;
+    const int g = ch / cpg;
+    const float mean = stats[(bt * 32 + g) * 2], rs = stats[(bt * 32 + g) * 2 + 1];
+    const float y = (v[j] - mean) * rs * gamma[ch] + beta[ch];
+    o[j] = f2bf(silu_f(y));
+  }
+  *reinterpret_cast<bf16x8*>(out + pix * c + c8 * 8) = o;
+}
+
+int launch_gn_apply_silu(const float* x, const float* stats, const float* gamma, const float* beta, bf16* out, int bt,
+                         int pixels, int c, hipStream_t s) {
+  const long total8 = (long)bt * pixels * (c / 8);
+  hipLaunchKernelGGL(gn_apply_silu_kernel, dim3(cdiv(total8, 256)), dim3(256), 0, s, x, stats, gamma, beta, out, total8,
+                     pixels, c);
+  DFOT_CHECK_HIP(hipGetLastError());
+  return DFOT_OK;
+}
+
+// RMS statistics: rstd[m] = rsqrt(mean(x[m,:]^2) + eps); one wave per row
+__global__ __launch_bounds__(256) void rms_stats_kernel(const float* __restrict__ x, float* __restrict__ rstd, long m, int c,
+                                                        float eps) {
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= m) return;
+  const int lane = threadIdx.x & 63;
+  const float* src = x + row * c;
+  float ss = 0.f;
+  for (int i = lane; i < c / 4; i += 64) {
+    const float4v v = *reinterpret_cast<const float4v*>(src + i * 4);
+    ss += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+  }
+  ss = wave_sum(ss);
+  if (lane == 0) rstd[row] = rsqrtf(ss / (float)c + eps);
+}
+
+int launch_rms_stats(const float* x, float* rstd, long m, int c, float eps, hipStream_t s) {
+  hipLaunchKernelGGL(rms_stats_kernel, dim3(cdiv(m, 4)), dim3(256), 0, s, x, rstd, m, c, eps);
+  DFOT_CHECK_HIP(hipGetLastError());
+  return DFOT_OK;
+}
+
+// --------------------------------------------------------------------------------------------
+// per-head QK RMSNorm + RoPE-3D + split to [B][heads][N][d]  (u_vit_blocks.py:253-259, embeddings.py:204-215)
+// qkv [B*N][3*heads*d] bf16, column order "(qkv h d)"; cs [N][d/2][2] = (cos, sin) of the pair's angle
+// thread = 8 consecutive head-dim elements; q is additionally multiplied by qscale (= log2(e)/sqrt(d))
+// --------------------------------------------------------------------------------------------
+__global__ void qk_norm_rope_kernel(const bf16* __restrict__ qkv, const float* __restrict__ qw, const float* __restrict__ kw,
+                                    const float* __restrict__ cs, bf16* __restrict__ q, bf16* __restrict__ k,
+                                    bf16* __restrict__ v, long total, int n, int heads, int d, float qscale, float eps) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = idx < total;
+  const int tph = d / 8;
+  const long safe = live ? idx : 0;
+  const int ch = (int)(safe % tph);
+  const int head = (int)((safe / tph) % heads);
+  const int which = (int)((safe / ((long)tph * heads)) % 3);
+  const long m = safe / ((long)tph * heads * 3);
+  const int c = heads * d;
+  const bf16x8 in = *reinterpret_cast<const bf16x8*>(qkv + m * 3 * c + (long)which * c + head * d + ch * 8);
+  float x[8];
+  float ss = 0.f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    x[j] = bf2f(in[j]);
+    ss += x[j] * x[j];
+  }
+  for (int o = 1; o < tph; o <<= 1) ss += __shfl_xor(ss, o);
+  const long b = m / n;
+  const int tok = (int)(m % n);
+  bf16x8 out;
+  if (which == 2) {
+    out = in;
+  } else {
+    const float rs = rsqrtf(ss / (float)d + eps);
+    const float* wgt = which == 0 ? qw : kw;
+    const float mul = which == 0 ? qscale : 1.f;
+    const float* csp = cs + ((long)tok * (d / 2) + ch * 4) * 2;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const float x0 = x[2 * p] * rs * wgt[ch * 8 + 2 * p];
+      const float x1 = x[2 * p + 1] * rs * wgt[ch * 8 + 2 * p + 1];
+      const float co = csp[2 * p], si = csp[2 * p + 1];
+      out[2 * p] = f2bf((x0 * co - x1 * si) * mul);
+      out[2 * p + 1] = f2bf((x1 * co + x0 * si) * mul);
+    }
+  }
+  if (!live) return;
+  bf16* dst = which == 0 ? q : (which == 1 ? k : v);
+  *reinterpret_cast<bf16x8*>(dst + ((b * heads + head) * n + tok) * (long)d + ch * 8) = out;
+}
+
+int launch_qk_norm_rope(const bf16* qkv, const float* qw, const float* kw, const float* cs, bf16* q, bf16* k, bf16* v,
+                        int batch, int n, int heads, int d, float qscale, float eps, hipStream_t s) {
+  DFOT_REQUIRE(d == 64 || d == 128, DFOT_ERR_SHAPE, "qk_norm_rope: head dim %d not in {64,128}", d);
+  const long total = (long)batch * n * 3 * heads * (d / 8);
+  hipLaunchKernelGGL(qk_norm_rope_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, qkv, qw, kw, cs, q, k, v, total, n,
+                     heads, d, qscale, eps);
+  DFOT_CHECK_HIP(hipGetLastError());
+  return DFOT_OK;
+}
+
+// --------------------------------------------------------------------------------------------
+// resampling and skip arithmetic (u_vit_blocks.py:284-314, u_vit3d_pose.py:124-127)
+// --------------------------------------------------------------------------------------------
+__global__ void pool2_bf16_kernel(const float* __restrict__ x, bf16* __restrict__ out, long total4, int h, int w, int c) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total4) return;
+  const int c4 = (int)(idx % (c / 4));
+  const long pix = idx / (c / 4);
+  const int ox = (int)(pix % (w / 2)), oy = (int)((pix / (w / 2)) % (h / 2));
+  const long bt = pix / ((long)(w / 2) * (h / 2));
+  const float* base = x + ((bt * h + 2 * oy) * w + 2 * ox) * (long)c + c4 * 4;
+  const float4v a = *reinterpret_cast<const float4v*>(base);
+  const float4v b = *reinterpret_cast<const float4v*>(base + c);
+  const float4v cc = *reinterpret_cast<const float4v*>(base + (long)w * c);
+  const float4v dd = *reinterpret_cast<const float4v*>(base + (long)w * c + c);
+  bf16x4 o;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) o[j] = f2bf((a[j] + b[j] + cc[j] + dd[j]) * 0.25f);
+  *reinterpret_cast<bf16x4*>(out + pix * c + c4 * 4) = o;
+}
+int launch_pool2_bf16(const float* x, bf16* out, int bt, int h, int w, int c, hipStream_t s) {
+  const long total4 = (long)bt * (h / 2) * (w / 2) * (c / 4);
+  hipLaunchKernelGGL(pool2_bf16_kernel, dim3(cdiv(total4, 256)), dim3(256), 0, s, x, out, total4, h, w, c);
+  DFOT_CHECK_HIP(hipGetLastError());
+  return DFOT_OK;
+}
+
+__global__ void sub_bf16_kernel(const float* __restrict__ a, const float* __restrict__ b, bf16* __restrict__ out, long n4) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n4) return;
+  const float4v x = *reinterpret_cast<const float4v*>(a + idx * 4);
+  const float4v y = *reinterpret_cast<const float4v*>(b + idx * 4);
+  bf16x4 o;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) o[j] = f2bf(x[j] - y[j]);
+  *reinterpret_cast<bf16x4*>(out + idx * 4) = o;
+}
+int launch_sub_bf16(const float* a, const float* b, bf16* out, long n, hipStream_t s) {
+  DFOT_REQUIRE(n % 4 == 0, DFOT_ERR_SHAPE, "sub: length %ld must be a multiple of 4", n);
+  hipLaunchKernelGGL(sub_bf16_kernel, dim3(cdiv(n / 4, 256)), dim3(256), 0, s, a, b, out, n / 4);
+  DFOT_CHECK_HIP(hipGetLastError());
+  return DFOT_OK;
+}
+
+// out[bt][y][x][:] = t[bt][y/2][x/2][:] + skip[bt][y][x][:]   (h,w are the LOW-resolution sizes)
+__global__ void upsample_add_kernel(const float* __restrict__ t, const float* __restrict__ skip, float* __restrict__ out,
+                                    long total4, int h, int w, int c) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total4) return;
+  const int c4 = (int)(idx % (c / 4));
+  const long pix = idx / (c / 4);
+  const int x = (int)(pix % (2 * w)), y = (int)((pix / (2 * w)) % (2 * h));
+  const long bt = pix / ((long)4 * w * h);
+  const float4v a = *reinterpret_cast<const float4v*>(t + ((bt * h + y / 2) * w + x / 2) * (long)c + c4 * 4);
+  const float4v b = *reinterpret_cast<const float4v*>(skip + pix * c + c4 * 4);
+  *reinterpret_cast<float4v*>(out + pix * c + c4 * 4) = a + b;
+}
+int launch_upsample_add(const float* t, const float* skip, float* out, int bt, int h, int w, int c, hipStream_t s) {
+  const long total4 = (long)bt * 4 * h * w * (c / 4);
+  hipLaunchKernelGGL(upsample_add_kernel, dim3(cdiv(total4, 256)), dim3(256), 0, s, t, skip, out, total4, h, w, c);
+  DFOT_CHECK_HIP(hipGetLastError());
+  return DFOT_OK;
+}
+
+// --------------------------------------------------------------------------------------------
+// camera-ray encoding (geometry_utils.py:49-81,102-133,244-295): raw [B][T][16] -> [B][T][180][res][res]
+// thread = one output element; the per-frame 3x3 algebra is recomputed per thread (27 FMAs)
+// --------------------------------------------------------------------------------------------
+__global__ void ray_encode_kernel(const float* __restrict__ poses, float* __restrict__ out, long total, int t, int res) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int x = (int)(idx % res), y = (int)((idx / res) % res);
+  const int ch = (int)((idx / ((long)res * res)) % 180);
+  const long bt = idx / ((long)res * res * 180);
+  const long b = bt / t;
+  const float* p = poses + bt * 16;
+  const float* p0 = poses + b * t * 16;
+  // R' = R R0^T ; T' = T - R' T0
+  float r[3][3], tr[3];
+  for (int i = 0; i < 3; ++i) {
+    for (int j = 0; j < 3; ++j) {
+      float acc = 0.f;
+      for (int m = 0; m < 3; ++m) acc = fmaf(p[4 + i * 4 + m], p0[4 + j * 4 + m], acc);
+      r[i][j] = acc;
+    }
+  }
+  for (int i = 0; i < 3; ++i) {
+    float acc = 0.f;
+    for (int j = 0; j < 3; ++j) acc = fmaf(r[i][j], p0[4 + j * 4 + 3], acc);
+    tr[i] = p[4 + i * 4 + 3] - acc;
+  }
+  const int which = ch / 90;   // 0 origin, 1 direction
+  const int rr = ch % 90;
+  const int phase = rr / 45;   // 0: sin(arg), 1: sin(arg + pi/2)
+  const int comp = (rr % 45) / 15, f = rr % 15;
+  float val;
+  if (which == 0) {
+    float acc = 0.f;
+    for (int j = 0; j < 3; ++j) acc = fmaf(r[j][comp], tr[j], acc);  // (R'^T T')[comp]
+    val = -acc;
+  } else {
+    const float fres = (float)res;
+    const float cx = __fdiv_rn(__fsub_rn((float)x + 0.5f, __fmul_rn(p[2], fres)), __fmul_rn(p[0], fres));
+    const float cy = __fdiv_rn(__fsub_rn((float)y + 0.5f, __fmul_rn(p[3], fres)), __fmul_rn(p[1], fres));
+    val = fmaf(r[2][comp], 1.f, fmaf(r[1][comp], cy, __fmul_rn(r[0][comp], cx)));
+  }
+  const float scale = 3.14159265358979323846f * (float)(1 << f);
+  float arg = __fmul_rn(val, scale);
+  if (phase) arg = __fadd_rn(arg, 0.5f * 3.14159265358979323846f);
+  out[idx] = sinf(arg);
+}
+
+int launch_ray_encode(const float* poses, float* out, int b, int t, int res, hipStream_t s) {
+  const long total = (long)b * t * 180 * res * res;
+  hipLaunchKernelGGL(ray_encode_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, poses, out, total, t, res);
+  DFOT_CHECK_HIP(hipGetLastError());
+  return DFOT_OK;
+}
+
+// --------------------------------------------------------------------------------------------
+// sampler step
+// --------------------------------------------------------------------------------------------
+__global__ void hg_prepare_kernel(const float* __restrict__ x, const float* __restrict__ noise, const float* __restrict__ qa,
+                                  const float* __restrict__ qb, float* __restrict__ x_in, long total4, int nfe, int tokens,
+                                  long f4) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total4) return;
+  const long e = idx % f4;
+  const long bt = idx / f4;  // over (b*nfe + h, t)
+  const int tk = (int)(bt % tokens);
+  const long bh = bt / tokens;
+  const long b = bh / nfe;
+  const float a = qa[bt], c = qb[bt];
+  const float4v xv = *reinterpret_cast<const float4v*>(x + ((b * tokens + tk) * f4 + e) * 4);
+  float4v o = xv * a;
+  if (c != 0.f) o += *reinterpret_cast<const float4v*>(noise + idx * 4) * c;
+  *reinterpret_cast<float4v*>(x_in + idx * 4) = o;
+}
+int launch_hg_prepare(const float* x, const float* noise, const float* qa, const float* qb, float* x_in, int batch,
+                      int nfe, int tokens, long f, hipStream_t s) {
+  DFOT_REQUIRE(f % 4 == 0, DFOT_ERR_SHAPE, "hg_prepare: frame elements %ld must be a multiple of 4", f);
+  const long total4 = (long)batch * nfe * tokens * (f / 4);
+  hipLaunchKernelGGL(hg_prepare_kernel, dim3(cdiv(total4, 256)), dim3(256), 0, s, x, noise, qa, qb, x_in, total4, nfe,
+                     tokens, f / 4);
+  DFOT_CHECK_HIP(hipGetLastError());
+  return DFOT_OK;
+}
+
+__global__ void ddim_compose_kernel(const float* __restrict__ x, const float* __restrict__ x_in, const float* __restrict__ v,
+                                    const float* __restrict__ sa, const float* __restrict__ s1, const float* __restrict__ an,
+                                    const float* __restrict__ cn, const float* __restrict__ keep,
+                                    const float* __restrict__ weight, const uint8_t* __restrict__ gen,
+                                    float* __restrict__ x_next, long total4, int nfe, int tokens, long f4) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total4) return;
+  const long e = idx % f4;
+  const long bt = idx / f4;  // over (b, t)
+  const int tk = (int)(bt % tokens);
+  const long b = bt / tokens;
+  float4v o;
+  if (!gen[bt]) {
+    o = *reinterpret_cast<const float4v*>(x + idx * 4);
+  } else {
+    o = float4v{0.f, 0.f, 0.f, 0.f};
+    for (int h = 0; h < nfe; ++h) {
+      const long row = (b * nfe + h) * tokens + tk;
+      const long off = (row * f4 + e) * 4;
+      const float4v xi = *reinterpret_cast<const float4v*>(x_in + off);
+      float4v xp;
+      if (keep[row] != 0.f) {
+        xp = xi;
+      } else {
+        const float4v vv = *reinterpret_cast<const float4v*>(v + off);
+        const float4v x0 = xi * sa[row] - vv * s1[row];
+        const float4v ep = vv * sa[row] + xi * s1[row];
+        xp = x0 * an[row] + ep * cn[row];
+      }
+      o += xp * weight[h];
+    }
+  }
+  *reinterpret_cast<float4v*>(x_next + idx * 4) = o;
+}
+int launch_ddim_compose(const float* x, const float* x_in, const float* v, const float* sa, const float* s1,
+                        const float* an, const float* cn, const float* keep, const float* weight, const uint8_t* gen,
+                        float* x_next, int batch, int nfe, int tokens, long f, hipStream_t s) {
+  DFOT_REQUIRE(f % 4 == 0, DFOT_ERR_SHAPE, "ddim_compose: frame elements %ld must be a multiple of 4", f);
+  const long total4 = (long)batch * tokens * (f / 4);
+  hipLaunchKernelGGL(ddim_compose_kernel, dim3(cdiv(total4, 256)), dim3(256), 0, s, x, x_in, v, sa, s1, an, cn, keep,
+                     weight, gen, x_next, total4, nfe, tokens, f / 4);
+  DFOT_CHECK_HIP(hipGetLastError());
+  return DFOT_OK;
+}
+
+// --------------------------------------------------------------------------------------------
+// casts, weight packing, layout taps
+// --------------------------------------------------------------------------------------------
+__global__ void f32_to_bf16_kernel(const float* __restrict__ s, bf16* __restrict__ d, long n) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) d[i] = f2bf(s[i]);
+}
+__global__ void bf16_to_f32_kernel(const bf16* __restrict__ s, float* __restrict__ d, long n) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) d[i] = bf2f(s[i]);
+}
+int launch_f32_to_bf16(const float* src, bf16* dst, long n, hipStream_t s) {
+  hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, src, dst, n);
+  DFOT_CHECK_HIP(hipGetLastError());
+  return DFOT_OK;
+}
+int launch_bf16_to_f32(const bf16* src, float* dst, long n, hipStream_t s) {
+  hipLaunchKernelGGL(bf16_to_f32_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, src, dst, n);
+  DFOT_CHECK_HIP(hipGetLastError());
+  return DFOT_OK;
+}
+
+__global__ void pack_rows_kernel(const float* __restrict__ src, bf16* __restrict__ dst, const int* __restrict__ map, long total,
+                                 int k, int kpad, long ldd, int col0) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int kk = (int)(i % kpad);
+  const long r = i / kpad;
+  const long sr = map ? map[r] : r;
+  dst[r * ldd + col0 + kk] = kk < k ? f2bf(src[sr * k + kk]) : f2bf(0.f);
+}
+int launch_pack_rows(const float* src, bf16* dst, const int* map, int rows, int k, int kpad, long ldd, int col0,
+                     hipStream_t s) {
+  const long total = (long)rows * kpad;
+  hipLaunchKernelGGL(pack_rows_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, src, dst, map, total, k, kpad, ldd, col0);
+  DFOT_CHECK_HIP(hipGetLastError());
+  return DFOT_OK;
+}
+
+__global__ void pack_conv3_kernel(const float* __restrict__ src, bf16* __restrict__ dst, long total, int ci) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int c = (int)(i % ci);
+  const int tap = (int)((i / ci) % 9);
+  const long co = i / ((long)ci * 9);
+  dst[i] = f2bf(src[(co * ci + c) * 9 + tap]);
+}
+int launch_pack_conv3(const float* src, bf16* dst, int co, int ci, hipStream_t s) {
+  const long total = (long)co * ci * 9;
+  hipLaunchKernelGGL(pack_conv3_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, src, dst, total, ci);
+  DFOT_CHECK_HIP(hipGetLastError());
+  return DFOT_OK;
+}
+
+__global__ void gather_f32_kernel(const float* __restrict__ src, float* __restrict__ dst, const int* __restrict__ map, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = src[map[i]];
+}
+int launch_gather_f32(const float* src, float* dst, const int* map, int n, hipStream_t s) {
+  hipLaunchKernelGGL(gather_f32_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, src, dst, map, n);
+  DFOT_CHECK_HIP(hipGetLastError());
+  return DFOT_OK;
+}
+
+template <typename T>
+__global__ void nhwc_to_nchw_kernel(const T* __restrict__ src, float* __restrict__ dst, long total, int p, int c) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int pp = (int)(i % p);
+  const int cc = (int)((i / p) % c);
+  const long bt = i / ((long)p * c);
+  dst[i] = (float)src[(bt * p + pp) * c + cc];
+}
+int launch_nhwc_to_nchw(const float* src, float* dst, int bt, int p, int c, hipStream_t s) {
+  const long total = (long)bt * p * c;
+  hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, dim3(cdiv(total, 256)), dim3(256), 0, s, src, dst, total, p, c);
+  DFOT_CHECK_HIP(hipGetLastError());
+  return DFOT_OK;
+}
+int launch_bf16_nhwc_to_nchw(const bf16* src, float* dst, int bt, int p, int c, hipStream_t s) {
+  const long total = (long)bt * p * c;
+  hipLaunchKernelGGL(nhwc_to_nchw_kernel<bf16>, dim3(cdiv(total, 256)), dim3(256), 0, s, src, dst, total, p, c);
+  DFOT_CHECK_HIP(hipGetLastError());
+  return DFOT_OK;
+}
+
+}  // namespace dfot

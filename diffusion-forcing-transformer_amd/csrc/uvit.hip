@@ -1,0 +1,683 @@
+// UViT3DPose backbone on MI355X: weight packing, workspace and forward orchestration.
+// Mirrors the module tree / state-dict names of the reference
+// (algorithms/dfot/backbones/u_vit/u_vit3d_pose.py:63-131, u_vit3d.py:30-185, u_vit_blocks.py).
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstring>
+#include <functional>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "dfot_hip.h"
+#include "gemm.h"
+#include "kernels.h"
+
+namespace dfot {
+
+// ------------------------------------------------------------------------------------------
+// error text
+// ------------------------------------------------------------------------------------------
+static thread_local char g_err[1024] = "";
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+const char* get_error() { return g_err; }
+
+// ------------------------------------------------------------------------------------------
+// model
+// ------------------------------------------------------------------------------------------
+struct ResW {
+  int c = 0;
+  bf16 *w_film = nullptr, *w1 = nullptr, *w2 = nullptr;
+  float *b_film_raw = nullptr, *b_film = nullptr, *g1 = nullptr, *be1 = nullptr, *bias1 = nullptr, *g2 = nullptr,
+        *be2 = nullptr, *bias2 = nullptr;
+};
+struct TrW {
+  int c = 0;
+  bf16 *w_film = nullptr, *w_fused = nullptr, *w_out = nullptr;
+  float *b_film_raw = nullptr, *b_film = nullptr, *nw = nullptr, *b_fused = nullptr, *qw = nullptr, *kw = nullptr,
+        *b_attn = nullptr, *b_mlp = nullptr, *b_out = nullptr;
+};
+struct ConvW {
+  int cin = 0, cout = 0;
+  bf16* w = nullptr;
+  float* b = nullptr;
+};
+
+struct Param {
+  std::string name;
+  std::vector<int64_t> shape;
+  std::function<int(const float*, hipStream_t)> load;
+  bool loaded = false;
+};
+
+}  // namespace dfot
+
+using namespace dfot;
+
+struct dfot_uvit_s {
+  dfot_uvit_config cfg{};
+  int T = 0, E = 0, heads = 0, r[4] = {0, 0, 0, 0}, ch[4] = {0, 0, 0, 0};
+  int kpose = 0;  // padded K of the pose patch-embed GEMM
+  std::vector<Param> params;
+  std::map<std::string, int> index;
+  std::vector<void*> owned;  // every hipMalloc'ed block
+
+  // weights
+  float *ne_freqs = nullptr, *ne_phases = nullptr, *ne_w1 = nullptr, *ne_b1 = nullptr, *ne_w2 = nullptr, *ne_b2 = nullptr;
+  bf16* pose_w = nullptr;
+  float* pose_b = nullptr;
+  float *ein_w = nullptr, *ein_b = nullptr, *pout_w = nullptr, *pout_b = nullptr;
+  std::vector<ResW> down_res[2], up_res[2];
+  std::vector<TrW> down_tr, mid_tr, up_tr;
+  ConvW down_conv[3], up_conv[3];  // up_conv[l] : level l+1 -> l
+  int* film_map[4] = {nullptr, nullptr, nullptr, nullptr};
+  float* rope_cs[4] = {nullptr, nullptr, nullptr, nullptr};
+  bf16* zeros = nullptr;
+  bool finalized = false;
+
+  // workspace
+  int max_batch = 0;
+  size_t ws_bytes = 0;
+  std::vector<void*> ws_owned;
+  float *nemb = nullptr, *X[4] = {nullptr, nullptr, nullptr, nullptr}, *HSA[3] = {nullptr, nullptr, nullptr}, *tmp = nullptr,
+        *gn_partial = nullptr, *gn_stats = nullptr, *rstd = nullptr;
+  bf16 *acond = nullptr, *emb[4] = {nullptr, nullptr, nullptr, nullptr}, *s1 = nullptr, *hbf = nullptr, *qkv = nullptr,
+       *cat = nullptr, *q = nullptr, *k = nullptr, *v = nullptr;
+  int last_batch = 0;
+  bool use_dma = true;
+  int attn_variant = 0;
+};
+
+namespace dfot {
+
+template <typename T>
+static int dev_alloc(dfot_uvit_s* h, T** out, size_t count, bool workspace = false) {
+  void* p = nullptr;
+  const size_t bytes = count * sizeof(T);
+  DFOT_CHECK_HIP(hipMalloc(&p, bytes ? bytes : 16));
+  (workspace ? h->ws_owned : h->owned).push_back(p);
+  if (workspace) h->ws_bytes += bytes;
+  *out = reinterpret_cast<T*>(p);
+  return DFOT_OK;
+}
+
+static int copy_f32(float* dst, const float* src, size_t n, hipStream_t s) {
+  DFOT_CHECK_HIP(hipMemcpyAsync(dst, src, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+  return DFOT_OK;
+}
+
+static void add_param(dfot_uvit_s* h, const std::string& name, std::vector<int64_t> shape,
+                      std::function<int(const float*, hipStream_t)> load) {
+  h->index[name] = (int)h->params.size();
+  h->params.push_back(Param{name, std::move(shape), std::move(load), false});
+}
+
+// plain fp32 tensor kept as-is
+static int add_f32(dfot_uvit_s* h, const std::string& name, std::vector<int64_t> shape, float** dst) {
+  size_t n = 1;
+  for (auto d : shape) n *= (size_t)d;
+  int rc = dev_alloc(h, dst, n);
+  if (rc) return rc;
+  float* d = *dst;
+  add_param(h, name, shape, [d, n](const float* src, hipStream_t s) { return copy_f32(d, src, n, s); });
+  return DFOT_OK;
+}
+
+static int add_res_block(dfot_uvit_s* h, const std::string& pre, int c, ResW* w) {
+  const int e = h->E;
+  w->c = c;
+  int rc = 0;
+  if ((rc = dev_alloc(h, &w->w_film, (size_t)2 * c * e))) return rc;
+  if ((rc = dev_alloc(h, &w->b_film_raw, (size_t)2 * c))) return rc;
+  if ((rc = dev_alloc(h, &w->b_film, (size_t)2 * c))) return rc;
+  if ((rc = dev_alloc(h, &w->w1, (size_t)c * 9 * c))) return rc;
+  if ((rc = dev_alloc(h, &w->w2, (size_t)c * 9 * c))) return rc;
+  const int lvl = c == h->ch[0] ? 0 : 1;
+  int* map = h->film_map[lvl];
+  bf16* wf = w->w_film;
+  add_param(h, pre + ".emb_layer.weight", {2 * c, e, 1, 1}, [=](const float* src, hipStream_t s) {
+    return launch_pack_rows(src, wf, map, 2 * c, e, e, e, 0, s);
+  });
+  float *braw = w->b_film_raw, *bre = w->b_film;
+  add_param(h, pre + ".emb_layer.bias", {2 * c}, [=](const float* src, hipStream_t s) {
+    int r2 = copy_f32(braw, src, 2 * c, s);
+    return r2 ? r2 : launch_gather_f32(braw, bre, map, 2 * c, s);
+  });
+  if ((rc = add_f32(h, pre + ".in_layers.0.weight", {c}, &w->g1))) return rc;
+  if ((rc = add_f32(h, pre + ".in_layers.0.bias", {c}, &w->be1))) return rc;
+  bf16* w1 = w->w1;
+  add_param(h, pre + ".in_layers.2.weight", {c, c, 3, 3}, [=](const float* src, hipStream_t s) { return launch_pack_conv3(src, w1, c, c, s); });
+  if ((rc = add_f32(h, pre + ".in_layers.2.bias", {c}, &w->bias1))) return rc;
+  if ((rc = add_f32(h, pre + ".out_norm.weight", {c}, &w->g2))) return rc;
+  if ((rc = add_f32(h, pre + ".out_norm.bias", {c}, &w->be2))) return rc;
+  bf16* w2 = w->w2;
+  add_param(h, pre + ".out_rest.1.weight", {c, c, 3, 3}, [=](const float* src, hipStream_t s) { return launch_pack_conv3(src, w2, c, c, s); });
+  if ((rc = add_f32(h, pre + ".out_rest.1.bias", {c}, &w->bias2))) return rc;
+  return DFOT_OK;
+}
+
+static int add_tr_block(dfot_uvit_s* h, const std::string& pre, int lvl, TrW* w) {
+  const int e = h->E, c = h->ch[lvl], d = c / h->heads;
+  w->c = c;
+  int rc = 0;
+  if ((rc = dev_alloc(h, &w->w_film, (size_t)2 * c * e))) return rc;
+  if ((rc = dev_alloc(h, &w->b_film_raw, (size_t)2 * c))) return rc;
+  if ((rc = dev_alloc(h, &w->b_film, (size_t)2 * c))) return rc;
+  if ((rc = dev_alloc(h, &w->w_fused, (size_t)7 * c * c))) return rc;
+  if ((rc = dev_alloc(h, &w->w_out, (size_t)c * 5 * c))) return rc;
+  if ((rc = dev_alloc(h, &w->b_out, (size_t)c))) return rc;
+  int* map = h->film_map[lvl];
+  bf16* wf = w->w_film;
+  add_param(h, pre + ".norm.emb_layer.weight", {2 * c, e}, [=](const float* src, hipStream_t s) {
+    return launch_pack_rows(src, wf, map, 2 * c, e, e, e, 0, s);
+  });
+  float *braw = w->b_film_raw, *bre = w->b_film;
+  add_param(h, pre + ".norm.emb_layer.bias", {2 * c}, [=](const float* src, hipStream_t s) {
+    int r2 = copy_f32(braw, src, 2 * c, s);
+    return r2 ? r2 : launch_gather_f32(braw, bre, map, 2 * c, s);
+  });
+  if ((rc = add_f32(h, pre + ".norm.norm.weight", {c}, &w->nw))) return rc;
+  bf16* wfu = w->w_fused;
+  add_param(h, pre + ".fused_attn_mlp_proj.weight", {7 * c, c}, [=](const float* src, hipStream_t s) {
+    return launch_pack_rows(src, wfu, nullptr, 7 * c, c, c, c, 0, s);
+  });
+  if ((rc = add_f32(h, pre + ".fused_attn_mlp_proj.bias", {7 * c}, &w->b_fused))) return rc;
+  if ((rc = add_f32(h, pre + ".q_norm.weight", {d}, &w->qw))) return rc;
+  if ((rc = add_f32(h, pre + ".k_norm.weight", {d}, &w->kw))) return rc;
+  bf16* wo = w->w_out;
+  add_param(h, pre + ".attn_out.weight", {c, c}, [=](const float* src, hipStream_t s) {
+    return launch_pack_rows(src, wo, nullptr, c, c, c, 5 * c, 0, s);
+  });
+  if ((rc = add_f32(h, pre + ".attn_out.bias", {c}, &w->b_attn))) return rc;
+  add_param(h, pre + ".mlp_out.2.weight", {c, 4 * c}, [=](const float* src, hipStream_t s) {
+    return launch_pack_rows(src, wo, nullptr, c, 4 * c, 4 * c, 5 * c, c, s);
+  });
+  if ((rc = add_f32(h, pre + ".mlp_out.2.bias", {c}, &w->b_mlp))) return rc;
+  return DFOT_OK;
+}
+
+static int add_conv(dfot_uvit_s* h, const std::string& pre, int cin, int cout, ConvW* w) {
+  w->cin = cin;
+  w->cout = cout;
+  int rc = 0;
+  if ((rc = dev_alloc(h, &w->w, (size_t)cout * 9 * cin))) return rc;
+  bf16* dst = w->w;
+  add_param(h, pre + ".weight", {cout, cin, 3, 3}, [=](const float* src, hipStream_t s) { return launch_pack_conv3(src, dst, cout, cin, s); });
+  return add_f32(h, pre + ".bias", {cout}, &w->b);
+}
+
+static int build(dfot_uvit_s* h) {
+  const dfot_uvit_config& c = h->cfg;
+  h->T = c.max_tokens;
+  h->E = c.emb_channels;
+  h->heads = c.num_heads;
+  for (int l = 0; l < 4; ++l) {
+    h->ch[l] = c.channels[l];
+    h->r[l] = c.resolution / 2 / (1 << l);
+  }
+  h->kpose = ((c.cond_dim * 4 + 63) / 64) * 64;
+  int rc = 0;
+  // FiLM row maps: within every 64-column group, 32 scale rows then the 32 matching shift rows
+  for (int l = 0; l < 4; ++l) {
+    const int cc = h->ch[l];
+    std::vector<int> m(2 * cc);
+    for (int n = 0; n < 2 * cc; ++n) {
+      const int g = n / 64, t = n % 64;
+      m[n] = t < 32 ? 32 * g + t : cc + 32 * g + (t - 32);
+    }
+    if ((rc = dev_alloc(h, &h->film_map[l], (size_t)2 * cc))) return rc;
+    DFOT_CHECK_HIP(hipMemcpy(h->film_map[l], m.data(), m.size() * sizeof(int), hipMemcpyHostToDevice));
+  }
+  if ((rc = dev_alloc(h, &h->zeros, 256))) return rc;
+  DFOT_CHECK_HIP(hipMemset(h->zeros, 0, 256 * sizeof(bf16)));
+
+  const int e = h->E, nd = c.noise_dim;
+  const std::string ne = "noise_level_pos_embedding.";
+  if ((rc = add_f32(h, ne + "timesteps.freqs", {nd}, &h->ne_freqs))) return rc;
+  if ((rc = add_f32(h, ne + "timesteps.phases", {nd}, &h->ne_phases))) return rc;
+  if ((rc = add_f32(h, ne + "embedding.linear_1.weight", {e, nd}, &h->ne_w1))) return rc;
+  if ((rc = add_f32(h, ne + "embedding.linear_1.bias", {e}, &h->ne_b1))) return rc;
+  if ((rc = add_f32(h, ne + "embedding.linear_2.weight", {e, e}, &h->ne_w2))) return rc;
+  if ((rc = add_f32(h, ne + "embedding.linear_2.bias", {e}, &h->ne_b2))) return rc;
+  if ((rc = dev_alloc(h, &h->pose_w, (size_t)e * h->kpose))) return rc;
+  {
+    bf16* pw = h->pose_w;
+    const int k = c.cond_dim * 4, kp = h->kpose;
+    add_param(h, "external_cond_embedding.patch_embedder.proj.weight", {e, c.cond_dim, 2, 2},
+              [=](const float* src, hipStream_t s) { return launch_pack_rows(src, pw, nullptr, e, k, kp, kp, 0, s); });
+  }
+  if ((rc = add_f32(h, "external_cond_embedding.patch_embedder.proj.bias", {e}, &h->pose_b))) return rc;
+  if ((rc = add_f32(h, "embed_input.proj.weight", {h->ch[0], c.in_channels, 2, 2}, &h->ein_w))) return rc;
+  if ((rc = add_f32(h, "embed_input.proj.bias", {h->ch[0]}, &h->ein_b))) return rc;
+  if ((rc = add_f32(h, "project_output.proj.weight", {h->ch[0], c.in_channels, 2, 2}, &h->pout_w))) return rc;
+  if ((rc = add_f32(h, "project_output.proj.bias", {c.in_channels}, &h->pout_b))) return rc;
+
+  for (int l = 0; l < 3; ++l) {
+    const int n = c.num_updown_blocks[l];
+    const std::string pre = "down_blocks." + std::to_string(l) + ".";
+    if (l < 2) {
+      h->down_res[l].resize(n);
+      for (int i = 0; i < n; ++i)
+        if ((rc = add_res_block(h, pre + std::to_string(i), h->ch[l], &h->down_res[l][i]))) return rc;
+    } else {
+      h->down_tr.resize(n);
+      for (int i = 0; i < n; ++i)
+        if ((rc = add_tr_block(h, pre + std::to_string(i), l, &h->down_tr[i]))) return rc;
+    }
+    if ((rc = add_conv(h, pre + std::to_string(n) + ".conv", h->ch[l], h->ch[l + 1], &h->down_conv[l]))) return rc;
+  }
+  h->mid_tr.resize(c.num_mid_blocks);
+  for (int i = 0; i < c.num_mid_blocks; ++i)
+    if ((rc = add_tr_block(h, "mid_blocks." + std::to_string(i), 3, &h->mid_tr[i]))) return rc;
+  for (int j = 0; j < 3; ++j) {
+    const int l = 2 - j;
+    const int n = c.num_updown_blocks[l];
+    const std::string pre = "up_blocks." + std::to_string(j) + ".";
+    if ((rc = add_conv(h, pre + "0.conv", h->ch[l + 1], h->ch[l], &h->up_conv[l]))) return rc;
+    if (l < 2) {
+      h->up_res[l].resize(n);
+      for (int i = 0; i < n; ++i)
+        if ((rc = add_res_block(h, pre + std::to_string(i + 1), h->ch[l], &h->up_res[l][i]))) return rc;
+    } else {
+      h->up_tr.resize(n);
+      for (int i = 0; i < n; ++i)
+        if ((rc = add_tr_block(h, pre + std::to_string(i + 1), l, &h->up_tr[i]))) return rc;
+    }
+  }
+  return DFOT_OK;
+}
+
+// RoPE-3D angle table for one level: [N][d/2][2] = (cos, sin); axis split of the head dim follows
+// RotaryEmbedding3D (embeddings.py:251-277), angle = position * theta^(-2j/dim_axis)
+static int build_rope(dfot_uvit_s* h, int lvl) {
+  const int d = h->ch[lvl] / h->heads, half = d / 2;
+  const int q = half / 3, rem = half % 3;
+  int parts[3] = {q, q, q};
+  if (rem == 1) parts[0] = q + 1;
+  if (rem == 2) parts[1] = parts[2] = q + 1;
+  const int rr = h->r[lvl], n = h->T * rr * rr;
+  std::vector<float> cs((size_t)n * half * 2);
+  for (int tok = 0; tok < n; ++tok) {
+    const int pos[3] = {tok / (rr * rr), (tok / rr) % rr, tok % rr};
+    int pair = 0;
+    for (int ax = 0; ax < 3; ++ax) {
+      const int dim = 2 * parts[ax];
+      for (int j = 0; j < parts[ax]; ++j, ++pair) {
+        const float inv = 1.0f / powf(h->cfg.rope_theta, (float)(2 * j) / (float)dim);
+        const float ang = (float)pos[ax] * inv;
+        cs[((size_t)tok * half + pair) * 2 + 0] = cosf(ang);
+        cs[((size_t)tok * half + pair) * 2 + 1] = sinf(ang);
+      }
+    }
+  }
+  int rc = dev_alloc(h, &h->rope_cs[lvl], cs.size());
+  if (rc) return rc;
+  DFOT_CHECK_HIP(hipMemcpy(h->rope_cs[lvl], cs.data(), cs.size() * sizeof(float), hipMemcpyHostToDevice));
+  return DFOT_OK;
+}
+
+__global__ void add_vec_kernel(const float* a, const float* b, float* o, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) o[i] = a[i] + b[i];
+}
+
+// ------------------------------------------------------------------------------------------
+// forward pieces
+// ------------------------------------------------------------------------------------------
+static int run_res_block(dfot_uvit_s* h, const ResW& w, int lvl, int bt, hipStream_t s) {
+  const int c = w.c, rr = h->r[lvl], pix = rr * rr;
+  const int m = bt * pix;
+  float* x = h->X[lvl];
+  int rc = 0;
+  if ((rc = launch_gn_stats_f32(x, h->gn_partial, h->gn_stats, bt, pix, c, h->cfg.eps, s))) return rc;
+  if ((rc = launch_gn_apply_silu(x, h->gn_stats, w.g1, w.be1, h->s1, bt, pix, c, s))) return rc;
+  GemmArgs g;
+  g.A = h->s1; g.W = w.w1; g.M = m; g.N = c; g.K = 9 * c; g.H = rr; g.Wd = rr; g.Cin = c; g.zeros = h->zeros;
+  g.bias = w.bias1; g.out_bf16 = h->hbf; g.ldo = c;
+  if ((rc = launch_gemm(A_CONV3, E_BF16, h->use_dma, g, s))) return rc;
+  if ((rc = launch_gn_stats_bf16(h->hbf, h->gn_partial, h->gn_stats, bt, pix, c, h->cfg.eps, s))) return rc;
+  GemmArgs f;
+  f.A = h->emb[lvl]; f.lda = h->E; f.W = w.w_film; f.M = m; f.N = 2 * c; f.K = h->E; f.bias = w.b_film;
+  f.h_bf16 = h->hbf; f.ldh = c; f.gn_sums = h->gn_stats; f.gamma = w.g2; f.beta = w.be2; f.rows_per_bt = pix; f.C = c;
+  f.eps = h->cfg.eps; f.out_bf16 = h->s1; f.ldo = c;
+  if ((rc = launch_gemm(A_DENSE, E_FILM_GN, h->use_dma, f, s))) return rc;
+  GemmArgs o;
+  o.A = h->s1; o.W = w.w2; o.M = m; o.N = c; o.K = 9 * c; o.H = rr; o.Wd = rr; o.Cin = c; o.zeros = h->zeros;
+  o.bias = w.bias2; o.out_f32 = x; o.resid = x; o.ldo = c;
+  return launch_gemm(A_CONV3, E_F32, h->use_dma, o, s);
+}
+
+static int run_tr_block(dfot_uvit_s* h, const TrW& w, int lvl, int batch, hipStream_t s) {
+  const int c = w.c, rr = h->r[lvl], n = h->T * rr * rr, d = c / h->heads;
+  const int m = batch * n;
+  float* x = h->X[lvl];
+  int rc = 0;
+  if ((rc = launch_rms_stats(x, h->rstd, m, c, h->cfg.eps, s))) return rc;
+  GemmArgs f;
+  f.A = h->emb[lvl]; f.lda = h->E; f.W = w.w_film; f.M = m; f.N = 2 * c; f.K = h->E; f.bias = w.b_film;
+  f.x_f32 = x; f.ldh = c; f.rstd = h->rstd; f.gamma = w.nw; f.C = c; f.out_bf16 = h->s1; f.ldo = c;
+  if ((rc = launch_gemm(A_DENSE, E_FILM_RMS, h->use_dma, f, s))) return rc;
+  GemmArgs p;
+  p.A = h->s1; p.lda = c; p.W = w.w_fused; p.M = m; p.N = 7 * c; p.K = c; p.bias = w.b_fused;
+  p.out_bf16 = h->qkv; p.ldo = 3 * c; p.out2 = h->cat + c; p.ldo2 = 5 * c; p.split = 3 * c;
+  if ((rc = launch_gemm(A_DENSE, E_QKV, h->use_dma, p, s))) return rc;
+  const float qscale = 1.4426950408889634f / sqrtf((float)d);
+  if ((rc = launch_qk_norm_rope(h->qkv, w.qw, w.kw, h->rope_cs[lvl], h->q, h->k, h->v, batch, n, h->heads, d, qscale,
+                                h->cfg.eps, s)))
+    return rc;
+  if ((rc = launch_attention(h->q, h->k, h->v, h->cat, 5 * c, batch, h->heads, n, d, h->attn_variant, s))) return rc;
+  GemmArgs o;
+  o.A = h->cat; o.lda = 5 * c; o.W = w.w_out; o.M = m; o.N = c; o.K = 5 * c; o.bias = w.b_out; o.out_f32 = x; o.resid = x;
+  o.ldo = c;
+  return launch_gemm(A_DENSE, E_F32, h->use_dma, o, s);
+}
+
+static int run_down(dfot_uvit_s* h, int l, int bt, hipStream_t s) {
+  const int rr = h->r[l], cin = h->ch[l], cout = h->ch[l + 1];
+  int rc = 0;
+  if ((rc = launch_pool2_bf16(h->X[l], h->s1, bt, rr, rr, cin, s))) return rc;
+  GemmArgs g;
+  g.A = h->s1; g.W = h->down_conv[l].w; g.M = bt * (rr / 2) * (rr / 2); g.N = cout; g.K = 9 * cin; g.H = rr / 2; g.Wd = rr / 2;
+  g.Cin = cin; g.zeros = h->zeros; g.bias = h->down_conv[l].b; g.out_f32 = h->HSA[l]; g.ldo = cout;
+  if ((rc = launch_gemm(A_CONV3, E_F32, h->use_dma, g, s))) return rc;
+  return copy_f32(h->X[l + 1], h->HSA[l], (size_t)g.M * cout, s);
+}
+
+static int run_up(dfot_uvit_s* h, int l, int bt, hipStream_t s) {  // level l+1 -> l
+  const int rr = h->r[l + 1], cin = h->ch[l + 1], cout = h->ch[l];
+  const long n_in = (long)bt * rr * rr * cin;
+  int rc = 0;
+  if ((rc = launch_sub_bf16(h->X[l + 1], h->HSA[l], h->s1, n_in, s))) return rc;
+  GemmArgs g;
+  g.A = h->s1; g.W = h->up_conv[l].w; g.M = bt * rr * rr; g.N = cout; g.K = 9 * cin; g.H = rr; g.Wd = rr; g.Cin = cin;
+  g.zeros = h->zeros; g.bias = h->up_conv[l].b; g.out_f32 = h->tmp; g.ldo = cout;
+  if ((rc = launch_gemm(A_CONV3, E_F32, h->use_dma, g, s))) return rc;
+  return launch_upsample_add(h->tmp, h->X[l], h->X[l], bt, rr, rr, cout, s);
+}
+
+}  // namespace dfot
+
+// ------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------
+extern "C" {
+
+const char* dfot_last_error(void) { return get_error(); }
+int dfot_version(void) { return 1; }
+
+int dfot_uvit_create(const dfot_uvit_config* cfg, dfot_uvit_t* out) {
+  DFOT_REQUIRE(cfg && out, DFOT_ERR_ARG, "dfot_uvit_create: null argument");
+  DFOT_REQUIRE(cfg->resolution % 16 == 0 && cfg->resolution >= 32, DFOT_ERR_SHAPE, "resolution %d must be a multiple of 16", cfg->resolution);
+  DFOT_REQUIRE(cfg->emb_channels % 64 == 0, DFOT_ERR_SHAPE, "emb_channels %d must be a multiple of 64", cfg->emb_channels);
+  DFOT_REQUIRE(cfg->in_channels <= 3 && cfg->cond_dim % 20 == 0, DFOT_ERR_SHAPE, "in_channels %d / cond_dim %d unsupported", cfg->in_channels, cfg->cond_dim);
+  for (int l = 0; l < 4; ++l)
+    DFOT_REQUIRE(cfg->channels[l] % 64 == 0, DFOT_ERR_SHAPE, "channels[%d]=%d must be a multiple of 64", l, cfg->channels[l]);
+  DFOT_REQUIRE(cfg->channels[0] % 128 == 0 && cfg->channels[1] % 128 == 0, DFOT_ERR_SHAPE, "ResBlock channels must be multiples of 128");
+  for (int l = 2; l < 4; ++l) {
+    const int d = cfg->channels[l] / cfg->num_heads;
+    DFOT_REQUIRE(d * cfg->num_heads == cfg->channels[l] && (d == 64 || d == 128), DFOT_ERR_SHAPE,
+                 "level %d head dim %d must be 64 or 128", l, d);
+  }
+  const int r3 = cfg->resolution / 16;
+  DFOT_REQUIRE((cfg->max_tokens * r3 * r3) % 128 == 0, DFOT_ERR_SHAPE, "tokens at the coarsest level (%d) must be a multiple of 128", cfg->max_tokens * r3 * r3);
+  auto* h = new dfot_uvit_s();
+  h->cfg = *cfg;
+  int rc = build(h);
+  if (rc) {
+    dfot_uvit_destroy(h);
+    return rc;
+  }
+  *out = h;
+  return DFOT_OK;
+}
+
+int dfot_uvit_destroy(dfot_uvit_t h) {
+  if (!h) return DFOT_OK;
+  for (void* p : h->owned) (void)hipFree(p);
+  for (void* p : h->ws_owned) (void)hipFree(p);
+  delete h;
+  return DFOT_OK;
+}
+
+int dfot_uvit_num_params(dfot_uvit_t h) { return h ? (int)h->params.size() : 0; }
+const char* dfot_uvit_param_name(dfot_uvit_t h, int i) {
+  return (h && i >= 0 && i < (int)h->params.size()) ? h->params[i].name.c_str() : nullptr;
+}
+int dfot_uvit_param_shape(dfot_uvit_t h, int i, int64_t shape[4], int* ndim) {
+  DFOT_REQUIRE(h && shape && ndim && i >= 0 && i < (int)h->params.size(), DFOT_ERR_ARG, "param_shape: bad argument");
+  *ndim = (int)h->params[i].shape.size();
+  for (int k = 0; k < *ndim; ++k) shape[k] = h->params[i].shape[k];
+  return DFOT_OK;
+}
+
+int dfot_uvit_load_weight(dfot_uvit_t h, const char* name, const float* data, const int64_t* shape, int ndim, void* stream) {
+  DFOT_REQUIRE(h && name && data && shape, DFOT_ERR_ARG, "load_weight: null argument");
+  auto it = h->index.find(name);
+  DFOT_REQUIRE(it != h->index.end(), DFOT_ERR_NAME, "load_weight: unexpected key '%s'", name);
+  Param& p = h->params[it->second];
+  bool same = (int)p.shape.size() == ndim;
+  for (int k = 0; same && k < ndim; ++k) same = p.shape[k] == shape[k];
+  DFOT_REQUIRE(same, DFOT_ERR_SHAPE, "load_weight: size mismatch for '%s'", name);
+  int rc = p.load(data, (hipStream_t)stream);
+  if (rc) return rc;
+  p.loaded = true;
+  h->finalized = false;
+  return DFOT_OK;
+}
+
+int dfot_uvit_finalize(dfot_uvit_t h, void* stream) {
+  DFOT_REQUIRE(h, DFOT_ERR_ARG, "finalize: null handle");
+  for (const Param& p : h->params) DFOT_REQUIRE(p.loaded, DFOT_ERR_STATE, "finalize: missing key '%s'", p.name.c_str());
+  hipStream_t s = (hipStream_t)stream;
+  auto fuse = [&](std::vector<TrW>& v) -> int {
+    for (TrW& w : v) {
+      hipLaunchKernelGGL(add_vec_kernel, dim3(cdiv(w.c, 256)), dim3(256), 0, s, w.b_attn, w.b_mlp, w.b_out, w.c);
+      DFOT_CHECK_HIP(hipGetLastError());
+    }
+    return DFOT_OK;
+  };
+  int rc = 0;
+  if ((rc = fuse(h->down_tr)) || (rc = fuse(h->mid_tr)) || (rc = fuse(h->up_tr))) return rc;
+  for (int l = 2; l < 4; ++l)
+    if (!h->rope_cs[l] && (rc = build_rope(h, l))) return rc;
+  DFOT_CHECK_HIP(hipStreamSynchronize(s));
+  h->finalized = true;
+  return DFOT_OK;
+}
+
+int dfot_uvit_reserve(dfot_uvit_t h, int max_batch) {
+  DFOT_REQUIRE(h && max_batch > 0, DFOT_ERR_ARG, "reserve: bad argument");
+  if (max_batch <= h->max_batch) return DFOT_OK;
+  for (void* p : h->ws_owned) (void)hipFree(p);
+  h->ws_owned.clear();
+  h->ws_bytes = 0;
+  h->max_batch = 0;
+  const size_t bt = (size_t)max_batch * h->T;
+  size_t pix[4];
+  for (int l = 0; l < 4; ++l) pix[l] = (size_t)h->r[l] * h->r[l];
+  int rc = 0;
+  if ((rc = dev_alloc(h, &h->nemb, bt * h->E, true))) return rc;
+  for (int l = 0; l < 4; ++l) {
+    if ((rc = dev_alloc(h, &h->X[l], bt * pix[l] * h->ch[l], true))) return rc;
+    if ((rc = dev_alloc(h, &h->emb[l], bt * pix[l] * h->E, true))) return rc;
+  }
+  for (int l = 0; l < 3; ++l)
+    if ((rc = dev_alloc(h, &h->HSA[l], bt * pix[l + 1] * h->ch[l + 1], true))) return rc;
+  if ((rc = dev_alloc(h, &h->acond, bt * pix[0] * h->kpose, true))) return rc;
+  DFOT_CHECK_HIP(hipMemset(h->acond, 0, bt * pix[0] * h->kpose * sizeof(bf16)));
+  size_t act = 0, tmpn = 0;
+  for (int l = 0; l < 4; ++l) act = std::max(act, bt * pix[l] * h->ch[l]);
+  for (int l = 0; l < 3; ++l) tmpn = std::max(tmpn, bt * pix[l + 1] * h->ch[l]);
+  if ((rc = dev_alloc(h, &h->s1, act, true))) return rc;
+  if ((rc = dev_alloc(h, &h->hbf, act, true))) return rc;
+  if ((rc = dev_alloc(h, &h->tmp, tmpn, true))) return rc;
+  if ((rc = dev_alloc(h, &h->gn_partial, bt * gn_partial_blocks((int)pix[0]) * 64, true))) return rc;
+  if ((rc = dev_alloc(h, &h->gn_stats, bt * 64, true))) return rc;
+  size_t mtr = 0, mc = 0;
+  for (int l = 2; l < 4; ++l) {
+    mtr = std::max(mtr, bt * pix[l]);
+    mc = std::max(mc, bt * pix[l] * h->ch[l]);
+  }
+  if ((rc = dev_alloc(h, &h->rstd, mtr, true))) return rc;
+  if ((rc = dev_alloc(h, &h->qkv, mc * 3, true))) return rc;
+  if ((rc = dev_alloc(h, &h->cat, mc * 5, true))) return rc;
+  if ((rc = dev_alloc(h, &h->q, mc, true))) return rc;
+  if ((rc = dev_alloc(h, &h->k, mc, true))) return rc;
+  if ((rc = dev_alloc(h, &h->v, mc, true))) return rc;
+  h->max_batch = max_batch;
+  return DFOT_OK;
+}
+
+size_t dfot_uvit_workspace_bytes(dfot_uvit_t h) { return h ? h->ws_bytes : 0; }
+
+int dfot_uvit_set_option(dfot_uvit_t h, const char* key, int value) {
+  DFOT_REQUIRE(h && key, DFOT_ERR_ARG, "set_option: null argument");
+  if (!strcmp(key, "lds_dma")) h->use_dma = value != 0;
+  else if (!strcmp(key, "attn_variant")) h->attn_variant = value;
+  else {
+    set_error("set_option: unknown key '%s'", key);
+    return DFOT_ERR_ARG;
+  }
+  return DFOT_OK;
+}
+
+int dfot_uvit_forward(dfot_uvit_t h, const float* x, const float* noise_levels, const float* external_cond,
+                      const uint8_t* external_cond_mask, float* out, int batch, void* stream) {
+  DFOT_REQUIRE(h && x && noise_levels && out, DFOT_ERR_ARG, "forward: null argument");
+  DFOT_REQUIRE(external_cond != nullptr, DFOT_ERR_ARG, "External condition (camera pose) is required for U-ViT3DPose model.");
+  DFOT_REQUIRE(h->finalized, DFOT_ERR_STATE, "forward: weights not finalized");
+  DFOT_REQUIRE(batch > 0 && batch <= h->max_batch, DFOT_ERR_STATE, "forward: batch %d exceeds reserved %d", batch, h->max_batch);
+  hipStream_t s = (hipStream_t)stream;
+  const dfot_uvit_config& c = h->cfg;
+  const int bt = batch * h->T, e = h->E;
+  int rc = 0;
+  if ((rc = launch_noise_emb(noise_levels, h->ne_freqs, h->ne_phases, h->ne_w1, h->ne_b1, h->ne_w2, h->ne_b2, h->nemb, bt,
+                             c.noise_dim, e, s)))
+    return rc;
+  if ((rc = launch_embed_input(x, h->ein_w, h->ein_b, h->X[0], bt, c.resolution, c.in_channels, h->ch[0], s))) return rc;
+  if ((rc = launch_cond_repack(external_cond, h->acond, bt, c.resolution, c.cond_dim, h->kpose, s))) return rc;
+  {
+    const int pix0 = h->r[0] * h->r[0];
+    GemmArgs g;
+    g.A = h->acond; g.lda = h->kpose; g.W = h->pose_w; g.M = bt * pix0; g.N = e; g.K = h->kpose; g.bias = h->pose_b;
+    g.out_bf16 = h->emb[0]; g.ldo = e; g.nemb = h->nemb; g.cond_mask = external_cond_mask; g.rows_per_bt = pix0;
+    g.rows_per_batch = pix0 * h->T;
+    if ((rc = launch_gemm(A_DENSE, E_POSE, h->use_dma, g, s))) return rc;
+  }
+  if ((rc = launch_emb_pyramid(h->emb[0], h->emb[1], h->emb[2], h->emb[3], bt, h->r[0], e, s))) return rc;
+
+  for (int l = 0; l < 2; ++l) {
+    for (const ResW& w : h->down_res[l])
+      if ((rc = run_res_block(h, w, l, bt, s))) return rc;
+    if ((rc = run_down(h, l, bt, s))) return rc;
+  }
+  for (const TrW& w : h->down_tr)
+    if ((rc = run_tr_block(h, w, 2, batch, s))) return rc;
+  if ((rc = run_down(h, 2, bt, s))) return rc;
+  for (const TrW& w : h->mid_tr)
+    if ((rc = run_tr_block(h, w, 3, batch, s))) return rc;
+  if ((rc = run_up(h, 2, bt, s))) return rc;
+  for (const TrW& w : h->up_tr)
+    if ((rc = run_tr_block(h, w, 2, batch, s))) return rc;
+  for (int l = 1; l >= 0; --l) {
+    if ((rc = run_up(h, l, bt, s))) return rc;
+    for (const ResW& w : h->up_res[l])
+      if ((rc = run_res_block(h, w, l, bt, s))) return rc;
+  }
+  h->last_batch = batch;
+  return launch_project_output(h->X[0], h->pout_w, h->pout_b, out, bt, c.resolution, h->ch[0], c.in_channels, s);
+}
+
+int dfot_uvit_read_tap(dfot_uvit_t h, const char* name, float* out, size_t capacity, void* stream) {
+  DFOT_REQUIRE(h && name && out, DFOT_ERR_ARG, "read_tap: null argument");
+  DFOT_REQUIRE(h->last_batch > 0, DFOT_ERR_STATE, "read_tap: no forward has run");
+  hipStream_t s = (hipStream_t)stream;
+  const int bt = h->last_batch * h->T;
+  auto pixels = [&](int l) { return h->r[l] * h->r[l]; };
+  struct Tap { const char* n; int lvl; int c; const float* f; const bf16* b; };
+  const Tap taps[] = {
+      {"emb0", 0, h->E, nullptr, h->emb[0]}, {"down0", 1, h->ch[1], h->HSA[0], nullptr},
+      {"down1", 2, h->ch[2], h->HSA[1], nullptr}, {"down2", 3, h->ch[3], h->HSA[2], nullptr},
+      {"mid", 3, h->ch[3], h->X[3], nullptr}, {"up2", 2, h->ch[2], h->X[2], nullptr},
+      {"up1", 1, h->ch[1], h->X[1], nullptr}, {"up0", 0, h->ch[0], h->X[0], nullptr},
+  };
+  for (const Tap& t : taps) {
+    if (strcmp(t.n, name)) continue;
+    const size_t need = (size_t)bt * pixels(t.lvl) * t.c;
+    DFOT_REQUIRE(capacity >= need, DFOT_ERR_SHAPE, "read_tap: need %zu floats, got %zu", need, capacity);
+    return t.f ? launch_nhwc_to_nchw(t.f, out, bt, pixels(t.lvl), t.c, s)
+               : launch_bf16_nhwc_to_nchw(t.b, out, bt, pixels(t.lvl), t.c, s);
+  }
+  set_error("read_tap: unknown tap '%s'", name);
+  return DFOT_ERR_NAME;
+}
+
+// ---- pose / sampler / primitives ------------------------------------------------------------
+int dfot_ray_encode(const float* raw_poses, float* out, int batch, int tokens, int resolution, void* stream) {
+  DFOT_REQUIRE(raw_poses && out && batch > 0 && tokens > 0 && resolution > 0, DFOT_ERR_ARG, "ray_encode: bad argument");
+  return launch_ray_encode(raw_poses, out, batch, tokens, resolution, (hipStream_t)stream);
+}
+
+int dfot_hg_prepare(const float* x, const float* noise, const float* qa, const float* qb, float* x_in, int batch, int nfe,
+                    int tokens, int64_t frame_elems, void* stream) {
+  DFOT_REQUIRE(x && qa && qb && x_in, DFOT_ERR_ARG, "hg_prepare: null argument");
+  return launch_hg_prepare(x, noise, qa, qb, x_in, batch, nfe, tokens, (long)frame_elems, (hipStream_t)stream);
+}
+
+int dfot_ddim_compose(const float* x, const float* x_in, const float* v, const float* sa, const float* s1, const float* an,
+                      const float* cn, const float* keep, const float* weight, const uint8_t* gen, float* x_next, int batch,
+                      int nfe, int tokens, int64_t frame_elems, void* stream) {
+  DFOT_REQUIRE(x && x_in && v && sa && s1 && an && cn && keep && weight && gen && x_next, DFOT_ERR_ARG, "ddim_compose: null argument");
+  return launch_ddim_compose(x, x_in, v, sa, s1, an, cn, keep, weight, gen, x_next, batch, nfe, tokens, (long)frame_elems,
+                             (hipStream_t)stream);
+}
+
+static bf16* g_zero_page = nullptr;
+static int zero_page(bf16** out) {
+  if (!g_zero_page) {
+    DFOT_CHECK_HIP(hipMalloc((void**)&g_zero_page, 512));
+    DFOT_CHECK_HIP(hipMemset(g_zero_page, 0, 512));
+  }
+  *out = g_zero_page;
+  return DFOT_OK;
+}
+
+int dfot_op_gemm(const void* a, int lda, const void* w, const float* bias, float* c, int m, int n, int k, int use_lds_dma,
+                 void* stream) {
+  GemmArgs g;
+  g.A = (const bf16*)a; g.lda = lda; g.W = (const bf16*)w; g.M = m; g.N = n; g.K = k; g.bias = bias; g.out_f32 = c; g.ldo = n;
+  DFOT_REQUIRE(c, DFOT_ERR_ARG, "op_gemm: null output");
+  return launch_gemm(A_DENSE, E_F32, use_lds_dma != 0, g, (hipStream_t)stream);
+}
+
+int dfot_op_conv3x3(const void* a, const void* w, const float* bias, float* y, int bt, int hh, int ww, int cin, int cout,
+                    int use_lds_dma, void* stream) {
+  GemmArgs g;
+  int rc = zero_page(const_cast<bf16**>(&g.zeros));
+  if (rc) return rc;
+  g.A = (const bf16*)a; g.W = (const bf16*)w; g.M = bt * hh * ww; g.N = cout; g.K = 9 * cin; g.H = hh; g.Wd = ww; g.Cin = cin;
+  g.bias = bias; g.out_f32 = y; g.ldo = cout;
+  DFOT_REQUIRE(y, DFOT_ERR_ARG, "op_conv3x3: null output");
+  return launch_gemm(A_CONV3, E_F32, use_lds_dma != 0, g, (hipStream_t)stream);
+}
+
+int dfot_op_attention(const void* q, const void* k, const void* v, void* o, int ldo, int batch, int heads, int n, int d,
+                      int variant, void* stream) {
+  return launch_attention((const bf16*)q, (const bf16*)k, (const bf16*)v, (bf16*)o, ldo, batch, heads, n, d, variant,
+                          (hipStream_t)stream);
+}
+
+int dfot_op_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream) {
+  return launch_f32_to_bf16(src, (bf16*)dst, (long)n, (hipStream_t)stream);
+}
+int dfot_op_bf16_to_f32(const void* src, float* dst, int64_t n, void* stream) {
+  return launch_bf16_to_f32((const bf16*)src, dst, (long)n, (hipStream_t)stream);
+}
+
+}  // extern "C"

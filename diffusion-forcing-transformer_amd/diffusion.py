@@ -1,0 +1,113 @@
+"""Host side of the diffusion wrapper: schedule tables and the per-step coefficient plan.
+
+Mirrors (host logic only; the arithmetic on frames runs in libdfot_hip.so):
+  * DiscreteDiffusion._build_buffer / make_beta_schedule / cosine_simple_diffusion_schedule
+      algorithms/dfot/diffusion/discrete_diffusion.py:94-168, noise_schedule.py:6-81
+  * ddim_idx_to_noise_level                         discrete_diffusion.py:379-384
+  * ContinuousDiffusion.model_predictions (level -> 0.125*logsnr[k])   continuous_diffusion.py:118-121
+  * ddim_sample_step coefficient algebra            discrete_diffusion.py:454-483,527-536
+  * q_sample coefficients                           discrete_diffusion.py:242-250
+  * _generate_scheduling_matrix                     algorithms/common/base_pytorch_video_algo.py:877-913
+Everything here is numpy on the host, evaluated once per sampling call; the device kernels
+only ever see small fp32 coefficient tables (one row per (branch-batch, token)).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Optional
+
+import numpy as np
+
+
+@dataclass
+class DiffusionConfig:
+    timesteps: int = 1000
+    sampling_timesteps: int = 50
+    beta_schedule: str = "cosine_simple_diffusion"
+    shifted: float = 0.125
+    interpolated: bool = False
+    logsnr_min: float = -15.0
+    logsnr_max: float = 15.0
+    clip_min: float = 1e-9
+    ddim_sampling_eta: float = 0.0
+    clip_noise: float = 20.0
+    precond_scale: float = 0.125
+    objective: str = "pred_v"
+
+
+class Schedule:
+    """float64 construction, float32 tables -- the dtype path of the reference's buffers."""
+
+    def __init__(self, cfg: DiffusionConfig):
+        self.cfg = cfg
+        n = cfg.timesteps
+        if cfg.beta_schedule == "cosine_simple_diffusion":
+            t_lo = np.arctan(np.exp(-0.5 * cfg.logsnr_max))
+            t_hi = np.arctan(np.exp(-0.5 * cfg.logsnr_min))
+            u = np.linspace(0.0, 1.0, n, dtype=np.float64)
+            lam = -2.0 * np.log(np.tan(t_lo + u * (t_hi - t_lo)))
+            if cfg.shifted != 1.0:
+                lam_s = lam + 2.0 * np.log(cfg.shifted)
+                lam = u * lam + (1.0 - u) * lam_s if cfg.interpolated else lam_s
+            abar = 1.0 / (1.0 + np.exp(-lam))
+        elif cfg.beta_schedule == "cosine":
+            u = np.linspace(0, n, n + 1, dtype=np.float64) / n
+            f = np.cos((u + 0.008) / 1.008 * np.pi * 0.5) ** 2
+            abar = (f / f[0])[1:]
+        else:
+            raise ValueError(f"unknown beta schedule {cfg.beta_schedule}")
+        alphas = np.concatenate([abar[:1], abar[1:] / abar[:-1]])
+        betas = np.clip(1.0 - alphas, cfg.clip_min, 1.0)
+        abar = np.cumprod(1.0 - betas)
+        self.alphas_cumprod = abar.astype(np.float32)
+        self.sqrt_alphas_cumprod = np.sqrt(abar).astype(np.float32)
+        self.sqrt_one_minus_alphas_cumprod = np.sqrt(1.0 - abar).astype(np.float32)
+        self.logsnr = np.log(abar / (1.0 - abar)).astype(np.float32)
+
+    # ---- index tables ---------------------------------------------------------------------
+    def ddim_idx_to_noise_level(self, indices: np.ndarray) -> np.ndarray:
+        c = self.cfg
+        # the reference builds this table with torch.linspace(float32).long(); reuse torch so that
+        # truncation of non-integer steps (e.g. 3 sampling steps) is bit-identical
+        import torch
+        steps = torch.linspace(-1, c.timesteps - 1, c.sampling_timesteps + 1).long().numpy()
+        return steps[np.asarray(indices, dtype=np.int64)]
+
+    def scheduling_matrix(self, kind: str, horizon: int, padding: int = 0) -> np.ndarray:
+        s = self.cfg.sampling_timesteps
+        if kind in ("full_sequence",):
+            idx = np.repeat(np.arange(s, -1, -1)[:, None], horizon, axis=1)
+        elif kind == "autoregressive":
+            height = s + (horizon - 1) + 1
+            idx = np.clip(s + np.arange(horizon)[None, :] - np.arange(height)[:, None], 0, s)
+        else:
+            raise ValueError(f"unsupported scheduling matrix '{kind}'")
+        levels = self.ddim_idx_to_noise_level(idx)
+        if padding > 0:
+            levels = np.concatenate([levels, np.full((levels.shape[0], padding), self.cfg.timesteps - 1, np.int64)], 1)
+        return levels
+
+    # ---- per-step coefficient tables (all float32, shape = levels.shape) -------------------
+    def model_level(self, k: np.ndarray) -> np.ndarray:
+        """what the backbone receives as `noise_levels`: precond_scale * logsnr[clamp(k,0)]"""
+        return (np.float32(self.cfg.precond_scale) * self.logsnr[np.clip(k, 0, None)]).astype(np.float32)
+
+    def q_sample_coef(self, k: np.ndarray):
+        """x_k = a*x0 + b*noise; negative k indexes from the end like the reference's a[t]"""
+        return self.sqrt_alphas_cumprod[k], self.sqrt_one_minus_alphas_cumprod[k]
+
+    def ddim_coef(self, curr: np.ndarray, nxt: np.ndarray):
+        """returns sa, s1 (v -> x0/eps at the clamped current level), an, cn (DDIM update) and keep"""
+        f32 = np.float32
+        kc = np.clip(curr, 0, None)
+        alpha = self.alphas_cumprod[kc]
+        alpha_next = np.where(nxt < 0, f32(1.0), self.alphas_cumprod[np.clip(nxt, 0, None)]).astype(f32)
+        eta = f32(self.cfg.ddim_sampling_eta)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            sig = eta * np.sqrt((f32(1) - alpha / alpha_next) * (f32(1) - alpha_next) / (f32(1) - alpha))
+        sigma = np.where(nxt < 0, f32(0.0), sig).astype(f32)
+        if eta == 0:
+            sigma = np.zeros_like(alpha)
+        cn = np.sqrt(f32(1) - alpha_next - sigma ** 2).astype(f32)
+        return (self.sqrt_alphas_cumprod[kc], self.sqrt_one_minus_alphas_cumprod[kc], np.sqrt(alpha_next).astype(f32),
+                cn, (curr == nxt).astype(f32), sigma)

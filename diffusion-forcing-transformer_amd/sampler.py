@@ -1,0 +1,320 @@
+"""DFoT sampler driver on the MI355X engine (host side).
+
+Same method names, arguments and error behaviour as the reference's sampling path:
+  * ``_process_conditions``  algorithms/dfot/dfot_video_pose.py:64-110   -> dfot_ray_encode
+  * ``_sample_sequence``     algorithms/dfot/dfot_video.py:516-763       -> dfot_hg_prepare /
+                             backbone / dfot_ddim_compose per step
+  * ``_predict_sequence``    dfot_video.py:362-514   (sliding window)
+  * ``_interpolate_videos``  dfot_video.py:181-360   (planner + batched windows)
+  * ``_predict_videos``      dfot_video.py:114-179   (keyframes then interpolation)
+  * ``_pad_to_max_tokens``   algorithms/common/base_pytorch_video_algo.py:666-682
+Differences by design: the per-step History-Guidance bookkeeping is planned on the host in numpy
+(no device syncs inside the step loop), the camera-ray encoding of a window is computed once per
+window instead of once per step (it does not depend on the step), and all frame arithmetic of a
+step is two fused kernels around the backbone call.
+Randomness is drawn through ``noise_fn(tag, shape)`` (tags: "init", "q_sample", "ddim") so tests can
+replay the reference's draws; the default draws on the GPU with ``torch.randn``.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Callable, Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import capi
+from .diffusion import DiffusionConfig, Schedule
+from .guidance import HistoryGuidance
+
+
+@dataclass
+class SamplerConfig:
+    x_shape: Tuple[int, int, int] = (3, 256, 256)
+    max_tokens: int = 8
+    diffusion: DiffusionConfig = field(default_factory=DiffusionConfig)
+    scheduling_matrix: str = "full_sequence"
+    is_full_sequence: bool = False
+    prediction_guidance: Dict = field(default_factory=lambda: {"name": "conditional"})
+    interpolation_guidance: Dict = field(default_factory=lambda: {"name": "conditional"})
+    keyframe_density: Optional[float] = None
+    sliding_context_len: Optional[int] = None
+    interpolation_max_batch_size: Optional[int] = None
+
+
+NoiseFn = Callable[[str, tuple], torch.Tensor]
+
+
+def device_noise_fn(generator: Optional[torch.Generator] = None, clip: float = 20.0) -> NoiseFn:
+    def fn(tag: str, shape: tuple) -> torch.Tensor:
+        return torch.randn(shape, device="cuda", generator=generator).clamp_(-clip, clip)
+    return fn
+
+
+class DFoTVideoPoseSampler:
+    def __init__(self, cfg: SamplerConfig, backbone, noise_fn: Optional[NoiseFn] = None):
+        self.cfg = cfg
+        self.model = backbone
+        self.schedule = Schedule(cfg.diffusion)
+        self.noise_fn = noise_fn or device_noise_fn(clip=cfg.diffusion.clip_noise)
+        self.timesteps = cfg.diffusion.timesteps
+        self.sampling_timesteps = cfg.diffusion.sampling_timesteps
+        self.max_tokens = cfg.max_tokens
+        self.x_shape = tuple(cfg.x_shape)
+        self.trace: List[dict] = []
+        self.window_forwards = 0
+        if cfg.diffusion.ddim_sampling_eta != 0:
+            raise NotImplementedError("only deterministic DDIM (eta = 0) is implemented on the device path")
+
+    # ------------------------------------------------------------------ conditions
+    @torch.no_grad()
+    def _process_conditions(self, conditions: Optional[torch.Tensor], noise_levels=None) -> Optional[torch.Tensor]:
+        if conditions is None:
+            return None
+        b, t = conditions.shape[:2]
+        raw = conditions.detach().to(device="cuda", dtype=torch.float32).contiguous()
+        if raw.shape[-1] != 16:
+            raise ValueError(f"raw camera poses must have 16 values per frame, got {raw.shape[-1]}")
+        res = self.x_shape[-1]
+        out = torch.empty(b, t, 180, res, res, device="cuda", dtype=torch.float32)
+        capi.check(capi.lib.dfot_ray_encode(capi.ptr(raw), capi.ptr(out), b, t, res, capi.stream_ptr()))
+        return out
+
+    def _pad_to_max_tokens(self, y: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+        if y is None or y.shape[1] >= self.max_tokens:
+            return y
+        tail = y[:, -1:].expand(-1, self.max_tokens - y.shape[1], *y.shape[2:])
+        return torch.cat([y, tail], dim=1)
+
+    # ------------------------------------------------------------------ one window
+    @torch.no_grad()
+    def _sample_sequence(self, batch_size: int, length: Optional[int] = None, context: Optional[torch.Tensor] = None,
+                         context_mask: Optional[torch.Tensor] = None, conditions: Optional[torch.Tensor] = None,
+                         history_guidance: Optional[HistoryGuidance] = None, **_) -> Tuple[torch.Tensor, None]:
+        cfg, sch = self.cfg, self.schedule
+        x_shape = self.x_shape
+        if length is None:
+            length = self.max_tokens if context is None else context.shape[1]
+        if length > self.max_tokens:
+            raise ValueError(f"length is expected to <={self.max_tokens}, got {length}.")
+        if context is not None:
+            if context_mask is None:
+                raise ValueError("context_mask must be provided if context is given.")
+            if context.shape[0] != batch_size:
+                raise ValueError(f"context batch size is expected to be {batch_size} but got {context.shape[0]}.")
+            if context.shape[1] != length:
+                raise ValueError(f"context length is expected to be {length} but got {context.shape[1]}.")
+            if tuple(context.shape[2:]) != tuple(x_shape):
+                raise ValueError(f"context shape not compatible with x_stacked_shape {x_shape}.")
+        if context_mask is not None:
+            if context is None:
+                raise ValueError("context must be provided if context_mask is given. ")
+            if tuple(context.shape[:2]) != tuple(context_mask.shape):
+                raise ValueError("context and context_mask must have the same shape.")
+        horizon = self.max_tokens
+        padding = horizon - length
+        f = int(np.prod(x_shape))
+        xs = self.noise_fn("init", (batch_size, horizon, *x_shape)).to(device="cuda", dtype=torch.float32)
+        xs = xs.clamp(-cfg.diffusion.clip_noise, cfg.diffusion.clip_noise)
+        if context is None:
+            mask = np.zeros((batch_size, horizon), np.int64)
+        else:
+            mask = context_mask.detach().cpu().numpy().astype(np.int64)
+            ctx = context.to(device="cuda", dtype=torch.float32)
+            if padding > 0:
+                ctx = torch.cat([ctx, ctx.new_zeros(batch_size, padding, *x_shape)], 1)
+                mask = np.concatenate([mask, -np.ones((batch_size, padding), np.int64)], 1)
+            keep = torch.from_numpy(mask >= 1).cuda().view(batch_size, horizon, 1, 1, 1)
+            xs = torch.where(keep, ctx, xs)
+        if history_guidance is None:
+            history_guidance = HistoryGuidance.conditional(timesteps=self.timesteps)
+
+        sm = sch.scheduling_matrix(cfg.scheduling_matrix, horizon - padding, padding)
+        sm = np.repeat(sm[:, None, :], batch_size, axis=1)
+        if not cfg.is_full_sequence:
+            sm = np.where(mask[None] >= 1, -1, sm)
+        changed = ~(sm[1:] == sm[:-1]).reshape(sm.shape[0] - 1, -1).all(axis=1)
+        sm = sm[int(np.argmax(changed)):]
+        self.trace.append({"context_mask": mask.copy(), "batch": batch_size, "rows": sm.shape[0]})
+
+        cond_full = self._process_conditions(conditions)
+        cond_rep, cond_nfe = None, 0
+        xs = xs.contiguous()
+        s = capi.stream_ptr
+        strict = bool(getattr(self.noise_fn, "strict_order", False))
+
+        for m in range(sm.shape[0] - 1):
+            frm, to = sm[m], sm[m + 1]
+            mask = np.where((mask == 0) & (frm == -1), 2, mask)
+            plan = history_guidance.plan(mask, frm, to, replacement_only=cfg.is_full_sequence)
+            nfe = plan.nfe
+            bm = batch_size * nfe
+            lv = plan.levels.reshape(bm, horizon)
+            tl = plan.to_levels.reshape(bm, horizon)
+            repl = plan.replace.reshape(bm, horizon)
+            qa_c, qb_c = sch.q_sample_coef(lv)
+            qa = np.where(repl, qa_c, np.float32(1)).astype(np.float32)
+            qb = np.where(repl, qb_c, np.float32(0)).astype(np.float32)
+            sa, s1, an, cn, keepf, sigma = sch.ddim_coef(lv, tl)
+            kmodel = sch.model_level(lv)
+            tables = torch.from_numpy(np.stack([qa, qb, sa, s1, an, cn, keepf, kmodel]).astype(np.float32)).cuda()
+            weights = torch.from_numpy(plan.weights.astype(np.float32)).cuda()
+            gen = torch.from_numpy((mask == 0).astype(np.uint8)).cuda()
+            # noise for re-noised history tokens; with a strict-order noise source (golden replay) every draw
+            # the reference makes is consumed, used or not (history_guidance.py:505,530; discrete_diffusion.py:525)
+            noise = None
+            need = bool(repl.any())
+            if history_guidance.is_simple:
+                if nfe == 2 and (need or strict):
+                    drawn = self.noise_fn("q_sample", (batch_size, horizon, *x_shape))
+                    noise = torch.zeros(batch_size, 2, horizon, *x_shape, device="cuda", dtype=torch.float32)
+                    noise[:, 0] = drawn.to(device="cuda", dtype=torch.float32)
+            else:
+                if need or strict:
+                    noise = self.noise_fn("q_sample", (bm, horizon, *x_shape)).to(device="cuda", dtype=torch.float32)
+                if strict:
+                    self.noise_fn("excluded", (bm, 1, horizon, *x_shape))
+            if noise is not None:
+                noise = noise.contiguous()
+            x_in = torch.empty(bm, horizon, *x_shape, device="cuda", dtype=torch.float32)
+            capi.check(capi.lib.dfot_hg_prepare(capi.ptr(xs), capi.ptr(noise), capi.ptr(tables[0]), capi.ptr(tables[1]),
+                                                capi.ptr(x_in), batch_size, nfe, horizon, f, s()))
+            if cond_full is not None and cond_nfe != nfe:
+                cond_rep = cond_full if nfe == 1 else cond_full.repeat_interleave(nfe, dim=0)
+                cond_nfe = nfe
+            cmask = None
+            if plan.cond_masked is not None:
+                cmask = torch.from_numpy(np.tile(plan.cond_masked, batch_size)).cuda()
+            v = self.model(x_in, tables[7], cond_rep, cmask)
+            self.window_forwards += bm
+            if strict:
+                self.noise_fn("ddim", (bm, horizon, *x_shape))  # multiplied by sigma = 0 in the reference
+            xs_next = torch.empty_like(xs)
+            capi.check(capi.lib.dfot_ddim_compose(capi.ptr(xs), capi.ptr(x_in), capi.ptr(v), capi.ptr(tables[2]),
+                                                  capi.ptr(tables[3]), capi.ptr(tables[4]), capi.ptr(tables[5]),
+                                                  capi.ptr(tables[6]), capi.ptr(weights), capi.ptr(gen), capi.ptr(xs_next),
+                                                  batch_size, nfe, horizon, f, s()))
+            xs = xs_next
+        if padding > 0:
+            xs = xs[:, :-padding]
+        return xs, None
+
+    # ------------------------------------------------------------------ sliding window
+    @torch.no_grad()
+    def _predict_sequence(self, context: torch.Tensor, length: Optional[int] = None,
+                          conditions: Optional[torch.Tensor] = None, history_guidance: Optional[HistoryGuidance] = None,
+                          sliding_context_len: Optional[int] = None, **_) -> Tuple[torch.Tensor, None]:
+        mt = self.max_tokens
+        if length is None:
+            length = mt
+        if sliding_context_len is None:
+            if mt < length:
+                raise ValueError("when length > max_tokens, sliding_context_len must be specified.")
+            sliding_context_len = mt - 1
+        if sliding_context_len == -1:
+            sliding_context_len = mt - 1
+        batch_size, gt_len = context.shape[:2]
+        if sliding_context_len < gt_len:
+            raise ValueError("sliding_context_len is expected to be >= length of initial context,"
+                             f"got {sliding_context_len}. If you are trying to use max context, "
+                             "consider specifying sliding_context_len=-1.")
+        xs = context.to(device="cuda", dtype=torch.float32)
+        cur = gt_len
+        while cur < length:
+            c = min(sliding_context_len, cur)
+            h = min(length - cur, mt - c)
+            window = torch.cat([xs[:, -c:], xs.new_zeros(batch_size, h, *self.x_shape)], 1)
+            generated = cur - max(cur - c, gt_len)
+            cmask = torch.ones(batch_size, c, dtype=torch.long)
+            if generated > 0:
+                cmask[:, -generated:] = 2
+            cmask = torch.cat([cmask, torch.zeros(batch_size, h, dtype=torch.long)], 1)
+            cond = None if conditions is None else conditions[:, cur - c: cur - c + mt]
+            new, _ = self._sample_sequence(batch_size, length=c + h, context=window, context_mask=cmask,
+                                           conditions=cond, history_guidance=history_guidance)
+            xs = torch.cat([xs, new[:, -h:]], 1)
+            cur = xs.shape[1]
+        return xs, None
+
+    # ------------------------------------------------------------------ interpolation
+    def _interpolation_plan(self, known: np.ndarray) -> List[List[np.ndarray]]:
+        mt = self.max_tokens
+        known = known.copy()
+        plan: List[List[np.ndarray]] = []
+        while not known.all():
+            keys = np.where(known)[0]
+            stage: List[np.ndarray] = []
+            chunk: Optional[np.ndarray] = None
+            for left, right in zip(keys[:-1], keys[1:]):
+                left, right = int(left), int(right)
+                if chunk is not None:
+                    if len(chunk) + right - left <= mt:
+                        chunk = np.concatenate([chunk, np.arange(left + 1, right + 1)])
+                        continue
+                    stage.append(chunk)
+                    chunk = None
+                if right - left == 1:
+                    continue
+                if right - left >= mt - 1:
+                    stage.append(torch.linspace(left, right, mt).round().long().numpy())
+                else:
+                    chunk = np.arange(left, right + 1)
+            if chunk is not None:
+                stage.append(chunk)
+            for w in stage:
+                known[w] = True
+            plan.append(stage)
+        return plan
+
+    @torch.no_grad()
+    def _interpolate_videos(self, context: torch.Tensor, context_mask: Optional[torch.Tensor] = None,
+                            conditions: Optional[torch.Tensor] = None, **_) -> torch.Tensor:
+        cfg = self.cfg
+        if context_mask is None:
+            context_mask = torch.zeros(context.shape[0], context.shape[1], dtype=torch.bool)
+            context_mask[:, [0, -1]] = True
+        else:
+            context_mask = context_mask.detach().cpu().bool()
+            assert bool(context_mask[:, [0, -1]].all()), "The first and last frames must be known to interpolate."
+        hg = HistoryGuidance.from_config(cfg.interpolation_guidance, timesteps=self.timesteps)
+        xs = context.to(device="cuda", dtype=torch.float32).clone()
+        known = context_mask.clone()
+        for stage in self._interpolation_plan(context_mask[0].numpy()):
+            ctx = torch.cat([self._pad_to_max_tokens(xs[:, w]) for w in stage], 0)
+            msk = torch.cat([self._pad_to_max_tokens(known[:, w]) for w in stage], 0)
+            cnd = None if conditions is None else torch.cat([self._pad_to_max_tokens(conditions[:, w]) for w in stage], 0)
+            mb = cfg.interpolation_max_batch_size or ctx.shape[0]
+            outs = []
+            for i in range(0, ctx.shape[0], mb):
+                sl = slice(i, i + mb)
+                o, _ = self._sample_sequence(ctx[sl].shape[0], context=ctx[sl], context_mask=msk[sl].long(),
+                                             conditions=None if cnd is None else cnd[sl], history_guidance=hg)
+                outs.append(o)
+            out = torch.cat(outs, 0)
+            for w, pred in zip(stage, out.chunk(len(stage), 0)):
+                xs[:, w] = pred[:, : len(w)]
+                known[:, w] = True
+        return xs
+
+    # ------------------------------------------------------------------ top level
+    @torch.no_grad()
+    def _predict_videos(self, xs: torch.Tensor, n_context_tokens: int,
+                        conditions: Optional[torch.Tensor] = None) -> torch.Tensor:
+        cfg = self.cfg
+        out = xs.to(device="cuda", dtype=torch.float32).clone()
+        hg = HistoryGuidance.from_config(cfg.prediction_guidance, timesteps=self.timesteps)
+        density = cfg.keyframe_density or 1
+        if density > 1:
+            raise ValueError("tasks.prediction.keyframe_density must be <= 1")
+        n = out.shape[1]
+        keys = torch.linspace(0, n - 1, round(density * n)).round().long()
+        keys = torch.cat([torch.arange(n_context_tokens), keys]).unique()
+        kc = None if conditions is None else conditions[:, keys]
+        pred, _ = self._predict_sequence(out[:, :n_context_tokens], length=len(keys), conditions=kc, history_guidance=hg,
+                                         sliding_context_len=cfg.sliding_context_len or self.max_tokens // 2)
+        out[:, keys.cuda()] = pred
+        if len(keys) < n:
+            known = torch.zeros(out.shape[0], n, dtype=torch.bool)
+            known[:, keys] = True
+            out = self._interpolate_videos(out, known, conditions)
+        return out

@@ -1,0 +1,130 @@
+/* dfot_hip.h -- C ABI of libdfot_hip.so: the MI355X (gfx950) DFoT denoising engine.
+ *
+ * Drop-in boundary for the reference's hot path (ktncktnc/diffusion-forcing-transformer):
+ *   - dfot_uvit_*      replaces   UViT3DPose / BaseBackbone.forward
+ *                                 algorithms/dfot/backbones/u_vit/u_vit3d_pose.py:63-131
+ *                                 algorithms/dfot/backbones/base_backbone.py:78-86
+ *                                 (called from diffusion/continuous_diffusion.py:119-121)
+ *   - dfot_ray_encode  replaces   DFoTVideoPose._process_conditions (ray_encoding)
+ *                                 algorithms/dfot/dfot_video_pose.py:64-110, utils/geometry_utils.py:49-81,244-295
+ *   - dfot_hg_prepare  replaces   HistoryGuidance prepare (q_sample of history tokens per branch)
+ *                                 algorithms/dfot/history_guidance.py:446-543,929-973 ; discrete_diffusion.py:242-250
+ *   - dfot_ddim_compose replaces  v->x0/eps, ddim_sample_step, HG compose, context clamp
+ *                                 diffusion/discrete_diffusion.py:213-223,454-538 ; history_guidance.py:545-568,978-982 ;
+ *                                 dfot_video.py:750-752
+ *   - dfot_op_*        unit-testable primitives the backbone is built from (GEMM / conv / attention / norms)
+ *
+ * Conventions: plain pointers and sizes only (no torch types).  Every data pointer is a DEVICE
+ * pointer unless it says "host".  `stream` is a hipStream_t passed as void*.  All functions return
+ * 0 (DFOT_OK) or a DFOT_ERR_* code; dfot_last_error() returns the message of the last failure on
+ * the calling thread.  Nothing here allocates or synchronises inside forward/step calls (graph-capturable)
+ * except dfot_uvit_reserve / dfot_uvit_create / dfot_uvit_load_weight.
+ */
+#ifndef DFOT_HIP_H_
+#define DFOT_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+  DFOT_OK = 0,
+  DFOT_ERR_ARG = 1,    /* null pointer / bad enum                      (reference: TypeError/ValueError) */
+  DFOT_ERR_SHAPE = 2,  /* shape or length violates the contract        (reference: ValueError / assert)   */
+  DFOT_ERR_HIP = 3,    /* a HIP runtime call failed                                                      */
+  DFOT_ERR_STATE = 4,  /* weights missing / workspace not reserved                                        */
+  DFOT_ERR_NAME = 5    /* unknown state-dict key                       (reference: load_state_dict strict) */
+};
+
+typedef struct dfot_uvit_s* dfot_uvit_t;
+
+/* Hyper-parameters of u_vit3d_pose (configurations/algorithm/backbone/u_vit3d_pose.yaml:1-14 overridden by
+ * configurations/dataset_experiment/realestate10k_video_generation.yaml:39-44). block types are fixed to
+ * [ResBlock, ResBlock, TransformerBlock, TransformerBlock] with RoPE-3D, as on every BASELINE config. */
+typedef struct {
+  int32_t channels[4];
+  int32_t emb_channels;
+  int32_t num_updown_blocks[3];
+  int32_t num_mid_blocks;
+  int32_t num_heads;
+  int32_t in_channels;   /* 3 */
+  int32_t resolution;    /* x_shape[-1], e.g. 256 */
+  int32_t max_tokens;    /* temporal length T, 8 */
+  int32_t cond_dim;      /* 180 (ray_encoding) */
+  int32_t noise_dim;     /* 256 */
+  float rope_theta;      /* 10000 */
+  float eps;             /* 1e-6 */
+} dfot_uvit_config;
+
+const char* dfot_last_error(void);
+int dfot_version(void);
+
+/* ---- backbone handle ------------------------------------------------------------------------- */
+int dfot_uvit_create(const dfot_uvit_config* cfg, dfot_uvit_t* out);
+int dfot_uvit_destroy(dfot_uvit_t h);
+/* state-dict inventory (reference key names) */
+int dfot_uvit_num_params(dfot_uvit_t h);
+const char* dfot_uvit_param_name(dfot_uvit_t h, int index);
+int dfot_uvit_param_shape(dfot_uvit_t h, int index, int64_t shape[4], int* ndim);
+/* copy one fp32 tensor (device pointer, contiguous, reference layout) into the engine's packed bf16/fp32 layout */
+int dfot_uvit_load_weight(dfot_uvit_t h, const char* name, const float* data, const int64_t* shape, int ndim,
+                          void* stream);
+/* verify every key was loaded; build derived tables (RoPE cos/sin, fused out-projection bias) */
+int dfot_uvit_finalize(dfot_uvit_t h, void* stream);
+/* allocate activations for a model batch of up to `max_batch` videos (B*NFE) */
+int dfot_uvit_reserve(dfot_uvit_t h, int max_batch);
+size_t dfot_uvit_workspace_bytes(dfot_uvit_t h);
+/* tuning/debug switches: "lds_dma" (1 = LDS-DMA staging in the GEMMs, 0 = register staging),
+ * "attn_variant" (0 = transposed LDS reads for V, 1 = scalar LDS reads) */
+int dfot_uvit_set_option(dfot_uvit_t h, const char* key, int value);
+
+/* out[B,T,C,H,W] = model(x[B,T,C,H,W], noise_levels[B,T], external_cond[B,T,180,H,W], external_cond_mask[B])
+ * all fp32 contiguous; noise_levels is the float level the reference passes (0.125*logsnr[k]);
+ * external_cond_mask: NULL or B bytes, non-zero => that video's pose embedding is zeroed.
+ * Inputs are not modified. */
+int dfot_uvit_forward(dfot_uvit_t h, const float* x, const float* noise_levels, const float* external_cond,
+                      const uint8_t* external_cond_mask, float* out, int batch, void* stream);
+/* debug/parity taps: copy an internal activation after the last forward (fp32). names: "emb0","down0","down1",
+ * "down2","mid","up2","up1","up0" in the oracle's NCHW layout. */
+int dfot_uvit_read_tap(dfot_uvit_t h, const char* name, float* out, size_t capacity_floats, void* stream);
+
+/* ---- camera-pose front end ------------------------------------------------------------------- */
+/* raw poses [B,T,16] (fx,fy,px,py | 3x4 RT) -> ray encoding [B,T,180,res,res] fp32, normalised by frame 0 */
+int dfot_ray_encode(const float* raw_poses, float* out, int batch, int tokens, int resolution, void* stream);
+
+/* ---- sampler step (per-step coefficient tables live in device memory) -------------------------- */
+/* coef tables are [n_branch_batch = B*NFE][T] fp32, row-major, for ONE step:
+ *   qa,qb : x_in = qa*x + qb*noise      (history token re-noising; (1,0) = keep)
+ * x[B,T,F] fp32, noise[B*NFE,T,F] fp32 (may be NULL when every qb is 0), x_in[B*NFE,T,F] fp32. */
+int dfot_hg_prepare(const float* x, const float* noise, const float* qa, const float* qb, float* x_in, int batch,
+                    int nfe, int tokens, int64_t frame_elems, void* stream);
+/* per (branch-batch,t): sa=sqrt(abar_k), s1=sqrt(1-abar_k), an=sqrt(abar_next), cn=sqrt(1-abar_next-sigma^2),
+ * keep (curr==next) as 0/1 floats; weight[NFE]; gen[B,T] (1 = token being generated, 0 = context/padding).
+ *   x0 = sa*x_in - s1*v ; eps = sa*v + s1*x_in ; x_pred = keep ? x_in : x0*an + eps*cn
+ *   x_next[b,t] = gen ? sum_h weight[h]*x_pred[b*NFE+h,t] : x[b,t] */
+int dfot_ddim_compose(const float* x, const float* x_in, const float* v, const float* sa, const float* s1,
+                      const float* an, const float* cn, const float* keep, const float* weight, const uint8_t* gen,
+                      float* x_next, int batch, int nfe, int tokens, int64_t frame_elems, void* stream);
+
+/* ---- unit-testable primitives ------------------------------------------------------------------ */
+/* C[M,N] (fp32) = A[M,K] (bf16, row stride lda) * W[N,K]^T (bf16) + bias[N] (fp32 or NULL) */
+int dfot_op_gemm(const void* a_bf16, int lda, const void* w_bf16, const float* bias, float* c, int m, int n, int k,
+                 int use_lds_dma, void* stream);
+/* y[BT,H,W,Cout] (fp32) = conv3x3(pad 1)(a[BT,H,W,Cin] bf16, w[Cout][9*Cin] bf16 tap-major) + bias */
+int dfot_op_conv3x3(const void* a_bf16, const void* w_bf16, const float* bias, float* y, int bt, int h, int w,
+                    int cin, int cout, int use_lds_dma, void* stream);
+/* o[B,N,heads*d] (bf16, row stride ldo) = softmax(q k^T) v ; q,k,v [B,heads,N,d] bf16; q pre-scaled by
+ * log2(e)/sqrt(d) (the kernel works in the exp2 domain). d in {64,128}; N % 128 == 0 (d=64) or % 64. */
+int dfot_op_attention(const void* q, const void* k, const void* v, void* o, int ldo, int batch, int heads, int n,
+                      int d, int variant, void* stream);
+/* fp32 <-> bf16 helpers for tests */
+int dfot_op_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);
+int dfot_op_bf16_to_f32(const void* src, float* dst, int64_t n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DFOT_HIP_H_ */

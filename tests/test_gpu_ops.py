@@ -1,0 +1,144 @@
+"""GPU parity tests of the C-ABI primitives against plain PyTorch fp32 references / the CPU oracle.
+Tolerances: bf16 inputs are exact in both paths (the reference consumes the same bf16-rounded values),
+so GEMM/conv/attention differ only by fp32 accumulation order (+ bf16 rounding of P in attention)."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def capi():
+    import dfot_amd  # noqa: F401
+    from dfot_amd import capi as c
+    assert torch.cuda.is_available()
+    return c
+
+
+def S():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def P(t):
+    return C.c_void_p(t.data_ptr())
+
+
+def report(name, got, ref):
+    err = (got - ref).abs().max().item()
+    rel = ((got - ref).norm() / ref.norm().clamp_min(1e-12)).item()
+    print(f"{name}: max_abs={err:.3e} rel_l2={rel:.3e}")
+    return err, rel
+
+
+@pytest.mark.parametrize("dma", [0, 1])
+@pytest.mark.parametrize("m,n,k", [(128, 128, 64), (256, 192, 128), (1024, 576, 576), (128, 4032, 576), (384, 100, 2880)])
+def test_gemm(capi, dma, m, n, k):
+    g = torch.Generator().manual_seed(m + n + k)
+    a = torch.randn(m, k, generator=g).bfloat16().cuda()
+    w = (torch.randn(n, k, generator=g) / math.sqrt(k)).bfloat16().cuda()
+    bias = torch.randn(n, generator=g).cuda()
+    out = torch.full((m, n), float("nan"), device="cuda")
+    capi.check(capi.lib.dfot_op_gemm(P(a), k, P(w), P(bias), P(out), m, n, k, dma, S()))
+    ref = a.float() @ w.float().t() + bias
+    err, rel = report(f"gemm dma={dma} {m}x{n}x{k}", out, ref)
+    assert torch.isfinite(out).all()
+    assert rel < 1e-5 and err < 1e-3
+
+
+def test_gemm_rejects_bad_shapes(capi):
+    a = torch.zeros(100, 64, device="cuda", dtype=torch.bfloat16)
+    out = torch.zeros(100, 64, device="cuda")
+    with pytest.raises(capi.DfotError):
+        capi.check(capi.lib.dfot_op_gemm(P(a), 64, P(a), None, P(out), 100, 64, 64, 1, S()))
+
+
+@pytest.mark.parametrize("dma", [0, 1])
+@pytest.mark.parametrize("bt,h,w,cin,cout", [(2, 8, 8, 128, 128), (1, 16, 16, 128, 256), (2, 8, 16, 576, 256), (3, 16, 8, 64, 100)])
+def test_conv3x3(capi, dma, bt, h, w, cin, cout):
+    g = torch.Generator().manual_seed(bt * 1000 + cin + cout)
+    x = torch.randn(bt, cin, h, w, generator=g).bfloat16()
+    wt = (torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(9 * cin)).bfloat16()
+    bias = torch.randn(cout, generator=g)
+    a = x.permute(0, 2, 3, 1).contiguous().cuda()                      # NHWC
+    wp = wt.permute(0, 2, 3, 1).reshape(cout, 9 * cin).contiguous().cuda()  # [Cout][tap][Cin]
+    out = torch.full((bt, h, w, cout), float("nan"), device="cuda")
+    capi.check(capi.lib.dfot_op_conv3x3(P(a), P(wp), P(bias.cuda()), P(out), bt, h, w, cin, cout, dma, S()))
+    ref = F.conv2d(x.float(), wt.float(), bias, padding=1).permute(0, 2, 3, 1).cuda()
+    err, rel = report(f"conv dma={dma} {bt}x{h}x{w} {cin}->{cout}", out, ref)
+    assert torch.isfinite(out).all()
+    assert rel < 1e-5 and err < 1e-3
+
+
+@pytest.mark.parametrize("variant", [1, 0])
+@pytest.mark.parametrize("b,heads,n,d", [(1, 2, 128, 64), (2, 9, 512, 64), (1, 3, 256, 128), (2, 9, 128, 128)])
+def test_attention(capi, variant, b, heads, n, d):
+    g = torch.Generator().manual_seed(n + d + heads)
+    q = torch.randn(b, heads, n, d, generator=g)
+    k = torch.randn(b, heads, n, d, generator=g)
+    v = torch.randn(b, heads, n, d, generator=g)
+    # spike a few keys so that the running max changes mid-sequence (online-softmax rescale path)
+    k[:, :, n // 2 + 3] *= 4.0
+    k[:, :, n - 5] *= 6.0
+    qs = (q * (math.log2(math.e) / math.sqrt(d))).bfloat16()
+    kb, vb = k.bfloat16(), v.bfloat16()
+    o = torch.full((b, n, heads * d), float("nan"), device="cuda", dtype=torch.bfloat16)
+    capi.check(capi.lib.dfot_op_attention(P(qs.cuda()), P(kb.cuda()), P(vb.cuda()), P(o), heads * d, b, heads, n, d,
+                                          variant, S()))
+    s = (qs.double() @ kb.double().transpose(-1, -2)) * math.log(2.0)
+    ref = (torch.softmax(s, dim=-1) @ vb.double()).permute(0, 2, 1, 3).reshape(b, n, heads * d).float()
+    err, rel = report(f"attention v{variant} b{b} h{heads} n{n} d{d}", o.float().cpu(), ref)
+    assert torch.isfinite(o.float()).all()
+    assert rel < 1e-2 and err < 3e-2
+
+
+def test_ray_encode_vs_oracle(capi):
+    from oracle import pose as opose
+    g = np.load("tests/golden/ray_encoding.npz")
+    poses = torch.from_numpy(g["poses"])
+    out = torch.empty(2, 8, 180, 8, 8, device="cuda")
+    capi.check(capi.lib.dfot_ray_encode(P(poses.cuda()), P(out), 2, 8, 8, S()))
+    got = out.cpu()
+    low = [c for c in range(180) if (c % 15) < 8]
+    np.testing.assert_allclose(got[:, :, low].numpy(), g["enc8"][:, :, low], atol=2e-4)
+    np.testing.assert_allclose(got.numpy(), g["enc8"], atol=3e-2)
+    ref = opose.ray_encoding(poses[:1], 64)
+    out = torch.empty(1, 8, 180, 64, 64, device="cuda")
+    capi.check(capi.lib.dfot_ray_encode(P(poses[:1].contiguous().cuda()), P(out), 1, 8, 64, S()))
+    np.testing.assert_allclose(out.cpu()[:, :, low].numpy(), ref[:, :, low].numpy(), atol=2e-4)
+
+
+def test_sampler_step_kernels(capi):
+    """dfot_hg_prepare + dfot_ddim_compose against the reference formulas in torch fp32."""
+    g = torch.Generator().manual_seed(9)
+    b, nfe, t, f = 2, 2, 8, 3 * 8 * 8
+    x = torch.randn(b, t, f, generator=g)
+    noise = torch.randn(b * nfe, t, f, generator=g)
+    qa = torch.rand(b * nfe, t, generator=g)
+    qb = torch.rand(b * nfe, t, generator=g)
+    qb[1] = 0
+    qa[1] = 1
+    x_in = torch.empty(b * nfe, t, f, device="cuda")
+    capi.check(capi.lib.dfot_hg_prepare(P(x.cuda()), P(noise.cuda()), P(qa.cuda()), P(qb.cuda()), P(x_in), b, nfe, t, f, S()))
+    ref_in = qa[..., None] * x.repeat_interleave(nfe, 0) + qb[..., None] * noise
+    np.testing.assert_allclose(x_in.cpu().numpy(), ref_in.numpy(), rtol=1e-6, atol=1e-6)
+    v = torch.randn(b * nfe, t, f, generator=g)
+    sa, s1, an, cn = (torch.rand(b * nfe, t, generator=g) for _ in range(4))
+    keep = (torch.rand(b * nfe, t, generator=g) < 0.3).float()
+    w = torch.tensor([-3.0, 4.0])
+    gen = (torch.rand(b, t, generator=g) < 0.6)
+    out = torch.empty(b, t, f, device="cuda")
+    capi.check(capi.lib.dfot_ddim_compose(P(x.cuda()), P(ref_in.cuda()), P(v.cuda()), P(sa.cuda()), P(s1.cuda()),
+                                          P(an.cuda()), P(cn.cuda()), P(keep.cuda()), P(w.cuda()),
+                                          P(gen.to(torch.uint8).cuda()), P(out), b, nfe, t, f, S()))
+    e = lambda a: a[..., None]
+    x0 = e(sa) * ref_in - e(s1) * v
+    eps = e(sa) * v + e(s1) * ref_in
+    xp = torch.where(e(keep) != 0, ref_in, x0 * e(an) + eps * e(cn))
+    comp = (xp.view(b, nfe, t, f) * w.view(1, nfe, 1, 1)).sum(1)
+    ref = torch.where(e(gen), comp, x)
+    np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), rtol=1e-5, atol=1e-5)
