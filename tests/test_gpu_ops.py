@@ -67,7 +67,8 @@ def test_conv3x3(capi, dma, bt, h, w, cin, cout):
     a = x.permute(0, 2, 3, 1).contiguous().cuda()                      # NHWC
     wp = wt.permute(0, 2, 3, 1).reshape(cout, 9 * cin).contiguous().cuda()  # [Cout][tap][Cin]
     out = torch.full((bt, h, w, cout), float("nan"), device="cuda")
-    capi.check(capi.lib.dfot_op_conv3x3(P(a), P(wp), P(bias.cuda()), P(out), bt, h, w, cin, cout, dma, S()))
+    bd = bias.cuda()
+    capi.check(capi.lib.dfot_op_conv3x3(P(a), P(wp), P(bd), P(out), bt, h, w, cin, cout, dma, S()))
     ref = F.conv2d(x.float(), wt.float(), bias, padding=1).permute(0, 2, 3, 1).cuda()
     err, rel = report(f"conv dma={dma} {bt}x{h}x{w} {cin}->{cout}", out, ref)
     assert torch.isfinite(out).all()
@@ -87,8 +88,9 @@ def test_attention(capi, variant, b, heads, n, d):
     qs = (q * (math.log2(math.e) / math.sqrt(d))).bfloat16()
     kb, vb = k.bfloat16(), v.bfloat16()
     o = torch.full((b, n, heads * d), float("nan"), device="cuda", dtype=torch.bfloat16)
-    capi.check(capi.lib.dfot_op_attention(P(qs.cuda()), P(kb.cuda()), P(vb.cuda()), P(o), heads * d, b, heads, n, d,
-                                          variant, S()))
+    qd, kd, vd = qs.cuda(), kb.cuda(), vb.cuda()  # keep the device tensors alive across the launch
+    capi.check(capi.lib.dfot_op_attention(P(qd), P(kd), P(vd), P(o), heads * d, b, heads, n, d, variant, S()))
+    torch.cuda.synchronize()
     s = (qs.double() @ kb.double().transpose(-1, -2)) * math.log(2.0)
     ref = (torch.softmax(s, dim=-1) @ vb.double()).permute(0, 2, 1, 3).reshape(b, n, heads * d).float()
     err, rel = report(f"attention v{variant} b{b} h{heads} n{n} d{d}", o.float().cpu(), ref)
@@ -101,14 +103,16 @@ def test_ray_encode_vs_oracle(capi):
     g = np.load("tests/golden/ray_encoding.npz")
     poses = torch.from_numpy(g["poses"])
     out = torch.empty(2, 8, 180, 8, 8, device="cuda")
-    capi.check(capi.lib.dfot_ray_encode(P(poses.cuda()), P(out), 2, 8, 8, S()))
+    pd = poses.cuda()
+    capi.check(capi.lib.dfot_ray_encode(P(pd), P(out), 2, 8, 8, S()))
     got = out.cpu()
     low = [c for c in range(180) if (c % 15) < 8]
     np.testing.assert_allclose(got[:, :, low].numpy(), g["enc8"][:, :, low], atol=2e-4)
     np.testing.assert_allclose(got.numpy(), g["enc8"], atol=3e-2)
     ref = opose.ray_encoding(poses[:1], 64)
     out = torch.empty(1, 8, 180, 64, 64, device="cuda")
-    capi.check(capi.lib.dfot_ray_encode(P(poses[:1].contiguous().cuda()), P(out), 1, 8, 64, S()))
+    pd1 = poses[:1].contiguous().cuda()
+    capi.check(capi.lib.dfot_ray_encode(P(pd1), P(out), 1, 8, 64, S()))
     np.testing.assert_allclose(out.cpu()[:, :, low].numpy(), ref[:, :, low].numpy(), atol=2e-4)
 
 
@@ -123,7 +127,8 @@ def test_sampler_step_kernels(capi):
     qb[1] = 0
     qa[1] = 1
     x_in = torch.empty(b * nfe, t, f, device="cuda")
-    capi.check(capi.lib.dfot_hg_prepare(P(x.cuda()), P(noise.cuda()), P(qa.cuda()), P(qb.cuda()), P(x_in), b, nfe, t, f, S()))
+    d = {n: v.cuda() for n, v in dict(x=x, noise=noise, qa=qa, qb=qb).items()}
+    capi.check(capi.lib.dfot_hg_prepare(P(d["x"]), P(d["noise"]), P(d["qa"]), P(d["qb"]), P(x_in), b, nfe, t, f, S()))
     ref_in = qa[..., None] * x.repeat_interleave(nfe, 0) + qb[..., None] * noise
     np.testing.assert_allclose(x_in.cpu().numpy(), ref_in.numpy(), rtol=1e-6, atol=1e-6)
     v = torch.randn(b * nfe, t, f, generator=g)
@@ -132,9 +137,10 @@ def test_sampler_step_kernels(capi):
     w = torch.tensor([-3.0, 4.0])
     gen = (torch.rand(b, t, generator=g) < 0.6)
     out = torch.empty(b, t, f, device="cuda")
-    capi.check(capi.lib.dfot_ddim_compose(P(x.cuda()), P(ref_in.cuda()), P(v.cuda()), P(sa.cuda()), P(s1.cuda()),
-                                          P(an.cuda()), P(cn.cuda()), P(keep.cuda()), P(w.cuda()),
-                                          P(gen.to(torch.uint8).cuda()), P(out), b, nfe, t, f, S()))
+    d = {n: v.cuda() for n, v in dict(x=x, xi=ref_in, v=v, sa=sa, s1=s1, an=an, cn=cn, keep=keep, w=w,
+                                      gen=gen.to(torch.uint8)).items()}
+    capi.check(capi.lib.dfot_ddim_compose(P(d["x"]), P(d["xi"]), P(d["v"]), P(d["sa"]), P(d["s1"]), P(d["an"]),
+                                          P(d["cn"]), P(d["keep"]), P(d["w"]), P(d["gen"]), P(out), b, nfe, t, f, S()))
     e = lambda a: a[..., None]
     x0 = e(sa) * ref_in - e(s1) * v
     eps = e(sa) * v + e(s1) * ref_in
