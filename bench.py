@@ -1,0 +1,155 @@
+#!/usr/bin/env python3
+"""DFoT RE10K sampling benchmark on MI355X (BASELINE.json metric: denoised frames/sec).
+
+One "step" = one complete 8-frame sample of BASELINE config 2 (DFoT_RE10K: UViT3DPose 458.8 M params,
+x_shape [3,256,256], context 1 frame, 50 DDIM steps, vanilla history guidance 4.0 => 100 window-forwards,
+7 generated frames) on synthetic latents and seeded random-init weights.  With --gpus N every rank samples
+its own video (independent units, no data-path collective; weak scaling); value = frames of all ranks / max time.
+
+Also reports on rank 0:
+  roofline     dominant kernel = level-2 flash attention (N=8192, d=64, 18 (batch,head) units per launch);
+               algorithmic FLOPs per launch = 4*N^2*d*heads*Bm = 309.2 GFLOP, duration = HIP events
+               recorded on the launch stream around every such launch inside the timed region.
+  cpu_baseline the CPU oracle (oracle/, a plain-PyTorch fp32 port of the reference path) timed on the host cores on a
+               bounded sample (one window-forward), converted to frames/s of the same workload.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+RE10K = dict(channels=[128, 256, 576, 1152], emb_channels=1024, patch_size=2,
+             block_types=["ResBlock", "ResBlock", "TransformerBlock", "TransformerBlock"],
+             num_updown_blocks=[3, 3, 6], num_mid_blocks=20, num_heads=9, pos_emb_type="rope",
+             use_fourier_noise_embedding=True, conditioning=dict(dim=180))
+WINDOW_FLOP = 6.63e12  # per 8-frame window-forward
+
+
+def synth_poses(b: int, t: int, seed: int) -> torch.Tensor:
+    g = torch.Generator().manual_seed(seed)
+    k = torch.tensor([0.5, 0.9, 0.5, 0.5]).repeat(b, t, 1)
+    ang = 0.1 * torch.randn(b, t, generator=g).cumsum(1)
+    c, s, o, z = ang.cos(), ang.sin(), torch.ones_like(ang), torch.zeros_like(ang)
+    rot = torch.stack([c, z, s, z, o, z, -s, z, c], -1).view(b, t, 3, 3)
+    trans = torch.stack([torch.linspace(0, 0.5, t).repeat(b, 1), torch.zeros(b, t), torch.linspace(0, -0.3, t).repeat(b, 1)], -1)
+    return torch.cat([k, torch.cat([rot, trans[..., None]], -1).reshape(b, t, 12)], -1)
+
+
+def cpu_baseline(res: int, sample_forwards: int, frames: int, forwards_per_sample: int):
+    from oracle import pose as opose, uvit as ouvit
+    ocfg = ouvit.UViTConfig(resolution=res)
+    params = ouvit.seeded_params(ocfg, 0)
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(1, 8, 3, res, res, generator=g)
+    k = torch.randn(1, 8, generator=g)
+    cond = opose.ray_encoding(synth_poses(1, 8, 7), res)
+    cores = min(16, os.cpu_count() or 1)  # a 1-GPU box has a 16-core CPU share
+    torch.set_num_threads(cores)
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        for _ in range(sample_forwards):
+            ouvit.forward(params, ocfg, x, k, cond, None)
+    dt = (time.perf_counter() - t0) / sample_forwards
+    return {"value": frames / (forwards_per_sample * dt), "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"{sample_forwards} window-forward(s) of the oracle (Bm=1, T=8, {res}x{res}), {dt:.2f} s each; "
+                      f"scaled to {forwards_per_sample} window-forwards per {frames}-frame sample"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--res", type=int, default=256)
+    ap.add_argument("--sampling-steps", type=int, default=50)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    import dfot_amd
+    from dfot_amd import DFoTVideoPoseSampler, DiffusionConfig, SamplerConfig, UViT3DPose
+
+    res = args.res
+    model = UViT3DPose(RE10K, x_shape=(3, res, res), max_tokens=8).cuda()
+    model.init_random(seed=0)
+    cfg = SamplerConfig(x_shape=(3, res, res), max_tokens=8,
+                        diffusion=DiffusionConfig(sampling_timesteps=args.sampling_steps),
+                        prediction_guidance=dict(name="vanilla", guidance_scale=4.0))
+    gen = torch.Generator(device="cuda").manual_seed(1234 + rank)
+    sampler = DFoTVideoPoseSampler(cfg, model, dfot_amd.device_noise_fn(gen))
+    xs = torch.randn(1, 8, 3, res, res, generator=torch.Generator().manual_seed(rank)).cuda()
+    conds = synth_poses(1, 8, 100 + rank).cuda()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        sampler._predict_videos(xs, n_context_tokens=1, conditions=conds)
+    attn_per_sample = args.sampling_steps * 12
+    model.set_option("time_attn", attn_per_sample * args.steps if rank == 0 else 0)
+    sampler.window_forwards = 0
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = sampler._predict_videos(xs, n_context_tokens=1, conditions=conds)
+    barrier()
+    dt = time.perf_counter() - t0
+    assert torch.isfinite(out).all()
+    if world > 1:
+        tmax = torch.tensor([dt], device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    frames_per_sample = 7
+    total_frames = frames_per_sample * args.steps * world
+    fwd = sampler.window_forwards
+
+    if rank == 0:
+        attn_ms, attn_n = model.attn_timing()
+        n2 = 8 * (res // 8) ** 2
+        flop_per_launch = 4.0 * n2 * n2 * 64 * 9 * 2
+        achieved = flop_per_launch / (attn_ms / max(attn_n, 1) * 1e-3) / 1e12 if attn_n else None
+        line = {
+            "metric": "denoised latent frames/sec, DFoT RE10K 8f & 200f rollout @1/2/4/8 GPU",
+            "value": total_frames / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic latents, seeded random-init weights",
+            "config": {"workload": f"DFoT_RE10K 8-frame sample: context 1, {args.sampling_steps} DDIM steps, vanilla history "
+                                   f"guidance 4.0 (NFE 2), {res}x{res}, one video per GPU",
+                       "window_forwards_per_step": fwd // args.steps, "frames_per_step": frames_per_sample},
+            "window_forward_ms": dt / fwd * 1e3,
+            "model_tflops": WINDOW_FLOP * (res / 256.0) ** 2 * fwd / dt / 1e12 if res == 256 else None,
+            "roofline": {"bound": "mfma", "kernel": "attn_kernel<64> (level-2 flash attention, N=%d, d=64)" % n2,
+                         "achieved": achieved, "peak": 2500.0, "unit": "TFLOP/s",
+                         "frac": achieved / 2500.0 if achieved else None, "traffic": None,
+                         "launches": attn_n, "avg_launch_ms": attn_ms / max(attn_n, 1),
+                         "flop_per_launch": flop_per_launch},
+        }
+        if not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(res, 1, frames_per_sample, fwd // args.steps)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

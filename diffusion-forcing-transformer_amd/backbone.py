@@ -146,6 +146,35 @@ class UViT3DPose(nn.Module):
     def set_option(self, key: str, value: int) -> None:
         capi.check(capi.lib.dfot_uvit_set_option(self._handle, key.encode(), int(value)))
 
+    def attn_timing(self):
+        """(total_ms, launches) of the level-2 attention launches recorded since set_option('time_attn', N)."""
+        tot, n = C.c_double(), C.c_int64()
+        capi.check(capi.lib.dfot_uvit_attn_timing(self._handle, C.byref(tot), C.byref(n)))
+        return tot.value, n.value
+
+    def init_random(self, seed: int = 0, zero_init_scale: float = 0.3) -> None:
+        """Non-degenerate random weights for benchmarks (the reference's default init zeroes every output
+        projection, which would make all activations trivial): weights ~ N(0, 1/fan_in), biases ~ N(0, 0.02^2),
+        gains ~ 1 + N(0, 0.1^2), Fourier freqs 2*pi*N(0,1), phases 2*pi*U(0,1)."""
+        g = torch.Generator().manual_seed(seed)
+        with torch.no_grad():
+            for name, t in self._tensors().items():
+                leaf = name.rsplit(".", 1)[-1]
+                if leaf == "freqs":
+                    v = 2 * math.pi * torch.randn(t.shape, generator=g)
+                elif leaf == "phases":
+                    v = 2 * math.pi * torch.rand(t.shape, generator=g)
+                elif leaf == "bias":
+                    v = 0.02 * torch.randn(t.shape, generator=g)
+                elif t.ndim == 1:
+                    v = 1.0 + 0.1 * torch.randn(t.shape, generator=g)
+                else:
+                    fan_in = t.shape[0] if name.startswith("project_output") else math.prod(t.shape[1:])
+                    v = torch.randn(t.shape, generator=g) / math.sqrt(fan_in)
+                    if any(s in name for s in (".attn_out.", ".mlp_out.2.", ".out_rest.1.", "project_output")):
+                        v = v * zero_init_scale
+                t.copy_(v.to(t.device))
+
     def reserve(self, batch: int) -> None:
         if batch > self._reserved:
             torch.cuda.synchronize()

@@ -6,7 +6,7 @@ namespace dfot {
 
 // ---- embeddings ----
 int launch_noise_emb(const float* k, const float* freqs, const float* phases, const float* w1, const float* b1,
-                     const float* w2, const float* b2, float* out, int bt, int ndim, int e, hipStream_t s);
+                     const float* w2, const float* b2, float* hidden, float* out, int bt, int ndim, int e, hipStream_t s);
 int launch_embed_input(const float* x, const float* w, const float* b, float* out, int bt, int res, int cin, int c0,
                        hipStream_t s);
 int launch_cond_repack(const float* cond, bf16* a, int bt, int res, int cdim, int kpad, hipStream_t s);

@@ -17,39 +17,37 @@ __device__ __forceinline__ float wave_sum(float v) {
 
 // --------------------------------------------------------------------------------------------
 // noise-level embedding: Fourier features -> Linear -> SiLU -> Linear  (embeddings.py:67-110)
-// one workgroup per (video, token); a wave computes one output row at a time (coalesced weights)
+// two launches; one wave per (token, output row) so the weight rows are read coalesced and the
+// grid (tokens x E / 4 workgroups) fills the chip
 // --------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void noise_emb_kernel(const float* __restrict__ k, const float* __restrict__ freqs,
-                                                        const float* __restrict__ phases, const float* __restrict__ w1,
-                                                        const float* __restrict__ b1, const float* __restrict__ w2,
-                                                        const float* __restrict__ b2, float* __restrict__ out, int ndim,
+template <bool FOURIER>
+__global__ __launch_bounds__(256) void noise_mlp_kernel(const float* __restrict__ in, const float* __restrict__ freqs,
+                                                        const float* __restrict__ phases, const float* __restrict__ w,
+                                                        const float* __restrict__ b, float* __restrict__ out, int kdim,
                                                         int e) {
-  extern __shared__ float sm[];  // [ndim] fourier, [e] hidden
-  float* f = sm;
-  float* h = sm + ndim;
-  const int bt = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const float kv = k[bt];
-  for (int i = tid; i < ndim; i += 256) f[i] = cosf(__fadd_rn(__fmul_rn(kv, freqs[i]), phases[i])) * 1.41421356237309515f;
-  __syncthreads();
-  for (int row = wave; row < e; row += 4) {
-    float acc = 0.f;
-    for (int i = lane; i < ndim; i += 64) acc += w1[(long)row * ndim + i] * f[i];
-    acc = wave_sum(acc);
-    if (lane == 0) h[row] = silu_f(acc + b1[row]);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int row = blockIdx.x * 4 + wave;
+  const int bt = blockIdx.y;
+  if (row >= e) return;
+  float acc = 0.f;
+  for (int i = lane; i < kdim; i += 64) {
+    float f;
+    if constexpr (FOURIER) {
+      f = cosf(__fadd_rn(__fmul_rn(in[bt], freqs[i]), phases[i])) * 1.41421356237309515f;
+    } else {
+      f = in[(long)bt * kdim + i];
+    }
+    acc += w[(long)row * kdim + i] * f;
   }
-  __syncthreads();
-  for (int row = wave; row < e; row += 4) {
-    float acc = 0.f;
-    for (int i = lane; i < e; i += 64) acc += w2[(long)row * e + i] * h[i];
-    acc = wave_sum(acc);
-    if (lane == 0) out[(long)bt * e + row] = acc + b2[row];
-  }
+  acc = wave_sum(acc);
+  if (lane == 0) out[(long)bt * e + row] = FOURIER ? silu_f(acc + b[row]) : acc + b[row];
 }
 
 int launch_noise_emb(const float* k, const float* freqs, const float* phases, const float* w1, const float* b1,
-                     const float* w2, const float* b2, float* out, int bt, int ndim, int e, hipStream_t s) {
-  hipLaunchKernelGGL(noise_emb_kernel, dim3(bt), dim3(256), (ndim + e) * sizeof(float), s, k, freqs, phases, w1, b1, w2,
-                     b2, out, ndim, e);
+                     const float* w2, const float* b2, float* hidden, float* out, int bt, int ndim, int e, hipStream_t s) {
+  hipLaunchKernelGGL(noise_mlp_kernel<true>, dim3(cdiv(e, 4), bt), dim3(256), 0, s, k, freqs, phases, w1, b1, hidden, ndim, e);
+  DFOT_CHECK_HIP(hipGetLastError());
+  hipLaunchKernelGGL(noise_mlp_kernel<false>, dim3(cdiv(e, 4), bt), dim3(256), 0, s, hidden, nullptr, nullptr, w2, b2, out, e, e);
   DFOT_CHECK_HIP(hipGetLastError());
   return DFOT_OK;
 }

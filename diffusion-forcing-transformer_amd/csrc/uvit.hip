@@ -85,13 +85,17 @@ struct dfot_uvit_s {
   int max_batch = 0;
   size_t ws_bytes = 0;
   std::vector<void*> ws_owned;
-  float *nemb = nullptr, *X[4] = {nullptr, nullptr, nullptr, nullptr}, *HSA[3] = {nullptr, nullptr, nullptr}, *tmp = nullptr,
+  float *nemb = nullptr, *nhid = nullptr, *X[4] = {nullptr, nullptr, nullptr, nullptr}, *HSA[3] = {nullptr, nullptr, nullptr}, *tmp = nullptr,
         *gn_partial = nullptr, *gn_stats = nullptr, *rstd = nullptr;
   bf16 *acond = nullptr, *emb[4] = {nullptr, nullptr, nullptr, nullptr}, *s1 = nullptr, *hbf = nullptr, *qkv = nullptr,
        *cat = nullptr, *q = nullptr, *k = nullptr, *v = nullptr;
   int last_batch = 0;
   bool use_dma = true;
   int attn_variant = 0;
+  // optional in-run timing of the level-2 attention launches (HIP events on the launch stream)
+  bool time_attn = false;
+  std::vector<hipEvent_t> ev_start, ev_stop;
+  size_t ev_used = 0;
 };
 
 namespace dfot {
@@ -371,7 +375,10 @@ static int run_tr_block(dfot_uvit_s* h, const TrW& w, int lvl, int batch, hipStr
   if ((rc = launch_qk_norm_rope(h->qkv, w.qw, w.kw, h->rope_cs[lvl], h->q, h->k, h->v, batch, n, h->heads, d, qscale,
                                 h->cfg.eps, s)))
     return rc;
+  const bool timed = h->time_attn && lvl == 2 && h->ev_used < h->ev_start.size();
+  if (timed) DFOT_CHECK_HIP(hipEventRecord(h->ev_start[h->ev_used], s));
   if ((rc = launch_attention(h->q, h->k, h->v, h->cat, 5 * c, batch, h->heads, n, d, h->attn_variant, s))) return rc;
+  if (timed) DFOT_CHECK_HIP(hipEventRecord(h->ev_stop[h->ev_used++], s));
   GemmArgs o;
   o.A = h->cat; o.lda = 5 * c; o.W = w.w_out; o.M = m; o.N = c; o.K = 5 * c; o.bias = w.b_out; o.out_f32 = x; o.resid = x;
   o.ldo = c;
@@ -441,6 +448,8 @@ int dfot_uvit_destroy(dfot_uvit_t h) {
   if (!h) return DFOT_OK;
   for (void* p : h->owned) (void)hipFree(p);
   for (void* p : h->ws_owned) (void)hipFree(p);
+  for (hipEvent_t e : h->ev_start) (void)hipEventDestroy(e);
+  for (hipEvent_t e : h->ev_stop) (void)hipEventDestroy(e);
   delete h;
   return DFOT_OK;
 }
@@ -503,6 +512,7 @@ int dfot_uvit_reserve(dfot_uvit_t h, int max_batch) {
   for (int l = 0; l < 4; ++l) pix[l] = (size_t)h->r[l] * h->r[l];
   int rc = 0;
   if ((rc = dev_alloc(h, &h->nemb, bt * h->E, true))) return rc;
+  if ((rc = dev_alloc(h, &h->nhid, bt * h->E, true))) return rc;
   for (int l = 0; l < 4; ++l) {
     if ((rc = dev_alloc(h, &h->X[l], bt * pix[l] * h->ch[l], true))) return rc;
     if ((rc = dev_alloc(h, &h->emb[l], bt * pix[l] * h->E, true))) return rc;
@@ -536,10 +546,37 @@ int dfot_uvit_reserve(dfot_uvit_t h, int max_batch) {
 
 size_t dfot_uvit_workspace_bytes(dfot_uvit_t h) { return h ? h->ws_bytes : 0; }
 
+int dfot_uvit_attn_timing(dfot_uvit_t h, double* total_ms, int64_t* launches) {
+  DFOT_REQUIRE(h && total_ms && launches, DFOT_ERR_ARG, "attn_timing: null argument");
+  double tot = 0.0;
+  for (size_t i = 0; i < h->ev_used; ++i) {
+    DFOT_CHECK_HIP(hipEventSynchronize(h->ev_stop[i]));
+    float ms = 0.f;
+    DFOT_CHECK_HIP(hipEventElapsedTime(&ms, h->ev_start[i], h->ev_stop[i]));
+    tot += ms;
+  }
+  *total_ms = tot;
+  *launches = (int64_t)h->ev_used;
+  h->ev_used = 0;
+  return DFOT_OK;
+}
+
 int dfot_uvit_set_option(dfot_uvit_t h, const char* key, int value) {
   DFOT_REQUIRE(h && key, DFOT_ERR_ARG, "set_option: null argument");
   if (!strcmp(key, "lds_dma")) h->use_dma = value != 0;
   else if (!strcmp(key, "attn_variant")) h->attn_variant = value;
+  else if (!strcmp(key, "time_attn")) {
+    // value = number of launches to record (0 disables); events are created here, never inside forward
+    h->time_attn = value > 0;
+    h->ev_used = 0;
+    while ((int)h->ev_start.size() < value) {
+      hipEvent_t a, b;
+      DFOT_CHECK_HIP(hipEventCreate(&a));
+      DFOT_CHECK_HIP(hipEventCreate(&b));
+      h->ev_start.push_back(a);
+      h->ev_stop.push_back(b);
+    }
+  }
   else {
     set_error("set_option: unknown key '%s'", key);
     return DFOT_ERR_ARG;
@@ -557,7 +594,7 @@ int dfot_uvit_forward(dfot_uvit_t h, const float* x, const float* noise_levels, 
   const dfot_uvit_config& c = h->cfg;
   const int bt = batch * h->T, e = h->E;
   int rc = 0;
-  if ((rc = launch_noise_emb(noise_levels, h->ne_freqs, h->ne_phases, h->ne_w1, h->ne_b1, h->ne_w2, h->ne_b2, h->nemb, bt,
+  if ((rc = launch_noise_emb(noise_levels, h->ne_freqs, h->ne_phases, h->ne_w1, h->ne_b1, h->ne_w2, h->ne_b2, h->nhid, h->nemb, bt,
                              c.noise_dim, e, s)))
     return rc;
   if ((rc = launch_embed_input(x, h->ein_w, h->ein_b, h->X[0], bt, c.resolution, c.in_channels, h->ch[0], s))) return rc;

@@ -78,8 +78,11 @@ int dfot_uvit_finalize(dfot_uvit_t h, void* stream);
 int dfot_uvit_reserve(dfot_uvit_t h, int max_batch);
 size_t dfot_uvit_workspace_bytes(dfot_uvit_t h);
 /* tuning/debug switches: "lds_dma" (1 = LDS-DMA staging in the GEMMs, 0 = register staging),
- * "attn_variant" (0 = transposed LDS reads for V, 1 = scalar LDS reads) */
+ * "attn_variant" (0 = transposed LDS reads for V, 1 = scalar LDS reads), "time_attn" (see below) */
 int dfot_uvit_set_option(dfot_uvit_t h, const char* key, int value);
+/* "time_attn" = N > 0 records HIP events (on the launch stream) around the next N level-2 attention launches;
+ * this call synchronises on them, returns the summed duration and the number of launches, and resets the count */
+int dfot_uvit_attn_timing(dfot_uvit_t h, double* total_ms, int64_t* launches);
 
 /* out[B,T,C,H,W] = model(x[B,T,C,H,W], noise_levels[B,T], external_cond[B,T,180,H,W], external_cond_mask[B])
  * all fp32 contiguous; noise_levels is the float level the reference passes (0.125*logsnr[k]);
