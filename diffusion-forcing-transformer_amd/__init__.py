@@ -7,3 +7,4 @@ from .backbone import UViT3DPose  # noqa: F401
 from .diffusion import DiffusionConfig, Schedule  # noqa: F401
 from .guidance import HistoryGuidance  # noqa: F401
 from .sampler import DFoTVideoPoseSampler, SamplerConfig, device_noise_fn  # noqa: F401
+from . import parallel  # noqa: F401,E402

@@ -1,0 +1,81 @@
+"""Multi-GPU sharding of independent sampling units (one process per GPU, torch.distributed over RCCL).
+
+The DFoT path has no sequence parallelism: a window is one 8-frame forward, and the windows of
+one interpolation plan stage (dfot_video.py:284-358) are independent.  They are dealt round-robin to ranks and the
+finished windows are exchanged with ONE all-gather per plan stage.  Randomness is keyed by window id, not by rank
+or batch position, so the sharded result is identical to the single-GPU result.
+"""
+from __future__ import annotations
+
+from typing import Callable, List, Optional, Sequence
+
+import torch
+import torch.distributed as dist
+
+
+def world_info(group=None):
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_world_size(group), dist.get_rank(group)
+    return 1, 0
+
+
+def shard_windows(n_windows: int, world: int, rank: int) -> List[int]:
+    """Window ids owned by `rank` (round-robin keeps both HG branches of a window on one GPU)."""
+    return list(range(rank, n_windows, world))
+
+
+def gather_windows(local: torch.Tensor, n_windows: int, group=None) -> torch.Tensor:
+    """local: [n_local, ...] results of shard_windows(n_windows, world, rank) in order -> [n_windows, ...] on every
+    rank.  One collective: ranks pad to ceil(n/world) rows, all-gather, and rows are re-interleaved."""
+    world, rank = world_info(group)
+    if world == 1:
+        return local
+    per = (n_windows + world - 1) // world
+    pad = local.new_zeros((per, *local.shape[1:]))
+    pad[: local.shape[0]] = local
+    out = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(out, pad.contiguous(), group=group)
+    stacked = torch.stack(out, dim=1)          # [per, world, ...]: window id = i*world + r
+    return stacked.reshape(per * world, *local.shape[1:])[:n_windows].contiguous()
+
+
+class WindowKeyedNoise:
+    """noise_fn whose draws depend only on (seed, window id, tag, draw counter of that window): the same window gets the
+    same noise whichever rank or batch slot it is sampled in.  `set_windows` is called by the sampler per batch."""
+
+    def __init__(self, seed: int, device: str = "cuda", clip: float = 20.0):
+        self.seed, self.device, self.clip = int(seed), device, clip
+        self.keys: Sequence[int] = (0,)
+        self.counters = {}
+
+    def set_windows(self, keys: Sequence[int]) -> None:
+        self.keys = tuple(int(k) for k in keys)
+
+    def __call__(self, tag: str, shape: tuple) -> torch.Tensor:
+        rows = shape[0]
+        per = max(rows // len(self.keys), 1)
+        out = torch.empty(shape, device=self.device, dtype=torch.float32)
+        tag_id = {"init": 1, "q_sample": 2, "excluded": 3, "ddim": 4}.get(tag, 9)
+        for i, key in enumerate(self.keys):
+            c = self.counters.get((key, tag_id), 0)
+            self.counters[(key, tag_id)] = c + 1
+            g = torch.Generator(device=self.device)
+            g.manual_seed((self.seed * 1000003 + key * 8191 + tag_id * 131 + c) % (2 ** 63 - 1))
+            out[i * per:(i + 1) * per] = torch.randn((per, *shape[1:]), device=self.device, generator=g)
+        return out.clamp_(-self.clip, self.clip) if tag != "excluded" else out
+
+
+def run_sharded(n_windows: int, sample_batch: Callable[[List[int]], torch.Tensor], max_batch: Optional[int],
+                group=None) -> torch.Tensor:
+    """Runs sample_batch(ids) -> [len(ids), ...] over this rank's windows in chunks of <= max_batch and returns
+    all n_windows results on every rank."""
+    world, rank = world_info(group)
+    mine = shard_windows(n_windows, world, rank)
+    mb = max_batch or max(len(mine), 1)
+    outs = [sample_batch(mine[i:i + mb]) for i in range(0, len(mine), mb)]
+    if outs:
+        local = torch.cat(outs, 0)
+    else:  # more ranks than windows: contribute an empty shard of the right trailing shape
+        probe = sample_batch([])
+        local = probe
+    return gather_windows(local, n_windows, group)

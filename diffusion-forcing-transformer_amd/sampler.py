@@ -23,7 +23,7 @@ from typing import Callable, Dict, List, Optional, Tuple
 import numpy as np
 import torch
 
-from . import capi
+from . import capi, parallel
 from .diffusion import DiffusionConfig, Schedule
 from .guidance import HistoryGuidance
 
@@ -63,6 +63,7 @@ class DFoTVideoPoseSampler:
         self.x_shape = tuple(cfg.x_shape)
         self.trace: List[dict] = []
         self.window_forwards = 0
+        self.shard_windows = False  # True: shard interpolation windows over torch.distributed ranks (parallel.py)
         if cfg.diffusion.ddim_sampling_eta != 0:
             raise NotImplementedError("only deterministic DDIM (eta = 0) is implemented on the device path")
 
@@ -279,18 +280,26 @@ class DFoTVideoPoseSampler:
         hg = HistoryGuidance.from_config(cfg.interpolation_guidance, timesteps=self.timesteps)
         xs = context.to(device="cuda", dtype=torch.float32).clone()
         known = context_mask.clone()
-        for stage in self._interpolation_plan(context_mask[0].numpy()):
+        for si, stage in enumerate(self._interpolation_plan(context_mask[0].numpy())):
             ctx = torch.cat([self._pad_to_max_tokens(xs[:, w]) for w in stage], 0)
             msk = torch.cat([self._pad_to_max_tokens(known[:, w]) for w in stage], 0)
             cnd = None if conditions is None else torch.cat([self._pad_to_max_tokens(conditions[:, w]) for w in stage], 0)
+
+            def sample_batch(ids, ctx=ctx, msk=msk, cnd=cnd, si=si):
+                if not ids:
+                    return ctx.new_zeros((0, *ctx.shape[1:]))
+                if hasattr(self.noise_fn, "set_windows"):
+                    self.noise_fn.set_windows([(si + 1) * 100000 + i for i in ids])
+                o, _ = self._sample_sequence(len(ids), context=ctx[ids], context_mask=msk[ids].long(),
+                                             conditions=None if cnd is None else cnd[ids], history_guidance=hg)
+                return o
+
             mb = cfg.interpolation_max_batch_size or ctx.shape[0]
-            outs = []
-            for i in range(0, ctx.shape[0], mb):
-                sl = slice(i, i + mb)
-                o, _ = self._sample_sequence(ctx[sl].shape[0], context=ctx[sl], context_mask=msk[sl].long(),
-                                             conditions=None if cnd is None else cnd[sl], history_guidance=hg)
-                outs.append(o)
-            out = torch.cat(outs, 0)
+            if self.shard_windows:
+                # windows of one plan stage are independent units: round-robin over ranks, one all-gather per stage
+                out = parallel.run_sharded(ctx.shape[0], sample_batch, mb)
+            else:
+                out = torch.cat([sample_batch(list(range(i, min(i + mb, ctx.shape[0])))) for i in range(0, ctx.shape[0], mb)], 0)
             for w, pred in zip(stage, out.chunk(len(stage), 0)):
                 xs[:, w] = pred[:, : len(w)]
                 known[:, w] = True

@@ -1,0 +1,89 @@
+"""CPU tests of the product's host-side planning (no device work): schedule tables, scheduling matrices and the
+History-Guidance branch planner, checked against the golden vectors captured from the reference."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from dfot_amd import DiffusionConfig, HistoryGuidance, Schedule
+
+
+def load(name):
+    return np.load(os.path.join(GOLDEN, name))
+
+
+def test_schedule_tables_match_reference_buffers():
+    g = load("schedule.npz")
+    s = Schedule(DiffusionConfig())
+    np.testing.assert_allclose(s.alphas_cumprod, g["alphas_cumprod"], rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(s.sqrt_alphas_cumprod, g["sqrt_alphas_cumprod"], rtol=1e-6)
+    np.testing.assert_allclose(s.sqrt_one_minus_alphas_cumprod, g["sqrt_one_minus_alphas_cumprod"], rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(s.logsnr, g["logsnr"], rtol=1e-6, atol=1e-6)
+    assert np.array_equal(s.ddim_idx_to_noise_level(np.arange(51)), g["ddim_levels"])
+    assert np.array_equal(s.scheduling_matrix("full_sequence", 8, 0), g["sched_8_0"])
+    assert np.array_equal(s.scheduling_matrix("full_sequence", 5, 3), g["sched_5_3"])
+
+
+SCHEMES = {
+    "conditional": dict(name="conditional"),
+    "vanilla": dict(name="vanilla", guidance_scale=4.0),
+    "stabilized_vanilla": dict(name="stabilized_vanilla", guidance_scale=4.0, stabilization_level=0.02),
+    "fractional": dict(name="fractional", guidance_scale=3.0, freq_scale=0.4),
+}
+
+
+@pytest.mark.parametrize("sname", list(SCHEMES))
+def test_branch_plan_matches_reference_prepare(sname):
+    """levels / cond-mask of every branch and the q_sample coefficients reproduce the reference's prepare()."""
+    g = load("step_trace.npz")
+    hg = HistoryGuidance.from_config(dict(SCHEMES[sname], visualize=False), timesteps=1000)
+    plan = hg.plan(g["cmask"], g["frm"], g["to"])
+    assert plan.nfe == int(g[f"{sname}_nfe"])
+    b, t = g["cmask"].shape
+    assert np.array_equal(plan.levels.reshape(b * plan.nfe, t), g[f"{sname}_from"])
+    assert np.array_equal(plan.to_levels.reshape(b * plan.nfe, t), g[f"{sname}_to"])
+    cm = g[f"{sname}_cond_mask"]
+    if cm.size == 0:
+        assert plan.cond_masked is None
+    else:
+        assert np.array_equal(np.tile(plan.cond_masked, b), cm)
+    # x_in = qa * x + qb * noise must reproduce the reference's prepared tensor
+    s = Schedule(DiffusionConfig())
+    lv = plan.levels.reshape(b * plan.nfe, t)
+    repl = plan.replace.reshape(b * plan.nfe, t)
+    qa_c, qb_c = s.q_sample_coef(lv)
+    qa = np.where(repl, qa_c, 1.0)[..., None, None, None]
+    qb = np.where(repl, qb_c, 0.0)[..., None, None, None]
+    x = np.repeat(g["xs"], plan.nfe, axis=0)
+    if repl.any():
+        n0 = g[f"{sname}_noise0"]
+        if hg.is_simple:  # the reference draws (B,T,...) for the unconditional branch only
+            noise = np.zeros_like(x).reshape(b, plan.nfe, *x.shape[1:])
+            noise[:, 0] = n0
+            noise = noise.reshape(x.shape)
+        else:
+            noise = n0
+    else:
+        noise = np.zeros_like(x)
+    np.testing.assert_allclose(qa * x + qb * noise, g[f"{sname}_x_in"], rtol=1e-6, atol=1e-6)
+    # composition weights reproduce compose(): sum_h w_h x_h on generated tokens
+    xo = g[f"{sname}_x_out"].reshape(b, plan.nfe, *x.shape[1:])
+    comp = (xo * plan.weights.reshape(1, -1, 1, 1, 1, 1)).sum(1)
+    np.testing.assert_allclose(comp, g[f"{sname}_x_composed"], rtol=1e-4, atol=1e-4)
+
+
+def test_ddim_coefficients_reproduce_reference_step():
+    g = load("step_trace.npz")
+    s = Schedule(DiffusionConfig())
+    frm, to = g["conditional_from"], g["conditional_to"]
+    sa, s1, an, cn, keep, sigma = s.ddim_coef(frm, to)
+    assert (sigma == 0).all()
+    assert np.array_equal(keep.astype(bool), frm == to)
+    # clean tokens (level -1): an = 1, cn = 0
+    assert np.allclose(an[to < 0], 1.0) and np.allclose(cn[to < 0], 0.0)
+
+
+def test_temporal_guidance_is_rejected():
+    with pytest.raises(NotImplementedError):
+        HistoryGuidance([__import__("dfot_amd").guidance.HistorySegment(time_indices=[0])], [1.0])

@@ -1,0 +1,69 @@
+"""Repository contract checks that need no GPU: the C-ABI library loads and exports every declared symbol, the
+product never imports the oracle, and the product has no CPU fallback."""
+import ast
+import ctypes
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+
+PKG = os.path.join(ROOT, "diffusion-forcing-transformer_amd")
+
+
+def test_library_exports_every_symbol_declared_in_header():
+    import __graft_entry__ as g
+    g.build()
+    hdr = open(os.path.join(ROOT, "include", "dfot_hip.h")).read()
+    declared = set(re.findall(r"\b(dfot_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 20
+    lib = ctypes.CDLL(os.path.join(PKG, "libdfot_hip.so"))
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"libdfot_hip.so does not export {name}"
+    from dfot_amd import capi
+    assert declared == set(capi.SIGNATURES), declared ^ set(capi.SIGNATURES)
+    assert lib.dfot_version() >= 1
+
+
+def _imports(path):
+    tree = ast.parse(open(path).read())
+    for node in ast.walk(tree):
+        if isinstance(node, ast.Import):
+            for a in node.names:
+                yield a.name
+        elif isinstance(node, ast.ImportFrom):
+            yield ("." * node.level) + (node.module or "")
+
+
+def test_product_never_imports_oracle_or_reference():
+    for fn in os.listdir(PKG):
+        if fn.endswith(".py"):
+            for mod in _imports(os.path.join(PKG, fn)):
+                assert not mod.lstrip(".").startswith("oracle"), f"{fn} imports {mod}"
+                assert "reference" not in mod
+    src = " ".join(open(os.path.join(PKG, "csrc", f)).read() for f in os.listdir(os.path.join(PKG, "csrc")))
+    assert "/root/reference" not in src
+    for fn in ("bench.py", "__graft_entry__.py"):
+        assert "/root/reference" not in open(os.path.join(ROOT, fn)).read()
+
+
+def test_missing_library_fails_loudly(tmp_path, monkeypatch):
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("capi_probe", os.path.join(PKG, "capi.py"))
+    mod = importlib.util.module_from_spec(spec)
+    real_exists = os.path.exists
+    monkeypatch.setattr(os.path, "exists", lambda p: False if str(p).endswith("libdfot_hip.so") else real_exists(p))
+    with pytest.raises(ImportError, match="no CPU fallback"):
+        spec.loader.exec_module(mod)
+
+
+def test_backbone_refuses_to_run_without_a_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import dfot_amd
+    cfg = dict(channels=[128, 256, 576, 1152], emb_channels=1024, num_updown_blocks=[1, 1, 1], num_mid_blocks=1,
+               num_heads=9, conditioning=dict(dim=180))
+    with pytest.raises(dfot_amd.capi.DfotError):
+        dfot_amd.UViT3DPose(cfg, x_shape=(3, 64, 64), max_tokens=8)
