@@ -82,6 +82,8 @@ class UViT3DPose(nn.Module):
             self._names.append(name)
         self._synced: Optional[Tuple] = None
         self._reserved = 0
+        self._cond_key = None
+        self._cond_refs = None
 
     # ------------------------------------------------------------------ module tree
     def _register(self, name: str, shape: Tuple[int, ...]) -> None:
@@ -180,6 +182,7 @@ class UViT3DPose(nn.Module):
             torch.cuda.synchronize()
             capi.check(capi.lib.dfot_uvit_reserve(self._handle, int(batch)))
             self._reserved = batch
+            self._cond_key = None
 
     # ------------------------------------------------------------------ forward
     def forward(self, x: torch.Tensor, noise_levels: torch.Tensor, external_cond: Optional[torch.Tensor] = None,
@@ -200,11 +203,19 @@ class UViT3DPose(nn.Module):
         self.reserve(b)
         xf = x.detach().to(torch.float32).contiguous()
         kf = noise_levels.detach().to(torch.float32).contiguous()
-        cf = external_cond.detach().to(torch.float32).contiguous()
-        mf = None if external_cond_mask is None else external_cond_mask.to(torch.uint8).contiguous()
+        # the pose caches are rebuilt only when the conditioning tensors change (the sampler passes the same
+        # tensors for all DDIM steps of a window)
+        key = (external_cond.data_ptr(), external_cond._version, tuple(external_cond.shape), self._synced,
+               None if external_cond_mask is None else (external_cond_mask.data_ptr(), external_cond_mask._version))
+        if key != self._cond_key:
+            cf = external_cond.detach().to(torch.float32).contiguous()
+            mf = None if external_cond_mask is None else external_cond_mask.to(torch.uint8).contiguous()
+            capi.check(capi.lib.dfot_uvit_set_conditions(self._handle, capi.ptr(cf), capi.ptr(mf), b, capi.stream_ptr()))
+            self._cond_key = key
+            self._cond_refs = (external_cond, external_cond_mask)  # keep the keyed tensors alive
         out = torch.empty_like(xf)
-        capi.check(capi.lib.dfot_uvit_forward(self._handle, capi.ptr(xf), capi.ptr(kf), capi.ptr(cf), capi.ptr(mf),
-                                              capi.ptr(out), b, capi.stream_ptr()))
+        capi.check(capi.lib.dfot_uvit_forward_cached(self._handle, capi.ptr(xf), capi.ptr(kf), capi.ptr(out), b,
+                                                     capi.stream_ptr()))
         return out.to(x.dtype)
 
     def read_tap(self, name: str, channels: int, level: int, batch: int) -> torch.Tensor:

@@ -47,6 +47,8 @@ SIGNATURES = {
     "dfot_uvit_set_option": (_I, [_P, C.c_char_p, _I]),
     "dfot_uvit_attn_timing": (_I, [_P, C.POINTER(C.c_double), C.POINTER(_L)]),
     "dfot_uvit_forward": (_I, [_P, _P, _P, _P, _P, _P, _I, _P]),
+    "dfot_uvit_set_conditions": (_I, [_P, _P, _P, _I, _P]),
+    "dfot_uvit_forward_cached": (_I, [_P, _P, _P, _P, _I, _P]),
     "dfot_uvit_read_tap": (_I, [_P, C.c_char_p, _P, C.c_size_t, _P]),
     "dfot_ray_encode": (_I, [_P, _P, _I, _I, _I, _P]),
     "dfot_hg_prepare": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _L, _P]),

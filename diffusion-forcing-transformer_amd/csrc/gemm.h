@@ -5,7 +5,7 @@
 namespace dfot {
 
 enum AMode { A_DENSE = 0, A_CONV3 = 1 };
-enum Epi { E_F32 = 0, E_BF16 = 1, E_QKV = 2, E_FILM_GN = 3, E_FILM_RMS = 4, E_POSE = 5 };
+enum Epi { E_F32 = 0, E_BF16 = 1, E_QKV = 2 };
 
 struct GemmArgs {
   // operands: A [M][K] bf16 (dense: row stride lda; conv: NHWC image [BT][H][Wd][Cin], K = 9*Cin tap-major)
@@ -24,19 +24,6 @@ struct GemmArgs {
   bf16* out2 = nullptr;          // E_QKV: columns >= split -> silu -> out2[m][col-split]
   long ldo2 = 0;
   int split = 0;
-  const bf16* h_bf16 = nullptr;  // E_FILM_GN: tensor being normalised [M][ldh]
-  const float* x_f32 = nullptr;  // E_FILM_RMS: tensor being normalised [M][ldh]
-  long ldh = 0;
-  const float* gn_sums = nullptr;  // [BT][32][2] (mean, rstd)
-  const float* gamma = nullptr;    // GN gamma / RMS weight, [C]
-  const float* beta = nullptr;     // GN beta
-  int rows_per_bt = 0;
-  int C = 0;
-  float eps = 1e-6f;
-  const float* rstd = nullptr;     // [M]
-  const float* nemb = nullptr;     // E_POSE: [BT][N]
-  const uint8_t* cond_mask = nullptr;
-  int rows_per_batch = 0;
 };
 
 // returns DFOT_OK / error; validates the divisibility contract before launching

@@ -20,12 +20,6 @@ constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int STAGE_BYTES = (BM + BN) * BK * 2;  // 32 KiB
 constexpr int A_BYTES = BM * BK * 2;
 
-template <int AMODE>
-struct RowSrc {
-  const bf16* ptr[4];  // dense: row base (+swizzled chunk); conv: pixel base of the centre tap
-  int y[4], x[4];
-};
-
 template <int AMODE, int EPI, bool DMA>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -163,49 +157,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 
   // ---- epilogue ----
   const int colq = lane & 15, rowq = (lane >> 4) * 4;
-  if constexpr (EPI == E_FILM_GN || EPI == E_FILM_RMS) {
-    // columns of this wave: [scale ch 0..31 | shift ch 0..31] of channel group (n0 + wn*64)/64
-    const int cgrp = (n0 + wn * 64) >> 6;
-    if (n0 + wn * 64 < g.N) {
-#pragma unroll
-      for (int ni = 0; ni < 2; ++ni) {
-        const int c = cgrp * 32 + ni * 16 + colq;
-        const int col_scale = n0 + wn * 64 + ni * 16 + colq;
-        const int col_shift = col_scale + 32;
-        const float b_scale = g.bias[col_scale], b_shift = g.bias[col_shift];
-        float na, nb;
-        if constexpr (EPI == E_FILM_GN) {
-          const int bt = m0 / g.rows_per_bt;
-          const int grp = c / (g.C / 32);
-          const float mean = g.gn_sums[(bt * 32 + grp) * 2 + 0], rs = g.gn_sums[(bt * 32 + grp) * 2 + 1];
-          na = rs * g.gamma[c];
-          nb = g.beta[c] - mean * na;
-        } else {
-          na = g.gamma[c];
-          nb = 0.f;
-        }
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi) {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const long m = (long)m0 + wm * 64 + mi * 16 + rowq + j;
-            const float scale = acc[mi][ni][j] + b_scale;
-            const float shift = acc[mi][ni + 2][j] + b_shift;
-            float y;
-            if constexpr (EPI == E_FILM_GN) {
-              const float hv = bf2f(g.h_bf16[m * g.ldh + c]);
-              y = silu_f((hv * na + nb) * (1.f + scale) + shift);
-            } else {
-              const float xv = g.x_f32[m * g.ldh + c];
-              // RMSNorm output is rounded to the activation dtype before the gain (normalization.py:52-53)
-              y = (xv * g.rstd[m]) * na * (1.f + scale) + shift;
-            }
-            g.out_bf16[m * g.ldo + c] = f2bf(y);
-          }
-        }
-      }
-    }
-  } else {
+  {
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) {
       const int col = n0 + wn * 64 + ni * 16 + colq;
@@ -228,11 +180,6 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
             } else {
               g.out2[m * g.ldo2 + (col - g.split)] = f2bf(silu_f(v));
             }
-          } else if constexpr (EPI == E_POSE) {
-            const int bt = (int)(m / g.rows_per_bt);
-            const int b = (int)(m / g.rows_per_batch);
-            const float keep = (g.cond_mask && g.cond_mask[b]) ? 0.f : 1.f;
-            g.out_bf16[m * g.ldo + col] = f2bf(v * keep + g.nemb[(long)bt * g.N + col]);
           }
         }
       }
@@ -270,18 +217,11 @@ int launch_gemm(int amode, int epi, bool lds_dma, const GemmArgs& g, hipStream_t
     DFOT_REQUIRE(g.zeros != nullptr, DFOT_ERR_ARG, "conv3x3: zero page missing");
     DFOT_REQUIRE(g.H > 0 && g.Wd > 0 && g.M % (g.H * g.Wd) == 0, DFOT_ERR_SHAPE, "conv3x3: M=%d not a whole number of %dx%d images", g.M, g.H, g.Wd);
   }
-  if (epi == E_FILM_GN || epi == E_FILM_RMS) {
-    DFOT_REQUIRE(g.N == 2 * g.C && g.C % 32 == 0, DFOT_ERR_SHAPE, "film: N=%d must be 2*C, C=%d %% 32 == 0", g.N, g.C);
-    DFOT_REQUIRE(epi == E_FILM_RMS || (g.rows_per_bt % BM == 0), DFOT_ERR_SHAPE, "film: rows per image %d must be a multiple of %d", g.rows_per_bt, BM);
-  }
   if (amode == A_DENSE) {
     switch (epi) {
       case E_F32: return launch_d<A_DENSE, E_F32>(lds_dma, g, stream);
       case E_BF16: return launch_d<A_DENSE, E_BF16>(lds_dma, g, stream);
       case E_QKV: return launch_d<A_DENSE, E_QKV>(lds_dma, g, stream);
-      case E_FILM_GN: return launch_d<A_DENSE, E_FILM_GN>(lds_dma, g, stream);
-      case E_FILM_RMS: return launch_d<A_DENSE, E_FILM_RMS>(lds_dma, g, stream);
-      case E_POSE: return launch_d<A_DENSE, E_POSE>(lds_dma, g, stream);
     }
   } else if (amode == A_CONV3) {
     switch (epi) {

@@ -20,7 +20,20 @@ int launch_gn_stats_bf16(const bf16* x, float* partial, float* stats, int bt, in
 int gn_partial_blocks(int pixels);
 int launch_gn_apply_silu(const float* x, const float* stats, const float* gamma, const float* beta, bf16* out, int bt,
                          int pixels, int c, hipStream_t s);
-int launch_rms_stats(const float* x, float* rstd, long m, int c, float eps, hipStream_t s);
+// FiLM with the per-window pose cache (see kernels.hip). One FilmChunk per 64 rows of every FiLM projection:
+struct FilmChunk {
+  const bf16* w;   // &W_film[row0][0], row stride = emb dim
+  const float* b;  // &bias[row0]
+  long out_off;    // sv element (bt, r) of this chunk lives at out_off + bt*rows + r
+  int rows;        // 2C of the owning block
+};
+int launch_film_vec(const FilmChunk* table, int chunks, const float* nemb, float* sv, int bt, int e, hipStream_t s);
+int launch_gn_film_silu(const bf16* h, const float* stats, const float* gamma, const float* beta, const bf16* fcache,
+                        const float* sv, const uint8_t* cond_mask, bf16* out, int bt, int pixels, int c, int tokens,
+                        hipStream_t s);
+int launch_rms_film(const float* x, const float* w, const bf16* fcache, const float* sv, const uint8_t* cond_mask, bf16* out,
+                    long m, int c, int rows_per_bt, int tokens, float eps, hipStream_t s);
+
 int launch_qk_norm_rope(const bf16* qkv, const float* qw, const float* kw, const float* cs, bf16* q, bf16* k, bf16* v,
                         int batch, int n, int heads, int d, float qscale, float eps, hipStream_t s);
 // ---- resampling / skips ----

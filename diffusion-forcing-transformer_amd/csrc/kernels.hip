@@ -342,24 +342,162 @@ int launch_gn_apply_silu(const float* x, const float* stats, const float* gamma,
   return DFOT_OK;
 }
 
-// RMS statistics: rstd[m] = rsqrt(mean(x[m,:]^2) + eps); one wave per row
-__global__ __launch_bounds__(256) void rms_stats_kernel(const float* __restrict__ x, float* __restrict__ rstd, long m, int c,
-                                                        float eps) {
+// --------------------------------------------------------------------------------------------
+// FiLM conditioning with the pose term cached per window.
+//   emb = noise_emb[bt] (per frame) + pose_emb[pixel] (constant over the DDIM steps, zero when the video's
+//   external_cond_mask is set), and emb_layer is linear, so
+//   (scale|shift)[m] = F[m] + sv[bt],  F = W_film * pose_emb (cached bf16, [M][2C]),  sv = W_film * noise_emb + b.
+// Column order of F / sv: within each 64-column group, 32 scale columns then the 32 matching shift columns
+// (the row permutation applied to W_film at load time), so 8 consecutive channels read two 16-byte chunks.
+// --------------------------------------------------------------------------------------------
+
+// sv for every FiLM projection of the model in ONE launch (FilmChunk table: kernels.h)
+__global__ __launch_bounds__(256) void film_vec_kernel(const FilmChunk* __restrict__ table, const float* __restrict__ nemb,
+                                                       float* __restrict__ sv, int e) {
+  const FilmChunk ck = table[blockIdx.x];
+  const int bt = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float* ne = nemb + (long)bt * e;
+  for (int r = wave * 16; r < wave * 16 + 16; ++r) {
+    const bf16* wr = ck.w + (long)r * e;
+    float acc = 0.f;
+    for (int i = lane * 8; i < e; i += 512) {
+      const bf16x8 wv = *reinterpret_cast<const bf16x8*>(wr + i);
+      const float4v a = *reinterpret_cast<const float4v*>(ne + i);
+      const float4v b = *reinterpret_cast<const float4v*>(ne + i + 4);
+      acc += bf2f(wv[0]) * a[0] + bf2f(wv[1]) * a[1] + bf2f(wv[2]) * a[2] + bf2f(wv[3]) * a[3] + bf2f(wv[4]) * b[0] +
+             bf2f(wv[5]) * b[1] + bf2f(wv[6]) * b[2] + bf2f(wv[7]) * b[3];
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) sv[ck.out_off + (long)bt * ck.rows + r] = acc + ck.b[r];
+  }
+}
+int launch_film_vec(const FilmChunk* table, int chunks, const float* nemb, float* sv, int bt, int e, hipStream_t s) {
+  DFOT_REQUIRE(e % 8 == 0, DFOT_ERR_SHAPE, "film_vec: emb dim %d must be a multiple of 8", e);
+  hipLaunchKernelGGL(film_vec_kernel, dim3(chunks, bt), dim3(256), 0, s, table, nemb, sv, e);
+  DFOT_CHECK_HIP(hipGetLastError());
+  return DFOT_OK;
+}
+
+// ResBlock: out = SiLU( GroupNorm(h) * (1 + scale) + shift ), bf16 in/out; thread = 8 channels of one pixel
+__global__ void gn_film_silu_kernel(const bf16* __restrict__ h, const float* __restrict__ stats,
+                                    const float* __restrict__ gamma, const float* __restrict__ beta,
+                                    const bf16* __restrict__ fcache, const float* __restrict__ sv,
+                                    const uint8_t* __restrict__ cond_mask, bf16* __restrict__ out, long total8, int pixels,
+                                    int c, int tokens) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total8) return;
+  const int c8 = (int)(idx % (c / 8));
+  const long pix = idx / (c / 8);
+  const int bt = (int)(pix / pixels);
+  const int cpg = c / 32;
+  const int c0 = c8 * 8;
+  const int col = (c0 >> 5) * 64 + (c0 & 31);  // scale columns col..col+7, shift columns col+32..col+39
+  const bf16x8 hv = *reinterpret_cast<const bf16x8*>(h + pix * c + c0);
+  const float* svp = sv + (long)bt * 2 * c + col;
+  float sc[8], sh[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    sc[j] = svp[j];
+    sh[j] = svp[32 + j];
+  }
+  const bool use_pose = !(cond_mask && cond_mask[bt / tokens]);
+  if (use_pose) {
+    const bf16x8 fs = *reinterpret_cast<const bf16x8*>(fcache + pix * 2 * c + col);
+    const bf16x8 fh = *reinterpret_cast<const bf16x8*>(fcache + pix * 2 * c + col + 32);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      sc[j] += bf2f(fs[j]);
+      sh[j] += bf2f(fh[j]);
+    }
+  }
+  bf16x8 o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int ch = c0 + j;
+    const int g = ch / cpg;
+    const float mean = stats[(bt * 32 + g) * 2], rs = stats[(bt * 32 + g) * 2 + 1];
+    const float y = ((bf2f(hv[j]) - mean) * rs * gamma[ch] + beta[ch]) * (1.f + sc[j]) + sh[j];
+    o[j] = f2bf(silu_f(y));
+  }
+  *reinterpret_cast<bf16x8*>(out + pix * c + c0) = o;
+}
+int launch_gn_film_silu(const bf16* h, const float* stats, const float* gamma, const float* beta, const bf16* fcache,
+                        const float* sv, const uint8_t* cond_mask, bf16* out, int bt, int pixels, int c, int tokens,
+                        hipStream_t s) {
+  const long total8 = (long)bt * pixels * (c / 8);
+  hipLaunchKernelGGL(gn_film_silu_kernel, dim3(cdiv(total8, 256)), dim3(256), 0, s, h, stats, gamma, beta, fcache, sv,
+                     cond_mask, out, total8, pixels, c, tokens);
+  DFOT_CHECK_HIP(hipGetLastError());
+  return DFOT_OK;
+}
+
+// TransformerBlock: xn = RMSNorm(x) * w * (1 + scale) + shift, fp32 stream in -> bf16 out; one wave per token
+template <int MAXCH>
+__global__ __launch_bounds__(256) void rms_film_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                       const bf16* __restrict__ fcache, const float* __restrict__ sv,
+                                                       const uint8_t* __restrict__ cond_mask, bf16* __restrict__ out,
+                                                       long m, int c, int rows_per_bt, int tokens, float eps) {
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= m) return;
   const int lane = threadIdx.x & 63;
+  const int nch = c / 8;
   const float* src = x + row * c;
+  float v[MAXCH][8];
   float ss = 0.f;
-  for (int i = lane; i < c / 4; i += 64) {
-    const float4v v = *reinterpret_cast<const float4v*>(src + i * 4);
-    ss += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+#pragma unroll
+  for (int k = 0; k < MAXCH; ++k) {
+    const int ch = lane + 64 * k;
+    if (ch < nch) {
+      const float4v a = *reinterpret_cast<const float4v*>(src + ch * 8);
+      const float4v b = *reinterpret_cast<const float4v*>(src + ch * 8 + 4);
+      v[k][0] = a[0]; v[k][1] = a[1]; v[k][2] = a[2]; v[k][3] = a[3];
+      v[k][4] = b[0]; v[k][5] = b[1]; v[k][6] = b[2]; v[k][7] = b[3];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) ss += v[k][j] * v[k][j];
+    }
   }
   ss = wave_sum(ss);
-  if (lane == 0) rstd[row] = rsqrtf(ss / (float)c + eps);
+  const float rs = rsqrtf(ss / (float)c + eps);
+  const int bt = (int)(row / rows_per_bt);
+  const bool use_pose = !(cond_mask && cond_mask[bt / tokens]);
+#pragma unroll
+  for (int k = 0; k < MAXCH; ++k) {
+    const int ch = lane + 64 * k;
+    if (ch < nch) {
+      const int c0 = ch * 8;
+      const int col = (c0 >> 5) * 64 + (c0 & 31);
+      const float* svp = sv + (long)bt * 2 * c + col;
+      float sc[8], sh[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        sc[j] = svp[j];
+        sh[j] = svp[32 + j];
+      }
+      if (use_pose) {
+        const bf16x8 fs = *reinterpret_cast<const bf16x8*>(fcache + row * 2 * c + col);
+        const bf16x8 fh = *reinterpret_cast<const bf16x8*>(fcache + row * 2 * c + col + 32);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          sc[j] += bf2f(fs[j]);
+          sh[j] += bf2f(fh[j]);
+        }
+      }
+      bf16x8 o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = f2bf(v[k][j] * rs * w[c0 + j] * (1.f + sc[j]) + sh[j]);
+      *reinterpret_cast<bf16x8*>(out + row * c + c0) = o;
+    }
+  }
 }
-
-int launch_rms_stats(const float* x, float* rstd, long m, int c, float eps, hipStream_t s) {
-  hipLaunchKernelGGL(rms_stats_kernel, dim3(cdiv(m, 4)), dim3(256), 0, s, x, rstd, m, c, eps);
+int launch_rms_film(const float* x, const float* w, const bf16* fcache, const float* sv, const uint8_t* cond_mask, bf16* out,
+                    long m, int c, int rows_per_bt, int tokens, float eps, hipStream_t s) {
+  DFOT_REQUIRE(c % 8 == 0 && c <= 8 * 64 * 3, DFOT_ERR_SHAPE, "rms_film: channels %d unsupported", c);
+  if (c <= 8 * 64 * 2)
+    hipLaunchKernelGGL(rms_film_kernel<2>, dim3(cdiv(m, 4)), dim3(256), 0, s, x, w, fcache, sv, cond_mask, out, m, c,
+                       rows_per_bt, tokens, eps);
+  else
+    hipLaunchKernelGGL(rms_film_kernel<3>, dim3(cdiv(m, 4)), dim3(256), 0, s, x, w, fcache, sv, cond_mask, out, m, c,
+                       rows_per_bt, tokens, eps);
   DFOT_CHECK_HIP(hipGetLastError());
   return DFOT_OK;
 }

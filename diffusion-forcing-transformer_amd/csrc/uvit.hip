@@ -33,12 +33,16 @@ const char* get_error() { return g_err; }
 // ------------------------------------------------------------------------------------------
 struct ResW {
   int c = 0;
+  bf16* fcache = nullptr;  // per-window cache of W_film * pose_emb, [BT*P][2C]
+  long sv_off = 0;
   bf16 *w_film = nullptr, *w1 = nullptr, *w2 = nullptr;
   float *b_film_raw = nullptr, *b_film = nullptr, *g1 = nullptr, *be1 = nullptr, *bias1 = nullptr, *g2 = nullptr,
         *be2 = nullptr, *bias2 = nullptr;
 };
 struct TrW {
   int c = 0;
+  bf16* fcache = nullptr;
+  long sv_off = 0;
   bf16 *w_film = nullptr, *w_fused = nullptr, *w_out = nullptr;
   float *b_film_raw = nullptr, *b_film = nullptr, *nw = nullptr, *b_fused = nullptr, *qw = nullptr, *kw = nullptr,
         *b_attn = nullptr, *b_mlp = nullptr, *b_out = nullptr;
@@ -86,7 +90,12 @@ struct dfot_uvit_s {
   size_t ws_bytes = 0;
   std::vector<void*> ws_owned;
   float *nemb = nullptr, *nhid = nullptr, *X[4] = {nullptr, nullptr, nullptr, nullptr}, *HSA[3] = {nullptr, nullptr, nullptr}, *tmp = nullptr,
-        *gn_partial = nullptr, *gn_stats = nullptr, *rstd = nullptr;
+        *gn_partial = nullptr, *gn_stats = nullptr, *sv = nullptr;
+  FilmChunk* film_table = nullptr;
+  int film_chunks = 0;
+  uint8_t* cond_mask = nullptr;  // device copy of the external_cond_mask of the cached conditions
+  bool have_mask = false;
+  int cond_batch = 0;            // batch the pose caches were built for (0 = none)
   bf16 *acond = nullptr, *emb[4] = {nullptr, nullptr, nullptr, nullptr}, *s1 = nullptr, *hbf = nullptr, *qkv = nullptr,
        *cat = nullptr, *q = nullptr, *k = nullptr, *v = nullptr;
   int last_batch = 0;
@@ -346,11 +355,9 @@ static int run_res_block(dfot_uvit_s* h, const ResW& w, int lvl, int bt, hipStre
   g.bias = w.bias1; g.out_bf16 = h->hbf; g.ldo = c;
   if ((rc = launch_gemm(A_CONV3, E_BF16, h->use_dma, g, s))) return rc;
   if ((rc = launch_gn_stats_bf16(h->hbf, h->gn_partial, h->gn_stats, bt, pix, c, h->cfg.eps, s))) return rc;
-  GemmArgs f;
-  f.A = h->emb[lvl]; f.lda = h->E; f.W = w.w_film; f.M = m; f.N = 2 * c; f.K = h->E; f.bias = w.b_film;
-  f.h_bf16 = h->hbf; f.ldh = c; f.gn_sums = h->gn_stats; f.gamma = w.g2; f.beta = w.be2; f.rows_per_bt = pix; f.C = c;
-  f.eps = h->cfg.eps; f.out_bf16 = h->s1; f.ldo = c;
-  if ((rc = launch_gemm(A_DENSE, E_FILM_GN, h->use_dma, f, s))) return rc;
+  if ((rc = launch_gn_film_silu(h->hbf, h->gn_stats, w.g2, w.be2, w.fcache, h->sv + w.sv_off,
+                                h->have_mask ? h->cond_mask : nullptr, h->s1, bt, pix, c, h->T, s)))
+    return rc;
   GemmArgs o;
   o.A = h->s1; o.W = w.w2; o.M = m; o.N = c; o.K = 9 * c; o.H = rr; o.Wd = rr; o.Cin = c; o.zeros = h->zeros;
   o.bias = w.bias2; o.out_f32 = x; o.resid = x; o.ldo = c;
@@ -362,11 +369,9 @@ static int run_tr_block(dfot_uvit_s* h, const TrW& w, int lvl, int batch, hipStr
   const int m = batch * n;
   float* x = h->X[lvl];
   int rc = 0;
-  if ((rc = launch_rms_stats(x, h->rstd, m, c, h->cfg.eps, s))) return rc;
-  GemmArgs f;
-  f.A = h->emb[lvl]; f.lda = h->E; f.W = w.w_film; f.M = m; f.N = 2 * c; f.K = h->E; f.bias = w.b_film;
-  f.x_f32 = x; f.ldh = c; f.rstd = h->rstd; f.gamma = w.nw; f.C = c; f.out_bf16 = h->s1; f.ldo = c;
-  if ((rc = launch_gemm(A_DENSE, E_FILM_RMS, h->use_dma, f, s))) return rc;
+  if ((rc = launch_rms_film(x, w.nw, w.fcache, h->sv + w.sv_off, h->have_mask ? h->cond_mask : nullptr, h->s1, m, c,
+                            rr * rr, h->T, h->cfg.eps, s)))
+    return rc;
   GemmArgs p;
   p.A = h->s1; p.lda = c; p.W = w.w_fused; p.M = m; p.N = 7 * c; p.K = c; p.bias = w.b_fused;
   p.out_bf16 = h->qkv; p.ldo = 3 * c; p.out2 = h->cat + c; p.ldo2 = 5 * c; p.split = 3 * c;
@@ -534,7 +539,33 @@ int dfot_uvit_reserve(dfot_uvit_t h, int max_batch) {
     mtr = std::max(mtr, bt * pix[l]);
     mc = std::max(mc, bt * pix[l] * h->ch[l]);
   }
-  if ((rc = dev_alloc(h, &h->rstd, mtr, true))) return rc;
+  (void)mtr;
+  // per-window FiLM caches + per-frame FiLM vectors + the chunk table of film_vec_kernel
+  {
+    std::vector<FilmChunk> table;
+    long sv_off = 0;
+    auto add = [&](bf16** fc, long* off, const bf16* wf, const float* bf_, int c, int lvl) -> int {
+      int r2 = dev_alloc(h, fc, bt * pix[lvl] * 2 * c, true);
+      if (r2) return r2;
+      *off = sv_off;
+      for (int r0 = 0; r0 < 2 * c; r0 += 64) table.push_back(FilmChunk{wf + (long)r0 * h->E, bf_ + r0, sv_off + r0, 2 * c});
+      sv_off += (long)bt * 2 * c;
+      return DFOT_OK;
+    };
+    for (int l = 0; l < 2; ++l) {
+      for (ResW& w : h->down_res[l]) if ((rc = add(&w.fcache, &w.sv_off, w.w_film, w.b_film, w.c, l))) return rc;
+      for (ResW& w : h->up_res[l]) if ((rc = add(&w.fcache, &w.sv_off, w.w_film, w.b_film, w.c, l))) return rc;
+    }
+    for (TrW& w : h->down_tr) if ((rc = add(&w.fcache, &w.sv_off, w.w_film, w.b_film, w.c, 2))) return rc;
+    for (TrW& w : h->up_tr) if ((rc = add(&w.fcache, &w.sv_off, w.w_film, w.b_film, w.c, 2))) return rc;
+    for (TrW& w : h->mid_tr) if ((rc = add(&w.fcache, &w.sv_off, w.w_film, w.b_film, w.c, 3))) return rc;
+    if ((rc = dev_alloc(h, &h->sv, (size_t)sv_off, true))) return rc;
+    if ((rc = dev_alloc(h, &h->film_table, table.size(), true))) return rc;
+    DFOT_CHECK_HIP(hipMemcpy(h->film_table, table.data(), table.size() * sizeof(FilmChunk), hipMemcpyHostToDevice));
+    h->film_chunks = (int)table.size();
+    if ((rc = dev_alloc(h, &h->cond_mask, (size_t)max_batch, true))) return rc;
+    h->cond_batch = 0;
+  }
   if ((rc = dev_alloc(h, &h->qkv, mc * 3, true))) return rc;
   if ((rc = dev_alloc(h, &h->cat, mc * 5, true))) return rc;
   if ((rc = dev_alloc(h, &h->q, mc, true))) return rc;
@@ -584,30 +615,60 @@ int dfot_uvit_set_option(dfot_uvit_t h, const char* key, int value) {
   return DFOT_OK;
 }
 
-int dfot_uvit_forward(dfot_uvit_t h, const float* x, const float* noise_levels, const float* external_cond,
-                      const uint8_t* external_cond_mask, float* out, int batch, void* stream) {
-  DFOT_REQUIRE(h && x && noise_levels && out, DFOT_ERR_ARG, "forward: null argument");
+int dfot_uvit_set_conditions(dfot_uvit_t h, const float* external_cond, const uint8_t* external_cond_mask, int batch,
+                             void* stream) {
+  DFOT_REQUIRE(h, DFOT_ERR_ARG, "set_conditions: null handle");
   DFOT_REQUIRE(external_cond != nullptr, DFOT_ERR_ARG, "External condition (camera pose) is required for U-ViT3DPose model.");
-  DFOT_REQUIRE(h->finalized, DFOT_ERR_STATE, "forward: weights not finalized");
-  DFOT_REQUIRE(batch > 0 && batch <= h->max_batch, DFOT_ERR_STATE, "forward: batch %d exceeds reserved %d", batch, h->max_batch);
+  DFOT_REQUIRE(h->finalized, DFOT_ERR_STATE, "set_conditions: weights not finalized");
+  DFOT_REQUIRE(batch > 0 && batch <= h->max_batch, DFOT_ERR_STATE, "set_conditions: batch %d exceeds reserved %d", batch, h->max_batch);
   hipStream_t s = (hipStream_t)stream;
   const dfot_uvit_config& c = h->cfg;
   const int bt = batch * h->T, e = h->E;
   int rc = 0;
-  if ((rc = launch_noise_emb(noise_levels, h->ne_freqs, h->ne_phases, h->ne_w1, h->ne_b1, h->ne_w2, h->ne_b2, h->nhid, h->nemb, bt,
-                             c.noise_dim, e, s)))
-    return rc;
-  if ((rc = launch_embed_input(x, h->ein_w, h->ein_b, h->X[0], bt, c.resolution, c.in_channels, h->ch[0], s))) return rc;
+  h->cond_batch = 0;
+  // pose patch-embed (+bias), then its average-pool pyramid: the pose half of `emb` at every level
   if ((rc = launch_cond_repack(external_cond, h->acond, bt, c.resolution, c.cond_dim, h->kpose, s))) return rc;
   {
-    const int pix0 = h->r[0] * h->r[0];
     GemmArgs g;
-    g.A = h->acond; g.lda = h->kpose; g.W = h->pose_w; g.M = bt * pix0; g.N = e; g.K = h->kpose; g.bias = h->pose_b;
-    g.out_bf16 = h->emb[0]; g.ldo = e; g.nemb = h->nemb; g.cond_mask = external_cond_mask; g.rows_per_bt = pix0;
-    g.rows_per_batch = pix0 * h->T;
-    if ((rc = launch_gemm(A_DENSE, E_POSE, h->use_dma, g, s))) return rc;
+    g.A = h->acond; g.lda = h->kpose; g.W = h->pose_w; g.M = bt * h->r[0] * h->r[0]; g.N = e; g.K = h->kpose;
+    g.bias = h->pose_b; g.out_bf16 = h->emb[0]; g.ldo = e;
+    if ((rc = launch_gemm(A_DENSE, E_BF16, h->use_dma, g, s))) return rc;
   }
   if ((rc = launch_emb_pyramid(h->emb[0], h->emb[1], h->emb[2], h->emb[3], bt, h->r[0], e, s))) return rc;
+  // every block's FiLM projection of the pose term: F = W_film * pose_emb  (no bias; it lives in sv)
+  auto fill = [&](bf16* fcache, const bf16* wf, int cc, int lvl) -> int {
+    GemmArgs g;
+    g.A = h->emb[lvl]; g.lda = e; g.W = wf; g.M = bt * h->r[lvl] * h->r[lvl]; g.N = 2 * cc; g.K = e;
+    g.out_bf16 = fcache; g.ldo = 2 * cc;
+    return launch_gemm(A_DENSE, E_BF16, h->use_dma, g, s);
+  };
+  for (int l = 0; l < 2; ++l) {
+    for (ResW& w : h->down_res[l]) if ((rc = fill(w.fcache, w.w_film, w.c, l))) return rc;
+    for (ResW& w : h->up_res[l]) if ((rc = fill(w.fcache, w.w_film, w.c, l))) return rc;
+  }
+  for (TrW& w : h->down_tr) if ((rc = fill(w.fcache, w.w_film, w.c, 2))) return rc;
+  for (TrW& w : h->up_tr) if ((rc = fill(w.fcache, w.w_film, w.c, 2))) return rc;
+  for (TrW& w : h->mid_tr) if ((rc = fill(w.fcache, w.w_film, w.c, 3))) return rc;
+  h->have_mask = external_cond_mask != nullptr;
+  if (h->have_mask) DFOT_CHECK_HIP(hipMemcpyAsync(h->cond_mask, external_cond_mask, batch, hipMemcpyDeviceToDevice, s));
+  h->cond_batch = batch;
+  return DFOT_OK;
+}
+
+int dfot_uvit_forward_cached(dfot_uvit_t h, const float* x, const float* noise_levels, float* out, int batch, void* stream) {
+  DFOT_REQUIRE(h && x && noise_levels && out, DFOT_ERR_ARG, "forward: null argument");
+  DFOT_REQUIRE(h->finalized, DFOT_ERR_STATE, "forward: weights not finalized");
+  DFOT_REQUIRE(batch > 0 && batch == h->cond_batch, DFOT_ERR_STATE,
+               "forward_cached: batch %d does not match the cached conditions (%d)", batch, h->cond_batch);
+  hipStream_t s = (hipStream_t)stream;
+  const dfot_uvit_config& c = h->cfg;
+  const int bt = batch * h->T, e = h->E;
+  int rc = 0;
+  if ((rc = launch_noise_emb(noise_levels, h->ne_freqs, h->ne_phases, h->ne_w1, h->ne_b1, h->ne_w2, h->ne_b2, h->nhid,
+                             h->nemb, bt, c.noise_dim, e, s)))
+    return rc;
+  if ((rc = launch_film_vec(h->film_table, h->film_chunks, h->nemb, h->sv, bt, e, s))) return rc;
+  if ((rc = launch_embed_input(x, h->ein_w, h->ein_b, h->X[0], bt, c.resolution, c.in_channels, h->ch[0], s))) return rc;
 
   for (int l = 0; l < 2; ++l) {
     for (const ResW& w : h->down_res[l])
@@ -631,6 +692,14 @@ int dfot_uvit_forward(dfot_uvit_t h, const float* x, const float* noise_levels, 
   return launch_project_output(h->X[0], h->pout_w, h->pout_b, out, bt, c.resolution, h->ch[0], c.in_channels, s);
 }
 
+int dfot_uvit_forward(dfot_uvit_t h, const float* x, const float* noise_levels, const float* external_cond,
+                      const uint8_t* external_cond_mask, float* out, int batch, void* stream) {
+  DFOT_REQUIRE(h && x && noise_levels && out, DFOT_ERR_ARG, "forward: null argument");
+  int rc = dfot_uvit_set_conditions(h, external_cond, external_cond_mask, batch, stream);
+  if (rc) return rc;
+  return dfot_uvit_forward_cached(h, x, noise_levels, out, batch, stream);
+}
+
 int dfot_uvit_read_tap(dfot_uvit_t h, const char* name, float* out, size_t capacity, void* stream) {
   DFOT_REQUIRE(h && name && out, DFOT_ERR_ARG, "read_tap: null argument");
   DFOT_REQUIRE(h->last_batch > 0, DFOT_ERR_STATE, "read_tap: no forward has run");
@@ -639,7 +708,7 @@ int dfot_uvit_read_tap(dfot_uvit_t h, const char* name, float* out, size_t capac
   auto pixels = [&](int l) { return h->r[l] * h->r[l]; };
   struct Tap { const char* n; int lvl; int c; const float* f; const bf16* b; };
   const Tap taps[] = {
-      {"emb0", 0, h->E, nullptr, h->emb[0]}, {"down0", 1, h->ch[1], h->HSA[0], nullptr},
+      {"pose_emb0", 0, h->E, nullptr, h->emb[0]}, {"down0", 1, h->ch[1], h->HSA[0], nullptr},
       {"down1", 2, h->ch[2], h->HSA[1], nullptr}, {"down2", 3, h->ch[3], h->HSA[2], nullptr},
       {"mid", 3, h->ch[3], h->X[3], nullptr}, {"up2", 2, h->ch[2], h->X[2], nullptr},
       {"up1", 1, h->ch[1], h->X[1], nullptr}, {"up0", 0, h->ch[0], h->X[0], nullptr},

@@ -140,6 +140,7 @@ class DFoTVideoPoseSampler:
 
         cond_full = self._process_conditions(conditions)
         cond_rep, cond_nfe = None, 0
+        cmask_cache: Dict[bytes, torch.Tensor] = {}
         xs = xs.contiguous()
         s = capi.stream_ptr
         strict = bool(getattr(self.noise_fn, "strict_order", False))
@@ -185,7 +186,12 @@ class DFoTVideoPoseSampler:
                 cond_nfe = nfe
             cmask = None
             if plan.cond_masked is not None:
-                cmask = torch.from_numpy(np.tile(plan.cond_masked, batch_size)).cuda()
+                # one device tensor per distinct mask pattern: the backbone keys its per-window pose caches on
+                # the identity of (external_cond, external_cond_mask)
+                pattern = np.tile(plan.cond_masked, batch_size)
+                cmask = cmask_cache.get(pattern.tobytes())
+                if cmask is None:
+                    cmask = cmask_cache[pattern.tobytes()] = torch.from_numpy(pattern).cuda()
             v = self.model(x_in, tables[7], cond_rep, cmask)
             self.window_forwards += bm
             if strict:

@@ -90,7 +90,15 @@ int dfot_uvit_attn_timing(dfot_uvit_t h, double* total_ms, int64_t* launches);
  * Inputs are not modified. */
 int dfot_uvit_forward(dfot_uvit_t h, const float* x, const float* noise_levels, const float* external_cond,
                       const uint8_t* external_cond_mask, float* out, int batch, void* stream);
-/* debug/parity taps: copy an internal activation after the last forward (fp32). names: "emb0","down0","down1",
+/* The camera-pose conditioning of a window does not change across its DDIM steps (and is zero for masked
+ * videos), and every FiLM projection is linear in it.  dfot_uvit_set_conditions computes the pose patch-embedding,
+ * its pyramid and every block's FiLM projection of it ONCE; dfot_uvit_forward_cached then runs the backbone for the
+ * cached conditions (batch must match).  dfot_uvit_forward == set_conditions + forward_cached. */
+int dfot_uvit_set_conditions(dfot_uvit_t h, const float* external_cond, const uint8_t* external_cond_mask, int batch,
+                             void* stream);
+int dfot_uvit_forward_cached(dfot_uvit_t h, const float* x, const float* noise_levels, float* out, int batch,
+                             void* stream);
+/* debug/parity taps: copy an internal activation after the last forward (fp32). names: "pose_emb0","down0","down1",
  * "down2","mid","up2","up1","up0" in the oracle's NCHW layout. */
 int dfot_uvit_read_tap(dfot_uvit_t h, const char* name, float* out, size_t capacity_floats, void* stream);
 

@@ -58,7 +58,7 @@ def test_backbone_vs_golden_and_oracle_taps(w64, dma, variant):
     with torch.no_grad():
         v = model(w64["x"].cuda(), w64["k"].cuda(), w64["cond"].cuda(), w64["mask"].cuda()).cpu()
     ocfg, taps = w64["ocfg"], w64["taps"]
-    spec = [("emb0", ocfg.emb_channels, 0), ("down0", ocfg.channels[1], 1), ("down1", ocfg.channels[2], 2),
+    spec = [("down0", ocfg.channels[1], 1), ("down1", ocfg.channels[2], 2),
             ("down2", ocfg.channels[3], 3), ("mid", ocfg.channels[3], 3), ("up2", ocfg.channels[2], 2),
             ("up1", ocfg.channels[1], 1), ("up0", ocfg.channels[0], 0)]
     for name, ch, lvl in spec:
