@@ -188,6 +188,188 @@ __global__ __launch_bounds__(256) void attn_kernel(const bf16* __restrict__ Q, c
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Tuned variant (default).  Same products and layouts as attn_kernel above, plus:
+//  * K/V tiles go global -> LDS by LDS-DMA (global_load_lds_dwordx4); the bank swizzles are involutions applied to
+//    the per-lane SOURCE chunk, so the reads above stay valid; no staging registers, no ds_write pass;
+//  * the running max is folded into the MFMA: the S^T accumulator starts at -m (per query column, lane-local),
+//    so the product leaves s - m ready and exp2 needs no subtract;
+//  * deferred rescale (threshold 8 in the log2 domain): O, l are rescaled only when some query's max grows by
+//    more than 2^8 -- the branch is wave-uniform; P is then bounded by 256, exact enough for bf16 P / fp32 sums;
+//  * row max via v_max3.
+// ---------------------------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(256) void attn_kernel_v2(const bf16* __restrict__ Q, const bf16* __restrict__ K,
+                                                      const bf16* __restrict__ V, bf16* __restrict__ O, long ldo, int N,
+                                                      int heads) {
+  using C = AttnCfg<D>;
+  constexpr float THR = 8.0f;
+  constexpr int RPI = 1024 / C::ROWB;           // rows covered by one 1-KiB DMA instruction (8 or 4)
+  constexpr int IPW = (C::TILE / 1024) / 4;     // DMA instructions per wave per tile (2 or 4)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lq = lane & 31, lh = lane >> 5;
+  const int bh = blockIdx.y;
+  const long base = (long)bh * N * D;
+  const int q0 = blockIdx.x * 128 + wave * 32;
+  const bf16* Qb = Q + base;
+  const bf16* Kb = K + base;
+  const bf16* Vb = V + base;
+
+  bf16x8 qf[D / 16];
+#pragma unroll
+  for (int ks = 0; ks < D / 16; ++ks)
+    qf[ks] = *reinterpret_cast<const bf16x8*>(Qb + (long)(q0 + lq) * D + ks * 16 + lh * 8);
+
+  // per-lane DMA source offsets (elements) within a tile: LDS position (row, pos) receives source chunk swz(row,pos)
+  int koff[IPW], voff[IPW];
+#pragma unroll
+  for (int i = 0; i < IPW; ++i) {
+    const int inst = wave * IPW + i;
+    const int row = inst * RPI + lane / C::CH;
+    const int pos = lane % C::CH;
+    koff[i] = row * D + C::swz_k(row, pos) * 8;
+    voff[i] = row * D + C::swz_v(row, pos) * 8;
+  }
+  auto issue = [&](int t, int stage) {
+    char* sk = smem + stage * 2 * C::TILE;
+    char* sv = sk + C::TILE;
+    const bf16* kt = Kb + (long)t * C::KV * D;
+    const bf16* vt = Vb + (long)t * C::KV * D;
+#pragma unroll
+    for (int i = 0; i < IPW; ++i) {
+      const int inst = wave * IPW + i;
+      __builtin_amdgcn_global_load_lds(DFOT_GLOBAL_PTR(kt + koff[i]), DFOT_LDS_PTR(sk + inst * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(DFOT_GLOBAL_PTR(vt + voff[i]), DFOT_LDS_PTR(sv + inst * 1024), 16, 0, 0);
+    }
+  };
+
+  f32x16 oacc[D / 32];
+#pragma unroll
+  for (int i = 0; i < D / 32; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[i][r] = 0.f;
+  float m_run = 0.f, l_i = 0.f;
+
+  const int nt = N / C::KV;
+  issue(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  for (int t = 0; t < nt; ++t) {
+    const int cur = t & 1;
+    const char* sk = smem + cur * 2 * C::TILE;
+    const char* sv = sk + C::TILE;
+    if (t + 1 < nt) issue(t + 1, cur ^ 1);
+
+    // ---- S^T - m = K Q^T - m ----
+    f32x16 sacc[2];
+#pragma unroll
+    for (int kt2 = 0; kt2 < 2; ++kt2) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sacc[kt2][r] = -m_run;
+      const int row = kt2 * 32 + lq;
+#pragma unroll
+      for (int ks = 0; ks < D / 16; ++ks) {
+        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sk + row * C::ROWB + C::swz_k(row, ks * 2 + lh) * 16);
+        sacc[kt2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sacc[kt2], 0, 0, 0);
+      }
+    }
+
+    // ---- row max of (s - m) over this lane's 32 keys and the partner half ----
+    float mx = fmaxf(fmaxf(sacc[0][0], sacc[0][1]), sacc[0][2]);
+#pragma unroll
+    for (int r = 3; r < 15; r += 2) mx = fmaxf(fmaxf(mx, sacc[0][r]), sacc[0][r + 1]);
+    mx = fmaxf(mx, sacc[0][15]);
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) mx = fmaxf(fmaxf(mx, sacc[1][r]), sacc[1][r + 1]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+
+    // first tile: adopt the max outright; later: only when it grew by more than THR (wave-uniform branch)
+    const bool grow = (t == 0) || (mx > THR);
+    if (__any(grow)) {
+      const float delta = (t == 0) ? mx : fmaxf(mx, 0.f);
+      const float alpha = __builtin_amdgcn_exp2f(-delta);  // t == 0: O and l are still zero
+      m_run += delta;
+      l_i *= alpha;
+#pragma unroll
+      for (int i = 0; i < D / 32; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
+#pragma unroll
+      for (int kt2 = 0; kt2 < 2; ++kt2)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sacc[kt2][r] -= delta;
+    }
+
+    float rs = 0.f;
+    bf16x8 pf[2][2];
+#pragma unroll
+    for (int kt2 = 0; kt2 < 2; ++kt2)
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float p = __builtin_amdgcn_exp2f(sacc[kt2][8 * s + j]);
+          rs += p;
+          pf[kt2][s][j] = f2bf(p);
+        }
+    l_i += rs;
+
+    // ---- O^T += V^T P^T ----
+#pragma unroll
+    for (int dvt = 0; dvt < D / 32; ++dvt) {
+#pragma unroll
+      for (int kt2 = 0; kt2 < 2; ++kt2) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          const int kb = kt2 * 32 + 16 * s + 4 * lh;
+          const int q4 = (lane & 15) >> 2, p4 = lane & 3;
+          const int col = dvt * 32 + 16 * ((lane >> 4) & 1) + 4 * p4;
+          const int r0 = kb + q4, r1 = kb + 8 + q4;
+          const char* a0 = sv + r0 * C::ROWB + C::swz_v(r0, col >> 3) * 16 + (col & 7) * 2;
+          const char* a1 = sv + r1 * C::ROWB + C::swz_v(r1, col >> 3) * 16 + (col & 7) * 2;
+          const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(a0));
+          const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(a1));
+          const bf16x8 vf = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          oacc[dvt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[kt2][s], oacc[dvt], 0, 0, 0);
+        }
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+
+  const float l_tot = l_i + __shfl_xor(l_i, 32);
+  const float inv = 1.0f / l_tot;
+  const int b = bh / heads, hd = bh % heads;
+  bf16* orow = O + ((long)b * N + q0 + lq) * ldo + hd * D;
+#pragma unroll
+  for (int dvt = 0; dvt < D / 32; ++dvt)
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      bf16x4 o4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o4[j] = f2bf(oacc[dvt][4 * g4 + j] * inv);
+      *reinterpret_cast<bf16x4*>(orow + dvt * 32 + 8 * g4 + 4 * lh) = o4;
+    }
+}
+
+template <int D>
+static int launch_attn_v2(const bf16* q, const bf16* k, const bf16* v, bf16* o, long ldo, int batch, int heads, int n,
+                          hipStream_t stream) {
+  auto kern = attn_kernel_v2<D>;
+  const int lds = 4 * AttnCfg<D>::TILE;
+  static bool attr_set = false;
+  if (!attr_set) {
+    DFOT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(n / 128, batch * heads), dim3(256), lds, stream, q, k, v, o, ldo, n, heads);
+  DFOT_CHECK_HIP(hipGetLastError());
+  return DFOT_OK;
+}
+
 template <int D, bool TR>
 static int launch_attn_t(const bf16* q, const bf16* k, const bf16* v, bf16* o, long ldo, int batch, int heads, int n,
                          hipStream_t stream) {
@@ -209,6 +391,10 @@ int launch_attention(const bf16* q, const bf16* k, const bf16* v, bf16* o, long 
   DFOT_REQUIRE(d == 64 || d == 128, DFOT_ERR_SHAPE, "attention: head dim %d not in {64,128}", d);
   DFOT_REQUIRE(n > 0 && n % 128 == 0, DFOT_ERR_SHAPE, "attention: N=%d must be a multiple of 128", n);
   DFOT_REQUIRE(ldo % 4 == 0, DFOT_ERR_SHAPE, "attention: output row stride %ld must be a multiple of 4", ldo);
+  if (variant == 2) {
+    return d == 64 ? launch_attn_v2<64>(q, k, v, o, ldo, batch, heads, n, stream)
+                   : launch_attn_v2<128>(q, k, v, o, ldo, batch, heads, n, stream);
+  }
   if (d == 64) {
     return variant == 1 ? launch_attn_t<64, false>(q, k, v, o, ldo, batch, heads, n, stream)
                         : launch_attn_t<64, true>(q, k, v, o, ldo, batch, heads, n, stream);

@@ -26,7 +26,15 @@ struct GemmArgs {
   int split = 0;
 };
 
+enum GemmVariant {
+  GEMM_REGS_128 = 0,  // 128x128 tile, register staging, 2 LDS stages (A/B reference)
+  GEMM_DMA_128 = 1,   // 128x128 tile, LDS-DMA, 2 stages
+  GEMM_DMA3_128 = 2,  // 128x128 tile, LDS-DMA, 3-stage ring with counted vmcnt
+  GEMM_DMA3_256 = 3,  // 256x128 tile (8 waves), LDS-DMA, 3-stage ring
+  GEMM_AUTO = -1      // pick by shape (gemm_pick_variant)
+};
+int gemm_pick_variant(int amode, int m, int n, int k);
 // returns DFOT_OK / error; validates the divisibility contract before launching
-int launch_gemm(int amode, int epi, bool lds_dma, const GemmArgs& g, hipStream_t stream);
+int launch_gemm(int amode, int epi, int variant, const GemmArgs& g, hipStream_t stream);
 
 }  // namespace dfot

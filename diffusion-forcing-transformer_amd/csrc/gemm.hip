@@ -1,8 +1,7 @@
 // bf16 MFMA GEMM (C = A * W^T) and implicit-GEMM 3x3 convolution for gfx950, with the DFoT
 // backbone's fused epilogues.
 //
-// Tile: 128x128x64 per 256-thread workgroup (4 waves as 2x2, each wave 64x64 = 4x4 MFMA
-// 16x16x32 bf16 tiles).  Both operands are K-major, so A and W fragments are read from LDS the
+// Tile: (128|256)x128x64 per workgroup of 4|8 waves, each wave 64x64 = 4x4 MFMA 16x16x32 bf16 tiles.  Both operands are K-major, so A and W fragments are read from LDS the
 // same way: one ds_read_b128 per lane = 8 consecutive k of one row.  LDS rows are 128 B (64 bf16);
 // the 16-byte chunk c of row r is stored at position c ^ ((r>>1)&7): any 16 consecutive rows
 // read at one logical chunk hit 16 distinct slots of the 256-B bank row (conflict-free
@@ -10,36 +9,45 @@
 // Staging: global_load_lds_dwordx4 (LDS-DMA).  The LDS image of one wave instruction is linear
 // (8 rows x 128 B), so the swizzle is applied to the per-lane SOURCE address
 // (cdna_hip_programming.md rule 21); a register-staged path (DMA=false) is kept for A/B testing.
-// Two LDS stages; next tile's loads are issued before the current tile's MFMAs.
+// Two or three LDS stages; with three, a tile's DMA stays in flight across one barrier (counted vmcnt).
 #include "gemm.h"
 #include "dfot_hip.h"
 
 namespace dfot {
 
-constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int STAGE_BYTES = (BM + BN) * BK * 2;  // 32 KiB
-constexpr int A_BYTES = BM * BK * 2;
+constexpr int BN = 128, BK = 64;
 
-template <int AMODE, int EPI, bool DMA>
-__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
+// BM_T = 128: 256 threads (waves 2x2), BM_T = 256: 512 threads (waves 4x2); every wave owns a 64x64 output block.
+// NST = LDS stages.  NST == 2: load tile t+1 while computing t (vmcnt(0) + barrier per tile).
+// NST == 3 (LDS-DMA only): tile t+2 is in flight across the barrier; the wait before the barrier is a COUNTED
+// s_waitcnt vmcnt(loads of one tile), so a tile's DMA has two compute phases to land
+// (cdna_hip_programming.md "Pipelining across barriers").
+template <int BM_T, int NST, int AMODE, int EPI, bool DMA>
+__global__ __launch_bounds__(BM_T * 2) void gemm_kernel(GemmArgs g) {
+  constexpr int NW = BM_T / 32;                 // waves per workgroup
+  constexpr int WCH = (BN * 8) / (BM_T * 2);    // W chunks (16 B) per thread per k-tile: 4 or 2
+  constexpr int A_BYTES = BM_T * BK * 2;
+  constexpr int STAGE_BYTES = (BM_T + BN) * BK * 2;
+  constexpr int LOADS = 4 + WCH;                // LDS-DMA instructions per thread per k-tile
+  static_assert(DMA || NST == 2, "register staging supports two stages only");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int tiles_n = (g.N + BN - 1) / BN;
   const int tn = blockIdx.x % tiles_n, tm = blockIdx.x / tiles_n;
-  const int m0 = tm * BM, n0 = tn * BN;
+  const int m0 = tm * BM_T, n0 = tn * BN;
   const int nk = g.K / BK;
 
-  // ---- per-thread staging geometry: 4 A chunks + 4 W chunks of 16 B per k-tile ----
+  // ---- per-thread staging geometry: 4 A chunks + WCH W chunks of 16 B per k-tile ----
   const int prow = lane >> 3;  // row within the 8-row group written by one wave instruction
   const int ppos = lane & 7;   // 16-byte position within the 128-byte LDS row
   const bf16* a_src[4];
   int a_y[4], a_x[4];
-  const bf16* w_src[4];
+  const bf16* w_src[WCH];
   int a_chunk[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const int r = 8 * (4 * i + wave) + prow;
+    const int r = 8 * (NW * i + wave) + prow;
     const int c = ppos ^ ((r >> 1) & 7);
     a_chunk[i] = c;
     const long m = (long)m0 + r;
@@ -53,6 +61,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
       a_y[i] = yh;
       a_src[i] = g.A + m * (long)g.Cin + c * 8;
     }
+  }
+#pragma unroll
+  for (int i = 0; i < WCH; ++i) {
+    const int r = 8 * (NW * i + wave) + prow;
+    const int c = ppos ^ ((r >> 1) & 7);
     int n = n0 + r;
     n = n < g.N ? n : g.N - 1;
     w_src[i] = g.W + (long)n * g.K + c * 8;
@@ -73,7 +86,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     }
   };
 
-  bf16x8 ra[4], rw[4];  // register staging (DMA=false)
+  bf16x8 ra[4], rw[WCH];  // register staging (DMA=false)
 
   auto issue = [&](int kt, int stage) {
     char* sa = smem + stage * STAGE_BYTES;
@@ -81,12 +94,18 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const bf16* pa = a_addr(i, kt);
-      const bf16* pw = w_src[i] + (long)kt * BK;
       if constexpr (DMA) {
-        __builtin_amdgcn_global_load_lds(DFOT_GLOBAL_PTR(pa), DFOT_LDS_PTR(sa + (4 * i + wave) * 1024), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds(DFOT_GLOBAL_PTR(pw), DFOT_LDS_PTR(sw + (4 * i + wave) * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(DFOT_GLOBAL_PTR(pa), DFOT_LDS_PTR(sa + (NW * i + wave) * 1024), 16, 0, 0);
       } else {
         ra[i] = *reinterpret_cast<const bf16x8*>(pa);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < WCH; ++i) {
+      const bf16* pw = w_src[i] + (long)kt * BK;
+      if constexpr (DMA) {
+        __builtin_amdgcn_global_load_lds(DFOT_GLOBAL_PTR(pw), DFOT_LDS_PTR(sw + (NW * i + wave) * 1024), 16, 0, 0);
+      } else {
         rw[i] = *reinterpret_cast<const bf16x8*>(pw);
       }
     }
@@ -95,11 +114,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     char* sa = smem + stage * STAGE_BYTES;
     char* sw = sa + A_BYTES;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int off = (4 * i + wave) * 1024 + lane * 16;
-      *reinterpret_cast<bf16x8*>(sa + off) = ra[i];
-      *reinterpret_cast<bf16x8*>(sw + off) = rw[i];
-    }
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<bf16x8*>(sa + (NW * i + wave) * 1024 + lane * 16) = ra[i];
+#pragma unroll
+    for (int i = 0; i < WCH; ++i) *reinterpret_cast<bf16x8*>(sw + (NW * i + wave) * 1024 + lane * 16) = rw[i];
   };
 
   f32x4 acc[4][4];
@@ -136,80 +153,146 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   };
 
   // ---- main loop ----
-  issue(0, 0);
-  if constexpr (DMA) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  } else {
-    commit(0);
-  }
-  __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nk) issue(kt + 1, cur ^ 1);
-    compute(cur);
+  if constexpr (NST == 2) {
+    issue(0, 0);
     if constexpr (DMA) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     } else {
-      if (kt + 1 < nk) commit(cur ^ 1);
+      commit(0);
     }
     __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+      const int cur = kt & 1;
+      if (kt + 1 < nk) issue(kt + 1, cur ^ 1);
+      compute(cur);
+      if constexpr (DMA) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      } else {
+        if (kt + 1 < nk) commit(cur ^ 1);
+      }
+      __syncthreads();
+    }
+  } else {
+    // 3-stage ring.  Invariant at the top of iteration kt: tile kt has landed and is visible to every wave
+    // (its waves waited for it, then passed a barrier); tile kt+1 may still be in flight.
+    issue(0, 0);
+    if (nk > 1) {
+      issue(1, 1);
+      if constexpr (LOADS == 8) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    int st = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+      // stage (kt+2)%3 == (kt-1)%3 was last read in iteration kt-1, which every wave left through a barrier
+      const int nxt2 = st == 0 ? 2 : st - 1;
+      if (kt + 2 < nk) issue(kt + 2, nxt2);
+      compute(st);
+      if (kt + 2 < nk) {
+        if constexpr (LOADS == 8) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+      }
+      st = st == 2 ? 0 : st + 1;
+    }
   }
 
   // ---- epilogue ----
+  // lane holds, per 16x16 sub-tile, one column (lane&15) and four consecutive rows ((lane>>4)*4 + j)
   const int colq = lane & 15, rowq = (lane >> 4) * 4;
-  {
+  const long mbase = (long)m0 + wm * 64 + rowq;
 #pragma unroll
-    for (int ni = 0; ni < 4; ++ni) {
-      const int col = n0 + wn * 64 + ni * 16 + colq;
-      if (col >= g.N) continue;
-      const float bv = g.bias ? g.bias[col] : 0.f;
+  for (int ni = 0; ni < 4; ++ni) {
+    const int col = n0 + wn * 64 + ni * 16 + colq;
+    if (col >= g.N) continue;
+    const float bv = g.bias ? g.bias[col] : 0.f;
+    if constexpr (EPI == E_F32) {
+      float* op = g.out_f32 + mbase * g.ldo + col;
+      if (g.resid) {  // condition hoisted: all 16 residual loads are issued before the first use
+        const float* rp = g.resid + mbase * g.ldo + col;
+        float rv[4][4];
 #pragma unroll
-      for (int mi = 0; mi < 4; ++mi) {
+        for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const long m = (long)m0 + wm * 64 + mi * 16 + rowq + j;
-          float v = acc[mi][ni][j] + bv;
-          if constexpr (EPI == E_F32) {
-            if (g.resid) v += g.resid[m * g.ldo + col];
-            g.out_f32[m * g.ldo + col] = v;
-          } else if constexpr (EPI == E_BF16) {
-            g.out_bf16[m * g.ldo + col] = f2bf(v);
-          } else if constexpr (EPI == E_QKV) {
-            if (col < g.split) {
-              g.out_bf16[m * g.ldo + col] = f2bf(v);
-            } else {
-              g.out2[m * g.ldo2 + (col - g.split)] = f2bf(silu_f(v));
-            }
-          }
-        }
+          for (int j = 0; j < 4; ++j) rv[mi][j] = rp[(long)(mi * 16 + j) * g.ldo];
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) op[(long)(mi * 16 + j) * g.ldo] = acc[mi][ni][j] + bv + rv[mi][j];
+      } else {
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) op[(long)(mi * 16 + j) * g.ldo] = acc[mi][ni][j] + bv;
+      }
+    } else if constexpr (EPI == E_BF16) {
+      bf16* op = g.out_bf16 + mbase * g.ldo + col;
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) op[(long)(mi * 16 + j) * g.ldo] = f2bf(acc[mi][ni][j] + bv);
+    } else if constexpr (EPI == E_QKV) {
+      // the split point is a multiple of 16, so a 16-column sub-tile lies entirely on one side
+      if (col < g.split) {
+        bf16* op = g.out_bf16 + mbase * g.ldo + col;
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) op[(long)(mi * 16 + j) * g.ldo] = f2bf(acc[mi][ni][j] + bv);
+      } else {
+        bf16* op = g.out2 + mbase * g.ldo2 + (col - g.split);
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) op[(long)(mi * 16 + j) * g.ldo2] = f2bf(silu_f(acc[mi][ni][j] + bv));
       }
     }
   }
 }
 
-template <int AMODE, int EPI, bool DMA>
+template <int BM_T, int NST, int AMODE, int EPI, bool DMA>
 static int launch_t(const GemmArgs& g, hipStream_t stream) {
-  const int tiles = (g.M / BM) * ((g.N + BN - 1) / BN);
-  auto kern = gemm_kernel<AMODE, EPI, DMA>;
+  constexpr int lds = NST * (BM_T + BN) * BK * 2;
+  const int tiles = (g.M / BM_T) * ((g.N + BN - 1) / BN);
+  auto kern = gemm_kernel<BM_T, NST, AMODE, EPI, DMA>;
   static bool attr_set = false;
   if (!attr_set) {
-    DFOT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       2 * STAGE_BYTES));
+    DFOT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3(tiles), dim3(256), 2 * STAGE_BYTES, stream, g);
+  hipLaunchKernelGGL(kern, dim3(tiles), dim3(BM_T * 2), lds, stream, g);
   DFOT_CHECK_HIP(hipGetLastError());
   return DFOT_OK;
 }
 
 template <int AMODE, int EPI>
-static int launch_d(bool dma, const GemmArgs& g, hipStream_t s) {
-  return dma ? launch_t<AMODE, EPI, true>(g, s) : launch_t<AMODE, EPI, false>(g, s);
+static int launch_v(int variant, const GemmArgs& g, hipStream_t s) {
+  switch (variant) {
+    case GEMM_REGS_128: return launch_t<128, 2, AMODE, EPI, false>(g, s);
+    case GEMM_DMA_128: return launch_t<128, 2, AMODE, EPI, true>(g, s);
+    case GEMM_DMA3_128: return launch_t<128, 3, AMODE, EPI, true>(g, s);
+    case GEMM_DMA3_256: return launch_t<256, 3, AMODE, EPI, true>(g, s);
+  }
+  set_error("gemm: unknown variant %d", variant);
+  return DFOT_ERR_ARG;
 }
 
-int launch_gemm(int amode, int epi, bool lds_dma, const GemmArgs& g, hipStream_t stream) {
+int gemm_pick_variant(int amode, int m, int n, int k) {
+  // measured on MI355X at the model's shapes (tools/bench_ops.py): the 256-row 3-stage ring wins only for long-K dense
+  // GEMMs with enough tiles to fill 256 CUs; everything else (short K, convs, small grids) prefers 2 blocks/CU of the
+  // 128x128 two-stage kernel
+  const long tiles256 = (long)(m / 256) * ((n + BN - 1) / BN);
+  if (amode == A_DENSE && m % 256 == 0 && k >= 1024 && tiles256 >= 384) return GEMM_DMA3_256;
+  return GEMM_DMA_128;
+}
+
+int launch_gemm(int amode, int epi, int variant, const GemmArgs& g, hipStream_t stream) {
   DFOT_REQUIRE(g.A && g.W, DFOT_ERR_ARG, "gemm: null operand");
-  DFOT_REQUIRE(g.M > 0 && g.M % BM == 0, DFOT_ERR_SHAPE, "gemm: M=%d must be a positive multiple of %d", g.M, BM);
+  if (variant == GEMM_AUTO) variant = gemm_pick_variant(amode, g.M, g.N, g.K);
+  const int bm = variant == GEMM_DMA3_256 ? 256 : 128;
+  DFOT_REQUIRE(g.M > 0 && g.M % bm == 0, DFOT_ERR_SHAPE, "gemm: M=%d must be a positive multiple of %d", g.M, bm);
   DFOT_REQUIRE(g.K > 0 && g.K % BK == 0, DFOT_ERR_SHAPE, "gemm: K=%d must be a positive multiple of %d", g.K, BK);
   DFOT_REQUIRE(g.N > 0, DFOT_ERR_SHAPE, "gemm: N=%d", g.N);
   if (amode == A_CONV3) {
@@ -219,14 +302,14 @@ int launch_gemm(int amode, int epi, bool lds_dma, const GemmArgs& g, hipStream_t
   }
   if (amode == A_DENSE) {
     switch (epi) {
-      case E_F32: return launch_d<A_DENSE, E_F32>(lds_dma, g, stream);
-      case E_BF16: return launch_d<A_DENSE, E_BF16>(lds_dma, g, stream);
-      case E_QKV: return launch_d<A_DENSE, E_QKV>(lds_dma, g, stream);
+      case E_F32: return launch_v<A_DENSE, E_F32>(variant, g, stream);
+      case E_BF16: return launch_v<A_DENSE, E_BF16>(variant, g, stream);
+      case E_QKV: return launch_v<A_DENSE, E_QKV>(variant, g, stream);
     }
   } else if (amode == A_CONV3) {
     switch (epi) {
-      case E_F32: return launch_d<A_CONV3, E_F32>(lds_dma, g, stream);
-      case E_BF16: return launch_d<A_CONV3, E_BF16>(lds_dma, g, stream);
+      case E_F32: return launch_v<A_CONV3, E_F32>(variant, g, stream);
+      case E_BF16: return launch_v<A_CONV3, E_BF16>(variant, g, stream);
     }
   }
   set_error("gemm: unsupported mode/epilogue combination %d/%d", amode, epi);

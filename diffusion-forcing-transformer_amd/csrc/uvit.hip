@@ -99,8 +99,8 @@ struct dfot_uvit_s {
   bf16 *acond = nullptr, *emb[4] = {nullptr, nullptr, nullptr, nullptr}, *s1 = nullptr, *hbf = nullptr, *qkv = nullptr,
        *cat = nullptr, *q = nullptr, *k = nullptr, *v = nullptr;
   int last_batch = 0;
-  bool use_dma = true;
-  int attn_variant = 0;
+  int gemm_variant = GEMM_AUTO;
+  int attn_variant = 2;
   // optional in-run timing of the level-2 attention launches (HIP events on the launch stream)
   bool time_attn = false;
   std::vector<hipEvent_t> ev_start, ev_stop;
@@ -353,7 +353,7 @@ static int run_res_block(dfot_uvit_s* h, const ResW& w, int lvl, int bt, hipStre
   GemmArgs g;
   g.A = h->s1; g.W = w.w1; g.M = m; g.N = c; g.K = 9 * c; g.H = rr; g.Wd = rr; g.Cin = c; g.zeros = h->zeros;
   g.bias = w.bias1; g.out_bf16 = h->hbf; g.ldo = c;
-  if ((rc = launch_gemm(A_CONV3, E_BF16, h->use_dma, g, s))) return rc;
+  if ((rc = launch_gemm(A_CONV3, E_BF16, h->gemm_variant, g, s))) return rc;
   if ((rc = launch_gn_stats_bf16(h->hbf, h->gn_partial, h->gn_stats, bt, pix, c, h->cfg.eps, s))) return rc;
   if ((rc = launch_gn_film_silu(h->hbf, h->gn_stats, w.g2, w.be2, w.fcache, h->sv + w.sv_off,
                                 h->have_mask ? h->cond_mask : nullptr, h->s1, bt, pix, c, h->T, s)))
@@ -361,7 +361,7 @@ static int run_res_block(dfot_uvit_s* h, const ResW& w, int lvl, int bt, hipStre
   GemmArgs o;
   o.A = h->s1; o.W = w.w2; o.M = m; o.N = c; o.K = 9 * c; o.H = rr; o.Wd = rr; o.Cin = c; o.zeros = h->zeros;
   o.bias = w.bias2; o.out_f32 = x; o.resid = x; o.ldo = c;
-  return launch_gemm(A_CONV3, E_F32, h->use_dma, o, s);
+  return launch_gemm(A_CONV3, E_F32, h->gemm_variant, o, s);
 }
 
 static int run_tr_block(dfot_uvit_s* h, const TrW& w, int lvl, int batch, hipStream_t s) {
@@ -375,7 +375,7 @@ static int run_tr_block(dfot_uvit_s* h, const TrW& w, int lvl, int batch, hipStr
   GemmArgs p;
   p.A = h->s1; p.lda = c; p.W = w.w_fused; p.M = m; p.N = 7 * c; p.K = c; p.bias = w.b_fused;
   p.out_bf16 = h->qkv; p.ldo = 3 * c; p.out2 = h->cat + c; p.ldo2 = 5 * c; p.split = 3 * c;
-  if ((rc = launch_gemm(A_DENSE, E_QKV, h->use_dma, p, s))) return rc;
+  if ((rc = launch_gemm(A_DENSE, E_QKV, h->gemm_variant, p, s))) return rc;
   const float qscale = 1.4426950408889634f / sqrtf((float)d);
   if ((rc = launch_qk_norm_rope(h->qkv, w.qw, w.kw, h->rope_cs[lvl], h->q, h->k, h->v, batch, n, h->heads, d, qscale,
                                 h->cfg.eps, s)))
@@ -387,7 +387,7 @@ static int run_tr_block(dfot_uvit_s* h, const TrW& w, int lvl, int batch, hipStr
   GemmArgs o;
   o.A = h->cat; o.lda = 5 * c; o.W = w.w_out; o.M = m; o.N = c; o.K = 5 * c; o.bias = w.b_out; o.out_f32 = x; o.resid = x;
   o.ldo = c;
-  return launch_gemm(A_DENSE, E_F32, h->use_dma, o, s);
+  return launch_gemm(A_DENSE, E_F32, h->gemm_variant, o, s);
 }
 
 static int run_down(dfot_uvit_s* h, int l, int bt, hipStream_t s) {
@@ -397,7 +397,7 @@ static int run_down(dfot_uvit_s* h, int l, int bt, hipStream_t s) {
   GemmArgs g;
   g.A = h->s1; g.W = h->down_conv[l].w; g.M = bt * (rr / 2) * (rr / 2); g.N = cout; g.K = 9 * cin; g.H = rr / 2; g.Wd = rr / 2;
   g.Cin = cin; g.zeros = h->zeros; g.bias = h->down_conv[l].b; g.out_f32 = h->HSA[l]; g.ldo = cout;
-  if ((rc = launch_gemm(A_CONV3, E_F32, h->use_dma, g, s))) return rc;
+  if ((rc = launch_gemm(A_CONV3, E_F32, h->gemm_variant, g, s))) return rc;
   return copy_f32(h->X[l + 1], h->HSA[l], (size_t)g.M * cout, s);
 }
 
@@ -409,7 +409,7 @@ static int run_up(dfot_uvit_s* h, int l, int bt, hipStream_t s) {  // level l+1 
   GemmArgs g;
   g.A = h->s1; g.W = h->up_conv[l].w; g.M = bt * rr * rr; g.N = cout; g.K = 9 * cin; g.H = rr; g.Wd = rr; g.Cin = cin;
   g.zeros = h->zeros; g.bias = h->up_conv[l].b; g.out_f32 = h->tmp; g.ldo = cout;
-  if ((rc = launch_gemm(A_CONV3, E_F32, h->use_dma, g, s))) return rc;
+  if ((rc = launch_gemm(A_CONV3, E_F32, h->gemm_variant, g, s))) return rc;
   return launch_upsample_add(h->tmp, h->X[l], h->X[l], bt, rr, rr, cout, s);
 }
 
@@ -594,7 +594,7 @@ int dfot_uvit_attn_timing(dfot_uvit_t h, double* total_ms, int64_t* launches) {
 
 int dfot_uvit_set_option(dfot_uvit_t h, const char* key, int value) {
   DFOT_REQUIRE(h && key, DFOT_ERR_ARG, "set_option: null argument");
-  if (!strcmp(key, "lds_dma")) h->use_dma = value != 0;
+  if (!strcmp(key, "gemm_variant")) h->gemm_variant = value;
   else if (!strcmp(key, "attn_variant")) h->attn_variant = value;
   else if (!strcmp(key, "time_attn")) {
     // value = number of launches to record (0 disables); events are created here, never inside forward
@@ -632,7 +632,7 @@ int dfot_uvit_set_conditions(dfot_uvit_t h, const float* external_cond, const ui
     GemmArgs g;
     g.A = h->acond; g.lda = h->kpose; g.W = h->pose_w; g.M = bt * h->r[0] * h->r[0]; g.N = e; g.K = h->kpose;
     g.bias = h->pose_b; g.out_bf16 = h->emb[0]; g.ldo = e;
-    if ((rc = launch_gemm(A_DENSE, E_BF16, h->use_dma, g, s))) return rc;
+    if ((rc = launch_gemm(A_DENSE, E_BF16, h->gemm_variant, g, s))) return rc;
   }
   if ((rc = launch_emb_pyramid(h->emb[0], h->emb[1], h->emb[2], h->emb[3], bt, h->r[0], e, s))) return rc;
   // every block's FiLM projection of the pose term: F = W_film * pose_emb  (no bias; it lives in sv)
@@ -640,7 +640,7 @@ int dfot_uvit_set_conditions(dfot_uvit_t h, const float* external_cond, const ui
     GemmArgs g;
     g.A = h->emb[lvl]; g.lda = e; g.W = wf; g.M = bt * h->r[lvl] * h->r[lvl]; g.N = 2 * cc; g.K = e;
     g.out_bf16 = fcache; g.ldo = 2 * cc;
-    return launch_gemm(A_DENSE, E_BF16, h->use_dma, g, s);
+    return launch_gemm(A_DENSE, E_BF16, h->gemm_variant, g, s);
   };
   for (int l = 0; l < 2; ++l) {
     for (ResW& w : h->down_res[l]) if ((rc = fill(w.fcache, w.w_film, w.c, l))) return rc;
@@ -754,23 +754,23 @@ static int zero_page(bf16** out) {
   return DFOT_OK;
 }
 
-int dfot_op_gemm(const void* a, int lda, const void* w, const float* bias, float* c, int m, int n, int k, int use_lds_dma,
+int dfot_op_gemm(const void* a, int lda, const void* w, const float* bias, float* c, int m, int n, int k, int variant,
                  void* stream) {
   GemmArgs g;
   g.A = (const bf16*)a; g.lda = lda; g.W = (const bf16*)w; g.M = m; g.N = n; g.K = k; g.bias = bias; g.out_f32 = c; g.ldo = n;
   DFOT_REQUIRE(c, DFOT_ERR_ARG, "op_gemm: null output");
-  return launch_gemm(A_DENSE, E_F32, use_lds_dma != 0, g, (hipStream_t)stream);
+  return launch_gemm(A_DENSE, E_F32, variant, g, (hipStream_t)stream);
 }
 
 int dfot_op_conv3x3(const void* a, const void* w, const float* bias, float* y, int bt, int hh, int ww, int cin, int cout,
-                    int use_lds_dma, void* stream) {
+                    int variant, void* stream) {
   GemmArgs g;
   int rc = zero_page(const_cast<bf16**>(&g.zeros));
   if (rc) return rc;
   g.A = (const bf16*)a; g.W = (const bf16*)w; g.M = bt * hh * ww; g.N = cout; g.K = 9 * cin; g.H = hh; g.Wd = ww; g.Cin = cin;
   g.bias = bias; g.out_f32 = y; g.ldo = cout;
   DFOT_REQUIRE(y, DFOT_ERR_ARG, "op_conv3x3: null output");
-  return launch_gemm(A_CONV3, E_F32, use_lds_dma != 0, g, (hipStream_t)stream);
+  return launch_gemm(A_CONV3, E_F32, variant, g, (hipStream_t)stream);
 }
 
 int dfot_op_attention(const void* q, const void* k, const void* v, void* o, int ldo, int batch, int heads, int n, int d,

@@ -77,8 +77,8 @@ int dfot_uvit_finalize(dfot_uvit_t h, void* stream);
 /* allocate activations for a model batch of up to `max_batch` videos (B*NFE) */
 int dfot_uvit_reserve(dfot_uvit_t h, int max_batch);
 size_t dfot_uvit_workspace_bytes(dfot_uvit_t h);
-/* tuning/debug switches: "lds_dma" (1 = LDS-DMA staging in the GEMMs, 0 = register staging),
- * "attn_variant" (0 = transposed LDS reads for V, 1 = scalar LDS reads), "time_attn" (see below) */
+/* tuning/debug switches: "gemm_variant" (-1 auto, 0..3 as in dfot_op_gemm),
+ * "attn_variant" (2 = tuned kernel (default), 0 = baseline with transposed LDS reads for V, 1 = baseline with scalar LDS reads), "time_attn" (see below) */
 int dfot_uvit_set_option(dfot_uvit_t h, const char* key, int value);
 /* "time_attn" = N > 0 records HIP events (on the launch stream) around the next N level-2 attention launches;
  * this call synchronises on them, returns the summed duration and the number of launches, and resets the count */
@@ -121,12 +121,14 @@ int dfot_ddim_compose(const float* x, const float* x_in, const float* v, const f
                       float* x_next, int batch, int nfe, int tokens, int64_t frame_elems, void* stream);
 
 /* ---- unit-testable primitives ------------------------------------------------------------------ */
-/* C[M,N] (fp32) = A[M,K] (bf16, row stride lda) * W[N,K]^T (bf16) + bias[N] (fp32 or NULL) */
+/* C[M,N] (fp32) = A[M,K] (bf16, row stride lda) * W[N,K]^T (bf16) + bias[N] (fp32 or NULL)
+ * variant: -1 auto, 0 = 128-tile register staging, 1 = 128-tile LDS-DMA 2 stages, 2 = 128-tile LDS-DMA 3-stage ring,
+ * 3 = 256x128-tile LDS-DMA 3-stage ring (M % 256 == 0) */
 int dfot_op_gemm(const void* a_bf16, int lda, const void* w_bf16, const float* bias, float* c, int m, int n, int k,
-                 int use_lds_dma, void* stream);
+                 int variant, void* stream);
 /* y[BT,H,W,Cout] (fp32) = conv3x3(pad 1)(a[BT,H,W,Cin] bf16, w[Cout][9*Cin] bf16 tap-major) + bias */
 int dfot_op_conv3x3(const void* a_bf16, const void* w_bf16, const float* bias, float* y, int bt, int h, int w,
-                    int cin, int cout, int use_lds_dma, void* stream);
+                    int cin, int cout, int variant, void* stream);
 /* o[B,N,heads*d] (bf16, row stride ldo) = softmax(q k^T) v ; q,k,v [B,heads,N,d] bf16; q pre-scaled by
  * log2(e)/sqrt(d) (the kernel works in the exp2 domain). d in {64,128}; N % 128 == 0 (d=64) or % 64. */
 int dfot_op_attention(const void* q, const void* k, const void* v, void* o, int ldo, int batch, int heads, int n,

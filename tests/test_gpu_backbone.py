@@ -50,10 +50,10 @@ def test_state_dict_keys_match_reference_inventory(w64):
         assert tuple(sd[k].shape) == tuple(v.shape), k
 
 
-@pytest.mark.parametrize("dma,variant", [(1, 0), (0, 1)])
+@pytest.mark.parametrize("dma,variant", [(-1, 2), (0, 1), (3, 0)])
 def test_backbone_vs_golden_and_oracle_taps(w64, dma, variant):
     model = make_model(w64["ocfg"], w64["params"], 64)
-    model.set_option("lds_dma", dma)
+    model.set_option("gemm_variant", dma)
     model.set_option("attn_variant", variant)
     with torch.no_grad():
         v = model(w64["x"].cuda(), w64["k"].cuda(), w64["cond"].cuda(), w64["mask"].cuda()).cpu()
@@ -67,7 +67,7 @@ def test_backbone_vs_golden_and_oracle_taps(w64, dma, variant):
         print(f"tap {name}: rel_l2={r:.3e}")
     r_or = rel(v, w64["ref"])
     r_go = rel(v, w64["golden"])
-    print(f"backbone dma={dma} attn_variant={variant}: rel_l2 vs oracle {r_or:.3e}, vs reference golden {r_go:.3e}, "
+    print(f"backbone gemm_variant={dma} attn_variant={variant}: rel_l2 vs oracle {r_or:.3e}, vs reference golden {r_go:.3e}, "
           f"max_abs {(v - w64['golden']).abs().max().item():.3e}")
     assert torch.isfinite(v).all()
     assert r_go < REL_TOL and r_or < REL_TOL

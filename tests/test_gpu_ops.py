@@ -35,8 +35,9 @@ def report(name, got, ref):
     return err, rel
 
 
-@pytest.mark.parametrize("dma", [0, 1])
-@pytest.mark.parametrize("m,n,k", [(128, 128, 64), (256, 192, 128), (1024, 576, 576), (128, 4032, 576), (384, 100, 2880)])
+@pytest.mark.parametrize("dma", [0, 1, 2, 3])
+@pytest.mark.parametrize("m,n,k", [(256, 128, 64), (256, 192, 128), (1024, 576, 576), (256, 4032, 576), (768, 100, 2880),
+                                   (512, 256, 192)])
 def test_gemm(capi, dma, m, n, k):
     g = torch.Generator().manual_seed(m + n + k)
     a = torch.randn(m, k, generator=g).bfloat16().cuda()
@@ -57,8 +58,8 @@ def test_gemm_rejects_bad_shapes(capi):
         capi.check(capi.lib.dfot_op_gemm(P(a), 64, P(a), None, P(out), 100, 64, 64, 1, S()))
 
 
-@pytest.mark.parametrize("dma", [0, 1])
-@pytest.mark.parametrize("bt,h,w,cin,cout", [(2, 8, 8, 128, 128), (1, 16, 16, 128, 256), (2, 8, 16, 576, 256), (3, 16, 8, 64, 100)])
+@pytest.mark.parametrize("dma", [0, 1, 2, 3])
+@pytest.mark.parametrize("bt,h,w,cin,cout", [(4, 8, 8, 128, 128), (1, 16, 16, 128, 256), (2, 8, 16, 576, 256), (4, 16, 8, 64, 100)])
 def test_conv3x3(capi, dma, bt, h, w, cin, cout):
     g = torch.Generator().manual_seed(bt * 1000 + cin + cout)
     x = torch.randn(bt, cin, h, w, generator=g).bfloat16()
@@ -75,7 +76,7 @@ def test_conv3x3(capi, dma, bt, h, w, cin, cout):
     assert rel < 1e-5 and err < 1e-3
 
 
-@pytest.mark.parametrize("variant", [1, 0])
+@pytest.mark.parametrize("variant", [1, 0, 2])
 @pytest.mark.parametrize("b,heads,n,d", [(1, 2, 128, 64), (2, 9, 512, 64), (1, 3, 256, 128), (2, 9, 128, 128)])
 def test_attention(capi, variant, b, heads, n, d):
     g = torch.Generator().manual_seed(n + d + heads)
