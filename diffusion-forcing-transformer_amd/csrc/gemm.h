@@ -31,6 +31,7 @@ enum GemmVariant {
   GEMM_DMA_128 = 1,   // 128x128 tile, LDS-DMA, 2 stages
   GEMM_DMA3_128 = 2,  // 128x128 tile, LDS-DMA, 3-stage ring with counted vmcnt
   GEMM_DMA3_256 = 3,  // 256x128 tile (8 waves), LDS-DMA, 3-stage ring
+  GEMM_DMA_256x256 = 4,  // 256x256 tile (16 waves), LDS-DMA, 2 stages: half the L2->LDS operand traffic per FLOP
   GEMM_AUTO = -1      // pick by shape (gemm_pick_variant)
 };
 int gemm_pick_variant(int amode, int m, int n, int k);

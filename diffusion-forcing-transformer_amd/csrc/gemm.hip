@@ -15,38 +15,52 @@
 
 namespace dfot {
 
-constexpr int BN = 128, BK = 64;
+constexpr int BK = 64;
+constexpr int EP_LD = 68;  // fp32 row stride of the per-wave epilogue scratch (64 + 4: rows shift by 4 banks)
 
 // BM_T = 128: 256 threads (waves 2x2), BM_T = 256: 512 threads (waves 4x2); every wave owns a 64x64 output block.
 // NST = LDS stages.  NST == 2: load tile t+1 while computing t (vmcnt(0) + barrier per tile).
 // NST == 3 (LDS-DMA only): tile t+2 is in flight across the barrier; the wait before the barrier is a COUNTED
 // s_waitcnt vmcnt(loads of one tile), so a tile's DMA has two compute phases to land
 // (cdna_hip_programming.md "Pipelining across barriers").
-template <int BM_T, int NST, int AMODE, int EPI, bool DMA>
-__global__ __launch_bounds__(BM_T * 2) void gemm_kernel(GemmArgs g) {
-  constexpr int NW = BM_T / 32;                 // waves per workgroup
-  constexpr int WCH = (BN * 8) / (BM_T * 2);    // W chunks (16 B) per thread per k-tile: 4 or 2
+// wait until at most N of this wave's LDS-DMA loads are outstanding, then barrier (one asm statement: memory
+// operations are not moved across it)
+template <int N>
+__device__ __forceinline__ void wait_all_but() {
+  static_assert(N == 4 || N == 6 || N == 8, "unexpected load count");
+  if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+  if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
+  if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+}
+
+template <int BM_T, int BN_T, int NST, int AMODE, int EPI, bool DMA>
+__global__ __launch_bounds__((BM_T / 64) * (BN_T / 64) * 64) void gemm_kernel(GemmArgs g) {
+  constexpr int WN = BN_T / 64;                 // waves along N
+  constexpr int NW = (BM_T / 64) * WN;          // waves per workgroup
+  constexpr int NT = NW * 64;                   // threads
+  constexpr int ACH = (BM_T * 8) / NT;          // A chunks (16 B) per thread per k-tile
+  constexpr int WCH = (BN_T * 8) / NT;          // W chunks per thread per k-tile
   constexpr int A_BYTES = BM_T * BK * 2;
-  constexpr int STAGE_BYTES = (BM_T + BN) * BK * 2;
-  constexpr int LOADS = 4 + WCH;                // LDS-DMA instructions per thread per k-tile
+  constexpr int STAGE_BYTES = (BM_T + BN_T) * BK * 2;
+  constexpr int LOADS = ACH + WCH;              // LDS-DMA instructions per thread per k-tile
   static_assert(DMA || NST == 2, "register staging supports two stages only");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int tiles_n = (g.N + BN - 1) / BN;
+  const int wm = wave / WN, wn = wave % WN;
+  const int tiles_n = (g.N + BN_T - 1) / BN_T;
   const int tn = blockIdx.x % tiles_n, tm = blockIdx.x / tiles_n;
-  const int m0 = tm * BM_T, n0 = tn * BN;
+  const int m0 = tm * BM_T, n0 = tn * BN_T;
   const int nk = g.K / BK;
 
   // ---- per-thread staging geometry: 4 A chunks + WCH W chunks of 16 B per k-tile ----
   const int prow = lane >> 3;  // row within the 8-row group written by one wave instruction
   const int ppos = lane & 7;   // 16-byte position within the 128-byte LDS row
-  const bf16* a_src[4];
-  int a_y[4], a_x[4];
+  const bf16* a_src[ACH];
+  int a_y[ACH], a_x[ACH];
   const bf16* w_src[WCH];
-  int a_chunk[4];
+  int a_chunk[ACH];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < ACH; ++i) {
     const int r = 8 * (NW * i + wave) + prow;
     const int c = ppos ^ ((r >> 1) & 7);
     a_chunk[i] = c;
@@ -86,13 +100,13 @@ __global__ __launch_bounds__(BM_T * 2) void gemm_kernel(GemmArgs g) {
     }
   };
 
-  bf16x8 ra[4], rw[WCH];  // register staging (DMA=false)
+  bf16x8 ra[ACH], rw[WCH];  // register staging (DMA=false)
 
   auto issue = [&](int kt, int stage) {
     char* sa = smem + stage * STAGE_BYTES;
     char* sw = sa + A_BYTES;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < ACH; ++i) {
       const bf16* pa = a_addr(i, kt);
       if constexpr (DMA) {
         __builtin_amdgcn_global_load_lds(DFOT_GLOBAL_PTR(pa), DFOT_LDS_PTR(sa + (NW * i + wave) * 1024), 16, 0, 0);
@@ -114,7 +128,7 @@ __global__ __launch_bounds__(BM_T * 2) void gemm_kernel(GemmArgs g) {
     char* sa = smem + stage * STAGE_BYTES;
     char* sw = sa + A_BYTES;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) *reinterpret_cast<bf16x8*>(sa + (NW * i + wave) * 1024 + lane * 16) = ra[i];
+    for (int i = 0; i < ACH; ++i) *reinterpret_cast<bf16x8*>(sa + (NW * i + wave) * 1024 + lane * 16) = ra[i];
 #pragma unroll
     for (int i = 0; i < WCH; ++i) *reinterpret_cast<bf16x8*>(sw + (NW * i + wave) * 1024 + lane * 16) = rw[i];
   };
@@ -178,8 +192,7 @@ __global__ __launch_bounds__(BM_T * 2) void gemm_kernel(GemmArgs g) {
     issue(0, 0);
     if (nk > 1) {
       issue(1, 1);
-      if constexpr (LOADS == 8) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
+      wait_all_but<LOADS>();
     } else {
       asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
     }
@@ -190,8 +203,7 @@ __global__ __launch_bounds__(BM_T * 2) void gemm_kernel(GemmArgs g) {
       if (kt + 2 < nk) issue(kt + 2, nxt2);
       compute(st);
       if (kt + 2 < nk) {
-        if constexpr (LOADS == 8) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
+        wait_all_but<LOADS>();
       } else {
         asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
       }
@@ -199,70 +211,88 @@ __global__ __launch_bounds__(BM_T * 2) void gemm_kernel(GemmArgs g) {
     }
   }
 
-  // ---- epilogue ----
-  // lane holds, per 16x16 sub-tile, one column (lane&15) and four consecutive rows ((lane>>4)*4 + j)
+  // ---- epilogue: 16 output rows at a time are transposed through a per-wave LDS scratch so that global traffic is
+  // 16 B per lane on whole 128/256-byte row segments (the MFMA C layout gives a lane one column and four rows).
+  // All stage buffers are dead after the last barrier; same-wave LDS accesses complete in order.
+  float* ep = reinterpret_cast<float*>(smem) + wave * (16 * EP_LD);
   const int colq = lane & 15, rowq = (lane >> 4) * 4;
-  const long mbase = (long)m0 + wm * 64 + rowq;
+  const int nw = n0 + wn * 64;
+  [[maybe_unused]] const bool has_res = g.resid != nullptr;
 #pragma unroll
-  for (int ni = 0; ni < 4; ++ni) {
-    const int col = n0 + wn * 64 + ni * 16 + colq;
-    if (col >= g.N) continue;
-    const float bv = g.bias ? g.bias[col] : 0.f;
+  for (int mi = 0; mi < 4; ++mi) {
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) ep[(rowq + j) * EP_LD + ni * 16 + colq] = acc[mi][ni][j];
+    const long mw = (long)m0 + wm * 64 + mi * 16;
     if constexpr (EPI == E_F32) {
-      float* op = g.out_f32 + mbase * g.ldo + col;
-      if (g.resid) {  // condition hoisted: all 16 residual loads are issued before the first use
-        const float* rp = g.resid + mbase * g.ldo + col;
-        float rv[4][4];
+      const int c4 = (lane & 15) * 4;
+      const int col = nw + c4;
+      if (col < g.N) {
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        if (g.bias) bv = *reinterpret_cast<const f32x4*>(g.bias + col);
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) rv[mi][j] = rp[(long)(mi * 16 + j) * g.ldo];
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) op[(long)(mi * 16 + j) * g.ldo] = acc[mi][ni][j] + bv + rv[mi][j];
-      } else {
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) op[(long)(mi * 16 + j) * g.ldo] = acc[mi][ni][j] + bv;
+        for (int p = 0; p < 4; ++p) {
+          const int r = p * 4 + (lane >> 4);
+          f32x4 v = *reinterpret_cast<const f32x4*>(ep + r * EP_LD + c4) + bv;
+          const long off = (mw + r) * g.ldo + col;
+          if (has_res) v += *reinterpret_cast<const f32x4*>(g.resid + off);
+          *reinterpret_cast<f32x4*>(g.out_f32 + off) = v;
+        }
       }
-    } else if constexpr (EPI == E_BF16) {
-      bf16* op = g.out_bf16 + mbase * g.ldo + col;
+    } else {
+      const int c8 = (lane & 7) * 8;
+      const int col = nw + c8;
+      if (col < g.N) {
+        f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = {0.f, 0.f, 0.f, 0.f};
+        if (g.bias) {
+          b0 = *reinterpret_cast<const f32x4*>(g.bias + col);
+          b1 = *reinterpret_cast<const f32x4*>(g.bias + col + 4);
+        }
+        bool act = false;
+        bf16* base = g.out_bf16;
+        long ld = g.ldo;
+        int ocol = col;
+        if constexpr (EPI == E_QKV) {
+          if (col >= g.split) {  // MLP half: SiLU, second output tensor
+            act = true;
+            base = g.out2;
+            ld = g.ldo2;
+            ocol = col - g.split;
+          }
+        }
 #pragma unroll
-      for (int mi = 0; mi < 4; ++mi)
+        for (int p = 0; p < 2; ++p) {
+          const int r = p * 8 + (lane >> 3);
+          const f32x4 v0 = *reinterpret_cast<const f32x4*>(ep + r * EP_LD + c8) + b0;
+          const f32x4 v1 = *reinterpret_cast<const f32x4*>(ep + r * EP_LD + c8 + 4) + b1;
+          bf16x8 o;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) op[(long)(mi * 16 + j) * g.ldo] = f2bf(acc[mi][ni][j] + bv);
-    } else if constexpr (EPI == E_QKV) {
-      // the split point is a multiple of 16, so a 16-column sub-tile lies entirely on one side
-      if (col < g.split) {
-        bf16* op = g.out_bf16 + mbase * g.ldo + col;
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) op[(long)(mi * 16 + j) * g.ldo] = f2bf(acc[mi][ni][j] + bv);
-      } else {
-        bf16* op = g.out2 + mbase * g.ldo2 + (col - g.split);
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) op[(long)(mi * 16 + j) * g.ldo2] = f2bf(silu_f(acc[mi][ni][j] + bv));
+          for (int j = 0; j < 4; ++j) {
+            o[j] = f2bf(act ? silu_f(v0[j]) : v0[j]);
+            o[4 + j] = f2bf(act ? silu_f(v1[j]) : v1[j]);
+          }
+          *reinterpret_cast<bf16x8*>(base + (mw + r) * ld + ocol) = o;
+        }
       }
     }
   }
 }
 
-template <int BM_T, int NST, int AMODE, int EPI, bool DMA>
+template <int BM_T, int BN_T, int NST, int AMODE, int EPI, bool DMA>
 static int launch_t(const GemmArgs& g, hipStream_t stream) {
-  constexpr int lds = NST * (BM_T + BN) * BK * 2;
-  const int tiles = (g.M / BM_T) * ((g.N + BN - 1) / BN);
-  auto kern = gemm_kernel<BM_T, NST, AMODE, EPI, DMA>;
+  constexpr int nthreads = (BM_T / 64) * (BN_T / 64) * 64;
+  constexpr int stage_lds = NST * (BM_T + BN_T) * BK * 2;
+  constexpr int ep_lds = (nthreads / 64) * 16 * EP_LD * 4;
+  constexpr int lds = stage_lds > ep_lds ? stage_lds : ep_lds;
+  const int tiles = (g.M / BM_T) * ((g.N + BN_T - 1) / BN_T);
+  auto kern = gemm_kernel<BM_T, BN_T, NST, AMODE, EPI, DMA>;
   static bool attr_set = false;
   if (!attr_set) {
     DFOT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3(tiles), dim3(BM_T * 2), lds, stream, g);
+  hipLaunchKernelGGL(kern, dim3(tiles), dim3(nthreads), lds, stream, g);
   DFOT_CHECK_HIP(hipGetLastError());
   return DFOT_OK;
 }
@@ -270,31 +300,36 @@ static int launch_t(const GemmArgs& g, hipStream_t stream) {
 template <int AMODE, int EPI>
 static int launch_v(int variant, const GemmArgs& g, hipStream_t s) {
   switch (variant) {
-    case GEMM_REGS_128: return launch_t<128, 2, AMODE, EPI, false>(g, s);
-    case GEMM_DMA_128: return launch_t<128, 2, AMODE, EPI, true>(g, s);
-    case GEMM_DMA3_128: return launch_t<128, 3, AMODE, EPI, true>(g, s);
-    case GEMM_DMA3_256: return launch_t<256, 3, AMODE, EPI, true>(g, s);
+    case GEMM_REGS_128: return launch_t<128, 128, 2, AMODE, EPI, false>(g, s);
+    case GEMM_DMA_128: return launch_t<128, 128, 2, AMODE, EPI, true>(g, s);
+    case GEMM_DMA3_128: return launch_t<128, 128, 3, AMODE, EPI, true>(g, s);
+    case GEMM_DMA3_256: return launch_t<256, 128, 3, AMODE, EPI, true>(g, s);
+    case GEMM_DMA_256x256: return launch_t<256, 256, 2, AMODE, EPI, true>(g, s);
   }
   set_error("gemm: unknown variant %d", variant);
   return DFOT_ERR_ARG;
 }
 
 int gemm_pick_variant(int amode, int m, int n, int k) {
-  // measured on MI355X at the model's shapes (tools/bench_ops.py): the 256-row 3-stage ring wins only for long-K dense
-  // GEMMs with enough tiles to fill 256 CUs; everything else (short K, convs, small grids) prefers 2 blocks/CU of the
-  // 128x128 two-stage kernel
-  const long tiles256 = (long)(m / 256) * ((n + BN - 1) / BN);
-  if (amode == A_DENSE && m % 256 == 0 && k >= 1024 && tiles256 >= 384) return GEMM_DMA3_256;
+  // Measured on MI355X at the model's shapes (tools/bench_ops.py, profiles/): these GEMMs are bound by L2->LDS operand
+  // traffic, so the 256x256 tile (128 FLOP per operand byte instead of 64) wins whenever it still fills the chip:
+  // N wide enough that the padded columns are cheap, and enough tiles for the 256 CUs.
+  (void)amode;
+  (void)k;
+  const long tiles = (long)(m / 256) * ((n + 255) / 256);
+  if (m % 256 == 0 && n >= 192 && tiles >= 160) return GEMM_DMA_256x256;
   return GEMM_DMA_128;
 }
 
 int launch_gemm(int amode, int epi, int variant, const GemmArgs& g, hipStream_t stream) {
   DFOT_REQUIRE(g.A && g.W, DFOT_ERR_ARG, "gemm: null operand");
   if (variant == GEMM_AUTO) variant = gemm_pick_variant(amode, g.M, g.N, g.K);
-  const int bm = variant == GEMM_DMA3_256 ? 256 : 128;
+  const int bm = (variant == GEMM_DMA3_256 || variant == GEMM_DMA_256x256) ? 256 : 128;
   DFOT_REQUIRE(g.M > 0 && g.M % bm == 0, DFOT_ERR_SHAPE, "gemm: M=%d must be a positive multiple of %d", g.M, bm);
   DFOT_REQUIRE(g.K > 0 && g.K % BK == 0, DFOT_ERR_SHAPE, "gemm: K=%d must be a positive multiple of %d", g.K, BK);
-  DFOT_REQUIRE(g.N > 0, DFOT_ERR_SHAPE, "gemm: N=%d", g.N);
+  DFOT_REQUIRE(g.N > 0 && g.N % (epi == E_F32 ? 4 : 8) == 0, DFOT_ERR_SHAPE, "gemm: N=%d must be a multiple of %d", g.N, epi == E_F32 ? 4 : 8);
+  DFOT_REQUIRE(g.ldo % (epi == E_F32 ? 4 : 8) == 0 && (epi != E_QKV || (g.ldo2 % 8 == 0 && g.split % 64 == 0)), DFOT_ERR_SHAPE,
+               "gemm: output row strides must be multiples of %d", epi == E_F32 ? 4 : 8);
   if (amode == A_CONV3) {
     DFOT_REQUIRE(g.Cin % BK == 0 && g.K == 9 * g.Cin, DFOT_ERR_SHAPE, "conv3x3: Cin=%d must be a multiple of %d", g.Cin, BK);
     DFOT_REQUIRE(g.zeros != nullptr, DFOT_ERR_ARG, "conv3x3: zero page missing");

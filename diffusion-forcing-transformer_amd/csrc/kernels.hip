@@ -354,26 +354,27 @@ int launch_gn_apply_silu(const float* x, const float* stats, const float* gamma,
 // sv for every FiLM projection of the model in ONE launch (FilmChunk table: kernels.h)
 __global__ __launch_bounds__(256) void film_vec_kernel(const FilmChunk* __restrict__ table, const float* __restrict__ nemb,
                                                        float* __restrict__ sv, int e) {
-  const FilmChunk ck = table[blockIdx.x];
-  const int bt = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // workgroup = 4 rows of one 64-row chunk (blockIdx.x = chunk*16 + part), one wave per row, all frames of blockIdx.y
+  const FilmChunk ck = table[blockIdx.x >> 4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = (blockIdx.x & 15) * 4 + wave;
+  const int bt = blockIdx.y;
   const float* ne = nemb + (long)bt * e;
-  for (int r = wave * 16; r < wave * 16 + 16; ++r) {
-    const bf16* wr = ck.w + (long)r * e;
-    float acc = 0.f;
-    for (int i = lane * 8; i < e; i += 512) {
-      const bf16x8 wv = *reinterpret_cast<const bf16x8*>(wr + i);
-      const float4v a = *reinterpret_cast<const float4v*>(ne + i);
-      const float4v b = *reinterpret_cast<const float4v*>(ne + i + 4);
-      acc += bf2f(wv[0]) * a[0] + bf2f(wv[1]) * a[1] + bf2f(wv[2]) * a[2] + bf2f(wv[3]) * a[3] + bf2f(wv[4]) * b[0] +
-             bf2f(wv[5]) * b[1] + bf2f(wv[6]) * b[2] + bf2f(wv[7]) * b[3];
-    }
-    acc = wave_sum(acc);
-    if (lane == 0) sv[ck.out_off + (long)bt * ck.rows + r] = acc + ck.b[r];
+  const bf16* wr = ck.w + (long)r * e;
+  float acc = 0.f;
+  for (int i = lane * 8; i < e; i += 512) {
+    const bf16x8 wv = *reinterpret_cast<const bf16x8*>(wr + i);
+    const float4v a = *reinterpret_cast<const float4v*>(ne + i);
+    const float4v b = *reinterpret_cast<const float4v*>(ne + i + 4);
+    acc += bf2f(wv[0]) * a[0] + bf2f(wv[1]) * a[1] + bf2f(wv[2]) * a[2] + bf2f(wv[3]) * a[3] + bf2f(wv[4]) * b[0] +
+           bf2f(wv[5]) * b[1] + bf2f(wv[6]) * b[2] + bf2f(wv[7]) * b[3];
   }
+  acc = wave_sum(acc);
+  if (lane == 0) sv[ck.out_off + (long)bt * ck.rows + r] = acc + ck.b[r];
 }
 int launch_film_vec(const FilmChunk* table, int chunks, const float* nemb, float* sv, int bt, int e, hipStream_t s) {
   DFOT_REQUIRE(e % 8 == 0, DFOT_ERR_SHAPE, "film_vec: emb dim %d must be a multiple of 8", e);
-  hipLaunchKernelGGL(film_vec_kernel, dim3(chunks, bt), dim3(256), 0, s, table, nemb, sv, e);
+  hipLaunchKernelGGL(film_vec_kernel, dim3(chunks * 16, bt), dim3(256), 0, s, table, nemb, sv, e);
   DFOT_CHECK_HIP(hipGetLastError());
   return DFOT_OK;
 }
