@@ -138,34 +138,62 @@ class DFoTVideoPoseSampler:
         sm = sm[int(np.argmax(changed)):]
         self.trace.append({"context_mask": mask.copy(), "batch": batch_size, "rows": sm.shape[0]})
 
-        cond_full = self._process_conditions(conditions)
-        cond_rep, cond_nfe = None, 0
-        cmask_cache: Dict[bytes, torch.Tensor] = {}
-        xs = xs.contiguous()
-        s = capi.stream_ptr
-        strict = bool(getattr(self.noise_fn, "strict_order", False))
-
+        # ---- plan every step on the host first and upload the coefficient tables ONCE: the step loop below then
+        # contains no host<->device synchronisation, so the CPU runs ahead of the GPU and launch latency stays hidden
+        plans = []
         for m in range(sm.shape[0] - 1):
             frm, to = sm[m], sm[m + 1]
             mask = np.where((mask == 0) & (frm == -1), 2, mask)
             plan = history_guidance.plan(mask, frm, to, replacement_only=cfg.is_full_sequence)
-            nfe = plan.nfe
-            bm = batch_size * nfe
+            bm = batch_size * plan.nfe
             lv = plan.levels.reshape(bm, horizon)
             tl = plan.to_levels.reshape(bm, horizon)
             repl = plan.replace.reshape(bm, horizon)
             qa_c, qb_c = sch.q_sample_coef(lv)
             qa = np.where(repl, qa_c, np.float32(1)).astype(np.float32)
             qb = np.where(repl, qb_c, np.float32(0)).astype(np.float32)
-            sa, s1, an, cn, keepf, sigma = sch.ddim_coef(lv, tl)
-            kmodel = sch.model_level(lv)
-            tables = torch.from_numpy(np.stack([qa, qb, sa, s1, an, cn, keepf, kmodel]).astype(np.float32)).cuda()
-            weights = torch.from_numpy(plan.weights.astype(np.float32)).cuda()
-            gen = torch.from_numpy((mask == 0).astype(np.uint8)).cuda()
+            sa, s1, an, cn, keepf, _sigma = sch.ddim_coef(lv, tl)
+            tables = np.stack([qa, qb, sa, s1, an, cn, keepf, sch.model_level(lv)]).astype(np.float32)
+            plans.append(dict(plan=plan, nfe=plan.nfe, bm=bm, need_noise=bool(repl.any()), tables=tables,
+                              gen=(mask == 0).astype(np.uint8),
+                              cmask=None if plan.cond_masked is None else np.tile(plan.cond_masked, batch_size)))
+        if not plans:
+            return (xs[:, :-padding] if padding > 0 else xs), None
+        flat_dev = torch.from_numpy(np.concatenate([p_["tables"].ravel() for p_ in plans])).cuda()
+        gens_dev = torch.from_numpy(np.stack([p_["gen"] for p_ in plans])).cuda()
+        off = 0
+        cmask_cache: Dict[bytes, torch.Tensor] = {}
+        weight_cache: Dict[bytes, torch.Tensor] = {}
+        for i, p_ in enumerate(plans):
+            n = p_["tables"].size
+            p_["tables_dev"] = flat_dev[off:off + n].view(8, p_["bm"], horizon)
+            off += n
+            p_["gen_dev"] = gens_dev[i]
+            wkey = p_["plan"].weights.tobytes()
+            if wkey not in weight_cache:
+                weight_cache[wkey] = torch.from_numpy(p_["plan"].weights.astype(np.float32)).cuda()
+            p_["weights_dev"] = weight_cache[wkey]
+            p_["cmask_dev"] = None
+            if p_["cmask"] is not None:
+                # one device tensor per distinct mask pattern: the backbone keys its per-window pose caches on the
+                # identity of (external_cond, external_cond_mask)
+                ckey = p_["cmask"].tobytes()
+                if ckey not in cmask_cache:
+                    cmask_cache[ckey] = torch.from_numpy(p_["cmask"]).cuda()
+                p_["cmask_dev"] = cmask_cache[ckey]
+
+        cond_full = self._process_conditions(conditions)
+        cond_rep, cond_nfe = None, 0
+        xs = xs.contiguous()
+        s = capi.stream_ptr
+        strict = bool(getattr(self.noise_fn, "strict_order", False))
+
+        for p_ in plans:
+            nfe, bm, tables = p_["nfe"], p_["bm"], p_["tables_dev"]
             # noise for re-noised history tokens; with a strict-order noise source (golden replay) every draw
             # the reference makes is consumed, used or not (history_guidance.py:505,530; discrete_diffusion.py:525)
             noise = None
-            need = bool(repl.any())
+            need = p_["need_noise"]
             if history_guidance.is_simple:
                 if nfe == 2 and (need or strict):
                     drawn = self.noise_fn("q_sample", (batch_size, horizon, *x_shape))
@@ -184,23 +212,15 @@ class DFoTVideoPoseSampler:
             if cond_full is not None and cond_nfe != nfe:
                 cond_rep = cond_full if nfe == 1 else cond_full.repeat_interleave(nfe, dim=0)
                 cond_nfe = nfe
-            cmask = None
-            if plan.cond_masked is not None:
-                # one device tensor per distinct mask pattern: the backbone keys its per-window pose caches on
-                # the identity of (external_cond, external_cond_mask)
-                pattern = np.tile(plan.cond_masked, batch_size)
-                cmask = cmask_cache.get(pattern.tobytes())
-                if cmask is None:
-                    cmask = cmask_cache[pattern.tobytes()] = torch.from_numpy(pattern).cuda()
-            v = self.model(x_in, tables[7], cond_rep, cmask)
+            v = self.model(x_in, tables[7], cond_rep, p_["cmask_dev"])
             self.window_forwards += bm
             if strict:
                 self.noise_fn("ddim", (bm, horizon, *x_shape))  # multiplied by sigma = 0 in the reference
             xs_next = torch.empty_like(xs)
             capi.check(capi.lib.dfot_ddim_compose(capi.ptr(xs), capi.ptr(x_in), capi.ptr(v), capi.ptr(tables[2]),
                                                   capi.ptr(tables[3]), capi.ptr(tables[4]), capi.ptr(tables[5]),
-                                                  capi.ptr(tables[6]), capi.ptr(weights), capi.ptr(gen), capi.ptr(xs_next),
-                                                  batch_size, nfe, horizon, f, s()))
+                                                  capi.ptr(tables[6]), capi.ptr(p_["weights_dev"]), capi.ptr(p_["gen_dev"]),
+                                                  capi.ptr(xs_next), batch_size, nfe, horizon, f, s()))
             xs = xs_next
         if padding > 0:
             xs = xs[:, :-padding]
