@@ -21,6 +21,11 @@ struct GemmArgs {
   bf16* out_bf16 = nullptr;
   long ldo = 0;
   const float* resid = nullptr;  // E_F32: optional fp32 residual, same ld as out
+  // optional fused GroupNorm(32) partial statistics of the OUTPUT (E_F32 / E_BF16, N == channel count):
+  // gn_part[((bt*slots + slot)*32 + group)*2 + {sum,sumsq}], slot = 64-row block index within the image
+  float* gn_part = nullptr;
+  int gn_rows_per_bt = 0;
+  int gn_cpg = 0;                // channels per group: 4 or 8
   bf16* out2 = nullptr;          // E_QKV: columns >= split -> silu -> out2[m][col-split]
   long ldo2 = 0;
   int split = 0;
@@ -32,6 +37,8 @@ enum GemmVariant {
   GEMM_DMA3_128 = 2,  // 128x128 tile, LDS-DMA, 3-stage ring with counted vmcnt
   GEMM_DMA3_256 = 3,  // 256x128 tile (8 waves), LDS-DMA, 3-stage ring
   GEMM_DMA_256x256 = 4,  // 256x256 tile (16 waves), LDS-DMA, 2 stages: half the L2->LDS operand traffic per FLOP
+  GEMM_DMA_256x128 = 5,  // 256x128 tile (8 waves), 2 stages
+  GEMM_DMA_512x128 = 6,  // 512x128 tile (16 waves), 2 stages (N = 128 convolutions)
   GEMM_AUTO = -1      // pick by shape (gemm_pick_variant)
 };
 int gemm_pick_variant(int amode, int m, int n, int k);

@@ -218,6 +218,8 @@ __global__ __launch_bounds__((BM_T / 64) * (BN_T / 64) * 64) void gemm_kernel(Ge
   const int colq = lane & 15, rowq = (lane >> 4) * 4;
   const int nw = n0 + wn * 64;
   [[maybe_unused]] const bool has_res = g.resid != nullptr;
+  // fused GroupNorm partial sums of this wave's 64 rows: (gsum,gsq) = lane's first 4 columns, (gsum2,gsq2) = next 4
+  [[maybe_unused]] float gsum = 0.f, gsq = 0.f, gsum2 = 0.f, gsq2 = 0.f;
 #pragma unroll
   for (int mi = 0; mi < 4; ++mi) {
 #pragma unroll
@@ -238,6 +240,8 @@ __global__ __launch_bounds__((BM_T / 64) * (BN_T / 64) * 64) void gemm_kernel(Ge
           const long off = (mw + r) * g.ldo + col;
           if (has_res) v += *reinterpret_cast<const f32x4*>(g.resid + off);
           *reinterpret_cast<f32x4*>(g.out_f32 + off) = v;
+          gsum += v[0] + v[1] + v[2] + v[3];
+          gsq += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
         }
       }
     } else {
@@ -273,6 +277,67 @@ __global__ __launch_bounds__((BM_T / 64) * (BN_T / 64) * 64) void gemm_kernel(Ge
             o[4 + j] = f2bf(act ? silu_f(v1[j]) : v1[j]);
           }
           *reinterpret_cast<bf16x8*>(base + (mw + r) * ld + ocol) = o;
+          if constexpr (EPI == E_BF16) {  // statistics of the values as stored (bf16-rounded)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const float a = bf2f(o[j]), c = bf2f(o[4 + j]);
+              gsum += a;
+              gsq += a * a;
+              gsum2 += c;
+              gsq2 += c * c;
+            }
+          }
+        }
+      }
+    }
+  }
+  if constexpr (EPI == E_F32 || EPI == E_BF16) {
+    if (g.gn_part) {  // wave-uniform
+      const long mrow = (long)m0 + wm * 64;
+      const int bt = (int)(mrow / g.gn_rows_per_bt);
+      const int slots = g.gn_rows_per_bt / 64;
+      const int slot = (int)((mrow % g.gn_rows_per_bt) / 64);
+      float* dst = g.gn_part + ((long)bt * slots + slot) * 64;
+      if constexpr (EPI == E_F32) {
+        // lane = 4 columns (one group when cpg == 4, half a group when cpg == 8) x 16 rows; rows of the other
+        // three 16-lane groups are folded in with xor 16 / 32
+        if (g.gn_cpg == 8) {
+          gsum += __shfl_xor(gsum, 1);
+          gsq += __shfl_xor(gsq, 1);
+        }
+        gsum += __shfl_xor(gsum, 16);
+        gsq += __shfl_xor(gsq, 16);
+        gsum += __shfl_xor(gsum, 32);
+        gsq += __shfl_xor(gsq, 32);
+        const int col = nw + (lane & 15) * 4;
+        const bool writer = lane < 16 && col < g.N && (g.gn_cpg == 4 || (lane & 1) == 0);
+        if (writer) {
+          const int grp = col / g.gn_cpg;
+          dst[grp * 2] = gsum;
+          dst[grp * 2 + 1] = gsq;
+        }
+      } else {
+        // lane = 8 columns (two groups when cpg == 4, one when cpg == 8) x 8 rows; fold the other 7 row groups
+        if (g.gn_cpg == 8) {
+          gsum += gsum2;
+          gsq += gsq2;
+        }
+#pragma unroll
+        for (int o = 8; o < 64; o <<= 1) {
+          gsum += __shfl_xor(gsum, o);
+          gsq += __shfl_xor(gsq, o);
+          gsum2 += __shfl_xor(gsum2, o);
+          gsq2 += __shfl_xor(gsq2, o);
+        }
+        const int col = nw + (lane & 7) * 8;
+        if (lane < 8 && col < g.N) {
+          const int grp = col / g.gn_cpg;
+          dst[grp * 2] = gsum;
+          dst[grp * 2 + 1] = gsq;
+          if (g.gn_cpg == 4) {
+            dst[grp * 2 + 2] = gsum2;
+            dst[grp * 2 + 3] = gsq2;
+          }
         }
       }
     }
@@ -305,6 +370,8 @@ static int launch_v(int variant, const GemmArgs& g, hipStream_t s) {
     case GEMM_DMA3_128: return launch_t<128, 128, 3, AMODE, EPI, true>(g, s);
     case GEMM_DMA3_256: return launch_t<256, 128, 3, AMODE, EPI, true>(g, s);
     case GEMM_DMA_256x256: return launch_t<256, 256, 2, AMODE, EPI, true>(g, s);
+    case GEMM_DMA_256x128: return launch_t<256, 128, 2, AMODE, EPI, true>(g, s);
+    case GEMM_DMA_512x128: return launch_t<512, 128, 2, AMODE, EPI, true>(g, s);
   }
   set_error("gemm: unknown variant %d", variant);
   return DFOT_ERR_ARG;
@@ -318,13 +385,15 @@ int gemm_pick_variant(int amode, int m, int n, int k) {
   (void)k;
   const long tiles = (long)(m / 256) * ((n + 255) / 256);
   if (m % 256 == 0 && n >= 192 && tiles >= 160) return GEMM_DMA_256x256;
+  // N = 128 (level-0 convolutions): one column of tiles, so grow the tile along M instead (16 waves, 102 FLOP/B)
+  if (m % 512 == 0 && n <= 128 && m / 512 >= 256) return GEMM_DMA_512x128;
   return GEMM_DMA_128;
 }
 
 int launch_gemm(int amode, int epi, int variant, const GemmArgs& g, hipStream_t stream) {
   DFOT_REQUIRE(g.A && g.W, DFOT_ERR_ARG, "gemm: null operand");
   if (variant == GEMM_AUTO) variant = gemm_pick_variant(amode, g.M, g.N, g.K);
-  const int bm = (variant == GEMM_DMA3_256 || variant == GEMM_DMA_256x256) ? 256 : 128;
+  const int bm = variant == GEMM_DMA_512x128 ? 512 : (variant == GEMM_DMA3_256 || variant == GEMM_DMA_256x256 || variant == GEMM_DMA_256x128) ? 256 : 128;
   DFOT_REQUIRE(g.M > 0 && g.M % bm == 0, DFOT_ERR_SHAPE, "gemm: M=%d must be a positive multiple of %d", g.M, bm);
   DFOT_REQUIRE(g.K > 0 && g.K % BK == 0, DFOT_ERR_SHAPE, "gemm: K=%d must be a positive multiple of %d", g.K, BK);
   DFOT_REQUIRE(g.N > 0 && g.N % (epi == E_F32 ? 4 : 8) == 0, DFOT_ERR_SHAPE, "gemm: N=%d must be a multiple of %d", g.N, epi == E_F32 ? 4 : 8);
@@ -334,6 +403,11 @@ int launch_gemm(int amode, int epi, int variant, const GemmArgs& g, hipStream_t 
     DFOT_REQUIRE(g.Cin % BK == 0 && g.K == 9 * g.Cin, DFOT_ERR_SHAPE, "conv3x3: Cin=%d must be a multiple of %d", g.Cin, BK);
     DFOT_REQUIRE(g.zeros != nullptr, DFOT_ERR_ARG, "conv3x3: zero page missing");
     DFOT_REQUIRE(g.H > 0 && g.Wd > 0 && g.M % (g.H * g.Wd) == 0, DFOT_ERR_SHAPE, "conv3x3: M=%d not a whole number of %dx%d images", g.M, g.H, g.Wd);
+  }
+  if (g.gn_part) {
+    DFOT_REQUIRE(epi != E_QKV && (g.gn_cpg == 4 || g.gn_cpg == 8) && g.N == 32 * g.gn_cpg && g.gn_rows_per_bt % 64 == 0 &&
+                     g.gn_rows_per_bt % bm == 0,
+                 DFOT_ERR_SHAPE, "gemm: fused GroupNorm statistics need N = 32 groups of 4 or 8 channels and whole images per tile");
   }
   if (amode == A_DENSE) {
     switch (epi) {

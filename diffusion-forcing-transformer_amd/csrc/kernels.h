@@ -14,9 +14,11 @@ int launch_emb_pyramid(const bf16* emb0, bf16* emb1, bf16* emb2, bf16* emb3, int
 int launch_project_output(const float* x0, const float* w, const float* b, float* out, int bt, int res, int c0, int cout,
                           hipStream_t s);
 // ---- norms ----
-// stats[bt][32][2] = (mean, rstd) over (pixels x channels-of-group); partial = scratch [bt][nblk][32][2]
-int launch_gn_stats_f32(const float* x, float* partial, float* stats, int bt, int pixels, int c, float eps, hipStream_t s);
-int launch_gn_stats_bf16(const bf16* x, float* partial, float* stats, int bt, int pixels, int c, float eps, hipStream_t s);
+// GroupNorm(32): partial[bt][nblk][32][2] = (sum, sumsq) per block of pixels (standalone kernels below, or the fused
+// GEMM epilogue with nblk = pixels/64); launch_gn_finalize reduces them deterministically to stats[bt][32][2] = (mean, rstd)
+int launch_gn_partial_f32(const float* x, float* partial, int bt, int pixels, int c, hipStream_t s);
+int launch_gn_partial_bf16(const bf16* x, float* partial, int bt, int pixels, int c, hipStream_t s);
+int launch_gn_finalize(const float* partial, float* stats, int bt, int nblk, int pixels, int c, float eps, hipStream_t s);
 int gn_partial_blocks(int pixels);
 int launch_gn_apply_silu(const float* x, const float* stats, const float* gamma, const float* beta, bf16* out, int bt,
                          int pixels, int c, hipStream_t s);

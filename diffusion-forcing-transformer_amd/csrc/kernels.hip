@@ -55,28 +55,42 @@ int launch_noise_emb(const float* k, const float* freqs, const float* phases, co
 // --------------------------------------------------------------------------------------------
 // EmbedInput: conv k2 s2, Cin(3) -> C0, NCHW fp32 in, channels-last fp32 out (u_vit_blocks.py:16-30)
 // --------------------------------------------------------------------------------------------
-__global__ void embed_input_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
-                                   float* __restrict__ out, long total, int res, int cin, int c0) {
+__global__ __launch_bounds__(256) void embed_input_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                          const float* __restrict__ b, float* __restrict__ out, long total4,
+                                                          int res, int cin, int c0) {
+  extern __shared__ float wt[];  // [cin*4][c0] : tap-major so that consecutive channels are consecutive addresses
+  const int taps = cin * 4;
+  for (int i = threadIdx.x; i < taps * c0; i += blockDim.x) {
+    const int c = i % c0, t = i / c0;
+    wt[i] = w[(long)c * taps + t];
+  }
+  __syncthreads();
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= total) return;
-  const int c = (int)(idx % c0);
-  const long pix = idx / c0;
+  if (idx >= total4) return;
+  const int q = c0 / 4;
+  const int c4 = (int)(idx % q) * 4;
+  const long pix = idx / q;
   const int r0 = res / 2;
   const int px = (int)(pix % r0), py = (int)((pix / r0) % r0);
   const long bt = pix / ((long)r0 * r0);
-  float acc = b[c];
+  float4v acc = *reinterpret_cast<const float4v*>(b + c4);
   for (int ci = 0; ci < cin; ++ci) {
     const float* xp = x + ((bt * cin + ci) * res + 2 * py) * (long)res + 2 * px;
-    const float* wp = w + ((long)c * cin + ci) * 4;
-    acc += xp[0] * wp[0] + xp[1] * wp[1] + xp[res] * wp[2] + xp[res + 1] * wp[3];
+    const float2v top = *reinterpret_cast<const float2v*>(xp);
+    const float2v bot = *reinterpret_cast<const float2v*>(xp + res);
+    const float* wp = wt + (ci * 4) * c0 + c4;
+    acc += *reinterpret_cast<const float4v*>(wp) * top[0] + *reinterpret_cast<const float4v*>(wp + c0) * top[1] +
+           *reinterpret_cast<const float4v*>(wp + 2 * c0) * bot[0] + *reinterpret_cast<const float4v*>(wp + 3 * c0) * bot[1];
   }
-  out[idx] = acc;
+  *reinterpret_cast<float4v*>(out + pix * c0 + c4) = acc;
 }
 
 int launch_embed_input(const float* x, const float* w, const float* b, float* out, int bt, int res, int cin, int c0,
                        hipStream_t s) {
-  const long total = (long)bt * (res / 2) * (res / 2) * c0;
-  hipLaunchKernelGGL(embed_input_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, x, w, b, out, total, res, cin, c0);
+  DFOT_REQUIRE(c0 % 4 == 0 && res % 2 == 0, DFOT_ERR_SHAPE, "embed_input: channels %d / resolution %d unsupported", c0, res);
+  const long total4 = (long)bt * (res / 2) * (res / 2) * (c0 / 4);
+  hipLaunchKernelGGL(embed_input_kernel, dim3(cdiv(total4, 256)), dim3(256), (size_t)cin * 4 * c0 * sizeof(float), s, x, w, b,
+                     out, total4, res, cin, c0);
   DFOT_CHECK_HIP(hipGetLastError());
   return DFOT_OK;
 }
@@ -274,37 +288,47 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const T* __restrict__ x
   }
 }
 
-__global__ void gn_finalize_kernel(const float* __restrict__ partial, float* __restrict__ stats, int nblk, float inv_count,
-                                   float eps) {
-  const int bt = blockIdx.x, g = threadIdx.x;
-  if (g >= 32) return;
+// one workgroup per image: 8 threads per group sum nblk/8 partials each in a fixed order, then a fixed shuffle tree
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ partial, float* __restrict__ stats,
+                                                          int nblk, float inv_count, float eps) {
+  const int bt = blockIdx.x, g = threadIdx.x >> 3, part = threadIdx.x & 7;
   float s = 0.f, ss = 0.f;
-  for (int b = 0; b < nblk; ++b) {
+  for (int b = part; b < nblk; b += 8) {
     s += partial[(((long)bt * nblk + b) * 32 + g) * 2 + 0];
     ss += partial[(((long)bt * nblk + b) * 32 + g) * 2 + 1];
   }
-  const float mean = s * inv_count;
-  const float var = fmaxf(ss * inv_count - mean * mean, 0.f);
-  stats[(bt * 32 + g) * 2 + 0] = mean;
-  stats[(bt * 32 + g) * 2 + 1] = rsqrtf(var + eps);
+#pragma unroll
+  for (int o = 1; o < 8; o <<= 1) {
+    s += __shfl_xor(s, o);
+    ss += __shfl_xor(ss, o);
+  }
+  if (part == 0) {
+    const float mean = s * inv_count;
+    const float var = fmaxf(ss * inv_count - mean * mean, 0.f);
+    stats[(bt * 32 + g) * 2 + 0] = mean;
+    stats[(bt * 32 + g) * 2 + 1] = rsqrtf(var + eps);
+  }
 }
 
-template <typename T>
-static int launch_gn_stats_t(const T* x, float* partial, float* stats, int bt, int pixels, int c, float eps, hipStream_t s) {
-  DFOT_REQUIRE(c == 128 || c == 256 || c == 512 || c == 1024, DFOT_ERR_SHAPE, "group_norm: channels %d not in {128,256,512,1024}", c);
-  const int nblk = gn_partial_blocks(pixels);
-  hipLaunchKernelGGL(gn_partial_kernel<T>, dim3(nblk, bt), dim3(256), 0, s, x, partial, pixels, c);
-  DFOT_CHECK_HIP(hipGetLastError());
+int launch_gn_finalize(const float* partial, float* stats, int bt, int nblk, int pixels, int c, float eps, hipStream_t s) {
   const float inv = 1.f / ((float)pixels * (float)(c / 32));
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(bt), dim3(64), 0, s, partial, stats, nblk, inv, eps);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(bt), dim3(256), 0, s, partial, stats, nblk, inv, eps);
   DFOT_CHECK_HIP(hipGetLastError());
   return DFOT_OK;
 }
-int launch_gn_stats_f32(const float* x, float* partial, float* stats, int bt, int pixels, int c, float eps, hipStream_t s) {
-  return launch_gn_stats_t<float>(x, partial, stats, bt, pixels, c, eps, s);
+
+template <typename T>
+static int launch_gn_partial_t(const T* x, float* partial, int bt, int pixels, int c, hipStream_t s) {
+  DFOT_REQUIRE(c == 128 || c == 256 || c == 512 || c == 1024, DFOT_ERR_SHAPE, "group_norm: channels %d not in {128,256,512,1024}", c);
+  hipLaunchKernelGGL(gn_partial_kernel<T>, dim3(gn_partial_blocks(pixels), bt), dim3(256), 0, s, x, partial, pixels, c);
+  DFOT_CHECK_HIP(hipGetLastError());
+  return DFOT_OK;
 }
-int launch_gn_stats_bf16(const bf16* x, float* partial, float* stats, int bt, int pixels, int c, float eps, hipStream_t s) {
-  return launch_gn_stats_t<bf16>(x, partial, stats, bt, pixels, c, eps, s);
+int launch_gn_partial_f32(const float* x, float* partial, int bt, int pixels, int c, hipStream_t s) {
+  return launch_gn_partial_t<float>(x, partial, bt, pixels, c, s);
+}
+int launch_gn_partial_bf16(const bf16* x, float* partial, int bt, int pixels, int c, hipStream_t s) {
+  return launch_gn_partial_t<bf16>(x, partial, bt, pixels, c, s);
 }
 
 // GroupNorm apply + SiLU, fp32 in -> bf16 out (feeds the 3x3 conv's A operand)
@@ -353,28 +377,47 @@ int launch_gn_apply_silu(const float* x, const float* stats, const float* gamma,
 
 // sv for every FiLM projection of the model in ONE launch (FilmChunk table: kernels.h)
 __global__ __launch_bounds__(256) void film_vec_kernel(const FilmChunk* __restrict__ table, const float* __restrict__ nemb,
-                                                       float* __restrict__ sv, int e) {
-  // workgroup = 4 rows of one 64-row chunk (blockIdx.x = chunk*16 + part), one wave per row, all frames of blockIdx.y
+                                                       float* __restrict__ sv, int e, int nbt) {
+  // workgroup = 4 rows of one 64-row chunk (blockIdx.x = chunk*16 + part); one wave per row keeps the weight row in
+  // registers and loops over all frames, so every weight byte is read once
   const FilmChunk ck = table[blockIdx.x >> 4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = (blockIdx.x & 15) * 4 + wave;
-  const int bt = blockIdx.y;
-  const float* ne = nemb + (long)bt * e;
   const bf16* wr = ck.w + (long)r * e;
-  float acc = 0.f;
-  for (int i = lane * 8; i < e; i += 512) {
-    const bf16x8 wv = *reinterpret_cast<const bf16x8*>(wr + i);
-    const float4v a = *reinterpret_cast<const float4v*>(ne + i);
-    const float4v b = *reinterpret_cast<const float4v*>(ne + i + 4);
-    acc += bf2f(wv[0]) * a[0] + bf2f(wv[1]) * a[1] + bf2f(wv[2]) * a[2] + bf2f(wv[3]) * a[3] + bf2f(wv[4]) * b[0] +
-           bf2f(wv[5]) * b[1] + bf2f(wv[6]) * b[2] + bf2f(wv[7]) * b[3];
+  float wv[2][8];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int i = lane * 8 + k * 512;
+    if (i < e) {
+      const bf16x8 t = *reinterpret_cast<const bf16x8*>(wr + i);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) wv[k][j] = bf2f(t[j]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) wv[k][j] = 0.f;
+    }
   }
-  acc = wave_sum(acc);
-  if (lane == 0) sv[ck.out_off + (long)bt * ck.rows + r] = acc + ck.b[r];
+  const float bias = ck.b[r];
+  for (int bt = 0; bt < nbt; ++bt) {
+    const float* ne = nemb + (long)bt * e;
+    float acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int i = lane * 8 + k * 512;
+      if (i < e) {
+        const float4v a = *reinterpret_cast<const float4v*>(ne + i);
+        const float4v b = *reinterpret_cast<const float4v*>(ne + i + 4);
+        acc += wv[k][0] * a[0] + wv[k][1] * a[1] + wv[k][2] * a[2] + wv[k][3] * a[3] + wv[k][4] * b[0] + wv[k][5] * b[1] +
+               wv[k][6] * b[2] + wv[k][7] * b[3];
+      }
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) sv[ck.out_off + (long)bt * ck.rows + r] = acc + bias;
+  }
 }
 int launch_film_vec(const FilmChunk* table, int chunks, const float* nemb, float* sv, int bt, int e, hipStream_t s) {
-  DFOT_REQUIRE(e % 8 == 0, DFOT_ERR_SHAPE, "film_vec: emb dim %d must be a multiple of 8", e);
-  hipLaunchKernelGGL(film_vec_kernel, dim3(chunks * 16, bt), dim3(256), 0, s, table, nemb, sv, e);
+  DFOT_REQUIRE(e % 8 == 0 && e <= 1024, DFOT_ERR_SHAPE, "film_vec: emb dim %d must be a multiple of 8 and <= 1024", e);
+  hipLaunchKernelGGL(film_vec_kernel, dim3(chunks * 16), dim3(256), 0, s, table, nemb, sv, e, bt);
   DFOT_CHECK_HIP(hipGetLastError());
   return DFOT_OK;
 }

@@ -90,7 +90,8 @@ struct dfot_uvit_s {
   size_t ws_bytes = 0;
   std::vector<void*> ws_owned;
   float *nemb = nullptr, *nhid = nullptr, *X[4] = {nullptr, nullptr, nullptr, nullptr}, *HSA[3] = {nullptr, nullptr, nullptr}, *tmp = nullptr,
-        *gn_partial = nullptr, *gn_stats = nullptr, *sv = nullptr;
+        *gn_partial = nullptr, *gn_partial2 = nullptr, *gn_stats = nullptr, *sv = nullptr;
+  int gn1_nblk = 0;  // > 0: gn_partial holds that many partial blocks per image for the next GroupNorm input
   FilmChunk* film_table = nullptr;
   int film_chunks = 0;
   uint8_t* cond_mask = nullptr;  // device copy of the external_cond_mask of the cached conditions
@@ -343,25 +344,39 @@ __global__ void add_vec_kernel(const float* a, const float* b, float* o, int n) 
 // ------------------------------------------------------------------------------------------
 // forward pieces
 // ------------------------------------------------------------------------------------------
+// GroupNorm statistics are produced by whoever writes the tensor: the 3x3-conv GEMM epilogues emit per-64-row partial
+// sums (conv1 -> statistics of h; conv2 / Downsample conv -> statistics of the next block's input); only the first block
+// after embed_input / upsample_add needs the standalone partial kernel.  h->gn1_nblk > 0 means gn_partial already holds
+// the partials of X[lvl].
 static int run_res_block(dfot_uvit_s* h, const ResW& w, int lvl, int bt, hipStream_t s) {
   const int c = w.c, rr = h->r[lvl], pix = rr * rr;
   const int m = bt * pix;
+  const int slots = pix / 64;
   float* x = h->X[lvl];
   int rc = 0;
-  if ((rc = launch_gn_stats_f32(x, h->gn_partial, h->gn_stats, bt, pix, c, h->cfg.eps, s))) return rc;
+  if (h->gn1_nblk == 0) {
+    if ((rc = launch_gn_partial_f32(x, h->gn_partial, bt, pix, c, s))) return rc;
+    h->gn1_nblk = gn_partial_blocks(pix);
+  }
+  if ((rc = launch_gn_finalize(h->gn_partial, h->gn_stats, bt, h->gn1_nblk, pix, c, h->cfg.eps, s))) return rc;
+  h->gn1_nblk = 0;
   if ((rc = launch_gn_apply_silu(x, h->gn_stats, w.g1, w.be1, h->s1, bt, pix, c, s))) return rc;
   GemmArgs g;
   g.A = h->s1; g.W = w.w1; g.M = m; g.N = c; g.K = 9 * c; g.H = rr; g.Wd = rr; g.Cin = c; g.zeros = h->zeros;
   g.bias = w.bias1; g.out_bf16 = h->hbf; g.ldo = c;
+  g.gn_part = h->gn_partial2; g.gn_rows_per_bt = pix; g.gn_cpg = c / 32;
   if ((rc = launch_gemm(A_CONV3, E_BF16, h->gemm_variant, g, s))) return rc;
-  if ((rc = launch_gn_stats_bf16(h->hbf, h->gn_partial, h->gn_stats, bt, pix, c, h->cfg.eps, s))) return rc;
+  if ((rc = launch_gn_finalize(h->gn_partial2, h->gn_stats, bt, slots, pix, c, h->cfg.eps, s))) return rc;
   if ((rc = launch_gn_film_silu(h->hbf, h->gn_stats, w.g2, w.be2, w.fcache, h->sv + w.sv_off,
                                 h->have_mask ? h->cond_mask : nullptr, h->s1, bt, pix, c, h->T, s)))
     return rc;
   GemmArgs o;
   o.A = h->s1; o.W = w.w2; o.M = m; o.N = c; o.K = 9 * c; o.H = rr; o.Wd = rr; o.Cin = c; o.zeros = h->zeros;
   o.bias = w.bias2; o.out_f32 = x; o.resid = x; o.ldo = c;
-  return launch_gemm(A_CONV3, E_F32, h->gemm_variant, o, s);
+  o.gn_part = h->gn_partial; o.gn_rows_per_bt = pix; o.gn_cpg = c / 32;
+  if ((rc = launch_gemm(A_CONV3, E_F32, h->gemm_variant, o, s))) return rc;
+  h->gn1_nblk = slots;
+  return DFOT_OK;
 }
 
 static int run_tr_block(dfot_uvit_s* h, const TrW& w, int lvl, int batch, hipStream_t s) {
@@ -397,7 +412,12 @@ static int run_down(dfot_uvit_s* h, int l, int bt, hipStream_t s) {
   GemmArgs g;
   g.A = h->s1; g.W = h->down_conv[l].w; g.M = bt * (rr / 2) * (rr / 2); g.N = cout; g.K = 9 * cin; g.H = rr / 2; g.Wd = rr / 2;
   g.Cin = cin; g.zeros = h->zeros; g.bias = h->down_conv[l].b; g.out_f32 = h->HSA[l]; g.ldo = cout;
+  const bool next_is_res = l + 1 < 2;
+  if (next_is_res) {
+    g.gn_part = h->gn_partial; g.gn_rows_per_bt = (rr / 2) * (rr / 2); g.gn_cpg = cout / 32;
+  }
   if ((rc = launch_gemm(A_CONV3, E_F32, h->gemm_variant, g, s))) return rc;
+  h->gn1_nblk = next_is_res ? g.gn_rows_per_bt / 64 : 0;
   return copy_f32(h->X[l + 1], h->HSA[l], (size_t)g.M * cout, s);
 }
 
@@ -410,6 +430,7 @@ static int run_up(dfot_uvit_s* h, int l, int bt, hipStream_t s) {  // level l+1 
   g.A = h->s1; g.W = h->up_conv[l].w; g.M = bt * rr * rr; g.N = cout; g.K = 9 * cin; g.H = rr; g.Wd = rr; g.Cin = cin;
   g.zeros = h->zeros; g.bias = h->up_conv[l].b; g.out_f32 = h->tmp; g.ldo = cout;
   if ((rc = launch_gemm(A_CONV3, E_F32, h->gemm_variant, g, s))) return rc;
+  h->gn1_nblk = 0;  // X[l] is rewritten by an elementwise kernel: its statistics come from the standalone kernel
   return launch_upsample_add(h->tmp, h->X[l], h->X[l], bt, rr, rr, cout, s);
 }
 
@@ -532,7 +553,8 @@ int dfot_uvit_reserve(dfot_uvit_t h, int max_batch) {
   if ((rc = dev_alloc(h, &h->s1, act, true))) return rc;
   if ((rc = dev_alloc(h, &h->hbf, act, true))) return rc;
   if ((rc = dev_alloc(h, &h->tmp, tmpn, true))) return rc;
-  if ((rc = dev_alloc(h, &h->gn_partial, bt * gn_partial_blocks((int)pix[0]) * 64, true))) return rc;
+  if ((rc = dev_alloc(h, &h->gn_partial, bt * (pix[0] / 64) * 64, true))) return rc;
+  if ((rc = dev_alloc(h, &h->gn_partial2, bt * (pix[0] / 64) * 64, true))) return rc;
   if ((rc = dev_alloc(h, &h->gn_stats, bt * 64, true))) return rc;
   size_t mtr = 0, mc = 0;
   for (int l = 2; l < 4; ++l) {
@@ -669,6 +691,7 @@ int dfot_uvit_forward_cached(dfot_uvit_t h, const float* x, const float* noise_l
     return rc;
   if ((rc = launch_film_vec(h->film_table, h->film_chunks, h->nemb, h->sv, bt, e, s))) return rc;
   if ((rc = launch_embed_input(x, h->ein_w, h->ein_b, h->X[0], bt, c.resolution, c.in_channels, h->ch[0], s))) return rc;
+  h->gn1_nblk = 0;
 
   for (int l = 0; l < 2; ++l) {
     for (const ResW& w : h->down_res[l])

@@ -123,7 +123,8 @@ int dfot_ddim_compose(const float* x, const float* x_in, const float* v, const f
 /* ---- unit-testable primitives ------------------------------------------------------------------ */
 /* C[M,N] (fp32) = A[M,K] (bf16, row stride lda) * W[N,K]^T (bf16) + bias[N] (fp32 or NULL)
  * variant: -1 auto, 0 = 128-tile register staging, 1 = 128-tile LDS-DMA 2 stages, 2 = 128-tile LDS-DMA 3-stage ring,
- * 3 = 256x128-tile LDS-DMA 3-stage ring (M % 256 == 0) */
+ * 3 = 256x128-tile LDS-DMA 3-stage ring, 4 = 256x256 tile (16 waves), 5 = 256x128 two stages, 6 = 512x128 (16 waves);
+ * variants 3-6 need M % 256 (512 for 6) == 0 */
 int dfot_op_gemm(const void* a_bf16, int lda, const void* w_bf16, const float* bias, float* c, int m, int n, int k,
                  int variant, void* stream);
 /* y[BT,H,W,Cout] (fp32) = conv3x3(pad 1)(a[BT,H,W,Cin] bf16, w[Cout][9*Cin] bf16 tap-major) + bias */

@@ -35,7 +35,7 @@ def report(name, got, ref):
     return err, rel
 
 
-@pytest.mark.parametrize("dma", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("dma", [0, 1, 2, 3, 4, 5])
 @pytest.mark.parametrize("m,n,k", [(256, 128, 64), (256, 192, 128), (1024, 576, 576), (256, 4032, 576), (768, 100, 2880),
                                    (512, 256, 192)])
 def test_gemm(capi, dma, m, n, k):
@@ -48,6 +48,18 @@ def test_gemm(capi, dma, m, n, k):
     ref = a.float() @ w.float().t() + bias
     err, rel = report(f"gemm dma={dma} {m}x{n}x{k}", out, ref)
     assert torch.isfinite(out).all()
+    assert rel < 1e-5 and err < 1e-3
+
+
+@pytest.mark.parametrize("m,n,k", [(512, 128, 192), (1024, 100, 640)])
+def test_gemm_512_row_tile(capi, m, n, k):
+    g = torch.Generator().manual_seed(m + n + k)
+    a = torch.randn(m, k, generator=g).bfloat16().cuda()
+    w = (torch.randn(n, k, generator=g) / math.sqrt(k)).bfloat16().cuda()
+    out = torch.full((m, n), float("nan"), device="cuda")
+    capi.check(capi.lib.dfot_op_gemm(P(a), k, P(w), None, P(out), m, n, k, 6, S()))
+    ref = a.float() @ w.float().t()
+    err, rel = report(f"gemm 512x128 {m}x{n}x{k}", out, ref)
     assert rel < 1e-5 and err < 1e-3
 
 
