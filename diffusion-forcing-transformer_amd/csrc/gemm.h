@@ -26,9 +26,17 @@ struct GemmArgs {
   float* gn_part = nullptr;
   int gn_rows_per_bt = 0;
   int gn_cpg = 0;                // channels per group: 4 or 8
-  bf16* out2 = nullptr;          // E_QKV: columns >= split -> silu -> out2[m][col-split]
+  // E_QKV (fused_attn_mlp_proj): columns [0,C) q | [C,2C) k | [2C,3C) v | [3C,7C) MLP hidden, C = heads*d = split/3.
+  //   q,k: per-head RMSNorm (weights qw/kw) + RoPE (rope_cs[tok][d/2][2] = cos,sin) (+ q *= qscale), written with v
+  //   as [B][heads][ntok][d] bf16 for the attention kernel; MLP half: SiLU -> out2[m][col-split] (row stride ldo2)
+  bf16* out2 = nullptr;
   long ldo2 = 0;
   int split = 0;
+  bf16 *q = nullptr, *k = nullptr, *v = nullptr;
+  const float *qw = nullptr, *kw = nullptr, *rope_cs = nullptr;
+  int heads = 0, d = 0, ntok = 0;
+  float qscale = 1.f;
+  float eps = 1e-6f;
 };
 
 enum GemmVariant {

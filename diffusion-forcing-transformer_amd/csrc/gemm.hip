@@ -220,6 +220,15 @@ __global__ __launch_bounds__((BM_T / 64) * (BN_T / 64) * 64) void gemm_kernel(Ge
   [[maybe_unused]] const bool has_res = g.resid != nullptr;
   // fused GroupNorm partial sums of this wave's 64 rows: (gsum,gsq) = lane's first 4 columns, (gsum2,gsq2) = next 4
   [[maybe_unused]] float gsum = 0.f, gsq = 0.f, gsum2 = 0.f, gsq2 = 0.f;
+  // lane geometry of the read-back: fp32 output = 4 columns x rows p*4 + lane/16; bf16 outputs = 8 columns x rows p*8 + lane/8
+  const int cw = EPI == E_F32 ? (lane & 15) * 4 : (lane & 7) * 8;
+  const int col = nw + cw;
+  const bool live = col < g.N;  // N is a multiple of the lane's column count, so a lane is entirely in or out
+  f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = {0.f, 0.f, 0.f, 0.f};
+  if (g.bias && live) {
+    b0 = *reinterpret_cast<const f32x4*>(g.bias + col);
+    if constexpr (EPI != E_F32) b1 = *reinterpret_cast<const f32x4*>(g.bias + col + 4);
+  }
 #pragma unroll
   for (int mi = 0; mi < 4; ++mi) {
 #pragma unroll
@@ -228,15 +237,11 @@ __global__ __launch_bounds__((BM_T / 64) * (BN_T / 64) * 64) void gemm_kernel(Ge
       for (int j = 0; j < 4; ++j) ep[(rowq + j) * EP_LD + ni * 16 + colq] = acc[mi][ni][j];
     const long mw = (long)m0 + wm * 64 + mi * 16;
     if constexpr (EPI == E_F32) {
-      const int c4 = (lane & 15) * 4;
-      const int col = nw + c4;
-      if (col < g.N) {
-        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-        if (g.bias) bv = *reinterpret_cast<const f32x4*>(g.bias + col);
+      if (live) {
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
           const int r = p * 4 + (lane >> 4);
-          f32x4 v = *reinterpret_cast<const f32x4*>(ep + r * EP_LD + c4) + bv;
+          f32x4 v = *reinterpret_cast<const f32x4*>(ep + r * EP_LD + cw) + b0;
           const long off = (mw + r) * g.ldo + col;
           if (has_res) v += *reinterpret_cast<const f32x4*>(g.resid + off);
           *reinterpret_cast<f32x4*>(g.out_f32 + off) = v;
@@ -245,41 +250,29 @@ __global__ __launch_bounds__((BM_T / 64) * (BN_T / 64) * 64) void gemm_kernel(Ge
         }
       }
     } else {
-      const int c8 = (lane & 7) * 8;
-      const int col = nw + c8;
-      if (col < g.N) {
-        f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = {0.f, 0.f, 0.f, 0.f};
-        if (g.bias) {
-          b0 = *reinterpret_cast<const f32x4*>(g.bias + col);
-          b1 = *reinterpret_cast<const f32x4*>(g.bias + col + 4);
+      float vals[2][8];
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        const int r = p * 8 + (lane >> 3);
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(ep + r * EP_LD + cw) + b0;
+        const f32x4 v1 = *reinterpret_cast<const f32x4*>(ep + r * EP_LD + cw + 4) + b1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          vals[p][j] = v0[j];
+          vals[p][4 + j] = v1[j];
         }
-        bool act = false;
-        bf16* base = g.out_bf16;
-        long ld = g.ldo;
-        int ocol = col;
-        if constexpr (EPI == E_QKV) {
-          if (col >= g.split) {  // MLP half: SiLU, second output tensor
-            act = true;
-            base = g.out2;
-            ld = g.ldo2;
-            ocol = col - g.split;
-          }
-        }
+      }
+      if constexpr (EPI == E_BF16) {
+        if (live) {
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
-          const int r = p * 8 + (lane >> 3);
-          const f32x4 v0 = *reinterpret_cast<const f32x4*>(ep + r * EP_LD + c8) + b0;
-          const f32x4 v1 = *reinterpret_cast<const f32x4*>(ep + r * EP_LD + c8 + 4) + b1;
-          bf16x8 o;
+          for (int p = 0; p < 2; ++p) {
+            const int r = p * 8 + (lane >> 3);
+            bf16x8 o;
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            o[j] = f2bf(act ? silu_f(v0[j]) : v0[j]);
-            o[4 + j] = f2bf(act ? silu_f(v1[j]) : v1[j]);
-          }
-          *reinterpret_cast<bf16x8*>(base + (mw + r) * ld + ocol) = o;
-          if constexpr (EPI == E_BF16) {  // statistics of the values as stored (bf16-rounded)
+            for (int j = 0; j < 8; ++j) o[j] = f2bf(vals[p][j]);
+            *reinterpret_cast<bf16x8*>(g.out_bf16 + (mw + r) * g.ldo + col) = o;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < 4; ++j) {  // GroupNorm statistics of the values as stored (bf16-rounded)
               const float a = bf2f(o[j]), c = bf2f(o[4 + j]);
               gsum += a;
               gsq += a * a;
@@ -288,9 +281,77 @@ __global__ __launch_bounds__((BM_T / 64) * (BN_T / 64) * 64) void gemm_kernel(Ge
             }
           }
         }
+      } else {  // E_QKV
+        // The wave's 64 columns lie inside one region (q | k | v | MLP) and, for q/k, inside one head: the whole head
+        // when d = 64, half of it when d = 128 -- then the other half belongs to wave^1 and the squared sums are
+        // exchanged through LDS.  Everything up to the barrier is executed by every lane of the workgroup.
+        float ssq[2];
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+          float t = 0.f;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) t += vals[p][j] * vals[p][j];
+#pragma unroll
+          for (int o = 1; o < 8; o <<= 1) t += __shfl_xor(t, o);  // 8 lanes = this wave's 64 columns of one row
+          ssq[p] = t;
+        }
+        if (g.d == 128) {  // workgroup-uniform
+          float* xch = reinterpret_cast<float*>(smem) + NW * 16 * EP_LD + (mi & 1) * NW * 16;
+          if ((lane & 7) == 0) {
+            xch[wave * 16 + (lane >> 3)] = ssq[0];
+            xch[wave * 16 + 8 + (lane >> 3)] = ssq[1];
+          }
+          __syncthreads();
+          ssq[0] += xch[(wave ^ 1) * 16 + (lane >> 3)];
+          ssq[1] += xch[(wave ^ 1) * 16 + 8 + (lane >> 3)];
+        }
+        if (live) {
+          if (col >= g.split) {  // MLP half: SiLU
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+              const int r = p * 8 + (lane >> 3);
+              bf16x8 o;
+#pragma unroll
+              for (int j = 0; j < 8; ++j) o[j] = f2bf(silu_f(vals[p][j]));
+              *reinterpret_cast<bf16x8*>(g.out2 + (mw + r) * g.ldo2 + (col - g.split)) = o;
+            }
+          } else {
+            const int cdim = g.split / 3;
+            const int which = col / cdim;
+            const int cc = col - which * cdim;
+            const int head = cc / g.d, e0 = cc % g.d;
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+              const long row = mw + p * 8 + (lane >> 3);
+              const long bidx = row / g.ntok;
+              const int tok = (int)(row % g.ntok);
+              bf16x8 o;
+              if (which == 2) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = f2bf(vals[p][j]);
+              } else {
+                const float rs = rsqrtf(ssq[p] / (float)g.d + g.eps);
+                const float* wgt = (which == 0 ? g.qw : g.kw) + e0;
+                const float mul = which == 0 ? g.qscale : 1.f;
+                const float* cs = g.rope_cs + ((long)tok * (g.d / 2) + e0 / 2) * 2;
+#pragma unroll
+                for (int pr = 0; pr < 4; ++pr) {
+                  const float x0 = vals[p][2 * pr] * rs * wgt[2 * pr];
+                  const float x1 = vals[p][2 * pr + 1] * rs * wgt[2 * pr + 1];
+                  const float co = cs[2 * pr], si = cs[2 * pr + 1];
+                  o[2 * pr] = f2bf((x0 * co - x1 * si) * mul);
+                  o[2 * pr + 1] = f2bf((x1 * co + x0 * si) * mul);
+                }
+              }
+              bf16* dst = which == 0 ? g.q : (which == 1 ? g.k : g.v);
+              *reinterpret_cast<bf16x8*>(dst + ((bidx * g.heads + head) * g.ntok + tok) * (long)g.d + e0) = o;
+            }
+          }
+        }
       }
     }
   }
+
   if constexpr (EPI == E_F32 || EPI == E_BF16) {
     if (g.gn_part) {  // wave-uniform
       const long mrow = (long)m0 + wm * 64;
@@ -309,9 +370,7 @@ __global__ __launch_bounds__((BM_T / 64) * (BN_T / 64) * 64) void gemm_kernel(Ge
         gsq += __shfl_xor(gsq, 16);
         gsum += __shfl_xor(gsum, 32);
         gsq += __shfl_xor(gsq, 32);
-        const int col = nw + (lane & 15) * 4;
-        const bool writer = lane < 16 && col < g.N && (g.gn_cpg == 4 || (lane & 1) == 0);
-        if (writer) {
+        if (lane < 16 && live && (g.gn_cpg == 4 || (lane & 1) == 0)) {
           const int grp = col / g.gn_cpg;
           dst[grp * 2] = gsum;
           dst[grp * 2 + 1] = gsq;
@@ -329,8 +388,7 @@ __global__ __launch_bounds__((BM_T / 64) * (BN_T / 64) * 64) void gemm_kernel(Ge
           gsum2 += __shfl_xor(gsum2, o);
           gsq2 += __shfl_xor(gsq2, o);
         }
-        const int col = nw + (lane & 7) * 8;
-        if (lane < 8 && col < g.N) {
+        if (lane < 8 && live) {
           const int grp = col / g.gn_cpg;
           dst[grp * 2] = gsum;
           dst[grp * 2 + 1] = gsq;
@@ -348,7 +406,7 @@ template <int BM_T, int BN_T, int NST, int AMODE, int EPI, bool DMA>
 static int launch_t(const GemmArgs& g, hipStream_t stream) {
   constexpr int nthreads = (BM_T / 64) * (BN_T / 64) * 64;
   constexpr int stage_lds = NST * (BM_T + BN_T) * BK * 2;
-  constexpr int ep_lds = (nthreads / 64) * 16 * EP_LD * 4;
+  constexpr int ep_lds = (nthreads / 64) * 16 * EP_LD * 4 + 2 * (nthreads / 64) * 16 * 4;
   constexpr int lds = stage_lds > ep_lds ? stage_lds : ep_lds;
   const int tiles = (g.M / BM_T) * ((g.N + BN_T - 1) / BN_T);
   auto kern = gemm_kernel<BM_T, BN_T, NST, AMODE, EPI, DMA>;
@@ -397,12 +455,17 @@ int launch_gemm(int amode, int epi, int variant, const GemmArgs& g, hipStream_t 
   DFOT_REQUIRE(g.M > 0 && g.M % bm == 0, DFOT_ERR_SHAPE, "gemm: M=%d must be a positive multiple of %d", g.M, bm);
   DFOT_REQUIRE(g.K > 0 && g.K % BK == 0, DFOT_ERR_SHAPE, "gemm: K=%d must be a positive multiple of %d", g.K, BK);
   DFOT_REQUIRE(g.N > 0 && g.N % (epi == E_F32 ? 4 : 8) == 0, DFOT_ERR_SHAPE, "gemm: N=%d must be a multiple of %d", g.N, epi == E_F32 ? 4 : 8);
-  DFOT_REQUIRE(g.ldo % (epi == E_F32 ? 4 : 8) == 0 && (epi != E_QKV || (g.ldo2 % 8 == 0 && g.split % 64 == 0)), DFOT_ERR_SHAPE,
-               "gemm: output row strides must be multiples of %d", epi == E_F32 ? 4 : 8);
+  DFOT_REQUIRE((epi == E_QKV || g.ldo % (epi == E_F32 ? 4 : 8) == 0) && (epi != E_QKV || (g.ldo2 % 8 == 0 && g.split % 64 == 0)),
+               DFOT_ERR_SHAPE, "gemm: output row strides must be multiples of %d", epi == E_F32 ? 4 : 8);
   if (amode == A_CONV3) {
     DFOT_REQUIRE(g.Cin % BK == 0 && g.K == 9 * g.Cin, DFOT_ERR_SHAPE, "conv3x3: Cin=%d must be a multiple of %d", g.Cin, BK);
     DFOT_REQUIRE(g.zeros != nullptr, DFOT_ERR_ARG, "conv3x3: zero page missing");
     DFOT_REQUIRE(g.H > 0 && g.Wd > 0 && g.M % (g.H * g.Wd) == 0, DFOT_ERR_SHAPE, "conv3x3: M=%d not a whole number of %dx%d images", g.M, g.H, g.Wd);
+  }
+  if (epi == E_QKV) {
+    DFOT_REQUIRE(g.q && g.k && g.v && g.qw && g.kw && g.rope_cs && g.out2, DFOT_ERR_ARG, "qkv epilogue: null pointer");
+    DFOT_REQUIRE((g.d == 64 || g.d == 128) && g.heads > 0 && g.split == 3 * g.heads * g.d && g.ntok > 0 && g.M % g.ntok == 0,
+                 DFOT_ERR_SHAPE, "qkv epilogue: heads=%d d=%d split=%d ntok=%d M=%d", g.heads, g.d, g.split, g.ntok, g.M);
   }
   if (g.gn_part) {
     DFOT_REQUIRE(epi != E_QKV && (g.gn_cpg == 4 || g.gn_cpg == 8) && g.N == 32 * g.gn_cpg && g.gn_rows_per_bt % 64 == 0 &&

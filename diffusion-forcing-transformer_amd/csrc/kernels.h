@@ -36,8 +36,6 @@ int launch_gn_film_silu(const bf16* h, const float* stats, const float* gamma, c
 int launch_rms_film(const float* x, const float* w, const bf16* fcache, const float* sv, const uint8_t* cond_mask, bf16* out,
                     long m, int c, int rows_per_bt, int tokens, float eps, hipStream_t s);
 
-int launch_qk_norm_rope(const bf16* qkv, const float* qw, const float* kw, const float* cs, bf16* q, bf16* k, bf16* v,
-                        int batch, int n, int heads, int d, float qscale, float eps, hipStream_t s);
 // ---- resampling / skips ----
 int launch_pool2_bf16(const float* x, bf16* out, int bt, int h, int w, int c, hipStream_t s);
 int launch_sub_bf16(const float* a, const float* b, bf16* out, long n, hipStream_t s);

@@ -547,66 +547,6 @@ int launch_rms_film(const float* x, const float* w, const bf16* fcache, const fl
 }
 
 // --------------------------------------------------------------------------------------------
-// per-head QK RMSNorm + RoPE-3D + split to [B][heads][N][d]  (u_vit_blocks.py:253-259, embeddings.py:204-215)
-// qkv [B*N][3*heads*d] bf16, column order "(qkv h d)"; cs [N][d/2][2] = (cos, sin) of the pair's angle
-// thread = 8 consecutive head-dim elements; q is additionally multiplied by qscale (= log2(e)/sqrt(d))
-// --------------------------------------------------------------------------------------------
-__global__ void qk_norm_rope_kernel(const bf16* __restrict__ qkv, const float* __restrict__ qw, const float* __restrict__ kw,
-                                    const float* __restrict__ cs, bf16* __restrict__ q, bf16* __restrict__ k,
-                                    bf16* __restrict__ v, long total, int n, int heads, int d, float qscale, float eps) {
-  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  const bool live = idx < total;
-  const int tph = d / 8;
-  const long safe = live ? idx : 0;
-  const int ch = (int)(safe % tph);
-  const int head = (int)((safe / tph) % heads);
-  const int which = (int)((safe / ((long)tph * heads)) % 3);
-  const long m = safe / ((long)tph * heads * 3);
-  const int c = heads * d;
-  const bf16x8 in = *reinterpret_cast<const bf16x8*>(qkv + m * 3 * c + (long)which * c + head * d + ch * 8);
-  float x[8];
-  float ss = 0.f;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    x[j] = bf2f(in[j]);
-    ss += x[j] * x[j];
-  }
-  for (int o = 1; o < tph; o <<= 1) ss += __shfl_xor(ss, o);
-  const long b = m / n;
-  const int tok = (int)(m % n);
-  bf16x8 out;
-  if (which == 2) {
-    out = in;
-  } else {
-    const float rs = rsqrtf(ss / (float)d + eps);
-    const float* wgt = which == 0 ? qw : kw;
-    const float mul = which == 0 ? qscale : 1.f;
-    const float* csp = cs + ((long)tok * (d / 2) + ch * 4) * 2;
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      const float x0 = x[2 * p] * rs * wgt[ch * 8 + 2 * p];
-      const float x1 = x[2 * p + 1] * rs * wgt[ch * 8 + 2 * p + 1];
-      const float co = csp[2 * p], si = csp[2 * p + 1];
-      out[2 * p] = f2bf((x0 * co - x1 * si) * mul);
-      out[2 * p + 1] = f2bf((x1 * co + x0 * si) * mul);
-    }
-  }
-  if (!live) return;
-  bf16* dst = which == 0 ? q : (which == 1 ? k : v);
-  *reinterpret_cast<bf16x8*>(dst + ((b * heads + head) * n + tok) * (long)d + ch * 8) = out;
-}
-
-int launch_qk_norm_rope(const bf16* qkv, const float* qw, const float* kw, const float* cs, bf16* q, bf16* k, bf16* v,
-                        int batch, int n, int heads, int d, float qscale, float eps, hipStream_t s) {
-  DFOT_REQUIRE(d == 64 || d == 128, DFOT_ERR_SHAPE, "qk_norm_rope: head dim %d not in {64,128}", d);
-  const long total = (long)batch * n * 3 * heads * (d / 8);
-  hipLaunchKernelGGL(qk_norm_rope_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, qkv, qw, kw, cs, q, k, v, total, n,
-                     heads, d, qscale, eps);
-  DFOT_CHECK_HIP(hipGetLastError());
-  return DFOT_OK;
-}
-
-// --------------------------------------------------------------------------------------------
 // resampling and skip arithmetic (u_vit_blocks.py:284-314, u_vit3d_pose.py:124-127)
 // --------------------------------------------------------------------------------------------
 __global__ void pool2_bf16_kernel(const float* __restrict__ x, bf16* __restrict__ out, long total4, int h, int w, int c) {

@@ -97,7 +97,7 @@ struct dfot_uvit_s {
   uint8_t* cond_mask = nullptr;  // device copy of the external_cond_mask of the cached conditions
   bool have_mask = false;
   int cond_batch = 0;            // batch the pose caches were built for (0 = none)
-  bf16 *acond = nullptr, *emb[4] = {nullptr, nullptr, nullptr, nullptr}, *s1 = nullptr, *hbf = nullptr, *qkv = nullptr,
+  bf16 *acond = nullptr, *emb[4] = {nullptr, nullptr, nullptr, nullptr}, *s1 = nullptr, *hbf = nullptr,
        *cat = nullptr, *q = nullptr, *k = nullptr, *v = nullptr;
   int last_batch = 0;
   int gemm_variant = GEMM_AUTO;
@@ -389,12 +389,10 @@ static int run_tr_block(dfot_uvit_s* h, const TrW& w, int lvl, int batch, hipStr
     return rc;
   GemmArgs p;
   p.A = h->s1; p.lda = c; p.W = w.w_fused; p.M = m; p.N = 7 * c; p.K = c; p.bias = w.b_fused;
-  p.out_bf16 = h->qkv; p.ldo = 3 * c; p.out2 = h->cat + c; p.ldo2 = 5 * c; p.split = 3 * c;
+  p.out2 = h->cat + c; p.ldo2 = 5 * c; p.split = 3 * c;
+  p.q = h->q; p.k = h->k; p.v = h->v; p.qw = w.qw; p.kw = w.kw; p.rope_cs = h->rope_cs[lvl]; p.heads = h->heads; p.d = d;
+  p.ntok = n; p.qscale = 1.4426950408889634f / sqrtf((float)d); p.eps = h->cfg.eps;
   if ((rc = launch_gemm(A_DENSE, E_QKV, h->gemm_variant, p, s))) return rc;
-  const float qscale = 1.4426950408889634f / sqrtf((float)d);
-  if ((rc = launch_qk_norm_rope(h->qkv, w.qw, w.kw, h->rope_cs[lvl], h->q, h->k, h->v, batch, n, h->heads, d, qscale,
-                                h->cfg.eps, s)))
-    return rc;
   const bool timed = h->time_attn && lvl == 2 && h->ev_used < h->ev_start.size();
   if (timed) DFOT_CHECK_HIP(hipEventRecord(h->ev_start[h->ev_used], s));
   if ((rc = launch_attention(h->q, h->k, h->v, h->cat, 5 * c, batch, h->heads, n, d, h->attn_variant, s))) return rc;
@@ -588,7 +586,6 @@ int dfot_uvit_reserve(dfot_uvit_t h, int max_batch) {
     if ((rc = dev_alloc(h, &h->cond_mask, (size_t)max_batch, true))) return rc;
     h->cond_batch = 0;
   }
-  if ((rc = dev_alloc(h, &h->qkv, mc * 3, true))) return rc;
   if ((rc = dev_alloc(h, &h->cat, mc * 5, true))) return rc;
   if ((rc = dev_alloc(h, &h->q, mc, true))) return rc;
   if ((rc = dev_alloc(h, &h->k, mc, true))) return rc;
