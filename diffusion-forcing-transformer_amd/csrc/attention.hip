@@ -201,7 +201,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const bf16* __restrict__ Q, c
 template <int D>
 __global__ __launch_bounds__(256) void attn_kernel_v2(const bf16* __restrict__ Q, const bf16* __restrict__ K,
                                                       const bf16* __restrict__ V, bf16* __restrict__ O, long ldo, int N,
-                                                      int heads) {
+                                                      int heads, int xcd) {
   using C = AttnCfg<D>;
   constexpr float THR = 8.0f;
   constexpr int RPI = 1024 / C::ROWB;           // rows covered by one 1-KiB DMA instruction (8 or 4)
@@ -209,9 +209,12 @@ __global__ __launch_bounds__(256) void attn_kernel_v2(const bf16* __restrict__ Q
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lq = lane & 31, lh = lane >> 5;
-  const int bh = blockIdx.y;
+  // 1-D grid, (batch*head)-major logical order handed out per XCD: the q-tiles of one head share K/V in one L2
+  const int qtiles = N / 128;
+  const int lin = xcd_remap(blockIdx.x, gridDim.x, xcd);
+  const int bh = lin / qtiles;
   const long base = (long)bh * N * D;
-  const int q0 = blockIdx.x * 128 + wave * 32;
+  const int q0 = (lin % qtiles) * 128 + wave * 32;
   const bf16* Qb = Q + base;
   const bf16* Kb = K + base;
   const bf16* Vb = V + base;
@@ -359,13 +362,14 @@ template <int D>
 static int launch_attn_v2(const bf16* q, const bf16* k, const bf16* v, bf16* o, long ldo, int batch, int heads, int n,
                           hipStream_t stream) {
   auto kern = attn_kernel_v2<D>;
+  static const int xcd_flag = tuning_flag("ATTN_XCD", 1);
   const int lds = 4 * AttnCfg<D>::TILE;
   static bool attr_set = false;
   if (!attr_set) {
     DFOT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3(n / 128, batch * heads), dim3(256), lds, stream, q, k, v, o, ldo, n, heads);
+  hipLaunchKernelGGL(kern, dim3((n / 128) * batch * heads), dim3(256), lds, stream, q, k, v, o, ldo, n, heads, xcd_flag);
   DFOT_CHECK_HIP(hipGetLastError());
   return DFOT_OK;
 }

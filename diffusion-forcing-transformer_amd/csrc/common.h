@@ -16,10 +16,21 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 #define DFOT_LDS_PTR(p) ((void __attribute__((address_space(3)))*)(p))
 #define DFOT_GLOBAL_PTR(p) ((const void __attribute__((address_space(1)))*)(p))
 
+// XCD-aware workgroup order (cdna_hip_programming.md T1): blocks b and b+8 share an XCD (and its L2), so hand each
+// XCD a CONTIGUOUS range of the logical tile order; neighbours in that order (same A rows / same K,V head) then hit
+// the same L2.  Bijective for any grid size.  Placement affects speed only.
+__device__ __forceinline__ int xcd_remap(int orig, int nwg, int enable = 1) {
+  if (!enable) return orig;
+  const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+}
+
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 
 __device__ __forceinline__ float bf2f(bf16 v) { return (float)v; }
 __device__ __forceinline__ bf16 f2bf(float v) { return (bf16)v; }
+
+int tuning_flag(const char* name, int dflt);  // DFOT_<NAME> environment override, read once (A/B experiments)
 
 // last error text for the C ABI (thread-local: one sampler thread per process in practice)
 void set_error(const char* fmt, ...);

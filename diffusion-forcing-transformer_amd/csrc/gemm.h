@@ -37,6 +37,7 @@ struct GemmArgs {
   int heads = 0, d = 0, ntok = 0;
   float qscale = 1.f;
   float eps = 1e-6f;
+  int xcd = 1;  // XCD-aware tile order
 };
 
 enum GemmVariant {

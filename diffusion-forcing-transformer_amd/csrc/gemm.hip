@@ -48,7 +48,8 @@ __global__ __launch_bounds__((BM_T / 64) * (BN_T / 64) * 64) void gemm_kernel(Ge
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int tiles_n = (g.N + BN_T - 1) / BN_T;
-  const int tn = blockIdx.x % tiles_n, tm = blockIdx.x / tiles_n;
+  const int bid = xcd_remap(blockIdx.x, gridDim.x, g.xcd);
+  const int tn = bid % tiles_n, tm = bid / tiles_n;
   const int m0 = tm * BM_T, n0 = tn * BN_T;
   const int nk = g.K / BK;
 
@@ -409,13 +410,16 @@ static int launch_t(const GemmArgs& g, hipStream_t stream) {
   constexpr int ep_lds = (nthreads / 64) * 16 * EP_LD * 4 + 2 * (nthreads / 64) * 16 * 4;
   constexpr int lds = stage_lds > ep_lds ? stage_lds : ep_lds;
   const int tiles = (g.M / BM_T) * ((g.N + BN_T - 1) / BN_T);
+  static const int xcd_flag = tuning_flag("GEMM_XCD", 1);
+  GemmArgs ga = g;
+  ga.xcd = xcd_flag;
   auto kern = gemm_kernel<BM_T, BN_T, NST, AMODE, EPI, DMA>;
   static bool attr_set = false;
   if (!attr_set) {
     DFOT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3(tiles), dim3(nthreads), lds, stream, g);
+  hipLaunchKernelGGL(kern, dim3(tiles), dim3(nthreads), lds, stream, ga);
   DFOT_CHECK_HIP(hipGetLastError());
   return DFOT_OK;
 }

@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdarg>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <map>
@@ -27,6 +28,12 @@ void set_error(const char* fmt, ...) {
   va_end(ap);
 }
 const char* get_error() { return g_err; }
+
+int tuning_flag(const char* name, int dflt) {
+  std::string key = std::string("DFOT_") + name;
+  const char* v = getenv(key.c_str());
+  return v ? atoi(v) : dflt;
+}
 
 // ------------------------------------------------------------------------------------------
 // model
