@@ -72,6 +72,10 @@ def main():
     ap.add_argument("--res", type=int, default=256)
     ap.add_argument("--sampling-steps", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", choices=["8f", "200f"], default="8f",
+                    help="8f: BASELINE config 2 (default, the metric's single-GPU configuration); 200f: config 3, the "
+                         "200-frame rollout (keyframe density 0.0625, stabilized HG 4.0/0.02 + interpolation HG 1.5, batches of "
+                         "4 windows), interpolation windows sharded over ranks")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -89,13 +93,28 @@ def main():
     res = args.res
     model = UViT3DPose(RE10K, x_shape=(3, res, res), max_tokens=8).cuda()
     model.init_random(seed=0)
-    cfg = SamplerConfig(x_shape=(3, res, res), max_tokens=8,
-                        diffusion=DiffusionConfig(sampling_timesteps=args.sampling_steps),
-                        prediction_guidance=dict(name="vanilla", guidance_scale=4.0))
-    gen = torch.Generator(device="cuda").manual_seed(1234 + rank)
-    sampler = DFoTVideoPoseSampler(cfg, model, dfot_amd.device_noise_fn(gen))
-    xs = torch.randn(1, 8, 3, res, res, generator=torch.Generator().manual_seed(rank)).cuda()
-    conds = synth_poses(1, 8, 100 + rank).cuda()
+    long_rollout = args.workload == "200f"
+    if long_rollout:
+        n_frames = 200
+        cfg = SamplerConfig(x_shape=(3, res, res), max_tokens=8,
+                            diffusion=DiffusionConfig(sampling_timesteps=args.sampling_steps),
+                            prediction_guidance=dict(name="stabilized_vanilla", guidance_scale=4.0, stabilization_level=0.02),
+                            interpolation_guidance=dict(name="vanilla", guidance_scale=1.5), keyframe_density=0.0625,
+                            interpolation_max_batch_size=4)
+        # every rank works on the SAME video; noise is keyed by window so replicated key-frame windows agree bitwise
+        sampler = DFoTVideoPoseSampler(cfg, model, dfot_amd.parallel.WindowKeyedNoise(1234))
+        sampler.shard_windows = world > 1
+        xs = torch.randn(1, n_frames, 3, res, res, generator=torch.Generator().manual_seed(0)).cuda()
+        conds = synth_poses(1, n_frames, 100).cuda()
+    else:
+        n_frames = 8
+        cfg = SamplerConfig(x_shape=(3, res, res), max_tokens=8,
+                            diffusion=DiffusionConfig(sampling_timesteps=args.sampling_steps),
+                            prediction_guidance=dict(name="vanilla", guidance_scale=4.0))
+        gen = torch.Generator(device="cuda").manual_seed(1234 + rank)
+        sampler = DFoTVideoPoseSampler(cfg, model, dfot_amd.device_noise_fn(gen))
+        xs = torch.randn(1, n_frames, 3, res, res, generator=torch.Generator().manual_seed(rank)).cuda()
+        conds = synth_poses(1, n_frames, 100 + rank).cuda()
 
     def barrier():
         if world > 1:
@@ -104,7 +123,7 @@ def main():
 
     for _ in range(args.warmup):
         sampler._predict_videos(xs, n_context_tokens=1, conditions=conds)
-    attn_per_sample = args.sampling_steps * 12
+    attn_per_sample = args.sampling_steps * 12 * (14 if long_rollout else 1)
     model.set_option("time_attn", attn_per_sample * args.steps if rank == 0 else 0)
     sampler.window_forwards = 0
     barrier()
@@ -118,28 +137,41 @@ def main():
         tmax = torch.tensor([dt], device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-    frames_per_sample = 7
-    total_frames = frames_per_sample * args.steps * world
+    frames_per_sample = n_frames - 1
+    # 8f: one video per rank (weak scaling); 200f: all ranks cooperate on one video (strong scaling)
+    total_frames = frames_per_sample * args.steps * (1 if long_rollout else world)
     fwd = sampler.window_forwards
 
     if rank == 0:
         attn_ms, attn_n = model.attn_timing()
         n2 = 8 * (res // 8) ** 2
+        # total level-2 attention FLOPs of the timed region = 4*N^2*d*heads per (window-forward, block) x 12 blocks
+        # x window-forwards; every one of those launches was event-timed, so achieved = FLOPs / summed duration.
+        # flop_per_launch is quoted for the model-batch-2 launch of the 8f workload.
         flop_per_launch = 4.0 * n2 * n2 * 64 * 9 * 2
-        achieved = flop_per_launch / (attn_ms / max(attn_n, 1) * 1e-3) / 1e12 if attn_n else None
+        total_attn_flop = 4.0 * n2 * n2 * 64 * 9 * 12 * fwd
+        achieved = total_attn_flop / (attn_ms * 1e-3) / 1e12 if attn_n else None
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")
+        if os.path.exists(pmc) and res == 256 and not long_rollout:
+            k = json.load(open(pmc))["kernels"].get("attn_kernel_v2<64>")
+            traffic = k and k["hbm_bytes_per_launch_corrected"]
         line = {
             "metric": "denoised latent frames/sec, DFoT RE10K 8f & 200f rollout @1/2/4/8 GPU",
             "value": total_frames / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if long_rollout else "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic latents, seeded random-init weights",
-            "config": {"workload": f"DFoT_RE10K 8-frame sample: context 1, {args.sampling_steps} DDIM steps, vanilla history "
-                                   f"guidance 4.0 (NFE 2), {res}x{res}, one video per GPU",
+            "config": {"workload": (f"DFoT_RE10K 200-frame rollout: 12 key frames (stabilized HG 4.0/0.02) + 2-stage interpolation "
+                                    f"(HG 1.5, batches of 4 windows), {args.sampling_steps} DDIM steps, {res}x{res}, windows sharded "
+                                    f"over ranks") if long_rollout else
+                                   (f"DFoT_RE10K 8-frame sample: context 1, {args.sampling_steps} DDIM steps, vanilla history "
+                                    f"guidance 4.0 (NFE 2), {res}x{res}, one video per GPU"),
                        "window_forwards_per_step": fwd // args.steps, "frames_per_step": frames_per_sample},
             "window_forward_ms": dt / fwd * 1e3,
             "model_tflops": WINDOW_FLOP * (res / 256.0) ** 2 * fwd / dt / 1e12 if res == 256 else None,
             "roofline": {"bound": "mfma", "kernel": "attn_kernel<64> (level-2 flash attention, N=%d, d=64)" % n2,
                          "achieved": achieved, "peak": 2500.0, "unit": "TFLOP/s",
-                         "frac": achieved / 2500.0 if achieved else None, "traffic": None,
+                         "frac": achieved / 2500.0 if achieved else None, "traffic": traffic,
                          "launches": attn_n, "avg_launch_ms": attn_ms / max(attn_n, 1),
                          "flop_per_launch": flop_per_launch},
         }

@@ -33,10 +33,11 @@ __device__ __forceinline__ void wait_all_but() {
   if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
 }
 
-template <int BM_T, int BN_T, int NST, int AMODE, int EPI, bool DMA>
-__global__ __launch_bounds__((BM_T / 64) * (BN_T / 64) * 64) void gemm_kernel(GemmArgs g) {
+template <int BM_T, int BN_T, int WTM, int NST, int AMODE, int EPI, bool DMA>
+__global__ __launch_bounds__((BM_T / WTM) * (BN_T / 64) * 64) void gemm_kernel(GemmArgs g) {
+  constexpr int MI = WTM / 16;                  // 16-row MFMA tiles per wave along M (wave tile = WTM x 64)
   constexpr int WN = BN_T / 64;                 // waves along N
-  constexpr int NW = (BM_T / 64) * WN;          // waves per workgroup
+  constexpr int NW = (BM_T / WTM) * WN;         // waves per workgroup
   constexpr int NT = NW * 64;                   // threads
   constexpr int ACH = (BM_T * 8) / NT;          // A chunks (16 B) per thread per k-tile
   constexpr int WCH = (BN_T * 8) / NT;          // W chunks per thread per k-tile
@@ -134,9 +135,9 @@ __global__ __launch_bounds__((BM_T / 64) * (BN_T / 64) * 64) void gemm_kernel(Ge
     for (int i = 0; i < WCH; ++i) *reinterpret_cast<bf16x8*>(sw + (NW * i + wave) * 1024 + lane * 16) = rw[i];
   };
 
-  f32x4 acc[4][4];
+  f32x4 acc[MI][4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -146,10 +147,10 @@ __global__ __launch_bounds__((BM_T / 64) * (BN_T / 64) * 64) void gemm_kernel(Ge
     const char* sw = sa + A_BYTES;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 af[4], wf[4];
+      bf16x8 af[MI], wf[4];
 #pragma unroll
-      for (int mi = 0; mi < 4; ++mi) {
-        const int r = wm * 64 + mi * 16 + frow;
+      for (int mi = 0; mi < MI; ++mi) {
+        const int r = wm * WTM + mi * 16 + frow;
         const int pos = (ks * 4 + fk) ^ ((r >> 1) & 7);
         af[mi] = *reinterpret_cast<const bf16x8*>(sa + r * 128 + pos * 16);
       }
@@ -160,7 +161,7 @@ __global__ __launch_bounds__((BM_T / 64) * (BN_T / 64) * 64) void gemm_kernel(Ge
         wf[ni] = *reinterpret_cast<const bf16x8*>(sw + r * 128 + pos * 16);
       }
 #pragma unroll
-      for (int mi = 0; mi < 4; ++mi)
+      for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni)
           acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mi], wf[ni], acc[mi][ni], 0, 0, 0);
@@ -231,12 +232,12 @@ __global__ __launch_bounds__((BM_T / 64) * (BN_T / 64) * 64) void gemm_kernel(Ge
     if constexpr (EPI != E_F32) b1 = *reinterpret_cast<const f32x4*>(g.bias + col + 4);
   }
 #pragma unroll
-  for (int mi = 0; mi < 4; ++mi) {
+  for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
       for (int j = 0; j < 4; ++j) ep[(rowq + j) * EP_LD + ni * 16 + colq] = acc[mi][ni][j];
-    const long mw = (long)m0 + wm * 64 + mi * 16;
+    const long mw = (long)m0 + wm * WTM + mi * 16;
     if constexpr (EPI == E_F32) {
       if (live) {
 #pragma unroll
@@ -354,8 +355,8 @@ __global__ __launch_bounds__((BM_T / 64) * (BN_T / 64) * 64) void gemm_kernel(Ge
   }
 
   if constexpr (EPI == E_F32 || EPI == E_BF16) {
-    if (g.gn_part) {  // wave-uniform
-      const long mrow = (long)m0 + wm * 64;
+    if (g.gn_part) {  // wave-uniform (launcher guarantees a 64-row wave tile)
+      const long mrow = (long)m0 + wm * WTM;
       const int bt = (int)(mrow / g.gn_rows_per_bt);
       const int slots = g.gn_rows_per_bt / 64;
       const int slot = (int)((mrow % g.gn_rows_per_bt) / 64);
@@ -403,9 +404,9 @@ __global__ __launch_bounds__((BM_T / 64) * (BN_T / 64) * 64) void gemm_kernel(Ge
   }
 }
 
-template <int BM_T, int BN_T, int NST, int AMODE, int EPI, bool DMA>
+template <int BM_T, int BN_T, int WTM, int NST, int AMODE, int EPI, bool DMA>
 static int launch_t(const GemmArgs& g, hipStream_t stream) {
-  constexpr int nthreads = (BM_T / 64) * (BN_T / 64) * 64;
+  constexpr int nthreads = (BM_T / WTM) * (BN_T / 64) * 64;
   constexpr int stage_lds = NST * (BM_T + BN_T) * BK * 2;
   constexpr int ep_lds = (nthreads / 64) * 16 * EP_LD * 4 + 2 * (nthreads / 64) * 16 * 4;
   constexpr int lds = stage_lds > ep_lds ? stage_lds : ep_lds;
@@ -413,7 +414,7 @@ static int launch_t(const GemmArgs& g, hipStream_t stream) {
   static const int xcd_flag = tuning_flag("GEMM_XCD", 1);
   GemmArgs ga = g;
   ga.xcd = xcd_flag;
-  auto kern = gemm_kernel<BM_T, BN_T, NST, AMODE, EPI, DMA>;
+  auto kern = gemm_kernel<BM_T, BN_T, WTM, NST, AMODE, EPI, DMA>;
   static bool attr_set = false;
   if (!attr_set) {
     DFOT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -427,13 +428,16 @@ static int launch_t(const GemmArgs& g, hipStream_t stream) {
 template <int AMODE, int EPI>
 static int launch_v(int variant, const GemmArgs& g, hipStream_t s) {
   switch (variant) {
-    case GEMM_REGS_128: return launch_t<128, 128, 2, AMODE, EPI, false>(g, s);
-    case GEMM_DMA_128: return launch_t<128, 128, 2, AMODE, EPI, true>(g, s);
-    case GEMM_DMA3_128: return launch_t<128, 128, 3, AMODE, EPI, true>(g, s);
-    case GEMM_DMA3_256: return launch_t<256, 128, 3, AMODE, EPI, true>(g, s);
-    case GEMM_DMA_256x256: return launch_t<256, 256, 2, AMODE, EPI, true>(g, s);
-    case GEMM_DMA_256x128: return launch_t<256, 128, 2, AMODE, EPI, true>(g, s);
-    case GEMM_DMA_512x128: return launch_t<512, 128, 2, AMODE, EPI, true>(g, s);
+    case GEMM_REGS_128: return launch_t<128, 128, 64, 2, AMODE, EPI, false>(g, s);
+    case GEMM_DMA_128: return launch_t<128, 128, 64, 2, AMODE, EPI, true>(g, s);
+    case GEMM_DMA3_128: return launch_t<128, 128, 64, 3, AMODE, EPI, true>(g, s);
+    case GEMM_DMA3_256: return launch_t<256, 128, 64, 3, AMODE, EPI, true>(g, s);
+    case GEMM_DMA_256x256: return launch_t<256, 256, 64, 2, AMODE, EPI, true>(g, s);
+    case GEMM_DMA_256x128: return launch_t<256, 128, 64, 2, AMODE, EPI, true>(g, s);
+    case GEMM_DMA_512x128: return launch_t<512, 128, 64, 2, AMODE, EPI, true>(g, s);
+    case GEMM_DMA_256x256_W128:
+      if (g.gn_part) break;  // fused GroupNorm partials assume 64-row wave tiles
+      return launch_t<256, 256, 128, 2, AMODE, EPI, true>(g, s);
   }
   set_error("gemm: unknown variant %d", variant);
   return DFOT_ERR_ARG;
@@ -455,7 +459,7 @@ int gemm_pick_variant(int amode, int m, int n, int k) {
 int launch_gemm(int amode, int epi, int variant, const GemmArgs& g, hipStream_t stream) {
   DFOT_REQUIRE(g.A && g.W, DFOT_ERR_ARG, "gemm: null operand");
   if (variant == GEMM_AUTO) variant = gemm_pick_variant(amode, g.M, g.N, g.K);
-  const int bm = variant == GEMM_DMA_512x128 ? 512 : (variant == GEMM_DMA3_256 || variant == GEMM_DMA_256x256 || variant == GEMM_DMA_256x128) ? 256 : 128;
+  const int bm = variant == GEMM_DMA_512x128 ? 512 : (variant == GEMM_DMA3_256 || variant == GEMM_DMA_256x256 || variant == GEMM_DMA_256x128 || variant == GEMM_DMA_256x256_W128) ? 256 : 128;
   DFOT_REQUIRE(g.M > 0 && g.M % bm == 0, DFOT_ERR_SHAPE, "gemm: M=%d must be a positive multiple of %d", g.M, bm);
   DFOT_REQUIRE(g.K > 0 && g.K % BK == 0, DFOT_ERR_SHAPE, "gemm: K=%d must be a positive multiple of %d", g.K, BK);
   DFOT_REQUIRE(g.N > 0 && g.N % (epi == E_F32 ? 4 : 8) == 0, DFOT_ERR_SHAPE, "gemm: N=%d must be a multiple of %d", g.N, epi == E_F32 ? 4 : 8);

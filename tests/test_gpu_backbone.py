@@ -100,3 +100,57 @@ def test_mask_none_equals_all_false(w64):
         a = model(x, k, c, None)
         b = model(x, k, c, torch.tensor([False, False]).cuda())
     assert torch.equal(a, b)
+
+
+def test_cached_conditions_api_matches_forward(w64):
+    """dfot_uvit_set_conditions + dfot_uvit_forward_cached (the per-window pose cache) == dfot_uvit_forward, and the
+    cache is rebuilt when the conditioning tensor, the mask or the weights change."""
+    import ctypes as C
+    from dfot_amd import capi
+    model = make_model(w64["ocfg"], w64["params"], 64)
+    x, k, c, m = (w64[n].cuda() for n in ("x", "k", "cond", "mask"))
+    with torch.no_grad():
+        ref = model(x, k, c, m)                      # builds the cache
+        again = model(x * 0.5, k, c, m)              # reuses it (same cond/mask tensors)
+        c2 = c.clone()
+        other = model(x, k, c2, m)                   # new tensor object -> rebuilt, same values -> same result
+        assert torch.equal(ref, other)
+        c2.mul_(0.5)                                 # in-place change bumps the version -> rebuilt
+        changed = model(x, k, c2, m)
+        assert not torch.equal(ref, changed)
+        flipped = model(x, k, c, torch.tensor([False, True]).cuda())
+        assert not torch.equal(ref, flipped)
+        # raw C ABI: explicit set_conditions / forward_cached
+        out = torch.empty_like(x)
+        mu = m.to(torch.uint8)
+        s = capi.stream_ptr()
+        capi.check(capi.lib.dfot_uvit_set_conditions(model._handle, capi.ptr(c), capi.ptr(mu), 2, s))
+        capi.check(capi.lib.dfot_uvit_forward_cached(model._handle, capi.ptr(x), capi.ptr(k), capi.ptr(out), 2, s))
+        assert torch.equal(out, ref)
+        with pytest.raises(capi.DfotError):          # batch does not match the cached conditions
+            capi.check(capi.lib.dfot_uvit_forward_cached(model._handle, capi.ptr(x), capi.ptr(k), capi.ptr(out), 1, s))
+        # weight change invalidates the cache
+        model._cond_key = None
+        p = next(model.parameters())
+        p.mul_(1.01)
+        after = model(x, k, c, m)
+        assert not torch.equal(after, ref)
+    assert torch.isfinite(again).all()
+
+
+def test_unknown_and_missing_weights_are_rejected(w64):
+    import dfot_amd
+    model = make_model(w64["ocfg"], w64["params"], 64)
+    bad = dict(w64["params"])
+    bad["not_a_key.weight"] = torch.zeros(3)
+    with pytest.raises(RuntimeError):
+        model.load_state_dict(bad, strict=True)
+    import ctypes as C
+    from dfot_amd import capi
+    t = torch.zeros(4, device="cuda")
+    shape = (C.c_int64 * 1)(4)
+    with pytest.raises(capi.DfotError):
+        capi.check(capi.lib.dfot_uvit_load_weight(model._handle, b"bogus.key", capi.ptr(t), shape, 1, capi.stream_ptr()))
+    with pytest.raises(capi.DfotError):  # right key, wrong shape
+        capi.check(capi.lib.dfot_uvit_load_weight(model._handle, b"embed_input.proj.bias", capi.ptr(t), shape, 1,
+                                                  capi.stream_ptr()))
