@@ -8,3 +8,4 @@ from .diffusion import DiffusionConfig, Schedule  # noqa: F401
 from .guidance import HistoryGuidance  # noqa: F401
 from .sampler import DFoTVideoPoseSampler, SamplerConfig, device_noise_fn  # noqa: F401
 from . import parallel  # noqa: F401,E402
+from .checkpoint import load_reference_checkpoint  # noqa: F401,E402

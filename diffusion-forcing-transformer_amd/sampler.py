@@ -81,6 +81,17 @@ class DFoTVideoPoseSampler:
         capi.check(capi.lib.dfot_ray_encode(capi.ptr(raw), capi.ptr(out), b, t, res, capi.stream_ptr()))
         return out
 
+    # data (un)normalisation of the reference (algorithms/common/base_pytorch_video_algo.py:491-502)
+    def _normalize_x(self, xs: torch.Tensor, mean, std) -> torch.Tensor:
+        m = torch.as_tensor(mean, dtype=xs.dtype, device=xs.device).view(-1, 1, 1)
+        s = torch.as_tensor(std, dtype=xs.dtype, device=xs.device).view(-1, 1, 1)
+        return (xs - m) / s
+
+    def _unnormalize_x(self, xs: torch.Tensor, mean, std) -> torch.Tensor:
+        m = torch.as_tensor(mean, dtype=xs.dtype, device=xs.device).view(-1, 1, 1)
+        s = torch.as_tensor(std, dtype=xs.dtype, device=xs.device).view(-1, 1, 1)
+        return xs * s + m
+
     def _pad_to_max_tokens(self, y: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
         if y is None or y.shape[1] >= self.max_tokens:
             return y

@@ -154,3 +154,41 @@ def test_unknown_and_missing_weights_are_rejected(w64):
     with pytest.raises(capi.DfotError):  # right key, wrong shape
         capi.check(capi.lib.dfot_uvit_load_weight(model._handle, b"embed_input.proj.bias", capi.ptr(t), shape, 1,
                                                   capi.stream_ptr()))
+
+
+def test_reference_checkpoint_ingestion(w64, tmp_path):
+    """Lightning-style .ckpt (prefix filter, torch.compile prefix, EMA list in the reference's parameter order) and
+    ema.safetensors both load; missing keys raise the reference's strict error."""
+    import dfot_amd
+    from dfot_amd import checkpoint as ck
+    model = make_model(w64["ocfg"], w64["params"], 64)
+    params = w64["params"]
+    x, k, c, m = (w64[n].cuda() for n in ("x", "k", "cond", "mask"))
+    with torch.no_grad():
+        ref = model(x, k, c, m).clone()
+    # trained weights are garbage, EMA holds the real ones (what validation uses)
+    sd = {"diffusion_model._orig_mod.model." + n: torch.zeros_like(t) if t.ndim > 1 else t for n, t in params.items()}
+    sd["diffusion_model.alphas_cumprod"] = torch.zeros(1000)       # schedule buffer: must be ignored
+    sd["vae.decoder.weight"] = torch.zeros(3)
+    blank = make_model(w64["ocfg"], {n: torch.zeros_like(t) for n, t in params.items()}, 64)
+    order = ck.reference_parameter_order(blank)
+    assert order.index("up_blocks.0.0.conv.weight") < order.index("mid_blocks.0.norm.emb_layer.weight")
+    ckpt = {"state_dict": sd, "optimizer_states": [{"ema": [params[n] for n in order]}], "pretrained_ema": False}
+    path = str(tmp_path / "model.ckpt")
+    torch.save(ckpt, path)
+    ignored = dfot_amd.load_reference_checkpoint(blank, path)
+    assert "vae.decoder.weight" in ignored and "diffusion_model.alphas_cumprod" in ignored
+    with torch.no_grad():
+        assert torch.equal(blank(x, k, c, m), ref)
+    # strict: a missing key is an error with the reference's wording
+    del sd["diffusion_model._orig_mod.model.embed_input.proj.bias"]
+    with pytest.raises(ValueError, match="not found in the checkpoint"):
+        dfot_amd.load_reference_checkpoint(blank, {"state_dict": sd, "pretrained_ema": True})
+    # accelerate-style ema.safetensors with bare names
+    from safetensors.torch import save_file
+    sp = str(tmp_path / "ema.safetensors")
+    save_file({n: t.contiguous() for n, t in params.items()}, sp)
+    blank2 = make_model(w64["ocfg"], {n: torch.zeros_like(t) for n, t in params.items()}, 64)
+    dfot_amd.load_reference_checkpoint(blank2, sp)
+    with torch.no_grad():
+        assert torch.equal(blank2(x, k, c, m), ref)
