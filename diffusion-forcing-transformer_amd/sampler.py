@@ -14,6 +14,7 @@ window instead of once per step (it does not depend on the step), and all frame 
 step is two fused kernels around the backbone call.
 Randomness is drawn through ``noise_fn(tag, shape)`` (tags: "init", "q_sample", "ddim") so tests can
 replay the reference's draws; the default draws on the GPU with ``torch.randn``.
+With ``use_graph = True`` one DDIM step is captured in a hipGraph (``torch.cuda.CUDAGraph``) and replayed.
 """
 from __future__ import annotations
 
@@ -64,6 +65,8 @@ class DFoTVideoPoseSampler:
         self.trace: List[dict] = []
         self.window_forwards = 0
         self.shard_windows = False  # True: shard interpolation windows over torch.distributed ranks (parallel.py)
+        self.use_graph = False      # True: capture one DDIM step in a hipGraph and replay it (see _run_steps_graph)
+        self.graph_replays = 0
         if cfg.diffusion.ddim_sampling_eta != 0:
             raise NotImplementedError("only deterministic DDIM (eta = 0) is implemented on the device path")
 
@@ -199,12 +202,11 @@ class DFoTVideoPoseSampler:
         s = capi.stream_ptr
         strict = bool(getattr(self.noise_fn, "strict_order", False))
 
-        for p_ in plans:
-            nfe, bm, tables = p_["nfe"], p_["bm"], p_["tables_dev"]
-            # noise for re-noised history tokens; with a strict-order noise source (golden replay) every draw
-            # the reference makes is consumed, used or not (history_guidance.py:505,530; discrete_diffusion.py:525)
+        def draw_noise(p_):
+            """noise for re-noised history tokens; with a strict-order noise source (golden replay) every draw the
+            reference makes is consumed, used or not (history_guidance.py:505,530; discrete_diffusion.py:525)"""
+            nfe, bm, need = p_["nfe"], p_["bm"], p_["need_noise"]
             noise = None
-            need = p_["need_noise"]
             if history_guidance.is_simple:
                 if nfe == 2 and (need or strict):
                     drawn = self.noise_fn("q_sample", (batch_size, horizon, *x_shape))
@@ -215,8 +217,11 @@ class DFoTVideoPoseSampler:
                     noise = self.noise_fn("q_sample", (bm, horizon, *x_shape)).to(device="cuda", dtype=torch.float32)
                 if strict:
                     self.noise_fn("excluded", (bm, 1, horizon, *x_shape))
-            if noise is not None:
-                noise = noise.contiguous()
+            return None if noise is None else noise.contiguous().view(bm, horizon, *x_shape)
+
+        def step(p_, xs, noise, tables, gen_dev, xs_next=None):
+            nonlocal cond_rep, cond_nfe
+            nfe, bm = p_["nfe"], p_["bm"]
             x_in = torch.empty(bm, horizon, *x_shape, device="cuda", dtype=torch.float32)
             capi.check(capi.lib.dfot_hg_prepare(capi.ptr(xs), capi.ptr(noise), capi.ptr(tables[0]), capi.ptr(tables[1]),
                                                 capi.ptr(x_in), batch_size, nfe, horizon, f, s()))
@@ -224,18 +229,58 @@ class DFoTVideoPoseSampler:
                 cond_rep = cond_full if nfe == 1 else cond_full.repeat_interleave(nfe, dim=0)
                 cond_nfe = nfe
             v = self.model(x_in, tables[7], cond_rep, p_["cmask_dev"])
-            self.window_forwards += bm
             if strict:
                 self.noise_fn("ddim", (bm, horizon, *x_shape))  # multiplied by sigma = 0 in the reference
-            xs_next = torch.empty_like(xs)
+            if xs_next is None:
+                xs_next = torch.empty_like(xs)
             capi.check(capi.lib.dfot_ddim_compose(capi.ptr(xs), capi.ptr(x_in), capi.ptr(v), capi.ptr(tables[2]),
                                                   capi.ptr(tables[3]), capi.ptr(tables[4]), capi.ptr(tables[5]),
-                                                  capi.ptr(tables[6]), capi.ptr(p_["weights_dev"]), capi.ptr(p_["gen_dev"]),
+                                                  capi.ptr(tables[6]), capi.ptr(p_["weights_dev"]), capi.ptr(gen_dev),
                                                   capi.ptr(xs_next), batch_size, nfe, horizon, f, s()))
-            xs = xs_next
+            return xs_next
+
+        uniform = all(p_["bm"] == plans[0]["bm"] and p_["cmask_dev"] is plans[0]["cmask_dev"]
+                      and p_["weights_dev"] is plans[0]["weights_dev"] for p_ in plans)
+        if self.use_graph and uniform and not strict and len(plans) > 2:
+            xs = self._run_steps_graph(plans, xs, draw_noise, step, flat_dev, gens_dev, horizon)
+        else:
+            for p_ in plans:
+                xs = step(p_, xs, draw_noise(p_), p_["tables_dev"], p_["gen_dev"])
+        self.window_forwards += sum(p_["bm"] for p_ in plans)
         if padding > 0:
             xs = xs[:, :-padding]
         return xs, None
+
+    def _run_steps_graph(self, plans, xs, draw_noise, step, flat_dev, gens_dev, horizon):
+        """hipGraph execution of the step loop: step 0 runs eagerly (lazy initialisation, pose caches), then ONE step
+        [select step tables -> hg_prepare -> backbone -> ddim/compose/clamp -> advance] is captured with a device-side
+        step counter indexing the per-step coefficient tables and replayed for the remaining steps."""
+        p0 = plans[0]
+        bm, n_steps = p0["bm"], len(plans)
+        tables_all = flat_dev.view(n_steps, 8, bm, horizon)
+        need_noise = any(p_["need_noise"] for p_ in plans)
+        noise_all = torch.stack([draw_noise(p_) if p_["need_noise"] else torch.zeros(bm, *xs.shape[1:], device="cuda")
+                                 for p_ in plans]) if need_noise else None
+        xs_buf = step(p0, xs, None if noise_all is None else noise_all[0], p0["tables_dev"], p0["gen_dev"])
+        step_idx = torch.ones(1, dtype=torch.long, device="cuda")
+        cur_tables = torch.empty(8, bm, horizon, device="cuda", dtype=torch.float32)
+        cur_gen = torch.empty_like(gens_dev[0])
+        cur_noise = None if noise_all is None else torch.empty_like(noise_all[0])
+        xs_next = torch.empty_like(xs_buf)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            cur_tables.copy_(tables_all.index_select(0, step_idx)[0])
+            cur_gen.copy_(gens_dev.index_select(0, step_idx)[0])
+            if cur_noise is not None:
+                cur_noise.copy_(noise_all.index_select(0, step_idx)[0])
+            step(p0, xs_buf, cur_noise, cur_tables, cur_gen, xs_next)
+            xs_buf.copy_(xs_next)
+            step_idx.add_(1)
+        for _ in range(n_steps - 1):
+            graph.replay()
+        self.graph_replays += n_steps - 1
+        return xs_buf.clone()
 
     # ------------------------------------------------------------------ sliding window
     @torch.no_grad()
