@@ -177,7 +177,7 @@ def main():
                          "launches": attn_n, "avg_launch_ms": attn_ms / max(attn_n, 1),
                          "flop_per_launch": flop_per_launch},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # reported baseline: rank 0 at N=1 only
             line["cpu_baseline"] = cpu_baseline(res, 1, frames_per_sample, fwd // args.steps)
         print(json.dumps(line), flush=True)
     if world > 1:

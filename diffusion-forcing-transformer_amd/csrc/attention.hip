@@ -198,7 +198,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const bf16* __restrict__ Q, c
 //    more than 2^8 -- the branch is wave-uniform; P is then bounded by 256, exact enough for bf16 P / fp32 sums;
 //  * row max via v_max3.
 // ---------------------------------------------------------------------------------------------
-template <int D>
+template <int D, int NST>
 __global__ __launch_bounds__(256) void attn_kernel_v2(const bf16* __restrict__ Q, const bf16* __restrict__ K,
                                                       const bf16* __restrict__ V, bf16* __restrict__ O, long ldo, int N,
                                                       int heads, int xcd) {
@@ -255,15 +255,31 @@ __global__ __launch_bounds__(256) void attn_kernel_v2(const bf16* __restrict__ Q
   float m_run = 0.f, l_i = 0.f;
 
   const int nt = N / C::KV;
+  // NST == 2: tile t+1 is loaded while t is computed (vmcnt(0) + barrier per tile).  NST == 3: tile t+2 stays in flight
+  // across the barrier; the wait before the barrier is counted (2*IPW loads of the newest tile may be outstanding).
   issue(0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
+  if constexpr (NST == 3) {
+    if (nt > 1) issue(1, 1);
+    if (nt > 1) {
+      if constexpr (IPW == 2) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
 
+  int cur = 0;
   for (int t = 0; t < nt; ++t) {
-    const int cur = t & 1;
     const char* sk = smem + cur * 2 * C::TILE;
     const char* sv = sk + C::TILE;
-    if (t + 1 < nt) issue(t + 1, cur ^ 1);
+    if constexpr (NST == 3) {
+      if (t + 2 < nt) issue(t + 2, cur == 0 ? 2 : cur - 1);
+    } else {
+      if (t + 1 < nt) issue(t + 1, cur ^ 1);
+    }
 
     // ---- S^T - m = K Q^T - m ----
     f32x16 sacc[2];
@@ -339,8 +355,19 @@ __global__ __launch_bounds__(256) void attn_kernel_v2(const bf16* __restrict__ Q
         }
       }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    if constexpr (NST == 3) {
+      if (t + 2 < nt) {
+        if constexpr (IPW == 2) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+      }
+      cur = cur == 2 ? 0 : cur + 1;
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      cur ^= 1;
+    }
   }
 
   const float l_tot = l_i + __shfl_xor(l_i, 32);
@@ -358,12 +385,12 @@ __global__ __launch_bounds__(256) void attn_kernel_v2(const bf16* __restrict__ Q
     }
 }
 
-template <int D>
+template <int D, int NST>
 static int launch_attn_v2(const bf16* q, const bf16* k, const bf16* v, bf16* o, long ldo, int batch, int heads, int n,
                           hipStream_t stream) {
-  auto kern = attn_kernel_v2<D>;
+  auto kern = attn_kernel_v2<D, NST>;
   static const int xcd_flag = tuning_flag("ATTN_XCD", 1);
-  const int lds = 4 * AttnCfg<D>::TILE;
+  const int lds = 2 * NST * AttnCfg<D>::TILE;
   static bool attr_set = false;
   if (!attr_set) {
     DFOT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -395,9 +422,13 @@ int launch_attention(const bf16* q, const bf16* k, const bf16* v, bf16* o, long 
   DFOT_REQUIRE(d == 64 || d == 128, DFOT_ERR_SHAPE, "attention: head dim %d not in {64,128}", d);
   DFOT_REQUIRE(n > 0 && n % 128 == 0, DFOT_ERR_SHAPE, "attention: N=%d must be a multiple of 128", n);
   DFOT_REQUIRE(ldo % 4 == 0, DFOT_ERR_SHAPE, "attention: output row stride %ld must be a multiple of 4", ldo);
-  if (variant == 2) {
-    return d == 64 ? launch_attn_v2<64>(q, k, v, o, ldo, batch, heads, n, stream)
-                   : launch_attn_v2<128>(q, k, v, o, ldo, batch, heads, n, stream);
+  if (variant == 2) {  // tuned kernel; K/V ring depth chosen by measurement: 3 stages (48 KiB) at d = 64, 2 stages at d = 128
+    return d == 64 ? launch_attn_v2<64, 3>(q, k, v, o, ldo, batch, heads, n, stream)
+                   : launch_attn_v2<128, 2>(q, k, v, o, ldo, batch, heads, n, stream);
+  }
+  if (variant == 3) {  // tuned kernel, two stages for both head sizes (A/B reference)
+    return d == 64 ? launch_attn_v2<64, 2>(q, k, v, o, ldo, batch, heads, n, stream)
+                   : launch_attn_v2<128, 2>(q, k, v, o, ldo, batch, heads, n, stream);
   }
   if (d == 64) {
     return variant == 1 ? launch_attn_t<64, false>(q, k, v, o, ldo, batch, heads, n, stream)
