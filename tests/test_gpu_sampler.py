@@ -145,3 +145,49 @@ def test_hipgraph_step_replay_matches_eager():
             assert samp.graph_replays == 5
     assert torch.isfinite(outs[0]).all()
     assert torch.equal(outs[0], outs[1])
+
+
+def _sample_pair(scheme, length, mask_row, steps=2, batch=2, seed=21):
+    """one _sample_sequence window on both paths with identical noise; returns (engine, oracle)"""
+    import dfot_amd
+    from oracle import guidance as ohg, pose as opose, sampler as osm, schedule as sch, uvit as ouvit
+    res = 64
+    ocfg, params, model = build(blocks=(1, 1, 1), mid=2)
+    g = torch.Generator().manual_seed(seed)
+    ctx = torch.randn(batch, length, 3, res, res, generator=g)
+    cmask = torch.tensor([mask_row] * batch)
+    cnd = poses(batch, 8, seed)
+    r1, r2 = Replay(5, "cpu"), Replay(5, "cuda")
+    diff = osm.Diffusion(sch.build_tables(), lambda x, k, c, m: ouvit.forward(params, ocfg, x, k, c, m), sampling_timesteps=steps)
+    osamp = osm.Sampler(osm.SamplerConfig(x_shape=(3, res, res), sampling_timesteps=steps), diff,
+                        lambda c: opose.ray_encoding(c, res), r1)
+    with torch.no_grad():
+        ref = osamp.sample_sequence(batch, ctx, cmask, cnd, ohg.make_scheme(**scheme), length=length)
+    samp = dfot_amd.DFoTVideoPoseSampler(
+        dfot_amd.SamplerConfig(x_shape=(3, res, res), diffusion=dfot_amd.DiffusionConfig(sampling_timesteps=steps)), model, r2)
+    out, _ = samp._sample_sequence(batch, length=length, context=ctx, context_mask=cmask, conditions=cnd,
+                                   history_guidance=dfot_amd.HistoryGuidance.from_config(scheme))
+    assert r1.log == r2.log
+    return out.cpu(), ref
+
+
+@pytest.mark.parametrize("scheme", [dict(name="conditional"),
+                                    dict(name="fractional", guidance_scale=3.0, freq_scale=0.4),
+                                    dict(name="stabilized_conditional", stabilization_level=0.02)])
+def test_other_guidance_schemes_one_window(scheme):
+    """NFE 1 (conditional), NFE 3 (fractional: three deduplicated branches) and stabilized conditional, batch of 2 videos,
+    history = 1 ground-truth + 2 generated frames."""
+    out, ref = _sample_pair(scheme, 8, [1, 2, 2, 0, 0, 0, 0, 0])
+    p = psnr(out, ref)
+    print(f"{scheme['name']}: PSNR {p:.1f} dB")
+    assert torch.isfinite(out).all() and p >= 35.0
+    assert torch.equal(out[:, :3], ref[:, :3])  # history frames are returned untouched on both paths
+
+
+def test_short_window_is_padded_with_noise_tokens():
+    """length 5 < max_tokens 8: three padding tokens (mask -1, level 999) ride along and are cut off again."""
+    out, ref = _sample_pair(dict(name="vanilla", guidance_scale=2.0), 5, [1, 1, 0, 0, 0])
+    assert out.shape[1] == 5
+    p = psnr(out, ref)
+    print(f"padded window: PSNR {p:.1f} dB")
+    assert p >= 35.0

@@ -59,3 +59,64 @@ def test_shard_assignment_covers_every_window_once():
             ids = sorted(i for r in range(world) for i in parallel.shard_windows(n, world, r))
             assert ids == list(range(n))
             assert max(len(parallel.shard_windows(n, world, r)) for r in range(world)) == -(-n // world)
+
+
+def _interp_worker(rank, world, port, q):
+    """Runs the sampler's REAL _interpolate_videos control flow (planner, batching, sharding, gather, write-back) with
+    the device step replaced by a deterministic stub, sharded over 2 gloo ranks, and compares with the serial run."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import dfot_amd
+    from dfot_amd import sampler as smp
+
+    class Stub(smp.DFoTVideoPoseSampler):
+        def __init__(self, cfg):
+            self.cfg, self.max_tokens, self.x_shape, self.timesteps = cfg, cfg.max_tokens, tuple(cfg.x_shape), 1000
+            self.noise_fn, self.shard_windows, self.calls = None, False, 0
+
+        def _sample_sequence(self, batch_size, length=None, context=None, context_mask=None, conditions=None,
+                             history_guidance=None, **_):
+            self.calls += batch_size
+            known = (context_mask >= 1).view(batch_size, -1, 1, 1, 1).float()
+            fill = conditions[..., 0].view(batch_size, -1, 1, 1, 1).expand_as(context)  # depends on the window only
+            return context * known + (1 - known) * fill, None
+
+    # the stub never touches the GPU: keep tensors on the CPU by bypassing the .to("cuda") calls
+    orig_to = torch.Tensor.to
+    torch.Tensor.to = lambda self, *a, **k: orig_to(self, *[x for x in a if x != "cuda"],
+                                                     **{kk: vv for kk, vv in k.items() if not (kk == "device" and vv == "cuda")})
+    cfg = dfot_amd.SamplerConfig(x_shape=(3, 4, 4), interpolation_guidance=dict(name="vanilla", guidance_scale=1.5),
+                                 interpolation_max_batch_size=4)
+    n = 200
+    xs = torch.arange(n, dtype=torch.float32).view(1, n, 1, 1, 1).expand(1, n, 3, 4, 4).contiguous()
+    known = torch.zeros(1, n, dtype=torch.bool)
+    keys = torch.linspace(0, n - 1, 12).round().long()
+    known[:, keys] = True
+    conds = torch.arange(n, dtype=torch.float32).view(1, n, 1).expand(1, n, 16).contiguous() + 0.5
+    serial = Stub(cfg)
+    ref = serial._interpolate_videos(xs, known, conds)
+    sharded = Stub(cfg)
+    sharded.shard_windows = True
+    out = sharded._interpolate_videos(xs, known, conds)
+    torch.Tensor.to = orig_to
+    q.put((rank, bool(torch.equal(out, ref)), serial.calls, sharded.calls))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_sharded_interpolation_control_flow_equals_serial_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_interp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(60)
+    assert all(ok for _, ok, _, _ in res), res
+    # 11 + 35 windows in total; each rank samples about half of them when sharded
+    assert all(serial == 46 for _, _, serial, _ in res), res
+    assert sorted(sh for _, _, _, sh in res) == [22, 24], res  # 11 -> 6+5 and 35 -> 18+17 windows
