@@ -156,8 +156,8 @@ def main():
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")
         if os.path.exists(pmc) and res == 256 and not long_rollout:
-            k = json.load(open(pmc))["kernels"].get("attn_kernel_v2<64>")
-            traffic = k and k["hbm_bytes_per_launch_corrected"]
+            ks = [v for n, v in json.load(open(pmc))["kernels"].items() if n.startswith("attn_kernel_v2<64")]
+            traffic = ks[0]["hbm_bytes_per_launch_corrected"] if ks else None
         line = {
             "metric": "denoised latent frames/sec, DFoT RE10K 8f & 200f rollout @1/2/4/8 GPU",
             "value": total_frames / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
