@@ -33,20 +33,27 @@ __device__ __forceinline__ void wait_all_but() {
   if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
 }
 
-template <int BM_T, int BN_T, int WTM, int NST, int AMODE, int EPI, bool DMA>
-__global__ __launch_bounds__((BM_T / WTM) * (BN_T / 64) * 64) void gemm_kernel(GemmArgs g) {
+// KS = 2: intra-workgroup split-K for grids too small to fill the chip (level-3 GEMMs at model batch 2): two groups of
+// NW waves each own a private pair of LDS stages and alternate k-tiles (group g takes k-tiles g, g+2, ...), doubling the
+// waves per CU and halving the serial k-loop; group 1's accumulators are folded into group 0's through LDS at the end.
+template <int BM_T, int BN_T, int WTM, int NST, int AMODE, int EPI, bool DMA, int KS = 1>
+__global__ __launch_bounds__((BM_T / WTM) * (BN_T / 64) * 64 * KS) void gemm_kernel(GemmArgs g) {
   constexpr int MI = WTM / 16;                  // 16-row MFMA tiles per wave along M (wave tile = WTM x 64)
   constexpr int WN = BN_T / 64;                 // waves along N
-  constexpr int NW = (BM_T / WTM) * WN;         // waves per workgroup
-  constexpr int NT = NW * 64;                   // threads
+  constexpr int NW = (BM_T / WTM) * WN;         // waves per k-group
+  constexpr int NT = NW * 64;                   // threads per k-group
   constexpr int ACH = (BM_T * 8) / NT;          // A chunks (16 B) per thread per k-tile
   constexpr int WCH = (BN_T * 8) / NT;          // W chunks per thread per k-tile
   constexpr int A_BYTES = BM_T * BK * 2;
   constexpr int STAGE_BYTES = (BM_T + BN_T) * BK * 2;
   constexpr int LOADS = ACH + WCH;              // LDS-DMA instructions per thread per k-tile
   static_assert(DMA || NST == 2, "register staging supports two stages only");
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  static_assert(KS == 1 || (NST == 2 && DMA && EPI != E_QKV), "split-K: two-stage LDS-DMA kernels without in-epilogue barriers");
+  extern __shared__ __attribute__((aligned(16))) char smem_all[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int kgroup = KS == 1 ? 0 : (tid >> 6) / NW;     // which k-group this wave belongs to
+  const int wave = KS == 1 ? (tid >> 6) : (tid >> 6) % NW;  // wave index inside the group
+  char* smem = smem_all + kgroup * (NST * STAGE_BYTES);
   const int wm = wave / WN, wn = wave % WN;
   const int tiles_n = (g.N + BN_T - 1) / BN_T;
   const int bid = xcd_remap(blockIdx.x, gridDim.x, g.xcd);
@@ -169,7 +176,7 @@ __global__ __launch_bounds__((BM_T / WTM) * (BN_T / 64) * 64) void gemm_kernel(G
   };
 
   // ---- main loop ----
-  if constexpr (NST == 2) {
+  if constexpr (NST == 2 && KS == 1) {
     issue(0, 0);
     if constexpr (DMA) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -188,6 +195,39 @@ __global__ __launch_bounds__((BM_T / WTM) * (BN_T / 64) * 64) void gemm_kernel(G
       }
       __syncthreads();
     }
+  } else if constexpr (NST == 2) {
+    // split-K: both groups run the same number of iterations (barriers are workgroup-wide); a group without a k-tile
+    // in an iteration simply skips its loads and MFMAs
+    const int nit = (nk + KS - 1) / KS;
+    if (kgroup < nk) issue(kgroup, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int it = 0; it < nit; ++it) {
+      const int cur = it & 1;
+      const int kt = it * KS + kgroup;
+      if (kt + KS < nk) issue(kt + KS, cur ^ 1);
+      if (kt < nk) compute(cur);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+    // fold group 1 into group 0: [wave][acc register][lane] fp32, conflict-free and coalesced
+    float* red = reinterpret_cast<float*>(smem_all) + wave * (MI * 16 * 64);
+    if (kgroup == 1) {
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) red[((mi * 4 + ni) * 4 + j) * 64 + lane] = acc[mi][ni][j];
+    }
+    __syncthreads();
+    if (kgroup == 1) return;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[mi][ni][j] += red[((mi * 4 + ni) * 4 + j) * 64 + lane];
   } else {
     // 3-stage ring.  Invariant at the top of iteration kt: tile kt has landed and is visible to every wave
     // (its waves waited for it, then passed a barrier); tile kt+1 may still be in flight.
@@ -216,7 +256,8 @@ __global__ __launch_bounds__((BM_T / WTM) * (BN_T / 64) * 64) void gemm_kernel(G
   // ---- epilogue: 16 output rows at a time are transposed through a per-wave LDS scratch so that global traffic is
   // 16 B per lane on whole 128/256-byte row segments (the MFMA C layout gives a lane one column and four rows).
   // All stage buffers are dead after the last barrier; same-wave LDS accesses complete in order.
-  float* ep = reinterpret_cast<float*>(smem) + wave * (16 * EP_LD);
+  // (with split-K the scratch sits behind the reduction area, which other waves of group 0 may still be reading)
+  float* ep = reinterpret_cast<float*>(smem_all) + (KS == 2 ? NW * MI * 16 * 64 : 0) + wave * (16 * EP_LD);
   const int colq = lane & 15, rowq = (lane >> 4) * 4;
   const int nw = n0 + wn * 64;
   [[maybe_unused]] const bool has_res = g.resid != nullptr;
@@ -404,17 +445,18 @@ __global__ __launch_bounds__((BM_T / WTM) * (BN_T / 64) * 64) void gemm_kernel(G
   }
 }
 
-template <int BM_T, int BN_T, int WTM, int NST, int AMODE, int EPI, bool DMA>
+template <int BM_T, int BN_T, int WTM, int NST, int AMODE, int EPI, bool DMA, int KS = 1>
 static int launch_t(const GemmArgs& g, hipStream_t stream) {
-  constexpr int nthreads = (BM_T / WTM) * (BN_T / 64) * 64;
-  constexpr int stage_lds = NST * (BM_T + BN_T) * BK * 2;
-  constexpr int ep_lds = (nthreads / 64) * 16 * EP_LD * 4 + 2 * (nthreads / 64) * 16 * 4;
+  constexpr int nthreads = (BM_T / WTM) * (BN_T / 64) * 64 * KS;
+  constexpr int stage_lds = KS * NST * (BM_T + BN_T) * BK * 2;
+  constexpr int ep_lds = (nthreads / 64) * 16 * EP_LD * 4 + 2 * (nthreads / 64) * 16 * 4 +
+                         (KS == 2 ? (nthreads / 128) * (WTM / 16) * 16 * 64 * 4 : 0);
   constexpr int lds = stage_lds > ep_lds ? stage_lds : ep_lds;
   const int tiles = (g.M / BM_T) * ((g.N + BN_T - 1) / BN_T);
   static const int xcd_flag = tuning_flag("GEMM_XCD", 1);
   GemmArgs ga = g;
   ga.xcd = xcd_flag;
-  auto kern = gemm_kernel<BM_T, BN_T, WTM, NST, AMODE, EPI, DMA>;
+  auto kern = gemm_kernel<BM_T, BN_T, WTM, NST, AMODE, EPI, DMA, KS>;
   static bool attr_set = false;
   if (!attr_set) {
     DFOT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -435,6 +477,9 @@ static int launch_v(int variant, const GemmArgs& g, hipStream_t s) {
     case GEMM_DMA_256x256: return launch_t<256, 256, 64, 2, AMODE, EPI, true>(g, s);
     case GEMM_DMA_256x128: return launch_t<256, 128, 64, 2, AMODE, EPI, true>(g, s);
     case GEMM_DMA_512x128: return launch_t<512, 128, 64, 2, AMODE, EPI, true>(g, s);
+    case GEMM_DMA_128_KS2:
+      if constexpr (EPI == E_QKV) break;
+      else return launch_t<128, 128, 64, 2, AMODE, EPI, true, 2>(g, s);
     case GEMM_DMA_256x256_W128:
       if (g.gn_part) break;  // fused GroupNorm partials assume 64-row wave tiles
       return launch_t<256, 256, 128, 2, AMODE, EPI, true>(g, s);
@@ -448,11 +493,13 @@ int gemm_pick_variant(int amode, int m, int n, int k) {
   // traffic, so the 256x256 tile (128 FLOP per operand byte instead of 64) wins whenever it still fills the chip:
   // N wide enough that the padded columns are cheap, and enough tiles for the 256 CUs.
   (void)amode;
-  (void)k;
   const long tiles = (long)(m / 256) * ((n + 255) / 256);
   if (m % 256 == 0 && n >= 192 && tiles >= 160) return GEMM_DMA_256x256;
   // N = 128 (level-0 convolutions): one column of tiles, so grow the tile along M instead (16 waves, 102 FLOP/B)
   if (m % 512 == 0 && n <= 128 && m / 512 >= 256) return GEMM_DMA_512x128;
+  // at most one 128x128 tile per CU and a long K (Upsample convolutions at 16x16 / 32x32): split K inside the workgroup
+  const long tiles128 = (long)(m / 128) * ((n + 127) / 128);
+  if (tiles128 <= 256 && k >= 2048) return GEMM_DMA_128_KS2;
   return GEMM_DMA_128;
 }
 

@@ -35,7 +35,7 @@ def report(name, got, ref):
     return err, rel
 
 
-@pytest.mark.parametrize("dma", [0, 1, 2, 3, 4, 5, 7])
+@pytest.mark.parametrize("dma", [0, 1, 2, 3, 4, 5, 7, 8])
 @pytest.mark.parametrize("m,n,k", [(256, 128, 64), (256, 192, 128), (1024, 576, 576), (256, 4032, 576), (768, 100, 2880),
                                    (512, 256, 192)])
 def test_gemm(capi, dma, m, n, k):
@@ -70,7 +70,7 @@ def test_gemm_rejects_bad_shapes(capi):
         capi.check(capi.lib.dfot_op_gemm(P(a), 64, P(a), None, P(out), 100, 64, 64, 1, S()))
 
 
-@pytest.mark.parametrize("dma", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("dma", [0, 1, 2, 3, 4, 8])
 @pytest.mark.parametrize("bt,h,w,cin,cout", [(4, 8, 8, 128, 128), (1, 16, 16, 128, 256), (2, 8, 16, 576, 256), (4, 16, 8, 64, 100)])
 def test_conv3x3(capi, dma, bt, h, w, cin, cout):
     g = torch.Generator().manual_seed(bt * 1000 + cin + cout)
