@@ -740,6 +740,56 @@ int launch_ddim_compose(const float* x, const float* x_in, const float* v, const
 }
 
 // --------------------------------------------------------------------------------------------
+// continuous-time v-prediction loss of one noised forward (ContinuousDiffusion.forward, continuous_diffusion.py:140-167;
+// used by training_step and by the validation denoising loss): x_t = a x + s eps ; eps_hat = a v + s x_t ;
+// loss = (eps_hat - eps)^2 * w ; x_pred = a x_t - s v.  Deterministic two-stage mean per (video, token).
+// --------------------------------------------------------------------------------------------
+constexpr int VL_CHUNK = 4096;
+__global__ __launch_bounds__(256) void vloss_partial_kernel(const float* __restrict__ x, const float* __restrict__ noise,
+                                                            const float* __restrict__ v, const float* __restrict__ a,
+                                                            const float* __restrict__ sg, const float* __restrict__ w,
+                                                            float* __restrict__ x_pred, float* __restrict__ partial, long f) {
+  __shared__ float red[4];
+  const int bt = blockIdx.y, chunk = blockIdx.x;
+  const float av = a[bt], sv = sg[bt], wv = w[bt];
+  const long base = (long)bt * f;
+  const long e0 = (long)chunk * VL_CHUNK;
+  float acc = 0.f;
+  for (long e = e0 + threadIdx.x * 4; e < min(e0 + VL_CHUNK, f); e += 1024) {
+    const float4v xv = *reinterpret_cast<const float4v*>(x + base + e);
+    const float4v nv = *reinterpret_cast<const float4v*>(noise + base + e);
+    const float4v vv = *reinterpret_cast<const float4v*>(v + base + e);
+    const float4v xt = xv * av + nv * sv;
+    const float4v eh = vv * av + xt * sv;
+    const float4v d = eh - nv;
+    acc += (d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3]) * wv;
+    if (x_pred) *reinterpret_cast<float4v*>(x_pred + base + e) = xt * av - vv * sv;
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[(long)bt * gridDim.x + chunk] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ void vloss_finalize_kernel(const float* __restrict__ partial, float* __restrict__ loss, int chunks, float inv_f) {
+  const int bt = blockIdx.x * blockDim.x + threadIdx.x;
+  if (bt >= (int)gridDim.x * (int)blockDim.x) return;
+  float s = 0.f;
+  for (int c = 0; c < chunks; ++c) s += partial[(long)bt * chunks + c];
+  loss[bt] = s * inv_f;
+}
+int vloss_chunks(long f) { return cdiv(f, VL_CHUNK); }
+int launch_vloss(const float* x, const float* noise, const float* v, const float* a, const float* sg, const float* w,
+                 float* x_pred, float* partial, float* loss, int bt, long f, hipStream_t s) {
+  DFOT_REQUIRE(f % 4 == 0, DFOT_ERR_SHAPE, "vloss: frame elements %ld must be a multiple of 4", f);
+  const int chunks = vloss_chunks(f);
+  hipLaunchKernelGGL(vloss_partial_kernel, dim3(chunks, bt), dim3(256), 0, s, x, noise, v, a, sg, w, x_pred, partial, f);
+  DFOT_CHECK_HIP(hipGetLastError());
+  hipLaunchKernelGGL(vloss_finalize_kernel, dim3(bt), dim3(1), 0, s, partial, loss, chunks, 1.0f / (float)f);
+  DFOT_CHECK_HIP(hipGetLastError());
+  return DFOT_OK;
+}
+
+// --------------------------------------------------------------------------------------------
 // casts, weight packing, layout taps
 // --------------------------------------------------------------------------------------------
 __global__ void f32_to_bf16_kernel(const float* __restrict__ s, bf16* __restrict__ d, long n) {

@@ -771,6 +771,17 @@ int dfot_ddim_compose(const float* x, const float* x_in, const float* v, const f
                              (hipStream_t)stream);
 }
 
+int dfot_vpred_loss(const float* x, const float* noise, const float* v, const float* alpha, const float* sigma,
+                    const float* weight, float* x_pred, float* scratch, float* loss, int batch, int tokens, int64_t frame_elems,
+                    void* stream) {
+  DFOT_REQUIRE(x && noise && v && alpha && sigma && weight && scratch && loss, DFOT_ERR_ARG, "vpred_loss: null argument");
+  return launch_vloss(x, noise, v, alpha, sigma, weight, x_pred, scratch, loss, batch * tokens, (long)frame_elems,
+                      (hipStream_t)stream);
+}
+int64_t dfot_vpred_loss_scratch_floats(int batch, int tokens, int64_t frame_elems) {
+  return (int64_t)batch * tokens * vloss_chunks((long)frame_elems);
+}
+
 static bf16* g_zero_page = nullptr;
 static int zero_page(bf16** out) {
   if (!g_zero_page) {

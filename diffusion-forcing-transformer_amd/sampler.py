@@ -84,6 +84,47 @@ class DFoTVideoPoseSampler:
         capi.check(capi.lib.dfot_ray_encode(capi.ptr(raw), capi.ptr(out), b, t, res, capi.stream_ptr()))
         return out
 
+    # ------------------------------------------------------------------ denoising loss (no backward)
+    @torch.no_grad()
+    def denoising_loss(self, xs: torch.Tensor, conditions: Optional[torch.Tensor], t: torch.Tensor,
+                       noise: Optional[torch.Tensor] = None, masks: Optional[torch.Tensor] = None,
+                       shift: float = 0.125, sigmoid_bias: float = -1.0):
+        """One noised forward + sigmoid-weighted v-prediction loss: ``ContinuousDiffusion.forward``
+        (diffusion/continuous_diffusion.py:140-167) followed by ``_reweight_loss``
+        (algorithms/common/base_pytorch_video_algo.py:684-693) -- what ``training_step`` and the validation
+        denoising loss evaluate (dfot_video.py:41-75).  t: (B,T) in [0,1] per-token noise levels.
+        Returns (x_pred, loss scalar, per-token loss (B,T))."""
+        b, tk = xs.shape[:2]
+        f = int(np.prod(xs.shape[2:]))
+        tt = t.detach().float().cpu()
+        # cosine logSNR schedule of the reference in fp32 (CosineNoiseSchedule, continuous_diffusion.py:46-92)
+        lo = torch.atan(torch.exp(-0.5 * torch.tensor(15.0)))
+        hi = torch.atan(torch.exp(-0.5 * torch.tensor(-15.0)))
+        logsnr = -2 * torch.log(torch.tan(lo + tt * (hi - lo))) + 2 * torch.log(torch.tensor(shift))
+        alpha = torch.sigmoid(logsnr).sqrt()
+        sigma = torch.sigmoid(-logsnr).sqrt()
+        weight = torch.sigmoid(sigmoid_bias - logsnr)
+        tab = torch.stack([alpha, sigma, weight, self.cfg.diffusion.precond_scale * logsnr]).float().cuda().contiguous()
+        x = xs.to(device="cuda", dtype=torch.float32).contiguous()
+        if noise is None:
+            noise = self.noise_fn("train", tuple(x.shape))
+        eps = noise.to(device="cuda", dtype=torch.float32).clamp(-self.cfg.diffusion.clip_noise, self.cfg.diffusion.clip_noise).contiguous()
+        ones = torch.ones(b, tk, device="cuda")
+        x_t = torch.empty_like(x)
+        capi.check(capi.lib.dfot_hg_prepare(capi.ptr(x), capi.ptr(eps), capi.ptr(tab[0]), capi.ptr(tab[1]), capi.ptr(x_t),
+                                            b, 1, tk, f, capi.stream_ptr()))
+        v = self.model(x_t, tab[3], self._process_conditions(conditions), None)
+        x_pred = torch.empty_like(x)
+        per_token = torch.empty(b, tk, device="cuda")
+        scratch = torch.empty(int(capi.lib.dfot_vpred_loss_scratch_floats(b, tk, f)), device="cuda")
+        capi.check(capi.lib.dfot_vpred_loss(capi.ptr(x), capi.ptr(eps), capi.ptr(v), capi.ptr(tab[0]), capi.ptr(tab[1]),
+                                            capi.ptr(tab[2]), capi.ptr(x_pred), capi.ptr(scratch), capi.ptr(per_token), b, tk, f,
+                                            capi.stream_ptr()))
+        del ones
+        if masks is not None:
+            per_token = per_token * masks.to(device="cuda", dtype=torch.float32).view(b, tk)
+        return x_pred, per_token.mean(), per_token
+
     # data (un)normalisation of the reference (algorithms/common/base_pytorch_video_algo.py:491-502)
     def _normalize_x(self, xs: torch.Tensor, mean, std) -> torch.Tensor:
         m = torch.as_tensor(mean, dtype=xs.dtype, device=xs.device).view(-1, 1, 1)

@@ -120,6 +120,16 @@ int dfot_ddim_compose(const float* x, const float* x_in, const float* v, const f
                       const float* an, const float* cn, const float* keep, const float* weight, const uint8_t* gen,
                       float* x_next, int batch, int nfe, int tokens, int64_t frame_elems, void* stream);
 
+/* ---- denoising loss of one noised forward (training_step / validation denoising loss) -------------------------- */
+/* replaces ContinuousDiffusion.forward's frame arithmetic (diffusion/continuous_diffusion.py:140-167):
+ *   x_t = alpha*x + sigma*noise ; eps_hat = alpha*v + sigma*x_t ; loss[b,t] = mean_frame( weight*(eps_hat-noise)^2 ) ;
+ *   x_pred = alpha*x_t - sigma*v (optional, may be NULL).  alpha/sigma/weight are [B*T] fp32 (host-computed from the
+ *   cosine logSNR schedule); scratch holds dfot_vpred_loss_scratch_floats() floats.  v = backbone(x_t, 0.125*logsnr, cond). */
+int dfot_vpred_loss(const float* x, const float* noise, const float* v, const float* alpha, const float* sigma,
+                    const float* weight, float* x_pred, float* scratch, float* loss, int batch, int tokens,
+                    int64_t frame_elems, void* stream);
+int64_t dfot_vpred_loss_scratch_floats(int batch, int tokens, int64_t frame_elems);
+
 /* ---- unit-testable primitives ------------------------------------------------------------------ */
 /* C[M,N] (fp32) = A[M,K] (bf16, row stride lda) * W[N,K]^T (bf16) + bias[N] (fp32 or NULL)
  * variant: -1 auto, 0 = 128-tile register staging, 1 = 128-tile LDS-DMA 2 stages, 2 = 128-tile LDS-DMA 3-stage ring,

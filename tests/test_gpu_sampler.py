@@ -191,3 +191,28 @@ def test_short_window_is_padded_with_noise_tokens():
     p = psnr(out, ref)
     print(f"padded window: PSNR {p:.1f} dB")
     assert p >= 35.0
+
+
+def test_denoising_loss_matches_oracle():
+    """training_step / validation denoising loss (one noised forward, sigmoid-weighted v-loss) vs the oracle's
+    restatement of ContinuousDiffusion.forward (itself pinned by tests/golden/training_loss.npz)."""
+    import dfot_amd
+    from oracle import pose as opose, sampler as osm, uvit as ouvit
+    res = 64
+    ocfg, params, model = build(blocks=(1, 1, 1), mid=2)
+    g = torch.Generator().manual_seed(77)
+    xs = torch.randn(2, 8, 3, res, res, generator=g)
+    t = torch.rand(2, 8, generator=g)
+    noise = torch.randn(2, 8, 3, res, res, generator=g)
+    cnd = poses(2, 8, 9)
+    with torch.no_grad():
+        x_pred_ref, loss_ref = osm.training_loss(lambda x, k, c, m: ouvit.forward(params, ocfg, x, k, c, m), xs,
+                                                 opose.ray_encoding(cnd, res), t, noise.clamp(-20, 20))
+    samp = dfot_amd.DFoTVideoPoseSampler(dfot_amd.SamplerConfig(x_shape=(3, res, res)), model)
+    x_pred, loss, per_token = samp.denoising_loss(xs, cnd, t, noise=noise)
+    ref_tok = loss_ref.mean(dim=(2, 3, 4))
+    rel_tok = ((per_token.cpu() - ref_tok).abs() / ref_tok.abs().clamp_min(1e-6)).max().item()
+    rel_x = ((x_pred.cpu() - x_pred_ref).norm() / x_pred_ref.norm()).item()
+    print(f"denoising loss: {loss.item():.6f} vs oracle {loss_ref.mean().item():.6f}; per-token rel err {rel_tok:.3e}; x_pred rel_l2 {rel_x:.3e}")
+    assert abs(loss.item() - loss_ref.mean().item()) / loss_ref.mean().item() < 2e-2
+    assert rel_tok < 5e-2 and rel_x < 2e-2
