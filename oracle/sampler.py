@@ -61,6 +61,7 @@ class Diffusion:
     eta: float = 0.0
     clip_noise: float = 20.0
     precond_scale: float = 0.125
+    is_continuous: bool = True  # False: DiscreteDiffusion.model_predictions hands the integer level to the backbone
 
     def q_sample(self, x0, k, noise):
         t = self.tables
@@ -69,7 +70,8 @@ class Diffusion:
 
     def predictions(self, x, k, cond, cond_mask):
         t = self.tables
-        v = self.model(x, self.precond_scale * t.logsnr[k], cond, cond_mask)
+        # continuous_diffusion.py model_predictions: precond_scale * logsnr[k]; discrete_diffusion.py:173-174: k itself
+        v = self.model(x, self.precond_scale * t.logsnr[k] if self.is_continuous else k, cond, cond_mask)
         a, s = _ext(t.sqrt_alphas_cumprod[k], x.ndim), _ext(t.sqrt_one_minus_alphas_cumprod[k], x.ndim)
         return v, a * x - s * v, a * v + s * x  # v, x0, eps
 

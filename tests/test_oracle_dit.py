@@ -1,0 +1,96 @@
+"""CPU: the DiT3D / Kinetics-600 oracle (oracle/dit.py + discrete-level sampler) against fixtures produced by running the
+reference's own DiT3D / DFoTVideo / DiscreteDiffusion source (tools/make_golden_dit.py)."""
+import hashlib
+import os
+
+import numpy as np
+import torch
+
+from conftest import GOLDEN
+from oracle import dit as odit
+from oracle import sampler as osm
+from oracle import schedule as sch
+
+torch.set_num_threads(8)
+
+TINY = odit.DiTConfig(hidden_size=128, depth=3, num_heads=4, patch_size=1, in_channels=4, resolution=(8, 8), max_tokens=5)
+TINY_MLP = odit.DiTConfig(hidden_size=128, depth=2, num_heads=4, patch_size=2, in_channels=4, resolution=(8, 8),
+                          max_tokens=5, spatial_mlp_ratio=4.0)
+SMALL = odit.DiTConfig(hidden_size=128, depth=2, num_heads=4, patch_size=1, in_channels=4, resolution=(8, 8), max_tokens=5)
+
+
+def load(name):
+    return np.load(os.path.join(GOLDEN, name))
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def digest(params):
+    h = hashlib.sha256()
+    for k in params:
+        h.update(k.encode())
+        h.update(params[k].contiguous().numpy().tobytes())
+    return h.hexdigest()
+
+
+def test_param_inventory_xl():
+    shapes = odit.param_shapes(odit.DiTConfig())
+    assert len(shapes) == 6 + 28 * 6 + 4
+    n = sum(int(np.prod(s)) for s in shapes.values())
+    assert n == 264_657_040  # 28 x (7 h^2 + 7 h) + embeddings + final layer (attention-only DiT/XL, 16-ch latents, patch 1)
+
+
+def test_timestep_features_layout():
+    f = odit.timestep_features(torch.tensor([0, 3]), 256)
+    assert torch.equal(f[0, :128], torch.ones(128)) and torch.equal(f[0, 128:], torch.zeros(128))  # [cos | sin]
+    assert abs(float(f[1, 128]) - np.sin(3.0)) < 1e-6
+
+
+def test_dit_tiny_forward():
+    g = load("dit_tiny.npz")
+    p = odit.seeded_params(TINY, 0)
+    assert digest(p) == str(g["digest"])
+    x, k = T(g["x"]), T(g["k"])
+    np.testing.assert_allclose(odit.forward(p, TINY, x, k).numpy(), g["out"], rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(odit.forward(p, TINY, x[:, :3], k[:, :3]).numpy(), g["out_t3"], rtol=1e-4, atol=2e-5)
+
+
+def test_dit_tiny_mlp_patch2():
+    g = load("dit_tiny.npz")
+    p = odit.seeded_params(TINY_MLP, 1)
+    assert digest(p) == str(g["digest_mlp"])
+    np.testing.assert_allclose(odit.forward(p, TINY_MLP, T(g["x"]), T(g["k"])).numpy(), g["out_mlp"], rtol=1e-4, atol=2e-5)
+
+
+def test_dit_k600_forward():
+    g = load("dit_k600.npz")
+    cfg = odit.DiTConfig()
+    p = odit.seeded_params(cfg, 0)
+    assert digest(p) == str(g["digest"])
+    taps = {}
+    out = odit.forward(p, cfg, T(g["x"]), T(g["k"]), taps)
+    for i in (0, 13, 27):
+        np.testing.assert_allclose(float(taps[f"block{i}"].abs().mean()), float(g[f"block{i}_absmean"]), rtol=1e-4)
+        np.testing.assert_allclose(taps[f"block{i}"][0, [0, 255, 700, 1279], :64].numpy(), g[f"block{i}_rows"], rtol=1e-3, atol=1e-3)
+    np.testing.assert_allclose(out.numpy(), g["out"], rtol=1e-3, atol=1e-3)
+
+
+def test_discrete_cosine_tables_and_sampler():
+    g = load("sampler_k600.npz")
+    tb = sch.build_tables(beta_schedule="cosine")
+    np.testing.assert_allclose(tb.alphas_cumprod.numpy(), g["alphas_cumprod"], rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(tb.sqrt_alphas_cumprod.numpy(), g["sqrt_alphas_cumprod"], rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(tb.sqrt_one_minus_alphas_cumprod.numpy(), g["sqrt_one_minus_alphas_cumprod"], rtol=1e-6, atol=1e-9)
+    p = odit.seeded_params(SMALL, 2)
+    assert digest(p) == str(g["digest"])
+    model = lambda x, k, c, m: odit.forward(p, SMALL, x, k)
+    noise = [T(g[f"noise{i}"]) for i in range(int(g["n_noise"]))]
+    nfn = osm.replay_noise_fn(noise)
+    cfg = osm.SamplerConfig(x_shape=(4, 8, 8), max_tokens=5, sampling_timesteps=4,
+                            prediction_guidance=dict(name="vanilla", guidance_scale=2.0))
+    diff = osm.Diffusion(tb, model, sampling_timesteps=4, is_continuous=False)
+    out = osm.Sampler(cfg, diff, None, nfn).predict_videos(T(g["xs"]), 2, None)
+    assert not nfn.queue
+    np.testing.assert_allclose(out.numpy(), g["out"], rtol=1e-3, atol=2e-3)

@@ -1,0 +1,137 @@
+#!/usr/bin/env python3
+"""Generate the DiT3D / Kinetics-600 fixtures under tests/golden/ by executing the reference's own source on CPU.
+
+Run ONLY in the build container (needs /root/reference):   python tools/make_golden_dit.py
+Fixtures are data (inputs, injected noise, expected outputs); weights come from oracle.dit.seeded_params(cfg, seed),
+loaded strictly into the reference module and re-created bit-identically by the tests (sha256 stored).
+
+  dit_tiny.npz      DiT3D.forward: hidden 128 / depth 3 / 4 heads (head dim 32 -> uneven RoPE split 12/10/10),
+                    T=5 and a shorter T=3 window; a second model with patch 2 and spatial_mlp_ratio 4 (MLP branch)
+  dit_k600.npz      DiT3D.forward at the K600 size: DiT/XL (hidden 1152, depth 28, 16 heads), latents 16x16x16, T=5
+  sampler_k600.npz  DFoTVideo._predict_videos with DiscreteDiffusion (cosine, pred_v, integer levels): 5 tokens,
+                    context 2, 4 DDIM steps, vanilla history guidance 2.0 (small DiT) with the injected noise
+"""
+from __future__ import annotations
+
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+import ref_loader  # noqa: E402
+from make_golden import RandnRecorder, save, weights_digest  # noqa: E402
+from oracle import dit as odit  # noqa: E402
+
+torch.set_num_threads(8)
+
+
+def ref_dit(R, ocfg: odit.DiTConfig, seed: int):
+    A = R["AttrDict"]
+    cfg = A(dict(name="dit3d", variant="full", pos_emb_type="rope_3d", patch_size=ocfg.patch_size,
+                 hidden_size=ocfg.hidden_size, depth=ocfg.depth, num_heads=ocfg.num_heads, mlp_ratio=4.0,
+                 use_gradient_checkpointing=False,
+                 **({"spatial_mlp_ratio": ocfg.spatial_mlp_ratio} if ocfg.spatial_mlp_ratio else {})))
+    m = R["DiT3D"](cfg, x_shape=[ocfg.in_channels, *ocfg.resolution], max_tokens=ocfg.max_tokens,
+                   external_cond_type="action", external_cond_num_classes=None, external_cond_dim=0,
+                   use_causal_mask=False).eval()
+    params = odit.seeded_params(ocfg, seed)
+    assert list(m.state_dict().keys()) == list(params.keys()), "oracle parameter inventory differs from the reference"
+    m.load_state_dict(params, strict=True)
+    return m, params
+
+
+def video_cfg(A, ocfg: odit.DiTConfig, sampling_steps: int, hg: dict):
+    c = ocfg.in_channels
+    return A(dict(
+        debug=False, lr=5e-5, x_shape=[c, *ocfg.resolution], max_frames=ocfg.max_tokens, n_frames=ocfg.max_tokens,
+        frame_skip=1, context_frames=2,
+        latent=dict(enabled=False, type="pre_sample", suffix=None, downsampling_factor=[1, 1], shape=None, num_channels=c),
+        data_mean=[[[0.0]]] * c, data_std=[[[1.0]]] * c,
+        external_cond_type="action", external_cond_num_classes=None, external_cond_dim=0, external_cond_stack=False,
+        external_cond_processing=None, compile=False, weight_decay=0.0, optimizer_beta=[0.9, 0.99],
+        lr_scheduler=dict(name="constant_with_warmup", num_warmup_steps=10),
+        noise_level="random_independent", uniform_future=dict(enabled=False),
+        fixed_context=dict(enabled=False, indices=None, dropout=0),
+        variable_context=dict(enabled=False, prob=0.25, dropout=0.3),
+        chunk_size=-1, scheduling_matrix="full_sequence", replacement="noisy_scale",
+        refinement_sampling=dict(enabled=False, goback_length=20, n_goback=5),
+        save_attn_map=dict(enabled=False, attn_map_dir=None),
+        diffusion=dict(is_continuous=False, timesteps=1000, beta_schedule="cosine", schedule_fn_kwargs=dict(shift=1.0),
+                       use_causal_mask=False, clip_noise=20.0, objective="pred_v",
+                       loss_weighting=dict(strategy="fused_min_snr", snr_clip=5.0, cum_snr_decay=0.96),
+                       sampling_timesteps=sampling_steps, ddim_sampling_eta=0.0, reconstruction_guidance=0.0),
+        vae=dict(pretrained_path=None, pretrained_kwargs={}, use_fp16=False, batch_size=2),
+        checkpoint=dict(reset_optimizer=False, strict=True),
+        tasks=dict(prediction=dict(enabled=True, history_guidance=dict(hg, visualize=False), keyframe_density=None,
+                                   sliding_context_len=None),
+                   interpolation=dict(enabled=False, history_guidance=dict(name="conditional", visualize=False),
+                                      max_batch_size=None)),
+        logging=dict(deterministic=0, loss_freq=100, grad_norm_freq=100, max_num_videos=8, n_metrics_frames=None,
+                     metrics=[], metrics_batch_size=16, sanity_generation=False, raw_dir=None),
+        backbone=dict(name="dit3d", variant="full", pos_emb_type="rope_3d", patch_size=ocfg.patch_size,
+                      hidden_size=ocfg.hidden_size, depth=ocfg.depth, num_heads=ocfg.num_heads, mlp_ratio=4.0,
+                      use_gradient_checkpointing=False),
+    ))
+
+
+@torch.no_grad()
+def main():
+    R = ref_loader.install()
+    A = R["AttrDict"]
+
+    print("dit tiny")
+    tiny = odit.DiTConfig(hidden_size=128, depth=3, num_heads=4, patch_size=1, in_channels=4, resolution=(8, 8), max_tokens=5)
+    m, p = ref_dit(R, tiny, 0)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 5, 4, 8, 8, generator=g)
+    k = torch.randint(0, 1000, (2, 5), generator=g)
+    tiny_mlp = odit.DiTConfig(hidden_size=128, depth=2, num_heads=4, patch_size=2, in_channels=4, resolution=(8, 8),
+                              max_tokens=5, spatial_mlp_ratio=4.0)
+    m2, p2 = ref_dit(R, tiny_mlp, 1)
+    save("dit_tiny.npz", x=x, k=k, out=m(x, k), out_t3=m(x[:, :3], k[:, :3]), digest=np.array(weights_digest(p)),
+         out_mlp=m2(x, k), digest_mlp=np.array(weights_digest(p2)))
+
+    print("dit k600")
+    xl = odit.DiTConfig()
+    m, p = ref_dit(R, xl, 0)
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(1, 5, 16, 16, 16, generator=g)
+    k = torch.tensor([[0, 17, 500, 871, 999]])
+    hooks, blocks = [], {}
+    for i in (0, 13, 27):
+        hooks.append(m.dit_base.blocks[i].register_forward_hook(lambda mod, a, o, i=i: blocks.__setitem__(i, o.clone())))
+    out = m(x, k)
+    # per-block fixtures: mean |x| and the first 64 channels of 4 tokens (the residual stream is [1, 1280, 1152])
+    extra = {}
+    for i, o in blocks.items():
+        extra[f"block{i}_absmean"] = o.abs().mean()
+        extra[f"block{i}_rows"] = o[0, [0, 255, 700, 1279], :64]
+    save("dit_k600.npz", x=x, k=k, out=out, digest=np.array(weights_digest(p)), **extra)
+    del m
+
+    print("sampler k600")
+    small = odit.DiTConfig(hidden_size=128, depth=2, num_heads=4, patch_size=1, in_channels=4, resolution=(8, 8), max_tokens=5)
+    cfg = video_cfg(A, small, sampling_steps=4, hg=dict(name="vanilla", guidance_scale=2.0))
+    algo = R["DFoTVideo"](cfg).eval()
+    ps = odit.seeded_params(small, 2)
+    algo.diffusion_model.model.load_state_dict(ps, strict=True)
+    dm = algo.diffusion_model
+    g = torch.Generator().manual_seed(7)
+    vid = torch.randn(2, 5, 4, 8, 8, generator=g)
+    algo.generator = torch.Generator().manual_seed(0)
+    with RandnRecorder() as rec:
+        out = algo._predict_videos(vid.clone(), n_context_tokens=2, conditions=None)
+    arrays = {f"noise{i}": d for i, d in enumerate(rec.draws)}
+    save("sampler_k600.npz", xs=vid, out=out, n_noise=np.array(len(rec.draws)), digest=np.array(weights_digest(ps)),
+         alphas_cumprod=dm.alphas_cumprod, sqrt_alphas_cumprod=dm.sqrt_alphas_cumprod,
+         sqrt_one_minus_alphas_cumprod=dm.sqrt_one_minus_alphas_cumprod, **arrays)
+    print("done")
+
+
+if __name__ == "__main__":
+    main()

@@ -228,15 +228,19 @@ def install():
     for n in ("Unet3D", "DiT3D", "DiT3DPose", "FARDiT", "DIT1D", "DifferenceDiT3D"):
         setattr(bb, n, None)
     bb.UViT3D, bb.UViT3DPose = uvit.UViT3D, uvit_pose.UViT3DPose
+    dit3d = imp("algorithms.dfot.backbones.dit.dit3d")  # K600 backbone (only the "full" variant is exercised)
+    bb.DiT3D = dit3d.DiT3D
     dd = imp("algorithms.dfot.diffusion.discrete_diffusion")
     cd = imp("algorithms.dfot.diffusion.continuous_diffusion")
     dpk = sys.modules["algorithms.dfot.diffusion"]
     dpk.DiscreteDiffusion, dpk.ContinuousDiffusion = dd.DiscreteDiffusion, cd.ContinuousDiffusion
     hgm = imp("algorithms.dfot.history_guidance")
     pose_algo = imp("algorithms.dfot.dfot_video_pose")
+    video_algo = sys.modules["algorithms.dfot.dfot_video"]
     geo = imp("utils.geometry_utils")
     return {
         "UViT3DPose": uvit_pose.UViT3DPose, "blocks": blocks, "DiscreteDiffusion": dd.DiscreteDiffusion,
         "ContinuousDiffusion": cd.ContinuousDiffusion, "HistoryGuidance": hgm.HistoryGuidance,
-        "DFoTVideoPose": pose_algo.DFoTVideoPose, "geometry": geo, "AttrDict": AttrDict,
+        "DFoTVideoPose": pose_algo.DFoTVideoPose, "DFoTVideo": video_algo.DFoTVideo, "DiT3D": dit3d.DiT3D,
+        "geometry": geo, "AttrDict": AttrDict,
     }
