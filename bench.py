@@ -64,6 +64,90 @@ def cpu_baseline(res: int, sample_forwards: int, frames: int, forwards_per_sampl
                       f"scaled to {forwards_per_sample} window-forwards per {frames}-frame sample"}
 
 
+def bench_k600(args, rank, world, dist):
+    """BASELINE config 4: Kinetics-600 latents [16,16,16], 17 frames = 5 latent tokens, context 5 frames = 2 tokens,
+    README model @DiT/XL (dit3d full, rope_3d; attention-only blocks in this fork), DiscreteDiffusion cosine / pred_v,
+    50 DDIM steps, history guidance 'conditional' (dfot_video.yaml default), `--batch` videos per GPU."""
+    import dfot_amd
+    from dfot_amd import DFoTVideoSampler, DiffusionConfig, DiT3D, SamplerConfig
+    xl = dict(name="dit3d", variant="full", pos_emb_type="rope_3d", patch_size=1, hidden_size=1152, depth=28, num_heads=16)
+    model = DiT3D(xl, x_shape=(16, 16, 16), max_tokens=5).cuda()
+    model.init_random(seed=0)
+    cfg = SamplerConfig(x_shape=(16, 16, 16), max_tokens=5,
+                        diffusion=DiffusionConfig(sampling_timesteps=args.sampling_steps, beta_schedule="cosine", is_continuous=False),
+                        prediction_guidance=dict(name="conditional"))
+    gen = torch.Generator(device="cuda").manual_seed(1234 + rank)
+    sampler = DFoTVideoSampler(cfg, model, dfot_amd.device_noise_fn(gen))
+    b = args.batch
+    xs = torch.randn(b, 5, 16, 16, 16, generator=torch.Generator().manual_seed(rank)).cuda()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        sampler._predict_videos(xs, n_context_tokens=2, conditions=None)
+    sampler.use_graph = args.graph
+    model.set_option("time_attn", 0 if args.graph or rank else args.sampling_steps * 28 * args.steps)
+    sampler.window_forwards = 0
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = sampler._predict_videos(xs, n_context_tokens=2, conditions=None)
+    barrier()
+    dt = time.perf_counter() - t0
+    assert torch.isfinite(out).all()
+    if dist is not None:
+        tmax = torch.tensor([dt], device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    fwd = sampler.window_forwards
+    tokens_per_step = 3 * b  # generated latent frames per sample call (5 tokens - 2 context) x videos
+    if rank == 0:
+        attn_ms, attn_n = model.attn_timing()
+        n, d, heads = 1280, 72, 16
+        flop_per_launch = 4.0 * n * n * d * heads * b
+        achieved = flop_per_launch * attn_n / (attn_ms * 1e-3) / 1e12 if attn_n else None
+        # model FLOPs per video-forward: 28 x (qkv 2*N*h*3h + proj 2*N*h*h + attention 4*N^2*d*heads)
+        video_flop = 28 * (2.0 * n * 1152 * 3456 + 2.0 * n * 1152 * 1152 + 4.0 * n * n * d * heads)
+        line = {
+            "metric": "denoised latent frames/sec, DFoT K600 (DiT/XL) 17-frame prediction", "value": tokens_per_step * args.steps * world / dt,
+            "unit": "latent frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+            "data": "synthetic latents, seeded random-init weights",
+            "config": {"workload": f"DFoT K600 @DiT/XL: {b} videos per GPU, latents 16x16x16, 5 tokens (17 frames), context 2 tokens, "
+                                   f"{args.sampling_steps} DDIM steps, conditional history guidance (NFE 1)",
+                       "window_forwards_per_step": fwd // args.steps, "frames_per_step": tokens_per_step,
+                       "pixel_frames_per_step": 12 * b},
+            "video_forward_ms": dt / fwd * 1e3, "model_tflops": video_flop * fwd / dt / 1e12,
+            "roofline": {"bound": "mfma", "kernel": "attn_kernel_v2<128,2,80,96> (DiT attention, N=1280, head dim 72 in 128-wide rows)",
+                         "achieved": achieved, "peak": 2500.0, "unit": "TFLOP/s", "frac": achieved / 2500.0 if achieved else None,
+                         "traffic": None, "launches": attn_n, "avg_launch_ms": attn_ms / max(attn_n, 1), "flop_per_launch": flop_per_launch},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            from oracle import dit as odit
+            ocfg = odit.DiTConfig()
+            params = odit.seeded_params(ocfg, 0)
+            cores = min(16, os.cpu_count() or 1)
+            torch.set_num_threads(cores)
+            x1 = torch.randn(1, 5, 16, 16, 16)
+            k1 = torch.randint(0, 1000, (1, 5))
+            t1 = time.perf_counter()
+            reps = 3
+            with torch.no_grad():
+                for _ in range(reps):
+                    odit.forward(params, ocfg, x1, k1)
+            per = (time.perf_counter() - t1) / reps
+            line["cpu_baseline"] = {"value": 3.0 / (args.sampling_steps * per), "unit": "latent frames/s", "cores": cores, "kind": "port",
+                                    "sample": f"{reps} single-video forwards of the oracle DiT/XL (1x5x16x16x16), {per:.2f} s each; scaled to "
+                                              f"{args.sampling_steps} forwards per 3 generated latent frames"}
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -73,7 +157,8 @@ def main():
     ap.add_argument("--sampling-steps", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", action="store_true", help="replay one hipGraph-captured DDIM step (no in-run attention timing)")
-    ap.add_argument("--workload", choices=["8f", "200f"], default="8f",
+    ap.add_argument("--batch", type=int, default=8, help="k600: videos per GPU (bash/k600 validation.batch_size)")
+    ap.add_argument("--workload", choices=["8f", "200f", "k600"], default="8f",
                     help="8f: BASELINE config 2 (default, the metric's single-GPU configuration); 200f: config 3, the "
                          "200-frame rollout (keyframe density 0.0625, stabilized HG 4.0/0.02 + interpolation HG 1.5, batches of "
                          "4 windows), interpolation windows sharded over ranks")
@@ -91,6 +176,8 @@ def main():
     import dfot_amd
     from dfot_amd import DFoTVideoPoseSampler, DiffusionConfig, SamplerConfig, UViT3DPose
 
+    if args.workload == "k600":
+        return bench_k600(args, rank, world, dist if world > 1 else None)
     res = args.res
     model = UViT3DPose(RE10K, x_shape=(3, res, res), max_tokens=8).cuda()
     model.init_random(seed=0)

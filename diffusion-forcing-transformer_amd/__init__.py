@@ -4,8 +4,9 @@ reference's backbone / sampler interfaces.  Importing it requires the built HIP 
 there is no CPU fallback."""
 from . import capi  # noqa: F401  (raises ImportError when libdfot_hip.so is missing)
 from .backbone import UViT3DPose  # noqa: F401
+from .dit_backbone import DiT3D  # noqa: F401
 from .diffusion import DiffusionConfig, Schedule  # noqa: F401
 from .guidance import HistoryGuidance  # noqa: F401
-from .sampler import DFoTVideoPoseSampler, SamplerConfig, device_noise_fn  # noqa: F401
+from .sampler import DFoTVideoPoseSampler, DFoTVideoSampler, SamplerConfig, device_noise_fn  # noqa: F401
 from . import parallel  # noqa: F401,E402
 from .checkpoint import load_reference_checkpoint  # noqa: F401,E402

@@ -30,6 +30,15 @@ class UViTConfig(C.Structure):
     ]
 
 
+class DiTConfig(C.Structure):
+    _fields_ = [
+        ("hidden_size", C.c_int32), ("depth", C.c_int32), ("num_heads", C.c_int32), ("patch_size", C.c_int32),
+        ("in_channels", C.c_int32), ("height", C.c_int32), ("width", C.c_int32), ("max_tokens", C.c_int32),
+        ("mlp_hidden", C.c_int32), ("noise_dim", C.c_int32), ("timesteps", C.c_int32),
+        ("rope_theta", C.c_float), ("eps", C.c_float),
+    ]
+
+
 # name -> (restype, argtypes); every symbol include/dfot_hip.h declares
 _P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
 SIGNATURES = {
@@ -50,6 +59,19 @@ SIGNATURES = {
     "dfot_uvit_set_conditions": (_I, [_P, _P, _P, _I, _P]),
     "dfot_uvit_forward_cached": (_I, [_P, _P, _P, _P, _I, _P]),
     "dfot_uvit_read_tap": (_I, [_P, C.c_char_p, _P, C.c_size_t, _P]),
+    "dfot_dit_create": (_I, [C.POINTER(DiTConfig), C.POINTER(_P)]),
+    "dfot_dit_destroy": (_I, [_P]),
+    "dfot_dit_num_params": (_I, [_P]),
+    "dfot_dit_param_name": (C.c_char_p, [_P, _I]),
+    "dfot_dit_param_shape": (_I, [_P, _I, C.POINTER(_L), C.POINTER(_I)]),
+    "dfot_dit_load_weight": (_I, [_P, C.c_char_p, _P, C.POINTER(_L), _I, _P]),
+    "dfot_dit_finalize": (_I, [_P, _P]),
+    "dfot_dit_reserve": (_I, [_P, _I]),
+    "dfot_dit_workspace_bytes": (C.c_size_t, [_P]),
+    "dfot_dit_set_option": (_I, [_P, C.c_char_p, _I]),
+    "dfot_dit_attn_timing": (_I, [_P, C.POINTER(C.c_double), C.POINTER(_L)]),
+    "dfot_dit_forward": (_I, [_P, _P, _P, _P, _I, _I, _P]),
+    "dfot_dit_read_tap": (_I, [_P, C.c_char_p, _P, C.c_size_t, _P]),
     "dfot_ray_encode": (_I, [_P, _P, _I, _I, _I, _P]),
     "dfot_hg_prepare": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _L, _P]),
     "dfot_ddim_compose": (_I, [_P] * 11 + [_I, _I, _I, _L, _P]),
@@ -58,6 +80,7 @@ SIGNATURES = {
     "dfot_op_gemm": (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _P]),
     "dfot_op_conv3x3": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "dfot_op_attention": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "dfot_op_attention_padded": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "dfot_op_f32_to_bf16": (_I, [_P, _P, _L, _P]),
     "dfot_op_bf16_to_f32": (_I, [_P, _P, _L, _P]),
 }

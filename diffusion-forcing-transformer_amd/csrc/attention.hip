@@ -198,10 +198,14 @@ __global__ __launch_bounds__(256) void attn_kernel(const bf16* __restrict__ Q, c
 //    more than 2^8 -- the branch is wave-uniform; P is then bounded by 256, exact enough for bf16 P / fp32 sums;
 //  * row max via v_max3.
 // ---------------------------------------------------------------------------------------------
-template <int D, int NST>
+// DQK / DV: head dims actually multiplied (multiples of 16 / 32, <= D) when the logical head dim is smaller than the
+// row stride D of the q/k/v layout (DiT: d = 72 in 128-element rows -> DQK 80, DV 96; the pad columns hold zeros).
+// Output: head hd of query row r goes to O[r*ldo + hd*ohs + c] for c < dvalid.
+template <int D, int NST, int DQK = D, int DV = D>
 __global__ __launch_bounds__(256) void attn_kernel_v2(const bf16* __restrict__ Q, const bf16* __restrict__ K,
                                                       const bf16* __restrict__ V, bf16* __restrict__ O, long ldo, int N,
-                                                      int heads, int xcd) {
+                                                      int heads, int xcd, int ohs, int dvalid) {
+  static_assert(DQK % 16 == 0 && DV % 32 == 0 && DQK <= D && DV <= D, "head-dim sub-range");
   using C = AttnCfg<D>;
   constexpr float THR = 8.0f;
   constexpr int RPI = 1024 / C::ROWB;           // rows covered by one 1-KiB DMA instruction (8 or 4)
@@ -219,9 +223,9 @@ __global__ __launch_bounds__(256) void attn_kernel_v2(const bf16* __restrict__ Q
   const bf16* Kb = K + base;
   const bf16* Vb = V + base;
 
-  bf16x8 qf[D / 16];
+  bf16x8 qf[DQK / 16];
 #pragma unroll
-  for (int ks = 0; ks < D / 16; ++ks)
+  for (int ks = 0; ks < DQK / 16; ++ks)
     qf[ks] = *reinterpret_cast<const bf16x8*>(Qb + (long)(q0 + lq) * D + ks * 16 + lh * 8);
 
   // per-lane DMA source offsets (elements) within a tile: LDS position (row, pos) receives source chunk swz(row,pos)
@@ -247,9 +251,9 @@ __global__ __launch_bounds__(256) void attn_kernel_v2(const bf16* __restrict__ Q
     }
   };
 
-  f32x16 oacc[D / 32];
+  f32x16 oacc[DV / 32];
 #pragma unroll
-  for (int i = 0; i < D / 32; ++i)
+  for (int i = 0; i < DV / 32; ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) oacc[i][r] = 0.f;
   float m_run = 0.f, l_i = 0.f;
@@ -289,7 +293,7 @@ __global__ __launch_bounds__(256) void attn_kernel_v2(const bf16* __restrict__ Q
       for (int r = 0; r < 16; ++r) sacc[kt2][r] = -m_run;
       const int row = kt2 * 32 + lq;
 #pragma unroll
-      for (int ks = 0; ks < D / 16; ++ks) {
+      for (int ks = 0; ks < DQK / 16; ++ks) {
         const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sk + row * C::ROWB + C::swz_k(row, ks * 2 + lh) * 16);
         sacc[kt2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sacc[kt2], 0, 0, 0);
       }
@@ -312,7 +316,7 @@ __global__ __launch_bounds__(256) void attn_kernel_v2(const bf16* __restrict__ Q
       m_run += delta;
       l_i *= alpha;
 #pragma unroll
-      for (int i = 0; i < D / 32; ++i)
+      for (int i = 0; i < DV / 32; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
 #pragma unroll
@@ -337,7 +341,7 @@ __global__ __launch_bounds__(256) void attn_kernel_v2(const bf16* __restrict__ Q
 
     // ---- O^T += V^T P^T ----
 #pragma unroll
-    for (int dvt = 0; dvt < D / 32; ++dvt) {
+    for (int dvt = 0; dvt < DV / 32; ++dvt) {
 #pragma unroll
       for (int kt2 = 0; kt2 < 2; ++kt2) {
 #pragma unroll
@@ -373,22 +377,23 @@ __global__ __launch_bounds__(256) void attn_kernel_v2(const bf16* __restrict__ Q
   const float l_tot = l_i + __shfl_xor(l_i, 32);
   const float inv = 1.0f / l_tot;
   const int b = bh / heads, hd = bh % heads;
-  bf16* orow = O + ((long)b * N + q0 + lq) * ldo + hd * D;
+  bf16* orow = O + ((long)b * N + q0 + lq) * ldo + hd * ohs;
 #pragma unroll
-  for (int dvt = 0; dvt < D / 32; ++dvt)
+  for (int dvt = 0; dvt < DV / 32; ++dvt)
 #pragma unroll
     for (int g4 = 0; g4 < 4; ++g4) {
       bf16x4 o4;
 #pragma unroll
       for (int j = 0; j < 4; ++j) o4[j] = f2bf(oacc[dvt][4 * g4 + j] * inv);
-      *reinterpret_cast<bf16x4*>(orow + dvt * 32 + 8 * g4 + 4 * lh) = o4;
+      const int c = dvt * 32 + 8 * g4 + 4 * lh;
+      if (c < dvalid) *reinterpret_cast<bf16x4*>(orow + c) = o4;
     }
 }
 
-template <int D, int NST>
+template <int D, int NST, int DQK = D, int DV = D>
 static int launch_attn_v2(const bf16* q, const bf16* k, const bf16* v, bf16* o, long ldo, int batch, int heads, int n,
-                          hipStream_t stream) {
-  auto kern = attn_kernel_v2<D, NST>;
+                          hipStream_t stream, int ohs = D, int dvalid = D) {
+  auto kern = attn_kernel_v2<D, NST, DQK, DV>;
   static const int xcd_flag = tuning_flag("ATTN_XCD", 1);
   const int lds = 2 * NST * AttnCfg<D>::TILE;
   static bool attr_set = false;
@@ -396,7 +401,7 @@ static int launch_attn_v2(const bf16* q, const bf16* k, const bf16* v, bf16* o, 
     DFOT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3((n / 128) * batch * heads), dim3(256), lds, stream, q, k, v, o, ldo, n, heads, xcd_flag);
+  hipLaunchKernelGGL(kern, dim3((n / 128) * batch * heads), dim3(256), lds, stream, q, k, v, o, ldo, n, heads, xcd_flag, ohs, dvalid);
   DFOT_CHECK_HIP(hipGetLastError());
   return DFOT_OK;
 }
@@ -436,6 +441,22 @@ int launch_attention(const bf16* q, const bf16* k, const bf16* v, bf16* o, long 
   }
   return variant == 1 ? launch_attn_t<128, false>(q, k, v, o, ldo, batch, heads, n, stream)
                       : launch_attn_t<128, true>(q, k, v, o, ldo, batch, heads, n, stream);
+}
+
+// Attention over q/k/v stored [B][heads][N][dstride] with a logical head dim d <= dstride (dstride = 64 or 128, pad
+// columns zero); the output is compact: O[row][head*d + c], c < d.  Used by the DiT blocks (d = 72).
+int attention_dstride(int d) { return d <= 64 ? 64 : 128; }
+int launch_attention_padded(const bf16* q, const bf16* k, const bf16* v, bf16* o, long ldo, int batch, int heads, int n, int d,
+                            hipStream_t stream) {
+  DFOT_REQUIRE(q && k && v && o, DFOT_ERR_ARG, "attention: null pointer");
+  DFOT_REQUIRE(d > 0 && d <= 128 && d % 4 == 0, DFOT_ERR_SHAPE, "attention: head dim %d must be a multiple of 4, <= 128", d);
+  DFOT_REQUIRE(n > 0 && n % 128 == 0, DFOT_ERR_SHAPE, "attention: N=%d must be a multiple of 128", n);
+  DFOT_REQUIRE(ldo % 4 == 0, DFOT_ERR_SHAPE, "attention: output row stride %ld must be a multiple of 4", ldo);
+  if (d <= 32) return launch_attn_v2<64, 3, 32, 32>(q, k, v, o, ldo, batch, heads, n, stream, d, d);
+  if (d <= 64) return launch_attn_v2<64, 3>(q, k, v, o, ldo, batch, heads, n, stream, d, d);
+  if (d <= 80) return launch_attn_v2<128, 2, 80, 96>(q, k, v, o, ldo, batch, heads, n, stream, d, d);
+  if (d <= 96) return launch_attn_v2<128, 2, 96, 96>(q, k, v, o, ldo, batch, heads, n, stream, d, d);
+  return launch_attn_v2<128, 2>(q, k, v, o, ldo, batch, heads, n, stream, d, d);
 }
 
 }  // namespace dfot

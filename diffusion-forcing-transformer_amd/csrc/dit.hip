@@ -1,0 +1,652 @@
+// DiT3D backbone (Kinetics-600 path) on MI355X: weight packing, noise-level modulation table, forward orchestration.
+// Mirrors the module tree / state-dict names of the reference
+// (algorithms/dfot/backbones/dit/dit3d.py:146-192, dit/dit_base.py:150-196,391-419, dit/dit_blocks.py:49-128,378-542).
+//
+// Layout: tokens are channels-last rows [B*T*P][hidden]; the residual stream is fp32, GEMM operands bf16.
+// Conditioning: c = MLP(sinusoidal(noise level)) depends on the integer level only, and every block consumes it through
+// Linear(SiLU(c)).  finalize() therefore evaluates all modulations (shift|scale|gate per AdaLN-Zero, shift|scale for the
+// final AdaLN) for every level with ONE GEMM into mod_table[level][...] (1000 x 99072 fp32 = 396 MB at DiT/XL; HBM is
+// 288 GB), and forward never touches the embedding MLP or the 228 MB of modulation weights again.
+#include <cmath>
+#include <cstring>
+#include <functional>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "dfot_hip.h"
+#include "gemm.h"
+#include "kernels.h"
+
+namespace dfot {
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) float float4v;
+
+struct DitParam {
+  std::string name;
+  std::vector<int64_t> shape;
+  std::function<int(const float*, hipStream_t)> load;
+  bool loaded = false;
+};
+
+struct DitBlockW {
+  bf16 *w_qkv = nullptr, *w_proj = nullptr, *w_fc1 = nullptr, *w_fc2 = nullptr;
+  float *b_qkv = nullptr, *b_proj = nullptr, *b_fc1 = nullptr, *b_fc2 = nullptr;
+  long mod1 = 0, mod2 = 0;  // column offsets of this block's (shift|scale|gate) triples inside a mod_table row
+};
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// ---- finalize-time kernels (run once per weight load) -------------------------------------------------------------
+// get_timestep_embedding(flip_sin_to_cos=True, downscale_freq_shift=0): feat[level] = [cos(level*f_i) | sin(level*f_i)]
+__global__ void tstep_features_kernel(const float* __restrict__ freqs, float* __restrict__ feat, int levels, int dim) {
+  const int half = dim / 2;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)levels * dim) return;
+  const int lv = (int)(i / dim), c = (int)(i % dim);
+  const float a = __fmul_rn((float)lv, freqs[c < half ? c : c - half]);
+  feat[i] = c < half ? cosf(a) : sinf(a);
+}
+
+// out[r][o] = act(b[o] + sum_k W[o][k] * in[r][k]); one wave per (o, r); ACT: 0 none, 1 SiLU
+template <int ACT>
+__global__ __launch_bounds__(256) void rows_linear_kernel(const float* __restrict__ in, const float* __restrict__ w,
+                                                          const float* __restrict__ b, float* __restrict__ out,
+                                                          bf16* __restrict__ out_silu_bf16, int kdim, int odim) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int o = blockIdx.x * 4 + wave;
+  const long r = blockIdx.y;
+  if (o >= odim) return;
+  float acc = 0.f;
+  for (int i = lane; i < kdim; i += 64) acc += w[(long)o * kdim + i] * in[r * kdim + i];
+  acc = wave_sum(acc);
+  if (lane == 0) {
+    float v = acc + b[o];
+    if (ACT == 1) v = silu_f(v);
+    out[r * odim + o] = v;
+    if (out_silu_bf16) out_silu_bf16[r * odim + o] = f2bf(silu_f(v));
+  }
+}
+
+// ---- forward kernels --------------------------------------------------------------------------------------------
+// PatchEmbed (Conv2d k = s = p): x [BT][C][H][W] fp32 -> tokens [BT*gh*gw][hidden] fp32.  8 tokens per workgroup so each
+// weight row is fetched once per 8 tokens; thread = output channels t, t+256, ...
+constexpr int PE_TOK = 8;
+__global__ __launch_bounds__(256) void patch_embed_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                          const float* __restrict__ b, float* __restrict__ out, int c,
+                                                          int hh, int ww, int ps, int hidden, long rows) {
+  extern __shared__ float patch[];  // [PE_TOK][kdim]
+  const int gh = hh / ps, gw = ww / ps, kdim = c * ps * ps;
+  const long row0 = (long)blockIdx.x * PE_TOK;
+  for (int i = threadIdx.x; i < PE_TOK * kdim; i += 256) {
+    const long row = row0 + i / kdim;
+    const int kk = i % kdim;  // (ci, py, px) -- the Conv2d weight's own flattening
+    float v = 0.f;
+    if (row < rows) {
+      const long bt = row / (gh * gw);
+      const int g = (int)(row % (gh * gw)), gy = g / gw, gx = g % gw;
+      const int ci = kk / (ps * ps), py = (kk / ps) % ps, px = kk % ps;
+      v = x[((bt * c + ci) * hh + gy * ps + py) * ww + gx * ps + px];
+    }
+    patch[i] = v;
+  }
+  __syncthreads();
+  for (int o = threadIdx.x; o < hidden; o += 256) {
+    float acc[PE_TOK];
+    const float bias = b[o];
+#pragma unroll
+    for (int t = 0; t < PE_TOK; ++t) acc[t] = bias;
+    for (int kk = 0; kk < kdim; ++kk) {
+      const float wv = w[(long)o * kdim + kk];
+#pragma unroll
+      for (int t = 0; t < PE_TOK; ++t) acc[t] += wv * patch[t * kdim + kk];
+    }
+#pragma unroll
+    for (int t = 0; t < PE_TOK; ++t)
+      if (row0 + t < rows) out[(row0 + t) * hidden + o] = acc[t];
+  }
+}
+
+// AdaLN: m = LayerNorm(x) * (1 + scale) + shift, (shift|scale) = mod_table[level of the row's frame][off ...].
+// One wave per token row (hidden <= 2048); writes m as fp32 (the block's residual base, in place) and bf16 (GEMM operand).
+constexpr int LN_MAXV = 8;  // float4 per lane
+__global__ __launch_bounds__(256) void ln_mod_kernel(float* __restrict__ x, bf16* __restrict__ obf,
+                                                     const float* __restrict__ table, const int* __restrict__ levels,
+                                                     long ldt, long off, int hidden, int rows_per_frame, long rows,
+                                                     float eps, int max_level) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  float* xr = x + row * hidden;
+  float4v v[LN_MAXV];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    if (c < hidden) {
+      v[i] = *reinterpret_cast<const float4v*>(xr + c);
+      s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+    }
+  }
+  const float mean = wave_sum(s) / (float)hidden;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    if (c < hidden) {
+      v[i] -= mean;
+      q += v[i][0] * v[i][0] + v[i][1] * v[i][1] + v[i][2] * v[i][2] + v[i][3] * v[i][3];
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(q) / (float)hidden + eps);
+  int lv = levels[row / rows_per_frame];
+  lv = lv < 0 ? 0 : (lv > max_level ? max_level : lv);
+  const float* sh = table + (long)lv * ldt + off;
+  const float* sc = sh + hidden;
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    if (c < hidden) {
+      const float4v a = *reinterpret_cast<const float4v*>(sh + c);
+      const float4v g = *reinterpret_cast<const float4v*>(sc + c);
+      const float4v m = v[i] * rstd * (1.0f + g) + a;
+      *reinterpret_cast<float4v*>(xr + c) = m;
+      bf16x4 o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = f2bf(m[j]);
+      *reinterpret_cast<bf16x4*>(obf + row * hidden + c) = o;
+    }
+  }
+}
+
+// Final layer: AdaLN (shift|scale) -> Linear(hidden, p*p*C) -> unpatchify to [BT][C][H][W] (dit3d.py:129-144).
+// One wave per token row; the (small) weight is read through L2.
+__global__ __launch_bounds__(256) void final_layer_kernel(const float* __restrict__ x, const float* __restrict__ table,
+                                                          const int* __restrict__ levels, long ldt, long off,
+                                                          const float* __restrict__ w, const float* __restrict__ b,
+                                                          float* __restrict__ out, int hidden, int rows_per_frame, long rows,
+                                                          float eps, int max_level, int c, int hh, int ww, int ps) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* xr = x + row * hidden;
+  float4v v[LN_MAXV];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    const int cc = (i * 64 + lane) * 4;
+    if (cc < hidden) {
+      v[i] = *reinterpret_cast<const float4v*>(xr + cc);
+      s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+    }
+  }
+  const float mean = wave_sum(s) / (float)hidden;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    const int cc = (i * 64 + lane) * 4;
+    if (cc < hidden) {
+      v[i] -= mean;
+      q += v[i][0] * v[i][0] + v[i][1] * v[i][1] + v[i][2] * v[i][2] + v[i][3] * v[i][3];
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(q) / (float)hidden + eps);
+  const long bt = row / rows_per_frame;
+  int lv = levels[bt];
+  lv = lv < 0 ? 0 : (lv > max_level ? max_level : lv);
+  const float* sh = table + (long)lv * ldt + off;
+  const float* sc = sh + hidden;
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    const int cc = (i * 64 + lane) * 4;
+    if (cc < hidden) {
+      const float4v a = *reinterpret_cast<const float4v*>(sh + cc);
+      const float4v g = *reinterpret_cast<const float4v*>(sc + cc);
+      v[i] = v[i] * rstd * (1.0f + g) + a;
+    }
+  }
+  const int gw = ww / ps, g = (int)(row % rows_per_frame), gy = g / gw, gx = g % gw;
+  const int oc = ps * ps * c;
+  for (int o = 0; o < oc; ++o) {  // o = (p, q, channel), channel fastest
+    const float* wr = w + (long)o * hidden;
+    float acc = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+      const int cc = (i * 64 + lane) * 4;
+      if (cc < hidden) {
+        const float4v t = *reinterpret_cast<const float4v*>(wr + cc);
+        acc += v[i][0] * t[0] + v[i][1] * t[1] + v[i][2] * t[2] + v[i][3] * t[3];
+      }
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) {
+      const int ch = o % c, pq = o / c, py = pq / ps, px = pq % ps;
+      out[((bt * c + ch) * hh + gy * ps + py) * ww + gx * ps + px] = acc + b[o];
+    }
+  }
+}
+
+}  // namespace
+}  // namespace dfot
+
+using namespace dfot;
+
+struct dfot_dit_s {
+  dfot_dit_config cfg{};
+  int gh = 0, gw = 0, P = 0, d = 0, dstride = 0, kpatch = 0, oc = 0;
+  int lpad = 0;      // level count padded to the GEMM's row tile
+  long ldt = 0;      // mod_table row stride (floats) = total modulation outputs
+  std::vector<DitParam> params;
+  std::map<std::string, int> index;
+  std::vector<void*> owned, ws_owned;
+  size_t ws_bytes = 0;
+  // weights
+  float *t_w1 = nullptr, *t_b1 = nullptr, *t_w2 = nullptr, *t_b2 = nullptr, *pe_w = nullptr, *pe_b = nullptr,
+        *fin_w = nullptr, *fin_b = nullptr, *b_mod = nullptr;
+  bf16* w_mod = nullptr;  // every modulation Linear stacked: [ldt][hidden]
+  std::vector<DitBlockW> blocks;
+  long mod_final = 0;
+  // derived at finalize
+  float *freqs = nullptr, *feat = nullptr, *thid = nullptr, *emb = nullptr, *mod_table = nullptr, *rope_cs = nullptr;
+  bf16* semb = nullptr;
+  bool finalized = false;
+  // workspace
+  int max_batch = 0, last_rows = 0;
+  float* X = nullptr;
+  bf16 *A = nullptr, *q = nullptr, *k = nullptr, *v = nullptr, *hid = nullptr;
+  int gemm_variant = GEMM_AUTO;
+  bool time_attn = false;
+  std::vector<hipEvent_t> ev_start, ev_stop;
+  size_t ev_used = 0;
+};
+
+namespace dfot {
+namespace {
+
+template <typename T>
+int dit_alloc(dfot_dit_s* h, T** out, size_t count, bool workspace = false) {
+  void* p = nullptr;
+  const size_t bytes = count * sizeof(T);
+  DFOT_CHECK_HIP(hipMalloc(&p, bytes ? bytes : 16));
+  (workspace ? h->ws_owned : h->owned).push_back(p);
+  if (workspace) h->ws_bytes += bytes;
+  *out = reinterpret_cast<T*>(p);
+  return DFOT_OK;
+}
+
+void dit_add(dfot_dit_s* h, const std::string& name, std::vector<int64_t> shape, std::function<int(const float*, hipStream_t)> load) {
+  h->index[name] = (int)h->params.size();
+  h->params.push_back(DitParam{name, std::move(shape), std::move(load), false});
+}
+
+int dit_add_f32(dfot_dit_s* h, const std::string& name, std::vector<int64_t> shape, float** dst) {
+  size_t n = 1;
+  for (auto d : shape) n *= (size_t)d;
+  int rc = dit_alloc(h, dst, n);
+  if (rc) return rc;
+  float* d = *dst;
+  dit_add(h, name, shape, [d, n](const float* src, hipStream_t s) {
+    DFOT_CHECK_HIP(hipMemcpyAsync(d, src, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+    return DFOT_OK;
+  });
+  return DFOT_OK;
+}
+
+// Linear weight [rows][k] fp32 -> bf16 at dst (row stride k)
+int dit_add_bf16(dfot_dit_s* h, const std::string& name, int rows, int k, bf16* dst) {
+  dit_add(h, name, {rows, k}, [=](const float* src, hipStream_t s) { return launch_pack_rows(src, dst, nullptr, rows, k, k, k, 0, s); });
+  return DFOT_OK;
+}
+
+int dit_add_slice(dfot_dit_s* h, const std::string& name, int n, float* dst) {
+  dit_add(h, name, {n}, [=](const float* src, hipStream_t s) {
+    DFOT_CHECK_HIP(hipMemcpyAsync(dst, src, (size_t)n * sizeof(float), hipMemcpyDeviceToDevice, s));
+    return DFOT_OK;
+  });
+  return DFOT_OK;
+}
+
+int dit_build(dfot_dit_s* h) {
+  const dfot_dit_config& c = h->cfg;
+  const int hd = c.hidden_size;
+  h->gh = c.height / c.patch_size;
+  h->gw = c.width / c.patch_size;
+  h->P = h->gh * h->gw;
+  h->d = hd / c.num_heads;
+  h->dstride = attention_dstride(h->d);
+  h->kpatch = c.in_channels * c.patch_size * c.patch_size;
+  h->oc = h->kpatch;
+  h->lpad = (c.timesteps + 255) / 256 * 256;
+  const int per_block = c.mlp_hidden ? 6 * hd : 3 * hd;
+  h->ldt = (long)c.depth * per_block + 2 * hd;
+  int rc = 0;
+  // registration order == the reference module's state_dict order
+  const std::string ne = "noise_level_pos_embedding.embedding";
+  if ((rc = dit_add_f32(h, ne + ".linear_1.weight", {hd, c.noise_dim}, &h->t_w1))) return rc;
+  if ((rc = dit_add_f32(h, ne + ".linear_1.bias", {hd}, &h->t_b1))) return rc;
+  if ((rc = dit_add_f32(h, ne + ".linear_2.weight", {hd, hd}, &h->t_w2))) return rc;
+  if ((rc = dit_add_f32(h, ne + ".linear_2.bias", {hd}, &h->t_b2))) return rc;
+  if ((rc = dit_add_f32(h, "patch_embedder.proj.weight", {hd, c.in_channels, c.patch_size, c.patch_size}, &h->pe_w))) return rc;
+  if ((rc = dit_add_f32(h, "patch_embedder.proj.bias", {hd}, &h->pe_b))) return rc;
+  if ((rc = dit_alloc(h, &h->w_mod, (size_t)h->ldt * hd))) return rc;
+  if ((rc = dit_alloc(h, &h->b_mod, (size_t)h->ldt))) return rc;
+  h->blocks.resize(c.depth);
+  long off = 0;
+  for (int i = 0; i < c.depth; ++i) {
+    DitBlockW& w = h->blocks[i];
+    const std::string pre = "dit_base.blocks." + std::to_string(i);
+    w.mod1 = off;
+    dit_add_bf16(h, pre + ".norm1.modulation.1.weight", 3 * hd, hd, h->w_mod + off * hd);
+    dit_add_slice(h, pre + ".norm1.modulation.1.bias", 3 * hd, h->b_mod + off);
+    off += 3 * hd;
+    if ((rc = dit_alloc(h, &w.w_qkv, (size_t)3 * hd * hd))) return rc;
+    dit_add_bf16(h, pre + ".attn.qkv.weight", 3 * hd, hd, w.w_qkv);
+    if ((rc = dit_add_f32(h, pre + ".attn.qkv.bias", {3 * hd}, &w.b_qkv))) return rc;
+    if ((rc = dit_alloc(h, &w.w_proj, (size_t)hd * hd))) return rc;
+    dit_add_bf16(h, pre + ".attn.proj.weight", hd, hd, w.w_proj);
+    if ((rc = dit_add_f32(h, pre + ".attn.proj.bias", {hd}, &w.b_proj))) return rc;
+    if (c.mlp_hidden) {
+      w.mod2 = off;
+      dit_add_bf16(h, pre + ".norm2.modulation.1.weight", 3 * hd, hd, h->w_mod + off * hd);
+      dit_add_slice(h, pre + ".norm2.modulation.1.bias", 3 * hd, h->b_mod + off);
+      off += 3 * hd;
+      if ((rc = dit_alloc(h, &w.w_fc1, (size_t)c.mlp_hidden * hd))) return rc;
+      dit_add_bf16(h, pre + ".mlp.fc1.weight", c.mlp_hidden, hd, w.w_fc1);
+      if ((rc = dit_add_f32(h, pre + ".mlp.fc1.bias", {c.mlp_hidden}, &w.b_fc1))) return rc;
+      if ((rc = dit_alloc(h, &w.w_fc2, (size_t)hd * c.mlp_hidden))) return rc;
+      dit_add_bf16(h, pre + ".mlp.fc2.weight", hd, c.mlp_hidden, w.w_fc2);
+      if ((rc = dit_add_f32(h, pre + ".mlp.fc2.bias", {hd}, &w.b_fc2))) return rc;
+    }
+  }
+  h->mod_final = off;
+  dit_add_bf16(h, "dit_base.final_layer.norm_final.modulation.1.weight", 2 * hd, hd, h->w_mod + off * hd);
+  dit_add_slice(h, "dit_base.final_layer.norm_final.modulation.1.bias", 2 * hd, h->b_mod + off);
+  if ((rc = dit_add_f32(h, "dit_base.final_layer.linear.weight", {h->oc, hd}, &h->fin_w))) return rc;
+  if ((rc = dit_add_f32(h, "dit_base.final_layer.linear.bias", {h->oc}, &h->fin_b))) return rc;
+
+  // derived tables
+  if ((rc = dit_alloc(h, &h->freqs, (size_t)c.noise_dim / 2))) return rc;
+  if ((rc = dit_alloc(h, &h->feat, (size_t)h->lpad * c.noise_dim))) return rc;
+  if ((rc = dit_alloc(h, &h->thid, (size_t)h->lpad * hd))) return rc;
+  if ((rc = dit_alloc(h, &h->emb, (size_t)h->lpad * hd))) return rc;
+  if ((rc = dit_alloc(h, &h->semb, (size_t)h->lpad * hd))) return rc;
+  if ((rc = dit_alloc(h, &h->mod_table, (size_t)h->lpad * h->ldt))) return rc;
+  {
+    const int half = c.noise_dim / 2;
+    std::vector<float> f(half);
+    for (int i = 0; i < half; ++i) f[i] = (float)std::exp(-std::log(10000.0) * (double)i / (double)half);
+    DFOT_CHECK_HIP(hipMemcpy(h->freqs, f.data(), f.size() * sizeof(float), hipMemcpyHostToDevice));
+  }
+  {  // RoPE-3D (cos, sin) table [Tmax*P][d/2][2]; axis split of the head dim as RotaryEmbedding3D (embeddings.py:251-277)
+    const int half = h->d / 2, q = half / 3, rem = half % 3;
+    int parts[3] = {q, q, q};
+    if (rem == 1) parts[0] = q + 1;
+    if (rem == 2) parts[1] = parts[2] = q + 1;
+    const int n = c.max_tokens * h->P;
+    std::vector<float> cs((size_t)n * half * 2);
+    for (int tok = 0; tok < n; ++tok) {
+      const int pos[3] = {tok / h->P, (tok / h->gw) % h->gh, tok % h->gw};
+      int pair = 0;
+      for (int ax = 0; ax < 3; ++ax) {
+        const int dim = 2 * parts[ax];
+        for (int j = 0; j < parts[ax]; ++j, ++pair) {
+          const float inv = 1.0f / powf(c.rope_theta, (float)(2 * j) / (float)dim);
+          const float ang = (float)pos[ax] * inv;
+          cs[((size_t)tok * half + pair) * 2 + 0] = cosf(ang);
+          cs[((size_t)tok * half + pair) * 2 + 1] = sinf(ang);
+        }
+      }
+    }
+    if ((rc = dit_alloc(h, &h->rope_cs, cs.size()))) return rc;
+    DFOT_CHECK_HIP(hipMemcpy(h->rope_cs, cs.data(), cs.size() * sizeof(float), hipMemcpyHostToDevice));
+  }
+  return DFOT_OK;
+}
+
+}  // namespace
+}  // namespace dfot
+
+extern "C" {
+
+int dfot_dit_destroy(dfot_dit_t h) {
+  if (!h) return DFOT_OK;
+  for (void* p : h->owned) (void)hipFree(p);
+  for (void* p : h->ws_owned) (void)hipFree(p);
+  for (hipEvent_t e : h->ev_start) (void)hipEventDestroy(e);
+  for (hipEvent_t e : h->ev_stop) (void)hipEventDestroy(e);
+  delete h;
+  return DFOT_OK;
+}
+
+int dfot_dit_create(const dfot_dit_config* cfg, dfot_dit_t* out) {
+  DFOT_REQUIRE(cfg && out, DFOT_ERR_ARG, "dfot_dit_create: null argument");
+  const dfot_dit_config& c = *cfg;
+  DFOT_REQUIRE(c.hidden_size > 0 && c.hidden_size % 64 == 0 && c.hidden_size <= 64 * 4 * LN_MAXV, DFOT_ERR_SHAPE,
+               "hidden_size %d must be a multiple of 64, <= %d", c.hidden_size, 64 * 4 * LN_MAXV);
+  DFOT_REQUIRE(c.num_heads > 0 && c.hidden_size % c.num_heads == 0, DFOT_ERR_SHAPE, "hidden_size %d not divisible by %d heads",
+               c.hidden_size, c.num_heads);
+  const int d = c.hidden_size / c.num_heads;
+  DFOT_REQUIRE(d % 8 == 0 && d <= 128, DFOT_ERR_SHAPE, "head dim %d must be a multiple of 8, <= 128", d);
+  DFOT_REQUIRE(c.patch_size > 0 && c.height % c.patch_size == 0 && c.width % c.patch_size == 0, DFOT_ERR_SHAPE,
+               "x_shape %dx%d not divisible by patch %d", c.height, c.width, c.patch_size);
+  DFOT_REQUIRE(c.in_channels > 0 && c.in_channels * c.patch_size * c.patch_size <= 256, DFOT_ERR_SHAPE, "patch vector too long");
+  DFOT_REQUIRE(c.mlp_hidden >= 0 && c.mlp_hidden % 64 == 0, DFOT_ERR_SHAPE, "mlp_hidden %d must be a multiple of 64", c.mlp_hidden);
+  DFOT_REQUIRE(c.noise_dim > 0 && c.noise_dim % 2 == 0 && c.timesteps > 0 && c.max_tokens > 0 && c.depth > 0, DFOT_ERR_SHAPE,
+               "bad noise_dim / timesteps / max_tokens / depth");
+  auto* h = new dfot_dit_s();
+  h->cfg = c;
+  int rc = dit_build(h);
+  if (rc) {
+    dfot_dit_destroy(h);
+    return rc;
+  }
+  *out = h;
+  return DFOT_OK;
+}
+
+int dfot_dit_num_params(dfot_dit_t h) { return h ? (int)h->params.size() : 0; }
+const char* dfot_dit_param_name(dfot_dit_t h, int i) {
+  return (h && i >= 0 && i < (int)h->params.size()) ? h->params[i].name.c_str() : nullptr;
+}
+int dfot_dit_param_shape(dfot_dit_t h, int i, int64_t shape[4], int* ndim) {
+  DFOT_REQUIRE(h && shape && ndim && i >= 0 && i < (int)h->params.size(), DFOT_ERR_ARG, "param_shape: bad argument");
+  *ndim = (int)h->params[i].shape.size();
+  for (int k = 0; k < *ndim; ++k) shape[k] = h->params[i].shape[k];
+  return DFOT_OK;
+}
+
+int dfot_dit_load_weight(dfot_dit_t h, const char* name, const float* data, const int64_t* shape, int ndim, void* stream) {
+  DFOT_REQUIRE(h && name && data && shape, DFOT_ERR_ARG, "load_weight: null argument");
+  auto it = h->index.find(name);
+  DFOT_REQUIRE(it != h->index.end(), DFOT_ERR_NAME, "load_weight: unexpected key '%s'", name);
+  DitParam& p = h->params[it->second];
+  bool same = (int)p.shape.size() == ndim;
+  for (int k = 0; same && k < ndim; ++k) same = p.shape[k] == shape[k];
+  DFOT_REQUIRE(same, DFOT_ERR_SHAPE, "load_weight: size mismatch for '%s'", name);
+  int rc = p.load(data, (hipStream_t)stream);
+  if (rc) return rc;
+  p.loaded = true;
+  h->finalized = false;
+  return DFOT_OK;
+}
+
+int dfot_dit_finalize(dfot_dit_t h, void* stream) {
+  DFOT_REQUIRE(h, DFOT_ERR_ARG, "finalize: null handle");
+  for (const DitParam& p : h->params) DFOT_REQUIRE(p.loaded, DFOT_ERR_STATE, "finalize: missing key '%s'", p.name.c_str());
+  hipStream_t s = (hipStream_t)stream;
+  const dfot_dit_config& c = h->cfg;
+  const int hd = c.hidden_size, L = c.timesteps;
+  // embedding of every level: features -> Linear -> SiLU -> Linear (emb) ; semb = bf16(SiLU(emb)) feeds every modulation
+  DFOT_CHECK_HIP(hipMemsetAsync(h->semb, 0, (size_t)h->lpad * hd * sizeof(bf16), s));
+  hipLaunchKernelGGL(tstep_features_kernel, dim3(cdiv((long)L * c.noise_dim, 256)), dim3(256), 0, s, h->freqs, h->feat, L, c.noise_dim);
+  DFOT_CHECK_HIP(hipGetLastError());
+  hipLaunchKernelGGL(rows_linear_kernel<1>, dim3(cdiv(hd, 4), L), dim3(256), 0, s, h->feat, h->t_w1, h->t_b1, h->thid,
+                     (bf16*)nullptr, c.noise_dim, hd);
+  DFOT_CHECK_HIP(hipGetLastError());
+  hipLaunchKernelGGL(rows_linear_kernel<0>, dim3(cdiv(hd, 4), L), dim3(256), 0, s, h->thid, h->t_w2, h->t_b2, h->emb, h->semb, hd, hd);
+  DFOT_CHECK_HIP(hipGetLastError());
+  // mod_table[level][:] = W_mod * SiLU(emb[level]) + b_mod for every modulation of the model
+  GemmArgs g;
+  g.A = h->semb; g.lda = hd; g.W = h->w_mod; g.M = h->lpad; g.N = (int)h->ldt; g.K = hd;
+  g.bias = h->b_mod; g.out_f32 = h->mod_table; g.ldo = h->ldt;
+  int rc = launch_gemm(A_DENSE, E_F32, GEMM_AUTO, g, s);
+  if (rc) return rc;
+  DFOT_CHECK_HIP(hipStreamSynchronize(s));
+  h->finalized = true;
+  return DFOT_OK;
+}
+
+int dfot_dit_reserve(dfot_dit_t h, int max_batch) {
+  DFOT_REQUIRE(h && max_batch > 0, DFOT_ERR_ARG, "reserve: bad argument");
+  if (max_batch <= h->max_batch) return DFOT_OK;
+  for (void* p : h->ws_owned) (void)hipFree(p);
+  h->ws_owned.clear();
+  h->ws_bytes = 0;
+  h->max_batch = 0;
+  const dfot_dit_config& c = h->cfg;
+  const size_t rows = (size_t)max_batch * c.max_tokens * h->P;
+  const size_t qkv = (size_t)max_batch * c.num_heads * c.max_tokens * h->P * h->dstride;
+  int rc = 0;
+  if ((rc = dit_alloc(h, &h->X, rows * c.hidden_size, true))) return rc;
+  if ((rc = dit_alloc(h, &h->A, rows * c.hidden_size, true))) return rc;
+  if ((rc = dit_alloc(h, &h->q, qkv, true)) || (rc = dit_alloc(h, &h->k, qkv, true)) || (rc = dit_alloc(h, &h->v, qkv, true))) return rc;
+  // pad columns d..dstride of q/k/v are never written by the QKV epilogue: zero them once
+  DFOT_CHECK_HIP(hipMemset(h->q, 0, qkv * sizeof(bf16)));
+  DFOT_CHECK_HIP(hipMemset(h->k, 0, qkv * sizeof(bf16)));
+  DFOT_CHECK_HIP(hipMemset(h->v, 0, qkv * sizeof(bf16)));
+  if (c.mlp_hidden && (rc = dit_alloc(h, &h->hid, rows * c.mlp_hidden, true))) return rc;
+  h->max_batch = max_batch;
+  return DFOT_OK;
+}
+
+size_t dfot_dit_workspace_bytes(dfot_dit_t h) { return h ? h->ws_bytes : 0; }
+
+int dfot_dit_set_option(dfot_dit_t h, const char* key, int value) {
+  DFOT_REQUIRE(h && key, DFOT_ERR_ARG, "set_option: null argument");
+  if (!strcmp(key, "gemm_variant")) {
+    h->gemm_variant = value;
+    return DFOT_OK;
+  }
+  if (!strcmp(key, "time_attn")) {
+    h->time_attn = value > 0;
+    h->ev_used = 0;
+    while ((int)h->ev_start.size() < value) {
+      hipEvent_t a, b;
+      DFOT_CHECK_HIP(hipEventCreate(&a));
+      DFOT_CHECK_HIP(hipEventCreate(&b));
+      h->ev_start.push_back(a);
+      h->ev_stop.push_back(b);
+    }
+    return DFOT_OK;
+  }
+  set_error("set_option: unknown key '%s'", key);
+  return DFOT_ERR_NAME;
+}
+
+int dfot_dit_attn_timing(dfot_dit_t h, double* total_ms, int64_t* launches) {
+  DFOT_REQUIRE(h && total_ms && launches, DFOT_ERR_ARG, "attn_timing: null argument");
+  double tot = 0;
+  for (size_t i = 0; i < h->ev_used; ++i) {
+    DFOT_CHECK_HIP(hipEventSynchronize(h->ev_stop[i]));
+    float ms = 0.f;
+    DFOT_CHECK_HIP(hipEventElapsedTime(&ms, h->ev_start[i], h->ev_stop[i]));
+    tot += ms;
+  }
+  *total_ms = tot;
+  *launches = (int64_t)h->ev_used;
+  h->ev_used = 0;
+  return DFOT_OK;
+}
+
+int dfot_dit_forward(dfot_dit_t h, const float* x, const int32_t* noise_levels, float* out, int batch, int tokens, void* stream) {
+  DFOT_REQUIRE(h && x && noise_levels && out, DFOT_ERR_ARG, "forward: null argument");
+  DFOT_REQUIRE(h->finalized, DFOT_ERR_STATE, "forward: weights not finalized");
+  DFOT_REQUIRE(batch > 0 && batch <= h->max_batch, DFOT_ERR_STATE, "forward: batch %d exceeds the reserved %d", batch, h->max_batch);
+  const dfot_dit_config& c = h->cfg;
+  DFOT_REQUIRE(tokens > 0 && tokens <= c.max_tokens, DFOT_ERR_SHAPE, "forward: %d tokens, max_tokens is %d", tokens, c.max_tokens);
+  const int n = tokens * h->P, hd = c.hidden_size;
+  DFOT_REQUIRE(n % 128 == 0, DFOT_ERR_SHAPE, "forward: sequence length %d (tokens x patches) must be a multiple of 128", n);
+  hipStream_t s = (hipStream_t)stream;
+  const long rows = (long)batch * n;
+  const int max_level = c.timesteps - 1;
+  int rc = 0;
+  hipLaunchKernelGGL(patch_embed_kernel, dim3(cdiv(rows, PE_TOK)), dim3(256), PE_TOK * h->kpatch * sizeof(float), s, x, h->pe_w,
+                     h->pe_b, h->X, c.in_channels, c.height, c.width, c.patch_size, hd, rows);
+  DFOT_CHECK_HIP(hipGetLastError());
+  const float qscale = 1.4426950408889634f / sqrtf((float)h->d);  // attention works in the exp2 domain
+  auto ln_mod = [&](long off) -> int {
+    hipLaunchKernelGGL(ln_mod_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, s, h->X, h->A, h->mod_table, noise_levels, h->ldt, off, hd,
+                       h->P, rows, c.eps, max_level);
+    DFOT_CHECK_HIP(hipGetLastError());
+    return DFOT_OK;
+  };
+  auto gated = [&](const bf16* a, int kdim, const bf16* w, const float* bias, long gate_off) -> int {
+    GemmArgs g;  // X <- X + gate * (a W^T + bias), in place
+    g.A = a; g.lda = kdim; g.W = w; g.M = (int)rows; g.N = hd; g.K = kdim; g.bias = bias;
+    g.out_f32 = h->X; g.ldo = hd; g.resid = h->X;
+    g.gate = h->mod_table + gate_off; g.gate_index = noise_levels; g.ldg = h->ldt; g.gate_rows = h->P;
+    return launch_gemm(A_DENSE, E_F32, h->gemm_variant, g, s);
+  };
+  for (const DitBlockW& w : h->blocks) {
+    if ((rc = ln_mod(w.mod1))) return rc;
+    {
+      GemmArgs g;
+      g.A = h->A; g.lda = hd; g.W = w.w_qkv; g.M = (int)rows; g.N = 3 * hd; g.K = hd; g.bias = w.b_qkv;
+      g.q = h->q; g.k = h->k; g.v = h->v; g.rope_cs = h->rope_cs; g.heads = c.num_heads; g.d = h->d; g.dstride = h->dstride;
+      g.ntok = n; g.qscale = qscale;
+      if ((rc = launch_gemm(A_DENSE, E_QKV_DIT, h->gemm_variant, g, s))) return rc;
+    }
+    const bool timed = h->time_attn && h->ev_used < h->ev_start.size();
+    if (timed) DFOT_CHECK_HIP(hipEventRecord(h->ev_start[h->ev_used], s));
+    if ((rc = launch_attention_padded(h->q, h->k, h->v, h->A, hd, batch, c.num_heads, n, h->d, s))) return rc;
+    if (timed) DFOT_CHECK_HIP(hipEventRecord(h->ev_stop[h->ev_used++], s));
+    if ((rc = gated(h->A, hd, w.w_proj, w.b_proj, w.mod1 + 2 * hd))) return rc;
+    if (c.mlp_hidden) {
+      if ((rc = ln_mod(w.mod2))) return rc;
+      GemmArgs g;
+      g.A = h->A; g.lda = hd; g.W = w.w_fc1; g.M = (int)rows; g.N = c.mlp_hidden; g.K = hd; g.bias = w.b_fc1;
+      g.out_bf16 = h->hid; g.ldo = c.mlp_hidden; g.act = 1;
+      if ((rc = launch_gemm(A_DENSE, E_BF16, h->gemm_variant, g, s))) return rc;
+      if ((rc = gated(h->hid, c.mlp_hidden, w.w_fc2, w.b_fc2, w.mod2 + 2 * hd))) return rc;
+    }
+  }
+  h->last_rows = (int)rows;
+  hipLaunchKernelGGL(final_layer_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, s, h->X, h->mod_table, noise_levels, h->ldt, h->mod_final,
+                     h->fin_w, h->fin_b, out, hd, h->P, rows, c.eps, max_level, c.in_channels, c.height, c.width, c.patch_size);
+  DFOT_CHECK_HIP(hipGetLastError());
+  return DFOT_OK;
+}
+
+int dfot_dit_read_tap(dfot_dit_t h, const char* name, float* out, size_t capacity, void* stream) {
+  DFOT_REQUIRE(h && name && out, DFOT_ERR_ARG, "read_tap: null argument");
+  hipStream_t s = (hipStream_t)stream;
+  const float* src = nullptr;
+  size_t need = 0;
+  if (!strcmp(name, "emb")) {
+    DFOT_REQUIRE(h->finalized, DFOT_ERR_STATE, "read_tap: weights not finalized");
+    src = h->emb;
+    need = (size_t)h->cfg.timesteps * h->cfg.hidden_size;
+  } else if (!strcmp(name, "stream")) {
+    DFOT_REQUIRE(h->last_rows > 0, DFOT_ERR_STATE, "read_tap: no forward has run");
+    src = h->X;
+    need = (size_t)h->last_rows * h->cfg.hidden_size;
+  } else {
+    set_error("read_tap: unknown tap '%s'", name);
+    return DFOT_ERR_NAME;
+  }
+  DFOT_REQUIRE(capacity >= need, DFOT_ERR_SHAPE, "read_tap: need %zu floats, got %zu", need, capacity);
+  DFOT_CHECK_HIP(hipMemcpyAsync(out, src, need * sizeof(float), hipMemcpyDeviceToDevice, s));
+  return DFOT_OK;
+}
+
+int dfot_op_attention_padded(const void* q, const void* k, const void* v, void* o, int ldo, int batch, int heads, int n, int d,
+                             void* stream) {
+  return launch_attention_padded((const bf16*)q, (const bf16*)k, (const bf16*)v, (bf16*)o, ldo, batch, heads, n, d, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -5,7 +5,7 @@
 namespace dfot {
 
 enum AMode { A_DENSE = 0, A_CONV3 = 1 };
-enum Epi { E_F32 = 0, E_BF16 = 1, E_QKV = 2 };
+enum Epi { E_F32 = 0, E_BF16 = 1, E_QKV = 2, E_QKV_DIT = 3 };
 
 struct GemmArgs {
   // operands: A [M][K] bf16 (dense: row stride lda; conv: NHWC image [BT][H][Wd][Cin], K = 9*Cin tap-major)
@@ -21,6 +21,13 @@ struct GemmArgs {
   bf16* out_bf16 = nullptr;
   long ldo = 0;
   const float* resid = nullptr;  // E_F32: optional fp32 residual, same ld as out
+  // E_F32: optional per-(frame, column) gate (DiT AdaLN-Zero): out = resid + gate[row / gate_rows][col] * (acc + bias)
+  //   (gate_index: optional indirection, gate row = gate_index[row / gate_rows] -- the per-level modulation table)
+  const float* gate = nullptr;
+  const int* gate_index = nullptr;
+  long ldg = 0;
+  int gate_rows = 0;
+  int act = 0;  // E_BF16: 0 = none, 1 = GELU(tanh approximation) applied before the bf16 store
   // optional fused GroupNorm(32) partial statistics of the OUTPUT (E_F32 / E_BF16, N == channel count):
   // gn_part[((bt*slots + slot)*32 + group)*2 + {sum,sumsq}], slot = 64-row block index within the image
   float* gn_part = nullptr;
@@ -36,6 +43,10 @@ struct GemmArgs {
   const float *qw = nullptr, *kw = nullptr, *rope_cs = nullptr;
   int heads = 0, d = 0, ntok = 0;
   float qscale = 1.f;
+  // E_QKV_DIT (DiT Attention.qkv): columns [0,C) q | [C,2C) k | [2C,3C) v, C = heads*d, d % 8 == 0 (no QK norm);
+  //   q,k: RoPE (+ q *= qscale); all three written as [B][heads][ntok][dstride] bf16, dstride >= d (pad columns are
+  //   never written: the caller zeroes them once)
+  int dstride = 0;
   float eps = 1e-6f;
   int xcd = 1;  // XCD-aware tile order
 };

@@ -261,6 +261,7 @@ __global__ __launch_bounds__((BM_T / WTM) * (BN_T / 64) * 64 * KS) void gemm_ker
   const int colq = lane & 15, rowq = (lane >> 4) * 4;
   const int nw = n0 + wn * 64;
   [[maybe_unused]] const bool has_res = g.resid != nullptr;
+  [[maybe_unused]] const bool has_gate = g.gate != nullptr;
   // fused GroupNorm partial sums of this wave's 64 rows: (gsum,gsq) = lane's first 4 columns, (gsum2,gsq2) = next 4
   [[maybe_unused]] float gsum = 0.f, gsq = 0.f, gsum2 = 0.f, gsq2 = 0.f;
   // lane geometry of the read-back: fp32 output = 4 columns x rows p*4 + lane/16; bf16 outputs = 8 columns x rows p*8 + lane/8
@@ -286,6 +287,11 @@ __global__ __launch_bounds__((BM_T / WTM) * (BN_T / 64) * 64 * KS) void gemm_ker
           const int r = p * 4 + (lane >> 4);
           f32x4 v = *reinterpret_cast<const f32x4*>(ep + r * EP_LD + cw) + b0;
           const long off = (mw + r) * g.ldo + col;
+          if (has_gate) {
+            long gr = (mw + r) / g.gate_rows;
+            if (g.gate_index) gr = g.gate_index[gr];
+            v *= *reinterpret_cast<const f32x4*>(g.gate + gr * g.ldg + col);
+          }
           if (has_res) v += *reinterpret_cast<const f32x4*>(g.resid + off);
           *reinterpret_cast<f32x4*>(g.out_f32 + off) = v;
           gsum += v[0] + v[1] + v[2] + v[3];
@@ -306,6 +312,16 @@ __global__ __launch_bounds__((BM_T / WTM) * (BN_T / 64) * 64 * KS) void gemm_ker
         }
       }
       if constexpr (EPI == E_BF16) {
+        if (g.act == 1) {  // GELU, tanh approximation (timm Mlp act of the DiT blocks)
+#pragma unroll
+          for (int p = 0; p < 2; ++p)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              const float x = vals[p][j];
+              const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
+              vals[p][j] = x * (1.0f - 1.0f / (1.0f + __expf(2.0f * u)));  // 0.5 x (1 + tanh u)
+            }
+        }
         if (live) {
 #pragma unroll
           for (int p = 0; p < 2; ++p) {
@@ -322,6 +338,36 @@ __global__ __launch_bounds__((BM_T / WTM) * (BN_T / 64) * 64 * KS) void gemm_ker
               gsum2 += c;
               gsq2 += c * c;
             }
+          }
+        }
+      } else if constexpr (EPI == E_QKV_DIT) {
+        if (live) {
+          const int cdim = g.heads * g.d;
+          const int which = col / cdim;
+          const int cc = col - which * cdim;
+          const int head = cc / g.d, e0 = cc % g.d;  // d % 8 == 0: the lane's 8 columns stay inside one head
+          bf16* dst = which == 0 ? g.q : (which == 1 ? g.k : g.v);
+          const float mul = which == 0 ? g.qscale : 1.f;
+#pragma unroll
+          for (int p = 0; p < 2; ++p) {
+            const long row = mw + p * 8 + (lane >> 3);
+            const long bidx = row / g.ntok;
+            const int tok = (int)(row % g.ntok);
+            bf16x8 o;
+            if (which == 2) {
+#pragma unroll
+              for (int j = 0; j < 8; ++j) o[j] = f2bf(vals[p][j]);
+            } else {
+              const float* cs = g.rope_cs + ((long)tok * (g.d / 2) + e0 / 2) * 2;
+#pragma unroll
+              for (int pr = 0; pr < 4; ++pr) {
+                const float x0 = vals[p][2 * pr], x1 = vals[p][2 * pr + 1];
+                const float co = cs[2 * pr], si = cs[2 * pr + 1];
+                o[2 * pr] = f2bf((x0 * co - x1 * si) * mul);
+                o[2 * pr + 1] = f2bf((x1 * co + x0 * si) * mul);
+              }
+            }
+            *reinterpret_cast<bf16x8*>(dst + ((bidx * g.heads + head) * g.ntok + tok) * (long)g.dstride + e0) = o;
           }
         }
       } else {  // E_QKV
@@ -511,7 +557,7 @@ int launch_gemm(int amode, int epi, int variant, const GemmArgs& g, hipStream_t 
   DFOT_REQUIRE(g.M > 0 && g.M % bm == 0, DFOT_ERR_SHAPE, "gemm: M=%d must be a positive multiple of %d", g.M, bm);
   DFOT_REQUIRE(g.K > 0 && g.K % BK == 0, DFOT_ERR_SHAPE, "gemm: K=%d must be a positive multiple of %d", g.K, BK);
   DFOT_REQUIRE(g.N > 0 && g.N % (epi == E_F32 ? 4 : 8) == 0, DFOT_ERR_SHAPE, "gemm: N=%d must be a multiple of %d", g.N, epi == E_F32 ? 4 : 8);
-  DFOT_REQUIRE((epi == E_QKV || g.ldo % (epi == E_F32 ? 4 : 8) == 0) && (epi != E_QKV || (g.ldo2 % 8 == 0 && g.split % 64 == 0)),
+  DFOT_REQUIRE((epi == E_QKV || epi == E_QKV_DIT || g.ldo % (epi == E_F32 ? 4 : 8) == 0) && (epi != E_QKV || (g.ldo2 % 8 == 0 && g.split % 64 == 0)),
                DFOT_ERR_SHAPE, "gemm: output row strides must be multiples of %d", epi == E_F32 ? 4 : 8);
   if (amode == A_CONV3) {
     DFOT_REQUIRE(g.Cin % BK == 0 && g.K == 9 * g.Cin, DFOT_ERR_SHAPE, "conv3x3: Cin=%d must be a multiple of %d", g.Cin, BK);
@@ -523,8 +569,18 @@ int launch_gemm(int amode, int epi, int variant, const GemmArgs& g, hipStream_t 
     DFOT_REQUIRE((g.d == 64 || g.d == 128) && g.heads > 0 && g.split == 3 * g.heads * g.d && g.ntok > 0 && g.M % g.ntok == 0,
                  DFOT_ERR_SHAPE, "qkv epilogue: heads=%d d=%d split=%d ntok=%d M=%d", g.heads, g.d, g.split, g.ntok, g.M);
   }
+  if (epi == E_QKV_DIT) {
+    DFOT_REQUIRE(g.q && g.k && g.v && g.rope_cs, DFOT_ERR_ARG, "dit qkv epilogue: null pointer");
+    DFOT_REQUIRE(g.d > 0 && g.d % 8 == 0 && g.dstride >= g.d && g.dstride % 8 == 0 && g.heads > 0 && g.N == 3 * g.heads * g.d &&
+                     g.ntok > 0 && g.M % g.ntok == 0,
+                 DFOT_ERR_SHAPE, "dit qkv epilogue: heads=%d d=%d dstride=%d ntok=%d M=%d N=%d", g.heads, g.d, g.dstride, g.ntok, g.M, g.N);
+  }
+  if (g.gate) {
+    DFOT_REQUIRE(epi == E_F32 && g.gate_rows > 0 && g.M % g.gate_rows == 0 && g.ldg % 4 == 0, DFOT_ERR_SHAPE,
+                 "gemm: gate needs the fp32 epilogue, gate_rows dividing M and ldg %% 4 == 0");
+  }
   if (g.gn_part) {
-    DFOT_REQUIRE(epi != E_QKV && (g.gn_cpg == 4 || g.gn_cpg == 8) && g.N == 32 * g.gn_cpg && g.gn_rows_per_bt % 64 == 0 &&
+    DFOT_REQUIRE(epi != E_QKV && epi != E_QKV_DIT && (g.gn_cpg == 4 || g.gn_cpg == 8) && g.N == 32 * g.gn_cpg && g.gn_rows_per_bt % 64 == 0 &&
                      g.gn_rows_per_bt % bm == 0,
                  DFOT_ERR_SHAPE, "gemm: fused GroupNorm statistics need N = 32 groups of 4 or 8 channels and whole images per tile");
   }
@@ -533,6 +589,7 @@ int launch_gemm(int amode, int epi, int variant, const GemmArgs& g, hipStream_t 
       case E_F32: return launch_v<A_DENSE, E_F32>(variant, g, stream);
       case E_BF16: return launch_v<A_DENSE, E_BF16>(variant, g, stream);
       case E_QKV: return launch_v<A_DENSE, E_QKV>(variant, g, stream);
+      case E_QKV_DIT: return launch_v<A_DENSE, E_QKV_DIT>(variant, g, stream);
     }
   } else if (amode == A_CONV3) {
     switch (epi) {

@@ -67,5 +67,8 @@ int launch_bf16_nhwc_to_nchw(const bf16* src, float* dst, int bt, int p, int c, 
 
 int launch_attention(const bf16* q, const bf16* k, const bf16* v, bf16* o, long ldo, int batch, int heads, int n, int d,
                      int variant, hipStream_t stream);
+int attention_dstride(int d);
+int launch_attention_padded(const bf16* q, const bf16* k, const bf16* v, bf16* o, long ldo, int batch, int heads, int n, int d,
+                            hipStream_t stream);
 
 }  // namespace dfot

@@ -33,6 +33,9 @@ class DiffusionConfig:
     clip_noise: float = 20.0
     precond_scale: float = 0.125
     objective: str = "pred_v"
+    # False: DiscreteDiffusion (the backbone receives the integer level index, discrete_diffusion.py:173-174);
+    # True: ContinuousDiffusion (precond_scale * logsnr[k])
+    is_continuous: bool = True
 
 
 class Schedule:
@@ -62,7 +65,8 @@ class Schedule:
         self.alphas_cumprod = abar.astype(np.float32)
         self.sqrt_alphas_cumprod = np.sqrt(abar).astype(np.float32)
         self.sqrt_one_minus_alphas_cumprod = np.sqrt(1.0 - abar).astype(np.float32)
-        self.logsnr = np.log(abar / (1.0 - abar)).astype(np.float32)
+        with np.errstate(divide="ignore"):  # the plain cosine schedule ends at abar = 0 (zero terminal SNR)
+            self.logsnr = np.log(abar / (1.0 - abar)).astype(np.float32)
 
     # ---- index tables ---------------------------------------------------------------------
     def ddim_idx_to_noise_level(self, indices: np.ndarray) -> np.ndarray:
@@ -89,7 +93,10 @@ class Schedule:
 
     # ---- per-step coefficient tables (all float32, shape = levels.shape) -------------------
     def model_level(self, k: np.ndarray) -> np.ndarray:
-        """what the backbone receives as `noise_levels`: precond_scale * logsnr[clamp(k,0)]"""
+        """what the backbone receives as `noise_levels`: precond_scale * logsnr[clamp(k,0)] (continuous) or the
+        clamped level index itself (discrete; exact in float32)"""
+        if not self.cfg.is_continuous:
+            return np.clip(k, 0, None).astype(np.float32)
         return (np.float32(self.cfg.precond_scale) * self.logsnr[np.clip(k, 0, None)]).astype(np.float32)
 
     def q_sample_coef(self, k: np.ndarray):

@@ -1,0 +1,188 @@
+"""Drop-in DiT3D backbone (the reference's Kinetics-600 model) backed by libdfot_hip.so.
+
+Mirrors the reference's plugin contract for this path:
+  * constructor keywords of DiscreteDiffusion._build_model (algorithms/dfot/diffusion/discrete_diffusion.py:64-92)
+    and DiT3D.__init__ (algorithms/dfot/backbones/dit/dit3d.py:13-83): variant "full", pos_emb_type "rope_3d",
+    no external condition, causal masking rejected exactly as the reference does;
+  * ``forward(x, noise_levels, external_cond=None, external_cond_mask=None)`` (dit3d.py:146-192) with integer
+    ``noise_levels`` -- the level index DiscreteDiffusion.model_predictions passes (discrete_diffusion.py:173-174);
+  * state-dict key names / shapes / order of the reference module, so its checkpoints load with ``load_state_dict``.
+Parameters live here as fp32 ``nn.Parameter``s; the C library keeps packed bf16 copies and a per-level modulation table
+that are rebuilt whenever a parameter changes.  Inference only.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Dict, Optional, Sequence, Tuple
+
+import torch
+from torch import nn
+
+from . import capi
+from .backbone import _Node, _get
+
+
+class DiT3D(nn.Module):
+    def __init__(self, cfg, x_shape: Sequence[int], max_tokens: int, external_cond_type: str = "action",
+                 external_cond_num_classes: Optional[int] = None, external_cond_dim: int = 0,
+                 use_causal_mask: bool = False, timesteps: int = 1000, **kwargs):
+        if use_causal_mask:
+            raise NotImplementedError("Causal masking is not yet implemented for DiT3D backbone")
+        super().__init__()
+        if _get(cfg, "variant", "full") != "full":
+            raise ValueError(f"unsupported DiT variant {_get(cfg, 'variant')!r}: only 'full' is built")
+        if _get(cfg, "pos_emb_type", "rope_3d") != "rope_3d":
+            raise ValueError("only pos_emb_type='rope_3d' is supported")
+        if external_cond_dim:
+            raise ValueError("external conditions are not supported by the DiT3D engine (kinetics_600 has none)")
+        self.cfg = cfg
+        self.x_shape = tuple(int(v) for v in x_shape)
+        self.max_tokens = int(max_tokens)
+        self.external_cond_dim = 0
+        self.use_causal_mask = False
+        self.patch_size = int(_get(cfg, "patch_size", 2))
+        self.hidden_size = int(_get(cfg, "hidden_size"))
+        ratio = _get(cfg, "spatial_mlp_ratio", None)
+        c = capi.DiTConfig()
+        c.hidden_size = self.hidden_size
+        c.depth = int(_get(cfg, "depth"))
+        c.num_heads = int(_get(cfg, "num_heads"))
+        c.patch_size = self.patch_size
+        c.in_channels, c.height, c.width = self.x_shape
+        c.max_tokens = self.max_tokens
+        c.mlp_hidden = int(self.hidden_size * ratio) if ratio else 0
+        c.noise_dim = 256
+        c.timesteps = int(timesteps)
+        c.rope_theta = 10000.0
+        c.eps = 1e-6
+        self._ccfg = c
+        self.num_patches = (c.height // c.patch_size) * (c.width // c.patch_size)
+        self._handle = C.c_void_p()
+        capi.check(capi.lib.dfot_dit_create(C.byref(c), C.byref(self._handle)))
+        self._names = []
+        shape = (C.c_int64 * 4)()
+        ndim = C.c_int()
+        for i in range(capi.lib.dfot_dit_num_params(self._handle)):
+            name = capi.lib.dfot_dit_param_name(self._handle, i).decode()
+            capi.check(capi.lib.dfot_dit_param_shape(self._handle, i, shape, C.byref(ndim)))
+            self._register(name, tuple(shape[k] for k in range(ndim.value)))
+            self._names.append(name)
+        self._synced: Optional[Tuple] = None
+        self._reserved = 0
+
+    @property
+    def in_channels(self) -> int:
+        return self.x_shape[0]
+
+    @property
+    def noise_level_dim(self) -> int:
+        return 256
+
+    def _register(self, name: str, shape: Tuple[int, ...]) -> None:
+        *path, leaf = name.split(".")
+        node: nn.Module = self
+        for part in path:
+            if part not in node._modules:
+                node.add_module(part, _Node())
+            node = node._modules[part]
+        node.register_parameter(leaf, nn.Parameter(torch.zeros(shape, dtype=torch.float32)))
+
+    def _tensors(self) -> Dict[str, torch.Tensor]:
+        return dict(self.named_parameters())
+
+    def reset_parameters(self, seed: int = 0) -> None:
+        """The reference's init (dit3d.py:92-109, dit_blocks.py:392-395,422-425,476-486,528-531): xavier-uniform Linear
+        weights, N(0, 0.02) embedding MLP, zero biases, zero modulations and zero final projection."""
+        g = torch.Generator().manual_seed(seed)
+        with torch.no_grad():
+            for name, t in self._tensors().items():
+                if name.endswith(".bias") or ".modulation." in name or name.startswith("dit_base.final_layer.linear"):
+                    t.zero_()
+                elif name.startswith("noise_level_pos_embedding"):
+                    t.copy_(0.02 * torch.randn(t.shape, generator=g))
+                else:
+                    fan_out, fan_in = t.shape[0], math.prod(t.shape[1:])
+                    bound = math.sqrt(6.0 / (fan_in + fan_out))
+                    t.copy_((torch.rand(t.shape, generator=g) * 2 - 1) * bound)
+
+    def init_random(self, seed: int = 0) -> None:
+        """Non-degenerate random weights for benchmarks (the reference zero-inits every modulation and the final
+        projection, which makes the output identically zero): weights ~ N(0, 1/fan_in) (modulations at half gain),
+        biases ~ N(0, 0.05^2) -- the distribution of oracle.dit.seeded_params."""
+        g = torch.Generator().manual_seed(seed)
+        with torch.no_grad():
+            for name, t in self._tensors().items():
+                if name.endswith(".bias"):
+                    v = 0.05 * torch.randn(t.shape, generator=g)
+                else:
+                    gain = 0.5 if ".modulation." in name else 1.0
+                    v = gain * torch.randn(t.shape, generator=g) / math.sqrt(math.prod(t.shape[1:]))
+                t.copy_(v.to(t.device))
+
+    def _signature(self) -> Tuple:
+        return tuple((t.data_ptr(), t._version) for t in self._tensors().values())
+
+    def sync_weights(self, force: bool = False) -> None:
+        sig = self._signature()
+        if not force and sig == self._synced:
+            return
+        tensors = self._tensors()
+        s = capi.stream_ptr()
+        for name in self._names:
+            t = tensors[name]
+            if not t.is_cuda:
+                raise RuntimeError(f"parameter {name} is on {t.device}; move the module to the GPU first")
+            src = t.detach().to(torch.float32).contiguous()
+            shape = (C.c_int64 * src.ndim)(*src.shape)
+            capi.check(capi.lib.dfot_dit_load_weight(self._handle, name.encode(), capi.ptr(src), shape, src.ndim, s))
+        capi.check(capi.lib.dfot_dit_finalize(self._handle, s))
+        self._synced = sig
+
+    def set_option(self, key: str, value: int) -> None:
+        capi.check(capi.lib.dfot_dit_set_option(self._handle, key.encode(), int(value)))
+
+    def attn_timing(self):
+        tot, n = C.c_double(), C.c_int64()
+        capi.check(capi.lib.dfot_dit_attn_timing(self._handle, C.byref(tot), C.byref(n)))
+        return tot.value, n.value
+
+    def reserve(self, batch: int) -> None:
+        if batch > self._reserved:
+            torch.cuda.synchronize()
+            capi.check(capi.lib.dfot_dit_reserve(self._handle, int(batch)))
+            self._reserved = batch
+
+    def forward(self, x: torch.Tensor, noise_levels: torch.Tensor, external_cond: Optional[torch.Tensor] = None,
+                external_cond_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+        if external_cond is not None:
+            raise ValueError("this DiT3D was built without an external condition embedding")
+        if x.ndim != 5 or tuple(x.shape[2:]) != self.x_shape:
+            raise ValueError(f"x has shape {tuple(x.shape)}, expected (B, T, {', '.join(map(str, self.x_shape))})")
+        b, t = x.shape[:2]
+        if t > self.max_tokens:
+            raise ValueError(f"{t} tokens exceed max_tokens={self.max_tokens}")
+        if tuple(noise_levels.shape) != (b, t):
+            raise ValueError(f"noise_levels has shape {tuple(noise_levels.shape)}, expected {(b, t)}")
+        if noise_levels.is_floating_point():
+            raise TypeError("DiT3D takes integer noise levels (DiscreteDiffusion passes the level index)")
+        self.sync_weights()
+        self.reserve(b)
+        xf = x.detach().to(torch.float32).contiguous()
+        kf = noise_levels.detach().to(torch.int32).contiguous()
+        out = torch.empty_like(xf)
+        capi.check(capi.lib.dfot_dit_forward(self._handle, capi.ptr(xf), capi.ptr(kf), capi.ptr(out), b, t, capi.stream_ptr()))
+        return out.to(x.dtype)
+
+    def read_tap(self, name: str, rows: int) -> torch.Tensor:
+        out = torch.empty(rows, self.hidden_size, device="cuda", dtype=torch.float32)
+        capi.check(capi.lib.dfot_dit_read_tap(self._handle, name.encode(), capi.ptr(out), out.numel(), capi.stream_ptr()))
+        return out
+
+    def __del__(self):
+        try:
+            if getattr(self, "_handle", None) and self._handle.value:
+                capi.lib.dfot_dit_destroy(self._handle)
+                self._handle = C.c_void_p()
+        except Exception:
+            pass

@@ -269,7 +269,9 @@ class DFoTVideoPoseSampler:
             if cond_full is not None and cond_nfe != nfe:
                 cond_rep = cond_full if nfe == 1 else cond_full.repeat_interleave(nfe, dim=0)
                 cond_nfe = nfe
-            v = self.model(x_in, tables[7], cond_rep, p_["cmask_dev"])
+            # discrete diffusion hands the backbone integer level indices (exact in the float32 table)
+            lvl = tables[7] if cfg.diffusion.is_continuous else tables[7].to(torch.int32)
+            v = self.model(x_in, lvl, cond_rep, p_["cmask_dev"])
             if strict:
                 self.noise_fn("ddim", (bm, horizon, *x_shape))  # multiplied by sigma = 0 in the reference
             if xs_next is None:
@@ -450,3 +452,13 @@ class DFoTVideoPoseSampler:
             known[:, keys] = True
             out = self._interpolate_videos(out, known, conditions)
         return out
+
+
+class DFoTVideoSampler(DFoTVideoPoseSampler):
+    """The reference's base algorithm (algorithms/dfot/dfot_video.py: DFoTVideo), used by the un-conditioned video
+    configurations such as Kinetics-600 (DiT3D + DiscreteDiffusion): identical sampling path, no camera poses."""
+
+    def _process_conditions(self, conditions: Optional[torch.Tensor], noise_levels=None) -> Optional[torch.Tensor]:
+        if conditions is not None:
+            raise ValueError("DFoTVideoSampler takes no external conditions; use DFoTVideoPoseSampler for camera poses")
+        return None

@@ -12,6 +12,9 @@
  *   - dfot_ddim_compose replaces  v->x0/eps, ddim_sample_step, HG compose, context clamp
  *                                 diffusion/discrete_diffusion.py:213-223,454-538 ; history_guidance.py:545-568,978-982 ;
  *                                 dfot_video.py:750-752
+ *   - dfot_dit_*       replaces   DiT3D / BaseBackbone.forward (Kinetics-600 backbone: DiTBase "full" variant, rope_3d)
+ *                                 algorithms/dfot/backbones/dit/dit3d.py:146-192, dit/dit_base.py:150-196,391-419,
+ *                                 dit/dit_blocks.py:49-128,378-542 (called from diffusion/discrete_diffusion.py:173-174)
  *   - dfot_op_*        unit-testable primitives the backbone is built from (GEMM / conv / attention / norms)
  *
  * Conventions: plain pointers and sizes only (no torch types).  Every data pointer is a DEVICE
@@ -102,6 +105,51 @@ int dfot_uvit_forward_cached(dfot_uvit_t h, const float* x, const float* noise_l
  * "down2","mid","up2","up1","up0" in the oracle's NCHW layout. */
 int dfot_uvit_read_tap(dfot_uvit_t h, const char* name, float* out, size_t capacity_floats, void* stream);
 
+/* ---- DiT3D backbone (Kinetics-600 path) --------------------------------------------------------------------- */
+typedef struct dfot_dit_s* dfot_dit_t;
+
+/* Hyper-parameters of dit3d (configurations/algorithm/backbone/dit3d.yaml:1-9 overridden by shortcut/DiT/XL.yaml and
+ * dataset_experiment/kinetics_600_video_generation.yaml:22-23): variant "full", pos_emb_type "rope_3d", no external
+ * condition, no causal mask. */
+typedef struct {
+  int32_t hidden_size;   /* 1152 */
+  int32_t depth;         /* 28 */
+  int32_t num_heads;     /* 16 (head dim 72) */
+  int32_t patch_size;    /* 1 */
+  int32_t in_channels;   /* 16 latent channels */
+  int32_t height;        /* x_shape[1], 16 */
+  int32_t width;         /* x_shape[2], 16 */
+  int32_t max_tokens;    /* temporal length of the RoPE grid, 5 */
+  int32_t mlp_hidden;    /* int(hidden*spatial_mlp_ratio); 0 = attention-only blocks (dit3d.yaml leaves it unset) */
+  int32_t noise_dim;     /* 256 (sinusoidal Timesteps channels) */
+  int32_t timesteps;     /* number of discrete noise levels, 1000 */
+  float rope_theta;      /* 10000 */
+  float eps;             /* 1e-6 (LayerNorm) */
+} dfot_dit_config;
+
+int dfot_dit_create(const dfot_dit_config* cfg, dfot_dit_t* out);
+int dfot_dit_destroy(dfot_dit_t h);
+int dfot_dit_num_params(dfot_dit_t h);
+const char* dfot_dit_param_name(dfot_dit_t h, int index);
+int dfot_dit_param_shape(dfot_dit_t h, int index, int64_t shape[4], int* ndim);
+int dfot_dit_load_weight(dfot_dit_t h, const char* name, const float* data, const int64_t* shape, int ndim, void* stream);
+/* verify every key was loaded; build the RoPE table and the noise-level modulation table: the conditioning of this
+ * backbone is a function of the integer noise level alone, so every AdaLN shift/scale/gate of every block is
+ * evaluated for all `timesteps` levels once (one GEMM) and forward only indexes it */
+int dfot_dit_finalize(dfot_dit_t h, void* stream);
+int dfot_dit_reserve(dfot_dit_t h, int max_batch);
+size_t dfot_dit_workspace_bytes(dfot_dit_t h);
+/* "gemm_variant" (-1 auto), "time_attn" (as for dfot_uvit_set_option) */
+int dfot_dit_set_option(dfot_dit_t h, const char* key, int value);
+int dfot_dit_attn_timing(dfot_dit_t h, double* total_ms, int64_t* launches);
+/* out[B,T,C,H,W] = model(x[B,T,C,H,W], noise_levels[B,T]) ; x/out fp32, noise_levels int32 in [0, timesteps)
+ * (device pointer; out-of-range levels are clamped), T <= max_tokens with T*(H/p)*(W/p) % 128 == 0. */
+int dfot_dit_forward(dfot_dit_t h, const float* x, const int32_t* noise_levels, float* out, int batch, int tokens,
+                     void* stream);
+/* parity taps after the last forward: "emb" [timesteps][hidden] (noise-level embedding of every level),
+ * "stream" [B*T*P][hidden] (residual stream after the last block) */
+int dfot_dit_read_tap(dfot_dit_t h, const char* name, float* out, size_t capacity_floats, void* stream);
+
 /* ---- camera-pose front end ------------------------------------------------------------------- */
 /* raw poses [B,T,16] (fx,fy,px,py | 3x4 RT) -> ray encoding [B,T,180,res,res] fp32, normalised by frame 0 */
 int dfot_ray_encode(const float* raw_poses, float* out, int batch, int tokens, int resolution, void* stream);
@@ -144,6 +192,10 @@ int dfot_op_conv3x3(const void* a_bf16, const void* w_bf16, const float* bias, f
  * log2(e)/sqrt(d) (the kernel works in the exp2 domain). d in {64,128}; N % 128 == 0 (d=64) or % 64. */
 int dfot_op_attention(const void* q, const void* k, const void* v, void* o, int ldo, int batch, int heads, int n,
                       int d, int variant, void* stream);
+/* same with a logical head dim d <= 128 (d % 4 == 0) stored in rows of dstride = (d <= 64 ? 64 : 128) elements whose
+ * pad columns are zero; o[B,N,heads*d] is compact (row stride ldo) */
+int dfot_op_attention_padded(const void* q, const void* k, const void* v, void* o, int ldo, int batch, int heads, int n,
+                             int d, void* stream);
 /* fp32 <-> bf16 helpers for tests */
 int dfot_op_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);
 int dfot_op_bf16_to_f32(const void* src, float* dst, int64_t n, void* stream);

@@ -13,10 +13,10 @@ from oracle import schedule as sch
 
 torch.set_num_threads(8)
 
-TINY = odit.DiTConfig(hidden_size=128, depth=3, num_heads=4, patch_size=1, in_channels=4, resolution=(8, 8), max_tokens=5)
-TINY_MLP = odit.DiTConfig(hidden_size=128, depth=2, num_heads=4, patch_size=2, in_channels=4, resolution=(8, 8),
+TINY = odit.DiTConfig(hidden_size=128, depth=3, num_heads=4, patch_size=1, in_channels=4, resolution=(16, 8), max_tokens=5)
+TINY_MLP = odit.DiTConfig(hidden_size=192, depth=2, num_heads=6, patch_size=2, in_channels=4, resolution=(32, 16),
                           max_tokens=5, spatial_mlp_ratio=4.0)
-SMALL = odit.DiTConfig(hidden_size=128, depth=2, num_heads=4, patch_size=1, in_channels=4, resolution=(8, 8), max_tokens=5)
+SMALL = odit.DiTConfig(hidden_size=128, depth=2, num_heads=4, patch_size=1, in_channels=4, resolution=(16, 8), max_tokens=5)
 
 
 def load(name):
@@ -61,7 +61,7 @@ def test_dit_tiny_mlp_patch2():
     g = load("dit_tiny.npz")
     p = odit.seeded_params(TINY_MLP, 1)
     assert digest(p) == str(g["digest_mlp"])
-    np.testing.assert_allclose(odit.forward(p, TINY_MLP, T(g["x"]), T(g["k"])).numpy(), g["out_mlp"], rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(odit.forward(p, TINY_MLP, T(g["x_mlp"]), T(g["k"])).numpy(), g["out_mlp"], rtol=1e-4, atol=2e-5)
 
 
 def test_dit_k600_forward():
@@ -88,7 +88,7 @@ def test_discrete_cosine_tables_and_sampler():
     model = lambda x, k, c, m: odit.forward(p, SMALL, x, k)
     noise = [T(g[f"noise{i}"]) for i in range(int(g["n_noise"]))]
     nfn = osm.replay_noise_fn(noise)
-    cfg = osm.SamplerConfig(x_shape=(4, 8, 8), max_tokens=5, sampling_timesteps=4,
+    cfg = osm.SamplerConfig(x_shape=(4, 16, 8), max_tokens=5, sampling_timesteps=4,
                             prediction_guidance=dict(name="vanilla", guidance_scale=2.0))
     diff = osm.Diffusion(tb, model, sampling_timesteps=4, is_continuous=False)
     out = osm.Sampler(cfg, diff, None, nfn).predict_videos(T(g["xs"]), 2, None)

@@ -5,8 +5,9 @@ Run ONLY in the build container (needs /root/reference):   python tools/make_gol
 Fixtures are data (inputs, injected noise, expected outputs); weights come from oracle.dit.seeded_params(cfg, seed),
 loaded strictly into the reference module and re-created bit-identically by the tests (sha256 stored).
 
-  dit_tiny.npz      DiT3D.forward: hidden 128 / depth 3 / 4 heads (head dim 32 -> uneven RoPE split 12/10/10),
-                    T=5 and a shorter T=3 window; a second model with patch 2 and spatial_mlp_ratio 4 (MLP branch)
+  dit_tiny.npz      DiT3D.forward: hidden 128 / depth 3 / 4 heads (head dim 32 -> uneven RoPE split 12/10/10), 16x8 latents,
+                    T=5 and a shorter T=3 window; a second model (hidden 192, 6 heads) with patch 2 on 32x16 and
+                    spatial_mlp_ratio 4 (MLP branch)
   dit_k600.npz      DiT3D.forward at the K600 size: DiT/XL (hidden 1152, depth 28, 16 heads), latents 16x16x16, T=5
   sampler_k600.npz  DFoTVideo._predict_videos with DiscreteDiffusion (cosine, pred_v, integer levels): 5 tokens,
                     context 2, 4 DDIM steps, vanilla history guidance 2.0 (small DiT) with the injected noise
@@ -85,16 +86,17 @@ def main():
     A = R["AttrDict"]
 
     print("dit tiny")
-    tiny = odit.DiTConfig(hidden_size=128, depth=3, num_heads=4, patch_size=1, in_channels=4, resolution=(8, 8), max_tokens=5)
+    tiny = odit.DiTConfig(hidden_size=128, depth=3, num_heads=4, patch_size=1, in_channels=4, resolution=(16, 8), max_tokens=5)
     m, p = ref_dit(R, tiny, 0)
     g = torch.Generator().manual_seed(5)
-    x = torch.randn(2, 5, 4, 8, 8, generator=g)
+    x = torch.randn(2, 5, 4, 16, 8, generator=g)
     k = torch.randint(0, 1000, (2, 5), generator=g)
-    tiny_mlp = odit.DiTConfig(hidden_size=128, depth=2, num_heads=4, patch_size=2, in_channels=4, resolution=(8, 8),
+    tiny_mlp = odit.DiTConfig(hidden_size=192, depth=2, num_heads=6, patch_size=2, in_channels=4, resolution=(32, 16),
                               max_tokens=5, spatial_mlp_ratio=4.0)
     m2, p2 = ref_dit(R, tiny_mlp, 1)
+    x2 = torch.randn(2, 5, 4, 32, 16, generator=g)
     save("dit_tiny.npz", x=x, k=k, out=m(x, k), out_t3=m(x[:, :3], k[:, :3]), digest=np.array(weights_digest(p)),
-         out_mlp=m2(x, k), digest_mlp=np.array(weights_digest(p2)))
+         x_mlp=x2, out_mlp=m2(x2, k), digest_mlp=np.array(weights_digest(p2)))
 
     print("dit k600")
     xl = odit.DiTConfig()
@@ -115,14 +117,14 @@ def main():
     del m
 
     print("sampler k600")
-    small = odit.DiTConfig(hidden_size=128, depth=2, num_heads=4, patch_size=1, in_channels=4, resolution=(8, 8), max_tokens=5)
+    small = odit.DiTConfig(hidden_size=128, depth=2, num_heads=4, patch_size=1, in_channels=4, resolution=(16, 8), max_tokens=5)
     cfg = video_cfg(A, small, sampling_steps=4, hg=dict(name="vanilla", guidance_scale=2.0))
     algo = R["DFoTVideo"](cfg).eval()
     ps = odit.seeded_params(small, 2)
     algo.diffusion_model.model.load_state_dict(ps, strict=True)
     dm = algo.diffusion_model
     g = torch.Generator().manual_seed(7)
-    vid = torch.randn(2, 5, 4, 8, 8, generator=g)
+    vid = torch.randn(2, 5, 4, 16, 8, generator=g)
     algo.generator = torch.Generator().manual_seed(0)
     with RandnRecorder() as rec:
         out = algo._predict_videos(vid.clone(), n_context_tokens=2, conditions=None)
