@@ -113,122 +113,189 @@ __global__ __launch_bounds__(256) void patch_embed_kernel(const float* __restric
 }
 
 // AdaLN: m = LayerNorm(x) * (1 + scale) + shift, (shift|scale) = mod_table[level of the row's frame][off ...].
-// One wave per token row (hidden <= 2048); writes m as fp32 (the block's residual base, in place) and bf16 (GEMM operand).
-constexpr int LN_MAXV = 8;  // float4 per lane
-__global__ __launch_bounds__(256) void ln_mod_kernel(float* __restrict__ x, bf16* __restrict__ obf,
-                                                     const float* __restrict__ table, const int* __restrict__ levels,
-                                                     long ldt, long off, int hidden, int rows_per_frame, long rows,
-                                                     float eps, int max_level) {
-  const int lane = threadIdx.x & 63;
-  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= rows) return;
-  float* xr = x + row * hidden;
-  float4v v[LN_MAXV];
+// One wave per token row; a lane owns CNT groups of VEC consecutive channels (hidden = 64 * VEC * CNT, compile-time so the
+// row lives in registers without guards).  Writes m as fp32 (the block's residual base, in place) and bf16 (GEMM operand).
+template <int VEC>
+struct VecT;
+template <>
+struct VecT<1> { typedef float type; };
+template <>
+struct VecT<2> { typedef __attribute__((ext_vector_type(2))) float type; };
+template <>
+struct VecT<4> { typedef __attribute__((ext_vector_type(4))) float type; };
+template <int VEC>
+struct BVecT;
+template <>
+struct BVecT<1> { typedef bf16 type; };
+template <>
+struct BVecT<2> { typedef bf16x2 type; };
+template <>
+struct BVecT<4> { typedef bf16x4 type; };
+
+template <int VEC>
+__device__ __forceinline__ float vsum(const typename VecT<VEC>::type& v) {
+  if constexpr (VEC == 1) return v;
+  else if constexpr (VEC == 2) return v[0] + v[1];
+  else return (v[0] + v[1]) + (v[2] + v[3]);
+}
+template <int VEC>
+__device__ __forceinline__ float vdot(const typename VecT<VEC>::type& a, const typename VecT<VEC>::type& b) {
+  if constexpr (VEC == 1) return a * b;
+  else if constexpr (VEC == 2) return a[0] * b[0] + a[1] * b[1];
+  else return (a[0] * b[0] + a[1] * b[1]) + (a[2] * b[2] + a[3] * b[3]);
+}
+
+// normalised + modulated row in registers: v[i] covers channels (i*64 + lane)*VEC ...
+template <int VEC, int CNT>
+__device__ __forceinline__ void ln_mod_row(const float* __restrict__ xr, const float* __restrict__ sh, int hidden, float eps,
+                                           int lane, typename VecT<VEC>::type (&v)[CNT]) {
+  typedef typename VecT<VEC>::type V;
   float s = 0.f;
 #pragma unroll
-  for (int i = 0; i < LN_MAXV; ++i) {
-    const int c = (i * 64 + lane) * 4;
-    if (c < hidden) {
-      v[i] = *reinterpret_cast<const float4v*>(xr + c);
-      s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
-    }
+  for (int i = 0; i < CNT; ++i) {
+    v[i] = *reinterpret_cast<const V*>(xr + (i * 64 + lane) * VEC);
+    s += vsum<VEC>(v[i]);
   }
   const float mean = wave_sum(s) / (float)hidden;
   float q = 0.f;
 #pragma unroll
-  for (int i = 0; i < LN_MAXV; ++i) {
-    const int c = (i * 64 + lane) * 4;
-    if (c < hidden) {
-      v[i] -= mean;
-      q += v[i][0] * v[i][0] + v[i][1] * v[i][1] + v[i][2] * v[i][2] + v[i][3] * v[i][3];
-    }
+  for (int i = 0; i < CNT; ++i) {
+    v[i] -= mean;
+    q += vdot<VEC>(v[i], v[i]);
   }
   const float rstd = rsqrtf(wave_sum(q) / (float)hidden + eps);
-  int lv = levels[row / rows_per_frame];
-  lv = lv < 0 ? 0 : (lv > max_level ? max_level : lv);
-  const float* sh = table + (long)lv * ldt + off;
   const float* sc = sh + hidden;
 #pragma unroll
-  for (int i = 0; i < LN_MAXV; ++i) {
-    const int c = (i * 64 + lane) * 4;
-    if (c < hidden) {
-      const float4v a = *reinterpret_cast<const float4v*>(sh + c);
-      const float4v g = *reinterpret_cast<const float4v*>(sc + c);
-      const float4v m = v[i] * rstd * (1.0f + g) + a;
-      *reinterpret_cast<float4v*>(xr + c) = m;
-      bf16x4 o;
+  for (int i = 0; i < CNT; ++i) {
+    const V a = *reinterpret_cast<const V*>(sh + (i * 64 + lane) * VEC);
+    const V g = *reinterpret_cast<const V*>(sc + (i * 64 + lane) * VEC);
+    v[i] = v[i] * rstd * (1.0f + g) + a;
+  }
+}
+
+template <int VEC, int CNT>
+__global__ __launch_bounds__(256) void ln_mod_kernel(float* __restrict__ x, bf16* __restrict__ obf,
+                                                     const float* __restrict__ table, const int* __restrict__ levels,
+                                                     long ldt, long off, int rows_per_frame, int rows, float eps,
+                                                     int max_level) {
+  typedef typename VecT<VEC>::type V;
+  typedef typename BVecT<VEC>::type B;
+  constexpr int hidden = 64 * VEC * CNT;
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  float* xr = x + (long)row * hidden;
+  int lv = levels[row / rows_per_frame];
+  lv = lv < 0 ? 0 : (lv > max_level ? max_level : lv);
+  V v[CNT];
+  ln_mod_row<VEC, CNT>(xr, table + (long)lv * ldt + off, hidden, eps, lane, v);
+  bf16* orow = obf + (long)row * hidden;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) o[j] = f2bf(m[j]);
-      *reinterpret_cast<bf16x4*>(obf + row * hidden + c) = o;
+  for (int i = 0; i < CNT; ++i) {
+    *reinterpret_cast<V*>(xr + (i * 64 + lane) * VEC) = v[i];
+    B o;
+    if constexpr (VEC == 1) {
+      o = f2bf(v[i]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) o[j] = f2bf(v[i][j]);
     }
+    *reinterpret_cast<B*>(orow + (i * 64 + lane) * VEC) = o;
   }
 }
 
 // Final layer: AdaLN (shift|scale) -> Linear(hidden, p*p*C) -> unpatchify to [BT][C][H][W] (dit3d.py:129-144).
-// One wave per token row; the (small) weight is read through L2.
+// One wave per token row; the weight (oc x hidden fp32, 72 KB at K600) is staged in LDS once per workgroup of FIN_ROWS rows.
+constexpr int FIN_ROWS = 16;
+template <int VEC, int CNT>
 __global__ __launch_bounds__(256) void final_layer_kernel(const float* __restrict__ x, const float* __restrict__ table,
                                                           const int* __restrict__ levels, long ldt, long off,
                                                           const float* __restrict__ w, const float* __restrict__ b,
-                                                          float* __restrict__ out, int hidden, int rows_per_frame, long rows,
-                                                          float eps, int max_level, int c, int hh, int ww, int ps) {
-  const int lane = threadIdx.x & 63;
-  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= rows) return;
-  const float* xr = x + row * hidden;
-  float4v v[LN_MAXV];
-  float s = 0.f;
-#pragma unroll
-  for (int i = 0; i < LN_MAXV; ++i) {
-    const int cc = (i * 64 + lane) * 4;
-    if (cc < hidden) {
-      v[i] = *reinterpret_cast<const float4v*>(xr + cc);
-      s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
-    }
-  }
-  const float mean = wave_sum(s) / (float)hidden;
-  float q = 0.f;
-#pragma unroll
-  for (int i = 0; i < LN_MAXV; ++i) {
-    const int cc = (i * 64 + lane) * 4;
-    if (cc < hidden) {
-      v[i] -= mean;
-      q += v[i][0] * v[i][0] + v[i][1] * v[i][1] + v[i][2] * v[i][2] + v[i][3] * v[i][3];
-    }
-  }
-  const float rstd = rsqrtf(wave_sum(q) / (float)hidden + eps);
-  const long bt = row / rows_per_frame;
-  int lv = levels[bt];
-  lv = lv < 0 ? 0 : (lv > max_level ? max_level : lv);
-  const float* sh = table + (long)lv * ldt + off;
-  const float* sc = sh + hidden;
-#pragma unroll
-  for (int i = 0; i < LN_MAXV; ++i) {
-    const int cc = (i * 64 + lane) * 4;
-    if (cc < hidden) {
-      const float4v a = *reinterpret_cast<const float4v*>(sh + cc);
-      const float4v g = *reinterpret_cast<const float4v*>(sc + cc);
-      v[i] = v[i] * rstd * (1.0f + g) + a;
-    }
-  }
-  const int gw = ww / ps, g = (int)(row % rows_per_frame), gy = g / gw, gx = g % gw;
+                                                          float* __restrict__ out, int rows_per_frame, int rows, float eps,
+                                                          int max_level, int c, int hh, int ww, int ps) {
+  typedef typename VecT<VEC>::type V;
+  constexpr int hidden = 64 * VEC * CNT;
+  extern __shared__ float wl[];  // [oc][hidden]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int oc = ps * ps * c;
-  for (int o = 0; o < oc; ++o) {  // o = (p, q, channel), channel fastest
-    const float* wr = w + (long)o * hidden;
-    float acc = 0.f;
+  for (int i = threadIdx.x * 4; i < oc * hidden; i += 1024)
+    *reinterpret_cast<float4v*>(wl + i) = *reinterpret_cast<const float4v*>(w + i);
+  __syncthreads();
+  const int gw = ww / ps;
+  for (int rr = wave; rr < FIN_ROWS; rr += 4) {
+    const int row = blockIdx.x * FIN_ROWS + rr;
+    if (row >= rows) break;
+    const int bt = row / rows_per_frame;
+    int lv = levels[bt];
+    lv = lv < 0 ? 0 : (lv > max_level ? max_level : lv);
+    V v[CNT];
+    ln_mod_row<VEC, CNT>(x + (long)row * hidden, table + (long)lv * ldt + off, hidden, eps, lane, v);
+    const int g = row % rows_per_frame, gy = g / gw, gx = g % gw;
+    for (int o = 0; o < oc; ++o) {  // o = (p, q, channel), channel fastest
+      const float* wr = wl + o * hidden;
+      float acc = 0.f;
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
-      const int cc = (i * 64 + lane) * 4;
-      if (cc < hidden) {
-        const float4v t = *reinterpret_cast<const float4v*>(wr + cc);
-        acc += v[i][0] * t[0] + v[i][1] * t[1] + v[i][2] * t[2] + v[i][3] * t[3];
+      for (int i = 0; i < CNT; ++i) acc += vdot<VEC>(v[i], *reinterpret_cast<const V*>(wr + (i * 64 + lane) * VEC));
+      acc = wave_sum(acc);
+      if (lane == 0) {
+        const int ch = o % c, pq = o / c, py = pq / ps, px = pq % ps;
+        out[(((long)bt * c + ch) * hh + gy * ps + py) * ww + gx * ps + px] = acc + b[o];
       }
     }
-    acc = wave_sum(acc);
-    if (lane == 0) {
-      const int ch = o % c, pq = o / c, py = pq / ps, px = pq % ps;
-      out[((bt * c + ch) * hh + gy * ps + py) * ww + gx * ps + px] = acc + b[o];
-    }
   }
+}
+
+// hidden = 64 * VEC * CNT with VEC = 2 when hidden % 128 == 0 (8-byte accesses), else 1
+#define DIT_LN_DISPATCH(CALL)                                  \
+  switch (hidden % 128 == 0 ? hidden / 128 : -(hidden / 64)) { \
+    case 1: CALL(2, 1); break;                                 \
+    case 2: CALL(2, 2); break;                                 \
+    case 3: CALL(2, 3); break;                                 \
+    case 4: CALL(2, 4); break;                                 \
+    case 5: CALL(2, 5); break;                                 \
+    case 6: CALL(2, 6); break;                                 \
+    case 7: CALL(2, 7); break;                                 \
+    case 8: CALL(2, 8); break;                                 \
+    case 9: CALL(2, 9); break;                                 \
+    case 10: CALL(2, 10); break;                               \
+    case 12: CALL(2, 12); break;                               \
+    case 16: CALL(2, 16); break;                               \
+    case -1: CALL(1, 1); break;                                \
+    case -3: CALL(1, 3); break;                                \
+    case -5: CALL(1, 5); break;                                \
+    case -7: CALL(1, 7); break;                                \
+    case -9: CALL(1, 9); break;                                \
+    default:                                                   \
+      set_error("DiT: hidden size %d has no LayerNorm kernel instance", hidden); \
+      return DFOT_ERR_SHAPE;                                   \
+  }
+
+int launch_ln_mod(float* x, bf16* obf, const float* table, const int* levels, long ldt, long off, int hidden, int rows_per_frame,
+                  int rows, float eps, int max_level, hipStream_t s) {
+#define CALL(V, C) \
+  hipLaunchKernelGGL((ln_mod_kernel<V, C>), dim3(cdiv(rows, 4)), dim3(256), 0, s, x, obf, table, levels, ldt, off, rows_per_frame, rows, eps, max_level)
+  DIT_LN_DISPATCH(CALL)
+#undef CALL
+  DFOT_CHECK_HIP(hipGetLastError());
+  return DFOT_OK;
+}
+
+int launch_final_layer(const float* x, const float* table, const int* levels, long ldt, long off, const float* w, const float* b,
+                       float* out, int hidden, int rows_per_frame, int rows, float eps, int max_level, int c, int hh, int ww, int ps,
+                       hipStream_t s) {
+  const int lds = ps * ps * c * hidden * (int)sizeof(float);
+  DFOT_REQUIRE(lds <= 160 * 1024, DFOT_ERR_SHAPE, "final layer: weight (%d B) does not fit in LDS", lds);
+#define CALL(V, C)                                                                                                          \
+  {                                                                                                                         \
+    auto kern = final_layer_kernel<V, C>;                                                                                   \
+    DFOT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds)); \
+    hipLaunchKernelGGL(kern, dim3(cdiv(rows, FIN_ROWS)), dim3(256), lds, s, x, table, levels, ldt, off, w, b, out, rows_per_frame, \
+                       rows, eps, max_level, c, hh, ww, ps);                                                                \
+  }
+  DIT_LN_DISPATCH(CALL)
+#undef CALL
+  DFOT_CHECK_HIP(hipGetLastError());
+  return DFOT_OK;
 }
 
 }  // namespace
@@ -426,8 +493,8 @@ int dfot_dit_destroy(dfot_dit_t h) {
 int dfot_dit_create(const dfot_dit_config* cfg, dfot_dit_t* out) {
   DFOT_REQUIRE(cfg && out, DFOT_ERR_ARG, "dfot_dit_create: null argument");
   const dfot_dit_config& c = *cfg;
-  DFOT_REQUIRE(c.hidden_size > 0 && c.hidden_size % 64 == 0 && c.hidden_size <= 64 * 4 * LN_MAXV, DFOT_ERR_SHAPE,
-               "hidden_size %d must be a multiple of 64, <= %d", c.hidden_size, 64 * 4 * LN_MAXV);
+  DFOT_REQUIRE(c.hidden_size > 0 && c.hidden_size % 64 == 0 && c.hidden_size <= 2048, DFOT_ERR_SHAPE,
+               "hidden_size %d must be a multiple of 64, <= 2048", c.hidden_size);
   DFOT_REQUIRE(c.num_heads > 0 && c.hidden_size % c.num_heads == 0, DFOT_ERR_SHAPE, "hidden_size %d not divisible by %d heads",
                c.hidden_size, c.num_heads);
   const int d = c.hidden_size / c.num_heads;
@@ -580,10 +647,7 @@ int dfot_dit_forward(dfot_dit_t h, const float* x, const int32_t* noise_levels, 
   DFOT_CHECK_HIP(hipGetLastError());
   const float qscale = 1.4426950408889634f / sqrtf((float)h->d);  // attention works in the exp2 domain
   auto ln_mod = [&](long off) -> int {
-    hipLaunchKernelGGL(ln_mod_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, s, h->X, h->A, h->mod_table, noise_levels, h->ldt, off, hd,
-                       h->P, rows, c.eps, max_level);
-    DFOT_CHECK_HIP(hipGetLastError());
-    return DFOT_OK;
+    return launch_ln_mod(h->X, h->A, h->mod_table, noise_levels, h->ldt, off, hd, h->P, (int)rows, c.eps, max_level, s);
   };
   auto gated = [&](const bf16* a, int kdim, const bf16* w, const float* bias, long gate_off) -> int {
     GemmArgs g;  // X <- X + gate * (a W^T + bias), in place
@@ -616,10 +680,8 @@ int dfot_dit_forward(dfot_dit_t h, const float* x, const int32_t* noise_levels, 
     }
   }
   h->last_rows = (int)rows;
-  hipLaunchKernelGGL(final_layer_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, s, h->X, h->mod_table, noise_levels, h->ldt, h->mod_final,
-                     h->fin_w, h->fin_b, out, hd, h->P, rows, c.eps, max_level, c.in_channels, c.height, c.width, c.patch_size);
-  DFOT_CHECK_HIP(hipGetLastError());
-  return DFOT_OK;
+  return launch_final_layer(h->X, h->mod_table, noise_levels, h->ldt, h->mod_final, h->fin_w, h->fin_b, out, hd, h->P, (int)rows, c.eps,
+                            max_level, c.in_channels, c.height, c.width, c.patch_size, s);
 }
 
 int dfot_dit_read_tap(dfot_dit_t h, const char* name, float* out, size_t capacity, void* stream) {

@@ -42,8 +42,13 @@ __global__ __launch_bounds__((BM_T / WTM) * (BN_T / 64) * 64 * KS) void gemm_ker
   constexpr int WN = BN_T / 64;                 // waves along N
   constexpr int NW = (BM_T / WTM) * WN;         // waves per k-group
   constexpr int NT = NW * 64;                   // threads per k-group
-  constexpr int ACH = (BM_T * 8) / NT;          // A chunks (16 B) per thread per k-tile
-  constexpr int WCH = (BN_T * 8) / NT;          // W chunks per thread per k-tile
+  // one wave instruction stages 8 rows (1 KiB) of a tile; AINS/WINS of them per k-tile are dealt round-robin to the NW
+  // waves.  When NW does not divide them (256x192 tile: 32 + 24 over 12 waves) the last turn is guarded per wave.
+  constexpr int AINS = BM_T / 8, WINS = BN_T / 8;
+  constexpr int ACH = (AINS + NW - 1) / NW;     // A chunks (16 B) per thread per k-tile
+  constexpr int WCH = (WINS + NW - 1) / NW;     // W chunks per thread per k-tile
+  constexpr bool A_EVEN = AINS % NW == 0, W_EVEN = WINS % NW == 0;
+  static_assert((A_EVEN && W_EVEN) || (DMA && NST == 2 && KS == 1), "uneven staging: two-stage LDS-DMA kernels only");
   constexpr int A_BYTES = BM_T * BK * 2;
   constexpr int STAGE_BYTES = (BM_T + BN_T) * BK * 2;
   constexpr int LOADS = ACH + WCH;              // LDS-DMA instructions per thread per k-tile
@@ -116,6 +121,7 @@ __global__ __launch_bounds__((BM_T / WTM) * (BN_T / 64) * 64 * KS) void gemm_ker
     char* sw = sa + A_BYTES;
 #pragma unroll
     for (int i = 0; i < ACH; ++i) {
+      if (!A_EVEN && NW * i + wave >= AINS) continue;  // wave-uniform
       const bf16* pa = a_addr(i, kt);
       if constexpr (DMA) {
         __builtin_amdgcn_global_load_lds(DFOT_GLOBAL_PTR(pa), DFOT_LDS_PTR(sa + (NW * i + wave) * 1024), 16, 0, 0);
@@ -125,6 +131,7 @@ __global__ __launch_bounds__((BM_T / WTM) * (BN_T / 64) * 64 * KS) void gemm_ker
     }
 #pragma unroll
     for (int i = 0; i < WCH; ++i) {
+      if (!W_EVEN && NW * i + wave >= WINS) continue;
       const bf16* pw = w_src[i] + (long)kt * BK;
       if constexpr (DMA) {
         __builtin_amdgcn_global_load_lds(DFOT_GLOBAL_PTR(pw), DFOT_LDS_PTR(sw + (NW * i + wave) * 1024), 16, 0, 0);
@@ -523,6 +530,9 @@ static int launch_v(int variant, const GemmArgs& g, hipStream_t s) {
     case GEMM_DMA_256x256: return launch_t<256, 256, 64, 2, AMODE, EPI, true>(g, s);
     case GEMM_DMA_256x128: return launch_t<256, 128, 64, 2, AMODE, EPI, true>(g, s);
     case GEMM_DMA_512x128: return launch_t<512, 128, 64, 2, AMODE, EPI, true>(g, s);
+    case GEMM_DMA_256x192:
+      if constexpr (AMODE != A_DENSE) break;
+      else return launch_t<256, 192, 64, 2, AMODE, EPI, true>(g, s);
     case GEMM_DMA_128_KS2:
       if constexpr (EPI == E_QKV) break;
       else return launch_t<128, 128, 64, 2, AMODE, EPI, true, 2>(g, s);
@@ -538,8 +548,16 @@ int gemm_pick_variant(int amode, int m, int n, int k) {
   // Measured on MI355X at the model's shapes (tools/bench_ops.py, profiles/): these GEMMs are bound by L2->LDS operand
   // traffic, so the 256x256 tile (128 FLOP per operand byte instead of 64) wins whenever it still fills the chip:
   // N wide enough that the padded columns are cheap, and enough tiles for the 256 CUs.
-  (void)amode;
   const long tiles = (long)(m / 256) * ((n + 255) / 256);
+  if (m % 256 == 0 && n >= 192 && amode == A_DENSE) {
+    // one workgroup per CU: useful fraction of the issued tile-rounds (padding columns + the last, partly filled round).
+    // 256x192 tiles win where N is a multiple of 192 but not of 256 (DiT/XL: 1152, 3456)
+    auto util = [&](int bn) {
+      const long t = (long)(m / 256) * ((n + bn - 1) / bn);
+      return (double)m * n / ((double)((t + 255) / 256) * 256 * 256 * bn);
+    };
+    if (util(192) > 1.05 * util(256) && (long)(m / 256) * ((n + 191) / 192) >= 160) return GEMM_DMA_256x192;
+  }
   if (m % 256 == 0 && n >= 192 && tiles >= 160) return GEMM_DMA_256x256;
   // N = 128 (level-0 convolutions): one column of tiles, so grow the tile along M instead (16 waves, 102 FLOP/B)
   if (m % 512 == 0 && n <= 128 && m / 512 >= 256) return GEMM_DMA_512x128;
@@ -553,7 +571,8 @@ int launch_gemm(int amode, int epi, int variant, const GemmArgs& g, hipStream_t 
   DFOT_REQUIRE(g.A && g.W, DFOT_ERR_ARG, "gemm: null operand");
   if (variant == GEMM_AUTO) variant = gemm_pick_variant(amode, g.M, g.N, g.K);
   if (variant == GEMM_DMA_128_KS2 && epi == E_QKV) variant = GEMM_DMA_128;  // the QKV epilogue has workgroup barriers
-  const int bm = variant == GEMM_DMA_512x128 ? 512 : (variant == GEMM_DMA3_256 || variant == GEMM_DMA_256x256 || variant == GEMM_DMA_256x128 || variant == GEMM_DMA_256x256_W128) ? 256 : 128;
+  if (variant == GEMM_DMA_256x192 && epi == E_QKV) variant = GEMM_DMA_256x256;  // its head pairing needs 128-aligned tiles
+  const int bm = variant == GEMM_DMA_512x128 ? 512 : (variant == GEMM_DMA3_256 || variant == GEMM_DMA_256x256 || variant == GEMM_DMA_256x128 || variant == GEMM_DMA_256x256_W128 || variant == GEMM_DMA_256x192) ? 256 : 128;
   DFOT_REQUIRE(g.M > 0 && g.M % bm == 0, DFOT_ERR_SHAPE, "gemm: M=%d must be a positive multiple of %d", g.M, bm);
   DFOT_REQUIRE(g.K > 0 && g.K % BK == 0, DFOT_ERR_SHAPE, "gemm: K=%d must be a positive multiple of %d", g.K, BK);
   DFOT_REQUIRE(g.N > 0 && g.N % (epi == E_F32 ? 4 : 8) == 0, DFOT_ERR_SHAPE, "gemm: N=%d must be a multiple of %d", g.N, epi == E_F32 ? 4 : 8);
