@@ -533,6 +533,9 @@ static int launch_v(int variant, const GemmArgs& g, hipStream_t s) {
     case GEMM_DMA_256x192:
       if constexpr (AMODE != A_DENSE) break;
       else return launch_t<256, 192, 64, 2, AMODE, EPI, true>(g, s);
+    case GEMM_DMA_128x192:
+      if constexpr (AMODE != A_DENSE || EPI == E_QKV) break;
+      else return launch_t<128, 192, 64, 2, AMODE, EPI, true>(g, s);
     case GEMM_DMA_128_KS2:
       if constexpr (EPI == E_QKV) break;
       else return launch_t<128, 128, 64, 2, AMODE, EPI, true, 2>(g, s);
@@ -561,8 +564,13 @@ int gemm_pick_variant(int amode, int m, int n, int k) {
   if (m % 256 == 0 && n >= 192 && tiles >= 160) return GEMM_DMA_256x256;
   // N = 128 (level-0 convolutions): one column of tiles, so grow the tile along M instead (16 waves, 102 FLOP/B)
   if (m % 512 == 0 && n <= 128 && m / 512 >= 256) return GEMM_DMA_512x128;
-  // at most one 128x128 tile per CU and a long K (Upsample convolutions at 16x16 / 32x32): split K inside the workgroup
   const long tiles128 = (long)(m / 128) * ((n + 127) / 128);
+  // a few more 128x128 tiles than CUs and a long K (level-3 attn_out+mlp_out: 288 tiles, K = 5760): 128x192 tiles give one
+  // round of <= 256 larger tiles instead of a short second round
+  if (amode == A_DENSE && tiles128 > 256 && n % 192 == 0 && (long)(m / 128) * (n / 192) <= 256 && (long)(m / 128) * (n / 192) >= 160 &&
+      k >= 1024)
+    return GEMM_DMA_128x192;
+  // at most one 128x128 tile per CU and a long K (Upsample convolutions at 16x16 / 32x32): split K inside the workgroup
   if (tiles128 <= 256 && k >= 2048) return GEMM_DMA_128_KS2;
   return GEMM_DMA_128;
 }
@@ -571,6 +579,7 @@ int launch_gemm(int amode, int epi, int variant, const GemmArgs& g, hipStream_t 
   DFOT_REQUIRE(g.A && g.W, DFOT_ERR_ARG, "gemm: null operand");
   if (variant == GEMM_AUTO) variant = gemm_pick_variant(amode, g.M, g.N, g.K);
   if (variant == GEMM_DMA_128_KS2 && epi == E_QKV) variant = GEMM_DMA_128;  // the QKV epilogue has workgroup barriers
+  if (variant == GEMM_DMA_128x192 && epi == E_QKV) variant = GEMM_DMA_128;
   if (variant == GEMM_DMA_256x192 && epi == E_QKV) variant = GEMM_DMA_256x256;  // its head pairing needs 128-aligned tiles
   const int bm = variant == GEMM_DMA_512x128 ? 512 : (variant == GEMM_DMA3_256 || variant == GEMM_DMA_256x256 || variant == GEMM_DMA_256x128 || variant == GEMM_DMA_256x256_W128 || variant == GEMM_DMA_256x192) ? 256 : 128;
   DFOT_REQUIRE(g.M > 0 && g.M % bm == 0, DFOT_ERR_SHAPE, "gemm: M=%d must be a positive multiple of %d", g.M, bm);
