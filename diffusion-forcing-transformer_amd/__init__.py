@@ -4,7 +4,7 @@ reference's backbone / sampler interfaces.  Importing it requires the built HIP 
 there is no CPU fallback."""
 from . import capi  # noqa: F401  (raises ImportError when libdfot_hip.so is missing)
 from .backbone import UViT3DPose  # noqa: F401
-from .dit_backbone import DiT3D  # noqa: F401
+from .dit_backbone import DiT3D, DifferenceDiT3D  # noqa: F401
 from .diffusion import DiffusionConfig, Schedule  # noqa: F401
 from .guidance import HistoryGuidance  # noqa: F401
 from .sampler import DFoTVideoPoseSampler, DFoTVideoSampler, SamplerConfig, device_noise_fn  # noqa: F401

@@ -36,6 +36,8 @@ class DiTConfig(C.Structure):
         ("in_channels", C.c_int32), ("height", C.c_int32), ("width", C.c_int32), ("max_tokens", C.c_int32),
         ("mlp_hidden", C.c_int32), ("noise_dim", C.c_int32), ("timesteps", C.c_int32),
         ("rope_theta", C.c_float), ("eps", C.c_float),
+        ("variant", C.c_int32), ("embed_col_dim", C.c_int32), ("num_col_heads", C.c_int32), ("num_row_heads", C.c_int32),
+        ("temporal_mlp_hidden", C.c_int32), ("use_bias", C.c_int32),
     ]
 
 

@@ -36,6 +36,14 @@ struct DitBlockW {
   long mod1 = 0, mod2 = 0;  // column offsets of this block's (shift|scale|gate) triples inside a mod_table row
 };
 
+struct DitMatrixW {  // MatrixDiTBlock (temporal block of the factorized-matrix variant)
+  bf16 *ut = nullptr, *vt = nullptr, *put = nullptr, *pvt = nullptr;  // qkv_u^T [E][P], qkv_v^T [3h][h], proj_u^T [P][E], proj_v^T [h][h]
+  float *qkv_bias = nullptr, *proj_bias = nullptr;                      // [E][3h], [P][h]
+  bf16 *w_fc1 = nullptr, *w_fc2 = nullptr;
+  float *b_fc1 = nullptr, *b_fc2 = nullptr;
+  long mod1 = 0, mod2 = 0;
+};
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -73,13 +81,113 @@ __global__ __launch_bounds__(256) void rows_linear_kernel(const float* __restric
   }
 }
 
+// semb[(flag*lpad + level)][:] = bf16(SiLU(emb[level] + diff_table[flag]))  (DifferenceDiT3D: c = noise emb + diff emb)
+__global__ void add_diff_silu_kernel(const float* __restrict__ emb, const float* __restrict__ diff_table, bf16* __restrict__ semb,
+                                     int levels, int lpad, int hidden, int flags) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)flags * levels * hidden) return;
+  const int c = (int)(i % hidden), lv = (int)((i / hidden) % levels), f = (int)(i / ((long)hidden * levels));
+  semb[((long)f * lpad + lv) * hidden + c] = f2bf(silu_f(emb[(long)lv * hidden + c] + diff_table[(long)f * hidden + c]));
+}
+
+// dst[c][r] (bf16) = src[r][c] (fp32): weight packing of the matrix factors (stored (in, out) in the reference)
+__global__ void pack_transpose_kernel(const float* __restrict__ src, bf16* __restrict__ dst, int rows, int cols) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)rows * cols) return;
+  const int r = (int)(i % rows), c = (int)(i / rows);
+  dst[i] = f2bf(src[(long)r * cols + c]);
+}
+
+// table row of every (video, token): level + lpad * flag, flag = 1 for difference tokens (even positions of the interleaved
+// merge, difference_dit3d.py:159-176 with diff_first=True)
+__global__ void make_index_kernel(const int* __restrict__ levels, int* __restrict__ idx, int n, int tokens, int max_level, int lpad) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int lv = levels[i];
+  lv = lv < 0 ? 0 : (lv > max_level ? max_level : lv);
+  idx[i] = lv + ((i % tokens) % 2 == 0 ? lpad : 0);
+}
+
+// per-frame 2-D transpose of a bf16 matrix: src [frames][R][C] -> dst [frames][C][R]; 64x64 tiles through LDS
+__global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16* __restrict__ src, bf16* __restrict__ dst, int R, int C) {
+  __shared__ bf16 tile[64][66];
+  const long f = blockIdx.z;
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const bf16* s = src + f * R * C;
+  bf16* d = dst + f * R * C;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) tile[ty * 16 + i][tx] = s[(long)(r0 + ty * 16 + i) * C + c0 + tx];
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 16; ++i) d[(long)(c0 + ty * 16 + i) * R + r0 + tx] = tile[tx][ty * 16 + i];
+}
+
+// MatrixAttention core (dit_blocks.py:289-336, multi_token = False, no RoPE): every frame is one token whose q/k/v are
+// (hn x hd) matrices; z [B*L*E][3h] holds (q|k|v) with columns (row head r, d) and rows (frame, col head c, n).
+// One workgroup per (video, c, r): scores L x L = scale * <q_l, k_l'> over the hn*hd entries, softmax over l', o = P v.
+// o [B*L*E][h] in the same row/column order.  L <= 32.
+__global__ __launch_bounds__(256) void matrix_attn_kernel(const bf16* __restrict__ z, bf16* __restrict__ o, int L, int E, int h,
+                                                          int cc, int rr, float scale) {
+  __shared__ float sc[32 * 32];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.x / (cc * rr), c = (blockIdx.x / rr) % cc, r = blockIdx.x % rr;
+  const int hn = E / cc, hd = h / rr, ne = hn * hd / 4;
+  const long ldz = 3L * h;
+  auto zrow = [&](int l, int n) { return z + (((long)b * L + l) * E + c * hn + n) * ldz + r * hd; };
+  for (int pi = wave; pi < L * L; pi += 4) {
+    const int l = pi / L, l2 = pi % L;
+    float acc = 0.f;
+    for (int e = lane; e < ne; e += 64) {
+      const int n = (e * 4) / hd, d = (e * 4) % hd;
+      const bf16x4 q4 = *reinterpret_cast<const bf16x4*>(zrow(l, n) + d);
+      const bf16x4 k4 = *reinterpret_cast<const bf16x4*>(zrow(l2, n) + h + d);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc += bf2f(q4[j]) * bf2f(k4[j]);
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) sc[pi] = acc * scale;
+  }
+  __syncthreads();
+  if (threadIdx.x < L) {
+    float* row = sc + threadIdx.x * L;
+    float mx = row[0];
+    for (int j = 1; j < L; ++j) mx = fmaxf(mx, row[j]);
+    float sum = 0.f;
+    for (int j = 0; j < L; ++j) {
+      row[j] = __expf(row[j] - mx);
+      sum += row[j];
+    }
+    const float inv = 1.0f / sum;
+    for (int j = 0; j < L; ++j) row[j] *= inv;
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < ne; e += 256) {
+    const int n = (e * 4) / hd, d = (e * 4) % hd;
+    for (int l = 0; l < L; ++l) {
+      float a[4] = {0.f, 0.f, 0.f, 0.f};
+      for (int l2 = 0; l2 < L; ++l2) {
+        const bf16x4 v4 = *reinterpret_cast<const bf16x4*>(zrow(l2, n) + 2 * h + d);
+        const float pw = sc[l * L + l2];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) a[j] += pw * bf2f(v4[j]);
+      }
+      bf16x4 o4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o4[j] = f2bf(a[j]);
+      *reinterpret_cast<bf16x4*>(o + (((long)b * L + l) * E + c * hn + n) * h + r * hd + d) = o4;
+    }
+  }
+}
+
 // ---- forward kernels --------------------------------------------------------------------------------------------
 // PatchEmbed (Conv2d k = s = p): x [BT][C][H][W] fp32 -> tokens [BT*gh*gw][hidden] fp32.  8 tokens per workgroup so each
 // weight row is fetched once per 8 tokens; thread = output channels t, t+256, ...
 constexpr int PE_TOK = 8;
 __global__ __launch_bounds__(256) void patch_embed_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                          const float* __restrict__ b, float* __restrict__ out, int c,
-                                                          int hh, int ww, int ps, int hidden, long rows) {
+                                                          const float* __restrict__ b, const float* __restrict__ pos,
+                                                          float* __restrict__ out, int c, int hh, int ww, int ps, int hidden,
+                                                          long rows) {
   extern __shared__ float patch[];  // [PE_TOK][kdim]
   const int gh = hh / ps, gw = ww / ps, kdim = c * ps * ps;
   const long row0 = (long)blockIdx.x * PE_TOK;
@@ -108,7 +216,8 @@ __global__ __launch_bounds__(256) void patch_embed_kernel(const float* __restric
     }
 #pragma unroll
     for (int t = 0; t < PE_TOK; ++t)
-      if (row0 + t < rows) out[(row0 + t) * hidden + o] = acc[t];
+      if (row0 + t < rows)  // pos: optional absolute positional embedding [P][hidden] of the token's patch (sinusoidal_2d)
+        out[(row0 + t) * hidden + o] = acc[t] + (pos ? pos[((row0 + t) % (gh * gw)) * hidden + o] : 0.f);
   }
 }
 
@@ -317,6 +426,8 @@ struct dfot_dit_s {
         *fin_w = nullptr, *fin_b = nullptr, *b_mod = nullptr;
   bf16* w_mod = nullptr;  // every modulation Linear stacked: [ldt][hidden]
   std::vector<DitBlockW> blocks;
+  std::vector<DitMatrixW> tblocks;  // variant 1: one MatrixDiTBlock after every spatial block
+  float *diff_table = nullptr, *pos2d = nullptr;
   long mod_final = 0;
   // derived at finalize
   float *freqs = nullptr, *feat = nullptr, *thid = nullptr, *emb = nullptr, *mod_table = nullptr, *rope_cs = nullptr;
@@ -326,6 +437,8 @@ struct dfot_dit_s {
   int max_batch = 0, last_rows = 0;
   float* X = nullptr;
   bf16 *A = nullptr, *q = nullptr, *k = nullptr, *v = nullptr, *hid = nullptr;
+  bf16 *T1 = nullptr, *W1 = nullptr, *W2 = nullptr, *Z = nullptr;  // variant 1: transposes / left-factor products / qkv of frames
+  int* idx = nullptr;                                              // variant 1: mod_table row per (video, token)
   int gemm_variant = GEMM_AUTO;
   bool time_attn = false;
   std::vector<hipEvent_t> ev_start, ev_stop;
@@ -389,7 +502,9 @@ int dit_build(dfot_dit_s* h) {
   h->kpatch = c.in_channels * c.patch_size * c.patch_size;
   h->oc = h->kpatch;
   h->lpad = (c.timesteps + 255) / 256 * 256;
-  const int per_block = c.mlp_hidden ? 6 * hd : 3 * hd;
+  const bool facmat = c.variant == 1;
+  const int E = c.embed_col_dim, P = h->P;
+  const int per_block = (c.mlp_hidden ? 6 * hd : 3 * hd) + (facmat ? (c.temporal_mlp_hidden ? 6 * hd : 3 * hd) : 0);
   h->ldt = (long)c.depth * per_block + 2 * hd;
   int rc = 0;
   // registration order == the reference module's state_dict order
@@ -400,6 +515,7 @@ int dit_build(dfot_dit_s* h) {
   if ((rc = dit_add_f32(h, ne + ".linear_2.bias", {hd}, &h->t_b2))) return rc;
   if ((rc = dit_add_f32(h, "patch_embedder.proj.weight", {hd, c.in_channels, c.patch_size, c.patch_size}, &h->pe_w))) return rc;
   if ((rc = dit_add_f32(h, "patch_embedder.proj.bias", {hd}, &h->pe_b))) return rc;
+  if (facmat && (rc = dit_add_f32(h, "diff_embedder.embedding_table.weight", {2, hd}, &h->diff_table))) return rc;
   if ((rc = dit_alloc(h, &h->w_mod, (size_t)h->ldt * hd))) return rc;
   if ((rc = dit_alloc(h, &h->b_mod, (size_t)h->ldt))) return rc;
   h->blocks.resize(c.depth);
@@ -430,6 +546,49 @@ int dit_build(dfot_dit_s* h) {
       if ((rc = dit_add_f32(h, pre + ".mlp.fc2.bias", {hd}, &w.b_fc2))) return rc;
     }
   }
+  // dst[c][r] bf16 = src[r][c]: the matrix factors are stored (in, out); the GEMMs want [out][in]
+  auto add_transposed = [&](const std::string& name, int rows, int cols, bf16* dst) {
+    dit_add(h, name, {rows, cols}, [=](const float* src, hipStream_t s) {
+      hipLaunchKernelGGL(pack_transpose_kernel, dim3(cdiv((long)rows * cols, 256)), dim3(256), 0, s, src, dst, rows, cols);
+      DFOT_CHECK_HIP(hipGetLastError());
+      return DFOT_OK;
+    });
+  };
+  if (facmat) {
+    h->tblocks.resize(c.depth);
+    for (int i = 0; i < c.depth; ++i) {
+      DitMatrixW& w = h->tblocks[i];
+      const std::string pre = "dit_base.temporal_blocks." + std::to_string(i);
+      w.mod1 = off;
+      dit_add_bf16(h, pre + ".norm1.modulation.1.weight", 3 * hd, hd, h->w_mod + off * hd);
+      dit_add_slice(h, pre + ".norm1.modulation.1.bias", 3 * hd, h->b_mod + off);
+      off += 3 * hd;
+      if ((rc = dit_alloc(h, &w.ut, (size_t)E * P)) || (rc = dit_alloc(h, &w.put, (size_t)P * E)) ||
+          (rc = dit_alloc(h, &w.vt, (size_t)3 * hd * hd)) || (rc = dit_alloc(h, &w.pvt, (size_t)hd * hd)))
+        return rc;
+      add_transposed(pre + ".attn.qkv_u", P, E, w.ut);
+      add_transposed(pre + ".attn.proj_u", E, P, w.put);
+      add_transposed(pre + ".attn.qkv_v", hd, 3 * hd, w.vt);
+      add_transposed(pre + ".attn.proj_v", hd, hd, w.pvt);
+      if (c.use_bias) {
+        if ((rc = dit_add_f32(h, pre + ".attn.qkv_bias", {E, 3 * hd}, &w.qkv_bias))) return rc;
+        if ((rc = dit_add_f32(h, pre + ".attn.proj_bias", {P, hd}, &w.proj_bias))) return rc;
+      }
+      if (c.temporal_mlp_hidden) {
+        const int th = c.temporal_mlp_hidden;
+        w.mod2 = off;
+        dit_add_bf16(h, pre + ".norm2.modulation.1.weight", 3 * hd, hd, h->w_mod + off * hd);
+        dit_add_slice(h, pre + ".norm2.modulation.1.bias", 3 * hd, h->b_mod + off);
+        off += 3 * hd;
+        if ((rc = dit_alloc(h, &w.w_fc1, (size_t)th * hd))) return rc;
+        dit_add_bf16(h, pre + ".mlp.fc1.weight", th, hd, w.w_fc1);
+        if ((rc = dit_add_f32(h, pre + ".mlp.fc1.bias", {th}, &w.b_fc1))) return rc;
+        if ((rc = dit_alloc(h, &w.w_fc2, (size_t)hd * th))) return rc;
+        dit_add_bf16(h, pre + ".mlp.fc2.weight", hd, th, w.w_fc2);
+        if ((rc = dit_add_f32(h, pre + ".mlp.fc2.bias", {hd}, &w.b_fc2))) return rc;
+      }
+    }
+  }
   h->mod_final = off;
   dit_add_bf16(h, "dit_base.final_layer.norm_final.modulation.1.weight", 2 * hd, hd, h->w_mod + off * hd);
   dit_add_slice(h, "dit_base.final_layer.norm_final.modulation.1.bias", 2 * hd, h->b_mod + off);
@@ -441,15 +600,33 @@ int dit_build(dfot_dit_s* h) {
   if ((rc = dit_alloc(h, &h->feat, (size_t)h->lpad * c.noise_dim))) return rc;
   if ((rc = dit_alloc(h, &h->thid, (size_t)h->lpad * hd))) return rc;
   if ((rc = dit_alloc(h, &h->emb, (size_t)h->lpad * hd))) return rc;
-  if ((rc = dit_alloc(h, &h->semb, (size_t)h->lpad * hd))) return rc;
-  if ((rc = dit_alloc(h, &h->mod_table, (size_t)h->lpad * h->ldt))) return rc;
+  const int nflag = facmat ? 2 : 1;  // variant 1: the conditioning also depends on the token kind (difference / frame)
+  if ((rc = dit_alloc(h, &h->semb, (size_t)nflag * h->lpad * hd))) return rc;
+  if ((rc = dit_alloc(h, &h->mod_table, (size_t)nflag * h->lpad * h->ldt))) return rc;
   {
     const int half = c.noise_dim / 2;
     std::vector<float> f(half);
     for (int i = 0; i < half; ++i) f[i] = (float)std::exp(-std::log(10000.0) * (double)i / (double)half);
     DFOT_CHECK_HIP(hipMemcpy(h->freqs, f.data(), f.size() * sizeof(float), hipMemcpyHostToDevice));
   }
-  {  // RoPE-3D (cos, sin) table [Tmax*P][d/2][2]; axis split of the head dim as RotaryEmbedding3D (embeddings.py:251-277)
+  if (facmat) {
+    // sinusoidal_2d table [P][hidden] (get_nd_sincos_pos_embed, dit_base.py:527-572): np.meshgrid's default "xy" indexing
+    // makes flattened entry m use position m % gh for the first half of the channels and m / gh for the second; each half
+    // is [sin | cos] of pos * 10000^(-i/(half/2)), computed in float64 like numpy
+    const int half = hd / 2, quarter = half / 2;
+    std::vector<float> pe((size_t)P * hd);
+    for (int m = 0; m < P; ++m) {
+      const int pos[2] = {m % h->gh, m / h->gh};
+      for (int a = 0; a < 2; ++a)
+        for (int i = 0; i < quarter; ++i) {
+          const double ang = (double)pos[a] / std::pow(10000.0, (double)i / (double)quarter);
+          pe[(size_t)m * hd + a * half + i] = (float)std::sin(ang);
+          pe[(size_t)m * hd + a * half + quarter + i] = (float)std::cos(ang);
+        }
+    }
+    if ((rc = dit_alloc(h, &h->pos2d, pe.size()))) return rc;
+    DFOT_CHECK_HIP(hipMemcpy(h->pos2d, pe.data(), pe.size() * sizeof(float), hipMemcpyHostToDevice));
+  } else {  // RoPE-3D (cos, sin) table [Tmax*P][d/2][2]; axis split of the head dim as RotaryEmbedding3D (embeddings.py:251-277)
     const int half = h->d / 2, q = half / 3, rem = half % 3;
     int parts[3] = {q, q, q};
     if (rem == 1) parts[0] = q + 1;
@@ -505,6 +682,19 @@ int dfot_dit_create(const dfot_dit_config* cfg, dfot_dit_t* out) {
   DFOT_REQUIRE(c.mlp_hidden >= 0 && c.mlp_hidden % 64 == 0, DFOT_ERR_SHAPE, "mlp_hidden %d must be a multiple of 64", c.mlp_hidden);
   DFOT_REQUIRE(c.noise_dim > 0 && c.noise_dim % 2 == 0 && c.timesteps > 0 && c.max_tokens > 0 && c.depth > 0, DFOT_ERR_SHAPE,
                "bad noise_dim / timesteps / max_tokens / depth");
+  DFOT_REQUIRE(c.variant == 0 || c.variant == 1, DFOT_ERR_ARG, "variant %d unknown (0 = dit3d full/rope_3d, 1 = difference_dit3d factorized matrix)", c.variant);
+  if (c.variant == 1) {
+    const int P = (c.height / c.patch_size) * (c.width / c.patch_size);
+    DFOT_REQUIRE(P % 128 == 0, DFOT_ERR_SHAPE, "factorized matrix variant: %d patches per frame must be a multiple of 128", P);
+    DFOT_REQUIRE(c.embed_col_dim > 0 && c.embed_col_dim % 64 == 0, DFOT_ERR_SHAPE, "embed_col_dim %d must be a multiple of 64", c.embed_col_dim);
+    DFOT_REQUIRE(c.num_col_heads > 0 && c.embed_col_dim % c.num_col_heads == 0 && c.num_row_heads > 0 &&
+                     c.hidden_size % c.num_row_heads == 0 && (c.hidden_size / c.num_row_heads) % 4 == 0,
+                 DFOT_ERR_SHAPE, "matrix attention heads (%d col, %d row) do not divide (%d, %d)", c.num_col_heads, c.num_row_heads,
+                 c.embed_col_dim, c.hidden_size);
+    DFOT_REQUIRE(c.max_tokens % 2 == 0 && c.max_tokens <= 32, DFOT_ERR_SHAPE, "max_tokens %d must be even (difference, frame pairs) and <= 32", c.max_tokens);
+    DFOT_REQUIRE(c.temporal_mlp_hidden >= 0 && c.temporal_mlp_hidden % 64 == 0 && c.hidden_size % 4 == 0 && (c.hidden_size / 2) % 2 == 0,
+                 DFOT_ERR_SHAPE, "temporal_mlp_hidden %d must be a multiple of 64", c.temporal_mlp_hidden);
+  }
   auto* h = new dfot_dit_s();
   h->cfg = c;
   int rc = dit_build(h);
@@ -549,17 +739,23 @@ int dfot_dit_finalize(dfot_dit_t h, void* stream) {
   const dfot_dit_config& c = h->cfg;
   const int hd = c.hidden_size, L = c.timesteps;
   // embedding of every level: features -> Linear -> SiLU -> Linear (emb) ; semb = bf16(SiLU(emb)) feeds every modulation
-  DFOT_CHECK_HIP(hipMemsetAsync(h->semb, 0, (size_t)h->lpad * hd * sizeof(bf16), s));
   hipLaunchKernelGGL(tstep_features_kernel, dim3(cdiv((long)L * c.noise_dim, 256)), dim3(256), 0, s, h->freqs, h->feat, L, c.noise_dim);
   DFOT_CHECK_HIP(hipGetLastError());
   hipLaunchKernelGGL(rows_linear_kernel<1>, dim3(cdiv(hd, 4), L), dim3(256), 0, s, h->feat, h->t_w1, h->t_b1, h->thid,
                      (bf16*)nullptr, c.noise_dim, hd);
   DFOT_CHECK_HIP(hipGetLastError());
-  hipLaunchKernelGGL(rows_linear_kernel<0>, dim3(cdiv(hd, 4), L), dim3(256), 0, s, h->thid, h->t_w2, h->t_b2, h->emb, h->semb, hd, hd);
+  const int nflag = c.variant == 1 ? 2 : 1;
+  DFOT_CHECK_HIP(hipMemsetAsync(h->semb, 0, (size_t)nflag * h->lpad * hd * sizeof(bf16), s));
+  hipLaunchKernelGGL(rows_linear_kernel<0>, dim3(cdiv(hd, 4), L), dim3(256), 0, s, h->thid, h->t_w2, h->t_b2, h->emb,
+                     c.variant == 1 ? (bf16*)nullptr : h->semb, hd, hd);
   DFOT_CHECK_HIP(hipGetLastError());
+  if (c.variant == 1) {  // c = noise-level embedding + diff_embedder(token kind)  (difference_dit3d.py:199-204)
+    hipLaunchKernelGGL(add_diff_silu_kernel, dim3(cdiv(2L * L * hd, 256)), dim3(256), 0, s, h->emb, h->diff_table, h->semb, L, h->lpad, hd, 2);
+    DFOT_CHECK_HIP(hipGetLastError());
+  }
   // mod_table[level][:] = W_mod * SiLU(emb[level]) + b_mod for every modulation of the model
   GemmArgs g;
-  g.A = h->semb; g.lda = hd; g.W = h->w_mod; g.M = h->lpad; g.N = (int)h->ldt; g.K = hd;
+  g.A = h->semb; g.lda = hd; g.W = h->w_mod; g.M = nflag * h->lpad; g.N = (int)h->ldt; g.K = hd;
   g.bias = h->b_mod; g.out_f32 = h->mod_table; g.ldo = h->ldt;
   int rc = launch_gemm(A_DENSE, E_F32, GEMM_AUTO, g, s);
   if (rc) return rc;
@@ -586,7 +782,16 @@ int dfot_dit_reserve(dfot_dit_t h, int max_batch) {
   DFOT_CHECK_HIP(hipMemset(h->q, 0, qkv * sizeof(bf16)));
   DFOT_CHECK_HIP(hipMemset(h->k, 0, qkv * sizeof(bf16)));
   DFOT_CHECK_HIP(hipMemset(h->v, 0, qkv * sizeof(bf16)));
-  if (c.mlp_hidden && (rc = dit_alloc(h, &h->hid, rows * c.mlp_hidden, true))) return rc;
+  const int hid_cols = c.variant == 1 && c.temporal_mlp_hidden > c.mlp_hidden ? c.temporal_mlp_hidden : c.mlp_hidden;
+  if (hid_cols && (rc = dit_alloc(h, &h->hid, rows * hid_cols, true))) return rc;
+  if (c.variant == 1) {
+    const size_t frames = (size_t)max_batch * c.max_tokens;
+    if ((rc = dit_alloc(h, &h->T1, rows * c.hidden_size, true))) return rc;
+    if ((rc = dit_alloc(h, &h->W1, frames * c.embed_col_dim * c.hidden_size, true))) return rc;
+    if ((rc = dit_alloc(h, &h->W2, frames * c.embed_col_dim * c.hidden_size, true))) return rc;
+    if ((rc = dit_alloc(h, &h->Z, frames * c.embed_col_dim * 3 * c.hidden_size, true))) return rc;
+    if ((rc = dit_alloc(h, &h->idx, frames, true))) return rc;
+  }
   h->max_batch = max_batch;
   return DFOT_OK;
 }
@@ -640,47 +845,98 @@ int dfot_dit_forward(dfot_dit_t h, const float* x, const int32_t* noise_levels, 
   DFOT_REQUIRE(n % 128 == 0, DFOT_ERR_SHAPE, "forward: sequence length %d (tokens x patches) must be a multiple of 128", n);
   hipStream_t s = (hipStream_t)stream;
   const long rows = (long)batch * n;
-  const int max_level = c.timesteps - 1;
+  const bool facmat = c.variant == 1;
+  const int frames = batch * tokens, P = h->P, E = c.embed_col_dim;
+  DFOT_REQUIRE(!facmat || tokens % 2 == 0, DFOT_ERR_SHAPE, "forward: %d tokens; the difference model takes (difference, frame) pairs", tokens);
+  int max_level = c.timesteps - 1;
+  const int* lvl = noise_levels;
   int rc = 0;
+  if (facmat) {  // table row = level + lpad * (token kind)
+    hipLaunchKernelGGL(make_index_kernel, dim3(cdiv(frames, 256)), dim3(256), 0, s, noise_levels, h->idx, frames, tokens, max_level, h->lpad);
+    DFOT_CHECK_HIP(hipGetLastError());
+    lvl = h->idx;
+    max_level = 2 * h->lpad - 1;
+  }
   hipLaunchKernelGGL(patch_embed_kernel, dim3(cdiv(rows, PE_TOK)), dim3(256), PE_TOK * h->kpatch * sizeof(float), s, x, h->pe_w,
-                     h->pe_b, h->X, c.in_channels, c.height, c.width, c.patch_size, hd, rows);
+                     h->pe_b, h->pos2d, h->X, c.in_channels, c.height, c.width, c.patch_size, hd, rows);
   DFOT_CHECK_HIP(hipGetLastError());
   const float qscale = 1.4426950408889634f / sqrtf((float)h->d);  // attention works in the exp2 domain
   auto ln_mod = [&](long off) -> int {
-    return launch_ln_mod(h->X, h->A, h->mod_table, noise_levels, h->ldt, off, hd, h->P, (int)rows, c.eps, max_level, s);
+    return launch_ln_mod(h->X, h->A, h->mod_table, lvl, h->ldt, off, hd, P, (int)rows, c.eps, max_level, s);
   };
-  auto gated = [&](const bf16* a, int kdim, const bf16* w, const float* bias, long gate_off) -> int {
+  auto gated = [&](const bf16* a, int kdim, const bf16* w, const float* bias, int bias_rows, long gate_off) -> int {
     GemmArgs g;  // X <- X + gate * (a W^T + bias), in place
-    g.A = a; g.lda = kdim; g.W = w; g.M = (int)rows; g.N = hd; g.K = kdim; g.bias = bias;
+    g.A = a; g.lda = kdim; g.W = w; g.M = (int)rows; g.N = hd; g.K = kdim; g.bias = bias; g.bias_rows = bias_rows;
     g.out_f32 = h->X; g.ldo = hd; g.resid = h->X;
-    g.gate = h->mod_table + gate_off; g.gate_index = noise_levels; g.ldg = h->ldt; g.gate_rows = h->P;
+    g.gate = h->mod_table + gate_off; g.gate_index = lvl; g.ldg = h->ldt; g.gate_rows = P;
     return launch_gemm(A_DENSE, E_F32, h->gemm_variant, g, s);
   };
-  for (const DitBlockW& w : h->blocks) {
+  auto mlp = [&](long mod2, int hidden_cols, const bf16* w1, const float* b1, const bf16* w2, const float* b2) -> int {
+    int r2 = ln_mod(mod2);
+    if (r2) return r2;
+    GemmArgs g;
+    g.A = h->A; g.lda = hd; g.W = w1; g.M = (int)rows; g.N = hidden_cols; g.K = hd; g.bias = b1;
+    g.out_bf16 = h->hid; g.ldo = hidden_cols; g.act = 1;
+    if ((r2 = launch_gemm(A_DENSE, E_BF16, h->gemm_variant, g, s))) return r2;
+    return gated(h->hid, hidden_cols, w2, b2, 0, mod2 + 2 * hd);
+  };
+  auto transpose = [&](const bf16* src, bf16* dst, int R, int C) -> int {  // per frame [R][C] -> [C][R]
+    hipLaunchKernelGGL(transpose_bf16_kernel, dim3(C / 64, R / 64, frames), dim3(256), 0, s, src, dst, R, C);
+    DFOT_CHECK_HIP(hipGetLastError());
+    return DFOT_OK;
+  };
+  // attention sequences: the whole video (variant 0) or one frame (variant 1, per-frame spatial blocks without RoPE)
+  const int seq = facmat ? P : n, nseq = facmat ? frames : batch;
+  for (size_t bi = 0; bi < h->blocks.size(); ++bi) {
+    const DitBlockW& w = h->blocks[bi];
     if ((rc = ln_mod(w.mod1))) return rc;
     {
       GemmArgs g;
       g.A = h->A; g.lda = hd; g.W = w.w_qkv; g.M = (int)rows; g.N = 3 * hd; g.K = hd; g.bias = w.b_qkv;
-      g.q = h->q; g.k = h->k; g.v = h->v; g.rope_cs = h->rope_cs; g.heads = c.num_heads; g.d = h->d; g.dstride = h->dstride;
-      g.ntok = n; g.qscale = qscale;
+      g.q = h->q; g.k = h->k; g.v = h->v; g.rope_cs = facmat ? nullptr : h->rope_cs; g.heads = c.num_heads; g.d = h->d;
+      g.dstride = h->dstride; g.ntok = seq; g.qscale = qscale;
       if ((rc = launch_gemm(A_DENSE, E_QKV_DIT, h->gemm_variant, g, s))) return rc;
     }
     const bool timed = h->time_attn && h->ev_used < h->ev_start.size();
     if (timed) DFOT_CHECK_HIP(hipEventRecord(h->ev_start[h->ev_used], s));
-    if ((rc = launch_attention_padded(h->q, h->k, h->v, h->A, hd, batch, c.num_heads, n, h->d, s))) return rc;
+    if ((rc = launch_attention_padded(h->q, h->k, h->v, h->A, hd, nseq, c.num_heads, seq, h->d, s))) return rc;
     if (timed) DFOT_CHECK_HIP(hipEventRecord(h->ev_stop[h->ev_used++], s));
-    if ((rc = gated(h->A, hd, w.w_proj, w.b_proj, w.mod1 + 2 * hd))) return rc;
-    if (c.mlp_hidden) {
-      if ((rc = ln_mod(w.mod2))) return rc;
-      GemmArgs g;
-      g.A = h->A; g.lda = hd; g.W = w.w_fc1; g.M = (int)rows; g.N = c.mlp_hidden; g.K = hd; g.bias = w.b_fc1;
-      g.out_bf16 = h->hid; g.ldo = c.mlp_hidden; g.act = 1;
+    if ((rc = gated(h->A, hd, w.w_proj, w.b_proj, 0, w.mod1 + 2 * hd))) return rc;
+    if (c.mlp_hidden && (rc = mlp(w.mod2, c.mlp_hidden, w.w_fc1, w.b_fc1, w.w_fc2, w.b_fc2))) return rc;
+    if (!facmat) continue;
+
+    // ---- MatrixDiTBlock: every frame is one token; qkv = U^T m V + bias, o = softmax(q k^T) v, out = U'^T o V' + bias' ----
+    const DitMatrixW& t = h->tblocks[bi];
+    if ((rc = ln_mod(t.mod1))) return rc;
+    if ((rc = transpose(h->A, h->T1, P, hd))) return rc;  // m^T per frame: [hd][P]
+    {
+      GemmArgs g;  // left factor: w[frame][e][d] = sum_p U[p][e] m[frame][p][d]   (rows (frame, d), K = p, transposed store)
+      g.A = h->T1; g.lda = P; g.W = t.ut; g.M = frames * hd; g.N = E; g.K = P; g.out_bf16 = h->W1; g.ldo = E; g.tr_rows = hd;
       if ((rc = launch_gemm(A_DENSE, E_BF16, h->gemm_variant, g, s))) return rc;
-      if ((rc = gated(h->hid, c.mlp_hidden, w.w_fc2, w.b_fc2, w.mod2 + 2 * hd))) return rc;
     }
+    {
+      GemmArgs g;  // right factor + bias[e][k]
+      g.A = h->W1; g.lda = hd; g.W = t.vt; g.M = frames * E; g.N = 3 * hd; g.K = hd; g.bias = t.qkv_bias; g.bias_rows = t.qkv_bias ? E : 0;
+      g.out_bf16 = h->Z; g.ldo = 3 * hd;
+      if ((rc = launch_gemm(A_DENSE, E_BF16, h->gemm_variant, g, s))) return rc;
+    }
+    {
+      const int hn = E / c.num_col_heads, hdr = hd / c.num_row_heads;
+      hipLaunchKernelGGL(matrix_attn_kernel, dim3(batch * c.num_col_heads * c.num_row_heads), dim3(256), 0, s, h->Z, h->W1, tokens, E, hd,
+                         c.num_col_heads, c.num_row_heads, 1.0f / sqrtf((float)hn * (float)hdr));
+      DFOT_CHECK_HIP(hipGetLastError());
+    }
+    if ((rc = transpose(h->W1, h->W2, E, hd))) return rc;  // o^T per frame: [hd][E]
+    {
+      GemmArgs g;  // left factor of the projection: s[frame][p][d] = sum_e U'[e][p] o[frame][e][d]
+      g.A = h->W2; g.lda = E; g.W = t.put; g.M = frames * hd; g.N = P; g.K = E; g.out_bf16 = h->T1; g.ldo = P; g.tr_rows = hd;
+      if ((rc = launch_gemm(A_DENSE, E_BF16, h->gemm_variant, g, s))) return rc;
+    }
+    if ((rc = gated(h->T1, hd, t.pvt, t.proj_bias, t.proj_bias ? P : 0, t.mod1 + 2 * hd))) return rc;
+    if (c.temporal_mlp_hidden && (rc = mlp(t.mod2, c.temporal_mlp_hidden, t.w_fc1, t.b_fc1, t.w_fc2, t.b_fc2))) return rc;
   }
   h->last_rows = (int)rows;
-  return launch_final_layer(h->X, h->mod_table, noise_levels, h->ldt, h->mod_final, h->fin_w, h->fin_b, out, hd, h->P, (int)rows, c.eps,
+  return launch_final_layer(h->X, h->mod_table, lvl, h->ldt, h->mod_final, h->fin_w, h->fin_b, out, hd, P, (int)rows, c.eps,
                             max_level, c.in_channels, c.height, c.width, c.patch_size, s);
 }
 

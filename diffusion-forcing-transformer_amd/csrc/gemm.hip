@@ -276,9 +276,33 @@ __global__ __launch_bounds__((BM_T / WTM) * (BN_T / 64) * 64 * KS) void gemm_ker
   const int col = nw + cw;
   const bool live = col < g.N;  // N is a multiple of the lane's column count, so a lane is entirely in or out
   f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = {0.f, 0.f, 0.f, 0.f};
-  if (g.bias && live) {
+  [[maybe_unused]] const bool bias2d = g.bias_rows > 0;  // bias[(row % bias_rows)][col] (MatrixAttention qkv_bias / proj_bias)
+  if (g.bias && live && !bias2d) {
     b0 = *reinterpret_cast<const f32x4*>(g.bias + col);
     if constexpr (EPI != E_F32) b1 = *reinterpret_cast<const f32x4*>(g.bias + col + 4);
+  }
+  if constexpr (EPI == E_BF16) {
+    if (g.tr_rows > 0) {
+      // transposed store straight from the MFMA C layout (a lane owns one column and four consecutive rows):
+      // out[frame][col][row % tr_rows], frame = row / tr_rows  -- no bias / activation / GroupNorm statistics
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+        const long row = (long)m0 + wm * WTM + mi * 16 + rowq;
+        const long frame = row / g.tr_rows;
+        const int rin = (int)(row % g.tr_rows);
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+          const int c = nw + ni * 16 + colq;
+          if (c < g.N) {
+            bf16x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = f2bf(acc[mi][ni][j]);
+            *reinterpret_cast<bf16x4*>(g.out_bf16 + (frame * g.N + c) * (long)g.tr_rows + rin) = o;
+          }
+        }
+      }
+      return;
+    }
   }
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
@@ -293,6 +317,7 @@ __global__ __launch_bounds__((BM_T / WTM) * (BN_T / 64) * 64 * KS) void gemm_ker
         for (int p = 0; p < 4; ++p) {
           const int r = p * 4 + (lane >> 4);
           f32x4 v = *reinterpret_cast<const f32x4*>(ep + r * EP_LD + cw) + b0;
+          if (bias2d) v += *reinterpret_cast<const f32x4*>(g.bias + ((mw + r) % g.bias_rows) * (long)g.N + col);
           const long off = (mw + r) * g.ldo + col;
           if (has_gate) {
             long gr = (mw + r) / g.gate_rows;
@@ -310,8 +335,15 @@ __global__ __launch_bounds__((BM_T / WTM) * (BN_T / 64) * 64 * KS) void gemm_ker
 #pragma unroll
       for (int p = 0; p < 2; ++p) {
         const int r = p * 8 + (lane >> 3);
-        const f32x4 v0 = *reinterpret_cast<const f32x4*>(ep + r * EP_LD + cw) + b0;
-        const f32x4 v1 = *reinterpret_cast<const f32x4*>(ep + r * EP_LD + cw + 4) + b1;
+        f32x4 v0 = *reinterpret_cast<const f32x4*>(ep + r * EP_LD + cw) + b0;
+        f32x4 v1 = *reinterpret_cast<const f32x4*>(ep + r * EP_LD + cw + 4) + b1;
+        if constexpr (EPI == E_BF16) {
+          if (bias2d && live) {
+            const float* bp = g.bias + ((mw + r) % g.bias_rows) * (long)g.N + col;
+            v0 += *reinterpret_cast<const f32x4*>(bp);
+            v1 += *reinterpret_cast<const f32x4*>(bp + 4);
+          }
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           vals[p][j] = v0[j];
@@ -361,9 +393,9 @@ __global__ __launch_bounds__((BM_T / WTM) * (BN_T / 64) * 64 * KS) void gemm_ker
             const long bidx = row / g.ntok;
             const int tok = (int)(row % g.ntok);
             bf16x8 o;
-            if (which == 2) {
+            if (which == 2 || g.rope_cs == nullptr) {  // v, or q/k without rotary embedding (per-frame spatial blocks)
 #pragma unroll
-              for (int j = 0; j < 8; ++j) o[j] = f2bf(vals[p][j]);
+              for (int j = 0; j < 8; ++j) o[j] = f2bf(vals[p][j] * mul);
             } else {
               const float* cs = g.rope_cs + ((long)tok * (g.d / 2) + e0 / 2) * 2;
 #pragma unroll
@@ -598,7 +630,7 @@ int launch_gemm(int amode, int epi, int variant, const GemmArgs& g, hipStream_t 
                  DFOT_ERR_SHAPE, "qkv epilogue: heads=%d d=%d split=%d ntok=%d M=%d", g.heads, g.d, g.split, g.ntok, g.M);
   }
   if (epi == E_QKV_DIT) {
-    DFOT_REQUIRE(g.q && g.k && g.v && g.rope_cs, DFOT_ERR_ARG, "dit qkv epilogue: null pointer");
+    DFOT_REQUIRE(g.q && g.k && g.v, DFOT_ERR_ARG, "dit qkv epilogue: null pointer");
     DFOT_REQUIRE(g.d > 0 && g.d % 8 == 0 && g.dstride >= g.d && g.dstride % 8 == 0 && g.heads > 0 && g.N == 3 * g.heads * g.d &&
                      g.ntok > 0 && g.M % g.ntok == 0,
                  DFOT_ERR_SHAPE, "dit qkv epilogue: heads=%d d=%d dstride=%d ntok=%d M=%d N=%d", g.heads, g.d, g.dstride, g.ntok, g.M, g.N);
@@ -606,6 +638,11 @@ int launch_gemm(int amode, int epi, int variant, const GemmArgs& g, hipStream_t 
   if (g.gate) {
     DFOT_REQUIRE(epi == E_F32 && g.gate_rows > 0 && g.M % g.gate_rows == 0 && g.ldg % 4 == 0, DFOT_ERR_SHAPE,
                  "gemm: gate needs the fp32 epilogue, gate_rows dividing M and ldg %% 4 == 0");
+  }
+  if (g.bias_rows) DFOT_REQUIRE((epi == E_F32 || epi == E_BF16) && g.bias && g.bias_rows > 0, DFOT_ERR_ARG, "gemm: 2-D bias needs a plain epilogue");
+  if (g.tr_rows) {
+    DFOT_REQUIRE(epi == E_BF16 && !g.bias && !g.act && !g.gn_part && g.tr_rows % 4 == 0 && g.M % g.tr_rows == 0 && amode == A_DENSE,
+                 DFOT_ERR_ARG, "gemm: transposed store needs the plain bf16 epilogue and tr_rows %% 4 == 0 dividing M");
   }
   if (g.gn_part) {
     DFOT_REQUIRE(epi != E_QKV && epi != E_QKV_DIT && (g.gn_cpg == 4 || g.gn_cpg == 8) && g.N == 32 * g.gn_cpg && g.gn_rows_per_bt % 64 == 0 &&

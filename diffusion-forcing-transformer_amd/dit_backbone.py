@@ -30,32 +30,25 @@ class DiT3D(nn.Module):
         if use_causal_mask:
             raise NotImplementedError("Causal masking is not yet implemented for DiT3D backbone")
         super().__init__()
-        if _get(cfg, "variant", "full") != "full":
-            raise ValueError(f"unsupported DiT variant {_get(cfg, 'variant')!r}: only 'full' is built")
-        if _get(cfg, "pos_emb_type", "rope_3d") != "rope_3d":
-            raise ValueError("only pos_emb_type='rope_3d' is supported")
         if external_cond_dim:
             raise ValueError("external conditions are not supported by the DiT3D engine (kinetics_600 has none)")
         self.cfg = cfg
         self.x_shape = tuple(int(v) for v in x_shape)
-        self.max_tokens = int(max_tokens)
         self.external_cond_dim = 0
         self.use_causal_mask = False
         self.patch_size = int(_get(cfg, "patch_size", 2))
-        self.hidden_size = int(_get(cfg, "hidden_size"))
-        ratio = _get(cfg, "spatial_mlp_ratio", None)
         c = capi.DiTConfig()
-        c.hidden_size = self.hidden_size
         c.depth = int(_get(cfg, "depth"))
         c.num_heads = int(_get(cfg, "num_heads"))
         c.patch_size = self.patch_size
         c.in_channels, c.height, c.width = self.x_shape
-        c.max_tokens = self.max_tokens
-        c.mlp_hidden = int(self.hidden_size * ratio) if ratio else 0
         c.noise_dim = 256
         c.timesteps = int(timesteps)
         c.rope_theta = 10000.0
         c.eps = 1e-6
+        self._configure(c, cfg, int(max_tokens))
+        self.hidden_size = int(c.hidden_size)
+        self.max_tokens = int(c.max_tokens)
         self._ccfg = c
         self.num_patches = (c.height // c.patch_size) * (c.width // c.patch_size)
         self._handle = C.c_void_p()
@@ -70,6 +63,18 @@ class DiT3D(nn.Module):
             self._names.append(name)
         self._synced: Optional[Tuple] = None
         self._reserved = 0
+
+    def _configure(self, c: "capi.DiTConfig", cfg, max_tokens: int) -> None:
+        """dit3d.yaml keys -> engine config (variant 0)."""
+        if _get(cfg, "variant", "full") != "full":
+            raise ValueError(f"unsupported DiT variant {_get(cfg, 'variant')!r}: DiT3D builds 'full' (see DifferenceDiT3D)")
+        if _get(cfg, "pos_emb_type", "rope_3d") != "rope_3d":
+            raise ValueError("only pos_emb_type='rope_3d' is supported")
+        ratio = _get(cfg, "spatial_mlp_ratio", None)
+        c.hidden_size = int(_get(cfg, "hidden_size"))
+        c.max_tokens = max_tokens
+        c.mlp_hidden = int(c.hidden_size * ratio) if ratio else 0
+        c.variant = 0
 
     @property
     def in_channels(self) -> int:
@@ -97,9 +102,9 @@ class DiT3D(nn.Module):
         g = torch.Generator().manual_seed(seed)
         with torch.no_grad():
             for name, t in self._tensors().items():
-                if name.endswith(".bias") or ".modulation." in name or name.startswith("dit_base.final_layer.linear"):
+                if name.endswith(("bias", "qkv_bias", "proj_bias")) or ".modulation." in name or name.startswith("dit_base.final_layer.linear"):
                     t.zero_()
-                elif name.startswith("noise_level_pos_embedding"):
+                elif name.startswith(("noise_level_pos_embedding", "diff_embedder")):
                     t.copy_(0.02 * torch.randn(t.shape, generator=g))
                 else:
                     fan_out, fan_in = t.shape[0], math.prod(t.shape[1:])
@@ -186,3 +191,49 @@ class DiT3D(nn.Module):
                 self._handle = C.c_void_p()
         except Exception:
             pass
+
+
+class DifferenceDiT3D(DiT3D):
+    """The bash/k600 backbone: ``difference_dit3d`` with variant ``factorized_matrix_attention`` (per-frame spatial DiT blocks
+    alternating with frame-token MatrixDiT blocks), ``pos_emb_type: sinusoidal_2d``, ``merge_type: interleaved``
+    (algorithms/dfot/backbones/dit/difference_dit3d.py:12-226; dit_base.py:155-226; dit_blocks.py:211-350,549-652).
+    Like the reference class it doubles ``max_tokens``: ``forward`` takes the 2T interleaved (difference, frame) tokens."""
+
+    def _configure(self, c: "capi.DiTConfig", cfg, max_tokens: int) -> None:
+        if _get(cfg, "variant") != "factorized_matrix_attention":
+            raise ValueError(f"unsupported DifferenceDiT3D variant {_get(cfg, 'variant')!r}: only 'factorized_matrix_attention'")
+        if _get(cfg, "pos_emb_type") != "sinusoidal_2d":
+            raise ValueError("only pos_emb_type='sinusoidal_2d' is supported")
+        if _get(cfg, "merge_type", "interleaved") != "interleaved":
+            raise ValueError("only merge_type='interleaved' is supported")
+        if _get(cfg, "matrix_block", "matrix") != "matrix" or _get(cfg, "matrix_multi_token", False) or _get(cfg, "fixed_u", None):
+            raise ValueError("only matrix_block='matrix' with learned factors and multi_token=False is supported")
+        ratio, tratio = _get(cfg, "spatial_mlp_ratio", None), _get(cfg, "mlp_ratio", None)
+        if ratio is None:
+            raise AssertionError("spatial_mlp_ratio must be specified for matrix attention")
+        c.hidden_size = int(_get(cfg, "embed_row_dim"))
+        c.max_tokens = 2 * max_tokens  # doubling max_tokens for difference encoding
+        c.mlp_hidden = int(c.hidden_size * ratio) if ratio else 0
+        c.variant = 1
+        c.embed_col_dim = int(_get(cfg, "embed_col_dim"))
+        c.num_col_heads = int(_get(cfg, "num_col_heads"))
+        c.num_row_heads = int(_get(cfg, "num_row_heads"))
+        c.temporal_mlp_hidden = int(c.hidden_size * tratio) if tratio else 0
+        c.use_bias = int(bool(_get(cfg, "use_bias")))
+
+    def init_random(self, seed: int = 0) -> None:
+        """As DiT3D.init_random; the matrix factors are (in, out) matrices (fan-in = rows), their biases ~ N(0, 0.05^2)."""
+        g = torch.Generator().manual_seed(seed)
+        with torch.no_grad():
+            for name, t in self._tensors().items():
+                leaf = name.rsplit(".", 1)[-1]
+                if leaf in ("bias", "qkv_bias", "proj_bias"):
+                    v = 0.05 * torch.randn(t.shape, generator=g)
+                elif leaf in ("qkv_u", "proj_u", "qkv_v", "proj_v"):
+                    v = torch.randn(t.shape, generator=g) / math.sqrt(t.shape[0])
+                elif name.startswith("diff_embedder"):
+                    v = 0.3 * torch.randn(t.shape, generator=g)
+                else:
+                    gain = 0.5 if ".modulation." in name else 1.0
+                    v = gain * torch.randn(t.shape, generator=g) / math.sqrt(math.prod(t.shape[1:]))
+                t.copy_(v.to(t.device))

@@ -125,6 +125,18 @@ typedef struct {
   int32_t timesteps;     /* number of discrete noise levels, 1000 */
   float rope_theta;      /* 10000 */
   float eps;             /* 1e-6 (LayerNorm) */
+  /* variant 0: DiT3D "full" + rope_3d (fields below ignored).
+   * variant 1: DifferenceDiT3D "factorized_matrix_attention" + sinusoidal_2d, merge_type "interleaved" (the bash/k600 model,
+   *   configurations/algorithm/backbone/difference_dit3d_factorized_matrix.yaml + shortcut/FacMatDiT/group_XL/XL-64-1.yaml):
+   *   per depth one per-frame spatial DiTBlock (num_heads heads, MLP mlp_hidden) and one MatrixDiTBlock whose attention
+   *   treats every frame as ONE token (a P x hidden matrix projected by left/right factors, dit_blocks.py:211-350);
+   *   max_tokens counts the merged (difference, frame) tokens = 2 x the algorithm's max_tokens; hidden_size = embed_row_dim */
+  int32_t variant;
+  int32_t embed_col_dim;        /* 64 */
+  int32_t num_col_heads;        /* 1 */
+  int32_t num_row_heads;        /* 16 */
+  int32_t temporal_mlp_hidden;  /* int(hidden * mlp_ratio) of the matrix blocks, 4608 */
+  int32_t use_bias;             /* qkv_bias / proj_bias of MatrixAttention present */
 } dfot_dit_config;
 
 int dfot_dit_create(const dfot_dit_config* cfg, dfot_dit_t* out);
@@ -143,7 +155,8 @@ size_t dfot_dit_workspace_bytes(dfot_dit_t h);
 int dfot_dit_set_option(dfot_dit_t h, const char* key, int value);
 int dfot_dit_attn_timing(dfot_dit_t h, double* total_ms, int64_t* launches);
 /* out[B,T,C,H,W] = model(x[B,T,C,H,W], noise_levels[B,T]) ; x/out fp32, noise_levels int32 in [0, timesteps)
- * (device pointer; out-of-range levels are clamped), T <= max_tokens with T*(H/p)*(W/p) % 128 == 0. */
+ * (device pointer; out-of-range levels are clamped), T <= max_tokens with T*(H/p)*(W/p) % 128 == 0.
+ * variant 1: x holds the interleaved (difference_0, frame_0, difference_1, ...) tokens, T even, (H/p)*(W/p) % 128 == 0. */
 int dfot_dit_forward(dfot_dit_t h, const float* x, const int32_t* noise_levels, float* out, int batch, int tokens,
                      void* stream);
 /* parity taps after the last forward: "emb" [timesteps][hidden] (noise-level embedding of every level),

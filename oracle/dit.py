@@ -180,3 +180,196 @@ def forward(p: Params, cfg: DiTConfig, x: torch.Tensor, noise_levels: torch.Tens
     out = F.linear(tok, p["dit_base.final_layer.linear.weight"], p["dit_base.final_layer.linear.bias"])
     out = out.reshape(b * t, gh, gw, ps, ps, ch).permute(0, 1, 3, 2, 4, 5).reshape(b * t, gh * ps, gw * ps, ch)
     return out.permute(0, 3, 1, 2).reshape(b, t, ch, hh, ww)
+
+
+# ============================================================================================================
+# DifferenceDiT3D, variant "factorized_matrix_attention" (the bash/k600 model)
+#   * DifferenceDiT3D.forward / create_diff_index        -- dit/difference_dit3d.py:159-226
+#   * DiTBase factorized-matrix wiring, sinusoidal_2d     -- dit/dit_base.py:155-226, 247-251, 352-419
+#   * MatrixAttention / matrix_mul                        -- dit/dit_blocks.py:211-350
+#   * MatrixDiTBlock                                      -- dit/dit_blocks.py:549-652
+#   * SinusoidalPositionalEmbedding / get_nd_sincos_pos_embed -- dit/dit_base.py:505-572
+#   (diffusers==0.32.2 LabelEmbedding with dropout 0: a plain nn.Embedding(2, hidden) named embedding_table;
+#    timm==1.0.17 Mlp: fc1 -> GELU(tanh) -> fc2)
+# ============================================================================================================
+@dataclass
+class DiffDiTConfig:
+    hidden_size: int = 1152        # embed_row_dim (FacMatDiT/group_XL/XL-64-1.yaml)
+    depth: int = 28
+    num_heads: int = 12            # spatial heads (difference_dit3d_factorized_matrix.yaml)
+    patch_size: int = 1
+    in_channels: int = 16
+    resolution: Tuple[int, int] = (16, 16)
+    max_tokens: int = 5            # the backbone sees 2 * max_tokens merged (difference, frame) tokens
+    embed_col_dim: int = 64
+    num_col_heads: int = 1
+    num_row_heads: int = 16
+    mlp_ratio: float = 4.0         # temporal (matrix) blocks
+    spatial_mlp_ratio: float = 4.0
+    use_bias: bool = True
+    noise_dim: int = 256
+    eps: float = 1e-6
+
+    @property
+    def grid(self) -> Tuple[int, int]:
+        return self.resolution[0] // self.patch_size, self.resolution[1] // self.patch_size
+
+    @property
+    def num_patches(self) -> int:
+        return self.grid[0] * self.grid[1]
+
+    @property
+    def out_channels(self) -> int:
+        return self.patch_size ** 2 * self.in_channels
+
+
+def diff_param_shapes(cfg: DiffDiTConfig) -> Dict[str, tuple]:
+    h, nd, p, pn, e = cfg.hidden_size, cfg.noise_dim, cfg.patch_size, cfg.num_patches, cfg.embed_col_dim
+    s: Dict[str, tuple] = {
+        "noise_level_pos_embedding.embedding.linear_1.weight": (h, nd),
+        "noise_level_pos_embedding.embedding.linear_1.bias": (h,),
+        "noise_level_pos_embedding.embedding.linear_2.weight": (h, h),
+        "noise_level_pos_embedding.embedding.linear_2.bias": (h,),
+        "patch_embedder.proj.weight": (h, cfg.in_channels, p, p),
+        "patch_embedder.proj.bias": (h,),
+        "diff_embedder.embedding_table.weight": (2, h),
+    }
+
+    def mlp(pre: str, ratio: float):
+        hid = int(h * ratio)
+        s[f"{pre}.norm2.modulation.1.weight"] = (3 * h, h)
+        s[f"{pre}.norm2.modulation.1.bias"] = (3 * h,)
+        s[f"{pre}.mlp.fc1.weight"] = (hid, h)
+        s[f"{pre}.mlp.fc1.bias"] = (hid,)
+        s[f"{pre}.mlp.fc2.weight"] = (h, hid)
+        s[f"{pre}.mlp.fc2.bias"] = (h,)
+
+    for i in range(cfg.depth):
+        pre = f"dit_base.blocks.{i}"
+        s[f"{pre}.norm1.modulation.1.weight"] = (3 * h, h)
+        s[f"{pre}.norm1.modulation.1.bias"] = (3 * h,)
+        s[f"{pre}.attn.qkv.weight"] = (3 * h, h)
+        s[f"{pre}.attn.qkv.bias"] = (3 * h,)
+        s[f"{pre}.attn.proj.weight"] = (h, h)
+        s[f"{pre}.attn.proj.bias"] = (h,)
+        if cfg.spatial_mlp_ratio:
+            mlp(pre, cfg.spatial_mlp_ratio)
+    for i in range(cfg.depth):
+        pre = f"dit_base.temporal_blocks.{i}"
+        s[f"{pre}.norm1.modulation.1.weight"] = (3 * h, h)
+        s[f"{pre}.norm1.modulation.1.bias"] = (3 * h,)
+        s[f"{pre}.attn.qkv_u"] = (pn, e)
+        s[f"{pre}.attn.proj_u"] = (e, pn)
+        s[f"{pre}.attn.qkv_v"] = (h, 3 * h)
+        s[f"{pre}.attn.proj_v"] = (h, h)
+        if cfg.use_bias:
+            s[f"{pre}.attn.qkv_bias"] = (e, 3 * h)
+            s[f"{pre}.attn.proj_bias"] = (pn, h)
+        if cfg.mlp_ratio:
+            mlp(pre, cfg.mlp_ratio)
+    s["dit_base.final_layer.norm_final.modulation.1.weight"] = (2 * h, h)
+    s["dit_base.final_layer.norm_final.modulation.1.bias"] = (2 * h,)
+    s["dit_base.final_layer.linear.weight"] = (cfg.out_channels, h)
+    s["dit_base.final_layer.linear.bias"] = (cfg.out_channels,)
+    return s
+
+
+def diff_seeded_params(cfg: DiffDiTConfig, seed: int = 0) -> Params:
+    """Non-degenerate weights (see seeded_params).  The matrix factors are (in, out) matrices: fan-in = shape[0]."""
+    g = torch.Generator().manual_seed(seed)
+    out: Params = {}
+    for name, shape in diff_param_shapes(cfg).items():
+        leaf = name.rsplit(".", 1)[-1]
+        if leaf in ("bias", "qkv_bias", "proj_bias"):
+            out[name] = 0.05 * torch.randn(shape, generator=g)
+        elif leaf in ("qkv_u", "proj_u", "qkv_v", "proj_v"):
+            out[name] = torch.randn(shape, generator=g) / math.sqrt(shape[0])
+        elif name.startswith("diff_embedder"):
+            out[name] = 0.3 * torch.randn(shape, generator=g)
+        else:
+            fan_in = 1
+            for d in shape[1:]:
+                fan_in *= d
+            gain = 0.5 if ".modulation." in name else 1.0
+            out[name] = gain * torch.randn(shape, generator=g) / math.sqrt(fan_in)
+    return out
+
+
+def sincos_2d(embed_dim: int, grid: Tuple[int, int]) -> torch.Tensor:
+    """get_nd_sincos_pos_embed for a 2-D grid: np.meshgrid's default 'xy' indexing makes flattened entry m use
+    position m % grid[0] for the first half of the channels and m // grid[0] for the second ([sin | cos] each)."""
+    import numpy as np
+    half = embed_dim // 2
+    omega = 1.0 / 10000 ** (np.arange(half // 2, dtype=np.float64) / (half / 2.0))
+    m = np.arange(grid[0] * grid[1])
+    parts = []
+    for pos in (m % grid[0], m // grid[0]):
+        ang = np.einsum("m,d->md", pos.astype(np.float32), omega)
+        parts.append(np.concatenate([np.sin(ang), np.cos(ang)], axis=1))
+    return torch.from_numpy(np.concatenate(parts, axis=1)).float()
+
+
+def _mlp_branch(p: Params, pre: str, x: torch.Tensor, c: torch.Tensor, eps: float) -> torch.Tensor:
+    m, gate = _ada_ln(p, f"{pre}.norm2", x, c, 3, eps)
+    hid = F.gelu(F.linear(m, p[f"{pre}.mlp.fc1.weight"], p[f"{pre}.mlp.fc1.bias"]), approximate="tanh")
+    return m + gate * F.linear(hid, p[f"{pre}.mlp.fc2.weight"], p[f"{pre}.mlp.fc2.bias"])
+
+
+def spatial_block(p: Params, pre: str, x: torch.Tensor, c: torch.Tensor, cfg: DiffDiTConfig) -> torch.Tensor:
+    """DiTBlock on (B*T, P, C): attention inside one frame, no RoPE (sinusoidal_2d was added once)."""
+    m, gate = _ada_ln(p, f"{pre}.norm1", x, c, 3, cfg.eps)
+    b, n, ch = m.shape
+    d = ch // cfg.num_heads
+    qkv = F.linear(m, p[f"{pre}.attn.qkv.weight"], p[f"{pre}.attn.qkv.bias"]).reshape(b, n, 3, cfg.num_heads, d).permute(2, 0, 3, 1, 4)
+    w = torch.softmax(qkv[0] @ qkv[1].transpose(-2, -1) / math.sqrt(d), dim=-1)
+    o = (w @ qkv[2]).transpose(1, 2).reshape(b, n, ch)
+    x = m + gate * F.linear(o, p[f"{pre}.attn.proj.weight"], p[f"{pre}.attn.proj.bias"])
+    return _mlp_branch(p, pre, x, c, cfg.eps) if cfg.spatial_mlp_ratio else x
+
+
+def matrix_attention(p: Params, pre: str, x: torch.Tensor, cfg: DiffDiTConfig) -> torch.Tensor:
+    """x (B, L, P, C): every frame is ONE token, a P x C matrix projected by left/right factors (dit_blocks.py:211-350)."""
+    b, l, _, _ = x.shape
+    cc, rr = cfg.num_col_heads, cfg.num_row_heads
+    hn, hd = cfg.embed_col_dim // cc, cfg.hidden_size // rr
+    qkv = torch.einsum("nm,blnd,dk->blmk", p[f"{pre}.qkv_u"], x, p[f"{pre}.qkv_v"])
+    if cfg.use_bias:
+        qkv = qkv + p[f"{pre}.qkv_bias"]
+    qkv = qkv.reshape(b, l, cc, hn, 3, rr, hd).permute(4, 0, 2, 5, 1, 3, 6)  # k b c r l n d
+    q, k, v = qkv[0] * (hn * hd) ** -0.5, qkv[1], qkv[2]
+    w = torch.softmax(torch.einsum("bcrlnd,bcrknd->bcrlk", q, k), dim=-1)
+    o = torch.einsum("bcrlk,bcrknd->bcrlnd", w, v).permute(0, 3, 1, 4, 2, 5).reshape(b, l, cc * hn, rr * hd)
+    o = torch.einsum("nm,blnd,dk->blmk", p[f"{pre}.proj_u"], o, p[f"{pre}.proj_v"])
+    return o + p[f"{pre}.proj_bias"] if cfg.use_bias else o
+
+
+def temporal_block(p: Params, pre: str, x: torch.Tensor, c: torch.Tensor, frames: int, cfg: DiffDiTConfig) -> torch.Tensor:
+    """MatrixDiTBlock on (B, T*P, C)."""
+    m, gate = _ada_ln(p, f"{pre}.norm1", x, c, 3, cfg.eps)
+    b, n, ch = m.shape
+    a = matrix_attention(p, f"{pre}.attn", m.reshape(b, frames, n // frames, ch), cfg).reshape(b, n, ch)
+    x = m + gate * a
+    return _mlp_branch(p, pre, x, c, cfg.eps) if cfg.mlp_ratio else x
+
+
+def diff_forward(p: Params, cfg: DiffDiTConfig, x: torch.Tensor, noise_levels: torch.Tensor,
+                 taps: Optional[Dict[str, torch.Tensor]] = None) -> torch.Tensor:
+    """x [B, 2T, C, H, W] interleaved (difference_0, frame_0, difference_1, ...), noise_levels [B, 2T] -> same shape as x."""
+    b, t, ch, hh, ww = x.shape
+    ps, (gh, gw), h = cfg.patch_size, cfg.grid, cfg.hidden_size
+    pn = gh * gw
+    idx = torch.tensor([1, 0] * (t // 2))  # create_diff_index(diff_first=True), merge_type "interleaved"
+    emb = p["diff_embedder.embedding_table.weight"][idx][None] + noise_level_embedding(p, cfg, noise_levels)  # [B,2T,h]
+    tok = F.conv2d(x.reshape(b * t, ch, hh, ww), p["patch_embedder.proj.weight"], p["patch_embedder.proj.bias"], stride=ps)
+    tok = tok.flatten(2).transpose(1, 2) + sincos_2d(h, (gh, gw))[None]  # (B*T, P, h)
+    c = emb.reshape(b * t, 1, h).expand(b * t, pn, h)
+    for i in range(cfg.depth):
+        tok = spatial_block(p, f"dit_base.blocks.{i}", tok, c, cfg)
+        tok = temporal_block(p, f"dit_base.temporal_blocks.{i}", tok.reshape(b, t * pn, h), c.reshape(b, t * pn, h), t, cfg)
+        tok = tok.reshape(b * t, pn, h)
+        if taps is not None:
+            taps[f"block{i}"] = tok.reshape(b, t * pn, h)
+    tok = _ada_ln(p, "dit_base.final_layer.norm_final", tok, c, 2, cfg.eps)
+    out = F.linear(tok, p["dit_base.final_layer.linear.weight"], p["dit_base.final_layer.linear.bias"])
+    out = out.reshape(b * t, gh, gw, ps, ps, ch).permute(0, 1, 3, 2, 4, 5).reshape(b * t, gh * ps, gw * ps, ch)
+    return out.permute(0, 3, 1, 2).reshape(b, t, ch, hh, ww)

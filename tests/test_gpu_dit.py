@@ -227,3 +227,58 @@ def test_sampler_k600_full_size_vs_oracle():
     out = dfot_amd.DFoTVideoSampler(cfg, model, nfn)._predict_videos(xs.cuda(), n_context_tokens=2, conditions=None).cpu()
     assert not nfn.queue
     assert psnr(out, ref) >= 35.0
+
+
+# ---- DifferenceDiT3D, factorized matrix attention (the bash/k600 backbone) ----------------------------------------
+def build_diff(ocfg, seed):
+    import dfot_amd
+    from oracle import dit as odit
+    params = odit.diff_seeded_params(ocfg, seed)
+    cfg = dict(name="difference_dit3d", variant="factorized_matrix_attention", pos_emb_type="sinusoidal_2d", merge_type="interleaved",
+               patch_size=ocfg.patch_size, hidden_size=None, embed_col_dim=ocfg.embed_col_dim, embed_row_dim=ocfg.hidden_size,
+               num_heads=ocfg.num_heads, num_col_heads=ocfg.num_col_heads, num_row_heads=ocfg.num_row_heads, depth=ocfg.depth,
+               mlp_ratio=ocfg.mlp_ratio or None, spatial_mlp_ratio=ocfg.spatial_mlp_ratio, use_bias=ocfg.use_bias, matrix_block="matrix",
+               flatten_matrix_rope=False, matrix_multi_token=False)
+    model = dfot_amd.DifferenceDiT3D(cfg, x_shape=(ocfg.in_channels, *ocfg.resolution), max_tokens=ocfg.max_tokens).cuda()
+    assert list(model.state_dict().keys()) == list(params.keys())
+    model.load_state_dict(params, strict=True)
+    return params, model
+
+
+def test_diffdit_vs_reference_fixture():
+    from oracle import dit as odit
+    g = load("diffdit.npz")
+    x, k = T(g["x"]).cuda(), T(g["k"]).cuda()
+    c1 = odit.DiffDiTConfig(hidden_size=128, depth=2, num_heads=4, in_channels=4, resolution=(16, 8), embed_col_dim=64, num_row_heads=4)
+    p1, m1 = build_diff(c1, 0)
+    assert digest(p1) == str(g["digest"])
+    with torch.no_grad():
+        out = m1(x, k).cpu()
+        out6 = m1(x[:, :6].contiguous(), k[:, :6].contiguous()).cpu()
+    assert rel(out, T(g["out"])) < 2e-2
+    assert rel(out6, T(g["out_t6"])) < 2e-2
+    c2 = odit.DiffDiTConfig(hidden_size=128, depth=1, num_heads=2, in_channels=4, resolution=(16, 8), embed_col_dim=64,
+                            num_col_heads=2, num_row_heads=2, use_bias=False, mlp_ratio=0.0)
+    p2, m2 = build_diff(c2, 1)
+    assert digest(p2) == str(g["digest2"])
+    with torch.no_grad():
+        out2 = m2(x, k).cpu()
+    assert rel(out2, T(g["out2"])) < 2e-2
+
+
+def test_diffdit_k600_width_vs_reference_fixture():
+    from oracle import dit as odit
+    g = load("diffdit.npz")
+    cw = odit.DiffDiTConfig(depth=3)
+    pw, mw = build_diff(cw, 2)
+    assert digest(pw) == str(g["digestw"])
+    with torch.no_grad():
+        out = mw(T(g["xw"]).cuda(), T(g["kw"]).cuda()).cpu()
+    assert rel(out, T(g["outw"])) < 2e-2
+    with pytest.raises(dfot_amd_error()):  # odd token count: the model takes (difference, frame) pairs
+        mw(torch.zeros(1, 3, 16, 16, 16, device="cuda"), torch.zeros(1, 3, dtype=torch.long, device="cuda"))
+
+
+def dfot_amd_error():
+    import dfot_amd
+    return dfot_amd.capi.DfotError

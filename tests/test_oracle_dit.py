@@ -94,3 +94,30 @@ def test_discrete_cosine_tables_and_sampler():
     out = osm.Sampler(cfg, diff, None, nfn).predict_videos(T(g["xs"]), 2, None)
     assert not nfn.queue
     np.testing.assert_allclose(out.numpy(), g["out"], rtol=1e-3, atol=2e-3)
+
+
+# ---- DifferenceDiT3D, factorized matrix attention (the bash/k600 backbone) ----------------------------------------
+DIFF_TINY = odit.DiffDiTConfig(hidden_size=128, depth=2, num_heads=4, in_channels=4, resolution=(16, 8), embed_col_dim=64, num_row_heads=4)
+DIFF_TINY2 = odit.DiffDiTConfig(hidden_size=128, depth=1, num_heads=2, in_channels=4, resolution=(16, 8), embed_col_dim=64,
+                                num_col_heads=2, num_row_heads=2, use_bias=False, mlp_ratio=0.0)
+DIFF_WIDE = odit.DiffDiTConfig(depth=3)
+
+
+def test_diffdit_param_inventory_k600():
+    n = sum(int(np.prod(s)) for s in odit.diff_param_shapes(odit.DiffDiTConfig()).values())
+    assert abs(n - 1358.2e6) < 0.1e6  # 1358.2 M parameters (probe of the reference module)
+
+
+def test_diffdit_forward_vs_reference_fixture():
+    g = load("diffdit.npz")
+    x, k = T(g["x"]), T(g["k"])
+    p1 = odit.diff_seeded_params(DIFF_TINY, 0)
+    assert digest(p1) == str(g["digest"])
+    np.testing.assert_allclose(odit.diff_forward(p1, DIFF_TINY, x, k).numpy(), g["out"], rtol=1e-4, atol=3e-5)
+    np.testing.assert_allclose(odit.diff_forward(p1, DIFF_TINY, x[:, :6], k[:, :6]).numpy(), g["out_t6"], rtol=1e-4, atol=3e-5)
+    p2 = odit.diff_seeded_params(DIFF_TINY2, 1)
+    assert digest(p2) == str(g["digest2"])
+    np.testing.assert_allclose(odit.diff_forward(p2, DIFF_TINY2, x, k).numpy(), g["out2"], rtol=1e-4, atol=3e-5)
+    p3 = odit.diff_seeded_params(DIFF_WIDE, 2)
+    assert digest(p3) == str(g["digestw"])
+    np.testing.assert_allclose(odit.diff_forward(p3, DIFF_WIDE, T(g["xw"]), T(g["kw"])).numpy(), g["outw"], rtol=1e-3, atol=1e-3)

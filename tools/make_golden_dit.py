@@ -9,6 +9,9 @@ loaded strictly into the reference module and re-created bit-identically by the 
                     T=5 and a shorter T=3 window; a second model (hidden 192, 6 heads) with patch 2 on 32x16 and
                     spatial_mlp_ratio 4 (MLP branch)
   dit_k600.npz      DiT3D.forward at the K600 size: DiT/XL (hidden 1152, depth 28, 16 heads), latents 16x16x16, T=5
+  diffdit.npz       DifferenceDiT3D.forward (factorized_matrix_attention, sinusoidal_2d, interleaved): a tiny model (hidden 128,
+                    depth 2, E 64, 1x4 matrix heads), a tiny model with 2 column heads and no biases / no temporal MLP, and the
+                    bash/k600 width (hidden 1152, 12 spatial heads, E 64, 1x16 matrix heads, MLP ratios 4) at depth 3
   sampler_k600.npz  DFoTVideo._predict_videos with DiscreteDiffusion (cosine, pred_v, integer levels): 5 tokens,
                     context 2, 4 DDIM steps, vanilla history guidance 2.0 (small DiT) with the injected noise
 """
@@ -44,6 +47,29 @@ def ref_dit(R, ocfg: odit.DiTConfig, seed: int):
     assert list(m.state_dict().keys()) == list(params.keys()), "oracle parameter inventory differs from the reference"
     m.load_state_dict(params, strict=True)
     return m, params
+
+
+def ref_diffdit(R, ocfg: "odit.DiffDiTConfig", seed: int):
+    import importlib
+    A = R["AttrDict"]
+    dd = importlib.import_module("algorithms.dfot.backbones.dit.difference_dit3d")
+    cfg = A(dict(name="difference_dit3d", variant="factorized_matrix_attention", pos_emb_type="sinusoidal_2d", merge_type="interleaved",
+                 patch_size=ocfg.patch_size, hidden_size=None, embed_col_dim=ocfg.embed_col_dim, embed_row_dim=ocfg.hidden_size,
+                 num_heads=ocfg.num_heads, num_col_heads=ocfg.num_col_heads, num_row_heads=ocfg.num_row_heads, depth=ocfg.depth,
+                 mlp_ratio=ocfg.mlp_ratio or None, spatial_mlp_ratio=ocfg.spatial_mlp_ratio, use_bias=ocfg.use_bias, matrix_block="matrix",
+                 flatten_matrix_rope=False, matrix_multi_token=False, use_gradient_checkpointing=False))
+    m = dd.DifferenceDiT3D(cfg, x_shape=[ocfg.in_channels, *ocfg.resolution], max_tokens=ocfg.max_tokens, external_cond_type="action",
+                           external_cond_num_classes=None, external_cond_dim=0, use_causal_mask=False).eval()
+    params = odit.diff_seeded_params(ocfg, seed)
+    assert list(m.state_dict().keys()) == list(params.keys()), "oracle parameter inventory differs from the reference"
+    m.load_state_dict(params, strict=True)
+    return m, params
+
+
+DIFF_TINY = dict(hidden_size=128, depth=2, num_heads=4, in_channels=4, resolution=(16, 8), embed_col_dim=64, num_row_heads=4)
+DIFF_TINY2 = dict(hidden_size=128, depth=1, num_heads=2, in_channels=4, resolution=(16, 8), embed_col_dim=64, num_col_heads=2,
+                  num_row_heads=2, use_bias=False, mlp_ratio=0.0)
+DIFF_WIDE = dict(depth=3)
 
 
 def video_cfg(A, ocfg: odit.DiTConfig, sampling_steps: int, hg: dict):
@@ -115,6 +141,20 @@ def main():
         extra[f"block{i}_rows"] = o[0, [0, 255, 700, 1279], :64]
     save("dit_k600.npz", x=x, k=k, out=out, digest=np.array(weights_digest(p)), **extra)
     del m
+
+    print("difference dit")
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(2, 10, 4, 16, 8, generator=g)
+    k = torch.randint(0, 1000, (2, 10), generator=g)
+    c1, c2, c3 = odit.DiffDiTConfig(**DIFF_TINY), odit.DiffDiTConfig(**DIFF_TINY2), odit.DiffDiTConfig(**DIFF_WIDE)
+    m1, p1 = ref_diffdit(R, c1, 0)
+    m2, p2 = ref_diffdit(R, c2, 1)
+    m3, p3 = ref_diffdit(R, c3, 2)
+    xw = torch.randn(1, 10, 16, 16, 16, generator=g)
+    kw = torch.tensor([[0, 0, 17, 17, 500, 500, 871, 871, 999, 999]])
+    save("diffdit.npz", x=x, k=k, out=m1(x, k), out_t6=m1(x[:, :6], k[:, :6]), digest=np.array(weights_digest(p1)),
+         out2=m2(x, k), digest2=np.array(weights_digest(p2)), xw=xw, kw=kw, outw=m3(xw, kw), digestw=np.array(weights_digest(p3)))
+    del m1, m2, m3
 
     print("sampler k600")
     small = odit.DiTConfig(hidden_size=128, depth=2, num_heads=4, patch_size=1, in_channels=4, resolution=(16, 8), max_tokens=5)
