@@ -69,17 +69,28 @@ def bench_k600(args, rank, world, dist):
     README model @DiT/XL (dit3d full, rope_3d; attention-only blocks in this fork), DiscreteDiffusion cosine / pred_v,
     50 DDIM steps, history guidance 'conditional' (dfot_video.yaml default), `--batch` videos per GPU."""
     import dfot_amd
-    from dfot_amd import DFoTVideoSampler, DiffusionConfig, DiT3D, SamplerConfig
-    xl = dict(name="dit3d", variant="full", pos_emb_type="rope_3d", patch_size=1, hidden_size=1152, depth=28, num_heads=16)
-    model = DiT3D(xl, x_shape=(16, 16, 16), max_tokens=5).cuda()
+    from dfot_amd import DFoTVideoSampler, DifferenceDFoTVideoSampler, DifferenceDiT3D, DiffusionConfig, DiT3D, SamplerConfig
+    diff = args.workload == "k600diff"  # the bash/k600 model: DifferenceDiT3D factorized matrix attention, XL-64-1, 1358 M parameters
+    if diff:
+        xl = dict(name="difference_dit3d", variant="factorized_matrix_attention", pos_emb_type="sinusoidal_2d", merge_type="interleaved",
+                  patch_size=1, hidden_size=None, embed_col_dim=64, embed_row_dim=1152, num_heads=12, num_col_heads=1, num_row_heads=16,
+                  depth=28, mlp_ratio=4.0, spatial_mlp_ratio=4.0, use_bias=True, matrix_block="matrix")
+        model = DifferenceDiT3D(xl, x_shape=(16, 16, 16), max_tokens=5).cuda()
+    else:
+        xl = dict(name="dit3d", variant="full", pos_emb_type="rope_3d", patch_size=1, hidden_size=1152, depth=28, num_heads=16)
+        model = DiT3D(xl, x_shape=(16, 16, 16), max_tokens=5).cuda()
     model.init_random(seed=0)
-    cfg = SamplerConfig(x_shape=(16, 16, 16), max_tokens=5,
+    cfg = SamplerConfig(x_shape=(16, 16, 16), max_tokens=10 if diff else 5,
                         diffusion=DiffusionConfig(sampling_timesteps=args.sampling_steps, beta_schedule="cosine", is_continuous=False),
                         prediction_guidance=dict(name="conditional"))
     gen = torch.Generator(device="cuda").manual_seed(1234 + rank)
-    sampler = DFoTVideoSampler(cfg, model, dfot_amd.device_noise_fn(gen))
+    sampler = (DifferenceDFoTVideoSampler if diff else DFoTVideoSampler)(cfg, model, dfot_amd.device_noise_fn(gen))
     b = args.batch
     xs = torch.randn(b, 5, 16, 16, 16, generator=torch.Generator().manual_seed(rank)).cuda()
+    if diff:
+        run = lambda: sampler._sample_all_videos(xs, n_context_tokens=2)["prediction"]
+    else:
+        run = lambda: sampler._predict_videos(xs, n_context_tokens=2, conditions=None)
 
     def barrier():
         if dist is not None:
@@ -87,14 +98,14 @@ def bench_k600(args, rank, world, dist):
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        sampler._predict_videos(xs, n_context_tokens=2, conditions=None)
+        run()
     sampler.use_graph = args.graph
     model.set_option("time_attn", 0 if args.graph or rank else args.sampling_steps * 28 * args.steps)
     sampler.window_forwards = 0
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        out = sampler._predict_videos(xs, n_context_tokens=2, conditions=None)
+        out = run()
     barrier()
     dt = time.perf_counter() - t0
     assert torch.isfinite(out).all()
@@ -108,39 +119,53 @@ def bench_k600(args, rank, world, dist):
         attn_ms, attn_n = model.attn_timing()
         n, d, heads = 1280, 72, 16
         flop_per_launch = 4.0 * n * n * d * heads * b
-        achieved = flop_per_launch * attn_n / (attn_ms * 1e-3) / 1e12 if attn_n else None
         # model FLOPs per video-forward: 28 x (qkv 2*N*h*3h + proj 2*N*h*h + attention 4*N^2*d*heads)
         video_flop = 28 * (2.0 * n * 1152 * 3456 + 2.0 * n * 1152 * 1152 + 4.0 * n * n * d * heads)
+        if diff:
+            # 10 merged tokens x 256 patches; per depth: spatial block (qkv, per-frame attention 12 heads x 96, proj, MLP 4x) +
+            # matrix block (left/right factors E=64, frame-token attention, MLP 4x)
+            n, h, e = 2560, 1152, 64
+            lin = lambda rows, k, nn: 2.0 * rows * k * nn
+            spatial = lin(n, h, 3 * h) + lin(n, h, h) + 4.0 * 256 * 256 * 96 * 12 * 10 + 2 * lin(n, h, 4 * h)
+            matrix = (lin(10 * h, 256, e) + lin(10 * e, h, 3 * h) + 4.0 * 10 * 10 * e * h + lin(10 * h, e, 256) + lin(n, h, h)
+                      + 2 * lin(n, h, 4 * h))
+            video_flop = 28 * (spatial + matrix)
+            flop_per_launch = 4.0 * 256 * 256 * 96 * 12 * 10 * b  # per-frame spatial attention, 80 x 12 (frame, head) units
+        achieved = flop_per_launch * attn_n / (attn_ms * 1e-3) / 1e12 if attn_n else None
         line = {
-            "metric": "denoised latent frames/sec, DFoT K600 (DiT/XL) 17-frame prediction", "value": tokens_per_step * args.steps * world / dt,
+            "metric": "denoised latent frames/sec, DFoT K600 (%s) 17-frame prediction" % ("DifferenceDiT3D FacMat XL-64-1" if diff else "DiT/XL"), "value": tokens_per_step * args.steps * world / dt,
             "unit": "latent frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
             "data": "synthetic latents, seeded random-init weights",
-            "config": {"workload": f"DFoT K600 @DiT/XL: {b} videos per GPU, latents 16x16x16, 5 tokens (17 frames), context 2 tokens, "
+            "config": {"workload": f"DFoT K600 {'bash/k600 difference_dit3d factorized_matrix_attention XL-64-1 (1358 M params)' if diff else '@DiT/XL'}: {b} videos per GPU, latents 16x16x16, 5 tokens (17 frames), context 2 tokens, "
                                    f"{args.sampling_steps} DDIM steps, conditional history guidance (NFE 1)",
                        "window_forwards_per_step": fwd // args.steps, "frames_per_step": tokens_per_step,
                        "pixel_frames_per_step": 12 * b},
             "video_forward_ms": dt / fwd * 1e3, "model_tflops": video_flop * fwd / dt / 1e12,
-            "roofline": {"bound": "mfma", "kernel": "attn_kernel_v2<128,2,80,96> (DiT attention, N=1280, head dim 72 in 128-wide rows)",
+            "roofline": {"bound": "mfma", "kernel": ("attn_kernel_v2<128,2,96,96> (per-frame spatial attention, N=256, head dim 96 in 128-wide rows)" if diff else
+                                                      "attn_kernel_v2<128,2,80,96> (DiT attention, N=1280, head dim 72 in 128-wide rows)"),
                          "achieved": achieved, "peak": 2500.0, "unit": "TFLOP/s", "frac": achieved / 2500.0 if achieved else None,
                          "traffic": None, "launches": attn_n, "avg_launch_ms": attn_ms / max(attn_n, 1), "flop_per_launch": flop_per_launch},
         }
         if not args.no_cpu_baseline and world == 1:
             from oracle import dit as odit
-            ocfg = odit.DiTConfig()
-            params = odit.seeded_params(ocfg, 0)
             cores = min(16, os.cpu_count() or 1)
             torch.set_num_threads(cores)
-            x1 = torch.randn(1, 5, 16, 16, 16)
-            k1 = torch.randint(0, 1000, (1, 5))
+            if diff:
+                ocfg = odit.DiffDiTConfig()
+                params = odit.diff_seeded_params(ocfg, 0)
+                x1, k1, reps, fwd_fn = torch.randn(1, 10, 16, 16, 16), torch.randint(0, 1000, (1, 10)), 1, odit.diff_forward
+            else:
+                ocfg = odit.DiTConfig()
+                params = odit.seeded_params(ocfg, 0)
+                x1, k1, reps, fwd_fn = torch.randn(1, 5, 16, 16, 16), torch.randint(0, 1000, (1, 5)), 3, odit.forward
             t1 = time.perf_counter()
-            reps = 3
             with torch.no_grad():
                 for _ in range(reps):
-                    odit.forward(params, ocfg, x1, k1)
+                    fwd_fn(params, ocfg, x1, k1)
             per = (time.perf_counter() - t1) / reps
             line["cpu_baseline"] = {"value": 3.0 / (args.sampling_steps * per), "unit": "latent frames/s", "cores": cores, "kind": "port",
-                                    "sample": f"{reps} single-video forwards of the oracle DiT/XL (1x5x16x16x16), {per:.2f} s each; scaled to "
+                                    "sample": f"{reps} single-video forward(s) of the oracle {'DifferenceDiT3D' if diff else 'DiT/XL'} ({tuple(x1.shape)}), {per:.2f} s each; scaled to "
                                               f"{args.sampling_steps} forwards per 3 generated latent frames"}
         print(json.dumps(line), flush=True)
     if dist is not None:
@@ -158,7 +183,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", action="store_true", help="replay one hipGraph-captured DDIM step (no in-run attention timing)")
     ap.add_argument("--batch", type=int, default=8, help="k600: videos per GPU (bash/k600 validation.batch_size)")
-    ap.add_argument("--workload", choices=["8f", "200f", "k600"], default="8f",
+    ap.add_argument("--workload", choices=["8f", "200f", "k600", "k600diff"], default="8f",
                     help="8f: BASELINE config 2 (default, the metric's single-GPU configuration); 200f: config 3, the "
                          "200-frame rollout (keyframe density 0.0625, stabilized HG 4.0/0.02 + interpolation HG 1.5, batches of "
                          "4 windows), interpolation windows sharded over ranks")
@@ -176,7 +201,7 @@ def main():
     import dfot_amd
     from dfot_amd import DFoTVideoPoseSampler, DiffusionConfig, SamplerConfig, UViT3DPose
 
-    if args.workload == "k600":
+    if args.workload in ("k600", "k600diff"):
         return bench_k600(args, rank, world, dist if world > 1 else None)
     res = args.res
     model = UViT3DPose(RE10K, x_shape=(3, res, res), max_tokens=8).cuda()

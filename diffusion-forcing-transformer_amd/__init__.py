@@ -7,6 +7,7 @@ from .backbone import UViT3DPose  # noqa: F401
 from .dit_backbone import DiT3D, DifferenceDiT3D  # noqa: F401
 from .diffusion import DiffusionConfig, Schedule  # noqa: F401
 from .guidance import HistoryGuidance  # noqa: F401
-from .sampler import DFoTVideoPoseSampler, DFoTVideoSampler, SamplerConfig, device_noise_fn  # noqa: F401
+from .sampler import (DFoTVideoPoseSampler, DFoTVideoSampler, DifferenceDFoTVideoSampler, SamplerConfig,  # noqa: F401
+                      device_noise_fn)  # noqa: F401
 from . import parallel  # noqa: F401,E402
 from .checkpoint import load_reference_checkpoint  # noqa: F401,E402

@@ -462,3 +462,34 @@ class DFoTVideoSampler(DFoTVideoPoseSampler):
         if conditions is not None:
             raise ValueError("DFoTVideoSampler takes no external conditions; use DFoTVideoPoseSampler for camera poses")
         return None
+
+
+class DifferenceDFoTVideoSampler(DFoTVideoSampler):
+    """The bash/k600 algorithm (algorithms/dfot/difference_dfot_video.py: DifferenceDFoTVideo): every frame travels with its
+    temporal difference as a second token, interleaved (difference_t, frame_t); the sampler itself is the DFoTVideo path run
+    on the 2T merged tokens (its `_sample_sequence` / `_predict_sequence` / `_predict_videos` differ from the base class
+    only by `max_tokens * 2`, difference_dfot_video.py:214-278,463-607,609-846).  Construct it with
+    ``SamplerConfig(max_tokens=2 * T)`` and a ``DifferenceDiT3D`` backbone built with ``max_tokens=T``."""
+
+    @staticmethod
+    def merge_tensors(x: Optional[torch.Tensor], y: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+        """merge_type 'interleaved' (difference_dfot_video.py:45-61): (x_0, y_0, x_1, y_1, ...) along the token axis."""
+        if x is None or y is None:
+            return None
+        assert x.shape == y.shape, "Tensors must have the same shape to be merged."
+        return torch.stack([x, y], dim=2).reshape(x.shape[0], 2 * x.shape[1], *x.shape[2:])
+
+    @staticmethod
+    def unmerge_tensors(x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        """inverse of merge_tensors (difference_dfot_video.py:63-75)."""
+        return x[:, 0::2], x[:, 1::2]
+
+    @torch.no_grad()
+    def _sample_all_videos(self, xs: torch.Tensor, n_context_tokens: int) -> Dict[str, torch.Tensor]:
+        """difference_dfot_video.py:166-212 without the logging/VAE tail: frames -> (difference, frame) tokens -> prediction
+        on the merged sequence with doubled context -> {"prediction", "prediction_diff"}."""
+        difference = torch.diff(xs, dim=1, prepend=xs[:, :1])
+        merged = self.merge_tensors(difference, xs)
+        out = self._predict_videos(merged, n_context_tokens=2 * n_context_tokens, conditions=None)
+        gen_diff, gen = self.unmerge_tensors(out)
+        return {"gt": xs.clone(), "prediction": gen, "prediction_diff": gen_diff}

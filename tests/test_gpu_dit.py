@@ -282,3 +282,25 @@ def test_diffdit_k600_width_vs_reference_fixture():
 def dfot_amd_error():
     import dfot_amd
     return dfot_amd.capi.DfotError
+
+
+def test_difference_sampler_vs_reference_fixture():
+    import dfot_amd
+    from oracle import dit as odit
+    g = load("sampler_k600_diff.npz")
+    oc = odit.DiffDiTConfig(hidden_size=128, depth=2, num_heads=4, in_channels=4, resolution=(16, 8), embed_col_dim=64, num_row_heads=4)
+    params, model = build_diff(oc, 3)
+    assert digest(params) == str(g["digest"])
+    nfn = ReplayList([T(g[f"noise{i}"]) for i in range(int(g["n_noise"]))])
+    cfg = dfot_amd.SamplerConfig(x_shape=(4, 16, 8), max_tokens=10,
+                                 diffusion=dfot_amd.DiffusionConfig(sampling_timesteps=3, beta_schedule="cosine", is_continuous=False),
+                                 prediction_guidance=dict(name="vanilla", guidance_scale=1.5))
+    sampler = dfot_amd.DifferenceDFoTVideoSampler(cfg, model, nfn)
+    xs = T(g["xs"]).cuda()
+    merged = sampler.merge_tensors(torch.diff(xs, dim=1, prepend=xs[:, :1]), xs)
+    assert torch.equal(merged.cpu(), T(g["merged"]))
+    vids = sampler._sample_all_videos(xs, n_context_tokens=2)
+    assert not nfn.queue
+    assert torch.equal(vids["prediction"][:, :2].cpu(), T(g["gen"])[:, :2])
+    assert psnr(vids["prediction"].cpu(), T(g["gen"])) >= 35.0
+    assert psnr(vids["prediction_diff"].cpu(), T(g["gen_diff"])) >= 35.0

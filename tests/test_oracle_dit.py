@@ -121,3 +121,25 @@ def test_diffdit_forward_vs_reference_fixture():
     p3 = odit.diff_seeded_params(DIFF_WIDE, 2)
     assert digest(p3) == str(g["digestw"])
     np.testing.assert_allclose(odit.diff_forward(p3, DIFF_WIDE, T(g["xw"]), T(g["kw"])).numpy(), g["outw"], rtol=1e-3, atol=1e-3)
+
+
+def test_difference_sampler_vs_reference_fixture():
+    """DifferenceDFoTVideo = the DFoTVideo sampling path on the 2T interleaved (difference, frame) tokens."""
+    g = load("sampler_k600_diff.npz")
+    p = odit.diff_seeded_params(DIFF_TINY, 3)
+    assert digest(p) == str(g["digest"])
+    xs = T(g["xs"])
+    diff = torch.diff(xs, dim=1, prepend=xs[:, :1])
+    merged = torch.stack([diff, xs], dim=2).reshape(2, 10, 4, 16, 8)
+    assert torch.equal(merged, T(g["merged"]))
+    model = lambda x, k, c, m: odit.diff_forward(p, DIFF_TINY, x, k)
+    noise = [T(g[f"noise{i}"]) for i in range(int(g["n_noise"]))]
+    nfn = osm.replay_noise_fn(noise)
+    cfg = osm.SamplerConfig(x_shape=(4, 16, 8), max_tokens=10, sampling_timesteps=3,
+                            prediction_guidance=dict(name="vanilla", guidance_scale=1.5))
+    diffusion = osm.Diffusion(sch.build_tables(beta_schedule="cosine"), model, sampling_timesteps=3, is_continuous=False)
+    out = osm.Sampler(cfg, diffusion, None, nfn).predict_videos(merged, 4, None)
+    assert not nfn.queue
+    np.testing.assert_allclose(out.numpy(), g["out"], rtol=1e-3, atol=2e-3)
+    np.testing.assert_allclose(out[:, 1::2].numpy(), g["gen"], rtol=1e-3, atol=2e-3)
+    np.testing.assert_allclose(out[:, 0::2].numpy(), g["gen_diff"], rtol=1e-3, atol=2e-3)

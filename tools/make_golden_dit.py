@@ -12,6 +12,8 @@ loaded strictly into the reference module and re-created bit-identically by the 
   diffdit.npz       DifferenceDiT3D.forward (factorized_matrix_attention, sinusoidal_2d, interleaved): a tiny model (hidden 128,
                     depth 2, E 64, 1x4 matrix heads), a tiny model with 2 column heads and no biases / no temporal MLP, and the
                     bash/k600 width (hidden 1152, 12 spatial heads, E 64, 1x16 matrix heads, MLP ratios 4) at depth 3
+  sampler_k600_diff.npz  DifferenceDFoTVideo: torch.diff + merge_tensors -> _predict_videos on the 10 merged tokens (context 2 frames =
+                    4 merged tokens, 3 DDIM steps, vanilla history guidance 1.5, tiny difference model) -> unmerge_tensors
   sampler_k600.npz  DFoTVideo._predict_videos with DiscreteDiffusion (cosine, pred_v, integer levels): 5 tokens,
                     context 2, 4 DDIM steps, vanilla history guidance 2.0 (small DiT) with the injected noise
 """
@@ -107,6 +109,33 @@ def video_cfg(A, ocfg: odit.DiTConfig, sampling_steps: int, hg: dict):
 
 
 @torch.no_grad()
+def diff_sampler_fixture(R):
+    print("sampler k600 difference")
+    A = R["AttrDict"]
+    oc = odit.DiffDiTConfig(**DIFF_TINY)
+    base = odit.DiTConfig(hidden_size=128, depth=2, num_heads=4, patch_size=1, in_channels=4, resolution=(16, 8), max_tokens=5)
+    cfg = video_cfg(A, base, sampling_steps=3, hg=dict(name="vanilla", guidance_scale=1.5))
+    cfg["backbone"] = A(dict(name="difference_dit3d", variant="factorized_matrix_attention", pos_emb_type="sinusoidal_2d",
+                             merge_type="interleaved", patch_size=1, hidden_size=None, embed_col_dim=oc.embed_col_dim,
+                             embed_row_dim=oc.hidden_size, num_heads=oc.num_heads, num_col_heads=1, num_row_heads=oc.num_row_heads,
+                             depth=oc.depth, mlp_ratio=4.0, spatial_mlp_ratio=4.0, use_bias=True, matrix_block="matrix",
+                             flatten_matrix_rope=False, matrix_multi_token=False, use_gradient_checkpointing=False))
+    algo = R["DifferenceDFoTVideo"](cfg).eval()
+    ps = odit.diff_seeded_params(oc, 3)
+    algo.diffusion_model.model.load_state_dict(ps, strict=True)
+    g = torch.Generator().manual_seed(9)
+    vid = torch.randn(2, 5, 4, 16, 8, generator=g)
+    merged = algo.merge_tensors(torch.diff(vid, dim=1, prepend=vid[:, :1]), vid)
+    algo.generator = torch.Generator().manual_seed(0)
+    with RandnRecorder() as rec:
+        out = algo._predict_videos(merged.clone(), n_context_tokens=4, conditions=None)
+    gen_diff, gen = algo.unmerge_tensors(out)
+    arrays = {f"noise{i}": d for i, d in enumerate(rec.draws)}
+    save("sampler_k600_diff.npz", xs=vid, merged=merged, out=out, gen=gen, gen_diff=gen_diff, n_noise=np.array(len(rec.draws)),
+         digest=np.array(weights_digest(ps)), **arrays)
+
+
+@torch.no_grad()
 def main():
     R = ref_loader.install()
     A = R["AttrDict"]
@@ -172,6 +201,7 @@ def main():
     save("sampler_k600.npz", xs=vid, out=out, n_noise=np.array(len(rec.draws)), digest=np.array(weights_digest(ps)),
          alphas_cumprod=dm.alphas_cumprod, sqrt_alphas_cumprod=dm.sqrt_alphas_cumprod,
          sqrt_one_minus_alphas_cumprod=dm.sqrt_one_minus_alphas_cumprod, **arrays)
+    diff_sampler_fixture(R)
     print("done")
 
 

@@ -230,6 +230,8 @@ def install():
     bb.UViT3D, bb.UViT3DPose = uvit.UViT3D, uvit_pose.UViT3DPose
     dit3d = imp("algorithms.dfot.backbones.dit.dit3d")  # K600 backbone (only the "full" variant is exercised)
     bb.DiT3D = dit3d.DiT3D
+    diffdit = imp("algorithms.dfot.backbones.dit.difference_dit3d")  # bash/k600 backbone (factorized matrix attention)
+    bb.DifferenceDiT3D = diffdit.DifferenceDiT3D
     dd = imp("algorithms.dfot.diffusion.discrete_diffusion")
     cd = imp("algorithms.dfot.diffusion.continuous_diffusion")
     dpk = sys.modules["algorithms.dfot.diffusion"]
@@ -237,10 +239,12 @@ def install():
     hgm = imp("algorithms.dfot.history_guidance")
     pose_algo = imp("algorithms.dfot.dfot_video_pose")
     video_algo = sys.modules["algorithms.dfot.dfot_video"]
+    diff_algo = imp("algorithms.dfot.difference_dfot_video")
     geo = imp("utils.geometry_utils")
     return {
         "UViT3DPose": uvit_pose.UViT3DPose, "blocks": blocks, "DiscreteDiffusion": dd.DiscreteDiffusion,
         "ContinuousDiffusion": cd.ContinuousDiffusion, "HistoryGuidance": hgm.HistoryGuidance,
         "DFoTVideoPose": pose_algo.DFoTVideoPose, "DFoTVideo": video_algo.DFoTVideo, "DiT3D": dit3d.DiT3D,
+        "DifferenceDiT3D": diffdit.DifferenceDiT3D, "DifferenceDFoTVideo": diff_algo.DifferenceDFoTVideo,
         "geometry": geo, "AttrDict": AttrDict,
     }
