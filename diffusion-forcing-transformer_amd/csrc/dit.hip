@@ -126,27 +126,64 @@ __global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16* __restr
 // MatrixAttention core (dit_blocks.py:289-336, multi_token = False, no RoPE): every frame is one token whose q/k/v are
 // (hn x hd) matrices; z [B*L*E][3h] holds (q|k|v) with columns (row head r, d) and rows (frame, col head c, n).
 // One workgroup per (video, c, r): scores L x L = scale * <q_l, k_l'> over the hn*hd entries, softmax over l', o = P v.
-// o [B*L*E][h] in the same row/column order.  L <= 32.
+// o [B*L*E][h] in the same row/column order.
+// LT > 0: L == LT is a compile-time constant and every thread keeps the L x L partial scores of its slice of the hn*hd
+// entries in registers (each q/k/v entry is read exactly once); LT == 0: generic L <= 32 (one pair of tokens per wave pass).
+template <int LT>
 __global__ __launch_bounds__(256) void matrix_attn_kernel(const bf16* __restrict__ z, bf16* __restrict__ o, int L, int E, int h,
                                                           int cc, int rr, float scale) {
   __shared__ float sc[32 * 32];
+  __shared__ float part[4][LT > 0 ? LT * LT : 1];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int b = blockIdx.x / (cc * rr), c = (blockIdx.x / rr) % cc, r = blockIdx.x % rr;
   const int hn = E / cc, hd = h / rr, ne = hn * hd / 4;
   const long ldz = 3L * h;
   auto zrow = [&](int l, int n) { return z + (((long)b * L + l) * E + c * hn + n) * ldz + r * hd; };
-  for (int pi = wave; pi < L * L; pi += 4) {
-    const int l = pi / L, l2 = pi % L;
-    float acc = 0.f;
-    for (int e = lane; e < ne; e += 64) {
-      const int n = (e * 4) / hd, d = (e * 4) % hd;
-      const bf16x4 q4 = *reinterpret_cast<const bf16x4*>(zrow(l, n) + d);
-      const bf16x4 k4 = *reinterpret_cast<const bf16x4*>(zrow(l2, n) + h + d);
+  if constexpr (LT > 0) {
+    float acc[LT * LT];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc += bf2f(q4[j]) * bf2f(k4[j]);
+    for (int i = 0; i < LT * LT; ++i) acc[i] = 0.f;
+    for (int e = threadIdx.x; e < ne; e += 256) {
+      const int n = (e * 4) / hd, d = (e * 4) % hd;
+      float q[LT][4], k[LT][4];
+#pragma unroll
+      for (int l = 0; l < LT; ++l) {
+        const bf16* p = zrow(l, n) + d;
+        const bf16x4 q4 = *reinterpret_cast<const bf16x4*>(p);
+        const bf16x4 k4 = *reinterpret_cast<const bf16x4*>(p + h);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          q[l][j] = bf2f(q4[j]);
+          k[l][j] = bf2f(k4[j]);
+        }
+      }
+#pragma unroll
+      for (int l = 0; l < LT; ++l)
+#pragma unroll
+        for (int l2 = 0; l2 < LT; ++l2)
+          acc[l * LT + l2] += (q[l][0] * k[l2][0] + q[l][1] * k[l2][1]) + (q[l][2] * k[l2][2] + q[l][3] * k[l2][3]);
     }
-    acc = wave_sum(acc);
-    if (lane == 0) sc[pi] = acc * scale;
+#pragma unroll
+    for (int i = 0; i < LT * LT; ++i) {
+      const float t = wave_sum(acc[i]);
+      if (lane == 0) part[wave][i] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x < LT * LT) sc[threadIdx.x] = (part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]) * scale;
+  } else {
+    for (int pi = wave; pi < L * L; pi += 4) {
+      const int l = pi / L, l2 = pi % L;
+      float acc = 0.f;
+      for (int e = lane; e < ne; e += 64) {
+        const int n = (e * 4) / hd, d = (e * 4) % hd;
+        const bf16x4 q4 = *reinterpret_cast<const bf16x4*>(zrow(l, n) + d);
+        const bf16x4 k4 = *reinterpret_cast<const bf16x4*>(zrow(l2, n) + h + d);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc += bf2f(q4[j]) * bf2f(k4[j]);
+      }
+      acc = wave_sum(acc);
+      if (lane == 0) sc[pi] = acc * scale;
+    }
   }
   __syncthreads();
   if (threadIdx.x < L) {
@@ -164,20 +201,59 @@ __global__ __launch_bounds__(256) void matrix_attn_kernel(const bf16* __restrict
   __syncthreads();
   for (int e = threadIdx.x; e < ne; e += 256) {
     const int n = (e * 4) / hd, d = (e * 4) % hd;
-    for (int l = 0; l < L; ++l) {
-      float a[4] = {0.f, 0.f, 0.f, 0.f};
-      for (int l2 = 0; l2 < L; ++l2) {
+    if constexpr (LT > 0) {
+      float v[LT][4];
+#pragma unroll
+      for (int l2 = 0; l2 < LT; ++l2) {
         const bf16x4 v4 = *reinterpret_cast<const bf16x4*>(zrow(l2, n) + 2 * h + d);
-        const float pw = sc[l * L + l2];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) a[j] += pw * bf2f(v4[j]);
+        for (int j = 0; j < 4; ++j) v[l2][j] = bf2f(v4[j]);
       }
-      bf16x4 o4;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) o4[j] = f2bf(a[j]);
-      *reinterpret_cast<bf16x4*>(o + (((long)b * L + l) * E + c * hn + n) * h + r * hd + d) = o4;
+      for (int l = 0; l < LT; ++l) {
+        float a[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int l2 = 0; l2 < LT; ++l2) {
+          const float pw = sc[l * LT + l2];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) a[j] += pw * v[l2][j];
+        }
+        bf16x4 o4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o4[j] = f2bf(a[j]);
+        *reinterpret_cast<bf16x4*>(o + (((long)b * LT + l) * E + c * hn + n) * h + r * hd + d) = o4;
+      }
+    } else {
+      for (int l = 0; l < L; ++l) {
+        float a[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int l2 = 0; l2 < L; ++l2) {
+          const bf16x4 v4 = *reinterpret_cast<const bf16x4*>(zrow(l2, n) + 2 * h + d);
+          const float pw = sc[l * L + l2];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) a[j] += pw * bf2f(v4[j]);
+        }
+        bf16x4 o4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o4[j] = f2bf(a[j]);
+        *reinterpret_cast<bf16x4*>(o + (((long)b * L + l) * E + c * hn + n) * h + r * hd + d) = o4;
+      }
     }
   }
+}
+
+int launch_matrix_attn(const bf16* z, bf16* o, int batch, int L, int E, int h, int cc, int rr, float scale, hipStream_t s) {
+  DFOT_REQUIRE(L > 0 && L <= 32, DFOT_ERR_SHAPE, "matrix attention: %d frame tokens (max 32)", L);
+  const dim3 grid(batch * cc * rr), blk(256);
+  switch (L) {
+    case 2: hipLaunchKernelGGL(matrix_attn_kernel<2>, grid, blk, 0, s, z, o, L, E, h, cc, rr, scale); break;
+    case 4: hipLaunchKernelGGL(matrix_attn_kernel<4>, grid, blk, 0, s, z, o, L, E, h, cc, rr, scale); break;
+    case 6: hipLaunchKernelGGL(matrix_attn_kernel<6>, grid, blk, 0, s, z, o, L, E, h, cc, rr, scale); break;
+    case 8: hipLaunchKernelGGL(matrix_attn_kernel<8>, grid, blk, 0, s, z, o, L, E, h, cc, rr, scale); break;
+    case 10: hipLaunchKernelGGL(matrix_attn_kernel<10>, grid, blk, 0, s, z, o, L, E, h, cc, rr, scale); break;
+    default: hipLaunchKernelGGL(matrix_attn_kernel<0>, grid, blk, 0, s, z, o, L, E, h, cc, rr, scale); break;
+  }
+  DFOT_CHECK_HIP(hipGetLastError());
+  return DFOT_OK;
 }
 
 // ---- forward kernels --------------------------------------------------------------------------------------------
@@ -922,9 +998,9 @@ int dfot_dit_forward(dfot_dit_t h, const float* x, const int32_t* noise_levels, 
     }
     {
       const int hn = E / c.num_col_heads, hdr = hd / c.num_row_heads;
-      hipLaunchKernelGGL(matrix_attn_kernel, dim3(batch * c.num_col_heads * c.num_row_heads), dim3(256), 0, s, h->Z, h->W1, tokens, E, hd,
-                         c.num_col_heads, c.num_row_heads, 1.0f / sqrtf((float)hn * (float)hdr));
-      DFOT_CHECK_HIP(hipGetLastError());
+      if ((rc = launch_matrix_attn(h->Z, h->W1, batch, tokens, E, hd, c.num_col_heads, c.num_row_heads,
+                                   1.0f / sqrtf((float)hn * (float)hdr), s)))
+        return rc;
     }
     if ((rc = transpose(h->W1, h->W2, E, hd))) return rc;  // o^T per frame: [hd][E]
     {

@@ -62,12 +62,18 @@ def main():
         for name, (m, n, k) in {"L2 qkv+mlp": (16384, 4032, 576), "L2 out": (16384, 576, 2880), "L3 qkv+mlp": (4096, 8064, 1152),
                                 "L3 out": (4096, 1152, 5760), "film L0": (131072, 256, 1024), "pose": (131072, 1024, 768),
                                 "square 4096": (4096, 4096, 4096), "DiT qkv B8": (10240, 3456, 1152), "DiT proj B8": (10240, 1152, 1152),
-                                "DiT qkv B2": (2560, 3456, 1152), "DiT proj B2": (2560, 1152, 1152)}.items():
+                                "DiT qkv B2": (2560, 3456, 1152), "DiT proj B2": (2560, 1152, 1152),
+                                "MLP fc1 B8": (20480, 4608, 1152), "MLP fc2 B8": (20480, 1152, 4608)}.items():
             if os.environ.get("ONLY") and os.environ["ONLY"] not in name:
                 continue
             for v in variants:
                 ms, tf = gemm(m, n, k, v)
                 print(f"gemm {name:12s} M={m:6d} N={n:5d} K={k:5d} variant={v}: {ms*1e3:8.1f} us  {tf:7.1f} TF/s", flush=True)
+            if os.environ.get("HIPBLASLT"):  # vendor library on the same shape, for orientation only (never on the product path)
+                a = torch.randn(m, k, device="cuda").bfloat16()
+                w = torch.randn(n, k, device="cuda").bfloat16()
+                ms = timeit(lambda: torch.nn.functional.linear(a, w))
+                print(f"gemm {name:12s} M={m:6d} N={n:5d} K={k:5d} torch/hipBLASLt: {ms*1e3:8.1f} us  {2.0*m*n*k/ms/1e9:7.1f} TF/s", flush=True)
     if "conv" in what:
         for name, (bt, h, w, ci, co) in {"L0 res": (16, 128, 128, 128, 128), "L1 res": (16, 64, 64, 256, 256),
                                          "down0": (16, 64, 64, 128, 256), "down1": (16, 32, 32, 256, 576),
