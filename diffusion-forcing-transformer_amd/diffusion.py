@@ -84,6 +84,18 @@ class Schedule:
         elif kind == "autoregressive":
             height = s + (horizon - 1) + 1
             idx = np.clip(s + np.arange(horizon)[None, :] - np.arange(height)[:, None], 0, s)
+        elif kind == "interleaved":
+            # _generate_interleaved_scheduling_matrix(horizon, 3, S): row r of token i (start = i % 3 + 1) is S while r < start,
+            # then max(S - start - 3 * ((r - start) // 3), 0)
+            r = np.arange(s + 3)[:, None]
+            start = (np.arange(horizon) % 3 + 1)[None, :]
+            idx = np.where(r < start, s, np.maximum(s - start - 3 * ((r - start) // 3), 0))
+        elif kind == "gibbs":
+            # each DDIM step i >= 1 is spread over `horizon` rows; row (i, j) has tokens 0..j at step i and the rest at i - 1
+            step = np.repeat(np.arange(s + 1), horizon)[:, None]
+            sub = np.tile(np.arange(horizon), s + 1)[:, None]
+            tok = np.arange(horizon)[None, :]
+            idx = s - np.where((tok <= sub) | (step == 0), step, step - 1)
         else:
             raise ValueError(f"unsupported scheduling matrix '{kind}'")
         levels = self.ddim_idx_to_noise_level(idx)

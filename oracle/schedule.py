@@ -92,6 +92,28 @@ def scheduling_matrix(kind: str, horizon: int, padding: int, timesteps: int,
         m = np.arange(rows)[:, None]
         t = np.arange(horizon)[None, :]
         idx = np.clip(s + t - m, 0, s)
+    elif kind == "interleaved":
+        # base_pytorch_video_algo.py:914-936 with interleaved_size 3: token i waits (i % 3) + 1 rows at pure noise, then drops
+        # three DDIM indices every three rows until it reaches 0
+        size = 3
+        cols = []
+        for i in range(horizon):
+            start = i % size + 1
+            col = [s] * start
+            j = 0
+            while len(col) < s + size:
+                level = max(s - start - size * j, 0)
+                col += [level] * (size if level > 0 else s + size - len(col))
+                j += 1
+            cols.append(col[: s + size])
+        idx = np.array(cols).T
+    elif kind == "gibbs":
+        # base_pytorch_video_algo.py:884-905: every DDIM step becomes `horizon` rows that move one more token to the new level
+        base = np.arange(s, -1, -1)
+        idx = np.zeros(((s + 1) * horizon, horizon), dtype=np.int64)
+        for i in range(s + 1):
+            for j in range(horizon):
+                idx[i * horizon + j] = base[i] if i == 0 else np.where(np.arange(horizon) <= j, base[i], base[i - 1])
     else:
         raise ValueError(f"oracle: unsupported scheduling matrix {kind}")
     levels = ddim_levels(timesteps, s)[torch.from_numpy(idx).long()]

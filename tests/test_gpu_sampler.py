@@ -59,7 +59,7 @@ def psnr(a, b):
     return 10 * math.log10(peak * peak / max(mse, 1e-20))
 
 
-def run_pair(pred_hg, n_frames, steps, density=None, interp_hg=None, max_batch=None, seed=5):
+def run_pair(pred_hg, n_frames, steps, density=None, interp_hg=None, max_batch=None, seed=5, scheduling="full_sequence"):
     import dfot_amd
     from oracle import pose as opose, sampler as osm, schedule as sch, uvit as ouvit
     res = 64
@@ -71,7 +71,7 @@ def run_pair(pred_hg, n_frames, steps, density=None, interp_hg=None, max_batch=N
     r1 = Replay(99, "cpu")
     ocfg_s = osm.SamplerConfig(x_shape=(3, res, res), sampling_timesteps=steps, prediction_guidance=pred_hg,
                                interpolation_guidance=interp_hg or {"name": "conditional"}, keyframe_density=density,
-                               interpolation_max_batch_size=max_batch)
+                               interpolation_max_batch_size=max_batch, scheduling_matrix=scheduling)
     diff = osm.Diffusion(sch.build_tables(), lambda x, k, c, m: ouvit.forward(params, ocfg, x, k, c, m),
                          sampling_timesteps=steps)
     osamp = osm.Sampler(ocfg_s, diff, lambda c: opose.ray_encoding(c, res), r1)
@@ -81,7 +81,7 @@ def run_pair(pred_hg, n_frames, steps, density=None, interp_hg=None, max_batch=N
     r2 = Replay(99, "cuda")
     cfg = dfot_amd.SamplerConfig(x_shape=(3, res, res), diffusion=dfot_amd.DiffusionConfig(sampling_timesteps=steps),
                                  prediction_guidance=pred_hg, interpolation_guidance=interp_hg or {"name": "conditional"},
-                                 keyframe_density=density, interpolation_max_batch_size=max_batch)
+                                 keyframe_density=density, interpolation_max_batch_size=max_batch, scheduling_matrix=scheduling)
     samp = dfot_amd.DFoTVideoPoseSampler(cfg, model, r2)
     out = samp._predict_videos(xs, n_context_tokens=1, conditions=cnd).cpu()
     assert r1.log == r2.log, "noise draw order/shapes differ from the oracle"
@@ -216,3 +216,14 @@ def test_denoising_loss_matches_oracle():
     print(f"denoising loss: {loss.item():.6f} vs oracle {loss_ref.mean().item():.6f}; per-token rel err {rel_tok:.3e}; x_pred rel_l2 {rel_x:.3e}")
     assert abs(loss.item() - loss_ref.mean().item()) / loss_ref.mean().item() < 2e-2
     assert rel_tok < 5e-2 and rel_x < 2e-2
+
+
+@pytest.mark.parametrize("scheduling", ["autoregressive", "interleaved", "gibbs"])
+def test_other_scheduling_matrices(scheduling):
+    """Per-token noise levels that differ inside a step (pyramid / interleaved / one-token-at-a-time sweeps): the step tables
+    carry a (from, to) pair per token, tokens whose level does not move are kept (base_pytorch_video_algo.py:876-941)."""
+    out, ref, xs = run_pair(dict(name="vanilla", guidance_scale=2.0), 8, 3, scheduling=scheduling)
+    assert torch.equal(out[:, :1], xs[:, :1].float())
+    p = psnr(out, ref)
+    print(f"{scheduling}: PSNR {p:.1f} dB")
+    assert torch.isfinite(out).all() and p >= 35.0

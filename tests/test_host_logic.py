@@ -87,3 +87,20 @@ def test_ddim_coefficients_reproduce_reference_step():
 def test_temporal_guidance_is_rejected():
     with pytest.raises(NotImplementedError):
         HistoryGuidance([__import__("dfot_amd").guidance.HistorySegment(time_indices=[0])], [1.0])
+
+
+@pytest.mark.parametrize("kind", ["interleaved", "gibbs", "autoregressive"])
+def test_other_scheduling_matrices(kind):
+    g = np.load(os.path.join(GOLDEN, "schedule_extra.npz"))
+    s = Schedule(DiffusionConfig(sampling_timesteps=int(g["sampling_steps"])))
+    for h, p in ((8, 0), (5, 3)):
+        assert np.array_equal(s.scheduling_matrix(kind, h, p), g[f"{kind}_{h}_{p}"])
+
+
+def test_discrete_cosine_schedule_matches_reference_buffers():
+    g = np.load(os.path.join(GOLDEN, "sampler_k600.npz"))
+    s = Schedule(DiffusionConfig(beta_schedule="cosine", is_continuous=False))
+    np.testing.assert_allclose(s.alphas_cumprod, g["alphas_cumprod"], rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(s.sqrt_one_minus_alphas_cumprod, g["sqrt_one_minus_alphas_cumprod"], rtol=1e-6, atol=1e-9)
+    k = np.array([[-1, 0, 17, 999]])
+    assert np.array_equal(s.model_level(k), np.array([[0, 0, 17, 999]], np.float32))  # clamped level index, exact in fp32

@@ -178,3 +178,11 @@ def test_training_loss():
     x_pred, loss = osm.training_loss(model, T(g["x"]), cond, T(g["t"]), T(g["noise"]).clamp(-20, 20))
     np.testing.assert_allclose(x_pred.numpy(), g["x_pred"], rtol=1e-4, atol=1e-4)
     np.testing.assert_allclose(loss.numpy(), g["loss"], rtol=1e-3, atol=1e-5)
+
+
+@pytest.mark.parametrize("kind", ["interleaved", "gibbs", "autoregressive"])
+def test_other_scheduling_matrices(kind):
+    g = load("schedule_extra.npz")
+    s = int(g["sampling_steps"])
+    for h, p in ((8, 0), (5, 3)):
+        assert torch.equal(sch.scheduling_matrix(kind, h, p, 1000, s), T(g[f"{kind}_{h}_{p}"]))

@@ -10,6 +10,7 @@ checksum of the weights is stored with each fixture.
 Fixtures
   schedule.npz        DiscreteDiffusion buffers for RE10K (cosine_simple_diffusion, shifted 0.125),
                       ddim level table, scheduling matrices
+  schedule_extra.npz  interleaved / gibbs / autoregressive scheduling matrices (7 sampling steps)
   ray_encoding.npz    DFoTVideoPose._process_conditions at resolution 8 and sampled rows at 256
   backbone_w64.npz    UViT3DPose.forward, RE10K widths [128,256,576,1152], resolution 64, Bm=2
   backbone_tiny.npz   UViT3DPose.forward, tiny widths, resolution 16
@@ -190,6 +191,16 @@ def main():
          sqrt_one_minus_alphas_cumprod=dm.sqrt_one_minus_alphas_cumprod, logsnr=dm.logsnr,
          ddim_levels=dm.ddim_idx_to_noise_level(torch.arange(51)), sched_8_0=sm_full, sched_5_3=sm_pad,
          train_t=torch.linspace(0, 1, 33), train_logsnr=dm.training_schedule(torch.linspace(0, 1, 33)))
+
+    # other scheduling matrices of the reference (base_pytorch_video_algo.py:876-941), 7 sampling steps
+    extra = {}
+    cfg7 = algo_cfg(A, 16, TINY, sampling_steps=7)
+    algo7, _, _ = build_algo(R, cfg7)
+    for kind in ("interleaved", "gibbs", "autoregressive"):
+        algo7.cfg["scheduling_matrix"] = kind
+        extra[f"{kind}_8_0"] = algo7._generate_scheduling_matrix(8, 0)
+        extra[f"{kind}_5_3"] = algo7._generate_scheduling_matrix(5, 3)
+    save("schedule_extra.npz", sampling_steps=np.array(7), **extra)
 
     # ---------------------------------------------------------------- ray encoding
     print("ray encoding")
