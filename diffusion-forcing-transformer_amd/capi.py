@@ -79,6 +79,7 @@ SIGNATURES = {
     "dfot_ddim_compose": (_I, [_P] * 11 + [_I, _I, _I, _L, _P]),
     "dfot_vpred_loss": (_I, [_P] * 9 + [_I, _I, _L, _P]),
     "dfot_vpred_loss_scratch_floats": (_L, [_I, _I, _L]),
+    "dfot_vspace_loss": (_I, [_P] * 9 + [_I, _I, _L, _P]),
     "dfot_op_gemm": (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _P]),
     "dfot_op_conv3x3": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "dfot_op_attention": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),

@@ -51,7 +51,7 @@ int launch_ddim_compose(const float* x, const float* x_in, const float* v, const
 // v-prediction loss: partial = scratch [bt][vloss_chunks(f)], loss[bt] = mean over the frame of w*(eps_hat-eps)^2
 int vloss_chunks(long f);
 int launch_vloss(const float* x, const float* noise, const float* v, const float* a, const float* sg, const float* w,
-                 float* x_pred, float* partial, float* loss, int bt, long f, hipStream_t s);
+                 float* x_pred, float* partial, float* loss, int bt, long f, bool vspace, hipStream_t s);
 // ---- casts / weight packing ----
 int launch_f32_to_bf16(const float* src, bf16* dst, long n, hipStream_t s);
 int launch_bf16_to_f32(const bf16* src, float* dst, long n, hipStream_t s);

@@ -744,7 +744,9 @@ int launch_ddim_compose(const float* x, const float* x_in, const float* v, const
 // used by training_step and by the validation denoising loss): x_t = a x + s eps ; eps_hat = a v + s x_t ;
 // loss = (eps_hat - eps)^2 * w ; x_pred = a x_t - s v.  Deterministic two-stage mean per (video, token).
 // --------------------------------------------------------------------------------------------
+// VSPACE (DiscreteDiffusion.forward with objective pred_v, discrete_diffusion.py:345-377): loss = (v - (a eps - s x))^2 * w.
 constexpr int VL_CHUNK = 4096;
+template <bool VSPACE>
 __global__ __launch_bounds__(256) void vloss_partial_kernel(const float* __restrict__ x, const float* __restrict__ noise,
                                                             const float* __restrict__ v, const float* __restrict__ a,
                                                             const float* __restrict__ sg, const float* __restrict__ w,
@@ -760,8 +762,7 @@ __global__ __launch_bounds__(256) void vloss_partial_kernel(const float* __restr
     const float4v nv = *reinterpret_cast<const float4v*>(noise + base + e);
     const float4v vv = *reinterpret_cast<const float4v*>(v + base + e);
     const float4v xt = xv * av + nv * sv;
-    const float4v eh = vv * av + xt * sv;
-    const float4v d = eh - nv;
+    const float4v d = VSPACE ? vv - (nv * av - xv * sv) : (vv * av + xt * sv) - nv;
     acc += (d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3]) * wv;
     if (x_pred) *reinterpret_cast<float4v*>(x_pred + base + e) = xt * av - vv * sv;
   }
@@ -779,10 +780,13 @@ __global__ void vloss_finalize_kernel(const float* __restrict__ partial, float* 
 }
 int vloss_chunks(long f) { return cdiv(f, VL_CHUNK); }
 int launch_vloss(const float* x, const float* noise, const float* v, const float* a, const float* sg, const float* w,
-                 float* x_pred, float* partial, float* loss, int bt, long f, hipStream_t s) {
+                 float* x_pred, float* partial, float* loss, int bt, long f, bool vspace, hipStream_t s) {
   DFOT_REQUIRE(f % 4 == 0, DFOT_ERR_SHAPE, "vloss: frame elements %ld must be a multiple of 4", f);
   const int chunks = vloss_chunks(f);
-  hipLaunchKernelGGL(vloss_partial_kernel, dim3(chunks, bt), dim3(256), 0, s, x, noise, v, a, sg, w, x_pred, partial, f);
+  if (vspace)
+    hipLaunchKernelGGL(vloss_partial_kernel<true>, dim3(chunks, bt), dim3(256), 0, s, x, noise, v, a, sg, w, x_pred, partial, f);
+  else
+    hipLaunchKernelGGL(vloss_partial_kernel<false>, dim3(chunks, bt), dim3(256), 0, s, x, noise, v, a, sg, w, x_pred, partial, f);
   DFOT_CHECK_HIP(hipGetLastError());
   hipLaunchKernelGGL(vloss_finalize_kernel, dim3(bt), dim3(1), 0, s, partial, loss, chunks, 1.0f / (float)f);
   DFOT_CHECK_HIP(hipGetLastError());

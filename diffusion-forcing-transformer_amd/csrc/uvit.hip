@@ -775,7 +775,14 @@ int dfot_vpred_loss(const float* x, const float* noise, const float* v, const fl
                     const float* weight, float* x_pred, float* scratch, float* loss, int batch, int tokens, int64_t frame_elems,
                     void* stream) {
   DFOT_REQUIRE(x && noise && v && alpha && sigma && weight && scratch && loss, DFOT_ERR_ARG, "vpred_loss: null argument");
-  return launch_vloss(x, noise, v, alpha, sigma, weight, x_pred, scratch, loss, batch * tokens, (long)frame_elems,
+  return launch_vloss(x, noise, v, alpha, sigma, weight, x_pred, scratch, loss, batch * tokens, (long)frame_elems, false,
+                      (hipStream_t)stream);
+}
+int dfot_vspace_loss(const float* x, const float* noise, const float* v, const float* alpha, const float* sigma,
+                     const float* weight, float* x_pred, float* scratch, float* loss, int batch, int tokens, int64_t frame_elems,
+                     void* stream) {
+  DFOT_REQUIRE(x && noise && v && alpha && sigma && weight && scratch && loss, DFOT_ERR_ARG, "vspace_loss: null argument");
+  return launch_vloss(x, noise, v, alpha, sigma, weight, x_pred, scratch, loss, batch * tokens, (long)frame_elems, true,
                       (hipStream_t)stream);
 }
 int64_t dfot_vpred_loss_scratch_floats(int batch, int tokens, int64_t frame_elems) {

@@ -65,6 +65,7 @@ class Schedule:
         self.alphas_cumprod = abar.astype(np.float32)
         self.sqrt_alphas_cumprod = np.sqrt(abar).astype(np.float32)
         self.sqrt_one_minus_alphas_cumprod = np.sqrt(1.0 - abar).astype(np.float32)
+        self.snr = (abar / (1.0 - abar)).astype(np.float32)  # float64 quotient, like the reference's buffer
         with np.errstate(divide="ignore"):  # the plain cosine schedule ends at abar = 0 (zero terminal SNR)
             self.logsnr = np.log(abar / (1.0 - abar)).astype(np.float32)
 
@@ -130,3 +131,40 @@ class Schedule:
         cn = np.sqrt(f32(1) - alpha_next - sigma ** 2).astype(f32)
         return (self.sqrt_alphas_cumprod[kc], self.sqrt_one_minus_alphas_cumprod[kc], np.sqrt(alpha_next).astype(f32),
                 cn, (curr == nxt).astype(f32), sigma)
+
+
+    # ---- training-loss weights of DiscreteDiffusion (compute_loss_weights, discrete_diffusion.py:274-343), objective pred_v ----
+    def loss_weights(self, k: np.ndarray, strategy: str = "fused_min_snr", snr_clip: float = 5.0, cum_snr_decay: float = 0.9,
+                     sigmoid_bias: float = -1.0, causal: bool = False) -> np.ndarray:
+        """k (B,T) integer levels -> (B,T) float32 weights of the v-space squared error."""
+        f32 = np.float32
+        if strategy == "uniform":
+            return np.ones(k.shape, f32)
+        snr_tab = self.snr
+        snr = snr_tab[k]
+        floor = f32(1e-8)
+        if strategy == "sigmoid":
+            with np.errstate(divide="ignore"):
+                eps_w = f32(1) / (f32(1) + np.exp(np.log(snr_tab)[k] - f32(sigmoid_bias)))
+        elif strategy == "min_snr":
+            eps_w = np.minimum(snr_tab, f32(snr_clip))[k] / np.maximum(snr, floor)
+        elif strategy == "fused_min_snr":
+            d = f32(cum_snr_decay)
+            nclip = np.minimum(snr_tab, f32(snr_clip))[k] / f32(snr_clip)
+            nsnr = snr / f32(snr_clip)
+
+            def history(x):  # EMA over the tokens BEFORE each position (zero at the first one)
+                out = np.zeros_like(x)
+                ema = x[:, 0].copy()
+                for t in range(1, x.shape[1]):
+                    out[:, t] = ema
+                    ema = d * ema + (f32(1) - d) * x[:, t]
+                return out
+            cum = history(nclip) if causal else f32(0.5) * (history(nclip[:, ::-1])[:, ::-1] + history(nclip))
+            keep = f32(1) - cum * d
+            clipped = (f32(1) - keep * (f32(1) - nclip)) * f32(snr_clip)
+            snr = (f32(1) - keep * (f32(1) - nsnr)) * f32(snr_clip)
+            eps_w = clipped / np.maximum(snr, floor)
+        else:
+            raise ValueError(f"unknown loss weighting strategy {strategy}")
+        return (eps_w * snr / (snr + f32(1))).astype(f32)

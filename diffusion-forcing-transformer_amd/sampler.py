@@ -125,6 +125,40 @@ class DFoTVideoPoseSampler:
             per_token = per_token * masks.to(device="cuda", dtype=torch.float32).view(b, tk)
         return x_pred, per_token.mean(), per_token
 
+    @torch.no_grad()
+    def discrete_denoising_loss(self, xs: torch.Tensor, k: torch.Tensor, noise: Optional[torch.Tensor] = None,
+                                masks: Optional[torch.Tensor] = None, loss_weighting: Optional[Dict] = None):
+        """``DiscreteDiffusion.forward`` (diffusion/discrete_diffusion.py:345-377, objective pred_v) + ``_reweight_loss``: noise
+        every token to its integer level k (B,T), one backbone forward, weighted v-space squared error (weights:
+        ``Schedule.loss_weights``, default = dfot_video.yaml's fused_min_snr / snr_clip 5 / cum_snr_decay 0.9).  No backward.
+        Returns (x_pred, loss scalar, per-token loss (B,T))."""
+        if self.cfg.diffusion.is_continuous:
+            raise ValueError("discrete_denoising_loss needs DiffusionConfig(is_continuous=False)")
+        b, tk = xs.shape[:2]
+        f = int(np.prod(xs.shape[2:]))
+        kk = k.detach().cpu().numpy().astype(np.int64)
+        sch = self.schedule
+        tab = np.stack([sch.sqrt_alphas_cumprod[kk], sch.sqrt_one_minus_alphas_cumprod[kk],
+                        sch.loss_weights(kk, **(loss_weighting or {}))]).astype(np.float32)
+        tab = torch.from_numpy(tab).cuda().contiguous()
+        x = xs.to(device="cuda", dtype=torch.float32).contiguous()
+        if noise is None:
+            noise = self.noise_fn("train", tuple(x.shape))
+        eps = noise.to(device="cuda", dtype=torch.float32).clamp(-self.cfg.diffusion.clip_noise, self.cfg.diffusion.clip_noise).contiguous()
+        x_k = torch.empty_like(x)
+        capi.check(capi.lib.dfot_hg_prepare(capi.ptr(x), capi.ptr(eps), capi.ptr(tab[0]), capi.ptr(tab[1]), capi.ptr(x_k),
+                                            b, 1, tk, f, capi.stream_ptr()))
+        v = self.model(x_k, k.to(device="cuda", dtype=torch.int32), None, None)
+        x_pred = torch.empty_like(x)
+        per_token = torch.empty(b, tk, device="cuda")
+        scratch = torch.empty(int(capi.lib.dfot_vpred_loss_scratch_floats(b, tk, f)), device="cuda")
+        capi.check(capi.lib.dfot_vspace_loss(capi.ptr(x), capi.ptr(eps), capi.ptr(v), capi.ptr(tab[0]), capi.ptr(tab[1]),
+                                             capi.ptr(tab[2]), capi.ptr(x_pred), capi.ptr(scratch), capi.ptr(per_token), b, tk, f,
+                                             capi.stream_ptr()))
+        if masks is not None:
+            per_token = per_token * masks.to(device="cuda", dtype=torch.float32).view(b, tk)
+        return x_pred, per_token.mean(), per_token
+
     # data (un)normalisation of the reference (algorithms/common/base_pytorch_video_algo.py:491-502)
     def _normalize_x(self, xs: torch.Tensor, mean, std) -> torch.Tensor:
         m = torch.as_tensor(mean, dtype=xs.dtype, device=xs.device).view(-1, 1, 1)

@@ -190,6 +190,12 @@ int dfot_vpred_loss(const float* x, const float* noise, const float* v, const fl
                     const float* weight, float* x_pred, float* scratch, float* loss, int batch, int tokens,
                     int64_t frame_elems, void* stream);
 int64_t dfot_vpred_loss_scratch_floats(int batch, int tokens, int64_t frame_elems);
+/* DiscreteDiffusion.forward, objective pred_v (diffusion/discrete_diffusion.py:345-377): same inputs, but the error is taken
+ * in v-space: loss[b,t] = mean_frame( weight * (v - (alpha*noise - sigma*x))^2 ); alpha/sigma = sqrt(abar_k), sqrt(1-abar_k) of the
+ * token's integer level, weight = compute_loss_weights (min-SNR / fused min-SNR / sigmoid, host-computed, :274-343) */
+int dfot_vspace_loss(const float* x, const float* noise, const float* v, const float* alpha, const float* sigma,
+                     const float* weight, float* x_pred, float* scratch, float* loss, int batch, int tokens,
+                     int64_t frame_elems, void* stream);
 
 /* ---- unit-testable primitives ------------------------------------------------------------------ */
 /* C[M,N] (fp32) = A[M,K] (bf16, row stride lda) * W[N,K]^T (bf16) + bias[N] (fp32 or NULL)

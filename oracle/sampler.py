@@ -292,3 +292,45 @@ def training_loss(model: ModelFn, x: torch.Tensor, cond: Optional[torch.Tensor],
     eps_hat = a * v + s * x_t
     w = _ext(torch.sigmoid(sigmoid_bias - logsnr), x.ndim)
     return a * x_t - s * v, (eps_hat - noise) ** 2 * w
+
+
+def discrete_loss_weights(tables: sch.ScheduleTables, k: torch.Tensor, strategy: str = "fused_min_snr", snr_clip: float = 5.0,
+                          cum_snr_decay: float = 0.96, sigmoid_bias: float = -1.0, causal: bool = False) -> torch.Tensor:
+    """DiscreteDiffusion.compute_loss_weights for objective pred_v (discrete_diffusion.py:274-343); k (B,T) long."""
+    if strategy == "uniform":
+        return torch.ones_like(k, dtype=torch.float32)
+    snr_all = tables.snr  # float64 quotient cast to fp32 (discrete_diffusion.py:160-161)
+    snr = snr_all[k]
+    if strategy == "sigmoid":
+        eps_w = torch.sigmoid(sigmoid_bias - torch.log(snr_all)[k])
+    elif strategy == "min_snr":
+        eps_w = snr_all.clamp(max=snr_clip)[k] / snr.clamp(min=1e-8)
+    elif strategy == "fused_min_snr":
+        nclip = snr_all.clamp(max=snr_clip)[k] / snr_clip
+        nsnr = snr / snr_clip
+
+        def running(x: torch.Tensor) -> torch.Tensor:  # exponential moving average of the PREVIOUS tokens, 0 for the first
+            out = torch.zeros_like(x)
+            acc = torch.zeros_like(x[:, 0])
+            for t in range(x.shape[1]):
+                out[:, t] = acc if t else 0.0
+                acc = x[:, t] if t == 0 else cum_snr_decay * acc + (1 - cum_snr_decay) * x[:, t]
+            return out
+        cum = running(nclip) if causal else 0.5 * (running(nclip) + running(nclip.flip(1)).flip(1))
+        clipped = (1 - (1 - cum * cum_snr_decay) * (1 - nclip)) * snr_clip
+        snr = (1 - (1 - cum * cum_snr_decay) * (1 - nsnr)) * snr_clip
+        eps_w = clipped / snr.clamp(min=1e-8)
+    else:
+        raise ValueError(f"unknown loss weighting strategy {strategy}")
+    return eps_w * snr / (snr + 1)
+
+
+def discrete_training_loss(model: ModelFn, tables: sch.ScheduleTables, x: torch.Tensor, k: torch.Tensor, noise: torch.Tensor,
+                           **weighting):
+    """DiscreteDiffusion.forward, objective pred_v (discrete_diffusion.py:345-377); returns (x_pred, per-element weighted loss)."""
+    a = _ext(tables.sqrt_alphas_cumprod[k], x.ndim)
+    s = _ext(tables.sqrt_one_minus_alphas_cumprod[k], x.ndim)
+    x_k = a * x + s * noise
+    v = model(x_k, k, None, None)
+    w = _ext(discrete_loss_weights(tables, k, **weighting), x.ndim)
+    return a * x_k - s * v, (v - (a * noise - s * x)) ** 2 * w

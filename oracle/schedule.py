@@ -27,6 +27,7 @@ class ScheduleTables:
     sqrt_one_minus_alphas_cumprod: torch.Tensor
     logsnr: torch.Tensor
     timesteps: int
+    snr: torch.Tensor = None  # alphas_cumprod / (1 - alphas_cumprod) formed in float64 like the reference's buffer
 
 
 def _alphas_cumprod_cosine_simple(timesteps: int, logsnr_min: float, logsnr_max: float,
@@ -72,6 +73,7 @@ def build_tables(timesteps: int = 1000, beta_schedule: str = "cosine_simple_diff
         sqrt_alphas_cumprod=torch.sqrt(ac).to(f32),
         sqrt_one_minus_alphas_cumprod=torch.sqrt(1.0 - ac).to(f32),
         logsnr=torch.log(snr).to(f32),
+        snr=snr.to(f32),
         timesteps=timesteps,
     )
 

@@ -304,3 +304,21 @@ def test_difference_sampler_vs_reference_fixture():
     assert torch.equal(vids["prediction"][:, :2].cpu(), T(g["gen"])[:, :2])
     assert psnr(vids["prediction"].cpu(), T(g["gen"])) >= 35.0
     assert psnr(vids["prediction_diff"].cpu(), T(g["gen_diff"])) >= 35.0
+
+
+def test_discrete_denoising_loss_vs_reference_fixture():
+    """DiscreteDiffusion.forward (pred_v, fused min-SNR weights) on the device: per-token means of the weighted v-space error."""
+    import dfot_amd
+    g = load("discrete_loss.npz")
+    _, _, small = tiny_cfgs()
+    params, model = build(small, 2)
+    assert digest(params) == str(g["digest"])
+    cfg = dfot_amd.SamplerConfig(x_shape=(4, 16, 8), max_tokens=5,
+                                 diffusion=dfot_amd.DiffusionConfig(beta_schedule="cosine", is_continuous=False))
+    sampler = dfot_amd.DFoTVideoSampler(cfg, model)
+    x_pred, loss, per_token = sampler.discrete_denoising_loss(T(g["x"]).cuda(), T(g["k"]).cuda(), noise=T(g["noise"]).cuda(),
+                                                              loss_weighting=dict(strategy="fused_min_snr", cum_snr_decay=0.96))
+    ref_tok = T(g["loss"]).flatten(2).mean(-1)
+    assert rel(per_token.cpu(), ref_tok) < 2e-2
+    assert abs(loss.item() - ref_tok.mean().item()) < 2e-2 * ref_tok.mean().item()
+    assert rel(x_pred.cpu(), T(g["x_pred"])) < 2e-2

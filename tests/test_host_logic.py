@@ -104,3 +104,14 @@ def test_discrete_cosine_schedule_matches_reference_buffers():
     np.testing.assert_allclose(s.sqrt_one_minus_alphas_cumprod, g["sqrt_one_minus_alphas_cumprod"], rtol=1e-6, atol=1e-9)
     k = np.array([[-1, 0, 17, 999]])
     assert np.array_equal(s.model_level(k), np.array([[0, 0, 17, 999]], np.float32))  # clamped level index, exact in fp32
+
+
+def test_discrete_loss_weights_match_reference():
+    g = np.load(os.path.join(GOLDEN, "discrete_loss.npz"))
+    s = Schedule(DiffusionConfig(beta_schedule="cosine", is_continuous=False))
+    k = g["k"]
+    # fp32 on both sides with a different operation order: 1 - keep * (1 - snr/clip) cancels for snr -> 0 (abs error ~2e-7)
+    np.testing.assert_allclose(s.loss_weights(k, "fused_min_snr", cum_snr_decay=0.96), g["w_fused_096"], rtol=1e-4, atol=5e-7)
+    np.testing.assert_allclose(s.loss_weights(k, "fused_min_snr", cum_snr_decay=0.9), g["w_fused_090"], rtol=1e-4, atol=5e-7)
+    np.testing.assert_allclose(s.loss_weights(k, "min_snr"), g["w_min_snr"], rtol=1e-4, atol=5e-7)
+    np.testing.assert_allclose(s.loss_weights(k, "uniform"), g["w_uniform"])

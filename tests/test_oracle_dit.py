@@ -143,3 +143,19 @@ def test_difference_sampler_vs_reference_fixture():
     np.testing.assert_allclose(out.numpy(), g["out"], rtol=1e-3, atol=2e-3)
     np.testing.assert_allclose(out[:, 1::2].numpy(), g["gen"], rtol=1e-3, atol=2e-3)
     np.testing.assert_allclose(out[:, 0::2].numpy(), g["gen_diff"], rtol=1e-3, atol=2e-3)
+
+
+def test_discrete_loss_weights_and_loss_vs_reference_fixture():
+    g = load("discrete_loss.npz")
+    tb = sch.build_tables(beta_schedule="cosine")
+    k = T(g["k"])
+    for key, kw in (("w_fused_096", dict(strategy="fused_min_snr", cum_snr_decay=0.96)),
+                    ("w_fused_090", dict(strategy="fused_min_snr", cum_snr_decay=0.9)),
+                    ("w_min_snr", dict(strategy="min_snr")), ("w_uniform", dict(strategy="uniform"))):
+        np.testing.assert_allclose(osm.discrete_loss_weights(tb, k, **kw).numpy(), g[key], rtol=2e-5, atol=1e-9)
+    p = odit.seeded_params(SMALL, 2)
+    assert digest(p) == str(g["digest"])
+    x_pred, loss = osm.discrete_training_loss(lambda x, kk, c, m: odit.forward(p, SMALL, x, kk), tb, T(g["x"]), k, T(g["noise"]),
+                                              strategy="fused_min_snr", cum_snr_decay=0.96)
+    np.testing.assert_allclose(x_pred.numpy(), g["x_pred"], rtol=1e-3, atol=1e-3)
+    np.testing.assert_allclose(loss.numpy(), g["loss"], rtol=1e-3, atol=1e-5)

@@ -14,6 +14,8 @@ loaded strictly into the reference module and re-created bit-identically by the 
                     bash/k600 width (hidden 1152, 12 spatial heads, E 64, 1x16 matrix heads, MLP ratios 4) at depth 3
   sampler_k600_diff.npz  DifferenceDFoTVideo: torch.diff + merge_tensors -> _predict_videos on the 10 merged tokens (context 2 frames =
                     4 merged tokens, 3 DDIM steps, vanilla history guidance 1.5, tiny difference model) -> unmerge_tensors
+  discrete_loss.npz DiscreteDiffusion.forward (pred_v, cosine) on the small DiT with injected noise: x_pred, weighted loss, and
+                    compute_loss_weights for fused_min_snr (decay 0.96 / 0.9), min_snr, sigmoid, uniform
   sampler_k600.npz  DFoTVideo._predict_videos with DiscreteDiffusion (cosine, pred_v, integer levels): 5 tokens,
                     context 2, 4 DDIM steps, vanilla history guidance 2.0 (small DiT) with the injected noise
 """
@@ -202,6 +204,19 @@ def main():
          alphas_cumprod=dm.alphas_cumprod, sqrt_alphas_cumprod=dm.sqrt_alphas_cumprod,
          sqrt_one_minus_alphas_cumprod=dm.sqrt_one_minus_alphas_cumprod, **arrays)
     diff_sampler_fixture(R)
+    print("discrete loss")
+    g = torch.Generator().manual_seed(10)
+    xt = torch.randn(2, 5, 4, 16, 8, generator=g)
+    kt = torch.randint(0, 1000, (2, 5), generator=g)
+    kt[0, 0], kt[1, 4] = 0, 999
+    with RandnRecorder() as rec:
+        x_pred, loss = dm(xt, None, kt)
+    weights = {"w_fused_096": dm.compute_loss_weights(kt, "fused_min_snr")}
+    dm.loss_weighting["cum_snr_decay"] = 0.9
+    weights["w_fused_090"] = dm.compute_loss_weights(kt, "fused_min_snr")
+    weights["w_min_snr"] = dm.compute_loss_weights(kt, "min_snr")
+    weights["w_uniform"] = dm.compute_loss_weights(kt, "uniform").float()
+    save("discrete_loss.npz", x=xt, k=kt, noise=rec.draws[0], x_pred=x_pred, loss=loss, digest=np.array(weights_digest(ps)), **weights)
     print("done")
 
 
