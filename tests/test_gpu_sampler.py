@@ -142,7 +142,17 @@ def test_hipgraph_step_replay_matches_eager():
         samp.use_graph = use_graph
         outs.append(samp._predict_videos(xs, n_context_tokens=1, conditions=cnd).cpu())
         if use_graph:
-            assert samp.graph_replays == 5
+            assert samp.graph_replays == 5 and samp.graph_captures == 1
+            # a second video of the same shape re-uses the captured graph (new poses, new noise, new tables)
+            xs2 = torch.randn(1, 8, 3, res, res, generator=torch.Generator().manual_seed(13))
+            cnd2 = poses(1, 8, 14)
+            samp.noise_fn = parallel.WindowKeyedNoise(7)
+            out2 = samp._predict_videos(xs2, n_context_tokens=1, conditions=cnd2).cpu()
+            assert samp.graph_replays == 10 and samp.graph_captures == 1
+            samp.use_graph = False
+            samp.noise_fn = parallel.WindowKeyedNoise(7)
+            ref2 = samp._predict_videos(xs2, n_context_tokens=1, conditions=cnd2).cpu()
+            assert torch.equal(out2, ref2)
     assert torch.isfinite(outs[0]).all()
     assert torch.equal(outs[0], outs[1])
 
