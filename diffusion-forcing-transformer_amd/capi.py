@@ -90,6 +90,10 @@ SIGNATURES = {
 
 
 def _load() -> C.CDLL:
+    # PyTorch-ROCm ships its own HIP runtime (torch/lib/libamdhip64.so).  It must be in the process BEFORE libdfot_hip.so is
+    # loaded, so that the library's libamdhip64 dependency resolves to the SAME runtime torch uses (one HIP runtime per
+    # process: with two, the second one finds no device and device pointers / streams could not be shared anyway).
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             f"{LIB_PATH} is missing: the HIP extension has not been built. There is no CPU fallback; "
