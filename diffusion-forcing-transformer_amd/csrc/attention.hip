@@ -215,7 +215,8 @@ __global__ __launch_bounds__(256) void attn_kernel_v2(const bf16* __restrict__ Q
   const int lq = lane & 31, lh = lane >> 5;
   // 1-D grid, (batch*head)-major logical order handed out per XCD: the q-tiles of one head share K/V in one L2
   const int qtiles = N / 128;
-  const int lin = xcd_remap(blockIdx.x, gridDim.x, xcd);
+  const int lin = xcd_remap(blockIdx.x, gridDim.x, xcd & 1);
+  const bool prio = (xcd & 2) != 0;  // A/B switch: raise the wave priority around the MFMA clusters
   const int bh = lin / qtiles;
   const long base = (long)bh * N * D;
   const int q0 = (lin % qtiles) * 128 + wave * 32;
@@ -287,6 +288,7 @@ __global__ __launch_bounds__(256) void attn_kernel_v2(const bf16* __restrict__ Q
 
     // ---- S^T - m = K Q^T - m ----
     f32x16 sacc[2];
+    if (prio) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int kt2 = 0; kt2 < 2; ++kt2) {
 #pragma unroll
@@ -298,6 +300,7 @@ __global__ __launch_bounds__(256) void attn_kernel_v2(const bf16* __restrict__ Q
         sacc[kt2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sacc[kt2], 0, 0, 0);
       }
     }
+    if (prio) __builtin_amdgcn_s_setprio(0);
 
     // ---- row max of (s - m) over this lane's 32 keys and the partner half ----
     float mx = fmaxf(fmaxf(sacc[0][0], sacc[0][1]), sacc[0][2]);
@@ -340,6 +343,7 @@ __global__ __launch_bounds__(256) void attn_kernel_v2(const bf16* __restrict__ Q
     l_i += rs;
 
     // ---- O^T += V^T P^T ----
+    if (prio) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int dvt = 0; dvt < DV / 32; ++dvt) {
 #pragma unroll
@@ -359,6 +363,7 @@ __global__ __launch_bounds__(256) void attn_kernel_v2(const bf16* __restrict__ Q
         }
       }
     }
+    if (prio) __builtin_amdgcn_s_setprio(0);
     if constexpr (NST == 3) {
       if (t + 2 < nt) {
         if constexpr (IPW == 2) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
@@ -394,7 +399,7 @@ template <int D, int NST, int DQK = D, int DV = D>
 static int launch_attn_v2(const bf16* q, const bf16* k, const bf16* v, bf16* o, long ldo, int batch, int heads, int n,
                           hipStream_t stream, int ohs = D, int dvalid = D) {
   auto kern = attn_kernel_v2<D, NST, DQK, DV>;
-  static const int xcd_flag = tuning_flag("ATTN_XCD", 1);
+  static const int xcd_flag = tuning_flag("ATTN_XCD", 1) | (tuning_flag("ATTN_PRIO", 1) << 1);
   const int lds = 2 * NST * AttnCfg<D>::TILE;
   static bool attr_set = false;
   if (!attr_set) {
