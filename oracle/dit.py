@@ -117,7 +117,7 @@ def seeded_params(cfg: DiTConfig, seed: int = 0) -> Params:
 def timestep_features(k: torch.Tensor, dim: int) -> torch.Tensor:
     """get_timestep_embedding(flip_sin_to_cos=True, downscale_freq_shift=0): [cos | sin] of k * 10000^(-i/half)."""
     half = dim // 2
-    freqs = torch.exp(-math.log(10000.0) * torch.arange(half, dtype=torch.float32) / half)
+    freqs = torch.exp(-math.log(10000.0) * torch.arange(half, dtype=torch.float32) / half).to(k.device)
     a = k[..., None].float() * freqs
     return torch.cat([a.cos(), a.sin()], dim=-1)
 
@@ -169,7 +169,7 @@ def forward(p: Params, cfg: DiTConfig, x: torch.Tensor, noise_levels: torch.Tens
     tok = tok.flatten(2).transpose(1, 2).reshape(b, t * gh * gw, h)
     emb = noise_level_embedding(p, cfg, noise_levels)  # [B,T,h]
     c = emb[:, :, None, :].expand(b, t, gh * gw, h).reshape(b, t * gh * gw, h)
-    ang = rope3d_angles(cfg.head_dim, (cfg.max_tokens, gh, gw), cfg.rope_theta)
+    ang = rope3d_angles(cfg.head_dim, (cfg.max_tokens, gh, gw), cfg.rope_theta).to(x.device)
     if taps is not None:
         taps["emb"], taps["tokens"] = emb, tok
     for i in range(cfg.depth):

@@ -23,6 +23,7 @@ import torch
 import torch.nn.functional as F
 
 Params = Dict[str, torch.Tensor]
+USE_SDPA = False  # True: F.scaled_dot_product_attention instead of the explicit softmax (same maths, fused kernel on a GPU)
 
 
 @dataclass
@@ -211,7 +212,10 @@ def transformer_block(p: Params, pre: str, x: torch.Tensor, emb: torch.Tensor, a
     q, k, v = qkv.view(b, n, 3, hds, d).permute(2, 0, 3, 1, 4)
     q = apply_rope(rms_norm(q, p[pre + ".q_norm.weight"], cfg.eps), ang)
     k = apply_rope(rms_norm(k, p[pre + ".k_norm.weight"], cfg.eps), ang)
-    att = torch.softmax((q @ k.transpose(-1, -2)) / math.sqrt(d), dim=-1) @ v
+    if USE_SDPA:  # the reference's own call (u_vit_blocks.py:264-268); used when the oracle is TIMED on a GPU
+        att = F.scaled_dot_product_attention(q, k.to(q.dtype), v.to(q.dtype))
+    else:
+        att = torch.softmax((q @ k.transpose(-1, -2)) / math.sqrt(d), dim=-1) @ v
     att = att.permute(0, 2, 1, 3).reshape(b, n, c)
     if taps is not None:
         taps.update(xn=xn, q=q, k=k, v=v, att=att, mlp_h=mlp_h)
@@ -250,7 +254,7 @@ def forward(p: Params, cfg: UViTConfig, x: torch.Tensor, noise_levels: torch.Ten
     for lvl, kind in enumerate(cfg.block_types):
         if kind == "TransformerBlock":
             r = cfg.level_res(lvl)
-            angles[lvl] = rope3d_angles(cfg.channels[lvl] // cfg.num_heads, (cfg.max_tokens, r, r), cfg.rope_theta)
+            angles[lvl] = rope3d_angles(cfg.channels[lvl] // cfg.num_heads, (cfg.max_tokens, r, r), cfg.rope_theta).to(x.device)
 
     def run_level(h, lvl, prefixes):
         if cfg.block_types[lvl] == "ResBlock":

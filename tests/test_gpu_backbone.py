@@ -192,3 +192,47 @@ def test_reference_checkpoint_ingestion(w64, tmp_path):
     dfot_amd.load_reference_checkpoint(blank2, sp)
     with torch.no_grad():
         assert torch.equal(blank2(x, k, c, m), ref)
+
+
+def test_report_torch_eager_time_on_this_gpu():
+    """Orientation only (prints, asserts nothing about speed): the CPU oracle's plain-PyTorch restatement of the reference
+    backbone moved to this GPU under bf16 autocast with F.scaled_dot_product_attention -- i.e. what the reference's own
+    PyTorch-ROCm path costs per window-forward here -- next to the HIP engine on the same inputs (RE10K size, model batch 2)."""
+    import time
+    import dfot_amd
+    from oracle import pose as opose, uvit as ouvit
+    ocfg = ouvit.UViTConfig(resolution=256)
+    params = ouvit.seeded_params(ocfg, 0)
+    cfg = dict(channels=list(ocfg.channels), emb_channels=ocfg.emb_channels, patch_size=2, block_types=list(ocfg.block_types),
+               num_updown_blocks=list(ocfg.num_updown_blocks), num_mid_blocks=ocfg.num_mid_blocks, num_heads=ocfg.num_heads,
+               pos_emb_type="rope", use_fourier_noise_embedding=True, conditioning=dict(dim=180))
+    model = dfot_amd.UViT3DPose(cfg, x_shape=(3, 256, 256), max_tokens=8).cuda()
+    model.load_state_dict(params, strict=True)
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(2, 8, 3, 256, 256, generator=g).cuda()
+    k = torch.randn(2, 8, generator=g).cuda()
+    pz = torch.eye(3, 4).reshape(1, 1, 12).repeat(2, 8, 1)
+    pz[..., 3] = torch.linspace(0, 0.5, 8)
+    cond = opose.ray_encoding(torch.cat([torch.tensor([0.5, 0.9, 0.5, 0.5]).repeat(2, 8, 1), pz], -1), 256).cuda()
+    gp = {n: t.cuda() for n, t in params.items()}
+
+    def timed(fn, reps):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            out = fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps * 1e3, out
+    ouvit.USE_SDPA = True
+    try:
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+            t_eager, ref = timed(lambda: ouvit.forward(gp, ocfg, x, k, cond, None), 3)
+    finally:
+        ouvit.USE_SDPA = False
+    with torch.no_grad():
+        t_hip, out = timed(lambda: model(x, k, cond, None), 10)
+    r = ((out.float() - ref.float()).norm() / ref.float().norm()).item()
+    print(f"\n[orientation] window-forward x2 on this GPU: torch eager bf16+SDPA {t_eager:.1f} ms, HIP engine {t_hip:.1f} ms "
+          f"({t_eager / t_hip:.2f}x); rel-L2 between the two {r:.2e}")
+    assert torch.isfinite(out).all() and r < 5e-2

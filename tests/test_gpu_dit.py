@@ -322,3 +322,33 @@ def test_discrete_denoising_loss_vs_reference_fixture():
     assert rel(per_token.cpu(), ref_tok) < 2e-2
     assert abs(loss.item() - ref_tok.mean().item()) < 2e-2 * ref_tok.mean().item()
     assert rel(x_pred.cpu(), T(g["x_pred"])) < 2e-2
+
+
+def test_report_torch_eager_time_on_this_gpu():
+    """Orientation only: the oracle's plain-PyTorch DiT/XL (materialised softmax attention, as the reference's DiT blocks do,
+    dit_blocks.py:21-44) on this GPU under bf16 autocast next to the HIP engine, 8 videos per forward."""
+    import time
+    from oracle import dit as odit
+    cfg = odit.DiTConfig()
+    params, model = build(cfg, 0)
+    gp = {n: t.cuda() for n, t in params.items()}
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(8, 5, 16, 16, 16, generator=g).cuda()
+    k = torch.randint(0, 1000, (8, 5), generator=g).cuda()
+
+    def timed(fn, reps):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            out = fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps * 1e3, out
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        t_eager, ref = timed(lambda: odit.forward(gp, cfg, x, k), 3)
+    with torch.no_grad():
+        t_hip, out = timed(lambda: model(x, k), 10)
+    r = rel(out.float().cpu(), ref.float().cpu())
+    print(f"\n[orientation] DiT/XL forward of 8 videos on this GPU: torch eager bf16 {t_eager:.1f} ms, HIP engine {t_hip:.1f} ms "
+          f"({t_eager / t_hip:.2f}x); rel-L2 between the two {r:.2e}")
+    assert r < 5e-2
