@@ -201,8 +201,8 @@ __global__ __launch_bounds__(256) void attn_kernel(const bf16* __restrict__ Q, c
 // DQK / DV: head dims actually multiplied (multiples of 16 / 32, <= D) when the logical head dim is smaller than the
 // row stride D of the q/k/v layout (DiT: d = 72 in 128-element rows -> DQK 80, DV 96; the pad columns hold zeros).
 // Output: head hd of query row r goes to O[r*ldo + hd*ohs + c] for c < dvalid.
-template <int D, int NST, int DQK = D, int DV = D>
-__global__ __launch_bounds__(256) void attn_kernel_v2(const bf16* __restrict__ Q, const bf16* __restrict__ K,
+template <int D, int NST, int DQK = D, int DV = D, bool QRELOAD = false>
+__global__ __launch_bounds__(256, QRELOAD ? 4 : 1) void attn_kernel_v2(const bf16* __restrict__ Q, const bf16* __restrict__ K,
                                                       const bf16* __restrict__ V, bf16* __restrict__ O, long ldo, int N,
                                                       int heads, int xcd, int ohs, int dvalid) {
   static_assert(DQK % 16 == 0 && DV % 32 == 0 && DQK <= D && DV <= D, "head-dim sub-range");
@@ -224,10 +224,14 @@ __global__ __launch_bounds__(256) void attn_kernel_v2(const bf16* __restrict__ Q
   const bf16* Kb = K + base;
   const bf16* Vb = V + base;
 
+  // QRELOAD: do not keep the Q fragments (DQK/16 x 4 VGPRs) live across the K/V loop; re-read them (L1/L2 hits) per tile so
+  // that the kernel fits 128 VGPRs = 4 waves per SIMD
   bf16x8 qf[DQK / 16];
+  const bf16* qrow = Qb + (long)(q0 + lq) * D + lh * 8;
+  if constexpr (!QRELOAD) {
 #pragma unroll
-  for (int ks = 0; ks < DQK / 16; ++ks)
-    qf[ks] = *reinterpret_cast<const bf16x8*>(Qb + (long)(q0 + lq) * D + ks * 16 + lh * 8);
+    for (int ks = 0; ks < DQK / 16; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qrow + ks * 16);
+  }
 
   // per-lane DMA source offsets (elements) within a tile: LDS position (row, pos) receives source chunk swz(row,pos)
   int koff[IPW], voff[IPW];
@@ -288,6 +292,12 @@ __global__ __launch_bounds__(256) void attn_kernel_v2(const bf16* __restrict__ Q
 
     // ---- S^T - m = K Q^T - m ----
     f32x16 sacc[2];
+    if constexpr (QRELOAD) {
+      const bf16* qp = qrow;
+      asm volatile("" : "+v"(qp));  // opaque per iteration: keeps the loads inside the loop
+#pragma unroll
+      for (int ks = 0; ks < DQK / 16; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qp + ks * 16);
+    }
     if (prio) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int kt2 = 0; kt2 < 2; ++kt2) {
@@ -395,10 +405,10 @@ __global__ __launch_bounds__(256) void attn_kernel_v2(const bf16* __restrict__ Q
     }
 }
 
-template <int D, int NST, int DQK = D, int DV = D>
+template <int D, int NST, int DQK = D, int DV = D, bool QRELOAD = false>
 static int launch_attn_v2(const bf16* q, const bf16* k, const bf16* v, bf16* o, long ldo, int batch, int heads, int n,
                           hipStream_t stream, int ohs = D, int dvalid = D) {
-  auto kern = attn_kernel_v2<D, NST, DQK, DV>;
+  auto kern = attn_kernel_v2<D, NST, DQK, DV, QRELOAD>;
   static const int xcd_flag = tuning_flag("ATTN_XCD", 1) | (tuning_flag("ATTN_PRIO", 1) << 1);
   const int lds = 2 * NST * AttnCfg<D>::TILE;
   static bool attr_set = false;
@@ -436,6 +446,10 @@ int launch_attention(const bf16* q, const bf16* k, const bf16* v, bf16* o, long 
     return d == 64 ? launch_attn_v2<64, 3>(q, k, v, o, ldo, batch, heads, n, stream)
                    : launch_attn_v2<128, 2>(q, k, v, o, ldo, batch, heads, n, stream);
   }
+  // A/B experiment kept for the record: two stages + Q fragments re-read per tile = 126 VGPRs, 4 waves per SIMD instead of 3.
+  // Measured slower (580-780 vs 750-960 TF/s at N = 8192): occupancy is not what limits this kernel.
+  if (variant == 4 && d == 64)
+    return launch_attn_v2<64, 2, 64, 64, true>(q, k, v, o, ldo, batch, heads, n, stream);
   if (variant == 3) {  // tuned kernel, two stages for both head sizes (A/B reference)
     return d == 64 ? launch_attn_v2<64, 2>(q, k, v, o, ldo, batch, heads, n, stream)
                    : launch_attn_v2<128, 2>(q, k, v, o, ldo, batch, heads, n, stream);

@@ -81,7 +81,8 @@ int dfot_uvit_finalize(dfot_uvit_t h, void* stream);
 int dfot_uvit_reserve(dfot_uvit_t h, int max_batch);
 size_t dfot_uvit_workspace_bytes(dfot_uvit_t h);
 /* tuning/debug switches: "gemm_variant" (-1 auto, 0..3 as in dfot_op_gemm),
- * "attn_variant" (2 = tuned kernel (default), 0 = baseline with transposed LDS reads for V, 1 = baseline with scalar LDS reads), "time_attn" (see below) */
+ * "attn_variant" (2 = tuned kernel (default), 0 = baseline with transposed LDS reads for V, 1 = baseline with scalar LDS reads,
+ * 3 = tuned kernel with two K/V stages, 4 = two stages + per-tile Q reload (4 waves per SIMD; slower, kept for A/B)), "time_attn" (see below) */
 int dfot_uvit_set_option(dfot_uvit_t h, const char* key, int value);
 /* "time_attn" = N > 0 records HIP events (on the launch stream) around the next N level-2 attention launches;
  * this call synchronises on them, returns the summed duration and the number of launches, and resets the count */

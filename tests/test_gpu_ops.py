@@ -88,7 +88,7 @@ def test_conv3x3(capi, dma, bt, h, w, cin, cout):
     assert rel < 1e-5 and err < 1e-3
 
 
-@pytest.mark.parametrize("variant", [1, 0, 2, 3])
+@pytest.mark.parametrize("variant", [1, 0, 2, 3, 4])
 @pytest.mark.parametrize("b,heads,n,d", [(1, 2, 128, 64), (2, 9, 512, 64), (1, 3, 256, 128), (2, 9, 128, 128)])
 def test_attention(capi, variant, b, heads, n, d):
     g = torch.Generator().manual_seed(n + d + heads)
