@@ -64,6 +64,15 @@ def cpu_baseline(res: int, sample_forwards: int, frames: int, forwards_per_sampl
                       f"scaled to {forwards_per_sample} window-forwards per {frames}-frame sample"}
 
 
+def k600_traffic(diff: bool, batch: int):
+    """HBM bytes per launch of the timed attention kernel from the committed PMC passes (8 videos per launch)."""
+    pmc = os.path.join(ROOT, "profiles", "r01_g_pmc_hbm_traffic_%s.json" % ("k600diff" if diff else "k600"))
+    if batch != 8 or not os.path.exists(pmc):
+        return None
+    ks = [v for n, v in json.load(open(pmc))["kernels"].items() if n.startswith("attn_kernel_v2<128")]
+    return ks[0]["hbm_bytes_per_launch_corrected"] if ks else None
+
+
 def bench_k600(args, rank, world, dist):
     """BASELINE config 4: Kinetics-600 latents [16,16,16], 17 frames = 5 latent tokens, context 5 frames = 2 tokens,
     README model @DiT/XL (dit3d full, rope_3d; attention-only blocks in this fork), DiscreteDiffusion cosine / pred_v,
@@ -145,7 +154,8 @@ def bench_k600(args, rank, world, dist):
             "roofline": {"bound": "mfma", "kernel": ("attn_kernel_v2<128,2,96,96> (per-frame spatial attention, N=256, head dim 96 in 128-wide rows)" if diff else
                                                       "attn_kernel_v2<128,2,80,96> (DiT attention, N=1280, head dim 72 in 128-wide rows)"),
                          "achieved": achieved, "peak": 2500.0, "unit": "TFLOP/s", "frac": achieved / 2500.0 if achieved else None,
-                         "traffic": None, "launches": attn_n, "avg_launch_ms": attn_ms / max(attn_n, 1), "flop_per_launch": flop_per_launch},
+                         "traffic": k600_traffic(diff, b), "launches": attn_n, "avg_launch_ms": attn_ms / max(attn_n, 1),
+                         "flop_per_launch": flop_per_launch},
         }
         if not args.no_cpu_baseline and world == 1:
             from oracle import dit as odit
@@ -266,7 +276,7 @@ def main():
         total_attn_flop = 4.0 * n2 * n2 * 64 * 9 * 12 * fwd
         achieved = total_attn_flop / (attn_ms * 1e-3) / 1e12 if attn_n else None
         traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")
+        pmc = os.path.join(ROOT, "profiles", "r01_g_pmc_hbm_traffic_8f.json")
         if os.path.exists(pmc) and res == 256 and not long_rollout:
             ks = [v for n, v in json.load(open(pmc))["kernels"].items() if n.startswith("attn_kernel_v2<64")]
             traffic = ks[0]["hbm_bytes_per_launch_corrected"] if ks else None
