@@ -67,6 +67,9 @@ enum GemmVariant {
   GEMM_DMA_128_KS2 = 8,  // 128x128 tile, 8 waves: two k-groups alternate k-tiles (intra-workgroup split-K)
   GEMM_DMA_256x192 = 9,  // 256x192 tile (12 waves), 2 stages, dense A only: N = multiples of 192 (1152, 3456) without padding
   GEMM_DMA_128x192 = 10,  // 128x192 tile (6 waves), 2 stages, dense A: long-K GEMMs with slightly more 128x128 tiles than CUs
+  // 256x256 tile, K-tiles of 32, 4-stage ring with counted vmcnt (three prefetches in flight), dense A.  A/B experiment:
+  // 6-15 % SLOWER than the two-stage BK = 64 loop on every model shape (twice the barriers per K), never auto-picked
+  GEMM_DMA4_256x256_BK32 = 11,
   GEMM_AUTO = -1      // pick by shape (gemm_pick_variant)
 };
 int gemm_pick_variant(int amode, int m, int n, int k);

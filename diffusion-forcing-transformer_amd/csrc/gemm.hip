@@ -27,30 +27,38 @@ constexpr int EP_LD = 68;  // fp32 row stride of the per-wave epilogue scratch (
 // operations are not moved across it)
 template <int N>
 __device__ __forceinline__ void wait_all_but() {
-  static_assert(N == 4 || N == 6 || N == 8, "unexpected load count");
+  static_assert(N == 2 || N == 4 || N == 6 || N == 8 || N == 12, "unexpected load count");
+  if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory");
   if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
   if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
   if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+  if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)\n\ts_barrier" ::: "memory");
 }
 
 // KS = 2: intra-workgroup split-K for grids too small to fill the chip (level-3 GEMMs at model batch 2): two groups of
 // NW waves each own a private pair of LDS stages and alternate k-tiles (group g takes k-tiles g, g+2, ...), doubling the
 // waves per CU and halving the serial k-loop; group 1's accumulators are folded into group 0's through LDS at the end.
-template <int BM_T, int BN_T, int WTM, int NST, int AMODE, int EPI, bool DMA, int KS = 1>
+// BKT = K-tile depth: 64 (LDS rows of 128 B) or 32 (rows of 64 B: half the stage size, so a 256x256 tile affords a 4-stage
+// ring -- the two-stage loop is bound by the latency of the ONE prefetch it has in flight, see gemm_pick_variant)
+template <int BM_T, int BN_T, int WTM, int NST, int AMODE, int EPI, bool DMA, int KS = 1, int BKT = BK>
 __global__ __launch_bounds__((BM_T / WTM) * (BN_T / 64) * 64 * KS) void gemm_kernel(GemmArgs g) {
+  static_assert(BKT == 64 || (BKT == 32 && AMODE == A_DENSE && DMA && KS == 1), "K-tile depth");
+  constexpr int CPR = BKT / 8;                  // 16-byte chunks per LDS row
+  constexpr int RPI = 64 / CPR;                 // rows staged by one wave instruction (1 KiB)
+  constexpr int ROWB = BKT * 2;                 // bytes per LDS row
   constexpr int MI = WTM / 16;                  // 16-row MFMA tiles per wave along M (wave tile = WTM x 64)
   constexpr int WN = BN_T / 64;                 // waves along N
   constexpr int NW = (BM_T / WTM) * WN;         // waves per k-group
   constexpr int NT = NW * 64;                   // threads per k-group
   // one wave instruction stages 8 rows (1 KiB) of a tile; AINS/WINS of them per k-tile are dealt round-robin to the NW
   // waves.  When NW does not divide them (256x192 tile: 32 + 24 over 12 waves) the last turn is guarded per wave.
-  constexpr int AINS = BM_T / 8, WINS = BN_T / 8;
+  constexpr int AINS = BM_T / RPI, WINS = BN_T / RPI;
   constexpr int ACH = (AINS + NW - 1) / NW;     // A chunks (16 B) per thread per k-tile
   constexpr int WCH = (WINS + NW - 1) / NW;     // W chunks per thread per k-tile
   constexpr bool A_EVEN = AINS % NW == 0, W_EVEN = WINS % NW == 0;
   static_assert((A_EVEN && W_EVEN) || (DMA && NST == 2 && KS == 1), "uneven staging: two-stage LDS-DMA kernels only");
-  constexpr int A_BYTES = BM_T * BK * 2;
-  constexpr int STAGE_BYTES = (BM_T + BN_T) * BK * 2;
+  constexpr int A_BYTES = BM_T * BKT * 2;
+  constexpr int STAGE_BYTES = (BM_T + BN_T) * BKT * 2;
   constexpr int LOADS = ACH + WCH;              // LDS-DMA instructions per thread per k-tile
   static_assert(DMA || NST == 2, "register staging supports two stages only");
   static_assert(KS == 1 || (NST == 2 && DMA && EPI != E_QKV), "split-K: two-stage LDS-DMA kernels without in-epilogue barriers");
@@ -64,19 +72,22 @@ __global__ __launch_bounds__((BM_T / WTM) * (BN_T / 64) * 64 * KS) void gemm_ker
   const int bid = xcd_remap(blockIdx.x, gridDim.x, g.xcd);
   const int tn = bid % tiles_n, tm = bid / tiles_n;
   const int m0 = tm * BM_T, n0 = tn * BN_T;
-  const int nk = g.K / BK;
+  const int nk = g.K / BKT;
+  // bank swizzle of the 16-byte chunk position inside a row (conflict-free ds_read_b128 fragment reads, MI355X_MICROARCH.md
+  // "LDS": lane groups of 16): 128-B rows: chunk ^ ((row >> 1) & 7); 64-B rows (4 rows per 256-B bank line): chunk ^ ((row >> 2) & 2)
+  auto swz = [](int r) { return BKT == 64 ? ((r >> 1) & 7) : ((r >> 2) & 2); };
 
-  // ---- per-thread staging geometry: 4 A chunks + WCH W chunks of 16 B per k-tile ----
-  const int prow = lane >> 3;  // row within the 8-row group written by one wave instruction
-  const int ppos = lane & 7;   // 16-byte position within the 128-byte LDS row
+  // ---- per-thread staging geometry: ACH A chunks + WCH W chunks of 16 B per k-tile ----
+  const int prow = lane / CPR;  // row within the group of RPI rows written by one wave instruction
+  const int ppos = lane % CPR;  // 16-byte position within the LDS row
   const bf16* a_src[ACH];
   int a_y[ACH], a_x[ACH];
   const bf16* w_src[WCH];
   int a_chunk[ACH];
 #pragma unroll
   for (int i = 0; i < ACH; ++i) {
-    const int r = 8 * (NW * i + wave) + prow;
-    const int c = ppos ^ ((r >> 1) & 7);
+    const int r = RPI * (NW * i + wave) + prow;
+    const int c = ppos ^ swz(r);
     a_chunk[i] = c;
     const long m = (long)m0 + r;
     if constexpr (AMODE == A_DENSE) {
@@ -92,8 +103,8 @@ __global__ __launch_bounds__((BM_T / WTM) * (BN_T / 64) * 64 * KS) void gemm_ker
   }
 #pragma unroll
   for (int i = 0; i < WCH; ++i) {
-    const int r = 8 * (NW * i + wave) + prow;
-    const int c = ppos ^ ((r >> 1) & 7);
+    const int r = RPI * (NW * i + wave) + prow;
+    const int c = ppos ^ swz(r);
     int n = n0 + r;
     n = n < g.N ? n : g.N - 1;
     w_src[i] = g.W + (long)n * g.K + c * 8;
@@ -101,9 +112,9 @@ __global__ __launch_bounds__((BM_T / WTM) * (BN_T / 64) * 64 * KS) void gemm_ker
 
   auto a_addr = [&](int i, int kt) -> const bf16* {
     if constexpr (AMODE == A_DENSE) {
-      return a_src[i] + (long)kt * BK;
+      return a_src[i] + (long)kt * BKT;
     } else {
-      const int kbase = kt * BK;
+      const int kbase = kt * BKT;
       const int tap = kbase / g.Cin;
       const int c0 = kbase - tap * g.Cin;
       const int dy = tap / 3 - 1, dx = tap % 3 - 1;
@@ -132,7 +143,7 @@ __global__ __launch_bounds__((BM_T / WTM) * (BN_T / 64) * 64 * KS) void gemm_ker
 #pragma unroll
     for (int i = 0; i < WCH; ++i) {
       if (!W_EVEN && NW * i + wave >= WINS) continue;
-      const bf16* pw = w_src[i] + (long)kt * BK;
+      const bf16* pw = w_src[i] + (long)kt * BKT;
       if constexpr (DMA) {
         __builtin_amdgcn_global_load_lds(DFOT_GLOBAL_PTR(pw), DFOT_LDS_PTR(sw + (NW * i + wave) * 1024), 16, 0, 0);
       } else {
@@ -160,19 +171,19 @@ __global__ __launch_bounds__((BM_T / WTM) * (BN_T / 64) * 64 * KS) void gemm_ker
     const char* sa = smem + stage * STAGE_BYTES;
     const char* sw = sa + A_BYTES;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
+    for (int ks = 0; ks < BKT / 32; ++ks) {
       bf16x8 af[MI], wf[4];
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi) {
         const int r = wm * WTM + mi * 16 + frow;
-        const int pos = (ks * 4 + fk) ^ ((r >> 1) & 7);
-        af[mi] = *reinterpret_cast<const bf16x8*>(sa + r * 128 + pos * 16);
+        const int pos = (ks * 4 + fk) ^ swz(r);
+        af[mi] = *reinterpret_cast<const bf16x8*>(sa + r * ROWB + pos * 16);
       }
 #pragma unroll
       for (int ni = 0; ni < 4; ++ni) {
         const int r = wn * 64 + ni * 16 + frow;
-        const int pos = (ks * 4 + fk) ^ ((r >> 1) & 7);
-        wf[ni] = *reinterpret_cast<const bf16x8*>(sw + r * 128 + pos * 16);
+        const int pos = (ks * 4 + fk) ^ swz(r);
+        wf[ni] = *reinterpret_cast<const bf16x8*>(sw + r * ROWB + pos * 16);
       }
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi)
@@ -236,27 +247,29 @@ __global__ __launch_bounds__((BM_T / WTM) * (BN_T / 64) * 64 * KS) void gemm_ker
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[mi][ni][j] += red[((mi * 4 + ni) * 4 + j) * 64 + lane];
   } else {
-    // 3-stage ring.  Invariant at the top of iteration kt: tile kt has landed and is visible to every wave
-    // (its waves waited for it, then passed a barrier); tile kt+1 may still be in flight.
-    issue(0, 0);
-    if (nk > 1) {
-      issue(1, 1);
-      wait_all_but<LOADS>();
+    // NST-stage ring (NST >= 3).  Invariant at the top of iteration kt: tile kt has landed and is visible to every wave
+    // (its waves waited for it, then passed a barrier); tiles kt+1 .. kt+NST-2 may still be in flight.
+    static_assert(NST >= 3 && A_EVEN && W_EVEN, "ring: even staging only");
+#pragma unroll
+    for (int t = 0; t < NST - 1; ++t)
+      if (t < nk) issue(t, t);
+    if (nk >= NST - 1) {
+      wait_all_but<(NST - 2) * LOADS>();
     } else {
       asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
     }
     int st = 0;
     for (int kt = 0; kt < nk; ++kt) {
-      // stage (kt+2)%3 == (kt-1)%3 was last read in iteration kt-1, which every wave left through a barrier
-      const int nxt2 = st == 0 ? 2 : st - 1;
-      if (kt + 2 < nk) issue(kt + 2, nxt2);
+      // stage (kt+NST-1) % NST == (kt-1) % NST was last read in iteration kt-1, which every wave left through a barrier
+      const int nxt = st == 0 ? NST - 1 : st - 1;
+      if (kt + NST - 1 < nk) issue(kt + NST - 1, nxt);
       compute(st);
-      if (kt + 2 < nk) {
-        wait_all_but<LOADS>();
+      if (kt + NST - 1 < nk) {
+        wait_all_but<(NST - 2) * LOADS>();  // tile kt+1 has landed; the NST-2 newer ones may stay in flight
       } else {
         asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
       }
-      st = st == 2 ? 0 : st + 1;
+      st = st == NST - 1 ? 0 : st + 1;
     }
   }
 
@@ -530,10 +543,10 @@ __global__ __launch_bounds__((BM_T / WTM) * (BN_T / 64) * 64 * KS) void gemm_ker
   }
 }
 
-template <int BM_T, int BN_T, int WTM, int NST, int AMODE, int EPI, bool DMA, int KS = 1>
+template <int BM_T, int BN_T, int WTM, int NST, int AMODE, int EPI, bool DMA, int KS = 1, int BKT = BK>
 static int launch_t(const GemmArgs& g, hipStream_t stream) {
   constexpr int nthreads = (BM_T / WTM) * (BN_T / 64) * 64 * KS;
-  constexpr int stage_lds = KS * NST * (BM_T + BN_T) * BK * 2;
+  constexpr int stage_lds = KS * NST * (BM_T + BN_T) * BKT * 2;
   constexpr int ep_lds = (nthreads / 64) * 16 * EP_LD * 4 + 2 * (nthreads / 64) * 16 * 4 +
                          (KS == 2 ? (nthreads / 128) * (WTM / 16) * 16 * 64 * 4 : 0);
   constexpr int lds = stage_lds > ep_lds ? stage_lds : ep_lds;
@@ -541,7 +554,7 @@ static int launch_t(const GemmArgs& g, hipStream_t stream) {
   static const int xcd_flag = tuning_flag("GEMM_XCD", 1);
   GemmArgs ga = g;
   ga.xcd = xcd_flag;
-  auto kern = gemm_kernel<BM_T, BN_T, WTM, NST, AMODE, EPI, DMA, KS>;
+  auto kern = gemm_kernel<BM_T, BN_T, WTM, NST, AMODE, EPI, DMA, KS, BKT>;
   static bool attr_set = false;
   if (!attr_set) {
     DFOT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -565,6 +578,9 @@ static int launch_v(int variant, const GemmArgs& g, hipStream_t s) {
     case GEMM_DMA_256x192:
       if constexpr (AMODE != A_DENSE) break;
       else return launch_t<256, 192, 64, 2, AMODE, EPI, true>(g, s);
+    case GEMM_DMA4_256x256_BK32:
+      if constexpr (AMODE != A_DENSE) break;
+      else return launch_t<256, 256, 64, 4, AMODE, EPI, true, 1, 32>(g, s);
     case GEMM_DMA_128x192:
       if constexpr (AMODE != A_DENSE || EPI == E_QKV) break;
       else return launch_t<128, 192, 64, 2, AMODE, EPI, true>(g, s);
@@ -616,7 +632,7 @@ int launch_gemm(int amode, int epi, int variant, const GemmArgs& g, hipStream_t 
   if (variant == GEMM_DMA_128_KS2 && epi == E_QKV) variant = GEMM_DMA_128;  // the QKV epilogue has workgroup barriers
   if (variant == GEMM_DMA_128x192 && epi == E_QKV) variant = GEMM_DMA_128;
   if (variant == GEMM_DMA_256x192 && epi == E_QKV) variant = GEMM_DMA_256x256;  // its head pairing needs 128-aligned tiles
-  const int bm = variant == GEMM_DMA_512x128 ? 512 : (variant == GEMM_DMA3_256 || variant == GEMM_DMA_256x256 || variant == GEMM_DMA_256x128 || variant == GEMM_DMA_256x256_W128 || variant == GEMM_DMA_256x192) ? 256 : 128;
+  const int bm = variant == GEMM_DMA_512x128 ? 512 : (variant == GEMM_DMA3_256 || variant == GEMM_DMA_256x256 || variant == GEMM_DMA_256x128 || variant == GEMM_DMA_256x256_W128 || variant == GEMM_DMA_256x192 || variant == GEMM_DMA4_256x256_BK32) ? 256 : 128;
   DFOT_REQUIRE(g.M > 0 && g.M % bm == 0, DFOT_ERR_SHAPE, "gemm: M=%d must be a positive multiple of %d", g.M, bm);
   DFOT_REQUIRE(g.K > 0 && g.K % BK == 0, DFOT_ERR_SHAPE, "gemm: K=%d must be a positive multiple of %d", g.K, BK);
   DFOT_REQUIRE(g.N > 0 && g.N % (epi == E_F32 ? 4 : 8) == 0, DFOT_ERR_SHAPE, "gemm: N=%d must be a multiple of %d", g.N, epi == E_F32 ? 4 : 8);
