@@ -70,6 +70,7 @@ enum GemmVariant {
   // 256x256 tile, K-tiles of 32, 4-stage ring with counted vmcnt (three prefetches in flight), dense A.  A/B experiment:
   // 6-15 % SLOWER than the two-stage BK = 64 loop on every model shape (twice the barriers per K), never auto-picked
   GEMM_DMA4_256x256_BK32 = 11,
+  GEMM_DMA4_256x256_W128_BK32 = 12,  // as 11 with 8 waves of 128x64 (42.7 FLOP per LDS byte, 2 waves per SIMD): equal to variant 7, slower than 4
   GEMM_AUTO = -1      // pick by shape (gemm_pick_variant)
 };
 int gemm_pick_variant(int amode, int m, int n, int k);

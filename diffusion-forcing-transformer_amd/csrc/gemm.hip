@@ -581,6 +581,12 @@ static int launch_v(int variant, const GemmArgs& g, hipStream_t s) {
     case GEMM_DMA4_256x256_BK32:
       if constexpr (AMODE != A_DENSE) break;
       else return launch_t<256, 256, 64, 4, AMODE, EPI, true, 1, 32>(g, s);
+    case GEMM_DMA4_256x256_W128_BK32:
+      if constexpr (AMODE != A_DENSE) break;
+      else {
+        if (g.gn_part) break;
+        return launch_t<256, 256, 128, 4, AMODE, EPI, true, 1, 32>(g, s);
+      }
     case GEMM_DMA_128x192:
       if constexpr (AMODE != A_DENSE || EPI == E_QKV) break;
       else return launch_t<128, 192, 64, 2, AMODE, EPI, true>(g, s);
@@ -632,7 +638,7 @@ int launch_gemm(int amode, int epi, int variant, const GemmArgs& g, hipStream_t 
   if (variant == GEMM_DMA_128_KS2 && epi == E_QKV) variant = GEMM_DMA_128;  // the QKV epilogue has workgroup barriers
   if (variant == GEMM_DMA_128x192 && epi == E_QKV) variant = GEMM_DMA_128;
   if (variant == GEMM_DMA_256x192 && epi == E_QKV) variant = GEMM_DMA_256x256;  // its head pairing needs 128-aligned tiles
-  const int bm = variant == GEMM_DMA_512x128 ? 512 : (variant == GEMM_DMA3_256 || variant == GEMM_DMA_256x256 || variant == GEMM_DMA_256x128 || variant == GEMM_DMA_256x256_W128 || variant == GEMM_DMA_256x192 || variant == GEMM_DMA4_256x256_BK32) ? 256 : 128;
+  const int bm = variant == GEMM_DMA_512x128 ? 512 : (variant == GEMM_DMA3_256 || variant == GEMM_DMA_256x256 || variant == GEMM_DMA_256x128 || variant == GEMM_DMA_256x256_W128 || variant == GEMM_DMA_256x192 || variant == GEMM_DMA4_256x256_BK32 || variant == GEMM_DMA4_256x256_W128_BK32) ? 256 : 128;
   DFOT_REQUIRE(g.M > 0 && g.M % bm == 0, DFOT_ERR_SHAPE, "gemm: M=%d must be a positive multiple of %d", g.M, bm);
   DFOT_REQUIRE(g.K > 0 && g.K % BK == 0, DFOT_ERR_SHAPE, "gemm: K=%d must be a positive multiple of %d", g.K, BK);
   DFOT_REQUIRE(g.N > 0 && g.N % (epi == E_F32 ? 4 : 8) == 0, DFOT_ERR_SHAPE, "gemm: N=%d must be a multiple of %d", g.N, epi == E_F32 ? 4 : 8);
