@@ -698,7 +698,7 @@ __global__ void ddim_compose_kernel(const float* __restrict__ x, const float* __
                                     const float* __restrict__ sa, const float* __restrict__ s1, const float* __restrict__ an,
                                     const float* __restrict__ cn, const float* __restrict__ keep,
                                     const float* __restrict__ weight, const uint8_t* __restrict__ gen,
-                                    float* __restrict__ x_next, long total4, int nfe, int tokens, long f4) {
+                                    float* __restrict__ x_next, long total4, int nfe, int tokens, long f4, int wstride) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= total4) return;
   const long e = idx % f4;
@@ -723,18 +723,18 @@ __global__ void ddim_compose_kernel(const float* __restrict__ x, const float* __
         const float4v ep = vv * sa[row] + xi * s1[row];
         xp = x0 * an[row] + ep * cn[row];
       }
-      o += xp * weight[h];
+      o += xp * weight[wstride ? h * wstride + tk : h];  // wstride = tokens: per-(branch, token) weights (gen segments)
     }
   }
   *reinterpret_cast<float4v*>(x_next + idx * 4) = o;
 }
 int launch_ddim_compose(const float* x, const float* x_in, const float* v, const float* sa, const float* s1,
                         const float* an, const float* cn, const float* keep, const float* weight, const uint8_t* gen,
-                        float* x_next, int batch, int nfe, int tokens, long f, hipStream_t s) {
+                        float* x_next, int batch, int nfe, int tokens, long f, bool weight_per_token, hipStream_t s) {
   DFOT_REQUIRE(f % 4 == 0, DFOT_ERR_SHAPE, "ddim_compose: frame elements %ld must be a multiple of 4", f);
   const long total4 = (long)batch * tokens * (f / 4);
   hipLaunchKernelGGL(ddim_compose_kernel, dim3(cdiv(total4, 256)), dim3(256), 0, s, x, x_in, v, sa, s1, an, cn, keep,
-                     weight, gen, x_next, total4, nfe, tokens, f / 4);
+                     weight, gen, x_next, total4, nfe, tokens, f / 4, weight_per_token ? tokens : 0);
   DFOT_CHECK_HIP(hipGetLastError());
   return DFOT_OK;
 }

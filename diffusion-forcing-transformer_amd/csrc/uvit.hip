@@ -767,7 +767,14 @@ int dfot_ddim_compose(const float* x, const float* x_in, const float* v, const f
                       const float* cn, const float* keep, const float* weight, const uint8_t* gen, float* x_next, int batch,
                       int nfe, int tokens, int64_t frame_elems, void* stream) {
   DFOT_REQUIRE(x && x_in && v && sa && s1 && an && cn && keep && weight && gen && x_next, DFOT_ERR_ARG, "ddim_compose: null argument");
-  return launch_ddim_compose(x, x_in, v, sa, s1, an, cn, keep, weight, gen, x_next, batch, nfe, tokens, (long)frame_elems,
+  return launch_ddim_compose(x, x_in, v, sa, s1, an, cn, keep, weight, gen, x_next, batch, nfe, tokens, (long)frame_elems, false,
+                             (hipStream_t)stream);
+}
+int dfot_ddim_compose_tokw(const float* x, const float* x_in, const float* v, const float* sa, const float* s1, const float* an,
+                           const float* cn, const float* keep, const float* weight, const uint8_t* gen, float* x_next, int batch,
+                           int nfe, int tokens, int64_t frame_elems, void* stream) {
+  DFOT_REQUIRE(x && x_in && v && sa && s1 && an && cn && keep && weight && gen && x_next, DFOT_ERR_ARG, "ddim_compose_tokw: null argument");
+  return launch_ddim_compose(x, x_in, v, sa, s1, an, cn, keep, weight, gen, x_next, batch, nfe, tokens, (long)frame_elems, true,
                              (hipStream_t)stream);
 }
 

@@ -11,8 +11,9 @@ planner emits, once per sampling step, a tiny table per (sample, branch, token):
     weight[h]      composition weight            cond_masked[h]  drop the camera pose?
 
 from which the sampler derives the q_sample / DDIM coefficient tables consumed by
-``dfot_hg_prepare`` and ``dfot_ddim_compose``.  Temporal guidance (gen/time sub-segments)
-is not on any BASELINE configuration and raises NotImplementedError.
+``dfot_hg_prepare`` and ``dfot_ddim_compose``.  Temporal / custom guidance (history sub-sequences via ``time_indices`` and
+several ``gen_segments``: :105-149, :357-568) adds per-(branch, token) composition weights and an "excluded" flag for tokens a
+gen segment leaves out (shown to the model as pure noise at level T-1, weight 0).
 """
 from __future__ import annotations
 
@@ -43,6 +44,10 @@ class BranchPlan:
     weights: np.ndarray      # (H,) float32
     cond_masked: Optional[np.ndarray]  # (H,) bool or None (no pose guidance at all)
     replace: np.ndarray      # (B, H, T) bool: history token re-noised to levels[b,h,t]
+    # several gen segments only (H = hist branches x gen segments, gen segment fastest):
+    excluded: Optional[np.ndarray] = None     # (B, H, T) bool: token to be generated but outside the branch's gen segment
+    tok_weights: Optional[np.ndarray] = None  # (H, T) float32: weight / (number of gen segments covering the token), 0 if excluded
+    n_gen: int = 1
 
     @property
     def nfe(self) -> int:
@@ -54,11 +59,8 @@ class HistoryGuidance:
                  timesteps: int = 1000, use_external_cond_guidance: bool = False, visualize: bool = False):
         if len(hist_segments) != len(hist_weights):
             raise AssertionError("Length of hist_segments and hist_weights should be the same")
-        if gen_segments not in (None, [ALL], (ALL,)):
-            raise NotImplementedError("gen_segments other than ['all'] (temporal guidance) are not supported")
-        for s in hist_segments:
-            if s.time_indices != ALL:
-                raise NotImplementedError("history sub-sequences (temporal guidance) are not supported")
+        self.needs_pose_interpolation = False
+        self.gen_segments = [ALL] if gen_segments is None else [g if g == ALL else list(g) for g in gen_segments]
         self.hist_segments, self.hist_weights = hist_segments, list(hist_weights)
         self.timesteps = timesteps
         self.use_external_cond_guidance = use_external_cond_guidance
@@ -107,13 +109,40 @@ class HistoryGuidance:
         return cls(segs, [1, guidance_scale - 1], timesteps=timesteps,
                    use_external_cond_guidance=use_external_cond_guidance)
 
+    @classmethod
+    def temporal(cls, hist_subsequences, hist_weights, gen_segments=None, timesteps: int = 1000,
+                 use_external_cond_guidance: bool = True, **_):
+        """Temporal History Guidance (HG-t, :832-859): one full-frequency segment per history sub-sequence."""
+        segs = [HistorySegment(time_indices=ALL if sub == ALL else list(sub)) for sub in hist_subsequences]
+        hg = cls(segs, hist_weights, gen_segments=gen_segments, timesteps=timesteps,
+                 use_external_cond_guidance=use_external_cond_guidance)
+        # with camera poses the reference re-interpolates the poses of fully masked frames (dfot_video_pose.py:77-84,
+        # CameraPose.replace_with_interpolation: quaternion slerp) -- not built; the pose sampler refuses this combination
+        hg.needs_pose_interpolation = True
+        return hg
+
+    @classmethod
+    def custom(cls, hist_segments, hist_weights, gen_segments=None, timesteps: int = 1000,
+               use_external_cond_guidance: bool = True, **_):
+        """The most flexible constructor (:861-900): hist_segments = dicts with time_indices / freq_ranges /
+        freq_ranges_if_generated."""
+        def ranges(r):
+            return None if r is None else tuple(ALL if x == ALL else tuple(x) for x in r)
+        segs = [HistorySegment(time_indices=ALL if d["time_indices"] == ALL else list(d["time_indices"]),
+                               freq_ranges=ranges(d["freq_ranges"]) or (ALL,),
+                               freq_ranges_if_generated=ranges(d.get("freq_ranges_if_generated")))
+                for d in hist_segments]
+        return cls(segs, hist_weights, gen_segments=gen_segments, timesteps=timesteps,
+                   use_external_cond_guidance=use_external_cond_guidance)
+
     # ---------------------------------------------------------------- planning
     @property
     def is_simple(self) -> bool:
         """the reference's dispatch to SimpleHistoryGuidanceManager (:635-653)"""
         s = self.hist_segments[0]
         gen = s.freq_ranges if s.freq_ranges_if_generated is None else s.freq_ranges_if_generated
-        return len(self.hist_weights) == 1 and len(s.freq_ranges) == 1 and s.freq_ranges[0] == ALL and gen[0] == ALL
+        return (len(self.hist_weights) == 1 and len(s.freq_ranges) == 1 and s.freq_ranges[0] == ALL and gen[0] == ALL
+                and s.time_indices == ALL and self.gen_segments == [ALL])
 
     @staticmethod
     def _range_for(ranges: Sequence, i: int, n: int) -> Tuple[float, float]:
@@ -167,7 +196,14 @@ class HistoryGuidance:
         ucg = bool(self.use_external_cond_guidance)
         add((1.0,) * n + (ucg,), 1.0)
         for seg, w in zip(self.hist_segments, self.hist_weights):
-            pairs = [self._range_for(seg.ranges(bool(generated[i])), i, n) for i in range(n)]
+            # HistorySegment.to_noise_levels (:105-149): tokens outside time_indices are fully masked (1.0, 1.0); the freq
+            # ranges are indexed by the position inside the chosen sub-sequence
+            chosen = list(range(n)) if seg.time_indices == ALL else [i if i >= 0 else n + i for i in seg.time_indices]
+            if any(not 0 <= i < n for i in chosen):
+                raise AssertionError("time_indices should be between 0 and hist_len.")
+            pairs = [(1.0, 1.0)] * n
+            for j, tok in enumerate(chosen):
+                pairs[tok] = self._range_for(seg.ranges(bool(generated[tok])), j, len(chosen))
             start = tuple(p[0] for p in pairs)
             end = tuple(p[1] for p in pairs)
             add(start + (False,), float(w))
@@ -181,5 +217,21 @@ class HistoryGuidance:
             lv[:, :, hidx] = hlev[None]
             tl[:, :, hidx] = hlev[None]
         repl = (lv >= 0) & hist[:, None, :]
-        return BranchPlan(lv, tl, np.array([acc[k] for k in keys], np.float32),
-                          np.array([bool(k[-1]) for k in keys]), repl)
+        weights = np.array([acc[k] for k in keys], np.float32)
+        cond = np.array([bool(k[-1]) for k in keys])
+        if self.gen_segments == [ALL]:
+            return BranchPlan(lv, tl, weights, cond, repl)
+        # several gen segments (:386-395, :512-536, :545-568): every history branch is evaluated once per segment; tokens
+        # to be generated but outside the segment are shown as pure noise at level T-1 and contribute nothing
+        gidx = np.where(row == 0)[0]
+        g = len(self.gen_segments)
+        gen_mask = np.zeros((g, t), bool)
+        for i, seg in enumerate(self.gen_segments):
+            gen_mask[i, gidx if seg == ALL else gidx[np.asarray(seg, dtype=np.int64)]] = True
+        cover = np.maximum(gen_mask.sum(0), 1).astype(np.float32)
+        lv, tl, repl = (np.repeat(a, g, axis=1) for a in (lv, tl, repl))          # (B, h*g, T), gen segment fastest
+        excl = np.tile(~gen_mask, (h, 1))[None] & (mask == 0)[:, None, :]          # (B, h*g, T)
+        top = self.timesteps - 1
+        lv, tl = np.where(excl, top, lv), np.where(excl, top, tl)
+        tokw = (np.repeat(weights, g)[:, None] * np.tile(gen_mask, (h, 1)) / cover[None]).astype(np.float32)
+        return BranchPlan(lv, tl, np.repeat(weights, g), np.repeat(cond, g), repl, excluded=excl, tok_weights=tokw, n_gen=g)

@@ -185,6 +185,9 @@ class DFoTVideoPoseSampler:
                          history_guidance: Optional[HistoryGuidance] = None, **_) -> Tuple[torch.Tensor, None]:
         cfg, sch = self.cfg, self.schedule
         x_shape = self.x_shape
+        if conditions is not None and history_guidance is not None and history_guidance.needs_pose_interpolation:
+            raise NotImplementedError("temporal history guidance with camera poses needs the reference's pose interpolation of "
+                                      "masked frames (CameraPose.replace_with_interpolation, slerp), which is not built")
         if length is None:
             length = self.max_tokens if context is None else context.shape[1]
         if length > self.max_tokens:
@@ -243,9 +246,13 @@ class DFoTVideoPoseSampler:
             qa_c, qb_c = sch.q_sample_coef(lv)
             qa = np.where(repl, qa_c, np.float32(1)).astype(np.float32)
             qb = np.where(repl, qb_c, np.float32(0)).astype(np.float32)
+            excl = None
+            if plan.excluded is not None:  # gen tokens outside the branch's gen segment: x_in = fresh (unclamped) noise
+                excl = plan.excluded.reshape(bm, horizon)
+                qa, qb = np.where(excl, np.float32(0), qa), np.where(excl, np.float32(1), qb)
             sa, s1, an, cn, keepf, _sigma = sch.ddim_coef(lv, tl)
             tables = np.stack([qa, qb, sa, s1, an, cn, keepf, sch.model_level(lv)]).astype(np.float32)
-            plans.append(dict(plan=plan, nfe=plan.nfe, bm=bm, need_noise=bool(repl.any()), tables=tables,
+            plans.append(dict(plan=plan, nfe=plan.nfe, bm=bm, need_noise=bool(repl.any()) or excl is not None, excl=excl, tables=tables,
                               gen=(mask == 0).astype(np.uint8),
                               cmask=None if plan.cond_masked is None else np.tile(plan.cond_masked, batch_size)))
         if not plans:
@@ -260,10 +267,12 @@ class DFoTVideoPoseSampler:
             p_["tables_dev"] = flat_dev[off:off + n].view(8, p_["bm"], horizon)
             off += n
             p_["gen_dev"] = gens_dev[i]
-            wkey = p_["plan"].weights.tobytes()
+            wsrc = p_["plan"].weights if p_["plan"].tok_weights is None else p_["plan"].tok_weights
+            wkey = wsrc.tobytes()
             if wkey not in weight_cache:
-                weight_cache[wkey] = torch.from_numpy(p_["plan"].weights.astype(np.float32)).cuda()
+                weight_cache[wkey] = torch.from_numpy(np.ascontiguousarray(wsrc, dtype=np.float32)).cuda()
             p_["weights_dev"] = weight_cache[wkey]
+            p_["tokw"] = p_["plan"].tok_weights is not None
             p_["cmask_dev"] = None
             if p_["cmask"] is not None:
                 # one device tensor per distinct mask pattern: the backbone keys its per-window pose caches on the
@@ -290,10 +299,18 @@ class DFoTVideoPoseSampler:
                     noise = torch.zeros(batch_size, 2, horizon, *x_shape, device="cuda", dtype=torch.float32)
                     noise[:, 0] = drawn.to(device="cuda", dtype=torch.float32)
             else:
+                g = p_["plan"].n_gen
+                bh = bm // g  # the reference draws the history noise per (sample, history branch), before the gen-segment split
                 if need or strict:
-                    noise = self.noise_fn("q_sample", (bm, horizon, *x_shape)).to(device="cuda", dtype=torch.float32)
-                if strict:
-                    self.noise_fn("excluded", (bm, 1, horizon, *x_shape))
+                    noise = self.noise_fn("q_sample", (bh, horizon, *x_shape)).to(device="cuda", dtype=torch.float32)
+                    if g > 1:
+                        noise = noise.repeat_interleave(g, dim=0)
+                if strict or p_["excl"] is not None:
+                    fresh = self.noise_fn("excluded", (bh, g, horizon, *x_shape))
+                    if p_["excl"] is not None:  # torch.randn_like(x) for the excluded gen tokens (:529-533), not clamped
+                        fresh = fresh.to(device="cuda", dtype=torch.float32).reshape(bm, horizon, *x_shape)
+                        em = torch.from_numpy(p_["excl"]).cuda().view(bm, horizon, *([1] * len(x_shape)))
+                        noise = torch.where(em, fresh, noise if noise is not None else torch.zeros_like(fresh))
             return None if noise is None else noise.contiguous().view(bm, horizon, *x_shape)
 
         def step(p_, xs, noise, tables, gen_dev, xs_next=None):
@@ -312,7 +329,8 @@ class DFoTVideoPoseSampler:
                 self.noise_fn("ddim", (bm, horizon, *x_shape))  # multiplied by sigma = 0 in the reference
             if xs_next is None:
                 xs_next = torch.empty_like(xs)
-            capi.check(capi.lib.dfot_ddim_compose(capi.ptr(xs), capi.ptr(x_in), capi.ptr(v), capi.ptr(tables[2]),
+            compose = capi.lib.dfot_ddim_compose_tokw if p_["tokw"] else capi.lib.dfot_ddim_compose
+            capi.check(compose(capi.ptr(xs), capi.ptr(x_in), capi.ptr(v), capi.ptr(tables[2]),
                                                   capi.ptr(tables[3]), capi.ptr(tables[4]), capi.ptr(tables[5]),
                                                   capi.ptr(tables[6]), capi.ptr(p_["weights_dev"]), capi.ptr(gen_dev),
                                                   capi.ptr(xs_next), batch_size, nfe, horizon, f, s()))

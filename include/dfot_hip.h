@@ -182,6 +182,12 @@ int dfot_ddim_compose(const float* x, const float* x_in, const float* v, const f
                       const float* an, const float* cn, const float* keep, const float* weight, const uint8_t* gen,
                       float* x_next, int batch, int nfe, int tokens, int64_t frame_elems, void* stream);
 
+/* same with weight[NFE][T]: one composition weight per (branch, token) -- History Guidance with several gen segments
+ * (history_guidance.py:545-568: excluded gen tokens contribute 0, the sum is divided by the number of segments covering the token) */
+int dfot_ddim_compose_tokw(const float* x, const float* x_in, const float* v, const float* sa, const float* s1,
+                           const float* an, const float* cn, const float* keep, const float* weight, const uint8_t* gen,
+                           float* x_next, int batch, int nfe, int tokens, int64_t frame_elems, void* stream);
+
 /* ---- denoising loss of one noised forward (training_step / validation denoising loss) -------------------------- */
 /* replaces ContinuousDiffusion.forward's frame arithmetic (diffusion/continuous_diffusion.py:140-167):
  *   x_t = alpha*x + sigma*noise ; eps_hat = alpha*v + sigma*x_t ; loss[b,t] = mean_frame( weight*(eps_hat-noise)^2 ) ;

@@ -5,7 +5,7 @@ Restates algorithms/dfot/history_guidance.py:
   * HistoryGuidanceManager.__enter__ / prepare / compose    -- :357-568
   * SimpleHistoryGuidanceManager.prepare / compose          -- :929-982
   * manager dispatch rule                                   -- :635-653
-  * scheme constructors conditional / vanilla / stabilized_* / fractional -- :700-835
+  * scheme constructors conditional / vanilla / stabilized_* / fractional / temporal / custom -- :700-900
 
 A *scheme* is (segments, weights, use_cond_guidance) with each segment =
 (time_indices|"all", freq_ranges, freq_ranges_if_generated).  A *branch* is one model
@@ -67,6 +67,14 @@ def make_scheme(name: str, timesteps: int = 1000, **kw) -> Scheme:
         segs = [Segment(ALL, (ALL,), ((kw["stabilization_level"], 1.0),)),
                 Segment(ALL, ((kw["freq_scale"], 1.0),))]
         return Scheme(segs, [1, kw["guidance_scale"] - 1], ucg, timesteps=timesteps)
+    if name == "temporal":  # :832-859
+        segs = [Segment(time_indices=ALL if sub == ALL else list(sub)) for sub in kw["hist_subsequences"]]
+        return Scheme(segs, list(kw["hist_weights"]), ucg, gen_segments=kw.get("gen_segments") or (ALL,), timesteps=timesteps)
+    if name == "custom":  # :861-900
+        tup = lambda r: None if r is None else tuple(ALL if x == ALL else tuple(x) for x in r)
+        segs = [Segment(ALL if d["time_indices"] == ALL else list(d["time_indices"]), tup(d["freq_ranges"]),
+                        tup(d.get("freq_ranges_if_generated"))) for d in kw["hist_segments"]]
+        return Scheme(segs, list(kw["hist_weights"]), ucg, gen_segments=kw.get("gen_segments") or (ALL,), timesteps=timesteps)
     raise ValueError(f"oracle: unsupported history guidance scheme {name}")
 
 

@@ -352,3 +352,21 @@ def test_report_torch_eager_time_on_this_gpu():
     print(f"\n[orientation] DiT/XL forward of 8 videos on this GPU: torch eager bf16 {t_eager:.1f} ms, HIP engine {t_hip:.1f} ms "
           f"({t_eager / t_hip:.2f}x); rel-L2 between the two {r:.2e}")
     assert r < 5e-2
+
+
+def test_temporal_guidance_sampler_vs_reference_fixture():
+    """History Guidance with history sub-sequences and two gen segments (excluded tokens shown as fresh noise at level T-1,
+    per-(branch, token) composition weights) through the device sampler, against the reference's recorded run."""
+    import dfot_amd
+    g = load("hg_temporal.npz")
+    _, _, small = tiny_cfgs()
+    params, model = build(small, 4)
+    assert digest(params) == str(g["digest"])
+    nfn = ReplayList([T(g[f"pred_noise{i}"]) for i in range(int(g["pred_n_noise"]))])
+    hgc = dict(name="temporal", hist_subsequences=[[0], [1], [0, 1]], hist_weights=[0.5, 0.5, 1.0], gen_segments=[[0, 1], [1, 2]])
+    cfg = dfot_amd.SamplerConfig(x_shape=(4, 16, 8), max_tokens=5,
+                                 diffusion=dfot_amd.DiffusionConfig(sampling_timesteps=3, beta_schedule="cosine", is_continuous=False),
+                                 prediction_guidance=hgc)
+    out = dfot_amd.DFoTVideoSampler(cfg, model, nfn)._predict_videos(T(g["vid"]).cuda(), n_context_tokens=2, conditions=None).cpu()
+    assert not nfn.queue
+    assert psnr(out, T(g["pred"])) >= 35.0

@@ -84,9 +84,15 @@ def test_ddim_coefficients_reproduce_reference_step():
     assert np.allclose(an[to < 0], 1.0) and np.allclose(cn[to < 0], 0.0)
 
 
-def test_temporal_guidance_is_rejected():
+def test_temporal_guidance_with_camera_poses_is_rejected():
+    """the reference re-interpolates the poses of masked frames for this scheme (slerp): not built, refused loudly"""
+    import torch
+    import dfot_amd
+    hg = HistoryGuidance.temporal(hist_subsequences=[[0]], hist_weights=[1.0])
+    sampler = dfot_amd.DFoTVideoPoseSampler(dfot_amd.SamplerConfig(x_shape=(3, 16, 16)), backbone=None)
     with pytest.raises(NotImplementedError):
-        HistoryGuidance([__import__("dfot_amd").guidance.HistorySegment(time_indices=[0])], [1.0])
+        sampler._sample_sequence(1, context=torch.zeros(1, 8, 3, 16, 16), context_mask=torch.zeros(1, 8, dtype=torch.long),
+                                 conditions=torch.zeros(1, 8, 16), history_guidance=hg)
 
 
 @pytest.mark.parametrize("kind", ["interleaved", "gibbs", "autoregressive"])
@@ -115,3 +121,28 @@ def test_discrete_loss_weights_match_reference():
     np.testing.assert_allclose(s.loss_weights(k, "fused_min_snr", cum_snr_decay=0.9), g["w_fused_090"], rtol=1e-4, atol=5e-7)
     np.testing.assert_allclose(s.loss_weights(k, "min_snr"), g["w_min_snr"], rtol=1e-4, atol=5e-7)
     np.testing.assert_allclose(s.loss_weights(k, "uniform"), g["w_uniform"])
+
+
+def test_temporal_and_custom_guidance_plans_match_reference():
+    """History sub-sequences (time_indices) and several gen segments: branch levels, excluded tokens and per-token weights."""
+    g = np.load(os.path.join(GOLDEN, "hg_temporal.npz"))
+    schemes = {
+        "temporal": dict(name="temporal", hist_subsequences=[[0], [1], [0, 1]], hist_weights=[0.5, 0.5, 1.0], gen_segments=[[0, 1], [1, 2]]),
+        "custom": dict(name="custom", hist_segments=[dict(time_indices=[0, -1], freq_ranges=[[0.0, 1.0], [0.3, 1.0]],
+                                                          freq_ranges_if_generated=[[0.1, 1.0]])], hist_weights=[2.0]),
+    }
+    for sname, sc in schemes.items():
+        hg = HistoryGuidance.from_config(sc, timesteps=1000)
+        assert not hg.is_simple
+        plan = hg.plan(g["cmask"], g["frm"], g["to"])
+        assert plan.nfe == int(g[f"{sname}_nfe"])
+        assert np.array_equal(plan.levels.reshape(-1, 5), g[f"{sname}_from"])
+        assert np.array_equal(plan.to_levels.reshape(-1, 5), g[f"{sname}_to"])
+    plan = HistoryGuidance.from_config(schemes["temporal"], timesteps=1000).plan(g["cmask"], g["frm"], g["to"])
+    assert plan.n_gen == 2 and plan.tok_weights.shape == (plan.nfe, 5)
+    # gen token 1 (sequence position 3) is covered by both segments -> its weights are halved; excluded tokens weigh 0
+    w = plan.tok_weights.reshape(-1, 2, 5)
+    assert np.allclose(w[:, 0, 4], 0) and np.allclose(w[:, 1, 2], 0)
+    assert np.allclose(w[:, 0, 3], 0.5 * w[:, 0, 2]) and np.allclose(w[:, 1, 3], 0.5 * w[:, 1, 4])
+    assert plan.excluded[0, 0].tolist() == [False, False, False, False, True]
+    assert plan.excluded[0, 1].tolist() == [False, False, True, False, False]

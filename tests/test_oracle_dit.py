@@ -159,3 +159,46 @@ def test_discrete_loss_weights_and_loss_vs_reference_fixture():
                                               strategy="fused_min_snr", cum_snr_decay=0.96)
     np.testing.assert_allclose(x_pred.numpy(), g["x_pred"], rtol=1e-3, atol=1e-3)
     np.testing.assert_allclose(loss.numpy(), g["loss"], rtol=1e-3, atol=1e-5)
+
+
+# ---- temporal / custom History Guidance (history sub-sequences, several gen segments) ----------------------------------
+HG_TEMPORAL = {
+    "temporal": dict(name="temporal", hist_subsequences=[[0], [1], [0, 1]], hist_weights=[0.5, 0.5, 1.0], gen_segments=[[0, 1], [1, 2]]),
+    "custom": dict(name="custom", hist_segments=[dict(time_indices=[0, -1], freq_ranges=[[0.0, 1.0], [0.3, 1.0]],
+                                                      freq_ranges_if_generated=[[0.1, 1.0]])],
+                   hist_weights=[2.0], gen_segments=None),
+}
+
+
+def _small_diffusion(steps=50):
+    p = odit.seeded_params(SMALL, 4)
+    model = lambda x, k, c, m: odit.forward(p, SMALL, x, k)
+    return p, osm.Diffusion(sch.build_tables(beta_schedule="cosine"), model, sampling_timesteps=steps, is_continuous=False)
+
+
+def test_temporal_and_custom_guidance_step_vs_reference_fixture():
+    from oracle import guidance as ohg
+    g = load("hg_temporal.npz")
+    p, diff = _small_diffusion()
+    assert digest(p) == str(g["digest"])
+    for sname, sc in HG_TEMPORAL.items():
+        nfn = osm.replay_noise_fn([T(g[f"{sname}_noise{i}"]) for i in range(int(g[f"{sname}_n_noise"]))])
+        gd = ohg.Guidance(ohg.make_scheme(**sc), T(g["cmask"]))
+        assert gd.nfe == int(g[f"{sname}_nfe"])
+        x_in, f_in, t_in, cm = gd.prepare(T(g["xs"]), T(g["frm"]), T(g["to"]), diff.q_sample, nfn)
+        np.testing.assert_allclose(x_in.numpy(), g[f"{sname}_x_in"], rtol=1e-6, atol=1e-6)
+        assert np.array_equal(f_in.numpy(), g[f"{sname}_from"]) and np.array_equal(t_in.numpy(), g[f"{sname}_to"])
+        x_out = diff.ddim_step(x_in, f_in, t_in, None, cm, nfn("ddim", tuple(x_in.shape)))
+        np.testing.assert_allclose(x_out.numpy(), g[f"{sname}_x_out"], rtol=1e-4, atol=1e-4)
+        np.testing.assert_allclose(gd.compose(x_out).numpy(), g[f"{sname}_x_composed"], rtol=1e-4, atol=5e-4)
+        assert not nfn.queue
+
+
+def test_temporal_guidance_sampler_vs_reference_fixture():
+    g = load("hg_temporal.npz")
+    _, diff = _small_diffusion(steps=3)
+    nfn = osm.replay_noise_fn([T(g[f"pred_noise{i}"]) for i in range(int(g["pred_n_noise"]))])
+    cfg = osm.SamplerConfig(x_shape=(4, 16, 8), max_tokens=5, sampling_timesteps=3, prediction_guidance=HG_TEMPORAL["temporal"])
+    out = osm.Sampler(cfg, diff, None, nfn).predict_videos(T(g["vid"]), 2, None)
+    assert not nfn.queue
+    np.testing.assert_allclose(out.numpy(), g["pred"], rtol=1e-3, atol=2e-3)

@@ -16,6 +16,8 @@ loaded strictly into the reference module and re-created bit-identically by the 
                     4 merged tokens, 3 DDIM steps, vanilla history guidance 1.5, tiny difference model) -> unmerge_tensors
   discrete_loss.npz DiscreteDiffusion.forward (pred_v, cosine) on the small DiT with injected noise: x_pred, weighted loss, and
                     compute_loss_weights for fused_min_snr (decay 0.96 / 0.9), min_snr, sigmoid, uniform
+  hg_temporal.npz   temporal / custom History Guidance (history sub-sequences, several gen segments) on the small DiT: one
+                    prepare -> sample_step -> compose per scheme, and DFoTVideo._predict_videos with the temporal scheme
   sampler_k600.npz  DFoTVideo._predict_videos with DiscreteDiffusion (cosine, pred_v, integer levels): 5 tokens,
                     context 2, 4 DDIM steps, vanilla history guidance 2.0 (small DiT) with the injected noise
 """
@@ -108,6 +110,52 @@ def video_cfg(A, ocfg: odit.DiTConfig, sampling_steps: int, hg: dict):
                       hidden_size=ocfg.hidden_size, depth=ocfg.depth, num_heads=ocfg.num_heads, mlp_ratio=4.0,
                       use_gradient_checkpointing=False),
     ))
+
+
+HG_TEMPORAL = {
+    "temporal": dict(name="temporal", hist_subsequences=[[0], [1], [0, 1]], hist_weights=[0.5, 0.5, 1.0], gen_segments=[[0, 1], [1, 2]]),
+    "custom": dict(name="custom", hist_segments=[dict(time_indices=[0, -1], freq_ranges=[[0.0, 1.0], [0.3, 1.0]],
+                                                      freq_ranges_if_generated=[[0.1, 1.0]])],
+                   hist_weights=[2.0], gen_segments=None),
+}
+
+
+@torch.no_grad()
+def hg_temporal_fixture(R):
+    print("history guidance: temporal / custom")
+    A = R["AttrDict"]
+    small = odit.DiTConfig(hidden_size=128, depth=2, num_heads=4, patch_size=1, in_channels=4, resolution=(16, 8), max_tokens=5)
+    cfg = video_cfg(A, small, sampling_steps=3, hg=HG_TEMPORAL["temporal"])
+    algo = R["DFoTVideo"](cfg).eval()
+    ps = odit.seeded_params(small, 4)
+    algo.diffusion_model.model.load_state_dict(ps, strict=True)
+    dm = algo.diffusion_model
+    g = torch.Generator().manual_seed(12)
+    xs = torch.randn(2, 5, 4, 16, 8, generator=g)
+    cmask = torch.tensor([[1, 2, 0, 0, 0]] * 2)
+    frm = torch.tensor([[-1, -1, 499, 499, 499]] * 2)
+    to = torch.tensor([[-1, -1, 479, 479, 479]] * 2)
+    out = dict(xs=xs, cmask=cmask, frm=frm, to=to, digest=np.array(weights_digest(ps)))
+    for sname, sc in HG_TEMPORAL.items():
+        hgo = R["HistoryGuidance"].from_config(A(dict({k: v for k, v in sc.items() if v is not None}, visualize=False)), timesteps=1000)
+        with RandnRecorder() as rec:
+            with hgo(cmask) as mgr:
+                xi, fi, ti, cm = mgr.prepare(xs.clone(), frm.clone(), to.clone(), replacement_fn=dm.q_sample, replacement_only=False)
+                xo = dm.sample_step(xi, fi, ti, None, cm)
+                xc = mgr.compose(xo)
+            out[f"{sname}_nfe"] = np.array(mgr.nfe)
+        out.update({f"{sname}_x_in": xi, f"{sname}_from": fi, f"{sname}_to": ti, f"{sname}_x_out": xo, f"{sname}_x_composed": xc,
+                    f"{sname}_n_noise": np.array(len(rec.draws))})
+        for i, d in enumerate(rec.draws):
+            out[f"{sname}_noise{i}"] = d
+    vid = torch.randn(2, 5, 4, 16, 8, generator=g)
+    algo.generator = torch.Generator().manual_seed(0)
+    with RandnRecorder() as rec:
+        pred = algo._predict_videos(vid.clone(), n_context_tokens=2, conditions=None)
+    out.update(vid=vid, pred=pred, pred_n_noise=np.array(len(rec.draws)))
+    for i, d in enumerate(rec.draws):
+        out[f"pred_noise{i}"] = d
+    save("hg_temporal.npz", **out)
 
 
 @torch.no_grad()
@@ -204,6 +252,7 @@ def main():
          alphas_cumprod=dm.alphas_cumprod, sqrt_alphas_cumprod=dm.sqrt_alphas_cumprod,
          sqrt_one_minus_alphas_cumprod=dm.sqrt_one_minus_alphas_cumprod, **arrays)
     diff_sampler_fixture(R)
+    hg_temporal_fixture(R)
     print("discrete loss")
     g = torch.Generator().manual_seed(10)
     xt = torch.randn(2, 5, 4, 16, 8, generator=g)
