@@ -10,4 +10,5 @@ from .guidance import HistoryGuidance  # noqa: F401
 from .sampler import (DFoTVideoPoseSampler, DFoTVideoSampler, DifferenceDFoTVideoSampler, SamplerConfig,  # noqa: F401
                       device_noise_fn)  # noqa: F401
 from . import parallel  # noqa: F401,E402
+from .training import ContextTraining, TrainingNoise, training_step_forward  # noqa: F401,E402
 from .checkpoint import load_reference_checkpoint  # noqa: F401,E402

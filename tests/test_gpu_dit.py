@@ -370,3 +370,30 @@ def test_temporal_guidance_sampler_vs_reference_fixture():
     out = dfot_amd.DFoTVideoSampler(cfg, model, nfn)._predict_videos(T(g["vid"]).cuda(), n_context_tokens=2, conditions=None).cpu()
     assert not nfn.queue
     assert psnr(out, T(g["pred"])) >= 35.0
+
+
+def test_training_step_forward_discrete():
+    """training_step up to the loss (noise levels -> noised forward -> fused-min-SNR loss -> masked mean) vs the oracle."""
+    import dfot_amd
+    from oracle import dit as odit, sampler as osm, schedule as sch
+    _, _, small = tiny_cfgs()
+    params, model = build(small, 2)
+    cfg = dfot_amd.SamplerConfig(x_shape=(4, 16, 8), max_tokens=5,
+                                 diffusion=dfot_amd.DiffusionConfig(beta_schedule="cosine", is_continuous=False))
+    sampler = dfot_amd.DFoTVideoSampler(cfg, model)
+    gen = torch.Generator().manual_seed(3)
+    xs = torch.randn(3, 5, 4, 16, 8, generator=gen)
+    noise = torch.randn(3, 5, 4, 16, 8, generator=gen)
+    masks = torch.ones(3, 5, dtype=torch.bool)
+    masks[2, 4:] = False
+    tn = dfot_amd.TrainingNoise(noise_level="random_independent", is_continuous=False, n_context_tokens=2,
+                                variable_context=dfot_amd.ContextTraining(enabled=True, prob=0.25, dropout=0.3))
+    lw = dict(strategy="fused_min_snr", cum_snr_decay=0.96)
+    out = dfot_amd.training_step_forward(sampler, xs.cuda(), masks, tn, generator=torch.Generator().manual_seed(5), noise=noise.cuda(),
+                                         loss_weighting=lw)
+    levels, loss_masks = tn.sample(3, 5, masks, torch.Generator().manual_seed(5))
+    assert torch.equal(out["noise_levels"], levels)
+    tb = sch.build_tables(beta_schedule="cosine")
+    _, ref_loss = osm.discrete_training_loss(lambda x, k, c, m: odit.forward(params, small, x, k), tb, xs, levels, noise.clamp(-20, 20), **lw)
+    ref = (ref_loss.flatten(2).mean(-1) * loss_masks.float()).mean()
+    assert abs(out["loss"].item() - ref.item()) < 2e-2 * abs(ref.item())

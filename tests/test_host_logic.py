@@ -146,3 +146,24 @@ def test_temporal_and_custom_guidance_plans_match_reference():
     assert np.allclose(w[:, 0, 3], 0.5 * w[:, 0, 2]) and np.allclose(w[:, 1, 3], 0.5 * w[:, 1, 4])
     assert plan.excluded[0, 0].tolist() == [False, False, False, False, True]
     assert plan.excluded[0, 1].tolist() == [False, False, True, False, False]
+
+
+def test_training_noise_levels_match_reference():
+    """_get_training_noise_levels with a seeded CPU generator: identical draws, context handling and loss masks."""
+    import torch
+    from dfot_amd import ContextTraining, TrainingNoise
+    g = np.load(os.path.join(GOLDEN, "training_noise.npz"))
+    cases = {
+        "indep": dict(noise_level="random_independent"),
+        "uniform": dict(noise_level="random_uniform"),
+        "interleaved": dict(noise_level="interleaved"),
+        "ufuture": dict(noise_level="random_independent", uniform_future=True),
+        "fixed": dict(noise_level="random_independent", fixed_context=ContextTraining(enabled=True, dropout=0.5)),
+        "variable": dict(noise_level="random_uniform", variable_context=ContextTraining(enabled=True, prob=0.25, dropout=0.3)),
+    }
+    for tag, cont, nt, mkey in (("c", True, 8, "masks8"), ("d", False, 5, "masks5")):
+        for name, kw in cases.items():
+            tn = TrainingNoise(is_continuous=cont, n_context_tokens=int(g[f"{tag}_n_context"]), **kw)
+            lv, mk = tn.sample(3, nt, torch.from_numpy(g[mkey]), torch.Generator().manual_seed(123), training=True)
+            assert np.array_equal(lv.numpy(), g[f"{tag}_{name}_levels"]), (tag, name)
+            assert np.array_equal(mk.numpy(), g[f"{tag}_{name}_masks"]), (tag, name)

@@ -18,6 +18,9 @@ loaded strictly into the reference module and re-created bit-identically by the 
                     compute_loss_weights for fused_min_snr (decay 0.96 / 0.9), min_snr, sigmoid, uniform
   hg_temporal.npz   temporal / custom History Guidance (history sub-sequences, several gen segments) on the small DiT: one
                     prepare -> sample_step -> compose per scheme, and DFoTVideo._predict_videos with the temporal scheme
+  training_noise.npz  BaseVideoAlgo._get_training_noise_levels (continuous RE10K-style algo and discrete K600-style algo) for
+                    random_independent / random_uniform / interleaved / uniform_future / fixed_context / variable_context,
+                    generator seed 123
   sampler_k600.npz  DFoTVideo._predict_videos with DiscreteDiffusion (cosine, pred_v, integer levels): 5 tokens,
                     context 2, 4 DDIM steps, vanilla history guidance 2.0 (small DiT) with the injected noise
 """
@@ -118,6 +121,44 @@ HG_TEMPORAL = {
                                                       freq_ranges_if_generated=[[0.1, 1.0]])],
                    hist_weights=[2.0], gen_segments=None),
 }
+
+
+TRAIN_NOISE_CASES = {
+    "indep": dict(noise_level="random_independent"),
+    "uniform": dict(noise_level="random_uniform"),
+    "interleaved": dict(noise_level="interleaved"),
+    "ufuture": dict(noise_level="random_independent", uniform_future=True),
+    "fixed": dict(noise_level="random_independent", fixed=dict(enabled=True, indices=None, dropout=0.5)),
+    "variable": dict(noise_level="random_uniform", variable=dict(enabled=True, prob=0.25, dropout=0.3)),
+}
+
+
+@torch.no_grad()
+def training_noise_fixture(R):
+    import types
+    import make_golden as MG
+    print("training noise levels")
+    A = R["AttrDict"]
+    algo_c, _, _ = MG.build_algo(R, MG.algo_cfg(A, 16, MG.TINY))  # continuous, 8 tokens, 1 context token
+    small = odit.DiTConfig(hidden_size=128, depth=2, num_heads=4, patch_size=1, in_channels=4, resolution=(16, 8), max_tokens=5)
+    algo_d = R["DFoTVideo"](video_cfg(A, small, sampling_steps=4, hg=dict(name="conditional"))).eval()  # discrete, 5 tokens, 2 context
+    masks8 = torch.ones(3, 8, dtype=torch.bool)
+    masks8[1, 6:] = False
+    masks5 = torch.ones(3, 5, dtype=torch.bool)
+    masks5[2, 4:] = False
+    out = dict(masks8=masks8, masks5=masks5)
+    for tag, algo, masks, nt in (("c", algo_c, masks8, 8), ("d", algo_d, masks5, 5)):
+        algo.trainer = types.SimpleNamespace(training=True)
+        for name, c in TRAIN_NOISE_CASES.items():
+            algo.cfg["noise_level"] = c["noise_level"]
+            algo.cfg["uniform_future"] = A(dict(enabled=bool(c.get("uniform_future"))))
+            algo.cfg["fixed_context"] = A(c.get("fixed", dict(enabled=False, indices=None, dropout=0)))
+            algo.cfg["variable_context"] = A(c.get("variable", dict(enabled=False, prob=0.25, dropout=0.3)))
+            algo.generator = torch.Generator().manual_seed(123)
+            lv, mk = algo._get_training_noise_levels(torch.zeros(3, nt, 4, 2, 2), masks.clone())
+            out[f"{tag}_{name}_levels"], out[f"{tag}_{name}_masks"] = lv, mk
+        out[f"{tag}_n_context"] = np.array(algo.n_context_tokens)
+    save("training_noise.npz", **out)
 
 
 @torch.no_grad()
@@ -253,6 +294,7 @@ def main():
          sqrt_one_minus_alphas_cumprod=dm.sqrt_one_minus_alphas_cumprod, **arrays)
     diff_sampler_fixture(R)
     hg_temporal_fixture(R)
+    training_noise_fixture(R)
     print("discrete loss")
     g = torch.Generator().manual_seed(10)
     xt = torch.randn(2, 5, 4, 16, 8, generator=g)
