@@ -182,6 +182,7 @@ class UViT3DPose(nn.Module):
             torch.cuda.synchronize()
             capi.check(capi.lib.dfot_uvit_reserve(self._handle, int(batch)))
             self._reserved = batch
+            self.reserve_generation = getattr(self, "reserve_generation", 0) + 1  # workspace pointers changed
             self._cond_key = None
 
     # ------------------------------------------------------------------ forward

@@ -473,7 +473,11 @@ int launch_final_layer(const float* x, const float* table, const int* levels, lo
 #define CALL(V, C)                                                                                                          \
   {                                                                                                                         \
     auto kern = final_layer_kernel<V, C>;                                                                                   \
-    DFOT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds)); \
+    static int lds_set = 0; /* once per instantiation and size (not inside a captured step) */                                \
+    if (lds_set < lds) {                                                                                                    \
+      DFOT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds)); \
+      lds_set = lds;                                                                                                        \
+    }                                                                                                                       \
     hipLaunchKernelGGL(kern, dim3(cdiv(rows, FIN_ROWS)), dim3(256), lds, s, x, table, levels, ldt, off, w, b, out, rows_per_frame, \
                        rows, eps, max_level, c, hh, ww, ps);                                                                \
   }

@@ -157,6 +157,7 @@ class DiT3D(nn.Module):
             torch.cuda.synchronize()
             capi.check(capi.lib.dfot_dit_reserve(self._handle, int(batch)))
             self._reserved = batch
+            self.reserve_generation = getattr(self, "reserve_generation", 0) + 1  # workspace pointers changed
 
     def forward(self, x: torch.Tensor, noise_levels: torch.Tensor, external_cond: Optional[torch.Tensor] = None,
                 external_cond_mask: Optional[torch.Tensor] = None) -> torch.Tensor:

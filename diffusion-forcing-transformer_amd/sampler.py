@@ -69,6 +69,7 @@ class DFoTVideoPoseSampler:
         self.graph_replays = 0
         self.graph_captures = 0
         self._graphs: Dict[tuple, dict] = {}
+        self._graphs_generation = 0
         if cfg.diffusion.ddim_sampling_eta != 0:
             raise NotImplementedError("only deterministic DDIM (eta = 0) is implemented on the device path")
 
@@ -358,6 +359,11 @@ class DFoTVideoPoseSampler:
         p0 = plans[0]
         bm, n_steps, nfe = p0["bm"], len(plans), p0["nfe"]
         need_noise = any(p_["need_noise"] for p_ in plans)
+        self.model.reserve(bm)  # before looking at the generation: a growing workspace invalidates every captured pointer
+        gen = getattr(self.model, "reserve_generation", 0)
+        if gen != self._graphs_generation:
+            self._graphs.clear()
+            self._graphs_generation = gen
         key = (bm, n_steps, nfe, horizon, tuple(xs.shape), need_noise, None if p0["cmask"] is None else p0["cmask"].tobytes(),
                id(self.model))
         ent = self._graphs.get(key)

@@ -237,3 +237,28 @@ def test_other_scheduling_matrices(scheduling):
     p = psnr(out, ref)
     print(f"{scheduling}: PSNR {p:.1f} dB")
     assert torch.isfinite(out).all() and p >= 35.0
+
+
+def test_hipgraph_survives_workspace_growth():
+    """Key-frame windows (model batch 2) are captured first, then interpolation batches need a larger workspace: the
+    reallocation invalidates the captured pointers, so the sampler drops its cached graphs -- result equals the eager loop."""
+    import dfot_amd
+    from dfot_amd import parallel
+    _, _, model = build(blocks=(1, 1, 1), mid=2)
+    res = 64
+    xs = torch.randn(1, 24, 3, res, res, generator=torch.Generator().manual_seed(8))
+    cnd = poses(1, 24, 9)
+    outs = []
+    for use_graph in (False, True):
+        cfg = dfot_amd.SamplerConfig(x_shape=(3, res, res), diffusion=dfot_amd.DiffusionConfig(sampling_timesteps=4),
+                                     prediction_guidance=dict(name="stabilized_vanilla", guidance_scale=4.0, stabilization_level=0.02),
+                                     interpolation_guidance=dict(name="vanilla", guidance_scale=1.5), keyframe_density=0.5,
+                                     interpolation_max_batch_size=4)
+        samp = dfot_amd.DFoTVideoPoseSampler(cfg, model, parallel.WindowKeyedNoise(11))
+        samp.use_graph = use_graph
+        model._reserved = 0  # force the workspace to grow again from the smallest window
+        outs.append(samp._predict_videos(xs, n_context_tokens=1, conditions=cnd).cpu())
+        if use_graph:
+            assert samp.graph_captures >= 2 and samp.graph_replays > 0
+    assert torch.isfinite(outs[0]).all()
+    assert torch.equal(outs[0], outs[1])
