@@ -104,6 +104,23 @@ class Schedule:
             levels = np.concatenate([levels, np.full((levels.shape[0], padding), self.cfg.timesteps - 1, np.int64)], 1)
         return levels
 
+    def refine_scheduling_matrix(self, horizon: int, goback_length: int, n_goback: int, padding: int = 0) -> np.ndarray:
+        """_generate_refine_scheduling_matrix (base_pytorch_video_algo.py:943-970): the full-sequence ladder with, at every
+        goback_length-th index, n_goback excursions goback_length steps back up and down again.  Only the matrix is built --
+        the refinement SAMPLER of the fork (re-noising branch, off by default) is not."""
+        s = self.cfg.sampling_timesteps
+        marks = set(range(1, s - goback_length, goback_length))
+        seq = []
+        for t in range(s, -1, -1):
+            seq.append(t)
+            if t in marks:
+                for _ in range(n_goback):
+                    seq += list(range(t + 1, t + goback_length + 1)) + list(range(t + goback_length - 1, t - 1, -1))
+        levels = np.repeat(self.ddim_idx_to_noise_level(np.asarray(seq))[:, None], horizon, axis=1)
+        if padding > 0:
+            levels = np.concatenate([levels, np.full((levels.shape[0], padding), self.cfg.timesteps - 1, np.int64)], 1)
+        return levels
+
     # ---- per-step coefficient tables (all float32, shape = levels.shape) -------------------
     def model_level(self, k: np.ndarray) -> np.ndarray:
         """what the backbone receives as `noise_levels`: precond_scale * logsnr[clamp(k,0)] (continuous) or the

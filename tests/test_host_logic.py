@@ -167,3 +167,9 @@ def test_training_noise_levels_match_reference():
             lv, mk = tn.sample(3, nt, torch.from_numpy(g[mkey]), torch.Generator().manual_seed(123), training=True)
             assert np.array_equal(lv.numpy(), g[f"{tag}_{name}_levels"]), (tag, name)
             assert np.array_equal(mk.numpy(), g[f"{tag}_{name}_masks"]), (tag, name)
+
+
+def test_refine_scheduling_matrix_matches_reference():
+    g = np.load(os.path.join(GOLDEN, "schedule_extra.npz"))
+    s = Schedule(DiffusionConfig(sampling_timesteps=50))
+    assert np.array_equal(s.refine_scheduling_matrix(5, goback_length=20, n_goback=2, padding=3), g["refine50_5_3"])

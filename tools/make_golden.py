@@ -200,6 +200,9 @@ def main():
         algo7.cfg["scheduling_matrix"] = kind
         extra[f"{kind}_8_0"] = algo7._generate_scheduling_matrix(8, 0)
         extra[f"{kind}_5_3"] = algo7._generate_scheduling_matrix(5, 3)
+    cfg50 = algo_cfg(A, 16, TINY, sampling_steps=50)
+    algo50, _, _ = build_algo(R, cfg50)
+    extra["refine50_5_3"] = algo50._generate_refine_scheduling_matrix(horizon=5, goback_length=20, n_goback=2, padding=3)
     save("schedule_extra.npz", sampling_steps=np.array(7), **extra)
 
     # ---------------------------------------------------------------- ray encoding
