@@ -54,6 +54,8 @@ def cpu_baseline(res: int, sample_forwards: int, frames: int, forwards_per_sampl
     cond = opose.ray_encoding(synth_poses(1, 8, 7), res)
     cores = min(16, os.cpu_count() or 1)  # a 1-GPU box has a 16-core CPU share
     torch.set_num_threads(cores)
+    ouvit.USE_SDPA = True  # the reference's own attention call (F.scaled_dot_product_attention); the explicit-softmax form
+    #                        the parity tests use is 2.4x slower on a CPU (tools/time_reference_cpu.py)
     t0 = time.perf_counter()
     with torch.no_grad():
         for _ in range(sample_forwards):
