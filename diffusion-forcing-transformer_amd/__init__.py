@@ -3,6 +3,7 @@
 reference's backbone / sampler interfaces.  Importing it requires the built HIP library --
 there is no CPU fallback."""
 from . import capi  # noqa: F401  (raises ImportError when libdfot_hip.so is missing)
+from . import ops  # noqa: F401  (registers the torch.library operators dfot::*)
 from .backbone import UViT3DPose  # noqa: F401
 from .dit_backbone import DiT3D, DifferenceDiT3D  # noqa: F401
 from .diffusion import DiffusionConfig, Schedule  # noqa: F401

@@ -20,7 +20,7 @@ from typing import Dict, Optional, Sequence, Tuple
 import torch
 from torch import nn
 
-from . import capi
+from . import capi, ops
 
 
 def _get(cfg, key, default=None):
@@ -82,6 +82,7 @@ class UViT3DPose(nn.Module):
             self._names.append(name)
         self._synced: Optional[Tuple] = None
         self._reserved = 0
+        self._op_key: Optional[int] = None
         self._cond_key = None
         self._cond_refs = None
 
@@ -188,6 +189,14 @@ class UViT3DPose(nn.Module):
     # ------------------------------------------------------------------ forward
     def forward(self, x: torch.Tensor, noise_levels: torch.Tensor, external_cond: Optional[torch.Tensor] = None,
                 external_cond_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """BaseBackbone.forward; dispatched as the torch operator ``dfot::uvit3d_pose_forward`` (ops.py)."""
+        assert external_cond is not None, "External condition (camera pose) is required for U-ViT3DPose model."
+        if self._op_key is None:
+            self._op_key = ops.register_model(self)
+        return torch.ops.dfot.uvit3d_pose_forward(x, noise_levels, external_cond, external_cond_mask, self._op_key)
+
+    def _forward_impl(self, x: torch.Tensor, noise_levels: torch.Tensor, external_cond: Optional[torch.Tensor] = None,
+                      external_cond_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
         assert x.shape[1] == self.temporal_length, (
             f"Temporal length of U-ViT is set to {self.temporal_length}, but input has temporal length {x.shape[1]}.")
         assert external_cond is not None, "External condition (camera pose) is required for U-ViT3DPose model."

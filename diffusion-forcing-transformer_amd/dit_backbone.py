@@ -19,7 +19,7 @@ from typing import Dict, Optional, Sequence, Tuple
 import torch
 from torch import nn
 
-from . import capi
+from . import capi, ops
 from .backbone import _Node, _get
 
 
@@ -63,6 +63,7 @@ class DiT3D(nn.Module):
             self._names.append(name)
         self._synced: Optional[Tuple] = None
         self._reserved = 0
+        self._op_key: Optional[int] = None
 
     def _configure(self, c: "capi.DiTConfig", cfg, max_tokens: int) -> None:
         """dit3d.yaml keys -> engine config (variant 0)."""
@@ -161,8 +162,14 @@ class DiT3D(nn.Module):
 
     def forward(self, x: torch.Tensor, noise_levels: torch.Tensor, external_cond: Optional[torch.Tensor] = None,
                 external_cond_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """BaseBackbone.forward; dispatched as the torch operator ``dfot::dit3d_forward`` (ops.py)."""
         if external_cond is not None:
             raise ValueError("this DiT3D was built without an external condition embedding")
+        if self._op_key is None:
+            self._op_key = ops.register_model(self)
+        return torch.ops.dfot.dit3d_forward(x, noise_levels, self._op_key)
+
+    def _forward_impl(self, x: torch.Tensor, noise_levels: torch.Tensor) -> torch.Tensor:
         if x.ndim != 5 or tuple(x.shape[2:]) != self.x_shape:
             raise ValueError(f"x has shape {tuple(x.shape)}, expected (B, T, {', '.join(map(str, self.x_shape))})")
         b, t = x.shape[:2]

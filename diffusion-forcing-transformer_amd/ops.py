@@ -1,0 +1,111 @@
+"""torch.library registration of the engine's entry points (namespace ``dfot``).
+
+The reference is a PyTorch program; its natural plug-in surface is a set of torch operators.  Each operator below is a thin
+shim over one C-ABI call of libdfot_hip.so (``capi``) with a fake ("meta") implementation for shape inference, so that
+FakeTensor tracing, ``torch.compile`` graphs and stream capture treat the HIP kernels as opaque ops:
+
+    dfot::uvit3d_pose_forward(x, noise_levels, external_cond, external_cond_mask?, model) -> v      [dfot_uvit_forward]
+    dfot::dit3d_forward(x, noise_levels, model) -> v                                                [dfot_dit_forward]
+    dfot::ray_encoding(raw_poses, resolution) -> cond                                               [dfot_ray_encode]
+    dfot::hg_prepare(x, noise?, qa, qb, nfe) -> x_in                                                [dfot_hg_prepare]
+    dfot::ddim_hg_step(x, x_in, v, sa, s1, an, cn, keep, weight, gen, nfe) -> x_next                [dfot_ddim_compose / _tokw]
+
+``model`` is an integer key of a live backbone module (``register_model``): operators take tensors and scalars only.
+The nn.Module mirrors (`UViT3DPose`, `DiT3D`, `DifferenceDiT3D`) dispatch their ``forward`` through these operators and the
+sampler's ``_process_conditions`` through ``dfot::ray_encoding``; the sampler's step loop calls the same C entry points
+directly (it re-uses its output buffers across steps), ``dfot::hg_prepare`` / ``dfot::ddim_hg_step`` are the functional forms
+for a host that drives the step itself.
+"""
+from __future__ import annotations
+
+import weakref
+from typing import Optional
+
+import torch
+from torch import Tensor
+from torch.library import custom_op
+
+from . import capi
+
+_MODELS: "weakref.WeakValueDictionary[int, torch.nn.Module]" = weakref.WeakValueDictionary()
+
+
+def register_model(module: torch.nn.Module) -> int:
+    key = id(module)
+    _MODELS[key] = module
+    return key
+
+
+def _model(key: int):
+    try:
+        return _MODELS[key]
+    except KeyError:
+        raise RuntimeError(f"dfot: backbone {key} is not registered (or was garbage-collected)") from None
+
+
+@custom_op("dfot::uvit3d_pose_forward", mutates_args=())
+def uvit3d_pose_forward(x: Tensor, noise_levels: Tensor, external_cond: Tensor, external_cond_mask: Optional[Tensor],
+                        model: int) -> Tensor:
+    return _model(model)._forward_impl(x, noise_levels, external_cond, external_cond_mask)
+
+
+@uvit3d_pose_forward.register_fake
+def _(x, noise_levels, external_cond, external_cond_mask, model):
+    return torch.empty_like(x)
+
+
+@custom_op("dfot::dit3d_forward", mutates_args=())
+def dit3d_forward(x: Tensor, noise_levels: Tensor, model: int) -> Tensor:
+    return _model(model)._forward_impl(x, noise_levels)
+
+
+@dit3d_forward.register_fake
+def _(x, noise_levels, model):
+    return torch.empty_like(x)
+
+
+@custom_op("dfot::ray_encoding", mutates_args=())
+def ray_encoding(raw_poses: Tensor, resolution: int) -> Tensor:
+    b, t = raw_poses.shape[:2]
+    raw = raw_poses.detach().to(device="cuda", dtype=torch.float32).contiguous()
+    out = torch.empty(b, t, 180, resolution, resolution, device="cuda", dtype=torch.float32)
+    capi.check(capi.lib.dfot_ray_encode(capi.ptr(raw), capi.ptr(out), b, t, resolution, capi.stream_ptr()))
+    return out
+
+
+@ray_encoding.register_fake
+def _(raw_poses, resolution):
+    b, t = raw_poses.shape[:2]
+    return raw_poses.new_empty((b, t, 180, resolution, resolution), dtype=torch.float32)
+
+
+@custom_op("dfot::hg_prepare", mutates_args=())
+def hg_prepare(x: Tensor, noise: Optional[Tensor], qa: Tensor, qb: Tensor, nfe: int) -> Tensor:
+    b, t = x.shape[:2]
+    f = x[0, 0].numel()
+    x_in = torch.empty(b * nfe, *x.shape[1:], device=x.device, dtype=torch.float32)
+    capi.check(capi.lib.dfot_hg_prepare(capi.ptr(x), capi.ptr(noise), capi.ptr(qa), capi.ptr(qb), capi.ptr(x_in), b, nfe, t, f,
+                                        capi.stream_ptr()))
+    return x_in
+
+
+@hg_prepare.register_fake
+def _(x, noise, qa, qb, nfe):
+    return x.new_empty((x.shape[0] * nfe, *x.shape[1:]))
+
+
+@custom_op("dfot::ddim_hg_step", mutates_args=())
+def ddim_hg_step(x: Tensor, x_in: Tensor, v: Tensor, sa: Tensor, s1: Tensor, an: Tensor, cn: Tensor, keep: Tensor,
+                 weight: Tensor, gen: Tensor, nfe: int) -> Tensor:
+    b, t = x.shape[:2]
+    f = x[0, 0].numel()
+    x_next = torch.empty_like(x)
+    fn = capi.lib.dfot_ddim_compose_tokw if weight.ndim == 2 else capi.lib.dfot_ddim_compose
+    capi.check(fn(capi.ptr(x), capi.ptr(x_in), capi.ptr(v), capi.ptr(sa), capi.ptr(s1), capi.ptr(an), capi.ptr(cn), capi.ptr(keep),
+                  capi.ptr(weight), capi.ptr(gen), capi.ptr(x_next), b, nfe, t, f, capi.stream_ptr()))
+    return x_next
+
+
+@ddim_hg_step.register_fake
+def _(x, x_in, v, sa, s1, an, cn, keep, weight, gen, nfe):
+    return torch.empty_like(x)

@@ -78,14 +78,9 @@ class DFoTVideoPoseSampler:
     def _process_conditions(self, conditions: Optional[torch.Tensor], noise_levels=None) -> Optional[torch.Tensor]:
         if conditions is None:
             return None
-        b, t = conditions.shape[:2]
-        raw = conditions.detach().to(device="cuda", dtype=torch.float32).contiguous()
-        if raw.shape[-1] != 16:
-            raise ValueError(f"raw camera poses must have 16 values per frame, got {raw.shape[-1]}")
-        res = self.x_shape[-1]
-        out = torch.empty(b, t, 180, res, res, device="cuda", dtype=torch.float32)
-        capi.check(capi.lib.dfot_ray_encode(capi.ptr(raw), capi.ptr(out), b, t, res, capi.stream_ptr()))
-        return out
+        if conditions.shape[-1] != 16:
+            raise ValueError(f"raw camera poses must have 16 values per frame, got {conditions.shape[-1]}")
+        return torch.ops.dfot.ray_encoding(conditions, int(self.x_shape[-1]))
 
     # ------------------------------------------------------------------ denoising loss (no backward)
     @torch.no_grad()

@@ -236,3 +236,31 @@ def test_report_torch_eager_time_on_this_gpu():
     print(f"\n[orientation] window-forward x2 on this GPU: torch eager bf16+SDPA {t_eager:.1f} ms, HIP engine {t_hip:.1f} ms "
           f"({t_eager / t_hip:.2f}x); rel-L2 between the two {r:.2e}")
     assert torch.isfinite(out).all() and r < 5e-2
+
+
+def test_backbone_dispatches_through_torch_operator_and_traces():
+    """forward == torch.ops.dfot.uvit3d_pose_forward; a torch.compile trace (eager backend, full graph) goes through the
+    operator's fake implementation and reproduces the eager result."""
+    import dfot_amd
+    from oracle import pose as opose, uvit as ouvit
+    ocfg = ouvit.UViTConfig(resolution=64, num_updown_blocks=(1, 1, 1), num_mid_blocks=1)
+    params = ouvit.seeded_params(ocfg, 3)
+    cfg = dict(channels=list(ocfg.channels), emb_channels=ocfg.emb_channels, patch_size=2, block_types=list(ocfg.block_types),
+               num_updown_blocks=[1, 1, 1], num_mid_blocks=1, num_heads=ocfg.num_heads, pos_emb_type="rope",
+               use_fourier_noise_embedding=True, conditioning=dict(dim=180))
+    model = dfot_amd.UViT3DPose(cfg, x_shape=(3, 64, 64), max_tokens=8).cuda()
+    model.load_state_dict(params, strict=True)
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(1, 8, 3, 64, 64, generator=g).cuda()
+    k = torch.randn(1, 8, generator=g).cuda()
+    pz = torch.eye(3, 4).reshape(1, 1, 12).repeat(1, 8, 1)
+    pz[..., 3] = torch.linspace(0, 0.5, 8)
+    raw = torch.cat([torch.tensor([0.5, 0.9, 0.5, 0.5]).repeat(1, 8, 1), pz], -1).cuda()
+    with torch.no_grad():
+        cond = torch.ops.dfot.ray_encoding(raw, 64)
+        assert torch.allclose(cond.cpu(), opose.ray_encoding(raw.cpu(), 64), atol=3e-2)
+        eager = model(x, k, cond, None)
+        direct = torch.ops.dfot.uvit3d_pose_forward(x, k, cond, None, model._op_key)
+        assert torch.equal(eager, direct)
+        traced = torch.compile(lambda a, b, c: model(a, b, c, None) * 1.0, backend="eager", fullgraph=True)
+        assert torch.equal(traced(x, k, cond), eager)

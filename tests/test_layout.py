@@ -67,3 +67,25 @@ def test_backbone_refuses_to_run_without_a_gpu():
                num_heads=9, conditioning=dict(dim=180))
     with pytest.raises(dfot_amd.capi.DfotError):
         dfot_amd.UViT3DPose(cfg, x_shape=(3, 64, 64), max_tokens=8)
+
+
+def test_torch_library_operators_are_registered_with_shape_inference():
+    """The engine's entry points are torch operators (namespace dfot) with fake implementations: FakeTensor tracing works
+    without a GPU and without touching the HIP library."""
+    import torch
+    from torch._subclasses.fake_tensor import FakeTensorMode
+    import dfot_amd  # noqa: F401  (registers the operators)
+    for name in ("uvit3d_pose_forward", "dit3d_forward", "ray_encoding", "hg_prepare", "ddim_hg_step"):
+        assert hasattr(torch.ops.dfot, name), name
+    with FakeTensorMode():
+        enc = torch.ops.dfot.ray_encoding(torch.empty(2, 8, 16), 64)
+        assert tuple(enc.shape) == (2, 8, 180, 64, 64)
+        x = torch.empty(2, 8, 3, 64, 64)
+        v = torch.ops.dfot.uvit3d_pose_forward(x, torch.empty(2, 8), enc, None, 0)
+        assert v.shape == x.shape
+        x_in = torch.ops.dfot.hg_prepare(x, None, torch.empty(4, 8), torch.empty(4, 8), 2)
+        assert tuple(x_in.shape) == (4, 8, 3, 64, 64)
+        nxt = torch.ops.dfot.ddim_hg_step(x, x_in, x_in, *(torch.empty(4, 8) for _ in range(5)), torch.empty(2), torch.empty(2, 8, dtype=torch.uint8), 2)
+        assert nxt.shape == x.shape
+        z = torch.empty(3, 5, 16, 16, 16)
+        assert torch.ops.dfot.dit3d_forward(z, torch.empty(3, 5, dtype=torch.long), 0).shape == z.shape
