@@ -53,6 +53,7 @@ struct GemmArgs {
   int dstride = 0;
   float eps = 1e-6f;
   int xcd = 1;  // XCD-aware tile order
+  int persist = 0;  // > 0: persistent workgroups (grid = resident workgroups, each loops over tiles)
 };
 
 enum GemmVariant {

@@ -40,8 +40,8 @@ __device__ __forceinline__ void wait_all_but() {
 // waves per CU and halving the serial k-loop; group 1's accumulators are folded into group 0's through LDS at the end.
 // BKT = K-tile depth: 64 (LDS rows of 128 B) or 32 (rows of 64 B: half the stage size, so a 256x256 tile affords a 4-stage
 // ring -- the two-stage loop is bound by the latency of the ONE prefetch it has in flight, see gemm_pick_variant)
-template <int BM_T, int BN_T, int WTM, int NST, int AMODE, int EPI, bool DMA, int KS = 1, int BKT = BK>
-__global__ __launch_bounds__((BM_T / WTM) * (BN_T / 64) * 64 * KS) void gemm_kernel(GemmArgs g) {
+template <int BM_T, int BN_T, int WTM, int NST, int AMODE, int EPI, bool DMA, int KS, int BKT>
+__device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int tile_index, const int tile_count) {
   static_assert(BKT == 64 || (BKT == 32 && AMODE == A_DENSE && DMA && KS == 1), "K-tile depth");
   constexpr int CPR = BKT / 8;                  // 16-byte chunks per LDS row
   constexpr int RPI = 64 / CPR;                 // rows staged by one wave instruction (1 KiB)
@@ -69,7 +69,7 @@ __global__ __launch_bounds__((BM_T / WTM) * (BN_T / 64) * 64 * KS) void gemm_ker
   char* smem = smem_all + kgroup * (NST * STAGE_BYTES);
   const int wm = wave / WN, wn = wave % WN;
   const int tiles_n = (g.N + BN_T - 1) / BN_T;
-  const int bid = xcd_remap(blockIdx.x, gridDim.x, g.xcd);
+  const int bid = xcd_remap(tile_index, tile_count, g.xcd);
   const int tn = bid % tiles_n, tm = bid / tiles_n;
   const int m0 = tm * BM_T, n0 = tn * BN_T;
   const int nk = g.K / BKT;
@@ -543,6 +543,18 @@ __global__ __launch_bounds__((BM_T / WTM) * (BN_T / 64) * 64 * KS) void gemm_ker
   }
 }
 
+// Kernel = tile loop.  With grid == tile count every workgroup does one tile (the default); a smaller grid (GemmArgs.persist)
+// makes the workgroups persistent: tile, tile + grid, ... -- no workgroup relaunch between the tiles of a CU, and the stores of
+// one tile drain while the next tile's first loads are already in flight.  gridDim.x is a multiple of 8 then, so a tile keeps
+// the XCD its index implies (xcd_remap).
+template <int BM_T, int BN_T, int WTM, int NST, int AMODE, int EPI, bool DMA, int KS = 1, int BKT = BK>
+__global__ __launch_bounds__((BM_T / WTM) * (BN_T / 64) * 64 * KS) void gemm_kernel(GemmArgs g, int tile_count) {
+  for (int tile = blockIdx.x; tile < tile_count; tile += gridDim.x) {
+    gemm_tile<BM_T, BN_T, WTM, NST, AMODE, EPI, DMA, KS, BKT>(g, tile, tile_count);
+    if (tile + (int)gridDim.x < tile_count) __syncthreads();  // the next tile's staging re-uses this tile's epilogue scratch
+  }
+}
+
 template <int BM_T, int BN_T, int WTM, int NST, int AMODE, int EPI, bool DMA, int KS = 1, int BKT = BK>
 static int launch_t(const GemmArgs& g, hipStream_t stream) {
   constexpr int nthreads = (BM_T / WTM) * (BN_T / 64) * 64 * KS;
@@ -552,15 +564,22 @@ static int launch_t(const GemmArgs& g, hipStream_t stream) {
   constexpr int lds = stage_lds > ep_lds ? stage_lds : ep_lds;
   const int tiles = (g.M / BM_T) * ((g.N + BN_T - 1) / BN_T);
   static const int xcd_flag = tuning_flag("GEMM_XCD", 1);
+  static const int persist_flag = tuning_flag("GEMM_PERSIST", 1);  // A/B: +0.6 % RE10K, +2.2 % bash/k600 model
   GemmArgs ga = g;
   ga.xcd = xcd_flag;
+  if (persist_flag) ga.persist = 1;
   auto kern = gemm_kernel<BM_T, BN_T, WTM, NST, AMODE, EPI, DMA, KS, BKT>;
   static bool attr_set = false;
   if (!attr_set) {
     DFOT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3(tiles), dim3(nthreads), lds, stream, ga);
+  int grid = tiles;
+  if (ga.persist > 0 && KS == 1) {
+    const int resident = 256 * (lds <= 80 * 1024 ? 2 : 1);  // workgroups the chip holds at once (LDS-limited)
+    if (tiles > resident) grid = resident;
+  }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(nthreads), lds, stream, ga, tiles);
   DFOT_CHECK_HIP(hipGetLastError());
   return DFOT_OK;
 }
