@@ -10,7 +10,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdfot_hip.so")
+LIB_PATH = os.environ.get("DFOT_LIB", os.path.join(_HERE, "libdfot_hip.so"))  # DFOT_LIB: A/B a differently built library
 
 OK, ERR_ARG, ERR_SHAPE, ERR_HIP, ERR_STATE, ERR_NAME = range(6)
 
