@@ -94,8 +94,9 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int tile_inde
       a_src[i] = g.A + m * g.lda + c * 8;
       a_y[i] = a_x[i] = 0;
     } else {
-      const int xw = (int)(m % g.Wd);
-      const int yh = (int)((m / g.Wd) % g.H);
+      const unsigned mu = (unsigned)m;  // 32-bit divisions (M < 2^31)
+      const int xw = (int)(mu % (unsigned)g.Wd);
+      const int yh = (int)((mu / (unsigned)g.Wd) % (unsigned)g.H);
       a_x[i] = xw;
       a_y[i] = yh;
       a_src[i] = g.A + m * (long)g.Cin + c * 8;
@@ -300,9 +301,9 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int tile_inde
       // out[frame][col][row % tr_rows], frame = row / tr_rows  -- no bias / activation / GroupNorm statistics
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi) {
-        const long row = (long)m0 + wm * WTM + mi * 16 + rowq;
-        const long frame = row / g.tr_rows;
-        const int rin = (int)(row % g.tr_rows);
+        const unsigned row = (unsigned)(m0 + wm * WTM + mi * 16 + rowq);  // 32-bit index arithmetic: M < 2^31 (launcher)
+        const long frame = row / (unsigned)g.tr_rows;
+        const int rin = (int)(row % (unsigned)g.tr_rows);
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) {
           const int c = nw + ni * 16 + colq;
@@ -330,10 +331,10 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int tile_inde
         for (int p = 0; p < 4; ++p) {
           const int r = p * 4 + (lane >> 4);
           f32x4 v = *reinterpret_cast<const f32x4*>(ep + r * EP_LD + cw) + b0;
-          if (bias2d) v += *reinterpret_cast<const f32x4*>(g.bias + ((mw + r) % g.bias_rows) * (long)g.N + col);
+          if (bias2d) v += *reinterpret_cast<const f32x4*>(g.bias + (long)((unsigned)(mw + r) % (unsigned)g.bias_rows) * g.N + col);
           const long off = (mw + r) * g.ldo + col;
           if (has_gate) {
-            long gr = (mw + r) / g.gate_rows;
+            long gr = (unsigned)(mw + r) / (unsigned)g.gate_rows;  // 32-bit division (a 64-bit one costs ~100 instructions)
             if (g.gate_index) gr = g.gate_index[gr];
             v *= *reinterpret_cast<const f32x4*>(g.gate + gr * g.ldg + col);
           }
@@ -352,7 +353,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int tile_inde
         f32x4 v1 = *reinterpret_cast<const f32x4*>(ep + r * EP_LD + cw + 4) + b1;
         if constexpr (EPI == E_BF16) {
           if (bias2d && live) {
-            const float* bp = g.bias + ((mw + r) % g.bias_rows) * (long)g.N + col;
+            const float* bp = g.bias + (long)((unsigned)(mw + r) % (unsigned)g.bias_rows) * g.N + col;
             v0 += *reinterpret_cast<const f32x4*>(bp);
             v1 += *reinterpret_cast<const f32x4*>(bp + 4);
           }
@@ -402,9 +403,9 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int tile_inde
           const float mul = which == 0 ? g.qscale : 1.f;
 #pragma unroll
           for (int p = 0; p < 2; ++p) {
-            const long row = mw + p * 8 + (lane >> 3);
-            const long bidx = row / g.ntok;
-            const int tok = (int)(row % g.ntok);
+            const unsigned row = (unsigned)(mw + p * 8 + (lane >> 3));
+            const long bidx = row / (unsigned)g.ntok;
+            const int tok = (int)(row % (unsigned)g.ntok);
             bf16x8 o;
             if (which == 2 || g.rope_cs == nullptr) {  // v, or q/k without rotary embedding (per-frame spatial blocks)
 #pragma unroll
@@ -463,9 +464,9 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int tile_inde
             const int head = cc / g.d, e0 = cc % g.d;
 #pragma unroll
             for (int p = 0; p < 2; ++p) {
-              const long row = mw + p * 8 + (lane >> 3);
-              const long bidx = row / g.ntok;
-              const int tok = (int)(row % g.ntok);
+              const unsigned row = (unsigned)(mw + p * 8 + (lane >> 3));
+              const long bidx = row / (unsigned)g.ntok;
+              const int tok = (int)(row % (unsigned)g.ntok);
               bf16x8 o;
               if (which == 2) {
 #pragma unroll
@@ -495,10 +496,10 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int tile_inde
 
   if constexpr (EPI == E_F32 || EPI == E_BF16) {
     if (g.gn_part) {  // wave-uniform (launcher guarantees a 64-row wave tile)
-      const long mrow = (long)m0 + wm * WTM;
-      const int bt = (int)(mrow / g.gn_rows_per_bt);
+      const unsigned mrow = (unsigned)(m0 + wm * WTM);
+      const int bt = (int)(mrow / (unsigned)g.gn_rows_per_bt);
       const int slots = g.gn_rows_per_bt / 64;
-      const int slot = (int)((mrow % g.gn_rows_per_bt) / 64);
+      const int slot = (int)((mrow % (unsigned)g.gn_rows_per_bt) / 64);
       float* dst = g.gn_part + ((long)bt * slots + slot) * 64;
       if constexpr (EPI == E_F32) {
         // lane = 4 columns (one group when cpg == 4, half a group when cpg == 8) x 16 rows; rows of the other
