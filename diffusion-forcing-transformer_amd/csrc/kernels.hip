@@ -67,12 +67,11 @@ __global__ __launch_bounds__(256) void embed_input_kernel(const float* __restric
   __syncthreads();
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= total4) return;
-  const int q = c0 / 4;
-  const int c4 = (int)(idx % q) * 4;
-  const long pix = idx / q;
-  const int r0 = res / 2;
+  const unsigned q = c0 / 4, r0 = res / 2, iu = (unsigned)idx;  // 32-bit index arithmetic (launcher: total < 2^31)
+  const int c4 = (int)(iu % q) * 4;
+  const unsigned pix = iu / q;
   const int px = (int)(pix % r0), py = (int)((pix / r0) % r0);
-  const long bt = pix / ((long)r0 * r0);
+  const long bt = pix / (r0 * r0);
   float4v acc = *reinterpret_cast<const float4v*>(b + c4);
   for (int ci = 0; ci < cin; ++ci) {
     const float* xp = x + ((bt * cin + ci) * res + 2 * py) * (long)res + 2 * px;
@@ -82,13 +81,14 @@ __global__ __launch_bounds__(256) void embed_input_kernel(const float* __restric
     acc += *reinterpret_cast<const float4v*>(wp) * top[0] + *reinterpret_cast<const float4v*>(wp + c0) * top[1] +
            *reinterpret_cast<const float4v*>(wp + 2 * c0) * bot[0] + *reinterpret_cast<const float4v*>(wp + 3 * c0) * bot[1];
   }
-  *reinterpret_cast<float4v*>(out + pix * c0 + c4) = acc;
+  *reinterpret_cast<float4v*>(out + (long)pix * c0 + c4) = acc;
 }
 
 int launch_embed_input(const float* x, const float* w, const float* b, float* out, int bt, int res, int cin, int c0,
                        hipStream_t s) {
   DFOT_REQUIRE(c0 % 4 == 0 && res % 2 == 0, DFOT_ERR_SHAPE, "embed_input: channels %d / resolution %d unsupported", c0, res);
   const long total4 = (long)bt * (res / 2) * (res / 2) * (c0 / 4);
+  DFOT_REQUIRE(total4 < (1L << 31), DFOT_ERR_SHAPE, "embed_input: %ld work items exceed the 32-bit index range", total4);
   hipLaunchKernelGGL(embed_input_kernel, dim3(cdiv(total4, 256)), dim3(256), (size_t)cin * 4 * c0 * sizeof(float), s, x, w, b,
                      out, total4, res, cin, c0);
   DFOT_CHECK_HIP(hipGetLastError());
@@ -141,8 +141,8 @@ __global__ void emb_pyramid_kernel(const bf16* __restrict__ e0, bf16* __restrict
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= total) return;
   const int ec = e / 8;
-  const int c8 = (int)(idx % ec);
-  const long blk = idx / ec;
+  const int c8 = (int)((unsigned)idx % (unsigned)ec);
+  const long blk = (unsigned)idx / (unsigned)ec;
   const int r3 = r0 / 8;
   const int bx = (int)(blk % r3), by = (int)((blk / r3) % r3);
   const long bt = blk / ((long)r3 * r3);
@@ -187,6 +187,7 @@ __global__ void emb_pyramid_kernel(const bf16* __restrict__ e0, bf16* __restrict
 int launch_emb_pyramid(const bf16* emb0, bf16* emb1, bf16* emb2, bf16* emb3, int bt, int r0, int e, hipStream_t s) {
   DFOT_REQUIRE(r0 % 8 == 0 && e % 8 == 0, DFOT_ERR_SHAPE, "emb_pyramid: level-0 size %d / emb %d must be multiples of 8", r0, e);
   const long total = (long)bt * (r0 / 8) * (r0 / 8) * (e / 8);
+  DFOT_REQUIRE(total < (1L << 31), DFOT_ERR_SHAPE, "emb_pyramid: %ld work items exceed the 32-bit index range", total);
   hipLaunchKernelGGL(emb_pyramid_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, emb0, emb1, emb2, emb3, total, r0, e);
   DFOT_CHECK_HIP(hipGetLastError());
   return DFOT_OK;
@@ -206,8 +207,9 @@ __global__ __launch_bounds__(256) void project_output_kernel(const float* __rest
   const long pix = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (pix >= npix) return;
   const int r0 = res / 2;
-  const int px = (int)(pix % r0), py = (int)((pix / r0) % r0);
-  const long bt = pix / ((long)r0 * r0);
+  const unsigned pu = (unsigned)pix, ru = (unsigned)r0;
+  const int px = (int)(pu % ru), py = (int)((pu / ru) % ru);
+  const long bt = pu / (ru * ru);
   float acc[12];
   for (int o = 0; o < cout * 4; ++o) acc[o] = 0.f;
   const float* xp = x0 + pix * c0;
@@ -230,6 +232,7 @@ int launch_project_output(const float* x0, const float* w, const float* b, float
                           hipStream_t s) {
   DFOT_REQUIRE(cout <= 3 && c0 % 4 == 0, DFOT_ERR_SHAPE, "project_output: cout=%d (<=3), c0=%d", cout, c0);
   const long npix = (long)bt * (res / 2) * (res / 2);
+  DFOT_REQUIRE(npix < (1L << 31), DFOT_ERR_SHAPE, "project_output: %ld pixels exceed the 32-bit index range", npix);
   hipLaunchKernelGGL(project_output_kernel, dim3(cdiv(npix, 256)), dim3(256), c0 * cout * 4 * sizeof(float), s, x0, w, b,
                      out, npix, res, c0, cout);
   DFOT_CHECK_HIP(hipGetLastError());
@@ -337,9 +340,10 @@ __global__ void gn_apply_silu_kernel(const float* __restrict__ x, const float* _
                                      bf16* __restrict__ out, long total8, int pixels, int c) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= total8) return;
-  const int c8 = (int)(idx % (c / 8));
-  const long pix = idx / (c / 8);
-  const int bt = (int)(pix / pixels);
+  const unsigned iu = (unsigned)idx, cq = (unsigned)(c / 8);  // 32-bit index arithmetic (launcher: total < 2^31)
+  const int c8 = (int)(iu % cq);
+  const long pix = iu / cq;
+  const int bt = (int)((unsigned)pix / (unsigned)pixels);
   const int cpg = c / 32;
   const float* src = x + pix * c + c8 * 8;
   const float4v a = *reinterpret_cast<const float4v*>(src);
@@ -360,6 +364,7 @@ __global__ void gn_apply_silu_kernel(const float* __restrict__ x, const float* _
 int launch_gn_apply_silu(const float* x, const float* stats, const float* gamma, const float* beta, bf16* out, int bt,
                          int pixels, int c, hipStream_t s) {
   const long total8 = (long)bt * pixels * (c / 8);
+  DFOT_REQUIRE(total8 < (1L << 31), DFOT_ERR_SHAPE, "groupnorm apply: %ld work items exceed the 32-bit index range", total8);
   hipLaunchKernelGGL(gn_apply_silu_kernel, dim3(cdiv(total8, 256)), dim3(256), 0, s, x, stats, gamma, beta, out, total8,
                      pixels, c);
   DFOT_CHECK_HIP(hipGetLastError());
@@ -430,9 +435,10 @@ __global__ void gn_film_silu_kernel(const bf16* __restrict__ h, const float* __r
                                     int c, int tokens) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= total8) return;
-  const int c8 = (int)(idx % (c / 8));
-  const long pix = idx / (c / 8);
-  const int bt = (int)(pix / pixels);
+  const unsigned iu = (unsigned)idx, cq = (unsigned)(c / 8);  // 32-bit index arithmetic (launcher: total < 2^31)
+  const int c8 = (int)(iu % cq);
+  const long pix = iu / cq;
+  const int bt = (int)((unsigned)pix / (unsigned)pixels);
   const int cpg = c / 32;
   const int c0 = c8 * 8;
   const int col = (c0 >> 5) * 64 + (c0 & 31);  // scale columns col..col+7, shift columns col+32..col+39
@@ -444,7 +450,7 @@ __global__ void gn_film_silu_kernel(const bf16* __restrict__ h, const float* __r
     sc[j] = svp[j];
     sh[j] = svp[32 + j];
   }
-  const bool use_pose = !(cond_mask && cond_mask[bt / tokens]);
+  const bool use_pose = !(cond_mask && cond_mask[(unsigned)bt / (unsigned)tokens]);
   if (use_pose) {
     const bf16x8 fs = *reinterpret_cast<const bf16x8*>(fcache + pix * 2 * c + col);
     const bf16x8 fh = *reinterpret_cast<const bf16x8*>(fcache + pix * 2 * c + col + 32);
@@ -469,6 +475,7 @@ int launch_gn_film_silu(const bf16* h, const float* stats, const float* gamma, c
                         const float* sv, const uint8_t* cond_mask, bf16* out, int bt, int pixels, int c, int tokens,
                         hipStream_t s) {
   const long total8 = (long)bt * pixels * (c / 8);
+  DFOT_REQUIRE(total8 < (1L << 31), DFOT_ERR_SHAPE, "groupnorm apply: %ld work items exceed the 32-bit index range", total8);
   hipLaunchKernelGGL(gn_film_silu_kernel, dim3(cdiv(total8, 256)), dim3(256), 0, s, h, stats, gamma, beta, fcache, sv,
                      cond_mask, out, total8, pixels, c, tokens);
   DFOT_CHECK_HIP(hipGetLastError());
@@ -503,7 +510,7 @@ __global__ __launch_bounds__(256) void rms_film_kernel(const float* __restrict__
   ss = wave_sum(ss);
   const float rs = rsqrtf(ss / (float)c + eps);
   const int bt = (int)(row / rows_per_bt);
-  const bool use_pose = !(cond_mask && cond_mask[bt / tokens]);
+  const bool use_pose = !(cond_mask && cond_mask[(unsigned)bt / (unsigned)tokens]);
 #pragma unroll
   for (int k = 0; k < MAXCH; ++k) {
     const int ch = lane + 64 * k;
@@ -552,10 +559,11 @@ int launch_rms_film(const float* x, const float* w, const bf16* fcache, const fl
 __global__ void pool2_bf16_kernel(const float* __restrict__ x, bf16* __restrict__ out, long total4, int h, int w, int c) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= total4) return;
-  const int c4 = (int)(idx % (c / 4));
-  const long pix = idx / (c / 4);
-  const int ox = (int)(pix % (w / 2)), oy = (int)((pix / (w / 2)) % (h / 2));
-  const long bt = pix / ((long)(w / 2) * (h / 2));
+  const unsigned iu = (unsigned)idx, cq = (unsigned)(c / 4), w2 = (unsigned)(w / 2), h2 = (unsigned)(h / 2);
+  const int c4 = (int)(iu % cq);
+  const unsigned pix = iu / cq;
+  const int ox = (int)(pix % w2), oy = (int)((pix / w2) % h2);
+  const long bt = pix / (w2 * h2);
   const float* base = x + ((bt * h + 2 * oy) * w + 2 * ox) * (long)c + c4 * 4;
   const float4v a = *reinterpret_cast<const float4v*>(base);
   const float4v b = *reinterpret_cast<const float4v*>(base + c);
@@ -568,6 +576,7 @@ __global__ void pool2_bf16_kernel(const float* __restrict__ x, bf16* __restrict_
 }
 int launch_pool2_bf16(const float* x, bf16* out, int bt, int h, int w, int c, hipStream_t s) {
   const long total4 = (long)bt * (h / 2) * (w / 2) * (c / 4);
+  DFOT_REQUIRE(total4 < (1L << 31), DFOT_ERR_SHAPE, "pool2: %ld work items exceed the 32-bit index range", total4);
   hipLaunchKernelGGL(pool2_bf16_kernel, dim3(cdiv(total4, 256)), dim3(256), 0, s, x, out, total4, h, w, c);
   DFOT_CHECK_HIP(hipGetLastError());
   return DFOT_OK;
@@ -595,16 +604,18 @@ __global__ void upsample_add_kernel(const float* __restrict__ t, const float* __
                                     long total4, int h, int w, int c) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= total4) return;
-  const int c4 = (int)(idx % (c / 4));
-  const long pix = idx / (c / 4);
-  const int x = (int)(pix % (2 * w)), y = (int)((pix / (2 * w)) % (2 * h));
-  const long bt = pix / ((long)4 * w * h);
+  const unsigned iu = (unsigned)idx, cq = (unsigned)(c / 4), w2 = (unsigned)(2 * w), h2 = (unsigned)(2 * h);
+  const int c4 = (int)(iu % cq);
+  const unsigned pix = iu / cq;
+  const int x = (int)(pix % w2), y = (int)((pix / w2) % h2);
+  const long bt = pix / (w2 * h2);
   const float4v a = *reinterpret_cast<const float4v*>(t + ((bt * h + y / 2) * w + x / 2) * (long)c + c4 * 4);
   const float4v b = *reinterpret_cast<const float4v*>(skip + pix * c + c4 * 4);
   *reinterpret_cast<float4v*>(out + pix * c + c4 * 4) = a + b;
 }
 int launch_upsample_add(const float* t, const float* skip, float* out, int bt, int h, int w, int c, hipStream_t s) {
   const long total4 = (long)bt * 4 * h * w * (c / 4);
+  DFOT_REQUIRE(total4 < (1L << 31), DFOT_ERR_SHAPE, "upsample_add: %ld work items exceed the 32-bit index range", total4);
   hipLaunchKernelGGL(upsample_add_kernel, dim3(cdiv(total4, 256)), dim3(256), 0, s, t, skip, out, total4, h, w, c);
   DFOT_CHECK_HIP(hipGetLastError());
   return DFOT_OK;
@@ -673,10 +684,11 @@ __global__ void hg_prepare_kernel(const float* __restrict__ x, const float* __re
                                   long f4) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= total4) return;
-  const long e = idx % f4;
-  const long bt = idx / f4;  // over (b*nfe + h, t)
-  const int tk = (int)(bt % tokens);
-  const long bh = bt / tokens;
+  const unsigned iu = (unsigned)idx, fu = (unsigned)f4;  // 32-bit index arithmetic (launcher: total < 2^31)
+  const long e = iu % fu;
+  const long bt = iu / fu;  // over (b*nfe + h, t)
+  const int tk = (int)((unsigned)bt % (unsigned)tokens);
+  const long bh = (unsigned)bt / (unsigned)tokens;
   const long b = bh / nfe;
   const float a = qa[bt], c = qb[bt];
   const float4v xv = *reinterpret_cast<const float4v*>(x + ((b * tokens + tk) * f4 + e) * 4);
@@ -688,6 +700,7 @@ int launch_hg_prepare(const float* x, const float* noise, const float* qa, const
                       int nfe, int tokens, long f, hipStream_t s) {
   DFOT_REQUIRE(f % 4 == 0, DFOT_ERR_SHAPE, "hg_prepare: frame elements %ld must be a multiple of 4", f);
   const long total4 = (long)batch * nfe * tokens * (f / 4);
+  DFOT_REQUIRE(total4 < (1L << 31), DFOT_ERR_SHAPE, "hg_prepare: %ld work items exceed the 32-bit index range", total4);
   hipLaunchKernelGGL(hg_prepare_kernel, dim3(cdiv(total4, 256)), dim3(256), 0, s, x, noise, qa, qb, x_in, total4, nfe,
                      tokens, f / 4);
   DFOT_CHECK_HIP(hipGetLastError());
@@ -701,10 +714,11 @@ __global__ void ddim_compose_kernel(const float* __restrict__ x, const float* __
                                     float* __restrict__ x_next, long total4, int nfe, int tokens, long f4, int wstride) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= total4) return;
-  const long e = idx % f4;
-  const long bt = idx / f4;  // over (b, t)
-  const int tk = (int)(bt % tokens);
-  const long b = bt / tokens;
+  const unsigned iu = (unsigned)idx, fu = (unsigned)f4;
+  const long e = iu % fu;
+  const long bt = iu / fu;  // over (b, t)
+  const int tk = (int)((unsigned)bt % (unsigned)tokens);
+  const long b = (unsigned)bt / (unsigned)tokens;
   float4v o;
   if (!gen[bt]) {
     o = *reinterpret_cast<const float4v*>(x + idx * 4);
@@ -733,6 +747,7 @@ int launch_ddim_compose(const float* x, const float* x_in, const float* v, const
                         float* x_next, int batch, int nfe, int tokens, long f, bool weight_per_token, hipStream_t s) {
   DFOT_REQUIRE(f % 4 == 0, DFOT_ERR_SHAPE, "ddim_compose: frame elements %ld must be a multiple of 4", f);
   const long total4 = (long)batch * tokens * (f / 4);
+  DFOT_REQUIRE(total4 < (1L << 31), DFOT_ERR_SHAPE, "ddim_compose: %ld work items exceed the 32-bit index range", total4);
   hipLaunchKernelGGL(ddim_compose_kernel, dim3(cdiv(total4, 256)), dim3(256), 0, s, x, x_in, v, sa, s1, an, cn, keep,
                      weight, gen, x_next, total4, nfe, tokens, f / 4, weight_per_token ? tokens : 0);
   DFOT_CHECK_HIP(hipGetLastError());
