@@ -111,18 +111,36 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int tile_inde
     w_src[i] = g.W + (long)n * g.K + c * 8;
   }
 
+  // conv3x3: k-tile kt covers channels [cv_c0, cv_c0 + BKT) of tap (cv_dy, cv_dx).  issue() is called with consecutive k-tiles
+  // (stride KS), so the tap position is carried along instead of being re-derived with three integer divisions per k-tile
+  [[maybe_unused]] int cv_c0 = 0, cv_dy = -1, cv_dx = -1;
+  if constexpr (AMODE == A_CONV3) {
+    const int kbase = kgroup * BKT;  // first k-tile of this k-group
+    const int tap = kbase / g.Cin;
+    cv_c0 = kbase - tap * g.Cin;
+    cv_dy = tap / 3 - 1;
+    cv_dx = tap % 3 - 1;
+  }
   auto a_addr = [&](int i, int kt) -> const bf16* {
     if constexpr (AMODE == A_DENSE) {
       return a_src[i] + (long)kt * BKT;
     } else {
-      const int kbase = kt * BKT;
-      const int tap = kbase / g.Cin;
-      const int c0 = kbase - tap * g.Cin;
-      const int dy = tap / 3 - 1, dx = tap % 3 - 1;
-      const int yy = a_y[i] + dy, xx = a_x[i] + dx;
+      const int yy = a_y[i] + cv_dy, xx = a_x[i] + cv_dx;
       const bool ok = (yy >= 0) && (yy < g.H) && (xx >= 0) && (xx < g.Wd);
-      const bf16* p = a_src[i] + ((long)dy * g.Wd + dx) * g.Cin + c0;
+      const bf16* p = a_src[i] + ((long)cv_dy * g.Wd + cv_dx) * g.Cin + cv_c0;
       return ok ? p : g.zeros + a_chunk[i] * 8;
+    }
+  };
+  auto conv_advance = [&]() {  // to the k-tile of the next issue() of this k-group
+    if constexpr (AMODE == A_CONV3) {
+      cv_c0 += KS * BKT;
+      while (cv_c0 >= g.Cin) {
+        cv_c0 -= g.Cin;
+        if (++cv_dx > 1) {
+          cv_dx = -1;
+          ++cv_dy;
+        }
+      }
     }
   };
 
@@ -151,6 +169,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int tile_inde
         rw[i] = *reinterpret_cast<const bf16x8*>(pw);
       }
     }
+    conv_advance();
   };
   auto commit = [&](int stage) {  // DMA=false only: registers -> LDS
     char* sa = smem + stage * STAGE_BYTES;
