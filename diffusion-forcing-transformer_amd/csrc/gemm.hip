@@ -563,12 +563,18 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int tile_inde
   }
 }
 
-// Kernel = tile loop.  With grid == tile count every workgroup does one tile (the default); a smaller grid (GemmArgs.persist)
-// makes the workgroups persistent: tile, tile + grid, ... -- no workgroup relaunch between the tiles of a CU, and the stores of
-// one tile drain while the next tile's first loads are already in flight.  gridDim.x is a multiple of 8 then, so a tile keeps
-// the XCD its index implies (xcd_remap).
+// One tile per workgroup.  (Wrapping this body in a tile loop costs the 16-wave kernels, which sit at the 128-VGPR cap, up to 35
+// spilled VGPRs -- the fused QKV GEMM went from 96.7 to 117.6 us -- so the loop lives in a separate kernel below.)
 template <int BM_T, int BN_T, int WTM, int NST, int AMODE, int EPI, bool DMA, int KS = 1, int BKT = BK>
-__global__ __launch_bounds__((BM_T / WTM) * (BN_T / 64) * 64 * KS) void gemm_kernel(GemmArgs g, int tile_count) {
+__global__ __launch_bounds__((BM_T / WTM) * (BN_T / 64) * 64 * KS) void gemm_kernel(GemmArgs g) {
+  gemm_tile<BM_T, BN_T, WTM, NST, AMODE, EPI, DMA, KS, BKT>(g, blockIdx.x, gridDim.x);
+}
+
+// Persistent form: grid = resident workgroups, each walks tile, tile + grid, ... -- no workgroup relaunch between the tiles of
+// a CU, and the stores of one tile drain while the next tile's first loads are in flight.  gridDim.x is a multiple of 8, so a
+// tile keeps the XCD its index implies (xcd_remap).  Only instantiated for kernels of <= 12 waves (>= 168 VGPRs per wave).
+template <int BM_T, int BN_T, int WTM, int NST, int AMODE, int EPI, bool DMA, int KS = 1, int BKT = BK>
+__global__ __launch_bounds__((BM_T / WTM) * (BN_T / 64) * 64 * KS) void gemm_kernel_persistent(GemmArgs g, int tile_count) {
   for (int tile = blockIdx.x; tile < tile_count; tile += gridDim.x) {
     gemm_tile<BM_T, BN_T, WTM, NST, AMODE, EPI, DMA, KS, BKT>(g, tile, tile_count);
     if (tile + (int)gridDim.x < tile_count) __syncthreads();  // the next tile's staging re-uses this tile's epilogue scratch
@@ -588,18 +594,30 @@ static int launch_t(const GemmArgs& g, hipStream_t stream) {
   GemmArgs ga = g;
   ga.xcd = xcd_flag;
   if (persist_flag) ga.persist = 1;
+  constexpr bool kPersistOK = KS == 1 && nthreads <= 768;
+  if constexpr (kPersistOK) {
+    if (ga.persist > 0) {
+      const int resident = 256 * (lds <= 80 * 1024 ? 2 : 1);  // workgroups the chip holds at once (LDS-limited)
+      if (tiles > resident) {
+        auto kp = gemm_kernel_persistent<BM_T, BN_T, WTM, NST, AMODE, EPI, DMA, KS, BKT>;
+        static bool pattr_set = false;
+        if (!pattr_set) {
+          DFOT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kp), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+          pattr_set = true;
+        }
+        hipLaunchKernelGGL(kp, dim3(resident), dim3(nthreads), lds, stream, ga, tiles);
+        DFOT_CHECK_HIP(hipGetLastError());
+        return DFOT_OK;
+      }
+    }
+  }
   auto kern = gemm_kernel<BM_T, BN_T, WTM, NST, AMODE, EPI, DMA, KS, BKT>;
   static bool attr_set = false;
   if (!attr_set) {
     DFOT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     attr_set = true;
   }
-  int grid = tiles;
-  if (ga.persist > 0 && KS == 1) {
-    const int resident = 256 * (lds <= 80 * 1024 ? 2 : 1);  // workgroups the chip holds at once (LDS-limited)
-    if (tiles > resident) grid = resident;
-  }
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(nthreads), lds, stream, ga, tiles);
+  hipLaunchKernelGGL(kern, dim3(tiles), dim3(nthreads), lds, stream, ga);
   DFOT_CHECK_HIP(hipGetLastError());
   return DFOT_OK;
 }
