@@ -89,3 +89,37 @@ def test_torch_library_operators_are_registered_with_shape_inference():
         assert nxt.shape == x.shape
         z = torch.empty(3, 5, 16, 16, 16)
         assert torch.ops.dfot.dit3d_forward(z, torch.empty(3, 5, dtype=torch.long), 0).shape == z.shape
+
+
+def test_no_kernel_spills_registers(tmp_path):
+    """Every gfx950 kernel must fit its register budget: a refactor once wrapped the 16-wave GEMM kernels (128-VGPR cap) in a
+    tile loop and silently spilled up to 35 VGPRs, 20 % of the fused QKV GEMM's time.  Compiles each source to ISA (no GPU
+    needed) and reads the code-object metadata."""
+    import shutil
+    import subprocess
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not shutil.which(hipcc) and not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    csrc = os.path.join(PKG, "csrc")
+    offenders = []
+    procs = []
+    for fn in sorted(os.listdir(csrc)):
+        if not fn.endswith(".hip"):
+            continue
+        out = tmp_path / (fn + ".s")
+        procs.append((fn, out, subprocess.Popen(
+            [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-mllvm", "-amdgpu-mfma-vgpr-form=1", "-I", os.path.join(ROOT, "include"),
+             "-I", csrc, "--offload-device-only", "-S", "-o", str(out), os.path.join(csrc, fn)],
+            stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)))
+    for fn, out, p in procs:
+        assert p.wait() == 0, f"{fn} failed to compile"
+        text = open(out).read()
+        names = re.findall(r"\.name:\s+(\S+)", text)
+        spills = re.findall(r"\.vgpr_spill_count:\s+(\d+)", text)
+        assert spills, fn
+        for m in re.finditer(r"\.name:\s+(\S+)(.*?)\.wavefront_size", text, re.S):
+            sp = re.search(r"\.vgpr_spill_count:\s+(\d+)", m.group(2))
+            if sp and int(sp.group(1)) > 0:
+                offenders.append((fn, m.group(1)[:80], int(sp.group(1))))
+        assert names
+    assert not offenders, offenders
