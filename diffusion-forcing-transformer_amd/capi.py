@@ -75,6 +75,7 @@ SIGNATURES = {
     "dfot_dit_forward": (_I, [_P, _P, _P, _P, _I, _I, _P]),
     "dfot_dit_read_tap": (_I, [_P, C.c_char_p, _P, C.c_size_t, _P]),
     "dfot_ray_encode": (_I, [_P, _P, _I, _I, _I, _P]),
+    "dfot_ray_encode_normalized": (_I, [_P, _P, _I, _I, _I, _P]),
     "dfot_hg_prepare": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _L, _P]),
     "dfot_ddim_compose": (_I, [_P] * 11 + [_I, _I, _I, _L, _P]),
     "dfot_ddim_compose_tokw": (_I, [_P] * 11 + [_I, _I, _I, _L, _P]),

@@ -41,7 +41,7 @@ int launch_pool2_bf16(const float* x, bf16* out, int bt, int h, int w, int c, hi
 int launch_sub_bf16(const float* a, const float* b, bf16* out, long n, hipStream_t s);
 int launch_upsample_add(const float* t, const float* skip, float* out, int bt, int h, int w, int c, hipStream_t s);
 // ---- pose ----
-int launch_ray_encode(const float* poses, float* out, int b, int t, int res, hipStream_t s);
+int launch_ray_encode(const float* poses, float* out, int b, int t, int res, int normalized, hipStream_t s);
 // ---- sampler ----
 int launch_hg_prepare(const float* x, const float* noise, const float* qa, const float* qb, float* x_in, int batch,
                       int nfe, int tokens, long f, hipStream_t s);

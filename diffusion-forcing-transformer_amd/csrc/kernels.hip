@@ -625,7 +625,8 @@ int launch_upsample_add(const float* t, const float* skip, float* out, int bt, i
 // camera-ray encoding (geometry_utils.py:49-81,102-133,244-295): raw [B][T][16] -> [B][T][180][res][res]
 // thread = one output element; the per-frame 3x3 algebra is recomputed per thread (27 FMAs)
 // --------------------------------------------------------------------------------------------
-__global__ void ray_encode_kernel(const float* __restrict__ poses, float* __restrict__ out, long total, int t, int res) {
+__global__ void ray_encode_kernel(const float* __restrict__ poses, float* __restrict__ out, long total, int t, int res,
+                                  int normalized) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= total) return;
   const int x = (int)(idx % res), y = (int)((idx / res) % res);
@@ -634,19 +635,26 @@ __global__ void ray_encode_kernel(const float* __restrict__ poses, float* __rest
   const long b = bt / t;
   const float* p = poses + bt * 16;
   const float* p0 = poses + b * t * 16;
-  // R' = R R0^T ; T' = T - R' T0
+  // R' = R R0^T ; T' = T - R' T0   (normalized: the caller already expressed the poses in its world frame)
   float r[3][3], tr[3];
-  for (int i = 0; i < 3; ++i) {
-    for (int j = 0; j < 3; ++j) {
-      float acc = 0.f;
-      for (int m = 0; m < 3; ++m) acc = fmaf(p[4 + i * 4 + m], p0[4 + j * 4 + m], acc);
-      r[i][j] = acc;
+  if (normalized) {
+    for (int i = 0; i < 3; ++i) {
+      for (int j = 0; j < 3; ++j) r[i][j] = p[4 + i * 4 + j];
+      tr[i] = p[4 + i * 4 + 3];
     }
-  }
-  for (int i = 0; i < 3; ++i) {
-    float acc = 0.f;
-    for (int j = 0; j < 3; ++j) acc = fmaf(r[i][j], p0[4 + j * 4 + 3], acc);
-    tr[i] = p[4 + i * 4 + 3] - acc;
+  } else {
+    for (int i = 0; i < 3; ++i) {
+      for (int j = 0; j < 3; ++j) {
+        float acc = 0.f;
+        for (int m = 0; m < 3; ++m) acc = fmaf(p[4 + i * 4 + m], p0[4 + j * 4 + m], acc);
+        r[i][j] = acc;
+      }
+    }
+    for (int i = 0; i < 3; ++i) {
+      float acc = 0.f;
+      for (int j = 0; j < 3; ++j) acc = fmaf(r[i][j], p0[4 + j * 4 + 3], acc);
+      tr[i] = p[4 + i * 4 + 3] - acc;
+    }
   }
   const int which = ch / 90;   // 0 origin, 1 direction
   const int rr = ch % 90;
@@ -669,9 +677,9 @@ __global__ void ray_encode_kernel(const float* __restrict__ poses, float* __rest
   out[idx] = sinf(arg);
 }
 
-int launch_ray_encode(const float* poses, float* out, int b, int t, int res, hipStream_t s) {
+int launch_ray_encode(const float* poses, float* out, int b, int t, int res, int normalized, hipStream_t s) {
   const long total = (long)b * t * 180 * res * res;
-  hipLaunchKernelGGL(ray_encode_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, poses, out, total, t, res);
+  hipLaunchKernelGGL(ray_encode_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, poses, out, total, t, res, normalized);
   DFOT_CHECK_HIP(hipGetLastError());
   return DFOT_OK;
 }

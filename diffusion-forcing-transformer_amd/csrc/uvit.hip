@@ -754,7 +754,12 @@ int dfot_uvit_read_tap(dfot_uvit_t h, const char* name, float* out, size_t capac
 // ---- pose / sampler / primitives ------------------------------------------------------------
 int dfot_ray_encode(const float* raw_poses, float* out, int batch, int tokens, int resolution, void* stream) {
   DFOT_REQUIRE(raw_poses && out && batch > 0 && tokens > 0 && resolution > 0, DFOT_ERR_ARG, "ray_encode: bad argument");
-  return launch_ray_encode(raw_poses, out, batch, tokens, resolution, (hipStream_t)stream);
+  return launch_ray_encode(raw_poses, out, batch, tokens, resolution, 0, (hipStream_t)stream);
+}
+
+int dfot_ray_encode_normalized(const float* poses, float* out, int batch, int tokens, int resolution, void* stream) {
+  DFOT_REQUIRE(poses && out && batch > 0 && tokens > 0 && resolution > 0, DFOT_ERR_ARG, "ray_encode_normalized: bad argument");
+  return launch_ray_encode(poses, out, batch, tokens, resolution, 1, (hipStream_t)stream);
 }
 
 int dfot_hg_prepare(const float* x, const float* noise, const float* qa, const float* qb, float* x_in, int batch, int nfe,

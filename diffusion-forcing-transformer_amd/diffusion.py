@@ -106,8 +106,8 @@ class Schedule:
 
     def refine_scheduling_matrix(self, horizon: int, goback_length: int, n_goback: int, padding: int = 0) -> np.ndarray:
         """_generate_refine_scheduling_matrix (base_pytorch_video_algo.py:943-970): the full-sequence ladder with, at every
-        goback_length-th index, n_goback excursions goback_length steps back up and down again.  Only the matrix is built --
-        the refinement SAMPLER of the fork (re-noising branch, off by default) is not."""
+        goback_length-th index, n_goback excursions goback_length steps back up and down again.
+        The sampler that walks it is ``sampler._sample_sequence_refine``."""
         s = self.cfg.sampling_timesteps
         marks = set(range(1, s - goback_length, goback_length))
         seq = []

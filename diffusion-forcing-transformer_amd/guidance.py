@@ -117,7 +117,7 @@ class HistoryGuidance:
         hg = cls(segs, hist_weights, gen_segments=gen_segments, timesteps=timesteps,
                  use_external_cond_guidance=use_external_cond_guidance)
         # with camera poses the reference re-interpolates the poses of fully masked frames (dfot_video_pose.py:77-84,
-        # CameraPose.replace_with_interpolation: quaternion slerp) -- not built; the pose sampler refuses this combination
+        # CameraPose.replace_with_interpolation: quaternion slerp): the pose sampler does so per branch (pose.py)
         hg.needs_pose_interpolation = True
         return hg
 

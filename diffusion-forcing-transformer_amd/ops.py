@@ -65,16 +65,19 @@ def _(x, noise_levels, model):
 
 
 @custom_op("dfot::ray_encoding", mutates_args=())
-def ray_encoding(raw_poses: Tensor, resolution: int) -> Tensor:
+def ray_encoding(raw_poses: Tensor, resolution: int, normalized: bool = False) -> Tensor:
+    """normalized = False: poses are raw and become relative to frame 0 (the reference's default, normalize_by "first");
+    True: the caller already expressed them in its world frame (pose.normalize_poses)"""
     b, t = raw_poses.shape[:2]
     raw = raw_poses.detach().to(device="cuda", dtype=torch.float32).contiguous()
     out = torch.empty(b, t, 180, resolution, resolution, device="cuda", dtype=torch.float32)
-    capi.check(capi.lib.dfot_ray_encode(capi.ptr(raw), capi.ptr(out), b, t, resolution, capi.stream_ptr()))
+    fn = capi.lib.dfot_ray_encode_normalized if normalized else capi.lib.dfot_ray_encode
+    capi.check(fn(capi.ptr(raw), capi.ptr(out), b, t, resolution, capi.stream_ptr()))
     return out
 
 
 @ray_encoding.register_fake
-def _(raw_poses, resolution):
+def _(raw_poses, resolution, normalized=False):
     b, t = raw_poses.shape[:2]
     return raw_poses.new_empty((b, t, 180, resolution, resolution), dtype=torch.float32)
 

@@ -41,6 +41,12 @@ class SamplerConfig:
     keyframe_density: Optional[float] = None
     sliding_context_len: Optional[int] = None
     interpolation_max_batch_size: Optional[int] = None
+    # refinement_sampling of dfot_video.yaml:41-44 ({enabled, goback_length, n_goback}); honoured by the difference sampler only,
+    # as in the reference (difference_dfot_video.py:433-440, 576-586)
+    refinement_sampling: Optional[Dict] = None
+    # camera_pose_conditioning of dfot_video_pose.yaml:7-9
+    camera_pose_normalize_by: str = "first"
+    camera_pose_bound: Optional[float] = None
 
 
 NoiseFn = Callable[[str, tuple], torch.Tensor]
@@ -76,11 +82,23 @@ class DFoTVideoPoseSampler:
     # ------------------------------------------------------------------ conditions
     @torch.no_grad()
     def _process_conditions(self, conditions: Optional[torch.Tensor], noise_levels=None) -> Optional[torch.Tensor]:
+        """raw poses (B,T,16) -> ray encoding (B,T,180,H,W).  ``noise_levels`` (B,T) is only looked at where the reference looks
+        at it: under temporal History Guidance the poses of tokens at pure noise are replaced by interpolated ones."""
         if conditions is None:
             return None
         if conditions.shape[-1] != 16:
             raise ValueError(f"raw camera poses must have 16 values per frame, got {conditions.shape[-1]}")
-        return torch.ops.dfot.ray_encoding(conditions, int(self.x_shape[-1]))
+        cfg = self.cfg
+        if cfg.camera_pose_normalize_by not in ("first", "mean"):
+            raise ValueError(f"Unknown camera pose normalization method: {cfg.camera_pose_normalize_by}")
+        interp = None
+        if noise_levels is not None and getattr(self, "_interpolate_masked_poses", False):
+            interp = np.asarray(noise_levels.detach().cpu().numpy() if torch.is_tensor(noise_levels) else noise_levels) == self.timesteps - 1
+        if cfg.camera_pose_normalize_by == "first" and cfg.camera_pose_bound is None and interp is None:
+            return torch.ops.dfot.ray_encoding(conditions, int(self.x_shape[-1]))
+        from . import pose
+        world = pose.normalize_poses(conditions.detach().float().cpu().numpy(), cfg.camera_pose_normalize_by, cfg.camera_pose_bound, interp)
+        return torch.ops.dfot.ray_encoding(torch.from_numpy(world), int(self.x_shape[-1]), True)
 
     # ------------------------------------------------------------------ denoising loss (no backward)
     @torch.no_grad()
@@ -178,12 +196,13 @@ class DFoTVideoPoseSampler:
     @torch.no_grad()
     def _sample_sequence(self, batch_size: int, length: Optional[int] = None, context: Optional[torch.Tensor] = None,
                          context_mask: Optional[torch.Tensor] = None, conditions: Optional[torch.Tensor] = None,
-                         history_guidance: Optional[HistoryGuidance] = None, **_) -> Tuple[torch.Tensor, None]:
+                         history_guidance: Optional[HistoryGuidance] = None, _refine: Optional[Tuple[int, int]] = None,
+                         **_) -> Tuple[torch.Tensor, None]:
         cfg, sch = self.cfg, self.schedule
         x_shape = self.x_shape
-        if conditions is not None and history_guidance is not None and history_guidance.needs_pose_interpolation:
-            raise NotImplementedError("temporal history guidance with camera poses needs the reference's pose interpolation of "
-                                      "masked frames (CameraPose.replace_with_interpolation, slerp), which is not built")
+        # temporal History Guidance + camera poses: the poses of tokens shown as pure noise are re-interpolated, per branch and
+        # per step (dfot_video_pose.py:75-83) -- one encoding per distinct mask pattern, cached for the window
+        pose_interp = conditions is not None and history_guidance is not None and history_guidance.needs_pose_interpolation
         if length is None:
             length = self.max_tokens if context is None else context.shape[1]
         if length > self.max_tokens:
@@ -220,12 +239,19 @@ class DFoTVideoPoseSampler:
         if history_guidance is None:
             history_guidance = HistoryGuidance.conditional(timesteps=self.timesteps)
 
-        sm = sch.scheduling_matrix(cfg.scheduling_matrix, horizon - padding, padding)
-        sm = np.repeat(sm[:, None, :], batch_size, axis=1)
-        if not cfg.is_full_sequence:
+        if _refine is None:
+            sm = sch.scheduling_matrix(cfg.scheduling_matrix, horizon - padding, padding)
+            sm = np.repeat(sm[:, None, :], batch_size, axis=1)
+            if not cfg.is_full_sequence:
+                sm = np.where(mask[None] >= 1, -1, sm)
+            changed = ~(sm[1:] == sm[:-1]).reshape(sm.shape[0] - 1, -1).all(axis=1)
+            sm = sm[int(np.argmax(changed)):]
+        else:  # refinement ladder: context tokens always at -1, no pruning of leading rows (dfot_video.py:881-890)
+            if cfg.scheduling_matrix != "full_sequence":
+                raise ValueError("Refining only support full_sequence scheduling matrix")
+            sm = sch.refine_scheduling_matrix(horizon - padding, _refine[0], _refine[1], padding)
+            sm = np.repeat(sm[:, None, :], batch_size, axis=1)
             sm = np.where(mask[None] >= 1, -1, sm)
-        changed = ~(sm[1:] == sm[:-1]).reshape(sm.shape[0] - 1, -1).all(axis=1)
-        sm = sm[int(np.argmax(changed)):]
         self.trace.append({"context_mask": mask.copy(), "batch": batch_size, "rows": sm.shape[0]})
 
         # ---- plan every step on the host first and upload the coefficient tables ONCE: the step loop below then
@@ -233,6 +259,16 @@ class DFoTVideoPoseSampler:
         plans = []
         for m in range(sm.shape[0] - 1):
             frm, to = sm[m], sm[m + 1]
+            if _refine is not None and not frm[0, -1] > to[0, -1]:
+                # going back up the ladder: every token is re-noised from its level to the next one,
+                # q_sample_from_x_k (discrete_diffusion.py:252-260); index -1 (clean tokens) wraps to the last table entry
+                # exactly as the reference's gather does, which makes their scale 1
+                ac = sch.alphas_cumprod.astype(np.float32)
+                scale = np.where(to == self.timesteps - 1, np.float32(1), ac[to] / ac[frm]).astype(np.float32)
+                tables = np.zeros((8, batch_size, horizon), np.float32)
+                tables[0], tables[1] = np.sqrt(scale), np.sqrt(np.float32(1) - scale)
+                plans.append(dict(renoise=True, nfe=1, bm=batch_size, tables=tables, gen=(mask == 0).astype(np.uint8), cmask=None))
+                continue
             mask = np.where((mask == 0) & (frm == -1), 2, mask)
             plan = history_guidance.plan(mask, frm, to, replacement_only=cfg.is_full_sequence)
             bm = batch_size * plan.nfe
@@ -263,6 +299,8 @@ class DFoTVideoPoseSampler:
             p_["tables_dev"] = flat_dev[off:off + n].view(8, p_["bm"], horizon)
             off += n
             p_["gen_dev"] = gens_dev[i]
+            if p_.get("renoise"):
+                continue
             wsrc = p_["plan"].weights if p_["plan"].tok_weights is None else p_["plan"].tok_weights
             wkey = wsrc.tobytes()
             if wkey not in weight_cache:
@@ -278,8 +316,22 @@ class DFoTVideoPoseSampler:
                     cmask_cache[ckey] = torch.from_numpy(p_["cmask"]).cuda()
                 p_["cmask_dev"] = cmask_cache[ckey]
 
-        cond_full = self._process_conditions(conditions)
+        cond_full = None if pose_interp else self._process_conditions(conditions)
         cond_rep, cond_nfe = None, 0
+        if pose_interp:
+            by_mask: Dict[bytes, torch.Tensor] = {}
+            self._interpolate_masked_poses = True
+            try:
+                for p_ in plans:
+                    if p_.get("renoise"):
+                        continue
+                    lv = p_["plan"].levels.reshape(p_["bm"], horizon)
+                    key = (lv == self.timesteps - 1).tobytes() + bytes([p_["nfe"]])
+                    if key not in by_mask:
+                        by_mask[key] = self._process_conditions(conditions.repeat_interleave(p_["nfe"], dim=0), lv)
+                    p_["cond"] = by_mask[key]
+            finally:
+                self._interpolate_masked_poses = False
         xs = xs.contiguous()
         s = capi.stream_ptr
         strict = bool(getattr(self.noise_fn, "strict_order", False))
@@ -318,6 +370,8 @@ class DFoTVideoPoseSampler:
             if cond_full is not None and cond_nfe != nfe:
                 cond_rep = cond_full if nfe == 1 else cond_full.repeat_interleave(nfe, dim=0)
                 cond_nfe = nfe
+            if "cond" in p_:
+                cond_rep = p_["cond"]
             # discrete diffusion hands the backbone integer level indices (exact in the float32 table)
             lvl = tables[7] if cfg.diffusion.is_continuous else tables[7].to(torch.int32)
             v = self.model(x_in, lvl, cond_rep, p_["cmask_dev"])
@@ -332,6 +386,24 @@ class DFoTVideoPoseSampler:
                                                   capi.ptr(xs_next), batch_size, nfe, horizon, f, s()))
             return xs_next
 
+        def renoise(p_, xs):
+            noise = self.noise_fn("renoise", (batch_size, horizon, *x_shape)).to(device="cuda", dtype=torch.float32)
+            noise = noise.clamp(-cfg.diffusion.clip_noise, cfg.diffusion.clip_noise).contiguous()
+            out = torch.empty_like(xs)
+            capi.check(capi.lib.dfot_hg_prepare(capi.ptr(xs), capi.ptr(noise), capi.ptr(p_["tables_dev"][0]), capi.ptr(p_["tables_dev"][1]),
+                                                capi.ptr(out), batch_size, 1, horizon, f, s()))
+            return out
+
+        if _refine is not None:
+            for p_ in plans:
+                if p_.get("renoise"):
+                    xs = renoise(p_, xs)
+                    continue
+                xs = step(p_, xs, draw_noise(p_), p_["tables_dev"], p_["gen_dev"])
+                if strict:  # the reference re-noises the context here (q_sample) and then discards it (dfot_video.py:984-992)
+                    self.noise_fn("refine_context", (batch_size, horizon, *x_shape))
+            self.window_forwards += sum(p_["bm"] for p_ in plans if not p_.get("renoise"))
+            return (xs[:, :-padding] if padding > 0 else xs), None
         uniform = all(p_["bm"] == plans[0]["bm"] and p_["cmask_dev"] is plans[0]["cmask_dev"]
                       and p_["weights_dev"] is plans[0]["weights_dev"] for p_ in plans)
         if self.use_graph and uniform and not strict and len(plans) > 2:
@@ -343,6 +415,24 @@ class DFoTVideoPoseSampler:
         if padding > 0:
             xs = xs[:, :-padding]
         return xs, None
+
+    @torch.no_grad()
+    def _sample_sequence_refine(self, batch_size: int, goback_length: int, n_goback: int, length: Optional[int] = None,
+                                context: Optional[torch.Tensor] = None, context_mask: Optional[torch.Tensor] = None,
+                                conditions: Optional[torch.Tensor] = None, history_guidance: Optional[HistoryGuidance] = None,
+                                **_) -> Tuple[torch.Tensor, None]:
+        """Refinement sampling of the fork (dfot_video.py:765-1008): the full-sequence ladder with excursions back up
+        (``Schedule.refine_scheduling_matrix``).  A row whose last token of the first sample moves DOWN is an ordinary History-
+        Guidance DDIM step; any other row re-noises every token from its level to the next (``q_sample_from_x_k``) with fresh
+        clamped noise (noise tag "renoise").  As in the reference, a window whose last token is context or padding therefore
+        only ever re-noises.  The reference's denoising branch is only well-formed for one-branch guidance (it re-noises the
+        (B,..) context with (B*NFE,..) levels and discards the result); with more branches this does the ordinary composed step."""
+        return self._sample_sequence(batch_size, length=length, context=context, context_mask=context_mask, conditions=conditions,
+                                     history_guidance=history_guidance, _refine=(int(goback_length), int(n_goback)))
+
+    def _window_sampler(self):
+        """which per-window sampler the rollout / interpolation drivers call (the base classes always use _sample_sequence)"""
+        return self._sample_sequence
 
     def _run_steps_graph(self, plans, xs, draw_noise, step, flat_dev, gens_dev, horizon):
         """hipGraph execution of the step loop: step 0 runs eagerly (lazy initialisation, pose caches), then ONE step
@@ -435,7 +525,7 @@ class DFoTVideoPoseSampler:
                 cmask[:, -generated:] = 2
             cmask = torch.cat([cmask, torch.zeros(batch_size, h, dtype=torch.long)], 1)
             cond = None if conditions is None else conditions[:, cur - c: cur - c + mt]
-            new, _ = self._sample_sequence(batch_size, length=c + h, context=window, context_mask=cmask,
+            new, _ = self._window_sampler()(batch_size, length=c + h, context=window, context_mask=cmask,
                                            conditions=cond, history_guidance=history_guidance)
             xs = torch.cat([xs, new[:, -h:]], 1)
             cur = xs.shape[1]
@@ -494,7 +584,7 @@ class DFoTVideoPoseSampler:
                     return ctx.new_zeros((0, *ctx.shape[1:]))
                 if hasattr(self.noise_fn, "set_windows"):
                     self.noise_fn.set_windows([(si + 1) * 100000 + i for i in ids])
-                o, _ = self._sample_sequence(len(ids), context=ctx[ids], context_mask=msk[ids].long(),
+                o, _ = self._window_sampler()(len(ids), context=ctx[ids], context_mask=msk[ids].long(),
                                              conditions=None if cnd is None else cnd[ids], history_guidance=hg)
                 return o
 
@@ -549,6 +639,13 @@ class DifferenceDFoTVideoSampler(DFoTVideoSampler):
     on the 2T merged tokens (its `_sample_sequence` / `_predict_sequence` / `_predict_videos` differ from the base class
     only by `max_tokens * 2`, difference_dfot_video.py:214-278,463-607,609-846).  Construct it with
     ``SamplerConfig(max_tokens=2 * T)`` and a ``DifferenceDiT3D`` backbone built with ``max_tokens=T``."""
+
+    def _window_sampler(self):
+        r = self.cfg.refinement_sampling
+        if r and r.get("enabled"):
+            import functools
+            return functools.partial(self._sample_sequence_refine, goback_length=int(r["goback_length"]), n_goback=int(r["n_goback"]))
+        return self._sample_sequence
 
     @staticmethod
     def merge_tensors(x: Optional[torch.Tensor], y: Optional[torch.Tensor]) -> Optional[torch.Tensor]:

@@ -155,11 +155,56 @@ class Sampler:
                                                 replacement_only=cfg.is_full_sequence)
             cond = None
             if conditions is not None:
-                cond = self.cond_fn(conditions.repeat_interleave(g.nfe, dim=0))
+                rep = conditions.repeat_interleave(g.nfe, dim=0)
+                # dfot_video_pose.py:75-83: under temporal guidance the pose processing also sees the branch's noise levels
+                cond = self.cond_fn(rep, f_in) if getattr(self, "cond_uses_levels", False) else self.cond_fn(rep)
             step_noise = self.noise_fn("ddim", tuple(x_in.shape))
             x_out = self.diff.ddim_step(x_in, f_in, t_in, cond, cmask, step_noise)
             xs = g.compose(x_out)
             xs = torch.where(_ext(context_mask, nd) == 0, xs, prev)
+        return xs[:, :length] if padding > 0 else xs
+
+    # ------------------------------------------------------------------ one window, refinement ladder
+    def sample_sequence_refine(self, batch_size: int, goback_length: int, n_goback: int, context: torch.Tensor,
+                               context_mask: torch.Tensor, conditions: Optional[torch.Tensor], scheme: hg.Scheme,
+                               length: Optional[int] = None) -> torch.Tensor:
+        """_sample_sequence_refine (dfot_video.py:765-1008) for one-branch guidance: a row whose last token (sample 0) moves
+        down is a DDIM step (followed by a q_sample of the context whose result the reference discards -- the draw is kept so a
+        replayed noise list stays aligned); every other row re-noises all tokens (q_sample_from_x_k, discrete_diffusion.py:252-260)."""
+        cfg = self.cfg
+        length = context.shape[1] if length is None else length
+        horizon = cfg.max_tokens
+        padding = horizon - length
+        xs = self.noise_fn("init", (batch_size, horizon, *cfg.x_shape))
+        if padding > 0:
+            context = torch.cat([context, context.new_zeros(batch_size, padding, *cfg.x_shape)], 1)
+            context_mask = torch.cat([context_mask, -torch.ones(batch_size, padding, dtype=torch.long)], 1)
+        nd = xs.ndim
+        xs = torch.where(_ext(context_mask, nd) >= 1, context, xs)
+        sm = sch.refine_scheduling_matrix(horizon - padding, goback_length, n_goback, padding, cfg.timesteps, cfg.sampling_timesteps)
+        sm = sm[:, None, :].repeat(1, batch_size, 1)
+        sm = torch.where(context_mask[None] >= 1, -1, sm)
+        ac = self.diff.tables.alphas_cumprod
+        for m in range(sm.shape[0] - 1):
+            frm, to = sm[m], sm[m + 1]
+            if frm[0, -1].item() > to[0, -1].item():
+                context_mask = torch.where((context_mask == 0) & (frm == -1), 2, context_mask)
+                prev = xs.clone()
+                g = hg.Guidance(scheme, context_mask)
+                if g.nfe != 1:
+                    raise ValueError("the reference's refinement step is only well-formed for one-branch guidance")
+                x_in, f_in, t_in, cmask = g.prepare(xs, frm, to, self.diff.q_sample, self.noise_fn, replacement_only=cfg.is_full_sequence)
+                cond = None if conditions is None else self.cond_fn(conditions)
+                x_out = self.diff.ddim_step(x_in, f_in, t_in, cond, cmask, self.noise_fn("ddim", tuple(x_in.shape)))
+                xs = g.compose(x_out)
+                xc_t = self.diff.q_sample(context, t_in, self.noise_fn("refine_context", tuple(context.shape)))
+                xs = torch.where(_ext(context_mask, nd) == 0, xs, xc_t)
+                xs = torch.where(_ext(context_mask, nd) == 0, xs, prev)
+            else:
+                noise = self.noise_fn("renoise", tuple(xs.shape))
+                scale = ac[to] / ac[frm]  # index -1 wraps to the last entry, as in the reference's gather
+                scale = torch.where(to == cfg.timesteps - 1, torch.ones_like(scale), scale)
+                xs = _ext(scale.sqrt(), nd) * xs + _ext((1 - scale).sqrt(), nd) * noise
         return xs[:, :length] if padding > 0 else xs
 
     # ------------------------------------------------------------------ sliding window

@@ -125,6 +125,25 @@ def scheduling_matrix(kind: str, horizon: int, padding: int, timesteps: int,
     return levels
 
 
+def refine_scheduling_matrix(horizon: int, goback_length: int, n_goback: int, padding: int, timesteps: int,
+                             sampling_timesteps: int) -> torch.Tensor:
+    """_generate_refine_scheduling_matrix (base_pytorch_video_algo.py:949-976): the full-sequence ladder; at every DDIM index in
+    range(1, S - goback_length, goback_length) it climbs goback_length indices back up and down again, n_goback times."""
+    s = sampling_timesteps
+    marks = list(range(1, s - goback_length, goback_length))
+    seq = []
+    for t in range(s, -1, -1):
+        seq.append(t)
+        if t in marks:
+            for _ in range(n_goback):
+                seq.extend(range(t + 1, t + goback_length + 1))
+                seq.extend(range(t + goback_length - 1, t - 1, -1))
+    levels = ddim_levels(timesteps, s)[torch.tensor(seq).long()][:, None].repeat(1, horizon)
+    if padding > 0:
+        levels = torch.cat([levels, torch.full((levels.shape[0], padding), timesteps - 1, dtype=torch.long)], dim=1)
+    return levels
+
+
 def training_logsnr(t: torch.Tensor, shift: float = 0.125, logsnr_min: float = -15.0,
                     logsnr_max: float = 15.0) -> torch.Tensor:
     """Continuous-time cosine logSNR(t), t in [0,1] (fp32 like the reference buffers)."""

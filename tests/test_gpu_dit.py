@@ -397,3 +397,30 @@ def test_training_step_forward_discrete():
     _, ref_loss = osm.discrete_training_loss(lambda x, k, c, m: odit.forward(params, small, x, k), tb, xs, levels, noise.clamp(-20, 20), **lw)
     ref = (ref_loss.flatten(2).mean(-1) * loss_masks.float()).mean()
     assert abs(out["loss"].item() - ref.item()) < 2e-2 * abs(ref.item())
+
+
+def test_refinement_sampler_vs_reference_fixture():
+    """_sample_sequence_refine: DDIM steps + re-noising rows on the refinement ladder, replaying the reference's draws"""
+    import dfot_amd
+    g = load("sampler_refine.npz")
+    _, _, small = tiny_cfgs()
+    params, model = build(small, 2)
+    assert digest(params) == str(g["digest"])
+    cfg = dfot_amd.SamplerConfig(x_shape=(4, 16, 8), max_tokens=5,
+                                 diffusion=dfot_amd.DiffusionConfig(sampling_timesteps=6, beta_schedule="cosine", is_continuous=False))
+    nfn = ReplayList([T(g[f"noise{i}"]) for i in range(int(g["n_noise"]))])
+    sampler = dfot_amd.DFoTVideoSampler(cfg, model, nfn)
+    out, _ = sampler._sample_sequence_refine(2, goback_length=2, n_goback=2, context=T(g["xs"]).cuda(), context_mask=T(g["mask"]))
+    assert not nfn.queue
+    ref = T(g["out"])
+    out = out.cpu()
+    assert torch.equal(out[:, :2], ref[:, :2])
+    assert psnr(out, ref) >= 35.0
+    # padded window: only re-noising rows (no backbone call at all), so the result is exact up to fp32 rounding
+    nfn = ReplayList([T(g[f"pnoise{i}"]) for i in range(int(g["n_pnoise"]))])
+    sampler = dfot_amd.DFoTVideoSampler(cfg, model, nfn)
+    before = sampler.window_forwards
+    out4, _ = sampler._sample_sequence_refine(2, goback_length=2, n_goback=2, length=4, context=T(g["xs"])[:, :4].cuda(),
+                                              context_mask=T(g["mask"])[:, :4])
+    assert not nfn.queue and sampler.window_forwards == before
+    torch.testing.assert_close(out4.cpu(), T(g["out4"]), rtol=1e-5, atol=1e-5)

@@ -262,3 +262,55 @@ def test_hipgraph_survives_workspace_growth():
             assert samp.graph_captures >= 2 and samp.graph_replays > 0
     assert torch.isfinite(outs[0]).all()
     assert torch.equal(outs[0], outs[1])
+
+
+def test_pose_options_vs_oracle():
+    """normalize_by mean, bound and masked-pose interpolation through _process_conditions -> dfot_ray_encode_normalized"""
+    import dfot_amd
+    from oracle import pose as opose
+    cnd = poses(2, 8, 4)
+    mask = torch.zeros(2, 8, dtype=torch.bool)
+    mask[0, [2, 3, 6]] = True
+    mask[1, 0] = True
+    for kw in (dict(normalize_by="mean"), dict(normalize_by="first", bound=1.0), dict(normalize_by="mean", bound=0.5, interpolate_mask=mask)):
+        cfg = dfot_amd.SamplerConfig(x_shape=(3, 64, 64), camera_pose_normalize_by=kw["normalize_by"], camera_pose_bound=kw.get("bound"))
+        samp = dfot_amd.DFoTVideoPoseSampler(cfg, backbone=None)
+        lv = None
+        if "interpolate_mask" in kw:
+            samp._interpolate_masked_poses = True
+            lv = torch.where(mask, 999, 500)
+        out = samp._process_conditions(cnd, lv).cpu()
+        ref = opose.process_conditions(cnd, 64, **kw)
+        # channels with frequency index <= 9: sin(2^f pi x) amplifies the fp32 rounding of x by 2^f pi
+        ch = torch.tensor([c for c in range(180) if c % 15 <= 9])
+        torch.testing.assert_close(out[:, :, ch], ref[:, :, ch], atol=3e-3, rtol=0)
+        assert (out - ref).abs().max() < 0.1
+
+
+def test_temporal_guidance_with_camera_poses():
+    """temporal History Guidance on the pose model: per branch, the poses of tokens shown as pure noise are interpolated
+    from the others (slerp / lerp) before the ray encoding -- one window, both paths on identical noise"""
+    import dfot_amd
+    from oracle import guidance as ohg, pose as opose, sampler as osm, schedule as sch, uvit as ouvit
+    res, steps, batch = 64, 2, 1
+    scheme = dict(name="temporal", hist_subsequences=[[0], [0, 1]], hist_weights=[0.5, 1.0])
+    ocfg, params, model = build(blocks=(1, 1, 1), mid=2)
+    g = torch.Generator().manual_seed(3)
+    ctx = torch.randn(batch, 8, 3, res, res, generator=g)
+    cmask = torch.tensor([[1, 1, 0, 0, 0, 0, 0, 0]] * batch)
+    cnd = poses(batch, 8, 7)
+    r1, r2 = Replay(5, "cpu"), Replay(5, "cuda")
+    diff = osm.Diffusion(sch.build_tables(), lambda x, k, c, m: ouvit.forward(params, ocfg, x, k, c, m), sampling_timesteps=steps)
+    osamp = osm.Sampler(osm.SamplerConfig(x_shape=(3, res, res), sampling_timesteps=steps), diff,
+                        lambda c, lv: opose.process_conditions(c, res, interpolate_mask=lv == 999), r1)
+    osamp.cond_uses_levels = True
+    with torch.no_grad():
+        ref = osamp.sample_sequence(batch, ctx, cmask, cnd, ohg.make_scheme(**scheme), length=8)
+    samp = dfot_amd.DFoTVideoPoseSampler(
+        dfot_amd.SamplerConfig(x_shape=(3, res, res), diffusion=dfot_amd.DiffusionConfig(sampling_timesteps=steps)), model, r2)
+    out, _ = samp._sample_sequence(batch, length=8, context=ctx, context_mask=cmask, conditions=cnd,
+                                   history_guidance=dfot_amd.HistoryGuidance.from_config(scheme))
+    assert r1.log == r2.log
+    p = psnr(out.cpu(), ref)
+    print(f"temporal + poses: PSNR {p:.1f} dB")
+    assert p >= 35.0

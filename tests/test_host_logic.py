@@ -84,15 +84,57 @@ def test_ddim_coefficients_reproduce_reference_step():
     assert np.allclose(an[to < 0], 1.0) and np.allclose(cn[to < 0], 0.0)
 
 
-def test_temporal_guidance_with_camera_poses_is_rejected():
-    """the reference re-interpolates the poses of masked frames for this scheme (slerp): not built, refused loudly"""
+def _random_poses(b, t, seed):
+    from scipy.spatial.transform import Rotation
+    rng = np.random.default_rng(seed)
+    rot = Rotation.random(b * t, random_state=seed).as_matrix().reshape(b, t, 3, 3)
+    rt = np.concatenate([rot, rng.normal(size=(b, t, 3, 1))], -1).reshape(b, t, 12)
+    return np.concatenate([np.tile([0.5, 0.9, 0.5, 0.5], (b, t, 1)), rt], -1).astype(np.float32)
+
+
+def test_pose_options_host_algebra():
+    """normalize_by mean / bound / interpolation of masked poses (the reference does these with roma, absent here: parity unpinned
+    against it).  Checked against SciPy's Rotation / Slerp -- the construction roma documents -- and against the oracle."""
     import torch
-    import dfot_amd
-    hg = HistoryGuidance.temporal(hist_subsequences=[[0]], hist_weights=[1.0])
-    sampler = dfot_amd.DFoTVideoPoseSampler(dfot_amd.SamplerConfig(x_shape=(3, 16, 16)), backbone=None)
-    with pytest.raises(NotImplementedError):
-        sampler._sample_sequence(1, context=torch.zeros(1, 8, 3, 16, 16), context_mask=torch.zeros(1, 8, dtype=torch.long),
-                                 conditions=torch.zeros(1, 8, 16), history_guidance=hg)
+    from scipy.spatial.transform import Rotation, Slerp
+    from dfot_amd import pose
+    from oracle import pose as opose
+    raw = _random_poses(2, 8, 3)
+    rot = raw[..., 4:].reshape(2, 8, 3, 4)[..., :3]
+    q = pose._to_quat(rot)
+    qs = Rotation.from_matrix(rot.reshape(-1, 3, 3)).as_quat().reshape(2, 8, 4)
+    assert np.minimum(np.abs(q - qs).max(-1), np.abs(q + qs).max(-1)).max() < 1e-6
+    np.testing.assert_allclose(pose._to_rotmat(q), rot, atol=1e-6)
+    # interpolation: frames 2..4 and 6 masked -> slerp/lerp between 1 and 5, 5 and 7; frame 0 masked -> held from frame 1
+    mask = np.zeros((2, 8), bool)
+    mask[0, [0, 2, 3, 4, 6]] = True
+    r2, t2 = pose.interpolate_masked(rot, raw[..., 4:].reshape(2, 8, 3, 4)[..., 3], mask)
+    np.testing.assert_allclose(r2[1], rot[1], atol=1e-6)  # unmasked video: only the quaternion round trip
+    np.testing.assert_allclose(r2[0, 0], rot[0, 1], atol=1e-6)
+    sl = Slerp([1, 5], Rotation.from_matrix(rot[0, [1, 5]]))
+    np.testing.assert_allclose(r2[0, 1:6], sl([1, 2, 3, 4, 5]).as_matrix(), atol=2e-6)
+    tr = raw[0, :, 4:].reshape(8, 3, 4)[..., 3]
+    np.testing.assert_allclose(t2[0, 3], 0.5 * (tr[1] + tr[5]), atol=1e-6)
+    np.testing.assert_allclose(t2[0, 6], 0.5 * (tr[5] + tr[7]), atol=1e-6)
+    # all options against the oracle's restatement
+    for kw in (dict(normalize_by="mean"), dict(normalize_by="first", bound=1.0), dict(normalize_by="mean", bound=0.5, interpolate_mask=mask)):
+        world = pose.normalize_poses(raw, **kw)
+        okw = dict(kw)
+        if "interpolate_mask" in okw:
+            okw["interpolate_mask"] = torch.from_numpy(mask)
+        _, r_ref, t_ref = opose.normalized_poses(torch.from_numpy(raw), **okw)
+        rt = world[..., 4:].reshape(2, 8, 3, 4)
+        np.testing.assert_allclose(rt[..., :3], r_ref.numpy(), atol=2e-6)
+        np.testing.assert_allclose(rt[..., 3], t_ref.numpy(), atol=5e-6)
+        assert np.array_equal(world[..., :4], raw[..., :4])
+    # normalised by the first frame: frame 0 becomes the identity pose
+    w = pose.normalize_poses(raw, "first")
+    np.testing.assert_allclose(w[:, 0, 4:].reshape(2, 3, 4), np.tile(np.eye(3, 4, dtype=np.float32), (2, 1, 1)), atol=1e-6)
+    # bound: every axis of the camera positions fits [-bound, bound] and touches it
+    w = pose.normalize_poses(raw, "first", bound=0.25)
+    assert np.allclose(np.abs(w[..., 4:].reshape(2, 8, 3, 4)[..., 3]).max(axis=1), 0.25, atol=1e-6)
+    with pytest.raises(ValueError):
+        pose.normalize_poses(raw, "median")
 
 
 @pytest.mark.parametrize("kind", ["interleaved", "gibbs", "autoregressive"])

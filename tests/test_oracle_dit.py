@@ -202,3 +202,25 @@ def test_temporal_guidance_sampler_vs_reference_fixture():
     out = osm.Sampler(cfg, diff, None, nfn).predict_videos(T(g["vid"]), 2, None)
     assert not nfn.queue
     np.testing.assert_allclose(out.numpy(), g["pred"], rtol=1e-3, atol=2e-3)
+
+
+def test_refinement_sampler_vs_reference_fixture():
+    """_sample_sequence_refine of the fork: DDIM steps + q_sample_from_x_k re-noising on the refinement ladder; a padded window
+    (last column pinned at pure noise) only ever re-noises, as in the reference."""
+    g = load("sampler_refine.npz")
+    p = odit.seeded_params(SMALL, 2)
+    assert digest(p) == str(g["digest"])
+    tb = sch.build_tables(beta_schedule="cosine")
+    model = lambda x, k, c, m: odit.forward(p, SMALL, x, k)
+    diff = osm.Diffusion(tb, model, sampling_timesteps=6, is_continuous=False)
+    cfg = osm.SamplerConfig(x_shape=(4, 16, 8), max_tokens=5, sampling_timesteps=6)
+    from oracle import guidance as hgo
+    scheme = hgo.make_scheme(name="conditional")
+    nfn = osm.replay_noise_fn([T(g[f"noise{i}"]) for i in range(int(g["n_noise"]))])
+    out = osm.Sampler(cfg, diff, None, nfn).sample_sequence_refine(2, 2, 2, T(g["xs"]), T(g["mask"]), None, scheme)
+    assert not nfn.queue
+    np.testing.assert_allclose(out.numpy(), g["out"], rtol=1e-3, atol=2e-3)
+    nfn = osm.replay_noise_fn([T(g[f"pnoise{i}"]) for i in range(int(g["n_pnoise"]))])
+    out4 = osm.Sampler(cfg, diff, None, nfn).sample_sequence_refine(2, 2, 2, T(g["xs"])[:, :4], T(g["mask"])[:, :4], None, scheme, length=4)
+    assert not nfn.queue
+    np.testing.assert_allclose(out4.numpy(), g["out4"], rtol=1e-3, atol=2e-3)

@@ -21,6 +21,8 @@ loaded strictly into the reference module and re-created bit-identically by the 
   training_noise.npz  BaseVideoAlgo._get_training_noise_levels (continuous RE10K-style algo and discrete K600-style algo) for
                     random_independent / random_uniform / interleaved / uniform_future / fixed_context / variable_context,
                     generator seed 123
+  sampler_refine.npz  DFoTVideo._sample_sequence_refine (refinement ladder: DDIM steps + q_sample_from_x_k re-noising), small DiT,
+                    6 DDIM indices, goback_length 2, n_goback 2, conditional guidance, full window and a padded (length 4) window
   sampler_k600.npz  DFoTVideo._predict_videos with DiscreteDiffusion (cosine, pred_v, integer levels): 5 tokens,
                     context 2, 4 DDIM steps, vanilla history guidance 2.0 (small DiT) with the injected noise
 """
@@ -200,6 +202,28 @@ def hg_temporal_fixture(R):
 
 
 @torch.no_grad()
+def refine_fixture(R):
+    print("sampler refine")
+    small = odit.DiTConfig(hidden_size=128, depth=2, num_heads=4, patch_size=1, in_channels=4, resolution=(16, 8), max_tokens=5)
+    algo = R["DFoTVideo"](video_cfg(R["AttrDict"], small, sampling_steps=6, hg=dict(name="conditional"))).eval()
+    ps = odit.seeded_params(small, 2)
+    algo.diffusion_model.model.load_state_dict(ps, strict=True)
+    g = torch.Generator().manual_seed(12)
+    vid = torch.randn(2, 5, 4, 16, 8, generator=g)
+    mask = torch.tensor([[1, 1, 0, 0, 0]] * 2)
+    algo.generator = torch.Generator().manual_seed(0)
+    with RandnRecorder() as rec:
+        out, _ = algo._sample_sequence_refine(2, goback_length=2, n_goback=2, context=vid.clone(), context_mask=mask.clone())
+    arrays = {f"noise{i}": d for i, d in enumerate(rec.draws)}
+    # a shorter window: the padded last column stays at pure noise, so the reference only ever re-noises
+    with RandnRecorder() as rec2:
+        out4, _ = algo._sample_sequence_refine(2, goback_length=2, n_goback=2, context=vid[:, :4].clone(), context_mask=mask[:, :4].clone())
+    arrays.update({f"pnoise{i}": d for i, d in enumerate(rec2.draws)})
+    save("sampler_refine.npz", xs=vid, mask=mask, out=out, out4=out4, n_noise=np.array(len(rec.draws)), n_pnoise=np.array(len(rec2.draws)),
+         digest=np.array(weights_digest(ps)), **arrays)
+
+
+@torch.no_grad()
 def diff_sampler_fixture(R):
     print("sampler k600 difference")
     A = R["AttrDict"]
@@ -230,6 +254,8 @@ def diff_sampler_fixture(R):
 def main():
     R = ref_loader.install()
     A = R["AttrDict"]
+    if os.environ.get("ONLY") == "refine":
+        return refine_fixture(R)
 
     print("dit tiny")
     tiny = odit.DiTConfig(hidden_size=128, depth=3, num_heads=4, patch_size=1, in_channels=4, resolution=(16, 8), max_tokens=5)
@@ -292,6 +318,7 @@ def main():
     save("sampler_k600.npz", xs=vid, out=out, n_noise=np.array(len(rec.draws)), digest=np.array(weights_digest(ps)),
          alphas_cumprod=dm.alphas_cumprod, sqrt_alphas_cumprod=dm.sqrt_alphas_cumprod,
          sqrt_one_minus_alphas_cumprod=dm.sqrt_one_minus_alphas_cumprod, **arrays)
+    refine_fixture(R)
     diff_sampler_fixture(R)
     hg_temporal_fixture(R)
     training_noise_fixture(R)
