@@ -264,7 +264,13 @@ class DFoTVideoPoseSampler:
                 # q_sample_from_x_k (discrete_diffusion.py:252-260); index -1 (clean tokens) wraps to the last table entry
                 # exactly as the reference's gather does, which makes their scale 1
                 ac = sch.alphas_cumprod.astype(np.float32)
-                scale = np.where(to == self.timesteps - 1, np.float32(1), ac[to] / ac[frm]).astype(np.float32)
+                with np.errstate(divide="ignore", invalid="ignore"):
+                    scale = np.where(to == self.timesteps - 1, np.float32(1), ac[to] / ac[frm]).astype(np.float32)
+                if not (np.isfinite(scale).all() and (scale <= 1).all()):
+                    # 0/0 when the schedule ends at alphas_cumprod = 0 (K600 cosine) and the window has context tokens; scale > 1
+                    # when a DESCENDING row is taken for a re-noising row (last token of sample 0 is context or padding)
+                    raise ValueError("refinement sampling: this window / schedule makes q_sample_from_x_k produce NaN in the reference "
+                                     "(alphas_cumprod ratio not in [0, 1]); refused instead of returning NaN")
                 tables = np.zeros((8, batch_size, horizon), np.float32)
                 tables[0], tables[1] = np.sqrt(scale), np.sqrt(np.float32(1) - scale)
                 plans.append(dict(renoise=True, nfe=1, bm=batch_size, tables=tables, gen=(mask == 0).astype(np.uint8), cmask=None))
@@ -424,8 +430,9 @@ class DFoTVideoPoseSampler:
         """Refinement sampling of the fork (dfot_video.py:765-1008): the full-sequence ladder with excursions back up
         (``Schedule.refine_scheduling_matrix``).  A row whose last token of the first sample moves DOWN is an ordinary History-
         Guidance DDIM step; any other row re-noises every token from its level to the next (``q_sample_from_x_k``) with fresh
-        clamped noise (noise tag "renoise").  As in the reference, a window whose last token is context or padding therefore
-        only ever re-noises.  The reference's denoising branch is only well-formed for one-branch guidance (it re-noises the
+        clamped noise (noise tag "renoise").  In the reference a window whose last token is context or padding therefore only
+        ever re-noises, also on descending rows, and returns NaN (so does a schedule ending at alphas_cumprod 0 with context
+        tokens): those cases raise ValueError here.  The reference's denoising branch is only well-formed for one-branch guidance (it re-noises the
         (B,..) context with (B*NFE,..) levels and discards the result); with more branches this does the ordinary composed step."""
         return self._sample_sequence(batch_size, length=length, context=context, context_mask=context_mask, conditions=conditions,
                                      history_guidance=history_guidance, _refine=(int(goback_length), int(n_goback)))

@@ -205,12 +205,12 @@ def test_temporal_guidance_sampler_vs_reference_fixture():
 
 
 def test_refinement_sampler_vs_reference_fixture():
-    """_sample_sequence_refine of the fork: DDIM steps + q_sample_from_x_k re-noising on the refinement ladder; a padded window
-    (last column pinned at pure noise) only ever re-noises, as in the reference."""
+    """_sample_sequence_refine of the fork: DDIM steps + q_sample_from_x_k re-noising on the refinement ladder (RE10K schedule:
+    with the K600 cosine schedule alphas_cumprod[T-1] is 0 in fp32 and the reference divides 0/0 for every context token)."""
     g = load("sampler_refine.npz")
     p = odit.seeded_params(SMALL, 2)
     assert digest(p) == str(g["digest"])
-    tb = sch.build_tables(beta_schedule="cosine")
+    tb = sch.build_tables()
     model = lambda x, k, c, m: odit.forward(p, SMALL, x, k)
     diff = osm.Diffusion(tb, model, sampling_timesteps=6, is_continuous=False)
     cfg = osm.SamplerConfig(x_shape=(4, 16, 8), max_tokens=5, sampling_timesteps=6)
@@ -219,8 +219,10 @@ def test_refinement_sampler_vs_reference_fixture():
     nfn = osm.replay_noise_fn([T(g[f"noise{i}"]) for i in range(int(g["n_noise"]))])
     out = osm.Sampler(cfg, diff, None, nfn).sample_sequence_refine(2, 2, 2, T(g["xs"]), T(g["mask"]), None, scheme)
     assert not nfn.queue
+    assert np.isfinite(g["out"]).all()
     np.testing.assert_allclose(out.numpy(), g["out"], rtol=1e-3, atol=2e-3)
-    nfn = osm.replay_noise_fn([T(g[f"pnoise{i}"]) for i in range(int(g["n_pnoise"]))])
+    # a padded window only ever re-noises, also on descending rows (scale > 1): NaN in the reference, and in its restatement
+    assert bool(g["padded_window_is_nan"])
+    nfn = osm.default_noise_fn(torch.Generator().manual_seed(0))
     out4 = osm.Sampler(cfg, diff, None, nfn).sample_sequence_refine(2, 2, 2, T(g["xs"])[:, :4], T(g["mask"])[:, :4], None, scheme, length=4)
-    assert not nfn.queue
-    np.testing.assert_allclose(out4.numpy(), g["out4"], rtol=1e-3, atol=2e-3)
+    assert torch.isnan(out4).any()

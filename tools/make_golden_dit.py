@@ -22,7 +22,8 @@ loaded strictly into the reference module and re-created bit-identically by the 
                     random_independent / random_uniform / interleaved / uniform_future / fixed_context / variable_context,
                     generator seed 123
   sampler_refine.npz  DFoTVideo._sample_sequence_refine (refinement ladder: DDIM steps + q_sample_from_x_k re-noising), small DiT,
-                    6 DDIM indices, goback_length 2, n_goback 2, conditional guidance, full window and a padded (length 4) window
+                    RE10K schedule, 6 DDIM indices, goback_length 2, n_goback 2, conditional guidance (+ the fact that the
+                    reference returns NaN for a padded window)
   sampler_k600.npz  DFoTVideo._predict_videos with DiscreteDiffusion (cosine, pred_v, integer levels): 5 tokens,
                     context 2, 4 DDIM steps, vanilla history guidance 2.0 (small DiT) with the injected noise
 """
@@ -205,7 +206,14 @@ def hg_temporal_fixture(R):
 def refine_fixture(R):
     print("sampler refine")
     small = odit.DiTConfig(hidden_size=128, depth=2, num_heads=4, patch_size=1, in_channels=4, resolution=(16, 8), max_tokens=5)
-    algo = R["DFoTVideo"](video_cfg(R["AttrDict"], small, sampling_steps=6, hg=dict(name="conditional"))).eval()
+    # the K600 cosine schedule has alphas_cumprod[T-1] == 0 in fp32: q_sample_from_x_k then divides 0/0 for every context token
+    # (their level -1 gathers the LAST table entry) and the reference returns NaN everywhere -- the fixture therefore uses the
+    # RE10K schedule (cosine_simple_diffusion shifted 0.125, alphas_cumprod[T-1] > 0) with the discrete model
+    vc = video_cfg(R["AttrDict"], small, sampling_steps=6, hg=dict(name="conditional"))
+    vc["diffusion"]["beta_schedule"] = "cosine_simple_diffusion"
+    vc["diffusion"]["schedule_fn_kwargs"] = R["AttrDict"](dict(shifted=0.125, interpolated=False))
+    algo = R["DFoTVideo"](vc).eval()
+    assert float(algo.diffusion_model.alphas_cumprod[-1]) > 0
     ps = odit.seeded_params(small, 2)
     algo.diffusion_model.model.load_state_dict(ps, strict=True)
     g = torch.Generator().manual_seed(12)
@@ -215,12 +223,12 @@ def refine_fixture(R):
     with RandnRecorder() as rec:
         out, _ = algo._sample_sequence_refine(2, goback_length=2, n_goback=2, context=vid.clone(), context_mask=mask.clone())
     arrays = {f"noise{i}": d for i, d in enumerate(rec.draws)}
-    # a shorter window: the padded last column stays at pure noise, so the reference only ever re-noises
-    with RandnRecorder() as rec2:
-        out4, _ = algo._sample_sequence_refine(2, goback_length=2, n_goback=2, context=vid[:, :4].clone(), context_mask=mask[:, :4].clone())
-    arrays.update({f"pnoise{i}": d for i, d in enumerate(rec2.draws)})
-    save("sampler_refine.npz", xs=vid, mask=mask, out=out, out4=out4, n_noise=np.array(len(rec.draws)), n_pnoise=np.array(len(rec2.draws)),
-         digest=np.array(weights_digest(ps)), **arrays)
+    # a shorter window: the padded last column stays at pure noise, so the reference treats EVERY row as a re-noising row, also
+    # the descending ones, where alphas_cumprod[to] / alphas_cumprod[from] > 1 and sqrt(1 - scale) is NaN: recorded as a fact only
+    out4, _ = algo._sample_sequence_refine(2, goback_length=2, n_goback=2, context=vid[:, :4].clone(), context_mask=mask[:, :4].clone())
+    assert torch.isfinite(out).all()
+    save("sampler_refine.npz", xs=vid, mask=mask, out=out, padded_window_is_nan=np.array(bool(torch.isnan(out4).any())),
+         n_noise=np.array(len(rec.draws)), digest=np.array(weights_digest(ps)), **arrays)
 
 
 @torch.no_grad()
