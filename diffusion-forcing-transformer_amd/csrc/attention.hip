@@ -204,7 +204,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const bf16* __restrict__ Q, c
 template <int D, int NST, int DQK = D, int DV = D, bool QRELOAD = false>
 __global__ __launch_bounds__(256, QRELOAD ? 4 : 1) void attn_kernel_v2(const bf16* __restrict__ Q, const bf16* __restrict__ K,
                                                       const bf16* __restrict__ V, bf16* __restrict__ O, long ldo, int N,
-                                                      int heads, int xcd, int ohs, int dvalid) {
+                                                      int heads, int xcd, int ohs, int dvalid, float* __restrict__ lse) {
   static_assert(DQK % 16 == 0 && DV % 32 == 0 && DQK <= D && DV <= D, "head-dim sub-range");
   using C = AttnCfg<D>;
   constexpr float THR = 8.0f;
@@ -392,6 +392,7 @@ __global__ __launch_bounds__(256, QRELOAD ? 4 : 1) void attn_kernel_v2(const bf1
   const float l_tot = l_i + __shfl_xor(l_i, 32);
   const float inv = 1.0f / l_tot;
   const int b = bh / heads, hd = bh % heads;
+  if (lse && lh == 0) lse[(long)bh * N + q0 + lq] = m_run + __log2f(l_tot);  // training: log2-domain log-sum-exp per query
   bf16* orow = O + ((long)b * N + q0 + lq) * ldo + hd * ohs;
 #pragma unroll
   for (int dvt = 0; dvt < DV / 32; ++dvt)
@@ -407,7 +408,7 @@ __global__ __launch_bounds__(256, QRELOAD ? 4 : 1) void attn_kernel_v2(const bf1
 
 template <int D, int NST, int DQK = D, int DV = D, bool QRELOAD = false>
 static int launch_attn_v2(const bf16* q, const bf16* k, const bf16* v, bf16* o, long ldo, int batch, int heads, int n,
-                          hipStream_t stream, int ohs = D, int dvalid = D) {
+                          hipStream_t stream, int ohs = D, int dvalid = D, float* lse = nullptr) {
   auto kern = attn_kernel_v2<D, NST, DQK, DV, QRELOAD>;
   static const int xcd_flag = tuning_flag("ATTN_XCD", 1) | (tuning_flag("ATTN_PRIO", 1) << 1);
   const int lds = 2 * NST * AttnCfg<D>::TILE;
@@ -416,7 +417,7 @@ static int launch_attn_v2(const bf16* q, const bf16* k, const bf16* v, bf16* o, 
     DFOT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3((n / 128) * batch * heads), dim3(256), lds, stream, q, k, v, o, ldo, n, heads, xcd_flag, ohs, dvalid);
+  hipLaunchKernelGGL(kern, dim3((n / 128) * batch * heads), dim3(256), lds, stream, q, k, v, o, ldo, n, heads, xcd_flag, ohs, dvalid, lse);
   DFOT_CHECK_HIP(hipGetLastError());
   return DFOT_OK;
 }
@@ -466,16 +467,16 @@ int launch_attention(const bf16* q, const bf16* k, const bf16* v, bf16* o, long 
 // columns zero); the output is compact: O[row][head*d + c], c < d.  Used by the DiT blocks (d = 72).
 int attention_dstride(int d) { return d <= 64 ? 64 : 128; }
 int launch_attention_padded(const bf16* q, const bf16* k, const bf16* v, bf16* o, long ldo, int batch, int heads, int n, int d,
-                            hipStream_t stream) {
+                            hipStream_t stream, float* lse) {
   DFOT_REQUIRE(q && k && v && o, DFOT_ERR_ARG, "attention: null pointer");
   DFOT_REQUIRE(d > 0 && d <= 128 && d % 4 == 0, DFOT_ERR_SHAPE, "attention: head dim %d must be a multiple of 4, <= 128", d);
   DFOT_REQUIRE(n > 0 && n % 128 == 0, DFOT_ERR_SHAPE, "attention: N=%d must be a multiple of 128", n);
   DFOT_REQUIRE(ldo % 4 == 0, DFOT_ERR_SHAPE, "attention: output row stride %ld must be a multiple of 4", ldo);
-  if (d <= 32) return launch_attn_v2<64, 3, 32, 32>(q, k, v, o, ldo, batch, heads, n, stream, d, d);
-  if (d <= 64) return launch_attn_v2<64, 3>(q, k, v, o, ldo, batch, heads, n, stream, d, d);
-  if (d <= 80) return launch_attn_v2<128, 2, 80, 96>(q, k, v, o, ldo, batch, heads, n, stream, d, d);
-  if (d <= 96) return launch_attn_v2<128, 2, 96, 96>(q, k, v, o, ldo, batch, heads, n, stream, d, d);
-  return launch_attn_v2<128, 2>(q, k, v, o, ldo, batch, heads, n, stream, d, d);
+  if (d <= 32) return launch_attn_v2<64, 3, 32, 32>(q, k, v, o, ldo, batch, heads, n, stream, d, d, lse);
+  if (d <= 64) return launch_attn_v2<64, 3>(q, k, v, o, ldo, batch, heads, n, stream, d, d, lse);
+  if (d <= 80) return launch_attn_v2<128, 2, 80, 96>(q, k, v, o, ldo, batch, heads, n, stream, d, d, lse);
+  if (d <= 96) return launch_attn_v2<128, 2, 96, 96>(q, k, v, o, ldo, batch, heads, n, stream, d, d, lse);
+  return launch_attn_v2<128, 2>(q, k, v, o, ldo, batch, heads, n, stream, d, d, lse);
 }
 
 }  // namespace dfot

@@ -1,0 +1,350 @@
+// Flash-attention backward for the DFoT transformer blocks (gfx950), training path.
+//
+// Same conventions as the forward (attention.hip): q/k/v are [B][heads][N][D] bf16 rows (D = 64 or 128, logical head dim
+// d <= D, pad columns zero), q is pre-multiplied by log2(e)/sqrt(d) so scores live in the exp2 domain, and the forward
+// leaves L2[q] = m + log2(sum) per query.  With P = exp2(S' - L2) (= softmax), delta[q] = sum_c dO[q][c] O[q][c] and
+// dS = P o (dP - delta):
+//      dV = P^T dO            dP = dO V^T
+//      dQ = sq * dS K         dK = sk * dS^T Q'        (sq = 1/sqrt(d) for the unscaled q, sk = ln 2 undoes q's log2 e)
+// Two kernels, each a structural clone of the forward kernel, so every product keeps its reduction index on MFMA registers
+// and its output index on the lanes -- no atomics and no transposes of P / dS through LDS, at the price of computing S
+// and dP in both orientations (8 instead of 5 GEMMs):
+//   * attn_bwd_dq : a wave owns 32 queries (q, dO fragments in registers), streams K/V tiles through LDS:
+//        S^T = K Q^T, dP^T = V dO^T, dS^T = P^T o (dP^T - delta), dQ^T += K^T dS^T   (K^T by ds_read_tr16_b64)
+//   * attn_bwd_dkv: a wave owns 32 keys (k, v fragments in registers), streams Q/dO tiles (+ L2, delta) through LDS:
+//        S = Q K^T, dP = dO V^T, P, dS, dV^T += dO^T P, dK^T += Q^T dS                 (dO^T, Q^T by ds_read_tr16_b64)
+// LDS rows are padded by 16 bytes instead of swizzled (one layout serves row reads and transposed reads).
+// v_mfma_f32_32x32x16_bf16 operand layout as in attention.hip: A lane (l32, h) = A[l32][8h..8h+7], B lane = B[8h..8h+7][l32],
+// C lane = C[8g + 4h + j][l32] in register 4g + j.
+#include "common.h"
+#include "dfot_hip.h"
+#include "kernels.h"
+
+namespace dfot {
+namespace {
+
+template <int D>
+struct BwdCfg {
+  static constexpr int TR = 64;               // rows per streamed tile
+  static constexpr int ROWB = D * 2 + 16;     // padded LDS row (bytes)
+  static constexpr int TILE = TR * ROWB;
+  static constexpr int CH = D / 8;            // 16-byte chunks per row
+  static constexpr int PER_THREAD = TR * CH / 256;
+};
+
+// A fragment of X^T for rows c0..c0+31 (feature index) and the 16 permuted tile rows of step (kt2, s): the order matches
+// the B fragment built from an accumulator (tile row = kt2*32 + 16s + 8(j>>2) + 4h + (j&3))
+template <int D>
+__device__ __forceinline__ bf16x8 tr_frag(const char* tile, int c0, int kt2, int s, int lane) {
+  using C = BwdCfg<D>;
+  const int lh = lane >> 5;
+  const int kb = kt2 * 32 + 16 * s + 4 * lh;
+  const int q4 = (lane & 15) >> 2, p4 = lane & 3;
+  const int col = c0 + 16 * ((lane >> 4) & 1) + 4 * p4;
+  const char* a0 = tile + (kb + q4) * C::ROWB + col * 2;
+  const char* a1 = tile + (kb + 8 + q4) * C::ROWB + col * 2;
+  const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(a0));
+  const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(a1));
+  return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+
+template <int D>
+__device__ __forceinline__ void tile_load(const bf16* __restrict__ src, bf16x8 (&r)[BwdCfg<D>::PER_THREAD], int tid) {
+  using C = BwdCfg<D>;
+#pragma unroll
+  for (int i = 0; i < C::PER_THREAD; ++i) {
+    const int c = tid + i * 256;
+    r[i] = *reinterpret_cast<const bf16x8*>(src + (long)(c / C::CH) * D + (c % C::CH) * 8);
+  }
+}
+template <int D>
+__device__ __forceinline__ void tile_store(char* dst, const bf16x8 (&r)[BwdCfg<D>::PER_THREAD], int tid) {
+  using C = BwdCfg<D>;
+#pragma unroll
+  for (int i = 0; i < C::PER_THREAD; ++i) {
+    const int c = tid + i * 256;
+    *reinterpret_cast<bf16x8*>(dst + (c / C::CH) * C::ROWB + (c % C::CH) * 16) = r[i];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K,
+                                                          const bf16* __restrict__ V, const bf16* __restrict__ dO,
+                                                          const float* __restrict__ L2, const float* __restrict__ delta,
+                                                          bf16* __restrict__ dQ, int N, float sq) {
+  using C = BwdCfg<D>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lq = lane & 31, lh = lane >> 5;
+  const int qtiles = N / 128;
+  const int lin = xcd_remap(blockIdx.x, gridDim.x);
+  const int bh = lin / qtiles;
+  const long base = (long)bh * N * D;
+  const int q0 = (lin % qtiles) * 128 + wave * 32;
+  const bf16* Kb = K + base;
+  const bf16* Vb = V + base;
+
+  bf16x8 qf[D / 16], dof[D / 16];
+#pragma unroll
+  for (int ks = 0; ks < D / 16; ++ks) {
+    qf[ks] = *reinterpret_cast<const bf16x8*>(Q + base + (long)(q0 + lq) * D + ks * 16 + lh * 8);
+    dof[ks] = *reinterpret_cast<const bf16x8*>(dO + base + (long)(q0 + lq) * D + ks * 16 + lh * 8);
+  }
+  const float l2 = L2[(long)bh * N + q0 + lq], dl = delta[(long)bh * N + q0 + lq];
+
+  f32x16 acc[D / 32];
+#pragma unroll
+  for (int i = 0; i < D / 32; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+  bf16x8 rk[C::PER_THREAD], rv[C::PER_THREAD];
+  tile_load<D>(Kb, rk, tid);
+  tile_load<D>(Vb, rv, tid);
+  tile_store<D>(smem, rk, tid);
+  tile_store<D>(smem + C::TILE, rv, tid);
+  __syncthreads();
+  const int nt = N / C::TR;
+  int cur = 0;
+  for (int t = 0; t < nt; ++t) {
+    const char* sk = smem + cur * 2 * C::TILE;
+    const char* sv = sk + C::TILE;
+    if (t + 1 < nt) {
+      tile_load<D>(Kb + (long)(t + 1) * C::TR * D, rk, tid);
+      tile_load<D>(Vb + (long)(t + 1) * C::TR * D, rv, tid);
+    }
+    bf16x8 dsf[2][2];
+#pragma unroll
+    for (int kt2 = 0; kt2 < 2; ++kt2) {
+      f32x16 sacc, pacc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { sacc[r] = -l2; pacc[r] = -dl; }
+      const int row = kt2 * 32 + lq;
+#pragma unroll
+      for (int ks = 0; ks < D / 16; ++ks) {
+        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sk + row * C::ROWB + (ks * 2 + lh) * 16);
+        sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sacc, 0, 0, 0);
+        const bf16x8 vf = *reinterpret_cast<const bf16x8*>(sv + row * C::ROWB + (ks * 2 + lh) * 16);
+        pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[ks], pacc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dsf[kt2][s][j] = f2bf(__builtin_amdgcn_exp2f(sacc[8 * s + j]) * pacc[8 * s + j]);
+    }
+    // dQ^T[c][q] += K^T[c][key] dS^T[key][q]
+#pragma unroll
+    for (int dvt = 0; dvt < D / 32; ++dvt)
+#pragma unroll
+      for (int kt2 = 0; kt2 < 2; ++kt2)
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+          acc[dvt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<D>(sk, dvt * 32, kt2, s, lane), dsf[kt2][s], acc[dvt], 0, 0, 0);
+    if (t + 1 < nt) {
+      char* nk = smem + (cur ^ 1) * 2 * C::TILE;
+      tile_store<D>(nk, rk, tid);
+      tile_store<D>(nk + C::TILE, rv, tid);
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+  bf16* orow = dQ + base + (long)(q0 + lq) * D;
+#pragma unroll
+  for (int dvt = 0; dvt < D / 32; ++dvt)
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      bf16x4 o4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o4[j] = f2bf(acc[dvt][4 * g4 + j] * sq);
+      *reinterpret_cast<bf16x4*>(orow + dvt * 32 + 8 * g4 + 4 * lh) = o4;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K,
+                                                           const bf16* __restrict__ V, const bf16* __restrict__ dO,
+                                                           const float* __restrict__ L2, const float* __restrict__ delta,
+                                                           bf16* __restrict__ dK, bf16* __restrict__ dV, int N, float sk_scale) {
+  using C = BwdCfg<D>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lq = lane & 31, lh = lane >> 5;
+  const int ktiles = N / 128;
+  const int lin = xcd_remap(blockIdx.x, gridDim.x);
+  const int bh = lin / ktiles;
+  const long base = (long)bh * N * D;
+  const int k0 = (lin % ktiles) * 128 + wave * 32;
+  const bf16* Qb = Q + base;
+  const bf16* Ob = dO + base;
+  const float* Lb = L2 + (long)bh * N;
+  const float* Db = delta + (long)bh * N;
+
+  bf16x8 kf[D / 16], vf[D / 16];
+#pragma unroll
+  for (int ks = 0; ks < D / 16; ++ks) {
+    kf[ks] = *reinterpret_cast<const bf16x8*>(K + base + (long)(k0 + lq) * D + ks * 16 + lh * 8);
+    vf[ks] = *reinterpret_cast<const bf16x8*>(V + base + (long)(k0 + lq) * D + ks * 16 + lh * 8);
+  }
+  f32x16 dka[D / 32], dva[D / 32];
+#pragma unroll
+  for (int i = 0; i < D / 32; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dka[i][r] = 0.f; dva[i][r] = 0.f; }
+
+  // LDS: [stage][Q tile | dO tile | L2[64] | delta[64]]
+  constexpr int STAGE = 2 * C::TILE + 2 * C::TR * 4;
+  bf16x8 rq[C::PER_THREAD], ro[C::PER_THREAD];
+  float rs = 0.f;
+  auto load = [&](int t) {
+    tile_load<D>(Qb + (long)t * C::TR * D, rq, tid);
+    tile_load<D>(Ob + (long)t * C::TR * D, ro, tid);
+    if (tid < 2 * C::TR) rs = tid < C::TR ? Lb[t * C::TR + tid] : Db[t * C::TR + tid - C::TR];
+  };
+  auto store = [&](int stage) {
+    char* b = smem + stage * STAGE;
+    tile_store<D>(b, rq, tid);
+    tile_store<D>(b + C::TILE, ro, tid);
+    if (tid < 2 * C::TR) reinterpret_cast<float*>(b + 2 * C::TILE)[tid] = rs;
+  };
+  load(0);
+  store(0);
+  __syncthreads();
+  const int nt = N / C::TR;
+  int cur = 0;
+  for (int t = 0; t < nt; ++t) {
+    const char* sq = smem + cur * STAGE;
+    const char* so = sq + C::TILE;
+    const float* sl = reinterpret_cast<const float*>(sq + 2 * C::TILE);
+    const float* sd = sl + C::TR;
+    bf16x8 pf[2][2], dsf[2][2];
+#pragma unroll
+    for (int kt2 = 0; kt2 < 2; ++kt2) {
+      f32x16 sacc, pacc;
+      // accumulators start at -L2[q] / -delta[q] of their row: q = kt2*32 + 8g + 4h + j
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 l4 = *reinterpret_cast<const f32x4*>(sl + kt2 * 32 + 8 * g + 4 * lh);
+        const f32x4 d4 = *reinterpret_cast<const f32x4*>(sd + kt2 * 32 + 8 * g + 4 * lh);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { sacc[4 * g + j] = -l4[j]; pacc[4 * g + j] = -d4[j]; }
+      }
+      const int row = kt2 * 32 + lq;
+#pragma unroll
+      for (int ks = 0; ks < D / 16; ++ks) {
+        const bf16x8 qa = *reinterpret_cast<const bf16x8*>(sq + row * C::ROWB + (ks * 2 + lh) * 16);
+        sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[ks], sacc, 0, 0, 0);
+        const bf16x8 oa = *reinterpret_cast<const bf16x8*>(so + row * C::ROWB + (ks * 2 + lh) * 16);
+        pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(oa, vf[ks], pacc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float p = __builtin_amdgcn_exp2f(sacc[8 * s + j]);
+          pf[kt2][s][j] = f2bf(p);
+          dsf[kt2][s][j] = f2bf(p * pacc[8 * s + j]);
+        }
+    }
+#pragma unroll
+    for (int dvt = 0; dvt < D / 32; ++dvt)
+#pragma unroll
+      for (int kt2 = 0; kt2 < 2; ++kt2)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          dva[dvt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<D>(so, dvt * 32, kt2, s, lane), pf[kt2][s], dva[dvt], 0, 0, 0);
+          dka[dvt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<D>(sq, dvt * 32, kt2, s, lane), dsf[kt2][s], dka[dvt], 0, 0, 0);
+        }
+    if (t + 1 < nt) {  // staged after the products: the tile registers are not live across them (register budget at D = 128)
+      load(t + 1);
+      store(cur ^ 1);
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+  bf16* krow = dK + base + (long)(k0 + lq) * D;
+  bf16* vrow = dV + base + (long)(k0 + lq) * D;
+#pragma unroll
+  for (int dvt = 0; dvt < D / 32; ++dvt)
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      bf16x4 k4, v4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        k4[j] = f2bf(dka[dvt][4 * g4 + j] * sk_scale);
+        v4[j] = f2bf(dva[dvt][4 * g4 + j]);
+      }
+      *reinterpret_cast<bf16x4*>(krow + dvt * 32 + 8 * g4 + 4 * lh) = k4;
+      *reinterpret_cast<bf16x4*>(vrow + dvt * 32 + 8 * g4 + 4 * lh) = v4;
+    }
+}
+
+// dO [B*N][ldo] compact (head hd at column hd*d) -> dOp [B][heads][N][D] bf16 (pad columns zero) and
+// delta[b][hd][n] = sum_c dO * O ; one wave per (row, head)
+__global__ __launch_bounds__(256) void attn_bwd_prepare_kernel(const bf16* __restrict__ O, const bf16* __restrict__ dO, long ldo,
+                                                               bf16* __restrict__ dOp, float* __restrict__ delta, long rows, int N,
+                                                               int heads, int d, int D) {
+  const long wid = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (wid >= rows * heads) return;
+  const long row = wid / heads;
+  const int hd = (int)(wid % heads);
+  const long b = row / N, n = row % N;
+  const bf16* o = O + row * ldo + (long)hd * d;
+  const bf16* g = dO + row * ldo + (long)hd * d;
+  bf16* out = dOp + ((b * heads + hd) * N + n) * D;
+  float acc = 0.f;
+  for (int c = lane; c < D; c += 64) {
+    const float gv = c < d ? bf2f(g[c]) : 0.f;
+    if (c < d) acc += gv * bf2f(o[c]);
+    out[c] = f2bf(gv);
+  }
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m);
+  if (lane == 0) delta[(b * heads + hd) * N + n] = acc;
+}
+
+}  // namespace
+
+int launch_attention_bwd_prepare(const bf16* o, const bf16* d_o, long ldo, bf16* dop, float* delta, int batch, int heads, int n, int d,
+                                 hipStream_t s) {
+  const int D = attention_dstride(d);
+  const long rows = (long)batch * n;
+  hipLaunchKernelGGL(attn_bwd_prepare_kernel, dim3(cdiv(rows * heads * 64, 256)), dim3(256), 0, s, o, d_o, ldo, dop, delta, rows, n,
+                     heads, d, D);
+  DFOT_CHECK_HIP(hipGetLastError());
+  return DFOT_OK;
+}
+
+template <int D>
+static int launch_bwd_t(const bf16* q, const bf16* k, const bf16* v, const bf16* dop, const float* l2, const float* delta, bf16* dq,
+                        bf16* dk, bf16* dv, int batch, int heads, int n, float sq, float sk, hipStream_t s) {
+  using C = BwdCfg<D>;
+  const int lds1 = 4 * C::TILE, lds2 = 2 * (2 * C::TILE + 2 * C::TR * 4);
+  static bool attr_set = false;
+  if (!attr_set) {
+    DFOT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_kernel<D>), hipFuncAttributeMaxDynamicSharedMemorySize, lds1));
+    DFOT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_kernel<D>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2));
+    attr_set = true;
+  }
+  const int grid = (n / 128) * batch * heads;
+  hipLaunchKernelGGL(attn_bwd_dq_kernel<D>, dim3(grid), dim3(256), lds1, s, q, k, v, dop, l2, delta, dq, n, sq);
+  DFOT_CHECK_HIP(hipGetLastError());
+  hipLaunchKernelGGL(attn_bwd_dkv_kernel<D>, dim3(grid), dim3(256), lds2, s, q, k, v, dop, l2, delta, dk, dv, n, sk);
+  DFOT_CHECK_HIP(hipGetLastError());
+  return DFOT_OK;
+}
+
+// q/k/v/dop/dq/dk/dv: [B][heads][N][dstride(d)] bf16 ; l2/delta: [B][heads][N] fp32
+int launch_attention_bwd(const bf16* q, const bf16* k, const bf16* v, const bf16* dop, const float* l2, const float* delta, bf16* dq,
+                         bf16* dk, bf16* dv, int batch, int heads, int n, int d, hipStream_t s) {
+  DFOT_REQUIRE(q && k && v && dop && l2 && delta && dq && dk && dv, DFOT_ERR_ARG, "attention_bwd: null pointer");
+  DFOT_REQUIRE(d > 0 && d <= 128, DFOT_ERR_SHAPE, "attention_bwd: head dim %d must be <= 128", d);
+  DFOT_REQUIRE(n > 0 && n % 128 == 0, DFOT_ERR_SHAPE, "attention_bwd: N=%d must be a multiple of 128", n);
+  const float sq = 1.0f / sqrtf((float)d), sk = 0.6931471805599453f;
+  return attention_dstride(d) == 64 ? launch_bwd_t<64>(q, k, v, dop, l2, delta, dq, dk, dv, batch, heads, n, sq, sk, s)
+                                    : launch_bwd_t<128>(q, k, v, dop, l2, delta, dq, dk, dv, batch, heads, n, sq, sk, s);
+}
+
+}  // namespace dfot

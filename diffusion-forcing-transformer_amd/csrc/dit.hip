@@ -1042,6 +1042,27 @@ int dfot_dit_read_tap(dfot_dit_t h, const char* name, float* out, size_t capacit
   return DFOT_OK;
 }
 
+// test entry of the training path: forward (o, lse) + backward of one attention call; temporaries are allocated here
+int dfot_op_attention_bwd(const void* q, const void* k, const void* v, const void* d_o, void* o, int ldo, void* dq, void* dk, void* dv,
+                          int batch, int heads, int n, int d, void* stream) {
+  DFOT_REQUIRE(q && k && v && d_o && o && dq && dk && dv, DFOT_ERR_ARG, "attention_bwd: null argument");
+  hipStream_t s = (hipStream_t)stream;
+  const int D = attention_dstride(d);
+  const size_t bhn = (size_t)batch * heads * n;
+  float *lse = nullptr, *delta = nullptr;
+  bf16* dop = nullptr;
+  DFOT_CHECK_HIP(hipMalloc(&lse, bhn * sizeof(float)));
+  DFOT_CHECK_HIP(hipMalloc(&delta, bhn * sizeof(float)));
+  DFOT_CHECK_HIP(hipMalloc(&dop, bhn * D * sizeof(bf16)));
+  int rc = launch_attention_padded((const bf16*)q, (const bf16*)k, (const bf16*)v, (bf16*)o, ldo, batch, heads, n, d, s, lse);
+  if (!rc) rc = launch_attention_bwd_prepare((const bf16*)o, (const bf16*)d_o, ldo, dop, delta, batch, heads, n, d, s);
+  if (!rc) rc = launch_attention_bwd((const bf16*)q, (const bf16*)k, (const bf16*)v, dop, lse, delta, (bf16*)dq, (bf16*)dk, (bf16*)dv,
+                                     batch, heads, n, d, s);
+  hipStreamSynchronize(s);
+  hipFree(lse); hipFree(delta); hipFree(dop);
+  return rc;
+}
+
 int dfot_op_attention_padded(const void* q, const void* k, const void* v, void* o, int ldo, int batch, int heads, int n, int d,
                              void* stream) {
   return launch_attention_padded((const bf16*)q, (const bf16*)k, (const bf16*)v, (bf16*)o, ldo, batch, heads, n, d, (hipStream_t)stream);

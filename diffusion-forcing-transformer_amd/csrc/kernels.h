@@ -68,7 +68,15 @@ int launch_bf16_nhwc_to_nchw(const bf16* src, float* dst, int bt, int p, int c, 
 int launch_attention(const bf16* q, const bf16* k, const bf16* v, bf16* o, long ldo, int batch, int heads, int n, int d,
                      int variant, hipStream_t stream);
 int attention_dstride(int d);
+// lse (optional, training): [B][heads][N] fp32, log2-domain log-sum-exp of every query row
 int launch_attention_padded(const bf16* q, const bf16* k, const bf16* v, bf16* o, long ldo, int batch, int heads, int n, int d,
-                            hipStream_t stream);
+                            hipStream_t stream, float* lse = nullptr);
+// ---- attention backward (attention_bwd.hip) ----
+// o / d_o compact [B*N][ldo] (head hd at column hd*d) -> dop [B][heads][N][dstride] (pads zero) and delta [B][heads][N]
+int launch_attention_bwd_prepare(const bf16* o, const bf16* d_o, long ldo, bf16* dop, float* delta, int batch, int heads, int n, int d,
+                                 hipStream_t s);
+// q (pre-scaled as in the forward) / k / v / dop / dq / dk / dv: [B][heads][N][dstride]; dq is the gradient of the UNSCALED q
+int launch_attention_bwd(const bf16* q, const bf16* k, const bf16* v, const bf16* dop, const float* l2, const float* delta, bf16* dq,
+                         bf16* dk, bf16* dv, int batch, int heads, int n, int d, hipStream_t s);
 
 }  // namespace dfot

@@ -227,6 +227,12 @@ int dfot_op_attention(const void* q, const void* k, const void* v, void* o, int 
  * pad columns are zero; o[B,N,heads*d] is compact (row stride ldo) */
 int dfot_op_attention_padded(const void* q, const void* k, const void* v, void* o, int ldo, int batch, int heads, int n,
                              int d, void* stream);
+/* training path, test entry: o = attention(q, k, v) as above and, for the upstream gradient d_o [B*N][ldo] (same compact layout as
+ * o), dq / dk / dv in the layout of q / k / v; dq is the gradient of the UNSCALED q (q itself is passed pre-multiplied by
+ * log2(e)/sqrt(d), as the forward wants it).  Replaces torch autograd through F.scaled_dot_product_attention
+ * (algorithms/dfot/backbones/dit/dit_blocks.py:21-44,100-123). */
+int dfot_op_attention_bwd(const void* q, const void* k, const void* v, const void* d_o, void* o, int ldo, void* dq, void* dk, void* dv,
+                          int batch, int heads, int n, int d, void* stream);
 /* fp32 <-> bf16 helpers for tests */
 int dfot_op_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);
 int dfot_op_bf16_to_f32(const void* src, float* dst, int64_t n, void* stream);
