@@ -13,3 +13,4 @@ from .sampler import (DFoTVideoPoseSampler, DFoTVideoSampler, DifferenceDFoTVide
 from . import parallel  # noqa: F401,E402
 from .training import ContextTraining, TrainingNoise, training_step_forward  # noqa: F401,E402
 from .checkpoint import load_reference_checkpoint  # noqa: F401,E402
+from .trainer import DiT3DTrainer  # noqa: F401,E402

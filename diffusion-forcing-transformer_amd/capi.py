@@ -74,6 +74,22 @@ SIGNATURES = {
     "dfot_dit_attn_timing": (_I, [_P, C.POINTER(C.c_double), C.POINTER(_L)]),
     "dfot_dit_forward": (_I, [_P, _P, _P, _P, _I, _I, _P]),
     "dfot_dit_read_tap": (_I, [_P, C.c_char_p, _P, C.c_size_t, _P]),
+    "dfot_dit_train_create": (_I, [C.POINTER(DiTConfig), C.POINTER(_P)]),
+    "dfot_dit_train_destroy": (_I, [_P]),
+    "dfot_dit_train_num_params": (_I, [_P]),
+    "dfot_dit_train_param_name": (C.c_char_p, [_P, _I]),
+    "dfot_dit_train_param_shape": (_I, [_P, _I, C.POINTER(_L), C.POINTER(_I)]),
+    "dfot_dit_train_param_offset": (_L, [_P, _I]),
+    "dfot_dit_train_total_numel": (_L, [_P]),
+    "dfot_dit_train_workspace_bytes": (C.c_size_t, [_P]),
+    "dfot_dit_train_attach": (_I, [_P, _P, _P]),
+    "dfot_dit_train_reserve": (_I, [_P, _I]),
+    "dfot_dit_train_sync_weights": (_I, [_P, _P]),
+    "dfot_dit_train_forward": (_I, [_P, _P, _P, _P, _I, _I, _P]),
+    "dfot_dit_train_backward": (_I, [_P, _P, _P]),
+    "dfot_vloss_grad": (_I, [_P] * 7 + [_I, _I, _L, _I, _P]),
+    "dfot_sumsq": (_I, [_P, _L, _P, _P]),
+    "dfot_adamw_step": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _P, _F, _P]),
     "dfot_ray_encode": (_I, [_P, _P, _I, _I, _I, _P]),
     "dfot_ray_encode_normalized": (_I, [_P, _P, _I, _I, _I, _P]),
     "dfot_hg_prepare": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _L, _P]),

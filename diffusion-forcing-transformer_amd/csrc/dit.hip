@@ -1058,8 +1058,8 @@ int dfot_op_attention_bwd(const void* q, const void* k, const void* v, const voi
   if (!rc) rc = launch_attention_bwd_prepare((const bf16*)o, (const bf16*)d_o, ldo, dop, delta, batch, heads, n, d, s);
   if (!rc) rc = launch_attention_bwd((const bf16*)q, (const bf16*)k, (const bf16*)v, dop, lse, delta, (bf16*)dq, (bf16*)dk, (bf16*)dv,
                                      batch, heads, n, d, s);
-  hipStreamSynchronize(s);
-  hipFree(lse); hipFree(delta); hipFree(dop);
+  (void)hipStreamSynchronize(s);
+  (void)hipFree(lse); (void)hipFree(delta); (void)hipFree(dop);
   return rc;
 }
 
@@ -1069,3 +1069,5 @@ int dfot_op_attention_padded(const void* q, const void* k, const void* v, void* 
 }
 
 }  // extern "C"
+
+#include "dit_train.inl"

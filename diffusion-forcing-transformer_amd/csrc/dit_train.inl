@@ -1,0 +1,743 @@
+// Training path of the DiT3D backbone ("full" variant, rope_3d, attention-only blocks: the README @DiT/XL K600 model):
+// forward with saved activations, hand-written backward, gradients in one flat fp32 buffer (reference parameter order).
+// Included at the end of dit.hip (same translation unit: shares its kernels).
+//
+// Replaces, for this model, torch autograd through DiT3D.forward / DiTBlock.forward (dit3d.py:153-192, dit_blocks.py:408-437,
+// 488-542) in DFoTVideo.training_step (dfot_video.py:41-75).  Layout of one block (fork semantics):
+//     m = LN(x) (1 + scale) + shift ;  qkv = m Wqkv^T + b ; o = attention(rope(q), rope(k), v) ; a = o Wp^T + bp ; y = m + gate a
+// Backward of a block for dY (fp32):   da = dY gate, dgate = sum_rows dY a ; dO = da Wp ; dWp = da^T o ; (dq,dk,dv) = attn_bwd ;
+//     dqkv = pack(rope^-1(dq), rope^-1(dk), dv) ; dm = dY + dqkv Wqkv ; dWqkv = dqkv^T m ; dx = LN_bwd(dm (1+scale)),
+//     dshift = sum_rows dm, dscale = sum_rows dm xhat.  The per-frame sums land in dmod[frame][ldt], whose GEMMs with
+//     SiLU(c) give the gradients of every modulation Linear and of the noise-level embedding MLP.
+// Weight gradients are GEMMs over the token axis (K = rows): both operands are transposed copies (HBM-bound passes).
+namespace dfot {
+namespace {
+
+struct TrainBlock {
+  long o_mod_w, o_mod_b, o_qkv_w, o_qkv_b, o_proj_w, o_proj_b;  // offsets into the flat parameter / gradient buffers
+  long mod;                                                     // column of this block's (shift|scale|gate) in the table
+  bf16 *w_qkv, *w_qkvT, *w_proj, *w_projT;                      // bf16 compute copies: [out][in] and [in][out]
+  // saved activations
+  float* x_in;   // [rows][hd] residual stream entering the block
+  bf16 *m, *q, *k, *v, *o, *a;
+  float* lse;
+};
+
+__global__ void tr_features_kernel(const float* __restrict__ freqs, const int* __restrict__ levels, float* __restrict__ feat, int frames,
+                                   int dim, int max_level) {
+  const int half = dim / 2;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)frames * dim) return;
+  const int f = (int)(i / dim), c = (int)(i % dim);
+  int lv = levels[f];
+  lv = lv < 0 ? 0 : (lv > max_level ? max_level : lv);
+  const float a = __fmul_rn((float)lv, freqs[c < half ? c : c - half]);
+  feat[i] = c < half ? cosf(a) : sinf(a);
+}
+__global__ void iota_kernel(int* __restrict__ p, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = i;
+}
+__global__ void silu_fwd_kernel(const float* __restrict__ h, float* __restrict__ out, long n) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = silu_f(h[i]);
+}
+// dh = dy * SiLU'(h)
+__global__ void silu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ h, float* __restrict__ dh, long n) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float x = h[i], sg = 1.0f / (1.0f + __expf(-x));
+  dh[i] = dy[i] * sg * (1.0f + x * (1.0f - sg));
+}
+// dW[o][k] = sum_f dy[f][o] x[f][k] ; db[o] = sum_f dy[f][o]   (frames is small: one thread per (o, k))
+__global__ void small_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ dW, float* __restrict__ db,
+                                   int frames, int odim, int kdim) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)odim * kdim) return;
+  const int o = (int)(i / kdim), k = (int)(i % kdim);
+  float acc = 0.f, bacc = 0.f;
+  for (int f = 0; f < frames; ++f) {
+    const float g = dy[(long)f * odim + o];
+    acc += g * x[(long)f * kdim + k];
+    bacc += g;
+  }
+  dW[i] = acc;
+  if (k == 0) db[o] = bacc;
+}
+// dx[f][k] = sum_o dy[f][o] w[o][k]
+__global__ void small_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ w, float* __restrict__ dx, int frames, int odim,
+                                   int kdim) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)frames * kdim) return;
+  const int f = (int)(i / kdim), k = (int)(i % kdim);
+  float acc = 0.f;
+  for (int o = 0; o < odim; ++o) acc += dy[(long)f * odim + o] * w[(long)o * kdim + k];
+  dx[i] = acc;
+}
+// out[c] = sum over the first `frames` rows of src[f][c]
+__global__ void frames_colsum_kernel(const float* __restrict__ src, float* __restrict__ out, int frames, long ld) {
+  const long c = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= ld) return;
+  float acc = 0.f;
+  for (int f = 0; f < frames; ++f) acc += src[(long)f * ld + c];
+  out[c] = acc;
+}
+
+// y = m + gate[frame] * a   (x holds m, fp32, updated in place)
+__global__ void gate_combine_kernel(float* __restrict__ x, const bf16* __restrict__ a, const float* __restrict__ table, long ldt, long off,
+                                    int hidden, int rows_per_frame, long total4) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total4) return;
+  const long e = i * 4, row = e / hidden;
+  const int c = (int)(e % hidden);
+  const float4v g = *reinterpret_cast<const float4v*>(table + (row / rows_per_frame) * ldt + off + c);
+  const bf16x4 av = *reinterpret_cast<const bf16x4*>(a + e);
+  float4v xv = *reinterpret_cast<float4v*>(x + e);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) xv[j] += g[j] * bf2f(av[j]);
+  *reinterpret_cast<float4v*>(x + e) = xv;
+}
+
+constexpr int TR_CHUNKS = 4;  // row chunks per frame in the per-(frame, channel) reductions
+// da = dY * gate (bf16) ; dgate[frame][c] += sum_rows dY * a ; dbias[c] += sum_rows da
+__global__ __launch_bounds__(256) void gate_bwd_kernel(const float* __restrict__ dy, const bf16* __restrict__ a, const float* __restrict__ table,
+                                                       long ldt, long off, bf16* __restrict__ da, float* __restrict__ dmod,
+                                                       float* __restrict__ dbias, int hidden, int rows_per_frame) {
+  const int c = blockIdx.y * 256 + threadIdx.x;
+  if (c >= hidden) return;
+  const long frame = blockIdx.x;
+  const int per = rows_per_frame / TR_CHUNKS, r0 = blockIdx.z * per;
+  const float g = table[frame * ldt + off + c];
+  float sg = 0.f, sb = 0.f;
+  for (int r = r0; r < r0 + per; ++r) {
+    const long e = (frame * rows_per_frame + r) * hidden + c;
+    const float d = dy[e];
+    const bf16 o = f2bf(d * g);
+    da[e] = o;
+    sg += d * bf2f(a[e]);
+    sb += bf2f(o);
+  }
+  atomicAdd(dmod + frame * ldt + off + c, sg);
+  atomicAdd(dbias + c, sb);
+}
+
+// LayerNorm + modulation backward, row part: dx = rstd (dxh - mean(dxh) - xhat mean(dxh xhat)), dxh = dm (1 + scale); stats = (mean, rstd)
+template <int VEC, int CNT>
+__global__ __launch_bounds__(256) void ln_bwd_rows_kernel(const float* __restrict__ dm, const float* __restrict__ x,
+                                                          const float* __restrict__ table, long ldt, long off, float* __restrict__ dx,
+                                                          float* __restrict__ stats, int rows_per_frame, int rows, float eps) {
+  typedef typename VecT<VEC>::type V;
+  constexpr int hidden = 64 * VEC * CNT;
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* xr = x + (long)row * hidden;
+  const float* dr = dm + (long)row * hidden;
+  const float* sc = table + (long)(row / rows_per_frame) * ldt + off + hidden;
+  V v[CNT], g[CNT];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < CNT; ++i) {
+    v[i] = *reinterpret_cast<const V*>(xr + (i * 64 + lane) * VEC);
+    s += vsum<VEC>(v[i]);
+  }
+  const float mean = wave_sum(s) / (float)hidden;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < CNT; ++i) {
+    v[i] -= mean;
+    q += vdot<VEC>(v[i], v[i]);
+  }
+  const float rstd = rsqrtf(wave_sum(q) / (float)hidden + eps);
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < CNT; ++i) {
+    v[i] = v[i] * rstd;  // xhat
+    const V d = *reinterpret_cast<const V*>(dr + (i * 64 + lane) * VEC);
+    const V sv = *reinterpret_cast<const V*>(sc + (i * 64 + lane) * VEC);
+    g[i] = d * (1.0f + sv);
+    s1 += vsum<VEC>(g[i]);
+    s2 += vdot<VEC>(g[i], v[i]);
+  }
+  s1 = wave_sum(s1) / (float)hidden;
+  s2 = wave_sum(s2) / (float)hidden;
+  float* orow = dx + (long)row * hidden;
+#pragma unroll
+  for (int i = 0; i < CNT; ++i) *reinterpret_cast<V*>(orow + (i * 64 + lane) * VEC) = (g[i] - s1 - v[i] * s2) * rstd;
+  if (lane == 0) {
+    stats[2 * (long)row] = mean;
+    stats[2 * (long)row + 1] = rstd;
+  }
+}
+// frame part: dshift[frame][c] += sum_rows dm ; dscale[frame][c] += sum_rows dm xhat
+__global__ __launch_bounds__(256) void ln_bwd_frames_kernel(const float* __restrict__ dm, const float* __restrict__ x,
+                                                            const float* __restrict__ stats, float* __restrict__ dmod, long ldt, long off,
+                                                            int hidden, int rows_per_frame) {
+  const int c = blockIdx.y * 256 + threadIdx.x;
+  if (c >= hidden) return;
+  const long frame = blockIdx.x;
+  const int per = rows_per_frame / TR_CHUNKS, r0 = blockIdx.z * per;
+  float ssh = 0.f, ssc = 0.f;
+  for (int r = r0; r < r0 + per; ++r) {
+    const long row = frame * rows_per_frame + r;
+    const float d = dm[row * hidden + c];
+    ssh += d;
+    ssc += d * (x[row * hidden + c] - stats[2 * row]) * stats[2 * row + 1];
+  }
+  atomicAdd(dmod + frame * ldt + off + c, ssh);
+  atomicAdd(dmod + frame * ldt + off + hidden + c, ssc);
+}
+
+// (dq, dk, dv) [B][heads][ntok][dstride] -> dqkv [rows][3*heads*d] bf16 in the Linear's column order (q | k | v, head-major);
+// q and k are rotated back (the transpose of the forward's RoPE rotation).  One thread per 8 columns.
+__global__ void qkv_grad_pack_kernel(const bf16* __restrict__ dq, const bf16* __restrict__ dk, const bf16* __restrict__ dv,
+                                     const float* __restrict__ rope_cs, bf16* __restrict__ out, long rows, int ntok, int heads, int d,
+                                     int dstride) {
+  const int per_row = 3 * heads * d / 8;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * per_row) return;
+  const long row = i / per_row;
+  const int col = (int)(i % per_row) * 8;
+  const int cdim = heads * d, which = col / cdim, cc = col - which * cdim, head = cc / d, e0 = cc % d;
+  const long b = row / ntok;
+  const int tok = (int)(row % ntok);
+  const bf16* src = (which == 0 ? dq : (which == 1 ? dk : dv)) + ((b * heads + head) * ntok + tok) * (long)dstride + e0;
+  bf16x8 g = *reinterpret_cast<const bf16x8*>(src);
+  if (which < 2 && rope_cs) {
+    const float* cs = rope_cs + ((long)tok * (d / 2) + e0 / 2) * 2;
+#pragma unroll
+    for (int pr = 0; pr < 4; ++pr) {
+      const float g0 = bf2f(g[2 * pr]), g1 = bf2f(g[2 * pr + 1]);
+      const float co = cs[2 * pr], si = cs[2 * pr + 1];
+      g[2 * pr] = f2bf(g0 * co + g1 * si);
+      g[2 * pr + 1] = f2bf(g1 * co - g0 * si);
+    }
+  }
+  *reinterpret_cast<bf16x8*>(out + row * (long)(3 * cdim) + col) = g;
+}
+
+// out[c] += sum_rows src[row][c]   (bf16 source; 128 rows per workgroup)
+__global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16* __restrict__ src, float* __restrict__ out, long rows, int n, long ld) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= n) return;
+  const long r0 = (long)blockIdx.y * 128;
+  float acc = 0.f;
+  for (long r = r0; r < r0 + 128 && r < rows; ++r) acc += bf2f(src[r * ld + c]);
+  atomicAdd(out + c, acc);
+}
+
+// gradient of the unpatchified output [BT][C][H][W] gathered per token: dyp [rows][64] bf16 (columns >= oc stay zero) and its
+// transpose dyt [.. >= oc rows][rows] (rows >= oc stay zero)
+__global__ void final_gather_kernel(const float* __restrict__ dout, bf16* __restrict__ dyp, bf16* __restrict__ dyt, long rows, int c, int hh,
+                                    int ww, int ps) {
+  const int oc = ps * ps * c, gw = ww / ps, P = (hh / ps) * gw;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * oc) return;
+  const long row = i / oc;
+  const int o = (int)(i % oc);
+  const long bt = row / P;
+  const int g = (int)(row % P), gy = g / gw, gx = g % gw;
+  const int ch = o % c, pq = o / c, py = pq / ps, px = pq % ps;
+  const bf16 v = f2bf(dout[((bt * c + ch) * hh + gy * ps + py) * ww + gx * ps + px]);
+  dyp[row * 64 + o] = v;
+  dyt[(long)o * rows + row] = v;
+}
+
+// PatchEmbed weight gradient: dW[o][kk] += sum_rows dx0[row][o] patch[row][kk], db[o] += sum_rows dx0[row][o]; 64 rows per workgroup
+__global__ __launch_bounds__(256) void pe_wgrad_kernel(const float* __restrict__ dx0, const float* __restrict__ x, float* __restrict__ dW,
+                                                       float* __restrict__ db, int c, int hh, int ww, int ps, int hidden, long rows) {
+  extern __shared__ float patch[];  // [64][kdim]
+  const int gh = hh / ps, gw = ww / ps, kdim = c * ps * ps;
+  const long row0 = (long)blockIdx.y * 64;
+  for (int i = threadIdx.x; i < 64 * kdim; i += 256) {
+    const long row = row0 + i / kdim;
+    const int kk = i % kdim;
+    float v = 0.f;
+    if (row < rows) {
+      const long bt = row / (gh * gw);
+      const int g = (int)(row % (gh * gw)), gy = g / gw, gx = g % gw;
+      const int ci = kk / (ps * ps), py = (kk / ps) % ps, px = kk % ps;
+      v = x[((bt * c + ci) * hh + gy * ps + py) * ww + gx * ps + px];
+    }
+    patch[i] = v;
+  }
+  __syncthreads();
+  const int o = blockIdx.x * 256 + threadIdx.x;
+  if (o >= hidden) return;
+  float bsum = 0.f;
+  for (int k0 = 0; k0 < kdim; k0 += 16) {
+    float acc[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+    for (int r = 0; r < 64 && row0 + r < rows; ++r) {
+      const float g = dx0[(row0 + r) * hidden + o];
+      if (k0 == 0) bsum += g;
+#pragma unroll
+      for (int j = 0; j < 16; ++j)
+        if (k0 + j < kdim) acc[j] += g * patch[r * kdim + k0 + j];
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+      if (k0 + j < kdim) atomicAdd(dW + (long)o * kdim + k0 + j, acc[j]);
+  }
+  atomicAdd(db + o, bsum);
+}
+
+int launch_ln_bwd_rows(const float* dm, const float* x, const float* table, long ldt, long off, float* dx, float* stats, int hidden,
+                       int rows_per_frame, int rows, float eps, hipStream_t s) {
+#define CALL(V, C) \
+  hipLaunchKernelGGL((ln_bwd_rows_kernel<V, C>), dim3(cdiv(rows, 4)), dim3(256), 0, s, dm, x, table, ldt, off, dx, stats, rows_per_frame, rows, eps)
+  DIT_LN_DISPATCH(CALL)
+#undef CALL
+  DFOT_CHECK_HIP(hipGetLastError());
+  return DFOT_OK;
+}
+
+}  // namespace
+}  // namespace dfot
+
+struct dfot_dit_train_s {
+  dfot_dit_config cfg{};
+  int gh = 0, gw = 0, P = 0, d = 0, dstride = 0, kpatch = 0, oc = 0;
+  long ldt = 0, total = 0;
+  std::vector<dfot::DitParam> params;   // name / shape (load unused)
+  std::vector<long> offsets;
+  float *params_f32 = nullptr, *grads = nullptr;  // attached flat buffers (owned by the caller)
+  long o_t_w1 = 0, o_t_b1 = 0, o_t_w2 = 0, o_t_b2 = 0, o_pe_w = 0, o_pe_b = 0, o_fmod_w = 0, o_fmod_b = 0, o_fin_w = 0, o_fin_b = 0;
+  long mod_final = 0;
+  std::vector<dfot::TrainBlock> blocks;
+  std::vector<void*> owned, ws_owned;
+  size_t ws_bytes = 0;
+  // compute copies
+  dfot::bf16 *w_mod = nullptr, *w_modT = nullptr, *wfT = nullptr;
+  float *b_mod = nullptr, *freqs = nullptr, *rope_cs = nullptr;
+  bool synced = false;
+  // workspace
+  int max_batch = 0, fp = 0, batch = 0, tokens = 0;
+  int* idx = nullptr;
+  const float* x_saved = nullptr;  // the forward's input (caller keeps it alive until backward)
+  float *feat = nullptr, *h1 = nullptr, *a1 = nullptr, *cemb = nullptr, *mod_table = nullptr, *X = nullptr, *x_fin = nullptr;
+  dfot::bf16* semb = nullptr;
+  float *dX = nullptr, *dX2 = nullptr, *stats = nullptr, *delta = nullptr, *dmod = nullptr, *dwmod = nullptr, *dsemb = nullptr, *dwf = nullptr;
+  float *dc = nullptr, *da1 = nullptr, *dh1 = nullptr, *dbmod = nullptr;
+  dfot::bf16 *da = nullptr, *dO = nullptr, *dop = nullptr, *dq = nullptr, *dk = nullptr, *dv = nullptr, *dqkv = nullptr, *T1 = nullptr,
+             *T2 = nullptr, *dmod_bf = nullptr, *dmodT = nullptr, *sembT = nullptr, *dyp = nullptr, *dyt = nullptr, *mfin = nullptr;
+};
+
+namespace dfot {
+namespace {
+
+template <typename T>
+int tr_alloc(dfot_dit_train_s* h, T** out, size_t count, bool workspace = false) {
+  void* p = nullptr;
+  DFOT_CHECK_HIP(hipMalloc(&p, count * sizeof(T)));
+  DFOT_CHECK_HIP(hipMemset(p, 0, count * sizeof(T)));
+  (workspace ? h->ws_owned : h->owned).push_back(p);
+  if (workspace) h->ws_bytes += count * sizeof(T);
+  *out = (T*)p;
+  return DFOT_OK;
+}
+
+long tr_add(dfot_dit_train_s* h, const std::string& name, std::vector<int64_t> shape) {
+  DitParam p;
+  p.name = name;
+  p.shape = shape;
+  long n = 1;
+  for (int64_t v : shape) n *= v;
+  const long off = h->total;
+  h->params.push_back(p);
+  h->offsets.push_back(off);
+  h->total += (n + 3) / 4 * 4;  // every tensor starts 16-byte aligned
+  return off;
+}
+
+int tr_transpose(const bf16* src, bf16* dst, int R, int C, hipStream_t s) {  // [R][C] -> [C][R]
+  DFOT_REQUIRE(R % 64 == 0 && C % 64 == 0, DFOT_ERR_SHAPE, "transpose: %d x %d must be multiples of 64", R, C);
+  hipLaunchKernelGGL(transpose_bf16_kernel, dim3(C / 64, R / 64, 1), dim3(256), 0, s, src, dst, R, C);
+  DFOT_CHECK_HIP(hipGetLastError());
+  return DFOT_OK;
+}
+
+// out[M][N] fp32 = A[M][K] W[N][K]^T (+ resid)
+int tr_gemm_f32(const bf16* A, long lda, const bf16* W, int M, int N, int K, float* out, long ldo, const float* resid, hipStream_t s) {
+  GemmArgs g;
+  g.A = A; g.lda = lda; g.W = W; g.M = M; g.N = N; g.K = K; g.out_f32 = out; g.ldo = ldo; g.resid = resid;
+  return launch_gemm(A_DENSE, E_F32, GEMM_AUTO, g, s);
+}
+int tr_gemm_bf16(const bf16* A, long lda, const bf16* W, int M, int N, int K, const float* bias, bf16* out, long ldo, hipStream_t s) {
+  GemmArgs g;
+  g.A = A; g.lda = lda; g.W = W; g.M = M; g.N = N; g.K = K; g.bias = bias; g.out_bf16 = out; g.ldo = ldo;
+  return launch_gemm(A_DENSE, E_BF16, GEMM_AUTO, g, s);
+}
+
+}  // namespace
+}  // namespace dfot
+
+extern "C" {
+using namespace dfot;
+
+int dfot_dit_train_destroy(dfot_dit_train_t h) {
+  if (!h) return DFOT_OK;
+  for (void* p : h->owned) (void)hipFree(p);
+  for (void* p : h->ws_owned) (void)hipFree(p);
+  delete h;
+  return DFOT_OK;
+}
+
+int dfot_dit_train_create(const dfot_dit_config* cfg, dfot_dit_train_t* out) {
+  DFOT_REQUIRE(cfg && out, DFOT_ERR_ARG, "train_create: null argument");
+  const dfot_dit_config& c = *cfg;
+  DFOT_REQUIRE(c.variant == 0, DFOT_ERR_ARG, "train_create: only the 'full' DiT3D variant has a training path");
+  DFOT_REQUIRE(c.mlp_hidden == 0, DFOT_ERR_ARG, "train_create: blocks with an MLP branch (spatial_mlp_ratio) have no training path yet");
+  DFOT_REQUIRE(c.hidden_size % 128 == 0 && c.num_heads > 0 && c.hidden_size % c.num_heads == 0, DFOT_ERR_ARG,
+               "train_create: hidden_size %d must be a multiple of 128 and of num_heads", c.hidden_size);
+  DFOT_REQUIRE((c.hidden_size / c.num_heads) % 8 == 0 && c.hidden_size / c.num_heads <= 128, DFOT_ERR_ARG, "train_create: head dim must be a multiple of 8, <= 128");
+  DFOT_REQUIRE(c.patch_size > 0 && c.height % c.patch_size == 0 && c.width % c.patch_size == 0, DFOT_ERR_ARG, "train_create: patch size");
+  DFOT_REQUIRE(c.in_channels * c.patch_size * c.patch_size <= 64, DFOT_ERR_ARG, "train_create: patch_size^2 * channels must be <= 64");
+  DFOT_REQUIRE(c.noise_dim > 0 && c.noise_dim % 2 == 0 && c.depth > 0 && c.timesteps > 0 && c.max_tokens > 0, DFOT_ERR_ARG, "train_create: bad config");
+  auto* h = new dfot_dit_train_s();
+  h->cfg = c;
+  const int hd = c.hidden_size;
+  h->gh = c.height / c.patch_size;
+  h->gw = c.width / c.patch_size;
+  h->P = h->gh * h->gw;
+  h->d = hd / c.num_heads;
+  h->dstride = attention_dstride(h->d);
+  h->kpatch = c.in_channels * c.patch_size * c.patch_size;
+  h->oc = h->kpatch;
+  h->ldt = (long)c.depth * 3 * hd + 2 * hd;
+  if (h->P % (4 * TR_CHUNKS) != 0) {
+    set_error("train_create: %d patches per frame must be a multiple of %d", h->P, 4 * TR_CHUNKS);
+    delete h;
+    return DFOT_ERR_ARG;
+  }
+  // registration order == the reference module's state_dict order (as dit_build)
+  const std::string ne = "noise_level_pos_embedding.embedding";
+  h->o_t_w1 = tr_add(h, ne + ".linear_1.weight", {hd, c.noise_dim});
+  h->o_t_b1 = tr_add(h, ne + ".linear_1.bias", {hd});
+  h->o_t_w2 = tr_add(h, ne + ".linear_2.weight", {hd, hd});
+  h->o_t_b2 = tr_add(h, ne + ".linear_2.bias", {hd});
+  h->o_pe_w = tr_add(h, "patch_embedder.proj.weight", {hd, c.in_channels, c.patch_size, c.patch_size});
+  h->o_pe_b = tr_add(h, "patch_embedder.proj.bias", {hd});
+  h->blocks.resize(c.depth);
+  long off = 0;
+  for (int i = 0; i < c.depth; ++i) {
+    TrainBlock& b = h->blocks[i];
+    const std::string pre = "dit_base.blocks." + std::to_string(i);
+    b.mod = off;
+    off += 3 * hd;
+    b.o_mod_w = tr_add(h, pre + ".norm1.modulation.1.weight", {3 * hd, hd});
+    b.o_mod_b = tr_add(h, pre + ".norm1.modulation.1.bias", {3 * hd});
+    b.o_qkv_w = tr_add(h, pre + ".attn.qkv.weight", {3 * hd, hd});
+    b.o_qkv_b = tr_add(h, pre + ".attn.qkv.bias", {3 * hd});
+    b.o_proj_w = tr_add(h, pre + ".attn.proj.weight", {hd, hd});
+    b.o_proj_b = tr_add(h, pre + ".attn.proj.bias", {hd});
+  }
+  h->mod_final = off;
+  h->o_fmod_w = tr_add(h, "dit_base.final_layer.norm_final.modulation.1.weight", {2 * hd, hd});
+  h->o_fmod_b = tr_add(h, "dit_base.final_layer.norm_final.modulation.1.bias", {2 * hd});
+  h->o_fin_w = tr_add(h, "dit_base.final_layer.linear.weight", {h->oc, hd});
+  h->o_fin_b = tr_add(h, "dit_base.final_layer.linear.bias", {h->oc});
+  int rc = 0;
+  auto fail = [&](int code) { dfot_dit_train_destroy(h); return code; };
+  if ((rc = tr_alloc(h, &h->w_mod, (size_t)h->ldt * hd)) || (rc = tr_alloc(h, &h->w_modT, (size_t)h->ldt * hd)) ||
+      (rc = tr_alloc(h, &h->b_mod, (size_t)h->ldt)) || (rc = tr_alloc(h, &h->wfT, (size_t)hd * 64)) ||
+      (rc = tr_alloc(h, &h->freqs, (size_t)c.noise_dim / 2)))
+    return fail(rc);
+  for (TrainBlock& b : h->blocks)
+    if ((rc = tr_alloc(h, &b.w_qkv, (size_t)3 * hd * hd)) || (rc = tr_alloc(h, &b.w_qkvT, (size_t)3 * hd * hd)) ||
+        (rc = tr_alloc(h, &b.w_proj, (size_t)hd * hd)) || (rc = tr_alloc(h, &b.w_projT, (size_t)hd * hd)))
+      return fail(rc);
+  {
+    const int half = c.noise_dim / 2;
+    std::vector<float> f(half);
+    for (int i = 0; i < half; ++i) f[i] = (float)std::exp(-std::log(10000.0) * (double)i / (double)half);
+    if (hipMemcpy(h->freqs, f.data(), f.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) return fail(DFOT_ERR_HIP);
+  }
+  {  // RoPE-3D table, as dit_build
+    const int half = h->d / 2, q = half / 3, rem = half % 3;
+    int parts[3] = {q, q, q};
+    if (rem == 1) parts[0] = q + 1;
+    if (rem == 2) parts[1] = parts[2] = q + 1;
+    const int n = c.max_tokens * h->P;
+    std::vector<float> cs((size_t)n * half * 2);
+    for (int tok = 0; tok < n; ++tok) {
+      const int pos[3] = {tok / h->P, (tok / h->gw) % h->gh, tok % h->gw};
+      int pair = 0;
+      for (int ax = 0; ax < 3; ++ax) {
+        const int dim = 2 * parts[ax];
+        for (int j = 0; j < parts[ax]; ++j, ++pair) {
+          const float inv = 1.0f / powf(c.rope_theta, (float)(2 * j) / (float)dim);
+          const float ang = (float)pos[ax] * inv;
+          cs[((size_t)tok * half + pair) * 2 + 0] = cosf(ang);
+          cs[((size_t)tok * half + pair) * 2 + 1] = sinf(ang);
+        }
+      }
+    }
+    if ((rc = tr_alloc(h, &h->rope_cs, cs.size()))) return fail(rc);
+    if (hipMemcpy(h->rope_cs, cs.data(), cs.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) return fail(DFOT_ERR_HIP);
+  }
+  *out = h;
+  return DFOT_OK;
+}
+
+int dfot_dit_train_num_params(dfot_dit_train_t h) { return h ? (int)h->params.size() : 0; }
+const char* dfot_dit_train_param_name(dfot_dit_train_t h, int i) {
+  return (h && i >= 0 && i < (int)h->params.size()) ? h->params[i].name.c_str() : nullptr;
+}
+int dfot_dit_train_param_shape(dfot_dit_train_t h, int i, int64_t shape[4], int* ndim) {
+  DFOT_REQUIRE(h && i >= 0 && i < (int)h->params.size() && shape && ndim, DFOT_ERR_ARG, "train_param_shape: bad argument");
+  *ndim = (int)h->params[i].shape.size();
+  for (int j = 0; j < *ndim; ++j) shape[j] = h->params[i].shape[j];
+  return DFOT_OK;
+}
+int64_t dfot_dit_train_param_offset(dfot_dit_train_t h, int i) { return (h && i >= 0 && i < (int)h->offsets.size()) ? h->offsets[i] : -1; }
+int64_t dfot_dit_train_total_numel(dfot_dit_train_t h) { return h ? h->total : 0; }
+size_t dfot_dit_train_workspace_bytes(dfot_dit_train_t h) { return h ? h->ws_bytes : 0; }
+
+int dfot_dit_train_attach(dfot_dit_train_t h, float* params, float* grads) {
+  DFOT_REQUIRE(h && params && grads, DFOT_ERR_ARG, "train_attach: null argument");
+  DFOT_REQUIRE(((uintptr_t)params & 15) == 0 && ((uintptr_t)grads & 15) == 0, DFOT_ERR_ARG, "train_attach: buffers must be 16-byte aligned");
+  h->params_f32 = params;
+  h->grads = grads;
+  h->synced = false;
+  return DFOT_OK;
+}
+
+// fp32 master weights -> bf16 compute copies ([out][in] and transposed), stacked modulation Linear; call after every optimizer step
+int dfot_dit_train_sync_weights(dfot_dit_train_t h, void* stream) {
+  DFOT_REQUIRE(h && h->params_f32, DFOT_ERR_STATE, "train_sync_weights: no parameter buffer attached");
+  hipStream_t s = (hipStream_t)stream;
+  const int hd = h->cfg.hidden_size;
+  const float* p = h->params_f32;
+  int rc = 0;
+  auto mod = [&](long o_w, long o_b, long col, int n) -> int {
+    int r = launch_f32_to_bf16(p + o_w, h->w_mod + col * hd, (long)n * hd, s);
+    if (r) return r;
+    DFOT_CHECK_HIP(hipMemcpyAsync(h->b_mod + col, p + o_b, (size_t)n * sizeof(float), hipMemcpyDeviceToDevice, s));
+    return DFOT_OK;
+  };
+  for (TrainBlock& b : h->blocks) {
+    if ((rc = mod(b.o_mod_w, b.o_mod_b, b.mod, 3 * hd))) return rc;
+    if ((rc = launch_f32_to_bf16(p + b.o_qkv_w, b.w_qkv, (long)3 * hd * hd, s)) || (rc = tr_transpose(b.w_qkv, b.w_qkvT, 3 * hd, hd, s)) ||
+        (rc = launch_f32_to_bf16(p + b.o_proj_w, b.w_proj, (long)hd * hd, s)) || (rc = tr_transpose(b.w_proj, b.w_projT, hd, hd, s)))
+      return rc;
+  }
+  if ((rc = mod(h->o_fmod_w, h->o_fmod_b, h->mod_final, 2 * hd))) return rc;
+  if ((rc = tr_transpose(h->w_mod, h->w_modT, (int)h->ldt, hd, s))) return rc;
+  // wfT[c][o] = fin_w[o][c] (bf16, 64 columns, zero padded): pack_transpose writes dst[c][r] = src[r][c] with dst row length `rows`
+  DFOT_CHECK_HIP(hipMemsetAsync(h->wfT, 0, (size_t)hd * 64 * sizeof(bf16), s));
+  {
+    // rows = oc source rows, cols = hd; destination rows are 64 wide -> write through a strided variant: one small kernel launch per o
+    for (int o = 0; o < h->oc; ++o) {
+      // dst[c*64 + o] = src[o*hd + c]
+      if ((rc = launch_pack_rows(p + h->o_fin_w + (long)o * hd, h->wfT, nullptr, hd, 1, 1, 64, o, s))) return rc;
+    }
+  }
+  h->synced = true;
+  return DFOT_OK;
+}
+
+int dfot_dit_train_reserve(dfot_dit_train_t h, int max_batch) {
+  DFOT_REQUIRE(h && max_batch > 0, DFOT_ERR_ARG, "train_reserve: bad argument");
+  if (max_batch <= h->max_batch) return DFOT_OK;
+  DFOT_CHECK_HIP(hipDeviceSynchronize());
+  for (void* p : h->ws_owned) (void)hipFree(p);
+  h->ws_owned.clear();
+  h->ws_bytes = 0;
+  h->max_batch = 0;
+  const dfot_dit_config& c = h->cfg;
+  const int hd = c.hidden_size, nd = c.noise_dim;
+  const size_t rows = (size_t)max_batch * c.max_tokens * h->P;
+  const int frames = max_batch * c.max_tokens;
+  const int fp = (frames + 255) / 256 * 256;
+  const size_t bhn = (size_t)max_batch * c.num_heads * c.max_tokens * h->P;
+  const size_t qsz = bhn * h->dstride;
+  int rc = 0;
+#define WS(ptr, count) if ((rc = tr_alloc(h, &(ptr), (count), true))) return rc
+  WS(h->idx, frames);
+  WS(h->feat, (size_t)frames * nd); WS(h->h1, (size_t)frames * hd); WS(h->a1, (size_t)frames * hd); WS(h->cemb, (size_t)frames * hd);
+  WS(h->semb, (size_t)fp * hd); WS(h->sembT, (size_t)fp * hd); WS(h->mod_table, (size_t)fp * h->ldt);
+  WS(h->X, rows * hd); WS(h->x_fin, rows * hd);
+  for (TrainBlock& b : h->blocks) {
+    WS(b.x_in, rows * hd); WS(b.m, rows * hd); WS(b.q, qsz); WS(b.k, qsz); WS(b.v, qsz); WS(b.o, rows * hd); WS(b.a, rows * hd);
+    WS(b.lse, bhn);
+  }
+  WS(h->dX, rows * hd); WS(h->dX2, rows * hd); WS(h->stats, rows * 2); WS(h->delta, bhn);
+  WS(h->dmod, (size_t)fp * h->ldt); WS(h->dmod_bf, (size_t)fp * h->ldt); WS(h->dmodT, (size_t)fp * h->ldt);
+  WS(h->dwmod, (size_t)h->ldt * hd); WS(h->dsemb, (size_t)fp * hd); WS(h->dwf, (size_t)256 * hd);
+  WS(h->dbmod, (size_t)h->ldt);
+  WS(h->dc, (size_t)frames * hd); WS(h->da1, (size_t)frames * hd); WS(h->dh1, (size_t)frames * hd);
+  WS(h->da, rows * hd); WS(h->dO, rows * hd); WS(h->dop, qsz); WS(h->dq, qsz); WS(h->dk, qsz); WS(h->dv, qsz);
+  WS(h->dqkv, rows * 3 * hd); WS(h->T1, rows * 3 * hd); WS(h->T2, rows * hd); WS(h->dyp, rows * 64); WS(h->dyt, (size_t)256 * rows);
+  WS(h->mfin, rows * hd);
+#undef WS
+  h->max_batch = max_batch;
+  h->fp = fp;
+  return DFOT_OK;
+}
+
+// out[B,T,C,H,W] = model(x, levels) with every activation the backward needs kept in the workspace; x must stay alive until backward
+int dfot_dit_train_forward(dfot_dit_train_t h, const float* x, const int32_t* noise_levels, float* out, int batch, int tokens, void* stream) {
+  DFOT_REQUIRE(h && x && noise_levels && out, DFOT_ERR_ARG, "train_forward: null argument");
+  DFOT_REQUIRE(h->synced, DFOT_ERR_STATE, "train_forward: call dfot_dit_train_sync_weights after attaching / updating the parameters");
+  DFOT_REQUIRE(batch > 0 && batch <= h->max_batch, DFOT_ERR_STATE, "train_forward: batch %d exceeds the reserved %d", batch, h->max_batch);
+  const dfot_dit_config& c = h->cfg;
+  DFOT_REQUIRE(tokens > 0 && tokens <= c.max_tokens, DFOT_ERR_SHAPE, "train_forward: %d tokens, max_tokens is %d", tokens, c.max_tokens);
+  const int n = tokens * h->P, hd = c.hidden_size, P = h->P, frames = batch * tokens, nd = c.noise_dim;
+  DFOT_REQUIRE(n % 128 == 0, DFOT_ERR_SHAPE, "train_forward: sequence length %d (tokens x patches) must be a multiple of 128", n);
+  hipStream_t s = (hipStream_t)stream;
+  const long rows = (long)batch * n;
+  const float* p = h->params_f32;
+  int rc = 0;
+  h->batch = batch; h->tokens = tokens; h->x_saved = x;
+  // ---- conditioning: c = Linear2(SiLU(Linear1(features(level)))) per frame; table = Linear_mod(SiLU(c)) for every modulation ----
+  hipLaunchKernelGGL(iota_kernel, dim3(cdiv(frames, 256)), dim3(256), 0, s, h->idx, frames);
+  hipLaunchKernelGGL(tr_features_kernel, dim3(cdiv((long)frames * nd, 256)), dim3(256), 0, s, h->freqs, noise_levels, h->feat, frames, nd, c.timesteps - 1);
+  hipLaunchKernelGGL(rows_linear_kernel<0>, dim3(cdiv(hd, 4), frames), dim3(256), 0, s, h->feat, p + h->o_t_w1, p + h->o_t_b1, h->h1, (bf16*)nullptr, nd, hd);
+  hipLaunchKernelGGL(silu_fwd_kernel, dim3(cdiv((long)frames * hd, 256)), dim3(256), 0, s, h->h1, h->a1, (long)frames * hd);
+  DFOT_CHECK_HIP(hipMemsetAsync(h->semb, 0, (size_t)h->fp * hd * sizeof(bf16), s));
+  hipLaunchKernelGGL(rows_linear_kernel<0>, dim3(cdiv(hd, 4), frames), dim3(256), 0, s, h->a1, p + h->o_t_w2, p + h->o_t_b2, h->cemb, h->semb, hd, hd);
+  DFOT_CHECK_HIP(hipGetLastError());
+  {
+    GemmArgs g;
+    g.A = h->semb; g.lda = hd; g.W = h->w_mod; g.M = h->fp; g.N = (int)h->ldt; g.K = hd; g.bias = h->b_mod; g.out_f32 = h->mod_table; g.ldo = h->ldt;
+    if ((rc = launch_gemm(A_DENSE, E_F32, GEMM_AUTO, g, s))) return rc;
+  }
+  hipLaunchKernelGGL(patch_embed_kernel, dim3(cdiv(rows, PE_TOK)), dim3(256), PE_TOK * h->kpatch * sizeof(float), s, x, p + h->o_pe_w,
+                     p + h->o_pe_b, (const float*)nullptr, h->X, c.in_channels, c.height, c.width, c.patch_size, hd, rows);
+  DFOT_CHECK_HIP(hipGetLastError());
+  const float qscale = 1.4426950408889634f / sqrtf((float)h->d);
+  for (TrainBlock& b : h->blocks) {
+    DFOT_CHECK_HIP(hipMemcpyAsync(b.x_in, h->X, (size_t)rows * hd * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if ((rc = launch_ln_mod(h->X, b.m, h->mod_table, h->idx, h->ldt, b.mod, hd, P, (int)rows, c.eps, frames - 1, s))) return rc;
+    {
+      GemmArgs g;
+      g.A = b.m; g.lda = hd; g.W = b.w_qkv; g.M = (int)rows; g.N = 3 * hd; g.K = hd; g.bias = p + b.o_qkv_b;
+      g.q = b.q; g.k = b.k; g.v = b.v; g.rope_cs = h->rope_cs; g.heads = c.num_heads; g.d = h->d; g.dstride = h->dstride; g.ntok = n; g.qscale = qscale;
+      if ((rc = launch_gemm(A_DENSE, E_QKV_DIT, GEMM_AUTO, g, s))) return rc;
+    }
+    if ((rc = launch_attention_padded(b.q, b.k, b.v, b.o, hd, batch, c.num_heads, n, h->d, s, b.lse))) return rc;
+    if ((rc = tr_gemm_bf16(b.o, hd, b.w_proj, (int)rows, hd, hd, p + b.o_proj_b, b.a, hd, s))) return rc;
+    hipLaunchKernelGGL(gate_combine_kernel, dim3(cdiv(rows * hd / 4, 256)), dim3(256), 0, s, h->X, b.a, h->mod_table, h->ldt, b.mod + 2 * hd, hd, P,
+                       rows * hd / 4);
+    DFOT_CHECK_HIP(hipGetLastError());
+  }
+  DFOT_CHECK_HIP(hipMemcpyAsync(h->x_fin, h->X, (size_t)rows * hd * sizeof(float), hipMemcpyDeviceToDevice, s));
+  return launch_final_layer(h->X, h->mod_table, h->idx, h->ldt, h->mod_final, p + h->o_fin_w, p + h->o_fin_b, out, hd, P, (int)rows, c.eps,
+                            frames - 1, c.in_channels, c.height, c.width, c.patch_size, s);
+}
+
+// gradients of every parameter for the upstream gradient d_out [B,T,C,H,W] of the last forward's output; OVERWRITES the grads buffer
+int dfot_dit_train_backward(dfot_dit_train_t h, const float* d_out, void* stream) {
+  DFOT_REQUIRE(h && d_out, DFOT_ERR_ARG, "train_backward: null argument");
+  DFOT_REQUIRE(h->batch > 0 && h->x_saved, DFOT_ERR_STATE, "train_backward: no forward to differentiate");
+  const dfot_dit_config& c = h->cfg;
+  const int batch = h->batch, tokens = h->tokens, n = tokens * h->P, hd = c.hidden_size, P = h->P, frames = batch * tokens, nd = c.noise_dim;
+  const int fp = h->fp;
+  hipStream_t s = (hipStream_t)stream;
+  const long rows = (long)batch * n;
+  const float* p = h->params_f32;
+  float* G = h->grads;
+  int rc = 0;
+  DFOT_CHECK_HIP(hipMemsetAsync(G, 0, (size_t)h->total * sizeof(float), s));
+  DFOT_CHECK_HIP(hipMemsetAsync(h->dmod, 0, (size_t)fp * h->ldt * sizeof(float), s));
+  const dim3 fgrid(frames, cdiv(hd, 256), TR_CHUNKS);
+
+  // ---- final layer: out = Linear(mfin), mfin = LN(x_fin)(1 + scale) + shift ----
+  DFOT_CHECK_HIP(hipMemsetAsync(h->dyp, 0, (size_t)rows * 64 * sizeof(bf16), s));
+  DFOT_CHECK_HIP(hipMemsetAsync(h->dyt, 0, (size_t)256 * rows * sizeof(bf16), s));
+  hipLaunchKernelGGL(final_gather_kernel, dim3(cdiv(rows * h->oc, 256)), dim3(256), 0, s, d_out, h->dyp, h->dyt, rows, c.in_channels, c.height,
+                     c.width, c.patch_size);
+  hipLaunchKernelGGL(colsum_bf16_kernel, dim3(1, cdiv(rows, 128)), dim3(256), 0, s, h->dyp, G + h->o_fin_b, rows, h->oc, 64L);
+  DFOT_CHECK_HIP(hipGetLastError());
+  float *dY = h->dX, *dN = h->dX2;  // gradient of the current block's output / scratch for the next one
+  DFOT_CHECK_HIP(hipMemcpyAsync(dN, h->x_fin, (size_t)rows * hd * sizeof(float), hipMemcpyDeviceToDevice, s));
+  if ((rc = launch_ln_mod(dN, h->mfin, h->mod_table, h->idx, h->ldt, h->mod_final, hd, P, (int)rows, c.eps, frames - 1, s))) return rc;
+  if ((rc = tr_transpose(h->mfin, h->T2, (int)rows, hd, s))) return rc;                                   // mfin^T [hd][rows]
+  if ((rc = tr_gemm_f32(h->dyt, rows, h->T2, 256, hd, (int)rows, h->dwf, hd, nullptr, s))) return rc;       // dWf in the first oc rows
+  DFOT_CHECK_HIP(hipMemcpyAsync(G + h->o_fin_w, h->dwf, (size_t)h->oc * hd * sizeof(float), hipMemcpyDeviceToDevice, s));
+  if ((rc = tr_gemm_f32(h->dyp, 64, h->wfT, (int)rows, hd, 64, dY, hd, nullptr, s))) return rc;             // d mfin
+  auto ln_bwd = [&](const float* x_in, long off) -> int {  // dY holds dm; leaves dx in dY
+    int r = launch_ln_bwd_rows(dY, x_in, h->mod_table, h->ldt, off, dN, h->stats, hd, P, (int)rows, c.eps, s);
+    if (r) return r;
+    hipLaunchKernelGGL(ln_bwd_frames_kernel, fgrid, dim3(256), 0, s, dY, x_in, h->stats, h->dmod, h->ldt, off, hd, P);
+    DFOT_CHECK_HIP(hipGetLastError());
+    std::swap(dY, dN);
+    return DFOT_OK;
+  };
+  if ((rc = ln_bwd(h->x_fin, h->mod_final))) return rc;
+
+  // ---- blocks, last to first ----
+  for (int bi = (int)h->blocks.size() - 1; bi >= 0; --bi) {
+    TrainBlock& b = h->blocks[bi];
+    hipLaunchKernelGGL(gate_bwd_kernel, fgrid, dim3(256), 0, s, dY, b.a, h->mod_table, h->ldt, b.mod + 2 * hd, h->da, h->dmod, G + b.o_proj_b, hd, P);
+    DFOT_CHECK_HIP(hipGetLastError());
+    if ((rc = tr_gemm_bf16(h->da, hd, b.w_projT, (int)rows, hd, hd, nullptr, h->dO, hd, s))) return rc;      // dO = da Wp
+    if ((rc = tr_transpose(h->da, h->T1, (int)rows, hd, s)) || (rc = tr_transpose(b.o, h->T2, (int)rows, hd, s))) return rc;
+    if ((rc = tr_gemm_f32(h->T1, rows, h->T2, hd, hd, (int)rows, G + b.o_proj_w, hd, nullptr, s))) return rc;  // dWp = da^T o
+    if ((rc = launch_attention_bwd_prepare(b.o, h->dO, hd, h->dop, h->delta, batch, c.num_heads, n, h->d, s))) return rc;
+    if ((rc = launch_attention_bwd(b.q, b.k, b.v, h->dop, b.lse, h->delta, h->dq, h->dk, h->dv, batch, c.num_heads, n, h->d, s))) return rc;
+    hipLaunchKernelGGL(qkv_grad_pack_kernel, dim3(cdiv(rows * (3 * hd / 8), 256)), dim3(256), 0, s, h->dq, h->dk, h->dv, h->rope_cs, h->dqkv, rows, n,
+                       c.num_heads, h->d, h->dstride);
+    hipLaunchKernelGGL(colsum_bf16_kernel, dim3(cdiv(3 * hd, 256), cdiv(rows, 128)), dim3(256), 0, s, h->dqkv, G + b.o_qkv_b, rows, 3 * hd, (long)3 * hd);
+    DFOT_CHECK_HIP(hipGetLastError());
+    if ((rc = tr_gemm_f32(h->dqkv, 3 * hd, b.w_qkvT, (int)rows, hd, 3 * hd, dY, hd, dY, s))) return rc;       // dm = dY + dqkv Wqkv (in place)
+    if ((rc = tr_transpose(h->dqkv, h->T1, (int)rows, 3 * hd, s)) || (rc = tr_transpose(b.m, h->T2, (int)rows, hd, s))) return rc;
+    if ((rc = tr_gemm_f32(h->T1, rows, h->T2, 3 * hd, hd, (int)rows, G + b.o_qkv_w, hd, nullptr, s))) return rc;  // dWqkv = dqkv^T m
+    if ((rc = ln_bwd(b.x_in, b.mod))) return rc;
+  }
+
+  // ---- patch embedding ----
+  hipLaunchKernelGGL(pe_wgrad_kernel, dim3(cdiv(hd, 256), cdiv(rows, 64)), dim3(256), 64 * h->kpatch * sizeof(float), s, dY, h->x_saved,
+                     G + h->o_pe_w, G + h->o_pe_b, c.in_channels, c.height, c.width, c.patch_size, hd, rows);
+  DFOT_CHECK_HIP(hipGetLastError());
+
+  // ---- modulation Linears: table = SiLU(c) W_mod^T + b_mod over the frames ----
+  hipLaunchKernelGGL(frames_colsum_kernel, dim3(cdiv(h->ldt, 256)), dim3(256), 0, s, h->dmod, h->dbmod, frames, h->ldt);
+  DFOT_CHECK_HIP(hipGetLastError());
+  if ((rc = launch_f32_to_bf16(h->dmod, h->dmod_bf, (long)fp * h->ldt, s))) return rc;
+  hipLaunchKernelGGL(pack_transpose_kernel, dim3(cdiv((long)fp * h->ldt, 256)), dim3(256), 0, s, h->dmod, h->dmodT, fp, (int)h->ldt);
+  DFOT_CHECK_HIP(hipGetLastError());
+  if ((rc = tr_transpose(h->semb, h->sembT, fp, hd, s))) return rc;
+  if ((rc = tr_gemm_f32(h->dmodT, fp, h->sembT, (int)h->ldt, hd, fp, h->dwmod, hd, nullptr, s))) return rc;   // dW_mod = dmod^T SiLU(c)
+  auto scatter = [&](long col, int nrow, long o_w, long o_b) -> int {
+    DFOT_CHECK_HIP(hipMemcpyAsync(G + o_w, h->dwmod + col * hd, (size_t)nrow * hd * sizeof(float), hipMemcpyDeviceToDevice, s));
+    DFOT_CHECK_HIP(hipMemcpyAsync(G + o_b, h->dbmod + col, (size_t)nrow * sizeof(float), hipMemcpyDeviceToDevice, s));
+    return DFOT_OK;
+  };
+  for (TrainBlock& b : h->blocks)
+    if ((rc = scatter(b.mod, 3 * hd, b.o_mod_w, b.o_mod_b))) return rc;
+  if ((rc = scatter(h->mod_final, 2 * hd, h->o_fmod_w, h->o_fmod_b))) return rc;
+  if ((rc = tr_gemm_f32(h->dmod_bf, h->ldt, h->w_modT, fp, hd, (int)h->ldt, h->dsemb, hd, nullptr, s))) return rc;  // d SiLU(c)
+
+  // ---- noise-level embedding MLP (frames x hidden, fp32) ----
+  const long fh = (long)frames * hd;
+  hipLaunchKernelGGL(silu_bwd_kernel, dim3(cdiv(fh, 256)), dim3(256), 0, s, h->dsemb, h->cemb, h->dc, fh);
+  hipLaunchKernelGGL(small_wgrad_kernel, dim3(cdiv((long)hd * hd, 256)), dim3(256), 0, s, h->dc, h->a1, G + h->o_t_w2, G + h->o_t_b2, frames, hd, hd);
+  hipLaunchKernelGGL(small_dgrad_kernel, dim3(cdiv(fh, 256)), dim3(256), 0, s, h->dc, p + h->o_t_w2, h->da1, frames, hd, hd);
+  hipLaunchKernelGGL(silu_bwd_kernel, dim3(cdiv(fh, 256)), dim3(256), 0, s, h->da1, h->h1, h->dh1, fh);
+  hipLaunchKernelGGL(small_wgrad_kernel, dim3(cdiv((long)hd * nd, 256)), dim3(256), 0, s, h->dh1, h->feat, G + h->o_t_w1, G + h->o_t_b1, frames, hd, nd);
+  DFOT_CHECK_HIP(hipGetLastError());
+  return DFOT_OK;
+}
+
+/* ---- flat-buffer optimizer pieces (generic) ---- */
+int dfot_vloss_grad(const float* x, const float* noise, const float* v, const float* a, const float* sigma, const float* coef, float* dv,
+                    int batch, int tokens, int64_t frame_elems, int vspace, void* stream) {
+  DFOT_REQUIRE(x && noise && v && a && sigma && coef && dv, DFOT_ERR_ARG, "vloss_grad: null argument");
+  return launch_vloss_grad(x, noise, v, a, sigma, coef, dv, batch * tokens, frame_elems, vspace != 0, (hipStream_t)stream);
+}
+int dfot_sumsq(const float* x, int64_t n, float* out, void* stream) {
+  DFOT_REQUIRE(x && out && n > 0, DFOT_ERR_ARG, "sumsq: bad argument");
+  DFOT_CHECK_HIP(hipMemsetAsync(out, 0, sizeof(float), (hipStream_t)stream));
+  return launch_sumsq(x, n, out, (hipStream_t)stream);
+}
+int dfot_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1, float beta2,
+                    float eps, float weight_decay, int step, const float* grad_sumsq, float max_grad_norm, void* stream) {
+  DFOT_REQUIRE(params && grads && exp_avg && exp_avg_sq && n > 0, DFOT_ERR_ARG, "adamw_step: bad argument");
+  return launch_adamw(params, grads, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, step, grad_sumsq, max_grad_norm,
+                      (hipStream_t)stream);
+}
+
+}  // extern "C"

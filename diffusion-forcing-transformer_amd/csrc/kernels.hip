@@ -903,3 +903,86 @@ int launch_bf16_nhwc_to_nchw(const bf16* src, float* dst, int bt, int p, int c, 
 }
 
 }  // namespace dfot
+
+// --------------------------------------------------------------------------------------------
+// training: loss gradient, AdamW, gradient norm
+// --------------------------------------------------------------------------------------------
+namespace dfot {
+// dv = coef[bt] * d(loss term)/dv of vloss_partial_kernel: VSPACE: v - (a eps - s x) ; else a * ((a v + s x_t) - eps)
+template <bool VSPACE>
+__global__ void vloss_grad_kernel(const float* __restrict__ x, const float* __restrict__ noise, const float* __restrict__ v,
+                                  const float* __restrict__ a, const float* __restrict__ sg, const float* __restrict__ coef,
+                                  float* __restrict__ dv, long f4, long total4) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total4) return;
+  const long bt = i / f4;
+  const float av = a[bt], sv = sg[bt], cv = coef[bt];
+  const float4v xv = *reinterpret_cast<const float4v*>(x + i * 4);
+  const float4v nv = *reinterpret_cast<const float4v*>(noise + i * 4);
+  const float4v vv = *reinterpret_cast<const float4v*>(v + i * 4);
+  float4v d;
+  if (VSPACE) d = (vv - (nv * av - xv * sv)) * cv;
+  else d = ((vv * av + (xv * av + nv * sv) * sv) - nv) * (cv * av);
+  *reinterpret_cast<float4v*>(dv + i * 4) = d;
+}
+int launch_vloss_grad(const float* x, const float* noise, const float* v, const float* a, const float* sg, const float* coef, float* dv,
+                      int bt, long f, bool vspace, hipStream_t s) {
+  DFOT_REQUIRE(f % 4 == 0, DFOT_ERR_SHAPE, "vloss_grad: frame elements %ld must be a multiple of 4", f);
+  const long total4 = (long)bt * (f / 4);
+  if (vspace) hipLaunchKernelGGL(vloss_grad_kernel<true>, dim3(cdiv(total4, 256)), dim3(256), 0, s, x, noise, v, a, sg, coef, dv, f / 4, total4);
+  else hipLaunchKernelGGL(vloss_grad_kernel<false>, dim3(cdiv(total4, 256)), dim3(256), 0, s, x, noise, v, a, sg, coef, dv, f / 4, total4);
+  DFOT_CHECK_HIP(hipGetLastError());
+  return DFOT_OK;
+}
+
+// out[0] += sum x^2 (caller zeroes out); grid-stride, one atomic per workgroup
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, long n, float* __restrict__ out) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (long)gridDim.x * 1024) {
+    if (i + 3 < n) {
+      const float4v v = *reinterpret_cast<const float4v*>(x + i);
+      acc += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+    } else {
+      for (long j = i; j < n; ++j) acc += x[j] * x[j];
+    }
+  }
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, (red[0] + red[1]) + (red[2] + red[3]));
+}
+int launch_sumsq(const float* x, long n, float* out, hipStream_t s) {
+  DFOT_REQUIRE(((uintptr_t)x & 15) == 0, DFOT_ERR_ARG, "sumsq: buffer must be 16-byte aligned");
+  hipLaunchKernelGGL(sumsq_kernel, dim3(cdiv(n, 1024) < 2048 ? cdiv(n, 1024) : 2048), dim3(256), 0, s, x, n, out);
+  DFOT_CHECK_HIP(hipGetLastError());
+  return DFOT_OK;
+}
+
+// torch.optim.AdamW (decoupled weight decay) on flat fp32 buffers.  The gradient is first multiplied by
+// min(1, max_norm / (sqrt(*sumsq) + 1e-6)) when sumsq is given (clip_grad_norm_ without a host round trip).
+__global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long n,
+                             float lr, float b1, float b2, float eps, float wd, float c1, float c2, const float* __restrict__ sumsq,
+                             float max_norm) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float clip = 1.f;
+  if (sumsq) clip = fminf(1.f, max_norm / (sqrtf(*sumsq) + 1e-6f));
+  const float gv = g[i] * clip;
+  const float mv = b1 * m[i] + (1.f - b1) * gv;
+  const float vv = b2 * v[i] + (1.f - b2) * gv * gv;
+  m[i] = mv;
+  v[i] = vv;
+  const float pv = p[i] * (1.f - lr * wd);
+  p[i] = pv - (lr / c1) * mv / (sqrtf(vv) / sqrtf(c2) + eps);
+}
+int launch_adamw(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps, float wd, int step,
+                 const float* sumsq, float max_norm, hipStream_t s) {
+  DFOT_REQUIRE(step >= 1, DFOT_ERR_ARG, "adamw: step counts from 1");
+  const float c1 = 1.f - powf(b1, (float)step), c2 = 1.f - powf(b2, (float)step);
+  hipLaunchKernelGGL(adamw_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, p, g, m, v, n, lr, b1, b2, eps, wd, c1, c2, sumsq, max_norm);
+  DFOT_CHECK_HIP(hipGetLastError());
+  return DFOT_OK;
+}
+}  // namespace dfot

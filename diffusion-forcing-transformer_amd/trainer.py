@@ -1,0 +1,178 @@
+"""Training of the DiT3D backbone on the MI355X engine: hand-written forward-with-saved-activations and backward
+(``csrc/dit_train.inl``), fused AdamW with gradient-norm clipping on flat fp32 buffers, data parallelism by ONE all-reduce of
+the flat gradient buffer per step (RCCL through ``torch.distributed``; the buffer is a torch tensor).
+
+Mirrors, for the DiT3D "full" / rope_3d model (README ``@DiT/XL``, attention-only blocks in this fork):
+  * ``DFoTVideo.training_step``                     algorithms/dfot/dfot_video.py:41-75
+  * ``DiscreteDiffusion.forward`` (pred_v)          algorithms/dfot/diffusion/discrete_diffusion.py:345-377
+  * ``BasePytorchAlgo.configure_optimizers``        AdamW(lr, weight_decay, betas) + Lightning's gradient_clip_val
+  * DDP gradient averaging                          experiments (Lightning ``ddp`` strategy)
+No autograd and no torch kernels on the path: torch provides device memory, the stream and the collective.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import capi
+from .backbone import _get
+from .diffusion import DiffusionConfig, Schedule
+
+
+class DiT3DTrainer:
+    def __init__(self, cfg, x_shape: Sequence[int], max_tokens: int, timesteps: int = 1000,
+                 diffusion: Optional[DiffusionConfig] = None, lr: float = 5e-5, weight_decay: float = 0.01,
+                 betas: Tuple[float, float] = (0.9, 0.99), eps: float = 1e-8, max_grad_norm: Optional[float] = 1.0,
+                 loss_weighting: Optional[Dict] = None):
+        if _get(cfg, "variant", "full") != "full" or _get(cfg, "pos_emb_type", "rope_3d") != "rope_3d":
+            raise ValueError("DiT3DTrainer builds the 'full' / rope_3d DiT3D")
+        if _get(cfg, "spatial_mlp_ratio", None):
+            raise NotImplementedError("blocks with an MLP branch (spatial_mlp_ratio) have no training path yet")
+        self.x_shape = tuple(int(v) for v in x_shape)
+        c = capi.DiTConfig()
+        c.hidden_size = int(_get(cfg, "hidden_size"))
+        c.depth = int(_get(cfg, "depth"))
+        c.num_heads = int(_get(cfg, "num_heads"))
+        c.patch_size = int(_get(cfg, "patch_size", 2))
+        c.in_channels, c.height, c.width = self.x_shape
+        c.max_tokens = int(max_tokens)
+        c.noise_dim, c.timesteps, c.rope_theta, c.eps, c.variant = 256, int(timesteps), 10000.0, 1e-6, 0
+        self._ccfg = c
+        self.max_tokens = int(max_tokens)
+        self._handle = C.c_void_p()
+        capi.check(capi.lib.dfot_dit_train_create(C.byref(c), C.byref(self._handle)))
+        lib, h = capi.lib, self._handle
+        self.numel = int(lib.dfot_dit_train_total_numel(h))
+        shape, ndim = (C.c_int64 * 4)(), C.c_int()
+        self.layout: Dict[str, Tuple[int, Tuple[int, ...]]] = {}
+        for i in range(lib.dfot_dit_train_num_params(h)):
+            capi.check(lib.dfot_dit_train_param_shape(h, i, shape, C.byref(ndim)))
+            self.layout[lib.dfot_dit_train_param_name(h, i).decode()] = (
+                int(lib.dfot_dit_train_param_offset(h, i)), tuple(int(shape[k]) for k in range(ndim.value)))
+        # flat buffers: torch owns them (the gradient buffer is what torch.distributed all-reduces)
+        self.params = torch.zeros(self.numel, device="cuda", dtype=torch.float32)
+        self.grads = torch.zeros_like(self.params)
+        self.exp_avg = torch.zeros_like(self.params)
+        self.exp_avg_sq = torch.zeros_like(self.params)
+        self._sumsq = torch.zeros(1, device="cuda", dtype=torch.float32)
+        capi.check(lib.dfot_dit_train_attach(h, capi.ptr(self.params), capi.ptr(self.grads)))
+        self.lr, self.weight_decay, self.betas, self.eps, self.max_grad_norm = lr, weight_decay, tuple(betas), eps, max_grad_norm
+        self.step_count = 0
+        self.schedule = Schedule(diffusion or DiffusionConfig(beta_schedule="cosine", is_continuous=False, timesteps=timesteps))
+        self.loss_weighting = dict(loss_weighting or {})
+        self._reserved = 0
+        self._dirty = True
+        self._last: Optional[dict] = None
+
+    def __del__(self):
+        h = getattr(self, "_handle", None)
+        if h:
+            capi.lib.dfot_dit_train_destroy(h)
+            self._handle = None
+
+    # ------------------------------------------------------------------ parameters (reference state_dict names)
+    def view(self, name: str, buf: Optional[torch.Tensor] = None) -> torch.Tensor:
+        off, shape = self.layout[name]
+        return (self.params if buf is None else buf)[off: off + int(np.prod(shape))].view(shape)
+
+    def load_state_dict(self, state: Dict[str, torch.Tensor], strict: bool = True) -> None:
+        missing = [k for k in self.layout if k not in state]
+        extra = [k for k in state if k not in self.layout]
+        if strict and (missing or extra):
+            raise KeyError(f"state_dict mismatch: missing {missing[:4]}, unexpected {extra[:4]}")
+        for k in self.layout:
+            if k in state:
+                t = state[k]
+                if tuple(t.shape) != self.layout[k][1]:
+                    raise ValueError(f"{k}: shape {tuple(t.shape)} != {self.layout[k][1]}")
+                self.view(k).copy_(t.to(device="cuda", dtype=torch.float32))
+        self._dirty = True
+
+    def state_dict(self) -> Dict[str, torch.Tensor]:
+        return {k: self.view(k).detach().clone() for k in self.layout}
+
+    def grad_dict(self) -> Dict[str, torch.Tensor]:
+        return {k: self.view(k, self.grads).detach().clone() for k in self.layout}
+
+    def _sync(self) -> None:
+        if self._dirty:
+            capi.check(capi.lib.dfot_dit_train_sync_weights(self._handle, capi.stream_ptr()))
+            self._dirty = False
+
+    # ------------------------------------------------------------------ forward / backward (the autograd pair)
+    def forward(self, x: torch.Tensor, noise_levels: torch.Tensor) -> torch.Tensor:
+        b, t = x.shape[:2]
+        if tuple(x.shape[2:]) != self.x_shape:
+            raise ValueError(f"x has frame shape {tuple(x.shape[2:])}, expected {self.x_shape}")
+        if b > self._reserved:
+            capi.check(capi.lib.dfot_dit_train_reserve(self._handle, b))
+            self._reserved = b
+        self._sync()
+        xd = x.to(device="cuda", dtype=torch.float32).contiguous()
+        lv = noise_levels.to(device="cuda", dtype=torch.int32).contiguous()
+        out = torch.empty_like(xd)
+        capi.check(capi.lib.dfot_dit_train_forward(self._handle, capi.ptr(xd), capi.ptr(lv), capi.ptr(out), b, t, capi.stream_ptr()))
+        self._keep = (xd, lv)  # the engine reads x again in backward (patch-embedding gradient)
+        return out
+
+    def backward(self, d_out: torch.Tensor) -> None:
+        g = d_out.to(device="cuda", dtype=torch.float32).contiguous()
+        capi.check(capi.lib.dfot_dit_train_backward(self._handle, capi.ptr(g), capi.stream_ptr()))
+
+    # ------------------------------------------------------------------ one training step
+    def loss_and_grads(self, xs: torch.Tensor, k: torch.Tensor, noise: torch.Tensor, masks: Optional[torch.Tensor] = None):
+        """DiscreteDiffusion.forward (pred_v) + _reweight_loss + backward: noise every token to its level, one forward, the
+        weighted v-space error averaged over (B, T) with the loss masks, gradients of every parameter.  Returns the loss (device scalar)."""
+        b, t = xs.shape[:2]
+        f = int(np.prod(xs.shape[2:]))
+        kk = k.detach().cpu().numpy().astype(np.int64)
+        sch = self.schedule
+        w = sch.loss_weights(kk, **self.loss_weighting).astype(np.float32)
+        mk = np.ones((b, t), np.float32) if masks is None else masks.detach().cpu().numpy().astype(np.float32).reshape(b, t)
+        tab = np.stack([sch.sqrt_alphas_cumprod[kk], sch.sqrt_one_minus_alphas_cumprod[kk], w, 2.0 * w * mk / (f * b * t)]).astype(np.float32)
+        tab = torch.from_numpy(tab).cuda().contiguous()
+        x = xs.to(device="cuda", dtype=torch.float32).contiguous()
+        eps = noise.to(device="cuda", dtype=torch.float32).clamp(-self.schedule.cfg.clip_noise, self.schedule.cfg.clip_noise).contiguous()
+        x_k = torch.empty_like(x)
+        s = capi.stream_ptr
+        capi.check(capi.lib.dfot_hg_prepare(capi.ptr(x), capi.ptr(eps), capi.ptr(tab[0]), capi.ptr(tab[1]), capi.ptr(x_k), b, 1, t, f, s()))
+        v = self.forward(x_k, k)
+        per_token = torch.empty(b, t, device="cuda")
+        scratch = torch.empty(int(capi.lib.dfot_vpred_loss_scratch_floats(b, t, f)), device="cuda")
+        capi.check(capi.lib.dfot_vspace_loss(capi.ptr(x), capi.ptr(eps), capi.ptr(v), capi.ptr(tab[0]), capi.ptr(tab[1]), capi.ptr(tab[2]),
+                                             None, capi.ptr(scratch), capi.ptr(per_token), b, t, f, s()))
+        dv = torch.empty_like(x)
+        capi.check(capi.lib.dfot_vloss_grad(capi.ptr(x), capi.ptr(eps), capi.ptr(v), capi.ptr(tab[0]), capi.ptr(tab[1]), capi.ptr(tab[3]),
+                                            capi.ptr(dv), b, t, f, 1, s()))
+        self.backward(dv)
+        return (per_token * torch.from_numpy(mk).cuda()).mean()
+
+    def optimizer_step(self, world_size: int = 1) -> None:
+        """[all-reduce + average the flat gradient buffer] -> global-norm clip -> AdamW -> refresh the bf16 compute weights"""
+        if world_size > 1:
+            import torch.distributed as dist
+            dist.all_reduce(self.grads)
+            self.grads.mul_(1.0 / world_size)
+        self.step_count += 1
+        s = capi.stream_ptr
+        sumsq = None
+        if self.max_grad_norm is not None:
+            capi.check(capi.lib.dfot_sumsq(capi.ptr(self.grads), self.numel, capi.ptr(self._sumsq), s()))
+            sumsq = self._sumsq
+        capi.check(capi.lib.dfot_adamw_step(capi.ptr(self.params), capi.ptr(self.grads), capi.ptr(self.exp_avg), capi.ptr(self.exp_avg_sq),
+                                            self.numel, self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay, self.step_count,
+                                            capi.ptr(sumsq), float(self.max_grad_norm or 0.0), s()))
+        self._dirty = True
+
+    def training_step(self, xs: torch.Tensor, k: torch.Tensor, noise: torch.Tensor, masks: Optional[torch.Tensor] = None,
+                      world_size: int = 1) -> torch.Tensor:
+        loss = self.loss_and_grads(xs, k, noise, masks)
+        self.optimizer_step(world_size)
+        return loss
+
+    def grad_norm(self) -> float:
+        capi.check(capi.lib.dfot_sumsq(capi.ptr(self.grads), self.numel, capi.ptr(self._sumsq), capi.stream_ptr()))
+        return float(self._sumsq.sqrt().item())

@@ -164,6 +164,39 @@ int dfot_dit_forward(dfot_dit_t h, const float* x, const int32_t* noise_levels, 
  * "stream" [B*T*P][hidden] (residual stream after the last block) */
 int dfot_dit_read_tap(dfot_dit_t h, const char* name, float* out, size_t capacity_floats, void* stream);
 
+/* ---- DiT3D training path ("full" variant, attention-only blocks) ----------------------------------
+ * Replaces torch autograd through DiT3D.forward (algorithms/dfot/backbones/dit/dit3d.py:153-192, dit_blocks.py:408-542) and the
+ * optimizer step of DFoTVideo.training_step / configure_optimizers (dfot_video.py:41-75, base_pytorch_algo: AdamW).
+ * Parameters, gradients and optimizer moments live in caller-owned flat fp32 buffers (reference state_dict order, every
+ * tensor 16-byte aligned at dfot_dit_train_param_offset) so a data-parallel job all-reduces ONE buffer.
+ *   create -> attach(params, grads) -> [copy weights into params] -> reserve(batch) -> sync_weights
+ *   step: forward(x_t, levels) -> loss + dfot_vloss_grad -> backward(d_out) -> [all-reduce grads] -> dfot_sumsq + dfot_adamw_step
+ *         -> sync_weights */
+typedef struct dfot_dit_train_s* dfot_dit_train_t;
+int dfot_dit_train_create(const dfot_dit_config* cfg, dfot_dit_train_t* out);
+int dfot_dit_train_destroy(dfot_dit_train_t h);
+int dfot_dit_train_num_params(dfot_dit_train_t h);
+const char* dfot_dit_train_param_name(dfot_dit_train_t h, int i);
+int dfot_dit_train_param_shape(dfot_dit_train_t h, int i, int64_t shape[4], int* ndim);
+int64_t dfot_dit_train_param_offset(dfot_dit_train_t h, int i);
+int64_t dfot_dit_train_total_numel(dfot_dit_train_t h);
+size_t dfot_dit_train_workspace_bytes(dfot_dit_train_t h);
+int dfot_dit_train_attach(dfot_dit_train_t h, float* params, float* grads);
+int dfot_dit_train_reserve(dfot_dit_train_t h, int max_batch);
+int dfot_dit_train_sync_weights(dfot_dit_train_t h, void* stream);
+/* out = model(x, levels), saving what backward needs; x must stay valid until backward */
+int dfot_dit_train_forward(dfot_dit_train_t h, const float* x, const int32_t* noise_levels, float* out, int batch, int tokens, void* stream);
+/* grads <- d(sum(out * d_out))/d(params) for the last forward (overwrites the attached gradient buffer) */
+int dfot_dit_train_backward(dfot_dit_train_t h, const float* d_out, void* stream);
+/* dv[B,T,F] = coef[b,t] * d/dv of the loss term of dfot_vspace_loss (vspace = 1) / dfot_vpred_loss (vspace = 0) */
+int dfot_vloss_grad(const float* x, const float* noise, const float* v, const float* a, const float* sigma, const float* coef, float* dv,
+                    int batch, int tokens, int64_t frame_elems, int vspace, void* stream);
+/* out[0] = sum x^2 (device scalar) */
+int dfot_sumsq(const float* x, int64_t n, float* out, void* stream);
+/* torch.optim.AdamW on flat buffers; grad_sumsq (optional device scalar): clip the gradient to max_grad_norm first */
+int dfot_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1, float beta2,
+                    float eps, float weight_decay, int step, const float* grad_sumsq, float max_grad_norm, void* stream);
+
 /* ---- camera-pose front end ------------------------------------------------------------------- */
 /* raw poses [B,T,16] (fx,fy,px,py | 3x4 RT) -> ray encoding [B,T,180,res,res] fp32, normalised by frame 0 */
 int dfot_ray_encode(const float* raw_poses, float* out, int batch, int tokens, int resolution, void* stream);
