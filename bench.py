@@ -75,6 +75,69 @@ def k600_traffic(diff: bool, batch: int):
     return ks[0]["hbm_bytes_per_launch_corrected"] if ks else None
 
 
+def bench_train_k600(args, rank, world, dist):
+    """BASELINE config 5's pattern on the model that has a training path (README @DiT/XL, K600 latents): one step = per-token
+    independent noise levels -> noised forward -> fused-min-SNR v-loss -> hand-written backward -> all-reduce of the flat gradient
+    buffer over the ranks (RCCL) -> global-norm clip + AdamW -> bf16 weight refresh.  `--batch` videos per GPU (weak scaling)."""
+    import dfot_amd
+    from dfot_amd import DiT3D, DiT3DTrainer
+    xl = dict(name="dit3d", variant="full", pos_emb_type="rope_3d", patch_size=1, hidden_size=1152, depth=28, num_heads=16)
+    init = DiT3D(xl, x_shape=(16, 16, 16), max_tokens=5)
+    init.init_random(seed=0)  # same seed on every rank: replicas start identical
+    tr = DiT3DTrainer(xl, x_shape=(16, 16, 16), max_tokens=5, lr=5e-5, weight_decay=0.01, betas=(0.9, 0.99), max_grad_norm=1.0)
+    tr.load_state_dict({k: v.detach() for k, v in init.state_dict().items()}, strict=True)
+    del init
+    b = args.batch
+    g = torch.Generator().manual_seed(100 + rank)
+    xs = torch.randn(b, 5, 16, 16, 16, generator=g).cuda()
+    noise = torch.randn(b, 5, 16, 16, 16, generator=g).cuda()
+    tn = dfot_amd.TrainingNoise(noise_level="random_independent", is_continuous=False, n_context_tokens=2)
+    masks = torch.ones(b, 5, dtype=torch.bool)
+    levels = [tn.sample(b, 5, masks, g, training=True) for _ in range(args.steps + args.warmup)]
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    losses = []
+    for i in range(args.warmup):
+        tr.training_step(xs, levels[i][0], noise, levels[i][1], world_size=world)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        losses.append(tr.training_step(xs, levels[args.warmup + i][0], noise, levels[args.warmup + i][1], world_size=world))
+    barrier()
+    dt = time.perf_counter() - t0
+    losses = [float(l.item()) for l in losses]
+    assert all(np.isfinite(losses)), losses
+    if dist is not None:
+        tmax = torch.tensor([dt], device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    if rank == 0:
+        n, d, heads = 1280, 72, 16
+        video_flop = 28 * (2.0 * n * 1152 * 3456 + 2.0 * n * 1152 * 1152 + 4.0 * n * n * d * heads)
+        step_flop = 3.0 * video_flop * b  # forward + backward (2x), algorithmic
+        line = {
+            "metric": "training samples/sec, DFoT K600 DiT/XL (per-token independent noise levels, AdamW, data parallel)",
+            "value": b * args.steps * world / dt, "unit": "videos/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+            "data": "synthetic latents, seeded random-init weights",
+            "config": {"workload": f"DFoT K600 @DiT/XL training step: {b} videos per GPU, latents 16x16x16, 5 tokens, random_independent levels, "
+                                   "fused_min_snr v-loss, AdamW lr 5e-5 wd 0.01 betas (0.9, 0.99), grad clip 1.0, fp32 master weights / bf16 compute; "
+                                   "one all-reduce of the 1.06 GB flat gradient buffer per step", "parameters": tr.numel},
+            "losses": losses, "model_tflops": step_flop * args.steps / dt / 1e12,
+            "roofline": {"bound": "mfma", "kernel": "whole training step (3 x forward FLOPs: GEMM dgrad/wgrad + attention backward); per-kernel split in profiles/",
+                         "achieved": step_flop * args.steps / dt / 1e12, "peak": 2500.0, "unit": "TFLOP/s", "frac": step_flop * args.steps / dt / 1e12 / 2500.0,
+                         "traffic": None},
+        }
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def bench_k600(args, rank, world, dist):
     """BASELINE config 4: Kinetics-600 latents [16,16,16], 17 frames = 5 latent tokens, context 5 frames = 2 tokens,
     README model @DiT/XL (dit3d full, rope_3d; attention-only blocks in this fork), DiscreteDiffusion cosine / pred_v,
@@ -195,7 +258,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", action="store_true", help="replay one hipGraph-captured DDIM step (no in-run attention timing)")
     ap.add_argument("--batch", type=int, default=8, help="k600: videos per GPU (bash/k600 validation.batch_size)")
-    ap.add_argument("--workload", choices=["8f", "200f", "k600", "k600diff"], default="8f",
+    ap.add_argument("--workload", choices=["8f", "200f", "k600", "k600diff", "train_k600"], default="8f",
                     help="8f: BASELINE config 2 (default, the metric's single-GPU configuration); 200f: config 3, the "
                          "200-frame rollout (keyframe density 0.0625, stabilized HG 4.0/0.02 + interpolation HG 1.5, batches of "
                          "4 windows), interpolation windows sharded over ranks")
@@ -213,6 +276,8 @@ def main():
     import dfot_amd
     from dfot_amd import DFoTVideoPoseSampler, DiffusionConfig, SamplerConfig, UViT3DPose
 
+    if args.workload == "train_k600":
+        return bench_train_k600(args, rank, world, dist if world > 1 else None)
     if args.workload in ("k600", "k600diff"):
         return bench_k600(args, rank, world, dist if world > 1 else None)
     res = args.res

@@ -79,3 +79,19 @@ def run_sharded(n_windows: int, sample_batch: Callable[[List[int]], torch.Tensor
         probe = sample_batch([])
         local = probe
     return gather_windows(local, n_windows, group)
+
+
+def allreduce_mean_(flat: torch.Tensor, group=None, bucket_numel: int = 1 << 26) -> torch.Tensor:
+    """Data-parallel gradient averaging of ONE flat buffer (trainer.DiT3DTrainer.grads): in-place sum over the ranks in buckets
+    of `bucket_numel` elements issued back to back (async) and awaited together, then scaled by 1/world.  xGMI is point-to-point,
+    so a ring all-reduce is bound per link: few large buckets (256 MiB of fp32 by default) rather than per-tensor calls."""
+    world, _ = world_info(group)
+    if world == 1:
+        return flat
+    works = []
+    for lo in range(0, flat.numel(), bucket_numel):
+        works.append(dist.all_reduce(flat[lo: lo + bucket_numel], group=group, async_op=True))
+    for w in works:
+        w.wait()
+    flat.mul_(1.0 / world)
+    return flat

@@ -17,7 +17,7 @@ from typing import Dict, Optional, Sequence, Tuple
 import numpy as np
 import torch
 
-from . import capi
+from . import capi, parallel
 from .backbone import _get
 from .diffusion import DiffusionConfig, Schedule
 
@@ -153,9 +153,7 @@ class DiT3DTrainer:
     def optimizer_step(self, world_size: int = 1) -> None:
         """[all-reduce + average the flat gradient buffer] -> global-norm clip -> AdamW -> refresh the bf16 compute weights"""
         if world_size > 1:
-            import torch.distributed as dist
-            dist.all_reduce(self.grads)
-            self.grads.mul_(1.0 / world_size)
+            parallel.allreduce_mean_(self.grads)
         self.step_count += 1
         s = capi.stream_ptr
         sumsq = None

@@ -120,3 +120,33 @@ def test_sharded_interpolation_control_flow_equals_serial_world2():
     # 11 + 35 windows in total; each rank samples about half of them when sharded
     assert all(serial == 46 for _, _, serial, _ in res), res
     assert sorted(sh for _, _, _, sh in res) == [22, 24], res  # 11 -> 6+5 and 35 -> 18+17 windows
+
+
+def _grad_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from dfot_amd import parallel
+    n = 1000 + 37
+    g = torch.Generator().manual_seed(5)
+    base = torch.randn(world, n, generator=g)       # every rank builds all shards, keeps its own
+    flat = base[rank].clone()
+    parallel.allreduce_mean_(flat, bucket_numel=256)  # several ragged buckets
+    q.put((rank, bool(torch.allclose(flat, base.mean(0), atol=1e-6))))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_flat_gradient_allreduce_mean_world2():
+    """the data-parallel training exchange: one flat gradient buffer, bucketed async all-reduce, mean over ranks"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_grad_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(60)
+    assert all(ok for _, ok in res), res
