@@ -68,7 +68,9 @@ __device__ __forceinline__ void tile_store(char* dst, const bf16x8 (&r)[BwdCfg<D
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-template <int D>
+// DC / DW: head-dim columns actually multiplied when the logical head dim is smaller than the row stride D (pad columns are
+// zero): DC (multiple of 16) where the head dim is contracted (S, dP), DW (multiple of 32) where it is the output (dQ, dK, dV)
+template <int D, int DC = D, int DW = D>
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K,
                                                           const bf16* __restrict__ V, const bf16* __restrict__ dO,
                                                           const float* __restrict__ L2, const float* __restrict__ delta,
@@ -85,17 +87,17 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16* __restrict
   const bf16* Kb = K + base;
   const bf16* Vb = V + base;
 
-  bf16x8 qf[D / 16], dof[D / 16];
+  bf16x8 qf[DC / 16], dof[DC / 16];
 #pragma unroll
-  for (int ks = 0; ks < D / 16; ++ks) {
+  for (int ks = 0; ks < DC / 16; ++ks) {
     qf[ks] = *reinterpret_cast<const bf16x8*>(Q + base + (long)(q0 + lq) * D + ks * 16 + lh * 8);
     dof[ks] = *reinterpret_cast<const bf16x8*>(dO + base + (long)(q0 + lq) * D + ks * 16 + lh * 8);
   }
   const float l2 = L2[(long)bh * N + q0 + lq], dl = delta[(long)bh * N + q0 + lq];
 
-  f32x16 acc[D / 32];
+  f32x16 acc[DW / 32];
 #pragma unroll
-  for (int i = 0; i < D / 32; ++i)
+  for (int i = 0; i < DW / 32; ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
@@ -122,7 +124,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16* __restrict
       for (int r = 0; r < 16; ++r) { sacc[r] = -l2; pacc[r] = -dl; }
       const int row = kt2 * 32 + lq;
 #pragma unroll
-      for (int ks = 0; ks < D / 16; ++ks) {
+      for (int ks = 0; ks < DC / 16; ++ks) {
         const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sk + row * C::ROWB + (ks * 2 + lh) * 16);
         sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sacc, 0, 0, 0);
         const bf16x8 vf = *reinterpret_cast<const bf16x8*>(sv + row * C::ROWB + (ks * 2 + lh) * 16);
@@ -135,7 +137,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16* __restrict
     }
     // dQ^T[c][q] += K^T[c][key] dS^T[key][q]
 #pragma unroll
-    for (int dvt = 0; dvt < D / 32; ++dvt)
+    for (int dvt = 0; dvt < DW / 32; ++dvt)
 #pragma unroll
       for (int kt2 = 0; kt2 < 2; ++kt2)
 #pragma unroll
@@ -150,8 +152,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16* __restrict
     cur ^= 1;
   }
   bf16* orow = dQ + base + (long)(q0 + lq) * D;
+  if constexpr (DW < D) {  // pad columns beyond DW: zero (the caller's buffers are re-used across blocks)
 #pragma unroll
-  for (int dvt = 0; dvt < D / 32; ++dvt)
+    for (int c = DW + 4 * lh; c < D; c += 8) *reinterpret_cast<bf16x4*>(orow + c) = bf16x4{f2bf(0.f), f2bf(0.f), f2bf(0.f), f2bf(0.f)};
+  }
+#pragma unroll
+  for (int dvt = 0; dvt < DW / 32; ++dvt)
 #pragma unroll
     for (int g4 = 0; g4 < 4; ++g4) {
       bf16x4 o4;
@@ -162,7 +168,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16* __restrict
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-template <int D>
+template <int D, int DC = D, int DW = D>
 __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K,
                                                            const bf16* __restrict__ V, const bf16* __restrict__ dO,
                                                            const float* __restrict__ L2, const float* __restrict__ delta,
@@ -181,15 +187,15 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16* __restric
   const float* Lb = L2 + (long)bh * N;
   const float* Db = delta + (long)bh * N;
 
-  bf16x8 kf[D / 16], vf[D / 16];
+  bf16x8 kf[DC / 16], vf[DC / 16];
 #pragma unroll
-  for (int ks = 0; ks < D / 16; ++ks) {
+  for (int ks = 0; ks < DC / 16; ++ks) {
     kf[ks] = *reinterpret_cast<const bf16x8*>(K + base + (long)(k0 + lq) * D + ks * 16 + lh * 8);
     vf[ks] = *reinterpret_cast<const bf16x8*>(V + base + (long)(k0 + lq) * D + ks * 16 + lh * 8);
   }
-  f32x16 dka[D / 32], dva[D / 32];
+  f32x16 dka[DW / 32], dva[DW / 32];
 #pragma unroll
-  for (int i = 0; i < D / 32; ++i)
+  for (int i = 0; i < DW / 32; ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) { dka[i][r] = 0.f; dva[i][r] = 0.f; }
 
@@ -232,7 +238,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16* __restric
       }
       const int row = kt2 * 32 + lq;
 #pragma unroll
-      for (int ks = 0; ks < D / 16; ++ks) {
+      for (int ks = 0; ks < DC / 16; ++ks) {
         const bf16x8 qa = *reinterpret_cast<const bf16x8*>(sq + row * C::ROWB + (ks * 2 + lh) * 16);
         sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[ks], sacc, 0, 0, 0);
         const bf16x8 oa = *reinterpret_cast<const bf16x8*>(so + row * C::ROWB + (ks * 2 + lh) * 16);
@@ -248,7 +254,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16* __restric
         }
     }
 #pragma unroll
-    for (int dvt = 0; dvt < D / 32; ++dvt)
+    for (int dvt = 0; dvt < DW / 32; ++dvt)
 #pragma unroll
       for (int kt2 = 0; kt2 < 2; ++kt2)
 #pragma unroll
@@ -265,8 +271,15 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16* __restric
   }
   bf16* krow = dK + base + (long)(k0 + lq) * D;
   bf16* vrow = dV + base + (long)(k0 + lq) * D;
+  if constexpr (DW < D) {
 #pragma unroll
-  for (int dvt = 0; dvt < D / 32; ++dvt)
+    for (int c = DW + 4 * lh; c < D; c += 8) {
+      *reinterpret_cast<bf16x4*>(krow + c) = bf16x4{f2bf(0.f), f2bf(0.f), f2bf(0.f), f2bf(0.f)};
+      *reinterpret_cast<bf16x4*>(vrow + c) = bf16x4{f2bf(0.f), f2bf(0.f), f2bf(0.f), f2bf(0.f)};
+    }
+  }
+#pragma unroll
+  for (int dvt = 0; dvt < DW / 32; ++dvt)
 #pragma unroll
     for (int g4 = 0; g4 < 4; ++g4) {
       bf16x4 k4, v4;
@@ -317,21 +330,21 @@ int launch_attention_bwd_prepare(const bf16* o, const bf16* d_o, long ldo, bf16*
   return DFOT_OK;
 }
 
-template <int D>
+template <int D, int DC = D, int DW = D>
 static int launch_bwd_t(const bf16* q, const bf16* k, const bf16* v, const bf16* dop, const float* l2, const float* delta, bf16* dq,
                         bf16* dk, bf16* dv, int batch, int heads, int n, float sq, float sk, hipStream_t s) {
   using C = BwdCfg<D>;
   const int lds1 = 4 * C::TILE, lds2 = 2 * (2 * C::TILE + 2 * C::TR * 4);
   static bool attr_set = false;
   if (!attr_set) {
-    DFOT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_kernel<D>), hipFuncAttributeMaxDynamicSharedMemorySize, lds1));
-    DFOT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_kernel<D>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2));
+    DFOT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_kernel<D, DC, DW>), hipFuncAttributeMaxDynamicSharedMemorySize, lds1));
+    DFOT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_kernel<D, DC, DW>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2));
     attr_set = true;
   }
   const int grid = (n / 128) * batch * heads;
-  hipLaunchKernelGGL(attn_bwd_dq_kernel<D>, dim3(grid), dim3(256), lds1, s, q, k, v, dop, l2, delta, dq, n, sq);
+  hipLaunchKernelGGL((attn_bwd_dq_kernel<D, DC, DW>), dim3(grid), dim3(256), lds1, s, q, k, v, dop, l2, delta, dq, n, sq);
   DFOT_CHECK_HIP(hipGetLastError());
-  hipLaunchKernelGGL(attn_bwd_dkv_kernel<D>, dim3(grid), dim3(256), lds2, s, q, k, v, dop, l2, delta, dk, dv, n, sk);
+  hipLaunchKernelGGL((attn_bwd_dkv_kernel<D, DC, DW>), dim3(grid), dim3(256), lds2, s, q, k, v, dop, l2, delta, dk, dv, n, sk);
   DFOT_CHECK_HIP(hipGetLastError());
   return DFOT_OK;
 }
@@ -343,8 +356,11 @@ int launch_attention_bwd(const bf16* q, const bf16* k, const bf16* v, const bf16
   DFOT_REQUIRE(d > 0 && d <= 128, DFOT_ERR_SHAPE, "attention_bwd: head dim %d must be <= 128", d);
   DFOT_REQUIRE(n > 0 && n % 128 == 0, DFOT_ERR_SHAPE, "attention_bwd: N=%d must be a multiple of 128", n);
   const float sq = 1.0f / sqrtf((float)d), sk = 0.6931471805599453f;
-  return attention_dstride(d) == 64 ? launch_bwd_t<64>(q, k, v, dop, l2, delta, dq, dk, dv, batch, heads, n, sq, sk, s)
-                                    : launch_bwd_t<128>(q, k, v, dop, l2, delta, dq, dk, dv, batch, heads, n, sq, sk, s);
+  if (d <= 32) return launch_bwd_t<64, 32, 32>(q, k, v, dop, l2, delta, dq, dk, dv, batch, heads, n, sq, sk, s);
+  if (d <= 64) return launch_bwd_t<64>(q, k, v, dop, l2, delta, dq, dk, dv, batch, heads, n, sq, sk, s);
+  if (d <= 80) return launch_bwd_t<128, 80, 96>(q, k, v, dop, l2, delta, dq, dk, dv, batch, heads, n, sq, sk, s);
+  if (d <= 96) return launch_bwd_t<128, 96, 96>(q, k, v, dop, l2, delta, dq, dk, dv, batch, heads, n, sq, sk, s);
+  return launch_bwd_t<128>(q, k, v, dop, l2, delta, dq, dk, dv, batch, heads, n, sq, sk, s);
 }
 
 }  // namespace dfot

@@ -13,7 +13,7 @@ def rel(a, b):
     return float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30))
 
 
-@pytest.mark.parametrize("d,heads,n,batch", [(72, 4, 640, 2), (32, 4, 256, 1), (64, 2, 384, 2), (128, 1, 256, 1)])
+@pytest.mark.parametrize("d,heads,n,batch", [(72, 4, 640, 2), (32, 4, 256, 1), (64, 2, 384, 2), (128, 1, 256, 1), (96, 2, 256, 1), (120, 1, 128, 2), (48, 3, 128, 1)])
 def test_attention_backward(d, heads, n, batch):
     """dq / dk / dv of softmax(q k^T / sqrt d) v for an upstream gradient d_o, vs autograd in fp32 on the bf16-rounded operands"""
     from dfot_amd import capi
