@@ -359,7 +359,7 @@ __device__ __forceinline__ void ln_mod_row(const float* __restrict__ xr, const f
 }
 
 template <int VEC, int CNT>
-__global__ __launch_bounds__(256) void ln_mod_kernel(float* __restrict__ x, bf16* __restrict__ obf,
+__global__ __launch_bounds__(256) void ln_mod_kernel(const float* xin, float* xout, bf16* __restrict__ obf,
                                                      const float* __restrict__ table, const int* __restrict__ levels,
                                                      long ldt, long off, int rows_per_frame, int rows, float eps,
                                                      int max_level) {
@@ -369,11 +369,11 @@ __global__ __launch_bounds__(256) void ln_mod_kernel(float* __restrict__ x, bf16
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
-  float* xr = x + (long)row * hidden;
+  float* xr = xout + (long)row * hidden;  // xout may alias xin (inference: in place); training keeps x for the backward
   int lv = levels[row / rows_per_frame];
   lv = lv < 0 ? 0 : (lv > max_level ? max_level : lv);
   V v[CNT];
-  ln_mod_row<VEC, CNT>(xr, table + (long)lv * ldt + off, hidden, eps, lane, v);
+  ln_mod_row<VEC, CNT>(xin + (long)row * hidden, table + (long)lv * ldt + off, hidden, eps, lane, v);
   bf16* orow = obf + (long)row * hidden;
 #pragma unroll
   for (int i = 0; i < CNT; ++i) {
@@ -455,10 +455,10 @@ __global__ __launch_bounds__(256) void final_layer_kernel(const float* __restric
       return DFOT_ERR_SHAPE;                                   \
   }
 
-int launch_ln_mod(float* x, bf16* obf, const float* table, const int* levels, long ldt, long off, int hidden, int rows_per_frame,
+int launch_ln_mod(const float* xin, float* x, bf16* obf, const float* table, const int* levels, long ldt, long off, int hidden, int rows_per_frame,
                   int rows, float eps, int max_level, hipStream_t s) {
 #define CALL(V, C) \
-  hipLaunchKernelGGL((ln_mod_kernel<V, C>), dim3(cdiv(rows, 4)), dim3(256), 0, s, x, obf, table, levels, ldt, off, rows_per_frame, rows, eps, max_level)
+  hipLaunchKernelGGL((ln_mod_kernel<V, C>), dim3(cdiv(rows, 4)), dim3(256), 0, s, xin, x, obf, table, levels, ldt, off, rows_per_frame, rows, eps, max_level)
   DIT_LN_DISPATCH(CALL)
 #undef CALL
   DFOT_CHECK_HIP(hipGetLastError());
@@ -942,7 +942,7 @@ int dfot_dit_forward(dfot_dit_t h, const float* x, const int32_t* noise_levels, 
   DFOT_CHECK_HIP(hipGetLastError());
   const float qscale = 1.4426950408889634f / sqrtf((float)h->d);  // attention works in the exp2 domain
   auto ln_mod = [&](long off) -> int {
-    return launch_ln_mod(h->X, h->A, h->mod_table, lvl, h->ldt, off, hd, P, (int)rows, c.eps, max_level, s);
+    return launch_ln_mod(h->X, h->X, h->A, h->mod_table, lvl, h->ldt, off, hd, P, (int)rows, c.eps, max_level, s);
   };
   auto gated = [&](const bf16* a, int kdim, const bf16* w, const float* bias, int bias_rows, long gate_off) -> int {
     GemmArgs g;  // X <- X + gate * (a W^T + bias), in place

@@ -83,42 +83,50 @@ __global__ void frames_colsum_kernel(const float* __restrict__ src, float* __res
   out[c] = acc;
 }
 
-// y = m + gate[frame] * a   (x holds m, fp32, updated in place)
-__global__ void gate_combine_kernel(float* __restrict__ x, const bf16* __restrict__ a, const float* __restrict__ table, long ldt, long off,
-                                    int hidden, int rows_per_frame, long total4) {
+// y = m + gate[frame] * a   (x holds m, fp32)
+__global__ void gate_combine_kernel(const float* __restrict__ x, float* __restrict__ y, const bf16* __restrict__ a, const float* __restrict__ table,
+                                    long ldt, long off, int hidden, int rows_per_frame, long total4) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total4) return;
   const long e = i * 4, row = e / hidden;
   const int c = (int)(e % hidden);
   const float4v g = *reinterpret_cast<const float4v*>(table + (row / rows_per_frame) * ldt + off + c);
   const bf16x4 av = *reinterpret_cast<const bf16x4*>(a + e);
-  float4v xv = *reinterpret_cast<float4v*>(x + e);
+  float4v xv = *reinterpret_cast<const float4v*>(x + e);
 #pragma unroll
   for (int j = 0; j < 4; ++j) xv[j] += g[j] * bf2f(av[j]);
-  *reinterpret_cast<float4v*>(x + e) = xv;
+  *reinterpret_cast<float4v*>(y + e) = xv;
 }
 
 constexpr int TR_CHUNKS = 4;  // row chunks per frame in the per-(frame, channel) reductions
-// da = dY * gate (bf16) ; dgate[frame][c] += sum_rows dY * a ; dbias[c] += sum_rows da
+// da = dY * gate (bf16) ; dgate[frame][c] += sum_rows dY * a ; dbias[c] += sum_rows da.  A thread owns 4 channels.
 __global__ __launch_bounds__(256) void gate_bwd_kernel(const float* __restrict__ dy, const bf16* __restrict__ a, const float* __restrict__ table,
                                                        long ldt, long off, bf16* __restrict__ da, float* __restrict__ dmod,
                                                        float* __restrict__ dbias, int hidden, int rows_per_frame) {
-  const int c = blockIdx.y * 256 + threadIdx.x;
+  const int c = (blockIdx.y * 256 + threadIdx.x) * 4;
   if (c >= hidden) return;
   const long frame = blockIdx.x;
   const int per = rows_per_frame / TR_CHUNKS, r0 = blockIdx.z * per;
-  const float g = table[frame * ldt + off + c];
-  float sg = 0.f, sb = 0.f;
+  const float4v g = *reinterpret_cast<const float4v*>(table + frame * ldt + off + c);
+  float4v sg = {0.f, 0.f, 0.f, 0.f}, sb = {0.f, 0.f, 0.f, 0.f};
   for (int r = r0; r < r0 + per; ++r) {
     const long e = (frame * rows_per_frame + r) * hidden + c;
-    const float d = dy[e];
-    const bf16 o = f2bf(d * g);
-    da[e] = o;
-    sg += d * bf2f(a[e]);
-    sb += bf2f(o);
+    const float4v d = *reinterpret_cast<const float4v*>(dy + e);
+    const bf16x4 av = *reinterpret_cast<const bf16x4*>(a + e);
+    bf16x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      o[j] = f2bf(d[j] * g[j]);
+      sg[j] += d[j] * bf2f(av[j]);
+      sb[j] += bf2f(o[j]);
+    }
+    *reinterpret_cast<bf16x4*>(da + e) = o;
   }
-  atomicAdd(dmod + frame * ldt + off + c, sg);
-  atomicAdd(dbias + c, sb);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    atomicAdd(dmod + frame * ldt + off + c + j, sg[j]);
+    atomicAdd(dbias + c + j, sb[j]);
+  }
 }
 
 // LayerNorm + modulation backward, row part: dx = rstd (dxh - mean(dxh) - xhat mean(dxh xhat)), dxh = dm (1 + scale); stats = (mean, rstd)
@@ -169,23 +177,28 @@ __global__ __launch_bounds__(256) void ln_bwd_rows_kernel(const float* __restric
     stats[2 * (long)row + 1] = rstd;
   }
 }
-// frame part: dshift[frame][c] += sum_rows dm ; dscale[frame][c] += sum_rows dm xhat
+// frame part: dshift[frame][c] += sum_rows dm ; dscale[frame][c] += sum_rows dm xhat.  A thread owns 4 channels.
 __global__ __launch_bounds__(256) void ln_bwd_frames_kernel(const float* __restrict__ dm, const float* __restrict__ x,
                                                             const float* __restrict__ stats, float* __restrict__ dmod, long ldt, long off,
                                                             int hidden, int rows_per_frame) {
-  const int c = blockIdx.y * 256 + threadIdx.x;
+  const int c = (blockIdx.y * 256 + threadIdx.x) * 4;
   if (c >= hidden) return;
   const long frame = blockIdx.x;
   const int per = rows_per_frame / TR_CHUNKS, r0 = blockIdx.z * per;
-  float ssh = 0.f, ssc = 0.f;
+  float4v ssh = {0.f, 0.f, 0.f, 0.f}, ssc = {0.f, 0.f, 0.f, 0.f};
   for (int r = r0; r < r0 + per; ++r) {
     const long row = frame * rows_per_frame + r;
-    const float d = dm[row * hidden + c];
+    const float4v d = *reinterpret_cast<const float4v*>(dm + row * hidden + c);
+    const float4v xv = *reinterpret_cast<const float4v*>(x + row * hidden + c);
+    const float mean = stats[2 * row], rstd = stats[2 * row + 1];
     ssh += d;
-    ssc += d * (x[row * hidden + c] - stats[2 * row]) * stats[2 * row + 1];
+    ssc += d * ((xv - mean) * rstd);
   }
-  atomicAdd(dmod + frame * ldt + off + c, ssh);
-  atomicAdd(dmod + frame * ldt + off + hidden + c, ssc);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    atomicAdd(dmod + frame * ldt + off + c + j, ssh[j]);
+    atomicAdd(dmod + frame * ldt + off + hidden + c + j, ssc[j]);
+  }
 }
 
 // (dq, dk, dv) [B][heads][ntok][dstride] -> dqkv [rows][3*heads*d] bf16 in the Linear's column order (q | k | v, head-major);
@@ -216,14 +229,20 @@ __global__ void qkv_grad_pack_kernel(const bf16* __restrict__ dq, const bf16* __
   *reinterpret_cast<bf16x8*>(out + row * (long)(3 * cdim) + col) = g;
 }
 
-// out[c] += sum_rows src[row][c]   (bf16 source; 128 rows per workgroup)
+// out[c] += sum_rows src[row][c]   (bf16 source, n % 8 == 0; a thread owns 8 columns, a workgroup 64 rows)
 __global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16* __restrict__ src, float* __restrict__ out, long rows, int n, long ld) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
+  const int c = (blockIdx.x * 256 + threadIdx.x) * 8;  // n need not be a multiple of 8 as long as the source row is (ld >= c + 8)
   if (c >= n) return;
-  const long r0 = (long)blockIdx.y * 128;
-  float acc = 0.f;
-  for (long r = r0; r < r0 + 128 && r < rows; ++r) acc += bf2f(src[r * ld + c]);
-  atomicAdd(out + c, acc);
+  const long r0 = (long)blockIdx.y * 64;
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (long r = r0; r < r0 + 64 && r < rows; ++r) {
+    const bf16x8 v = *reinterpret_cast<const bf16x8*>(src + r * ld + c);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] += bf2f(v[j]);
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+    if (c + j < n) atomicAdd(out + c + j, acc[j]);
 }
 
 // gradient of the unpatchified output [BT][C][H][W] gathered per token: dyp [rows][64] bf16 (columns >= oc stay zero) and its
@@ -359,10 +378,27 @@ int tr_transpose(const bf16* src, bf16* dst, int R, int C, hipStream_t s) {  // 
 }
 
 // out[M][N] fp32 = A[M][K] W[N][K]^T (+ resid)
-int tr_gemm_f32(const bf16* A, long lda, const bf16* W, int M, int N, int K, float* out, long ldo, const float* resid, hipStream_t s) {
+int tr_gemm_f32(const bf16* A, long lda, const bf16* W, int M, int N, int K, float* out, long ldo, const float* resid, hipStream_t s,
+                int variant = GEMM_AUTO, int ksplit = 1) {
+  while (ksplit > 1 && K / 64 < 4 * ksplit) ksplit /= 2;
   GemmArgs g;
-  g.A = A; g.lda = lda; g.W = W; g.M = M; g.N = N; g.K = K; g.out_f32 = out; g.ldo = ldo; g.resid = resid;
-  return launch_gemm(A_DENSE, E_F32, GEMM_AUTO, g, s);
+  g.A = A; g.lda = lda; g.W = W; g.M = M; g.N = N; g.K = K; g.out_f32 = out; g.ldo = ldo; g.resid = resid; g.ksplit = ksplit;
+  return launch_gemm(A_DENSE, E_F32, variant, g, s);
+}
+// Weight gradient out[M][N] = A[M][K] W[N][K]^T with M, N = feature counts (multiples of 128 only) and K = tokens (long).
+// A/B (same box, DiT/XL, 8 videos): splitting K over workgroups with atomic accumulation (DFOT_TRAIN_WGRAD_WGS = target number of
+// workgroups) fills the chip for the 81-tile out-projection gradient but the 8 M fp32 atomics per GEMM cost more than that gains:
+// 42.3 ms/step at 512 workgroups, 46.0 at 768, 48.8 at 1024 vs 40.9 unsplit -- off by default.
+int tr_wgrad(const bf16* A, const bf16* W, int M, int N, int K, float* out, hipStream_t s) {
+  static const int variant = tuning_flag("TRAIN_WGRAD_VARIANT", GEMM_AUTO);
+  static const int target = tuning_flag("TRAIN_WGRAD_WGS", 0);
+  int split = 1;
+  if (target > 0) {
+    const long tiles = (long)(M / 128) * ((N + 127) / 128);
+    split = (int)((target + tiles / 2) / tiles);
+    split = split < 1 ? 1 : (split > 16 ? 16 : split);
+  }
+  return tr_gemm_f32(A, K, W, M, N, K, out, N, nullptr, s, split > 1 && variant == GEMM_AUTO ? (int)GEMM_DMA_128 : variant, split);
 }
 int tr_gemm_bf16(const bf16* A, long lda, const bf16* W, int M, int N, int K, const float* bias, bf16* out, long ldo, hipStream_t s) {
   GemmArgs g;
@@ -604,13 +640,15 @@ int dfot_dit_train_forward(dfot_dit_train_t h, const float* x, const int32_t* no
     g.A = h->semb; g.lda = hd; g.W = h->w_mod; g.M = h->fp; g.N = (int)h->ldt; g.K = hd; g.bias = h->b_mod; g.out_f32 = h->mod_table; g.ldo = h->ldt;
     if ((rc = launch_gemm(A_DENSE, E_F32, GEMM_AUTO, g, s))) return rc;
   }
+  // the residual stream lives in the blocks' own x_in buffers (each is what the backward of that block needs): no copies
   hipLaunchKernelGGL(patch_embed_kernel, dim3(cdiv(rows, PE_TOK)), dim3(256), PE_TOK * h->kpatch * sizeof(float), s, x, p + h->o_pe_w,
-                     p + h->o_pe_b, (const float*)nullptr, h->X, c.in_channels, c.height, c.width, c.patch_size, hd, rows);
+                     p + h->o_pe_b, (const float*)nullptr, h->blocks[0].x_in, c.in_channels, c.height, c.width, c.patch_size, hd, rows);
   DFOT_CHECK_HIP(hipGetLastError());
   const float qscale = 1.4426950408889634f / sqrtf((float)h->d);
-  for (TrainBlock& b : h->blocks) {
-    DFOT_CHECK_HIP(hipMemcpyAsync(b.x_in, h->X, (size_t)rows * hd * sizeof(float), hipMemcpyDeviceToDevice, s));
-    if ((rc = launch_ln_mod(h->X, b.m, h->mod_table, h->idx, h->ldt, b.mod, hd, P, (int)rows, c.eps, frames - 1, s))) return rc;
+  for (size_t bi = 0; bi < h->blocks.size(); ++bi) {
+    TrainBlock& b = h->blocks[bi];
+    float* next = bi + 1 < h->blocks.size() ? h->blocks[bi + 1].x_in : h->x_fin;
+    if ((rc = launch_ln_mod(b.x_in, h->X, b.m, h->mod_table, h->idx, h->ldt, b.mod, hd, P, (int)rows, c.eps, frames - 1, s))) return rc;
     {
       GemmArgs g;
       g.A = b.m; g.lda = hd; g.W = b.w_qkv; g.M = (int)rows; g.N = 3 * hd; g.K = hd; g.bias = p + b.o_qkv_b;
@@ -619,12 +657,11 @@ int dfot_dit_train_forward(dfot_dit_train_t h, const float* x, const int32_t* no
     }
     if ((rc = launch_attention_padded(b.q, b.k, b.v, b.o, hd, batch, c.num_heads, n, h->d, s, b.lse))) return rc;
     if ((rc = tr_gemm_bf16(b.o, hd, b.w_proj, (int)rows, hd, hd, p + b.o_proj_b, b.a, hd, s))) return rc;
-    hipLaunchKernelGGL(gate_combine_kernel, dim3(cdiv(rows * hd / 4, 256)), dim3(256), 0, s, h->X, b.a, h->mod_table, h->ldt, b.mod + 2 * hd, hd, P,
-                       rows * hd / 4);
+    hipLaunchKernelGGL(gate_combine_kernel, dim3(cdiv(rows * hd / 4, 256)), dim3(256), 0, s, h->X, next, b.a, h->mod_table, h->ldt, b.mod + 2 * hd, hd,
+                       P, rows * hd / 4);
     DFOT_CHECK_HIP(hipGetLastError());
   }
-  DFOT_CHECK_HIP(hipMemcpyAsync(h->x_fin, h->X, (size_t)rows * hd * sizeof(float), hipMemcpyDeviceToDevice, s));
-  return launch_final_layer(h->X, h->mod_table, h->idx, h->ldt, h->mod_final, p + h->o_fin_w, p + h->o_fin_b, out, hd, P, (int)rows, c.eps,
+  return launch_final_layer(h->x_fin, h->mod_table, h->idx, h->ldt, h->mod_final, p + h->o_fin_w, p + h->o_fin_b, out, hd, P, (int)rows, c.eps,
                             frames - 1, c.in_channels, c.height, c.width, c.patch_size, s);
 }
 
@@ -642,18 +679,17 @@ int dfot_dit_train_backward(dfot_dit_train_t h, const float* d_out, void* stream
   int rc = 0;
   DFOT_CHECK_HIP(hipMemsetAsync(G, 0, (size_t)h->total * sizeof(float), s));
   DFOT_CHECK_HIP(hipMemsetAsync(h->dmod, 0, (size_t)fp * h->ldt * sizeof(float), s));
-  const dim3 fgrid(frames, cdiv(hd, 256), TR_CHUNKS);
+  const dim3 fgrid(frames, cdiv(hd / 4, 256), TR_CHUNKS);
 
   // ---- final layer: out = Linear(mfin), mfin = LN(x_fin)(1 + scale) + shift ----
   DFOT_CHECK_HIP(hipMemsetAsync(h->dyp, 0, (size_t)rows * 64 * sizeof(bf16), s));
   DFOT_CHECK_HIP(hipMemsetAsync(h->dyt, 0, (size_t)256 * rows * sizeof(bf16), s));
   hipLaunchKernelGGL(final_gather_kernel, dim3(cdiv(rows * h->oc, 256)), dim3(256), 0, s, d_out, h->dyp, h->dyt, rows, c.in_channels, c.height,
                      c.width, c.patch_size);
-  hipLaunchKernelGGL(colsum_bf16_kernel, dim3(1, cdiv(rows, 128)), dim3(256), 0, s, h->dyp, G + h->o_fin_b, rows, h->oc, 64L);
+  hipLaunchKernelGGL(colsum_bf16_kernel, dim3(1, cdiv(rows, 64)), dim3(256), 0, s, h->dyp, G + h->o_fin_b, rows, h->oc, 64L);
   DFOT_CHECK_HIP(hipGetLastError());
   float *dY = h->dX, *dN = h->dX2;  // gradient of the current block's output / scratch for the next one
-  DFOT_CHECK_HIP(hipMemcpyAsync(dN, h->x_fin, (size_t)rows * hd * sizeof(float), hipMemcpyDeviceToDevice, s));
-  if ((rc = launch_ln_mod(dN, h->mfin, h->mod_table, h->idx, h->ldt, h->mod_final, hd, P, (int)rows, c.eps, frames - 1, s))) return rc;
+  if ((rc = launch_ln_mod(h->x_fin, dN, h->mfin, h->mod_table, h->idx, h->ldt, h->mod_final, hd, P, (int)rows, c.eps, frames - 1, s))) return rc;
   if ((rc = tr_transpose(h->mfin, h->T2, (int)rows, hd, s))) return rc;                                   // mfin^T [hd][rows]
   if ((rc = tr_gemm_f32(h->dyt, rows, h->T2, 256, hd, (int)rows, h->dwf, hd, nullptr, s))) return rc;       // dWf in the first oc rows
   DFOT_CHECK_HIP(hipMemcpyAsync(G + h->o_fin_w, h->dwf, (size_t)h->oc * hd * sizeof(float), hipMemcpyDeviceToDevice, s));
@@ -675,16 +711,16 @@ int dfot_dit_train_backward(dfot_dit_train_t h, const float* d_out, void* stream
     DFOT_CHECK_HIP(hipGetLastError());
     if ((rc = tr_gemm_bf16(h->da, hd, b.w_projT, (int)rows, hd, hd, nullptr, h->dO, hd, s))) return rc;      // dO = da Wp
     if ((rc = tr_transpose(h->da, h->T1, (int)rows, hd, s)) || (rc = tr_transpose(b.o, h->T2, (int)rows, hd, s))) return rc;
-    if ((rc = tr_gemm_f32(h->T1, rows, h->T2, hd, hd, (int)rows, G + b.o_proj_w, hd, nullptr, s))) return rc;  // dWp = da^T o
+    if ((rc = tr_wgrad(h->T1, h->T2, hd, hd, (int)rows, G + b.o_proj_w, s))) return rc;  // dWp = da^T o
     if ((rc = launch_attention_bwd_prepare(b.o, h->dO, hd, h->dop, h->delta, batch, c.num_heads, n, h->d, s))) return rc;
     if ((rc = launch_attention_bwd(b.q, b.k, b.v, h->dop, b.lse, h->delta, h->dq, h->dk, h->dv, batch, c.num_heads, n, h->d, s))) return rc;
     hipLaunchKernelGGL(qkv_grad_pack_kernel, dim3(cdiv(rows * (3 * hd / 8), 256)), dim3(256), 0, s, h->dq, h->dk, h->dv, h->rope_cs, h->dqkv, rows, n,
                        c.num_heads, h->d, h->dstride);
-    hipLaunchKernelGGL(colsum_bf16_kernel, dim3(cdiv(3 * hd, 256), cdiv(rows, 128)), dim3(256), 0, s, h->dqkv, G + b.o_qkv_b, rows, 3 * hd, (long)3 * hd);
+    hipLaunchKernelGGL(colsum_bf16_kernel, dim3(cdiv(3 * hd / 8, 256), cdiv(rows, 64)), dim3(256), 0, s, h->dqkv, G + b.o_qkv_b, rows, 3 * hd, (long)3 * hd);
     DFOT_CHECK_HIP(hipGetLastError());
     if ((rc = tr_gemm_f32(h->dqkv, 3 * hd, b.w_qkvT, (int)rows, hd, 3 * hd, dY, hd, dY, s))) return rc;       // dm = dY + dqkv Wqkv (in place)
     if ((rc = tr_transpose(h->dqkv, h->T1, (int)rows, 3 * hd, s)) || (rc = tr_transpose(b.m, h->T2, (int)rows, hd, s))) return rc;
-    if ((rc = tr_gemm_f32(h->T1, rows, h->T2, 3 * hd, hd, (int)rows, G + b.o_qkv_w, hd, nullptr, s))) return rc;  // dWqkv = dqkv^T m
+    if ((rc = tr_wgrad(h->T1, h->T2, 3 * hd, hd, (int)rows, G + b.o_qkv_w, s))) return rc;  // dWqkv = dqkv^T m
     if ((rc = ln_bwd(b.x_in, b.mod))) return rc;
   }
 
@@ -709,7 +745,8 @@ int dfot_dit_train_backward(dfot_dit_train_t h, const float* d_out, void* stream
   for (TrainBlock& b : h->blocks)
     if ((rc = scatter(b.mod, 3 * hd, b.o_mod_w, b.o_mod_b))) return rc;
   if ((rc = scatter(h->mod_final, 2 * hd, h->o_fmod_w, h->o_fmod_b))) return rc;
-  if ((rc = tr_gemm_f32(h->dmod_bf, h->ldt, h->w_modT, fp, hd, (int)h->ldt, h->dsemb, hd, nullptr, s))) return rc;  // d SiLU(c)
+  DFOT_CHECK_HIP(hipMemsetAsync(h->dsemb, 0, (size_t)fp * hd * sizeof(float), s));
+  if ((rc = tr_gemm_f32(h->dmod_bf, h->ldt, h->w_modT, fp, hd, (int)h->ldt, h->dsemb, hd, nullptr, s, GEMM_DMA_128, 16))) return rc;  // d SiLU(c)
 
   // ---- noise-level embedding MLP (frames x hidden, fp32) ----
   const long fh = (long)frames * hd;

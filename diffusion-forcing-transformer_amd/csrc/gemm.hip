@@ -69,10 +69,19 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int tile_inde
   char* smem = smem_all + kgroup * (NST * STAGE_BYTES);
   const int wm = wave / WN, wn = wave % WN;
   const int tiles_n = (g.N + BN_T - 1) / BN_T;
-  const int bid = xcd_remap(tile_index, tile_count, g.xcd);
+  // split-K over workgroups (EPI == E_F32 only): consecutive workgroups share a tile and take consecutive K slices
+  const int ksplit = (EPI == E_F32 && AMODE == A_DENSE && g.ksplit > 1) ? g.ksplit : 1;
+  const int kslice = ksplit > 1 ? tile_index % ksplit : 0;
+  const int bid = ksplit > 1 ? xcd_remap(tile_index / ksplit, tile_count / ksplit, g.xcd) : xcd_remap(tile_index, tile_count, g.xcd);
   const int tn = bid % tiles_n, tm = bid / tiles_n;
   const int m0 = tm * BM_T, n0 = tn * BN_T;
-  const int nk = g.K / BKT;
+  int nk = g.K / BKT;
+  long kbeg = 0;  // first element of this workgroup's K range
+  if (ksplit > 1) {
+    const int per = nk / ksplit, rem = nk % ksplit;
+    kbeg = (long)(kslice * per + (kslice < rem ? kslice : rem)) * BKT;
+    nk = per + (kslice < rem ? 1 : 0);
+  }
   // bank swizzle of the 16-byte chunk position inside a row (conflict-free ds_read_b128 fragment reads, MI355X_MICROARCH.md
   // "LDS": lane groups of 16): 128-B rows: chunk ^ ((row >> 1) & 7); 64-B rows (4 rows per 256-B bank line): chunk ^ ((row >> 2) & 2)
   auto swz = [](int r) { return BKT == 64 ? ((r >> 1) & 7) : ((r >> 2) & 2); };
@@ -91,7 +100,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int tile_inde
     a_chunk[i] = c;
     const long m = (long)m0 + r;
     if constexpr (AMODE == A_DENSE) {
-      a_src[i] = g.A + m * g.lda + c * 8;
+      a_src[i] = g.A + m * g.lda + c * 8 + kbeg;
       a_y[i] = a_x[i] = 0;
     } else {
       const unsigned mu = (unsigned)m;  // 32-bit divisions (M < 2^31)
@@ -108,7 +117,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int tile_inde
     const int c = ppos ^ swz(r);
     int n = n0 + r;
     n = n < g.N ? n : g.N - 1;
-    w_src[i] = g.W + (long)n * g.K + c * 8;
+    w_src[i] = g.W + (long)n * g.K + c * 8 + kbeg;
   }
 
   // conv3x3: k-tile kt covers channels [cv_c0, cv_c0 + BKT) of tap (cv_dy, cv_dx).  issue() is called with consecutive k-tiles
@@ -358,7 +367,12 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int tile_inde
             v *= *reinterpret_cast<const f32x4*>(g.gate + gr * g.ldg + col);
           }
           if (has_res) v += *reinterpret_cast<const f32x4*>(g.resid + off);
-          *reinterpret_cast<f32x4*>(g.out_f32 + off) = v;
+          if (ksplit > 1) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) atomicAdd(g.out_f32 + off + j, v[j]);
+          } else {
+            *reinterpret_cast<f32x4*>(g.out_f32 + off) = v;
+          }
           gsum += v[0] + v[1] + v[2] + v[3];
           gsq += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
         }
@@ -588,7 +602,8 @@ static int launch_t(const GemmArgs& g, hipStream_t stream) {
   constexpr int ep_lds = (nthreads / 64) * 16 * EP_LD * 4 + 2 * (nthreads / 64) * 16 * 4 +
                          (KS == 2 ? (nthreads / 128) * (WTM / 16) * 16 * 64 * 4 : 0);
   constexpr int lds = stage_lds > ep_lds ? stage_lds : ep_lds;
-  const int tiles = (g.M / BM_T) * ((g.N + BN_T - 1) / BN_T);
+  const int ksplit = (EPI == E_F32 && AMODE == A_DENSE && g.ksplit > 1) ? g.ksplit : 1;
+  const int tiles = (g.M / BM_T) * ((g.N + BN_T - 1) / BN_T) * ksplit;
   static const int xcd_flag = tuning_flag("GEMM_XCD", 1);
   static const int persist_flag = tuning_flag("GEMM_PERSIST", 1);  // A/B: +0.6 % RE10K, +2.2 % bash/k600 model
   GemmArgs ga = g;
@@ -596,7 +611,7 @@ static int launch_t(const GemmArgs& g, hipStream_t stream) {
   if (persist_flag) ga.persist = 1;
   constexpr bool kPersistOK = KS == 1 && nthreads <= 768;
   if constexpr (kPersistOK) {
-    if (ga.persist > 0) {
+    if (ga.persist > 0 && ksplit == 1) {
       const int resident = 256 * (lds <= 80 * 1024 ? 2 : 1);  // workgroups the chip holds at once (LDS-limited)
       if (tiles > resident) {
         auto kp = gemm_kernel_persistent<BM_T, BN_T, WTM, NST, AMODE, EPI, DMA, KS, BKT>;
@@ -721,6 +736,9 @@ int launch_gemm(int amode, int epi, int variant, const GemmArgs& g, hipStream_t 
     DFOT_REQUIRE(epi == E_F32 && g.gate_rows > 0 && g.M % g.gate_rows == 0 && g.ldg % 4 == 0, DFOT_ERR_SHAPE,
                  "gemm: gate needs the fp32 epilogue, gate_rows dividing M and ldg %% 4 == 0");
   }
+  if (g.ksplit > 1)
+    DFOT_REQUIRE(epi == E_F32 && amode == A_DENSE && !g.bias && !g.resid && !g.gate && !g.gn_part && g.K / BK >= 2 * g.ksplit, DFOT_ERR_ARG,
+                 "gemm: split-K over workgroups needs the plain fp32 epilogue (no bias / residual / gate) and K >= %d", 2 * g.ksplit * BK);
   if (g.bias_rows) DFOT_REQUIRE((epi == E_F32 || epi == E_BF16) && g.bias && g.bias_rows > 0, DFOT_ERR_ARG, "gemm: 2-D bias needs a plain epilogue");
   if (g.tr_rows) {
     DFOT_REQUIRE(epi == E_BF16 && !g.bias && !g.act && !g.gn_part && g.tr_rows % 4 == 0 && g.M % g.tr_rows == 0 && amode == A_DENSE,
