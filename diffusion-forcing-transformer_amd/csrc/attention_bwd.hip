@@ -72,9 +72,9 @@ __device__ __forceinline__ void tile_store(char* dst, const bf16x8 (&r)[BwdCfg<D
 // zero): DC (multiple of 16) where the head dim is contracted (S, dP), DW (multiple of 32) where it is the output (dQ, dK, dV)
 template <int D, int DC = D, int DW = D>
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K,
-                                                          const bf16* __restrict__ V, const bf16* __restrict__ dO,
+                                                          const bf16* __restrict__ V, const bf16* __restrict__ dO, long ldo,
                                                           const float* __restrict__ L2, const float* __restrict__ delta,
-                                                          bf16* __restrict__ dQ, int N, float sq) {
+                                                          bf16* __restrict__ dQ, int N, int heads, int d, float sq) {
   using C = BwdCfg<D>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -88,10 +88,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16* __restrict
   const bf16* Vb = V + base;
 
   bf16x8 qf[DC / 16], dof[DC / 16];
+  // dO is read from the compact activation layout [B*N][ldo] (head hd at column hd*d); columns >= d belong to the next head: zero
+  const bf16* dorow = dO + ((long)(bh / heads) * N + q0 + lq) * ldo + (long)(bh % heads) * d;
 #pragma unroll
   for (int ks = 0; ks < DC / 16; ++ks) {
     qf[ks] = *reinterpret_cast<const bf16x8*>(Q + base + (long)(q0 + lq) * D + ks * 16 + lh * 8);
-    dof[ks] = *reinterpret_cast<const bf16x8*>(dO + base + (long)(q0 + lq) * D + ks * 16 + lh * 8);
+    const int col = ks * 16 + lh * 8;
+    const bf16 z = f2bf(0.f);
+    dof[ks] = col < d ? *reinterpret_cast<const bf16x8*>(dorow + col) : bf16x8{z, z, z, z, z, z, z, z};
   }
   const float l2 = L2[(long)bh * N + q0 + lq], dl = delta[(long)bh * N + q0 + lq];
 
@@ -170,9 +174,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16* __restrict
 // ---------------------------------------------------------------------------------------------------------------
 template <int D, int DC = D, int DW = D>
 __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K,
-                                                           const bf16* __restrict__ V, const bf16* __restrict__ dO,
+                                                           const bf16* __restrict__ V, const bf16* __restrict__ dO, long ldo,
                                                            const float* __restrict__ L2, const float* __restrict__ delta,
-                                                           bf16* __restrict__ dK, bf16* __restrict__ dV, int N, float sk_scale) {
+                                                           bf16* __restrict__ dK, bf16* __restrict__ dV, int N, int heads, int d,
+                                                           float sk_scale) {
   using C = BwdCfg<D>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -183,7 +188,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16* __restric
   const long base = (long)bh * N * D;
   const int k0 = (lin % ktiles) * 128 + wave * 32;
   const bf16* Qb = Q + base;
-  const bf16* Ob = dO + base;
+  const bf16* Ob = dO + (long)(bh / heads) * N * ldo + (long)(bh % heads) * d;  // compact [B*N][ldo], this head's columns
   const float* Lb = L2 + (long)bh * N;
   const float* Db = delta + (long)bh * N;
 
@@ -205,7 +210,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16* __restric
   float rs = 0.f;
   auto load = [&](int t) {
     tile_load<D>(Qb + (long)t * C::TR * D, rq, tid);
-    tile_load<D>(Ob + (long)t * C::TR * D, ro, tid);
+#pragma unroll
+    for (int i = 0; i < C::PER_THREAD; ++i) {  // dO tile from the compact layout; columns >= d (next head / padding) read as zero
+      const int c = tid + i * 256, row = c / C::CH, col = (c % C::CH) * 8;
+      const bf16 z = f2bf(0.f);
+      ro[i] = col < d ? *reinterpret_cast<const bf16x8*>(Ob + (long)(t * C::TR + row) * ldo + col) : bf16x8{z, z, z, z, z, z, z, z};
+    }
     if (tid < 2 * C::TR) rs = tid < C::TR ? Lb[t * C::TR + tid] : Db[t * C::TR + tid - C::TR];
   };
   auto store = [&](int stage) {
@@ -293,46 +303,38 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16* __restric
     }
 }
 
-// dO [B*N][ldo] compact (head hd at column hd*d) -> dOp [B][heads][N][D] bf16 (pad columns zero) and
-// delta[b][hd][n] = sum_c dO * O ; one wave per (row, head)
-__global__ __launch_bounds__(256) void attn_bwd_prepare_kernel(const bf16* __restrict__ O, const bf16* __restrict__ dO, long ldo,
-                                                               bf16* __restrict__ dOp, float* __restrict__ delta, long rows, int N,
-                                                               int heads, int d, int D) {
-  const long wid = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const int lane = threadIdx.x & 63;
-  if (wid >= rows * heads) return;
-  const long row = wid / heads;
-  const int hd = (int)(wid % heads);
-  const long b = row / N, n = row % N;
+// delta[b][hd][n] = sum_c dO[row][hd*d + c] * O[row][hd*d + c]  (compact [B*N][ldo] activations, d % 8 == 0); thread per (row, head)
+__global__ __launch_bounds__(256) void attn_bwd_delta_kernel(const bf16* __restrict__ O, const bf16* __restrict__ dO, long ldo,
+                                                             float* __restrict__ delta, long rows, int N, int heads, int d) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * heads) return;
+  const long row = i / heads;
+  const int hd = (int)(i % heads);
   const bf16* o = O + row * ldo + (long)hd * d;
   const bf16* g = dO + row * ldo + (long)hd * d;
-  bf16* out = dOp + ((b * heads + hd) * N + n) * D;
   float acc = 0.f;
-  for (int c = lane; c < D; c += 64) {
-    const float gv = c < d ? bf2f(g[c]) : 0.f;
-    if (c < d) acc += gv * bf2f(o[c]);
-    out[c] = f2bf(gv);
-  }
+  for (int c = 0; c < d; c += 8) {
+    const bf16x8 ov = *reinterpret_cast<const bf16x8*>(o + c);
+    const bf16x8 gv = *reinterpret_cast<const bf16x8*>(g + c);
 #pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m);
-  if (lane == 0) delta[(b * heads + hd) * N + n] = acc;
+    for (int j = 0; j < 8; ++j) acc += bf2f(ov[j]) * bf2f(gv[j]);
+  }
+  delta[((row / N) * heads + hd) * N + row % N] = acc;
 }
 
 }  // namespace
 
-int launch_attention_bwd_prepare(const bf16* o, const bf16* d_o, long ldo, bf16* dop, float* delta, int batch, int heads, int n, int d,
-                                 hipStream_t s) {
-  const int D = attention_dstride(d);
+int launch_attention_bwd_delta(const bf16* o, const bf16* d_o, long ldo, float* delta, int batch, int heads, int n, int d, hipStream_t s) {
+  DFOT_REQUIRE(d % 8 == 0 && ldo % 8 == 0, DFOT_ERR_SHAPE, "attention_bwd: head dim %d and row stride %ld must be multiples of 8", d, ldo);
   const long rows = (long)batch * n;
-  hipLaunchKernelGGL(attn_bwd_prepare_kernel, dim3(cdiv(rows * heads * 64, 256)), dim3(256), 0, s, o, d_o, ldo, dop, delta, rows, n,
-                     heads, d, D);
+  hipLaunchKernelGGL(attn_bwd_delta_kernel, dim3(cdiv(rows * heads, 256)), dim3(256), 0, s, o, d_o, ldo, delta, rows, n, heads, d);
   DFOT_CHECK_HIP(hipGetLastError());
   return DFOT_OK;
 }
 
 template <int D, int DC = D, int DW = D>
-static int launch_bwd_t(const bf16* q, const bf16* k, const bf16* v, const bf16* dop, const float* l2, const float* delta, bf16* dq,
-                        bf16* dk, bf16* dv, int batch, int heads, int n, float sq, float sk, hipStream_t s) {
+static int launch_bwd_t(const bf16* q, const bf16* k, const bf16* v, const bf16* d_o, long ldo, const float* l2, const float* delta, bf16* dq,
+                        bf16* dk, bf16* dv, int batch, int heads, int n, int d, float sq, float sk, hipStream_t s) {
   using C = BwdCfg<D>;
   const int lds1 = 4 * C::TILE, lds2 = 2 * (2 * C::TILE + 2 * C::TR * 4);
   static bool attr_set = false;
@@ -342,25 +344,27 @@ static int launch_bwd_t(const bf16* q, const bf16* k, const bf16* v, const bf16*
     attr_set = true;
   }
   const int grid = (n / 128) * batch * heads;
-  hipLaunchKernelGGL((attn_bwd_dq_kernel<D, DC, DW>), dim3(grid), dim3(256), lds1, s, q, k, v, dop, l2, delta, dq, n, sq);
+  hipLaunchKernelGGL((attn_bwd_dq_kernel<D, DC, DW>), dim3(grid), dim3(256), lds1, s, q, k, v, d_o, ldo, l2, delta, dq, n, heads, d, sq);
   DFOT_CHECK_HIP(hipGetLastError());
-  hipLaunchKernelGGL((attn_bwd_dkv_kernel<D, DC, DW>), dim3(grid), dim3(256), lds2, s, q, k, v, dop, l2, delta, dk, dv, n, sk);
+  hipLaunchKernelGGL((attn_bwd_dkv_kernel<D, DC, DW>), dim3(grid), dim3(256), lds2, s, q, k, v, d_o, ldo, l2, delta, dk, dv, n, heads, d, sk);
   DFOT_CHECK_HIP(hipGetLastError());
   return DFOT_OK;
 }
 
-// q/k/v/dop/dq/dk/dv: [B][heads][N][dstride(d)] bf16 ; l2/delta: [B][heads][N] fp32
-int launch_attention_bwd(const bf16* q, const bf16* k, const bf16* v, const bf16* dop, const float* l2, const float* delta, bf16* dq,
-                         bf16* dk, bf16* dv, int batch, int heads, int n, int d, hipStream_t s) {
-  DFOT_REQUIRE(q && k && v && dop && l2 && delta && dq && dk && dv, DFOT_ERR_ARG, "attention_bwd: null pointer");
-  DFOT_REQUIRE(d > 0 && d <= 128, DFOT_ERR_SHAPE, "attention_bwd: head dim %d must be <= 128", d);
+// q/k/v/dq/dk/dv: [B][heads][N][dstride(d)] bf16 ; d_o: compact [B*N][ldo] ; l2/delta: [B][heads][N] fp32
+int launch_attention_bwd(const bf16* q, const bf16* k, const bf16* v, const bf16* d_o, long ldo, const float* l2, const float* delta,
+                         bf16* dq, bf16* dk, bf16* dv, int batch, int heads, int n, int d, hipStream_t s) {
+  DFOT_REQUIRE(q && k && v && d_o && l2 && delta && dq && dk && dv, DFOT_ERR_ARG, "attention_bwd: null pointer");
+  DFOT_REQUIRE(d > 0 && d <= 128 && d % 8 == 0 && ldo % 8 == 0, DFOT_ERR_SHAPE, "attention_bwd: head dim %d must be a multiple of 8, <= 128", d);
   DFOT_REQUIRE(n > 0 && n % 128 == 0, DFOT_ERR_SHAPE, "attention_bwd: N=%d must be a multiple of 128", n);
   const float sq = 1.0f / sqrtf((float)d), sk = 0.6931471805599453f;
-  if (d <= 32) return launch_bwd_t<64, 32, 32>(q, k, v, dop, l2, delta, dq, dk, dv, batch, heads, n, sq, sk, s);
-  if (d <= 64) return launch_bwd_t<64>(q, k, v, dop, l2, delta, dq, dk, dv, batch, heads, n, sq, sk, s);
-  if (d <= 80) return launch_bwd_t<128, 80, 96>(q, k, v, dop, l2, delta, dq, dk, dv, batch, heads, n, sq, sk, s);
-  if (d <= 96) return launch_bwd_t<128, 96, 96>(q, k, v, dop, l2, delta, dq, dk, dv, batch, heads, n, sq, sk, s);
-  return launch_bwd_t<128>(q, k, v, dop, l2, delta, dq, dk, dv, batch, heads, n, sq, sk, s);
+#define BWD_ARGS q, k, v, d_o, ldo, l2, delta, dq, dk, dv, batch, heads, n, d, sq, sk, s
+  if (d <= 32) return launch_bwd_t<64, 32, 32>(BWD_ARGS);
+  if (d <= 64) return launch_bwd_t<64>(BWD_ARGS);
+  if (d <= 80) return launch_bwd_t<128, 80, 96>(BWD_ARGS);
+  if (d <= 96) return launch_bwd_t<128, 96, 96>(BWD_ARGS);
+  return launch_bwd_t<128>(BWD_ARGS);
+#undef BWD_ARGS
 }
 
 }  // namespace dfot

@@ -1047,19 +1047,16 @@ int dfot_op_attention_bwd(const void* q, const void* k, const void* v, const voi
                           int batch, int heads, int n, int d, void* stream) {
   DFOT_REQUIRE(q && k && v && d_o && o && dq && dk && dv, DFOT_ERR_ARG, "attention_bwd: null argument");
   hipStream_t s = (hipStream_t)stream;
-  const int D = attention_dstride(d);
   const size_t bhn = (size_t)batch * heads * n;
   float *lse = nullptr, *delta = nullptr;
-  bf16* dop = nullptr;
   DFOT_CHECK_HIP(hipMalloc(&lse, bhn * sizeof(float)));
   DFOT_CHECK_HIP(hipMalloc(&delta, bhn * sizeof(float)));
-  DFOT_CHECK_HIP(hipMalloc(&dop, bhn * D * sizeof(bf16)));
   int rc = launch_attention_padded((const bf16*)q, (const bf16*)k, (const bf16*)v, (bf16*)o, ldo, batch, heads, n, d, s, lse);
-  if (!rc) rc = launch_attention_bwd_prepare((const bf16*)o, (const bf16*)d_o, ldo, dop, delta, batch, heads, n, d, s);
-  if (!rc) rc = launch_attention_bwd((const bf16*)q, (const bf16*)k, (const bf16*)v, dop, lse, delta, (bf16*)dq, (bf16*)dk, (bf16*)dv,
-                                     batch, heads, n, d, s);
+  if (!rc) rc = launch_attention_bwd_delta((const bf16*)o, (const bf16*)d_o, ldo, delta, batch, heads, n, d, s);
+  if (!rc) rc = launch_attention_bwd((const bf16*)q, (const bf16*)k, (const bf16*)v, (const bf16*)d_o, ldo, lse, delta, (bf16*)dq, (bf16*)dk,
+                                     (bf16*)dv, batch, heads, n, d, s);
   (void)hipStreamSynchronize(s);
-  (void)hipFree(lse); (void)hipFree(delta); (void)hipFree(dop);
+  (void)hipFree(lse); (void)hipFree(delta);
   return rc;
 }
 

@@ -339,7 +339,7 @@ struct dfot_dit_train_s {
   dfot::bf16* semb = nullptr;
   float *dX = nullptr, *dX2 = nullptr, *stats = nullptr, *delta = nullptr, *dmod = nullptr, *dwmod = nullptr, *dsemb = nullptr, *dwf = nullptr;
   float *dc = nullptr, *da1 = nullptr, *dh1 = nullptr, *dbmod = nullptr;
-  dfot::bf16 *da = nullptr, *dO = nullptr, *dop = nullptr, *dq = nullptr, *dk = nullptr, *dv = nullptr, *dqkv = nullptr, *T1 = nullptr,
+  dfot::bf16 *da = nullptr, *dO = nullptr, *dq = nullptr, *dk = nullptr, *dv = nullptr, *dqkv = nullptr, *T1 = nullptr,
              *T2 = nullptr, *dmod_bf = nullptr, *dmodT = nullptr, *sembT = nullptr, *dyp = nullptr, *dyt = nullptr, *mfin = nullptr;
 };
 
@@ -604,7 +604,7 @@ int dfot_dit_train_reserve(dfot_dit_train_t h, int max_batch) {
   WS(h->dwmod, (size_t)h->ldt * hd); WS(h->dsemb, (size_t)fp * hd); WS(h->dwf, (size_t)256 * hd);
   WS(h->dbmod, (size_t)h->ldt);
   WS(h->dc, (size_t)frames * hd); WS(h->da1, (size_t)frames * hd); WS(h->dh1, (size_t)frames * hd);
-  WS(h->da, rows * hd); WS(h->dO, rows * hd); WS(h->dop, qsz); WS(h->dq, qsz); WS(h->dk, qsz); WS(h->dv, qsz);
+  WS(h->da, rows * hd); WS(h->dO, rows * hd); WS(h->dq, qsz); WS(h->dk, qsz); WS(h->dv, qsz);
   WS(h->dqkv, rows * 3 * hd); WS(h->T1, rows * 3 * hd); WS(h->T2, rows * hd); WS(h->dyp, rows * 64); WS(h->dyt, (size_t)256 * rows);
   WS(h->mfin, rows * hd);
 #undef WS
@@ -712,8 +712,8 @@ int dfot_dit_train_backward(dfot_dit_train_t h, const float* d_out, void* stream
     if ((rc = tr_gemm_bf16(h->da, hd, b.w_projT, (int)rows, hd, hd, nullptr, h->dO, hd, s))) return rc;      // dO = da Wp
     if ((rc = tr_transpose(h->da, h->T1, (int)rows, hd, s)) || (rc = tr_transpose(b.o, h->T2, (int)rows, hd, s))) return rc;
     if ((rc = tr_wgrad(h->T1, h->T2, hd, hd, (int)rows, G + b.o_proj_w, s))) return rc;  // dWp = da^T o
-    if ((rc = launch_attention_bwd_prepare(b.o, h->dO, hd, h->dop, h->delta, batch, c.num_heads, n, h->d, s))) return rc;
-    if ((rc = launch_attention_bwd(b.q, b.k, b.v, h->dop, b.lse, h->delta, h->dq, h->dk, h->dv, batch, c.num_heads, n, h->d, s))) return rc;
+    if ((rc = launch_attention_bwd_delta(b.o, h->dO, hd, h->delta, batch, c.num_heads, n, h->d, s))) return rc;
+    if ((rc = launch_attention_bwd(b.q, b.k, b.v, h->dO, hd, b.lse, h->delta, h->dq, h->dk, h->dv, batch, c.num_heads, n, h->d, s))) return rc;
     hipLaunchKernelGGL(qkv_grad_pack_kernel, dim3(cdiv(rows * (3 * hd / 8), 256)), dim3(256), 0, s, h->dq, h->dk, h->dv, h->rope_cs, h->dqkv, rows, n,
                        c.num_heads, h->d, h->dstride);
     hipLaunchKernelGGL(colsum_bf16_kernel, dim3(cdiv(3 * hd / 8, 256), cdiv(rows, 64)), dim3(256), 0, s, h->dqkv, G + b.o_qkv_b, rows, 3 * hd, (long)3 * hd);

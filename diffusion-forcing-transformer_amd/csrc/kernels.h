@@ -78,11 +78,10 @@ int attention_dstride(int d);
 int launch_attention_padded(const bf16* q, const bf16* k, const bf16* v, bf16* o, long ldo, int batch, int heads, int n, int d,
                             hipStream_t stream, float* lse = nullptr);
 // ---- attention backward (attention_bwd.hip) ----
-// o / d_o compact [B*N][ldo] (head hd at column hd*d) -> dop [B][heads][N][dstride] (pads zero) and delta [B][heads][N]
-int launch_attention_bwd_prepare(const bf16* o, const bf16* d_o, long ldo, bf16* dop, float* delta, int batch, int heads, int n, int d,
-                                 hipStream_t s);
-// q (pre-scaled as in the forward) / k / v / dop / dq / dk / dv: [B][heads][N][dstride]; dq is the gradient of the UNSCALED q
-int launch_attention_bwd(const bf16* q, const bf16* k, const bf16* v, const bf16* dop, const float* l2, const float* delta, bf16* dq,
-                         bf16* dk, bf16* dv, int batch, int heads, int n, int d, hipStream_t s);
+// delta[b][head][n] = sum_c d_o * o over the head's columns; o / d_o compact [B*N][ldo] (head hd at column hd*d), d % 8 == 0
+int launch_attention_bwd_delta(const bf16* o, const bf16* d_o, long ldo, float* delta, int batch, int heads, int n, int d, hipStream_t s);
+// q (pre-scaled as in the forward) / k / v / dq / dk / dv: [B][heads][N][dstride]; d_o compact; dq is the gradient of the UNSCALED q
+int launch_attention_bwd(const bf16* q, const bf16* k, const bf16* v, const bf16* d_o, long ldo, const float* l2, const float* delta,
+                         bf16* dq, bf16* dk, bf16* dv, int batch, int heads, int n, int d, hipStream_t s);
 
 }  // namespace dfot
