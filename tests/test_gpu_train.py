@@ -124,3 +124,66 @@ def test_dit_training_step_matches_torch_adamw():
             assert r < 5e-2, (n, r)
             checked += int(big.sum())
     assert checked > 1000
+
+
+def _ddp_worker(rank, world, port, q):
+    import os
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)  # one GPU on the test box: gloo carries the CUDA gradient buffer
+    try:
+        ocfg, params, tr = _tiny_trainer(depth=2)
+        tr.lr, tr.max_grad_norm = 1e-3, 1.0
+        g = torch.Generator().manual_seed(4)
+        xs = torch.randn(4, 5, 4, 16, 8, generator=g)
+        k = torch.randint(0, 1000, (4, 5), generator=g)
+        noise = torch.randn(4, 5, 4, 16, 8, generator=g)
+        sl = slice(2 * rank, 2 * rank + 2)
+        loss = tr.training_step(xs[sl], k[sl], noise[sl], None, world_size=world)
+        q.put((rank, float(loss.item()), tr.grads.cpu().numpy(), tr.params.cpu().numpy()))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_data_parallel_step_equals_single_process_step():
+    """two ranks with half the batch each (flat-gradient all-reduce, mean) take the same optimizer step as one process with the
+    whole batch: averaged gradients and updated parameters agree"""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=480) for _ in procs), key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+    ocfg, params, tr = _tiny_trainer(depth=2)
+    tr.lr, tr.max_grad_norm = 1e-3, 1.0
+    g = torch.Generator().manual_seed(4)
+    xs = torch.randn(4, 5, 4, 16, 8, generator=g)
+    k = torch.randint(0, 1000, (4, 5), generator=g)
+    noise = torch.randn(4, 5, 4, 16, 8, generator=g)
+    loss = float(tr.training_step(xs, k, noise, None).item())
+    grads, new = tr.grads.cpu().numpy(), tr.params.cpu().numpy()
+    assert np.array_equal(res[0][2], res[1][2]) and np.array_equal(res[0][3], res[1][3])  # replicas stay identical
+    assert abs(0.5 * (res[0][1] + res[1][1]) - loss) < 1e-3 * abs(loss)
+    gr = np.linalg.norm(res[0][2] - grads) / np.linalg.norm(grads)
+    print(f"data-parallel vs single-process gradient rel-L2 {gr:.2e}")
+    assert gr < 2e-2  # bf16 GEMMs over different row groupings
+    big = np.abs(grads) > 1e-2 * np.abs(grads).max()
+    upd, ref = res[0][3] - tr_initial(params, tr), new - tr_initial(params, tr)
+    assert np.linalg.norm(upd[big] - ref[big]) / np.linalg.norm(ref[big]) < 5e-2
+
+
+def tr_initial(params, tr):
+    flat = np.zeros(tr.numel, np.float32)
+    for name, (off, shape) in tr.layout.items():
+        flat[off: off + int(np.prod(shape))] = params[name].numpy().ravel()
+    return flat
