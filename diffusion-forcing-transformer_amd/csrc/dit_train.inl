@@ -21,6 +21,11 @@ struct TrainBlock {
   float* x_in;   // [rows][hd] residual stream entering the block
   bf16 *m, *q, *k, *v, *o, *a;
   float* lse;
+  // MLP branch (spatial_mlp_ratio): m2 = LN(x_mid)(1+scale2)+shift2 ; u = m2 W1^T + b1 ; y = GELU(u) W2^T + b2 ; out = m2 + gate2 y
+  long o_mod2_w = 0, o_mod2_b = 0, o_fc1_w = 0, o_fc1_b = 0, o_fc2_w = 0, o_fc2_b = 0, mod2 = 0;
+  bf16 *w_fc1 = nullptr, *w_fc1T = nullptr, *w_fc2 = nullptr, *w_fc2T = nullptr;
+  float* x_mid = nullptr;
+  bf16 *m2 = nullptr, *u = nullptr, *y = nullptr;
 };
 
 __global__ void tr_features_kernel(const float* __restrict__ freqs, const int* __restrict__ levels, float* __restrict__ feat, int frames,
@@ -49,6 +54,28 @@ __global__ void silu_bwd_kernel(const float* __restrict__ dy, const float* __res
   const float x = h[i], sg = 1.0f / (1.0f + __expf(-x));
   dh[i] = dy[i] * sg * (1.0f + x * (1.0f - sg));
 }
+// GELU (tanh approximation, as the GEMM epilogue of the inference path): h = gelu(u) ; optionally du = dh * gelu'(u) in place of dh
+__global__ void gelu_kernel(const bf16* __restrict__ u, bf16* __restrict__ h, bf16* __restrict__ dh_to_du, long n8) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n8) return;
+  const bf16x8 uv = *reinterpret_cast<const bf16x8*>(u + i * 8);
+  bf16x8 hv, gv;
+  if (dh_to_du) gv = *reinterpret_cast<const bf16x8*>(dh_to_du + i * 8);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float x = bf2f(uv[j]);
+    const float t = 0.7978845608028654f * (x + 0.044715f * x * x * x);
+    const float sg = 1.0f - 1.0f / (1.0f + __expf(2.0f * t));  // 0.5 (1 + tanh t)
+    hv[j] = f2bf(x * sg);
+    if (dh_to_du) {
+      const float dt = 0.7978845608028654f * (1.0f + 3.0f * 0.044715f * x * x);
+      gv[j] = f2bf(bf2f(gv[j]) * (sg + x * 2.0f * sg * (1.0f - sg) * dt));  // d/dx [x s(x)], s = sigmoid(2t): s' = 2 s (1-s) t'
+    }
+  }
+  if (h) *reinterpret_cast<bf16x8*>(h + i * 8) = hv;
+  if (dh_to_du) *reinterpret_cast<bf16x8*>(dh_to_du + i * 8) = gv;
+}
+
 // dW[o][k] = sum_f dy[f][o] x[f][k] ; db[o] = sum_f dy[f][o]   (frames is small: one thread per (o, k))
 __global__ void small_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ dW, float* __restrict__ db,
                                    int frames, int odim, int kdim) {
@@ -323,7 +350,7 @@ struct dfot_dit_train_s {
   float *dX = nullptr, *dX2 = nullptr, *stats = nullptr, *delta = nullptr, *dmod = nullptr, *dwmod = nullptr, *dsemb = nullptr, *dwf = nullptr;
   float *dc = nullptr, *da1 = nullptr, *dh1 = nullptr, *dbmod = nullptr;
   dfot::bf16 *da = nullptr, *dO = nullptr, *dq = nullptr, *dk = nullptr, *dv = nullptr, *dqkv = nullptr, *T1 = nullptr,
-             *T2 = nullptr, *dmod_bf = nullptr, *dmodT = nullptr, *sembT = nullptr, *dyp = nullptr, *dyt = nullptr, *mfin = nullptr;
+             *T2 = nullptr, *dmod_bf = nullptr, *dmodT = nullptr, *sembT = nullptr, *dyp = nullptr, *dyt = nullptr, *mfin = nullptr, *hbuf = nullptr, *dh = nullptr;
 };
 
 namespace dfot {
@@ -407,7 +434,7 @@ int dfot_dit_train_create(const dfot_dit_config* cfg, dfot_dit_train_t* out) {
   DFOT_REQUIRE(cfg && out, DFOT_ERR_ARG, "train_create: null argument");
   const dfot_dit_config& c = *cfg;
   DFOT_REQUIRE(c.variant == 0, DFOT_ERR_ARG, "train_create: only the 'full' DiT3D variant has a training path");
-  DFOT_REQUIRE(c.mlp_hidden == 0, DFOT_ERR_ARG, "train_create: blocks with an MLP branch (spatial_mlp_ratio) have no training path yet");
+  DFOT_REQUIRE(c.mlp_hidden >= 0 && c.mlp_hidden % 128 == 0, DFOT_ERR_ARG, "train_create: MLP width %d must be a multiple of 128", c.mlp_hidden);
   DFOT_REQUIRE(c.hidden_size % 128 == 0 && c.num_heads > 0 && c.hidden_size % c.num_heads == 0, DFOT_ERR_ARG,
                "train_create: hidden_size %d must be a multiple of 128 and of num_heads", c.hidden_size);
   DFOT_REQUIRE((c.hidden_size / c.num_heads) % 8 == 0 && c.hidden_size / c.num_heads <= 128, DFOT_ERR_ARG, "train_create: head dim must be a multiple of 8, <= 128");
@@ -424,7 +451,8 @@ int dfot_dit_train_create(const dfot_dit_config* cfg, dfot_dit_train_t* out) {
   h->dstride = attention_dstride(h->d);
   h->kpatch = c.in_channels * c.patch_size * c.patch_size;
   h->oc = h->kpatch;
-  h->ldt = (long)c.depth * 3 * hd + 2 * hd;
+  const int mh = c.mlp_hidden;
+  h->ldt = (long)c.depth * (mh ? 6 : 3) * hd + 2 * hd;
   if (h->P % TR_CHUNKS != 0) {
     set_error("train_create: %d patches per frame must be a multiple of %d", h->P, TR_CHUNKS);
     delete h;
@@ -451,6 +479,16 @@ int dfot_dit_train_create(const dfot_dit_config* cfg, dfot_dit_train_t* out) {
     b.o_qkv_b = tr_add(h, pre + ".attn.qkv.bias", {3 * hd});
     b.o_proj_w = tr_add(h, pre + ".attn.proj.weight", {hd, hd});
     b.o_proj_b = tr_add(h, pre + ".attn.proj.bias", {hd});
+    if (mh) {
+      b.mod2 = off;
+      off += 3 * hd;
+      b.o_mod2_w = tr_add(h, pre + ".norm2.modulation.1.weight", {3 * hd, hd});
+      b.o_mod2_b = tr_add(h, pre + ".norm2.modulation.1.bias", {3 * hd});
+      b.o_fc1_w = tr_add(h, pre + ".mlp.fc1.weight", {mh, hd});
+      b.o_fc1_b = tr_add(h, pre + ".mlp.fc1.bias", {mh});
+      b.o_fc2_w = tr_add(h, pre + ".mlp.fc2.weight", {hd, mh});
+      b.o_fc2_b = tr_add(h, pre + ".mlp.fc2.bias", {hd});
+    }
   }
   h->mod_final = off;
   h->o_fmod_w = tr_add(h, "dit_base.final_layer.norm_final.modulation.1.weight", {2 * hd, hd});
@@ -465,7 +503,9 @@ int dfot_dit_train_create(const dfot_dit_config* cfg, dfot_dit_train_t* out) {
     return fail(rc);
   for (TrainBlock& b : h->blocks)
     if ((rc = tr_alloc(h, &b.w_qkv, (size_t)3 * hd * hd)) || (rc = tr_alloc(h, &b.w_qkvT, (size_t)3 * hd * hd)) ||
-        (rc = tr_alloc(h, &b.w_proj, (size_t)hd * hd)) || (rc = tr_alloc(h, &b.w_projT, (size_t)hd * hd)))
+        (rc = tr_alloc(h, &b.w_proj, (size_t)hd * hd)) || (rc = tr_alloc(h, &b.w_projT, (size_t)hd * hd)) ||
+        (mh && ((rc = tr_alloc(h, &b.w_fc1, (size_t)mh * hd)) || (rc = tr_alloc(h, &b.w_fc1T, (size_t)mh * hd)) ||
+                (rc = tr_alloc(h, &b.w_fc2, (size_t)mh * hd)) || (rc = tr_alloc(h, &b.w_fc2T, (size_t)mh * hd)))))
       return fail(rc);
   {
     const int half = c.noise_dim / 2;
@@ -541,6 +581,12 @@ int dfot_dit_train_sync_weights(dfot_dit_train_t h, void* stream) {
     if ((rc = launch_f32_to_bf16(p + b.o_qkv_w, b.w_qkv, (long)3 * hd * hd, s)) || (rc = tr_transpose(b.w_qkv, b.w_qkvT, 3 * hd, hd, s)) ||
         (rc = launch_f32_to_bf16(p + b.o_proj_w, b.w_proj, (long)hd * hd, s)) || (rc = tr_transpose(b.w_proj, b.w_projT, hd, hd, s)))
       return rc;
+    if (const int mh = h->cfg.mlp_hidden) {
+      if ((rc = mod(b.o_mod2_w, b.o_mod2_b, b.mod2, 3 * hd))) return rc;
+      if ((rc = launch_f32_to_bf16(p + b.o_fc1_w, b.w_fc1, (long)mh * hd, s)) || (rc = tr_transpose(b.w_fc1, b.w_fc1T, mh, hd, s)) ||
+          (rc = launch_f32_to_bf16(p + b.o_fc2_w, b.w_fc2, (long)mh * hd, s)) || (rc = tr_transpose(b.w_fc2, b.w_fc2T, hd, mh, s)))
+        return rc;
+    }
   }
   if ((rc = mod(h->o_fmod_w, h->o_fmod_b, h->mod_final, 2 * hd))) return rc;
   if ((rc = tr_transpose(h->w_mod, h->w_modT, (int)h->ldt, hd, s))) return rc;
@@ -581,14 +627,17 @@ int dfot_dit_train_reserve(dfot_dit_train_t h, int max_batch) {
   for (TrainBlock& b : h->blocks) {
     WS(b.x_in, rows * hd); WS(b.m, rows * hd); WS(b.q, qsz); WS(b.k, qsz); WS(b.v, qsz); WS(b.o, rows * hd); WS(b.a, rows * hd);
     WS(b.lse, bhn);
+    if (c.mlp_hidden) { WS(b.x_mid, rows * hd); WS(b.m2, rows * hd); WS(b.u, rows * c.mlp_hidden); WS(b.y, rows * hd); }
   }
+  const size_t wide = (size_t)(c.mlp_hidden > 3 * hd ? c.mlp_hidden : 3 * hd);
+  if (c.mlp_hidden) { WS(h->hbuf, rows * c.mlp_hidden); WS(h->dh, rows * c.mlp_hidden); }
   WS(h->dX, rows * hd); WS(h->dX2, rows * hd); WS(h->stats, rows * 2); WS(h->delta, bhn);
   WS(h->dmod, (size_t)fp * h->ldt); WS(h->dmod_bf, (size_t)fp * h->ldt); WS(h->dmodT, (size_t)fp * h->ldt);
   WS(h->dwmod, (size_t)h->ldt * hd); WS(h->dsemb, (size_t)fp * hd); WS(h->dwf, (size_t)256 * hd);
   WS(h->dbmod, (size_t)h->ldt);
   WS(h->dc, (size_t)frames * hd); WS(h->da1, (size_t)frames * hd); WS(h->dh1, (size_t)frames * hd);
   WS(h->da, rows * hd); WS(h->dO, rows * hd); WS(h->dq, qsz); WS(h->dk, qsz); WS(h->dv, qsz);
-  WS(h->dqkv, rows * 3 * hd); WS(h->T1, rows * 3 * hd); WS(h->T2, rows * hd); WS(h->dyp, rows * 64); WS(h->dyt, (size_t)256 * rows);
+  WS(h->dqkv, rows * 3 * hd); WS(h->T1, rows * wide); WS(h->T2, rows * hd); WS(h->dyp, rows * 64); WS(h->dyt, (size_t)256 * rows);
   WS(h->mfin, rows * hd);
 #undef WS
   h->max_batch = max_batch;
@@ -631,6 +680,8 @@ int dfot_dit_train_forward(dfot_dit_train_t h, const float* x, const int32_t* no
   for (size_t bi = 0; bi < h->blocks.size(); ++bi) {
     TrainBlock& b = h->blocks[bi];
     float* next = bi + 1 < h->blocks.size() ? h->blocks[bi + 1].x_in : h->x_fin;
+    const int mh = c.mlp_hidden;
+    float* after_attn = mh ? b.x_mid : next;
     if ((rc = launch_ln_mod(b.x_in, h->X, b.m, h->mod_table, h->idx, h->ldt, b.mod, hd, P, (int)rows, c.eps, frames - 1, s))) return rc;
     {
       GemmArgs g;
@@ -640,9 +691,19 @@ int dfot_dit_train_forward(dfot_dit_train_t h, const float* x, const int32_t* no
     }
     if ((rc = launch_attention_padded(b.q, b.k, b.v, b.o, hd, batch, c.num_heads, n, h->d, s, b.lse))) return rc;
     if ((rc = tr_gemm_bf16(b.o, hd, b.w_proj, (int)rows, hd, hd, p + b.o_proj_b, b.a, hd, s))) return rc;
-    hipLaunchKernelGGL(gate_combine_kernel, dim3(cdiv(rows * hd / 4, 256)), dim3(256), 0, s, h->X, next, b.a, h->mod_table, h->ldt, b.mod + 2 * hd, hd,
-                       P, rows * hd / 4);
+    hipLaunchKernelGGL(gate_combine_kernel, dim3(cdiv(rows * hd / 4, 256)), dim3(256), 0, s, h->X, after_attn, b.a, h->mod_table, h->ldt,
+                       b.mod + 2 * hd, hd, P, rows * hd / 4);
     DFOT_CHECK_HIP(hipGetLastError());
+    if (mh) {
+      if ((rc = launch_ln_mod(b.x_mid, h->X, b.m2, h->mod_table, h->idx, h->ldt, b.mod2, hd, P, (int)rows, c.eps, frames - 1, s))) return rc;
+      if ((rc = tr_gemm_bf16(b.m2, hd, b.w_fc1, (int)rows, mh, hd, p + b.o_fc1_b, b.u, mh, s))) return rc;
+      hipLaunchKernelGGL(gelu_kernel, dim3(cdiv(rows * mh / 8, 256)), dim3(256), 0, s, b.u, h->hbuf, (bf16*)nullptr, rows * mh / 8);
+      DFOT_CHECK_HIP(hipGetLastError());
+      if ((rc = tr_gemm_bf16(h->hbuf, mh, b.w_fc2, (int)rows, hd, mh, p + b.o_fc2_b, b.y, hd, s))) return rc;
+      hipLaunchKernelGGL(gate_combine_kernel, dim3(cdiv(rows * hd / 4, 256)), dim3(256), 0, s, h->X, next, b.y, h->mod_table, h->ldt,
+                         b.mod2 + 2 * hd, hd, P, rows * hd / 4);
+      DFOT_CHECK_HIP(hipGetLastError());
+    }
   }
   return launch_final_layer(h->x_fin, h->mod_table, h->idx, h->ldt, h->mod_final, p + h->o_fin_w, p + h->o_fin_b, out, hd, P, (int)rows, c.eps,
                             frames - 1, c.in_channels, c.height, c.width, c.patch_size, s);
@@ -690,6 +751,21 @@ int dfot_dit_train_backward(dfot_dit_train_t h, const float* d_out, void* stream
   // ---- blocks, last to first ----
   for (int bi = (int)h->blocks.size() - 1; bi >= 0; --bi) {
     TrainBlock& b = h->blocks[bi];
+    if (const int mh = c.mlp_hidden) {  // out = m2 + gate2 * y, y = GELU(m2 W1^T + b1) W2^T + b2
+      hipLaunchKernelGGL(gate_bwd_kernel, fgrid, dim3(256), 0, s, dY, b.y, h->mod_table, h->ldt, b.mod2 + 2 * hd, h->da, h->dmod, G + b.o_fc2_b, hd, P);
+      hipLaunchKernelGGL(gelu_kernel, dim3(cdiv(rows * mh / 8, 256)), dim3(256), 0, s, b.u, h->hbuf, (bf16*)nullptr, rows * mh / 8);  // h again
+      DFOT_CHECK_HIP(hipGetLastError());
+      if ((rc = tr_gemm_bf16(h->da, hd, b.w_fc2T, (int)rows, mh, hd, nullptr, h->dh, mh, s))) return rc;        // dh = dy W2
+      if ((rc = tr_transpose(h->da, h->T2, (int)rows, hd, s)) || (rc = tr_transpose(h->hbuf, h->T1, (int)rows, mh, s))) return rc;
+      if ((rc = tr_wgrad(h->T2, h->T1, hd, mh, (int)rows, G + b.o_fc2_w, s))) return rc;                           // dW2 = dy^T h
+      hipLaunchKernelGGL(gelu_kernel, dim3(cdiv(rows * mh / 8, 256)), dim3(256), 0, s, b.u, (bf16*)nullptr, h->dh, rows * mh / 8);  // du
+      hipLaunchKernelGGL(colsum_bf16_kernel, dim3(cdiv(mh, 256), cdiv(rows, 128)), dim3(256), 0, s, h->dh, G + b.o_fc1_b, rows, mh, (long)mh);
+      DFOT_CHECK_HIP(hipGetLastError());
+      if ((rc = tr_gemm_f32(h->dh, mh, b.w_fc1T, (int)rows, hd, mh, dY, hd, dY, s))) return rc;                    // dm2 = dY + du W1
+      if ((rc = tr_transpose(h->dh, h->T1, (int)rows, mh, s)) || (rc = tr_transpose(b.m2, h->T2, (int)rows, hd, s))) return rc;
+      if ((rc = tr_wgrad(h->T1, h->T2, mh, hd, (int)rows, G + b.o_fc1_w, s))) return rc;                           // dW1 = du^T m2
+      if ((rc = ln_bwd(b.x_mid, b.mod2))) return rc;
+    }
     hipLaunchKernelGGL(gate_bwd_kernel, fgrid, dim3(256), 0, s, dY, b.a, h->mod_table, h->ldt, b.mod + 2 * hd, h->da, h->dmod, G + b.o_proj_b, hd, P);
     DFOT_CHECK_HIP(hipGetLastError());
     if ((rc = tr_gemm_bf16(h->da, hd, b.w_projT, (int)rows, hd, hd, nullptr, h->dO, hd, s))) return rc;      // dO = da Wp
@@ -725,8 +801,10 @@ int dfot_dit_train_backward(dfot_dit_train_t h, const float* d_out, void* stream
     DFOT_CHECK_HIP(hipMemcpyAsync(G + o_b, h->dbmod + col, (size_t)nrow * sizeof(float), hipMemcpyDeviceToDevice, s));
     return DFOT_OK;
   };
-  for (TrainBlock& b : h->blocks)
+  for (TrainBlock& b : h->blocks) {
     if ((rc = scatter(b.mod, 3 * hd, b.o_mod_w, b.o_mod_b))) return rc;
+    if (c.mlp_hidden && (rc = scatter(b.mod2, 3 * hd, b.o_mod2_w, b.o_mod2_b))) return rc;
+  }
   if ((rc = scatter(h->mod_final, 2 * hd, h->o_fmod_w, h->o_fmod_b))) return rc;
   DFOT_CHECK_HIP(hipMemsetAsync(h->dsemb, 0, (size_t)fp * hd * sizeof(float), s));
   if ((rc = tr_gemm_f32(h->dmod_bf, h->ldt, h->w_modT, fp, hd, (int)h->ldt, h->dsemb, hd, nullptr, s, GEMM_DMA_128, 16))) return rc;  // d SiLU(c)

@@ -29,8 +29,6 @@ class DiT3DTrainer:
                  loss_weighting: Optional[Dict] = None):
         if _get(cfg, "variant", "full") != "full" or _get(cfg, "pos_emb_type", "rope_3d") != "rope_3d":
             raise ValueError("DiT3DTrainer builds the 'full' / rope_3d DiT3D")
-        if _get(cfg, "spatial_mlp_ratio", None):
-            raise NotImplementedError("blocks with an MLP branch (spatial_mlp_ratio) have no training path yet")
         self.x_shape = tuple(int(v) for v in x_shape)
         c = capi.DiTConfig()
         c.hidden_size = int(_get(cfg, "hidden_size"))
@@ -40,6 +38,8 @@ class DiT3DTrainer:
         c.in_channels, c.height, c.width = self.x_shape
         c.max_tokens = int(max_tokens)
         c.noise_dim, c.timesteps, c.rope_theta, c.eps, c.variant = 256, int(timesteps), 10000.0, 1e-6, 0
+        ratio = _get(cfg, "spatial_mlp_ratio", None)
+        c.mlp_hidden = int(c.hidden_size * ratio) if ratio else 0
         self._ccfg = c
         self.max_tokens = int(max_tokens)
         self._handle = C.c_void_p()

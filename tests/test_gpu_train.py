@@ -51,26 +51,29 @@ def test_attention_backward(d, heads, n, batch):
         assert r < 2e-2, (name, r)
 
 
-def _tiny_trainer(depth=2, hidden=128, heads=4, seed=3, res=(16, 8), chans=4, tokens=5, patch=1):
+def _tiny_trainer(depth=2, hidden=128, heads=4, seed=3, res=(16, 8), chans=4, tokens=5, patch=1, mlp_ratio=None):
     import dfot_amd
     from oracle import dit as odit
-    ocfg = odit.DiTConfig(hidden_size=hidden, depth=depth, num_heads=heads, patch_size=patch, in_channels=chans, resolution=res, max_tokens=tokens)
+    ocfg = odit.DiTConfig(hidden_size=hidden, depth=depth, num_heads=heads, patch_size=patch, in_channels=chans, resolution=res, max_tokens=tokens,
+                          spatial_mlp_ratio=mlp_ratio)
     params = odit.seeded_params(ocfg, seed)
-    tr = dfot_amd.DiT3DTrainer(dict(variant="full", pos_emb_type="rope_3d", patch_size=patch, hidden_size=hidden, depth=depth, num_heads=heads),
-                               x_shape=(chans, *res), max_tokens=tokens)
+    tr = dfot_amd.DiT3DTrainer(dict(variant="full", pos_emb_type="rope_3d", patch_size=patch, hidden_size=hidden, depth=depth, num_heads=heads,
+                                    spatial_mlp_ratio=mlp_ratio), x_shape=(chans, *res), max_tokens=tokens)
     tr.load_state_dict(params, strict=True)
     return ocfg, params, tr
 
 
-@pytest.mark.parametrize("hidden,heads,depth", [(128, 4, 2), (256, 4, 1)])
-def test_dit_backward_matches_autograd(hidden, heads, depth):
-    """every parameter gradient of sum(out * d_out) vs torch autograd through the fp32 oracle restatement of DiT3D.forward"""
+@pytest.mark.parametrize("hidden,heads,depth,mlp,patch,res", [(128, 4, 2, None, 1, (16, 8)), (256, 4, 1, None, 1, (16, 8)),
+                                                              (256, 4, 2, 4.0, 2, (32, 16)), (128, 2, 1, 2.0, 1, (16, 8))])
+def test_dit_backward_matches_autograd(hidden, heads, depth, mlp, patch, res):
+    """every parameter gradient of sum(out * d_out) vs torch autograd through the fp32 oracle restatement of DiT3D.forward
+    (attention-only blocks as README @DiT/XL, and blocks with the MLP branch of spatial_mlp_ratio, patch 2)"""
     from oracle import dit as odit
-    ocfg, params, tr = _tiny_trainer(depth=depth, hidden=hidden, heads=heads)
+    ocfg, params, tr = _tiny_trainer(depth=depth, hidden=hidden, heads=heads, mlp_ratio=mlp, patch=patch, res=res)
     g = torch.Generator().manual_seed(1)
-    x = torch.randn(2, 5, 4, 16, 8, generator=g)
+    x = torch.randn(2, 5, 4, *res, generator=g)
     k = torch.randint(0, 1000, (2, 5), generator=g)
-    d_out = torch.randn(2, 5, 4, 16, 8, generator=g)
+    d_out = torch.randn(2, 5, 4, *res, generator=g)
     out = tr.forward(x, k).cpu()
     tr.backward(d_out)
     grads = {n: t.cpu() for n, t in tr.grad_dict().items()}
