@@ -54,9 +54,9 @@ struct GemmArgs {
   float eps = 1e-6f;
   int xcd = 1;  // XCD-aware tile order
   int persist = 0;  // > 0: persistent workgroups (grid = resident workgroups, each loops over tiles)
-  // E_F32, dense A, no bias / residual / gate: ksplit = S > 1 launches S workgroups per tile, each over one slice of K, which
-  // ADD their partial tile to out_f32 with atomics (out must hold the value to add to, normally zeros).  For weight gradients:
-  // few output tiles, very long K (the token axis)
+  // E_F32, dense A, no gate: ksplit = S > 1 launches S workgroups per tile, each over one slice of K, which ADD their partial
+  // tile to out_f32 with atomics: out must already hold the value to add to -- zeros, or the residual when resid == out_f32
+  // (in-place residual GEMMs); the bias is added by slice 0.  For few output tiles and a long K
   int ksplit = 1;
 };
 

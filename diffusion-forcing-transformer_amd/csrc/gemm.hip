@@ -319,7 +319,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int tile_inde
   const bool live = col < g.N;  // N is a multiple of the lane's column count, so a lane is entirely in or out
   f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = {0.f, 0.f, 0.f, 0.f};
   [[maybe_unused]] const bool bias2d = g.bias_rows > 0;  // bias[(row % bias_rows)][col] (MatrixAttention qkv_bias / proj_bias)
-  if (g.bias && live && !bias2d) {
+  if (g.bias && live && !bias2d && kslice == 0) {  // split-K: slice 0 alone adds the bias
     b0 = *reinterpret_cast<const f32x4*>(g.bias + col);
     if constexpr (EPI != E_F32) b1 = *reinterpret_cast<const f32x4*>(g.bias + col + 4);
   }
@@ -366,8 +366,8 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int tile_inde
             if (g.gate_index) gr = g.gate_index[gr];
             v *= *reinterpret_cast<const f32x4*>(g.gate + gr * g.ldg + col);
           }
-          if (has_res) v += *reinterpret_cast<const f32x4*>(g.resid + off);
-          if (ksplit > 1) {
+          if (has_res && ksplit == 1) v += *reinterpret_cast<const f32x4*>(g.resid + off);
+          if (ksplit > 1) {  // out already holds the residual (resid == out, checked by the launcher) or zeros
 #pragma unroll
             for (int j = 0; j < 4; ++j) atomicAdd(g.out_f32 + off + j, v[j]);
           } else {
@@ -737,8 +737,9 @@ int launch_gemm(int amode, int epi, int variant, const GemmArgs& g, hipStream_t 
                  "gemm: gate needs the fp32 epilogue, gate_rows dividing M and ldg %% 4 == 0");
   }
   if (g.ksplit > 1)
-    DFOT_REQUIRE(epi == E_F32 && amode == A_DENSE && !g.bias && !g.resid && !g.gate && !g.gn_part && g.K / BK >= 2 * g.ksplit, DFOT_ERR_ARG,
-                 "gemm: split-K over workgroups needs the plain fp32 epilogue (no bias / residual / gate) and K >= %d", 2 * g.ksplit * BK);
+    DFOT_REQUIRE(epi == E_F32 && amode == A_DENSE && !g.bias_rows && (!g.resid || g.resid == g.out_f32) && !g.gate && !g.gn_part &&
+                     g.K / BK >= 2 * g.ksplit, DFOT_ERR_ARG,
+                 "gemm: split-K over workgroups needs the fp32 epilogue with an in-place residual (or none), no gate, and K >= %d", 2 * g.ksplit * BK);
   if (g.bias_rows) DFOT_REQUIRE((epi == E_F32 || epi == E_BF16) && g.bias && g.bias_rows > 0, DFOT_ERR_ARG, "gemm: 2-D bias needs a plain epilogue");
   if (g.tr_rows) {
     DFOT_REQUIRE(epi == E_BF16 && !g.bias && !g.act && !g.gn_part && g.tr_rows % 4 == 0 && g.M % g.tr_rows == 0 && amode == A_DENSE,

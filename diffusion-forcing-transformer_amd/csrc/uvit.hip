@@ -407,6 +407,9 @@ static int run_tr_block(dfot_uvit_s* h, const TrW& w, int lvl, int batch, hipStr
   GemmArgs o;
   o.A = h->cat; o.lda = 5 * c; o.W = w.w_out; o.M = m; o.N = c; o.K = 5 * c; o.bias = w.b_out; o.out_f32 = x; o.resid = x;
   o.ldo = c;
+  // A/B: K split over workgroups where the out-projection has fewer tiles than CUs (level 3: 96 tiles of 256x192)
+  static const int l3_split = tuning_flag("UVIT_OUT_KSPLIT", 1);
+  if (l3_split > 1 && (long)(m / 256) * ((c + 191) / 192) < 200) o.ksplit = l3_split;
   return launch_gemm(A_DENSE, E_F32, h->gemm_variant, o, s);
 }
 
