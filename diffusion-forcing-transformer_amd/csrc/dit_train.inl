@@ -1,4 +1,5 @@
-// Training path of the DiT3D backbone ("full" variant, rope_3d, attention-only blocks: the README @DiT/XL K600 model):
+// Training path of the DiT backbones: DiT3D ("full", rope_3d: the README @DiT/XL K600 model, with or without the MLP branch) and
+// DifferenceDiT3D (factorized matrix attention, the bash/k600 model):
 // forward with saved activations, hand-written backward, gradients in one flat fp32 buffer (reference parameter order).
 // Included at the end of dit.hip (same translation unit: shares its kernels).
 //
@@ -14,18 +15,25 @@ namespace dfot {
 namespace {
 
 struct TrainBlock {
-  long o_mod_w, o_mod_b, o_qkv_w, o_qkv_b, o_proj_w, o_proj_b;  // offsets into the flat parameter / gradient buffers
-  long mod;                                                     // column of this block's (shift|scale|gate) in the table
-  bf16 *w_qkv, *w_qkvT, *w_proj, *w_projT;                      // bf16 compute copies: [out][in] and [in][out]
+  bool matrix = false;  // false: DiTBlock (token attention); true: MatrixDiTBlock (every frame is one token, factorized projections)
+  int mh = 0;           // width of the block's MLP branch (0: none)
+  long o_mod_w = 0, o_mod_b = 0, o_qkv_w = 0, o_qkv_b = 0, o_proj_w = 0, o_proj_b = 0;  // offsets into the flat parameter / gradient buffers
+  long mod = 0;                                                 // column of this block's (shift|scale|gate) in the table
+  bf16 *w_qkv = nullptr, *w_qkvT = nullptr, *w_proj = nullptr, *w_projT = nullptr;  // bf16 compute copies: [out][in] and [in][out]
   // saved activations
-  float* x_in;   // [rows][hd] residual stream entering the block
-  bf16 *m, *q, *k, *v, *o, *a;
-  float* lse;
-  // MLP branch (spatial_mlp_ratio): m2 = LN(x_mid)(1+scale2)+shift2 ; u = m2 W1^T + b1 ; y = GELU(u) W2^T + b2 ; out = m2 + gate2 y
+  float* x_in = nullptr;   // [rows][hd] residual stream entering the block
+  bf16 *m = nullptr, *q = nullptr, *k = nullptr, *v = nullptr, *o = nullptr, *a = nullptr;
+  float* lse = nullptr;
+  // MLP branch: m2 = LN(x_mid)(1+scale2)+shift2 ; u = m2 W1^T + b1 ; y = GELU(u) W2^T + b2 ; out = m2 + gate2 y
   long o_mod2_w = 0, o_mod2_b = 0, o_fc1_w = 0, o_fc1_b = 0, o_fc2_w = 0, o_fc2_b = 0, mod2 = 0;
   bf16 *w_fc1 = nullptr, *w_fc1T = nullptr, *w_fc2 = nullptr, *w_fc2T = nullptr;
   float* x_mid = nullptr;
   bf16 *m2 = nullptr, *u = nullptr, *y = nullptr;
+  // MatrixDiTBlock: qkv = U^T m V + bias[E][3h] per frame, o = attention over the frames, a = U'^T o V' + bias'[P][h]
+  // parameters are stored (in, out): qkv_u [P][E], qkv_v [h][3h], proj_u [E][P], proj_v [h][h]
+  long o_qkv_u = 0, o_qkv_v = 0, o_qkv_bias = -1, o_proj_u = 0, o_proj_v = 0, o_proj_bias = -1;
+  bf16 *u_s = nullptr, *u_t = nullptr, *v_s = nullptr, *v_t = nullptr, *pu_s = nullptr, *pu_t = nullptr, *pv_s = nullptr, *pv_t = nullptr;  // as stored / transposed
+  bf16 *w1 = nullptr, *z = nullptr, *o2 = nullptr, *sfac = nullptr;  // U^T m [frames*E][h], qkv [frames*E][3h], attention out, U'^T o [rows][h]
 };
 
 __global__ void tr_features_kernel(const float* __restrict__ freqs, const int* __restrict__ levels, float* __restrict__ feat, int frames,
@@ -312,6 +320,158 @@ __global__ __launch_bounds__(256) void pe_wgrad_kernel(const float* __restrict__
   atomicAdd(db + o, bsum);
 }
 
+// ---- MatrixDiTBlock (factorized matrix attention, variant 1) ------------------------------------------------------------
+// backward of matrix_attn_kernel: z [B*L*E][3h] (q|k|v), d_o [B*L*E][h] -> dz [B*L*E][3h].  One workgroup per (video, c, r):
+// pass A: S = scale <q_l, k_l'> and dP = <do_l, v_l'> over the head's hn*hd entries (a wave per pair), softmax, dS = P (dP - sum P dP) scale
+// pass B: dq_l = sum_l' dS[l][l'] k_l', dk_l' = sum_l dS[l][l'] q_l, dv_l' = sum_l P[l][l'] do_l   (operands re-read: L2 hits)
+__global__ __launch_bounds__(256) void matrix_attn_bwd_kernel(const bf16* __restrict__ z, const bf16* __restrict__ d_o, bf16* __restrict__ dz,
+                                                              int L, int E, int h, int cc, int rr, float scale) {
+  __shared__ float sS[32 * 32], sP[32 * 32];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.x / (cc * rr), c = (blockIdx.x / rr) % cc, r = blockIdx.x % rr;
+  const int hn = E / cc, hd = h / rr, ne = hn * hd / 4;
+  const long ldz = 3L * h;
+  auto zoff = [&](int l, int n) { return (((long)b * L + l) * E + c * hn + n) * ldz + r * hd; };
+  auto ooff = [&](int l, int n) { return (((long)b * L + l) * E + c * hn + n) * (long)h + r * hd; };
+  for (int pi = wave; pi < L * L; pi += 4) {
+    const int l = pi / L, l2 = pi % L;
+    float as = 0.f, ap = 0.f;
+    for (int e = lane; e < ne; e += 64) {
+      const int n = (e * 4) / hd, d = (e * 4) % hd;
+      const bf16x4 q4 = *reinterpret_cast<const bf16x4*>(z + zoff(l, n) + d);
+      const bf16x4 k4 = *reinterpret_cast<const bf16x4*>(z + zoff(l2, n) + h + d);
+      const bf16x4 v4 = *reinterpret_cast<const bf16x4*>(z + zoff(l2, n) + 2 * h + d);
+      const bf16x4 g4 = *reinterpret_cast<const bf16x4*>(d_o + ooff(l, n) + d);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        as += bf2f(q4[j]) * bf2f(k4[j]);
+        ap += bf2f(g4[j]) * bf2f(v4[j]);
+      }
+    }
+    as = wave_sum(as);
+    ap = wave_sum(ap);
+    if (lane == 0) {
+      sS[pi] = as * scale;
+      sP[pi] = ap;  // dP for now
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < L) {
+    float* srow = sS + threadIdx.x * L;
+    float* prow = sP + threadIdx.x * L;
+    float mx = srow[0];
+    for (int j = 1; j < L; ++j) mx = fmaxf(mx, srow[j]);
+    float sum = 0.f;
+    for (int j = 0; j < L; ++j) {
+      srow[j] = __expf(srow[j] - mx);
+      sum += srow[j];
+    }
+    const float inv = 1.0f / sum;
+    float dot = 0.f;
+    for (int j = 0; j < L; ++j) {
+      srow[j] *= inv;            // P
+      dot += srow[j] * prow[j];  // sum_j P dP
+    }
+    for (int j = 0; j < L; ++j) {
+      const float pj = srow[j];
+      srow[j] = pj * (prow[j] - dot) * scale;  // sS <- dS (scaled)
+      prow[j] = pj;                            // sP <- P
+    }
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < ne; e += 256) {
+    const int n = (e * 4) / hd, d = (e * 4) % hd;
+    for (int l = 0; l < L; ++l) {  // dq_l
+      float a[4] = {0.f, 0.f, 0.f, 0.f};
+      for (int l2 = 0; l2 < L; ++l2) {
+        const bf16x4 k4 = *reinterpret_cast<const bf16x4*>(z + zoff(l2, n) + h + d);
+        const float w = sS[l * L + l2];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) a[j] += w * bf2f(k4[j]);
+      }
+      bf16x4 o4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o4[j] = f2bf(a[j]);
+      *reinterpret_cast<bf16x4*>(dz + zoff(l, n) + d) = o4;
+    }
+    for (int l2 = 0; l2 < L; ++l2) {  // dk_l2, dv_l2
+      float ak[4] = {0.f, 0.f, 0.f, 0.f}, av[4] = {0.f, 0.f, 0.f, 0.f};
+      for (int l = 0; l < L; ++l) {
+        const bf16x4 q4 = *reinterpret_cast<const bf16x4*>(z + zoff(l, n) + d);
+        const bf16x4 g4 = *reinterpret_cast<const bf16x4*>(d_o + ooff(l, n) + d);
+        const float ws = sS[l * L + l2], wp = sP[l * L + l2];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          ak[j] += ws * bf2f(q4[j]);
+          av[j] += wp * bf2f(g4[j]);
+        }
+      }
+      bf16x4 k4, v4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        k4[j] = f2bf(ak[j]);
+        v4[j] = f2bf(av[j]);
+      }
+      *reinterpret_cast<bf16x4*>(dz + zoff(l2, n) + h + d) = k4;
+      *reinterpret_cast<bf16x4*>(dz + zoff(l2, n) + 2 * h + d) = v4;
+    }
+  }
+}
+
+// out[i] = sum_f src[f][i]  (two-dimensional biases: the sum runs over the frames); n % 4 == 0
+__global__ void frames_sum_bf16_kernel(const bf16* __restrict__ src, float* __restrict__ out, int frames, long n) {
+  const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i >= n) return;
+  float a[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int f = 0; f < frames; ++f) {
+    const bf16x4 v = *reinterpret_cast<const bf16x4*>(src + (long)f * n + i);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) a[j] += bf2f(v[j]);
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) out[i + j] = a[j];
+}
+// src [frames][R][C] -> dst [R][frames][C]  (8 elements per thread, C % 8 == 0)
+__global__ void permute_frames_kernel(const bf16* __restrict__ src, bf16* __restrict__ dst, int frames, int R, int C) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int c8 = C / 8;
+  if (i >= (long)frames * R * c8) return;
+  const int cc = (int)(i % c8);
+  const int rrow = (int)((i / c8) % R);
+  const long f = i / ((long)c8 * R);
+  *reinterpret_cast<bf16x8*>(dst + ((long)rrow * frames + f) * C + cc * 8) = *reinterpret_cast<const bf16x8*>(src + i * 8);
+}
+// y (fp32) += x (bf16)
+__global__ void add_bf16_kernel(float* __restrict__ y, const bf16* __restrict__ x, long n4) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  const bf16x4 v = *reinterpret_cast<const bf16x4*>(x + i * 4);
+  float4v o = *reinterpret_cast<float4v*>(y + i * 4);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) o[j] += bf2f(v[j]);
+  *reinterpret_cast<float4v*>(y + i * 4) = o;
+}
+// DifferenceDiT3D conditioning: c[f] += diff_table[kind(f)] (kind 1 = difference token = even position), semb = bf16(SiLU(c))
+__global__ void add_diff_kernel(float* __restrict__ cemb, const float* __restrict__ diff_table, bf16* __restrict__ semb, int frames, int tokens,
+                                int hidden) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)frames * hidden) return;
+  const int f = (int)(i / hidden), c = (int)(i % hidden);
+  const int kind = ((f % tokens) % 2 == 0) ? 1 : 0;
+  const float v = cemb[i] + diff_table[(long)kind * hidden + c];
+  cemb[i] = v;
+  semb[i] = f2bf(silu_f(v));
+}
+__global__ void diff_grad_kernel(const float* __restrict__ dc, float* __restrict__ dtable, int frames, int tokens, int hidden) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 2 * hidden) return;
+  const int kind = i / hidden, c = i % hidden;
+  float acc = 0.f;
+  for (int f = 0; f < frames; ++f)
+    if ((((f % tokens) % 2 == 0) ? 1 : 0) == kind) acc += dc[(long)f * hidden + c];
+  dtable[i] = acc;
+}
+
 int launch_ln_bwd_rows(const float* dm, const float* x, const float* table, long ldt, long off, float* dx, float* stats, int hidden,
                        int rows_per_frame, int rows, float eps, hipStream_t s) {
 #define CALL(V, C) \
@@ -332,14 +492,14 @@ struct dfot_dit_train_s {
   std::vector<dfot::DitParam> params;   // name / shape (load unused)
   std::vector<long> offsets;
   float *params_f32 = nullptr, *grads = nullptr;  // attached flat buffers (owned by the caller)
-  long o_t_w1 = 0, o_t_b1 = 0, o_t_w2 = 0, o_t_b2 = 0, o_pe_w = 0, o_pe_b = 0, o_fmod_w = 0, o_fmod_b = 0, o_fin_w = 0, o_fin_b = 0;
+  long o_t_w1 = 0, o_t_b1 = 0, o_t_w2 = 0, o_t_b2 = 0, o_pe_w = 0, o_pe_b = 0, o_diff = -1, o_fmod_w = 0, o_fmod_b = 0, o_fin_w = 0, o_fin_b = 0;
   long mod_final = 0;
-  std::vector<dfot::TrainBlock> blocks;
+  std::vector<dfot::TrainBlock> blocks;  // execution order (variant 1: spatial 0, temporal 0, spatial 1, ...)
   std::vector<void*> owned, ws_owned;
   size_t ws_bytes = 0;
   // compute copies
   dfot::bf16 *w_mod = nullptr, *w_modT = nullptr, *wfT = nullptr;
-  float *b_mod = nullptr, *freqs = nullptr, *rope_cs = nullptr;
+  float *b_mod = nullptr, *freqs = nullptr, *rope_cs = nullptr, *pos2d = nullptr;
   bool synced = false;
   // workspace
   int max_batch = 0, fp = 0, batch = 0, tokens = 0;
@@ -348,9 +508,12 @@ struct dfot_dit_train_s {
   float *feat = nullptr, *h1 = nullptr, *a1 = nullptr, *cemb = nullptr, *mod_table = nullptr, *X = nullptr, *x_fin = nullptr;
   dfot::bf16* semb = nullptr;
   float *dX = nullptr, *dX2 = nullptr, *stats = nullptr, *delta = nullptr, *dmod = nullptr, *dwmod = nullptr, *dsemb = nullptr, *dwf = nullptr;
-  float *dc = nullptr, *da1 = nullptr, *dh1 = nullptr, *dbmod = nullptr;
+  float *dc = nullptr, *da1 = nullptr, *dh1 = nullptr, *dbmod = nullptr, *scratch_f = nullptr;
   dfot::bf16 *da = nullptr, *dO = nullptr, *dq = nullptr, *dk = nullptr, *dv = nullptr, *dqkv = nullptr, *T1 = nullptr,
-             *T2 = nullptr, *dmod_bf = nullptr, *dmodT = nullptr, *sembT = nullptr, *dyp = nullptr, *dyt = nullptr, *mfin = nullptr, *hbuf = nullptr, *dh = nullptr;
+             *T2 = nullptr, *dmod_bf = nullptr, *dmodT = nullptr, *sembT = nullptr, *dyp = nullptr, *dyt = nullptr, *mfin = nullptr, *hbuf = nullptr,
+             *dh = nullptr;
+  // matrix-block workspace
+  dfot::bf16 *mt = nullptr, *do2 = nullptr, *dz = nullptr, *dw1 = nullptr, *perm_a = nullptr, *perm_b = nullptr;
 };
 
 namespace dfot {
@@ -380,9 +543,10 @@ long tr_add(dfot_dit_train_s* h, const std::string& name, std::vector<int64_t> s
   return off;
 }
 
-int tr_transpose(const bf16* src, bf16* dst, int R, int C, hipStream_t s) {  // [R][C] -> [C][R]
+// [batches][R][C] -> [batches][C][R]
+int tr_transpose(const bf16* src, bf16* dst, int R, int C, hipStream_t s, int batches = 1) {
   DFOT_REQUIRE(R % 64 == 0 && C % 64 == 0, DFOT_ERR_SHAPE, "transpose: %d x %d must be multiples of 64", R, C);
-  hipLaunchKernelGGL(transpose_bf16_kernel, dim3(C / 64, R / 64, 1), dim3(256), 0, s, src, dst, R, C);
+  hipLaunchKernelGGL(transpose_bf16_kernel, dim3(C / 64, R / 64, batches), dim3(256), 0, s, src, dst, R, C);
   DFOT_CHECK_HIP(hipGetLastError());
   return DFOT_OK;
 }
@@ -410,9 +574,10 @@ int tr_wgrad(const bf16* A, const bf16* W, int M, int N, int K, float* out, hipS
   }
   return tr_gemm_f32(A, K, W, M, N, K, out, N, nullptr, s, split > 1 && variant == GEMM_AUTO ? (int)GEMM_DMA_128 : variant, split);
 }
-int tr_gemm_bf16(const bf16* A, long lda, const bf16* W, int M, int N, int K, const float* bias, bf16* out, long ldo, hipStream_t s) {
+int tr_gemm_bf16(const bf16* A, long lda, const bf16* W, int M, int N, int K, const float* bias, bf16* out, long ldo, hipStream_t s,
+                 int bias_rows = 0, int tr_rows = 0) {
   GemmArgs g;
-  g.A = A; g.lda = lda; g.W = W; g.M = M; g.N = N; g.K = K; g.bias = bias; g.out_bf16 = out; g.ldo = ldo;
+  g.A = A; g.lda = lda; g.W = W; g.M = M; g.N = N; g.K = K; g.bias = bias; g.bias_rows = bias_rows; g.out_bf16 = out; g.ldo = ldo; g.tr_rows = tr_rows;
   return launch_gemm(A_DENSE, E_BF16, GEMM_AUTO, g, s);
 }
 
@@ -433,14 +598,22 @@ int dfot_dit_train_destroy(dfot_dit_train_t h) {
 int dfot_dit_train_create(const dfot_dit_config* cfg, dfot_dit_train_t* out) {
   DFOT_REQUIRE(cfg && out, DFOT_ERR_ARG, "train_create: null argument");
   const dfot_dit_config& c = *cfg;
-  DFOT_REQUIRE(c.variant == 0, DFOT_ERR_ARG, "train_create: only the 'full' DiT3D variant has a training path");
-  DFOT_REQUIRE(c.mlp_hidden >= 0 && c.mlp_hidden % 128 == 0, DFOT_ERR_ARG, "train_create: MLP width %d must be a multiple of 128", c.mlp_hidden);
+  DFOT_REQUIRE(c.variant == 0 || c.variant == 1, DFOT_ERR_ARG, "train_create: unknown variant %d", c.variant);
+  const bool facmat = c.variant == 1;
+  DFOT_REQUIRE(c.mlp_hidden >= 0 && c.mlp_hidden % 128 == 0 && c.temporal_mlp_hidden >= 0 && c.temporal_mlp_hidden % 128 == 0, DFOT_ERR_ARG,
+               "train_create: MLP widths %d / %d must be multiples of 128", c.mlp_hidden, c.temporal_mlp_hidden);
   DFOT_REQUIRE(c.hidden_size % 128 == 0 && c.num_heads > 0 && c.hidden_size % c.num_heads == 0, DFOT_ERR_ARG,
                "train_create: hidden_size %d must be a multiple of 128 and of num_heads", c.hidden_size);
   DFOT_REQUIRE((c.hidden_size / c.num_heads) % 8 == 0 && c.hidden_size / c.num_heads <= 128, DFOT_ERR_ARG, "train_create: head dim must be a multiple of 8, <= 128");
   DFOT_REQUIRE(c.patch_size > 0 && c.height % c.patch_size == 0 && c.width % c.patch_size == 0, DFOT_ERR_ARG, "train_create: patch size");
   DFOT_REQUIRE(c.in_channels * c.patch_size * c.patch_size <= 64, DFOT_ERR_ARG, "train_create: patch_size^2 * channels must be <= 64");
   DFOT_REQUIRE(c.noise_dim > 0 && c.noise_dim % 2 == 0 && c.depth > 0 && c.timesteps > 0 && c.max_tokens > 0, DFOT_ERR_ARG, "train_create: bad config");
+  if (facmat) {
+    DFOT_REQUIRE(c.embed_col_dim > 0 && c.embed_col_dim % 64 == 0 && c.embed_col_dim <= 128, DFOT_ERR_ARG, "train_create: embed_col_dim %d must be 64 or 128", c.embed_col_dim);
+    DFOT_REQUIRE(c.num_col_heads > 0 && c.num_row_heads > 0 && c.embed_col_dim % c.num_col_heads == 0 && c.hidden_size % c.num_row_heads == 0 &&
+                     (c.hidden_size / c.num_row_heads) % 4 == 0 && c.max_tokens <= 32,
+                 DFOT_ERR_ARG, "train_create: matrix attention heads");
+  }
   auto* h = new dfot_dit_train_s();
   h->cfg = c;
   const int hd = c.hidden_size;
@@ -451,14 +624,14 @@ int dfot_dit_train_create(const dfot_dit_config* cfg, dfot_dit_train_t* out) {
   h->dstride = attention_dstride(h->d);
   h->kpatch = c.in_channels * c.patch_size * c.patch_size;
   h->oc = h->kpatch;
-  const int mh = c.mlp_hidden;
-  h->ldt = (long)c.depth * (mh ? 6 : 3) * hd + 2 * hd;
-  if (h->P % TR_CHUNKS != 0) {
-    set_error("train_create: %d patches per frame must be a multiple of %d", h->P, TR_CHUNKS);
+  const int mh = c.mlp_hidden, th = facmat ? c.temporal_mlp_hidden : 0, E = c.embed_col_dim, P = h->P;
+  h->ldt = (long)c.depth * ((mh ? 6 : 3) + (facmat ? (th ? 6 : 3) : 0)) * hd + 2 * hd;
+  if (h->P % TR_CHUNKS != 0 || (facmat && h->P % 128 != 0)) {
+    set_error("train_create: %d patches per frame must be a multiple of %d", h->P, facmat ? 128 : TR_CHUNKS);
     delete h;
     return DFOT_ERR_ARG;
   }
-  // registration order == the reference module's state_dict order (as dit_build)
+  // registration order == the reference module's state_dict order (as dit_build): all spatial blocks, then all temporal blocks
   const std::string ne = "noise_level_pos_embedding.embedding";
   h->o_t_w1 = tr_add(h, ne + ".linear_1.weight", {hd, c.noise_dim});
   h->o_t_b1 = tr_add(h, ne + ".linear_1.bias", {hd});
@@ -466,10 +639,23 @@ int dfot_dit_train_create(const dfot_dit_config* cfg, dfot_dit_train_t* out) {
   h->o_t_b2 = tr_add(h, ne + ".linear_2.bias", {hd});
   h->o_pe_w = tr_add(h, "patch_embedder.proj.weight", {hd, c.in_channels, c.patch_size, c.patch_size});
   h->o_pe_b = tr_add(h, "patch_embedder.proj.bias", {hd});
-  h->blocks.resize(c.depth);
+  if (facmat) h->o_diff = tr_add(h, "diff_embedder.embedding_table.weight", {2, hd});
+  std::vector<TrainBlock> spatial(c.depth), temporal(facmat ? c.depth : 0);
   long off = 0;
+  auto add_mlp = [&](TrainBlock& b, const std::string& pre, int width) {
+    b.mh = width;
+    if (!width) return;
+    b.mod2 = off;
+    off += 3 * hd;
+    b.o_mod2_w = tr_add(h, pre + ".norm2.modulation.1.weight", {3 * hd, hd});
+    b.o_mod2_b = tr_add(h, pre + ".norm2.modulation.1.bias", {3 * hd});
+    b.o_fc1_w = tr_add(h, pre + ".mlp.fc1.weight", {width, hd});
+    b.o_fc1_b = tr_add(h, pre + ".mlp.fc1.bias", {width});
+    b.o_fc2_w = tr_add(h, pre + ".mlp.fc2.weight", {hd, width});
+    b.o_fc2_b = tr_add(h, pre + ".mlp.fc2.bias", {hd});
+  };
   for (int i = 0; i < c.depth; ++i) {
-    TrainBlock& b = h->blocks[i];
+    TrainBlock& b = spatial[i];
     const std::string pre = "dit_base.blocks." + std::to_string(i);
     b.mod = off;
     off += 3 * hd;
@@ -479,16 +665,29 @@ int dfot_dit_train_create(const dfot_dit_config* cfg, dfot_dit_train_t* out) {
     b.o_qkv_b = tr_add(h, pre + ".attn.qkv.bias", {3 * hd});
     b.o_proj_w = tr_add(h, pre + ".attn.proj.weight", {hd, hd});
     b.o_proj_b = tr_add(h, pre + ".attn.proj.bias", {hd});
-    if (mh) {
-      b.mod2 = off;
-      off += 3 * hd;
-      b.o_mod2_w = tr_add(h, pre + ".norm2.modulation.1.weight", {3 * hd, hd});
-      b.o_mod2_b = tr_add(h, pre + ".norm2.modulation.1.bias", {3 * hd});
-      b.o_fc1_w = tr_add(h, pre + ".mlp.fc1.weight", {mh, hd});
-      b.o_fc1_b = tr_add(h, pre + ".mlp.fc1.bias", {mh});
-      b.o_fc2_w = tr_add(h, pre + ".mlp.fc2.weight", {hd, mh});
-      b.o_fc2_b = tr_add(h, pre + ".mlp.fc2.bias", {hd});
+    add_mlp(b, pre, mh);
+  }
+  for (int i = 0; i < (int)temporal.size(); ++i) {
+    TrainBlock& b = temporal[i];
+    b.matrix = true;
+    const std::string pre = "dit_base.temporal_blocks." + std::to_string(i);
+    b.mod = off;
+    off += 3 * hd;
+    b.o_mod_w = tr_add(h, pre + ".norm1.modulation.1.weight", {3 * hd, hd});
+    b.o_mod_b = tr_add(h, pre + ".norm1.modulation.1.bias", {3 * hd});
+    b.o_qkv_u = tr_add(h, pre + ".attn.qkv_u", {P, E});
+    b.o_proj_u = tr_add(h, pre + ".attn.proj_u", {E, P});
+    b.o_qkv_v = tr_add(h, pre + ".attn.qkv_v", {hd, 3 * hd});
+    b.o_proj_v = tr_add(h, pre + ".attn.proj_v", {hd, hd});
+    if (c.use_bias) {
+      b.o_qkv_bias = tr_add(h, pre + ".attn.qkv_bias", {E, 3 * hd});
+      b.o_proj_bias = tr_add(h, pre + ".attn.proj_bias", {P, hd});
     }
+    add_mlp(b, pre, th);
+  }
+  for (int i = 0; i < c.depth; ++i) {
+    h->blocks.push_back(spatial[i]);
+    if (facmat) h->blocks.push_back(temporal[i]);
   }
   h->mod_final = off;
   h->o_fmod_w = tr_add(h, "dit_base.final_layer.norm_final.modulation.1.weight", {2 * hd, hd});
@@ -501,19 +700,42 @@ int dfot_dit_train_create(const dfot_dit_config* cfg, dfot_dit_train_t* out) {
       (rc = tr_alloc(h, &h->b_mod, (size_t)h->ldt)) || (rc = tr_alloc(h, &h->wfT, (size_t)hd * 64)) ||
       (rc = tr_alloc(h, &h->freqs, (size_t)c.noise_dim / 2)))
     return fail(rc);
-  for (TrainBlock& b : h->blocks)
-    if ((rc = tr_alloc(h, &b.w_qkv, (size_t)3 * hd * hd)) || (rc = tr_alloc(h, &b.w_qkvT, (size_t)3 * hd * hd)) ||
-        (rc = tr_alloc(h, &b.w_proj, (size_t)hd * hd)) || (rc = tr_alloc(h, &b.w_projT, (size_t)hd * hd)) ||
-        (mh && ((rc = tr_alloc(h, &b.w_fc1, (size_t)mh * hd)) || (rc = tr_alloc(h, &b.w_fc1T, (size_t)mh * hd)) ||
-                (rc = tr_alloc(h, &b.w_fc2, (size_t)mh * hd)) || (rc = tr_alloc(h, &b.w_fc2T, (size_t)mh * hd)))))
+  for (TrainBlock& b : h->blocks) {
+    if (!b.matrix) {
+      if ((rc = tr_alloc(h, &b.w_qkv, (size_t)3 * hd * hd)) || (rc = tr_alloc(h, &b.w_qkvT, (size_t)3 * hd * hd)) ||
+          (rc = tr_alloc(h, &b.w_proj, (size_t)hd * hd)) || (rc = tr_alloc(h, &b.w_projT, (size_t)hd * hd)))
+        return fail(rc);
+    } else {
+      if ((rc = tr_alloc(h, &b.u_s, (size_t)P * E)) || (rc = tr_alloc(h, &b.u_t, (size_t)P * E)) || (rc = tr_alloc(h, &b.pu_s, (size_t)P * E)) ||
+          (rc = tr_alloc(h, &b.pu_t, (size_t)P * E)) || (rc = tr_alloc(h, &b.v_s, (size_t)3 * hd * hd)) || (rc = tr_alloc(h, &b.v_t, (size_t)3 * hd * hd)) ||
+          (rc = tr_alloc(h, &b.pv_s, (size_t)hd * hd)) || (rc = tr_alloc(h, &b.pv_t, (size_t)hd * hd)))
+        return fail(rc);
+    }
+    if (b.mh && ((rc = tr_alloc(h, &b.w_fc1, (size_t)b.mh * hd)) || (rc = tr_alloc(h, &b.w_fc1T, (size_t)b.mh * hd)) ||
+                 (rc = tr_alloc(h, &b.w_fc2, (size_t)b.mh * hd)) || (rc = tr_alloc(h, &b.w_fc2T, (size_t)b.mh * hd))))
       return fail(rc);
+  }
   {
     const int half = c.noise_dim / 2;
     std::vector<float> f(half);
     for (int i = 0; i < half; ++i) f[i] = (float)std::exp(-std::log(10000.0) * (double)i / (double)half);
     if (hipMemcpy(h->freqs, f.data(), f.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) return fail(DFOT_ERR_HIP);
   }
-  {  // RoPE-3D table, as dit_build
+  if (facmat) {  // sinusoidal_2d table, as dit_build
+    const int half = hd / 2, quarter = half / 2;
+    std::vector<float> pe((size_t)P * hd);
+    for (int m = 0; m < P; ++m) {
+      const int pos[2] = {m % h->gh, m / h->gh};
+      for (int a = 0; a < 2; ++a)
+        for (int i = 0; i < quarter; ++i) {
+          const double ang = (double)pos[a] / std::pow(10000.0, (double)i / (double)quarter);
+          pe[(size_t)m * hd + a * half + i] = (float)std::sin(ang);
+          pe[(size_t)m * hd + a * half + quarter + i] = (float)std::cos(ang);
+        }
+    }
+    if ((rc = tr_alloc(h, &h->pos2d, pe.size()))) return fail(rc);
+    if (hipMemcpy(h->pos2d, pe.data(), pe.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) return fail(DFOT_ERR_HIP);
+  } else {  // RoPE-3D table, as dit_build
     const int half = h->d / 2, q = half / 3, rem = half % 3;
     int parts[3] = {q, q, q};
     if (rem == 1) parts[0] = q + 1;
@@ -567,7 +789,7 @@ int dfot_dit_train_attach(dfot_dit_train_t h, float* params, float* grads) {
 int dfot_dit_train_sync_weights(dfot_dit_train_t h, void* stream) {
   DFOT_REQUIRE(h && h->params_f32, DFOT_ERR_STATE, "train_sync_weights: no parameter buffer attached");
   hipStream_t s = (hipStream_t)stream;
-  const int hd = h->cfg.hidden_size;
+  const int hd = h->cfg.hidden_size, P = h->P, E = h->cfg.embed_col_dim;
   const float* p = h->params_f32;
   int rc = 0;
   auto mod = [&](long o_w, long o_b, long col, int n) -> int {
@@ -576,29 +798,30 @@ int dfot_dit_train_sync_weights(dfot_dit_train_t h, void* stream) {
     DFOT_CHECK_HIP(hipMemcpyAsync(h->b_mod + col, p + o_b, (size_t)n * sizeof(float), hipMemcpyDeviceToDevice, s));
     return DFOT_OK;
   };
+  auto pair = [&](long o_w, bf16* as_stored, bf16* transposed, int R, int C) -> int {  // [R][C] fp32 -> bf16 and its transpose [C][R]
+    int r = launch_f32_to_bf16(p + o_w, as_stored, (long)R * C, s);
+    return r ? r : tr_transpose(as_stored, transposed, R, C, s);
+  };
   for (TrainBlock& b : h->blocks) {
     if ((rc = mod(b.o_mod_w, b.o_mod_b, b.mod, 3 * hd))) return rc;
-    if ((rc = launch_f32_to_bf16(p + b.o_qkv_w, b.w_qkv, (long)3 * hd * hd, s)) || (rc = tr_transpose(b.w_qkv, b.w_qkvT, 3 * hd, hd, s)) ||
-        (rc = launch_f32_to_bf16(p + b.o_proj_w, b.w_proj, (long)hd * hd, s)) || (rc = tr_transpose(b.w_proj, b.w_projT, hd, hd, s)))
-      return rc;
-    if (const int mh = h->cfg.mlp_hidden) {
-      if ((rc = mod(b.o_mod2_w, b.o_mod2_b, b.mod2, 3 * hd))) return rc;
-      if ((rc = launch_f32_to_bf16(p + b.o_fc1_w, b.w_fc1, (long)mh * hd, s)) || (rc = tr_transpose(b.w_fc1, b.w_fc1T, mh, hd, s)) ||
-          (rc = launch_f32_to_bf16(p + b.o_fc2_w, b.w_fc2, (long)mh * hd, s)) || (rc = tr_transpose(b.w_fc2, b.w_fc2T, hd, mh, s)))
+    if (!b.matrix) {
+      if ((rc = pair(b.o_qkv_w, b.w_qkv, b.w_qkvT, 3 * hd, hd)) || (rc = pair(b.o_proj_w, b.w_proj, b.w_projT, hd, hd))) return rc;
+    } else {
+      if ((rc = pair(b.o_qkv_u, b.u_s, b.u_t, P, E)) || (rc = pair(b.o_proj_u, b.pu_s, b.pu_t, E, P)) ||
+          (rc = pair(b.o_qkv_v, b.v_s, b.v_t, hd, 3 * hd)) || (rc = pair(b.o_proj_v, b.pv_s, b.pv_t, hd, hd)))
         return rc;
+    }
+    if (b.mh) {
+      if ((rc = mod(b.o_mod2_w, b.o_mod2_b, b.mod2, 3 * hd))) return rc;
+      if ((rc = pair(b.o_fc1_w, b.w_fc1, b.w_fc1T, b.mh, hd)) || (rc = pair(b.o_fc2_w, b.w_fc2, b.w_fc2T, hd, b.mh))) return rc;
     }
   }
   if ((rc = mod(h->o_fmod_w, h->o_fmod_b, h->mod_final, 2 * hd))) return rc;
   if ((rc = tr_transpose(h->w_mod, h->w_modT, (int)h->ldt, hd, s))) return rc;
-  // wfT[c][o] = fin_w[o][c] (bf16, 64 columns, zero padded): pack_transpose writes dst[c][r] = src[r][c] with dst row length `rows`
+  // wfT[c][o] = fin_w[o][c] (bf16, rows of 64, zero padded)
   DFOT_CHECK_HIP(hipMemsetAsync(h->wfT, 0, (size_t)hd * 64 * sizeof(bf16), s));
-  {
-    // rows = oc source rows, cols = hd; destination rows are 64 wide -> write through a strided variant: one small kernel launch per o
-    for (int o = 0; o < h->oc; ++o) {
-      // dst[c*64 + o] = src[o*hd + c]
-      if ((rc = launch_pack_rows(p + h->o_fin_w + (long)o * hd, h->wfT, nullptr, hd, 1, 1, 64, o, s))) return rc;
-    }
-  }
+  for (int o = 0; o < h->oc; ++o)
+    if ((rc = launch_pack_rows(p + h->o_fin_w + (long)o * hd, h->wfT, nullptr, hd, 1, 1, 64, o, s))) return rc;
   h->synced = true;
   return DFOT_OK;
 }
@@ -612,33 +835,44 @@ int dfot_dit_train_reserve(dfot_dit_train_t h, int max_batch) {
   h->ws_bytes = 0;
   h->max_batch = 0;
   const dfot_dit_config& c = h->cfg;
-  const int hd = c.hidden_size, nd = c.noise_dim;
+  const bool facmat = c.variant == 1;
+  const int hd = c.hidden_size, nd = c.noise_dim, E = c.embed_col_dim;
   const size_t rows = (size_t)max_batch * c.max_tokens * h->P;
   const int frames = max_batch * c.max_tokens;
   const int fp = (frames + 255) / 256 * 256;
   const size_t bhn = (size_t)max_batch * c.num_heads * c.max_tokens * h->P;
   const size_t qsz = bhn * h->dstride;
+  const size_t fe = (size_t)frames * E;
+  int widest = 3 * hd;
+  for (const TrainBlock& b : h->blocks) widest = b.mh > widest ? b.mh : widest;
   int rc = 0;
 #define WS(ptr, count) if ((rc = tr_alloc(h, &(ptr), (count), true))) return rc
   WS(h->idx, frames);
   WS(h->feat, (size_t)frames * nd); WS(h->h1, (size_t)frames * hd); WS(h->a1, (size_t)frames * hd); WS(h->cemb, (size_t)frames * hd);
   WS(h->semb, (size_t)fp * hd); WS(h->sembT, (size_t)fp * hd); WS(h->mod_table, (size_t)fp * h->ldt);
   WS(h->X, rows * hd); WS(h->x_fin, rows * hd);
+  bool any_mlp = false;
   for (TrainBlock& b : h->blocks) {
-    WS(b.x_in, rows * hd); WS(b.m, rows * hd); WS(b.q, qsz); WS(b.k, qsz); WS(b.v, qsz); WS(b.o, rows * hd); WS(b.a, rows * hd);
-    WS(b.lse, bhn);
-    if (c.mlp_hidden) { WS(b.x_mid, rows * hd); WS(b.m2, rows * hd); WS(b.u, rows * c.mlp_hidden); WS(b.y, rows * hd); }
+    WS(b.x_in, rows * hd); WS(b.m, rows * hd); WS(b.a, rows * hd);
+    if (!b.matrix) {
+      WS(b.q, qsz); WS(b.k, qsz); WS(b.v, qsz); WS(b.o, rows * hd); WS(b.lse, bhn);
+    } else {
+      WS(b.w1, fe * hd); WS(b.z, fe * 3 * hd); WS(b.o2, fe * hd); WS(b.sfac, rows * hd);
+    }
+    if (b.mh) { WS(b.x_mid, rows * hd); WS(b.m2, rows * hd); WS(b.u, rows * b.mh); WS(b.y, rows * hd); any_mlp = true; }
   }
-  const size_t wide = (size_t)(c.mlp_hidden > 3 * hd ? c.mlp_hidden : 3 * hd);
-  if (c.mlp_hidden) { WS(h->hbuf, rows * c.mlp_hidden); WS(h->dh, rows * c.mlp_hidden); }
+  if (any_mlp) { WS(h->hbuf, rows * widest); WS(h->dh, rows * widest); }
   WS(h->dX, rows * hd); WS(h->dX2, rows * hd); WS(h->stats, rows * 2); WS(h->delta, bhn);
-  WS(h->dmod, (size_t)fp * h->ldt); WS(h->dmod_bf, (size_t)fp * h->ldt); WS(h->dmodT, (size_t)fp * h->ldt);
-  WS(h->dwmod, (size_t)h->ldt * hd); WS(h->dsemb, (size_t)fp * hd); WS(h->dwf, (size_t)256 * hd);
-  WS(h->dbmod, (size_t)h->ldt);
-  WS(h->dc, (size_t)frames * hd); WS(h->da1, (size_t)frames * hd); WS(h->dh1, (size_t)frames * hd);
+  WS(h->dmod, (size_t)fp * h->ldt); WS(h->dmod_bf, (size_t)fp * h->ldt); WS(h->dmodT, (size_t)fp * h->ldt); WS(h->dbmod, (size_t)h->ldt);
+  WS(h->dwmod, (size_t)h->ldt * hd); WS(h->dsemb, (size_t)fp * hd); WS(h->dwf, (size_t)256 * hd > (size_t)128 * h->P ? (size_t)256 * hd : (size_t)128 * h->P);
+  WS(h->dc, (size_t)frames * hd); WS(h->da1, (size_t)frames * hd); WS(h->dh1, (size_t)frames * hd); WS(h->scratch_f, (size_t)hd);
   WS(h->da, rows * hd); WS(h->dO, rows * hd); WS(h->dq, qsz); WS(h->dk, qsz); WS(h->dv, qsz);
-  WS(h->dqkv, rows * 3 * hd); WS(h->T1, rows * wide); WS(h->T2, rows * hd); WS(h->dyp, rows * 64); WS(h->dyt, (size_t)256 * rows);
+  WS(h->dqkv, rows * 3 * hd); WS(h->T1, rows * widest); WS(h->T2, rows * hd); WS(h->dyp, rows * 64); WS(h->dyt, (size_t)256 * rows);
   WS(h->mfin, rows * hd);
+  if (facmat) {
+    WS(h->mt, rows * hd); WS(h->do2, fe * hd); WS(h->dz, fe * 3 * hd); WS(h->dw1, fe * hd);
+    WS(h->perm_a, (size_t)(h->P > 128 ? h->P : 128) * frames * hd); WS(h->perm_b, (size_t)(h->P > 128 ? h->P : 128) * frames * hd);
+  }
 #undef WS
   h->max_batch = max_batch;
   h->fp = fp;
@@ -651,21 +885,25 @@ int dfot_dit_train_forward(dfot_dit_train_t h, const float* x, const int32_t* no
   DFOT_REQUIRE(h->synced, DFOT_ERR_STATE, "train_forward: call dfot_dit_train_sync_weights after attaching / updating the parameters");
   DFOT_REQUIRE(batch > 0 && batch <= h->max_batch, DFOT_ERR_STATE, "train_forward: batch %d exceeds the reserved %d", batch, h->max_batch);
   const dfot_dit_config& c = h->cfg;
+  const bool facmat = c.variant == 1;
   DFOT_REQUIRE(tokens > 0 && tokens <= c.max_tokens, DFOT_ERR_SHAPE, "train_forward: %d tokens, max_tokens is %d", tokens, c.max_tokens);
-  const int n = tokens * h->P, hd = c.hidden_size, P = h->P, frames = batch * tokens, nd = c.noise_dim;
+  DFOT_REQUIRE(!facmat || tokens % 2 == 0, DFOT_ERR_SHAPE, "train_forward: %d tokens; the difference model takes (difference, frame) pairs", tokens);
+  const int n = tokens * h->P, hd = c.hidden_size, P = h->P, frames = batch * tokens, nd = c.noise_dim, E = c.embed_col_dim;
   DFOT_REQUIRE(n % 128 == 0, DFOT_ERR_SHAPE, "train_forward: sequence length %d (tokens x patches) must be a multiple of 128", n);
   hipStream_t s = (hipStream_t)stream;
   const long rows = (long)batch * n;
   const float* p = h->params_f32;
   int rc = 0;
   h->batch = batch; h->tokens = tokens; h->x_saved = x;
-  // ---- conditioning: c = Linear2(SiLU(Linear1(features(level)))) per frame; table = Linear_mod(SiLU(c)) for every modulation ----
+  // ---- conditioning: c = Linear2(SiLU(Linear1(features(level)))) [+ diff embedding] per frame; table = Linear_mod(SiLU(c)) ----
   hipLaunchKernelGGL(iota_kernel, dim3(cdiv(frames, 256)), dim3(256), 0, s, h->idx, frames);
   hipLaunchKernelGGL(tr_features_kernel, dim3(cdiv((long)frames * nd, 256)), dim3(256), 0, s, h->freqs, noise_levels, h->feat, frames, nd, c.timesteps - 1);
   hipLaunchKernelGGL(rows_linear_kernel<0>, dim3(cdiv(hd, 4), frames), dim3(256), 0, s, h->feat, p + h->o_t_w1, p + h->o_t_b1, h->h1, (bf16*)nullptr, nd, hd);
   hipLaunchKernelGGL(silu_fwd_kernel, dim3(cdiv((long)frames * hd, 256)), dim3(256), 0, s, h->h1, h->a1, (long)frames * hd);
   DFOT_CHECK_HIP(hipMemsetAsync(h->semb, 0, (size_t)h->fp * hd * sizeof(bf16), s));
   hipLaunchKernelGGL(rows_linear_kernel<0>, dim3(cdiv(hd, 4), frames), dim3(256), 0, s, h->a1, p + h->o_t_w2, p + h->o_t_b2, h->cemb, h->semb, hd, hd);
+  if (facmat)
+    hipLaunchKernelGGL(add_diff_kernel, dim3(cdiv((long)frames * hd, 256)), dim3(256), 0, s, h->cemb, p + h->o_diff, h->semb, frames, tokens, hd);
   DFOT_CHECK_HIP(hipGetLastError());
   {
     GemmArgs g;
@@ -674,35 +912,51 @@ int dfot_dit_train_forward(dfot_dit_train_t h, const float* x, const int32_t* no
   }
   // the residual stream lives in the blocks' own x_in buffers (each is what the backward of that block needs): no copies
   hipLaunchKernelGGL(patch_embed_kernel, dim3(cdiv(rows, PE_TOK)), dim3(256), PE_TOK * h->kpatch * sizeof(float), s, x, p + h->o_pe_w,
-                     p + h->o_pe_b, (const float*)nullptr, h->blocks[0].x_in, c.in_channels, c.height, c.width, c.patch_size, hd, rows);
+                     p + h->o_pe_b, (const float*)h->pos2d, h->blocks[0].x_in, c.in_channels, c.height, c.width, c.patch_size, hd, rows);
   DFOT_CHECK_HIP(hipGetLastError());
   const float qscale = 1.4426950408889634f / sqrtf((float)h->d);
+  // attention sequences: the whole video with RoPE-3D (variant 0) or one frame without RoPE (variant 1 spatial blocks)
+  const int seq = facmat ? P : n, nseq = facmat ? frames : batch;
+  auto combine = [&](const bf16* a, long gate_off, float* dst) -> int {
+    hipLaunchKernelGGL(gate_combine_kernel, dim3(cdiv(rows * hd / 4, 256)), dim3(256), 0, s, h->X, dst, a, h->mod_table, h->ldt, gate_off, hd, P,
+                       rows * hd / 4);
+    DFOT_CHECK_HIP(hipGetLastError());
+    return DFOT_OK;
+  };
   for (size_t bi = 0; bi < h->blocks.size(); ++bi) {
     TrainBlock& b = h->blocks[bi];
     float* next = bi + 1 < h->blocks.size() ? h->blocks[bi + 1].x_in : h->x_fin;
-    const int mh = c.mlp_hidden;
-    float* after_attn = mh ? b.x_mid : next;
+    float* after_attn = b.mh ? b.x_mid : next;
     if ((rc = launch_ln_mod(b.x_in, h->X, b.m, h->mod_table, h->idx, h->ldt, b.mod, hd, P, (int)rows, c.eps, frames - 1, s))) return rc;
-    {
+    if (!b.matrix) {
       GemmArgs g;
       g.A = b.m; g.lda = hd; g.W = b.w_qkv; g.M = (int)rows; g.N = 3 * hd; g.K = hd; g.bias = p + b.o_qkv_b;
-      g.q = b.q; g.k = b.k; g.v = b.v; g.rope_cs = h->rope_cs; g.heads = c.num_heads; g.d = h->d; g.dstride = h->dstride; g.ntok = n; g.qscale = qscale;
+      g.q = b.q; g.k = b.k; g.v = b.v; g.rope_cs = facmat ? nullptr : h->rope_cs; g.heads = c.num_heads; g.d = h->d; g.dstride = h->dstride; g.ntok = seq;
+      g.qscale = qscale;
       if ((rc = launch_gemm(A_DENSE, E_QKV_DIT, GEMM_AUTO, g, s))) return rc;
+      if ((rc = launch_attention_padded(b.q, b.k, b.v, b.o, hd, nseq, c.num_heads, seq, h->d, s, b.lse))) return rc;
+      if ((rc = tr_gemm_bf16(b.o, hd, b.w_proj, (int)rows, hd, hd, p + b.o_proj_b, b.a, hd, s))) return rc;
+    } else {
+      const bool bias = b.o_qkv_bias >= 0;
+      if ((rc = tr_transpose(b.m, h->mt, P, hd, s, frames))) return rc;                                                    // m^T per frame [hd][P]
+      if ((rc = tr_gemm_bf16(h->mt, P, b.u_t, frames * hd, E, P, nullptr, b.w1, E, s, 0, hd))) return rc;                   // w1[f][e][d] = sum_p U[p][e] m[f][p][d]
+      if ((rc = tr_gemm_bf16(b.w1, hd, b.v_t, frames * E, 3 * hd, hd, bias ? p + b.o_qkv_bias : nullptr, b.z, 3 * hd, s, bias ? E : 0))) return rc;
+      {
+        const int hn = E / c.num_col_heads, hdr = hd / c.num_row_heads;
+        if ((rc = launch_matrix_attn(b.z, b.o2, batch, tokens, E, hd, c.num_col_heads, c.num_row_heads, 1.0f / sqrtf((float)hn * (float)hdr), s))) return rc;
+      }
+      if ((rc = tr_transpose(b.o2, h->mt, E, hd, s, frames))) return rc;                                                   // o^T per frame [hd][E]
+      if ((rc = tr_gemm_bf16(h->mt, E, b.pu_t, frames * hd, P, E, nullptr, b.sfac, P, s, 0, hd))) return rc;                // s[f][p][d] = sum_e U'[e][p] o[f][e][d]
+      if ((rc = tr_gemm_bf16(b.sfac, hd, b.pv_t, (int)rows, hd, hd, bias ? p + b.o_proj_bias : nullptr, b.a, hd, s, bias ? P : 0))) return rc;
     }
-    if ((rc = launch_attention_padded(b.q, b.k, b.v, b.o, hd, batch, c.num_heads, n, h->d, s, b.lse))) return rc;
-    if ((rc = tr_gemm_bf16(b.o, hd, b.w_proj, (int)rows, hd, hd, p + b.o_proj_b, b.a, hd, s))) return rc;
-    hipLaunchKernelGGL(gate_combine_kernel, dim3(cdiv(rows * hd / 4, 256)), dim3(256), 0, s, h->X, after_attn, b.a, h->mod_table, h->ldt,
-                       b.mod + 2 * hd, hd, P, rows * hd / 4);
-    DFOT_CHECK_HIP(hipGetLastError());
-    if (mh) {
+    if ((rc = combine(b.a, b.mod + 2 * hd, after_attn))) return rc;
+    if (b.mh) {
       if ((rc = launch_ln_mod(b.x_mid, h->X, b.m2, h->mod_table, h->idx, h->ldt, b.mod2, hd, P, (int)rows, c.eps, frames - 1, s))) return rc;
-      if ((rc = tr_gemm_bf16(b.m2, hd, b.w_fc1, (int)rows, mh, hd, p + b.o_fc1_b, b.u, mh, s))) return rc;
-      hipLaunchKernelGGL(gelu_kernel, dim3(cdiv(rows * mh / 8, 256)), dim3(256), 0, s, b.u, h->hbuf, (bf16*)nullptr, rows * mh / 8);
+      if ((rc = tr_gemm_bf16(b.m2, hd, b.w_fc1, (int)rows, b.mh, hd, p + b.o_fc1_b, b.u, b.mh, s))) return rc;
+      hipLaunchKernelGGL(gelu_kernel, dim3(cdiv(rows * b.mh / 8, 256)), dim3(256), 0, s, b.u, h->hbuf, (bf16*)nullptr, rows * b.mh / 8);
       DFOT_CHECK_HIP(hipGetLastError());
-      if ((rc = tr_gemm_bf16(h->hbuf, mh, b.w_fc2, (int)rows, hd, mh, p + b.o_fc2_b, b.y, hd, s))) return rc;
-      hipLaunchKernelGGL(gate_combine_kernel, dim3(cdiv(rows * hd / 4, 256)), dim3(256), 0, s, h->X, next, b.y, h->mod_table, h->ldt,
-                         b.mod2 + 2 * hd, hd, P, rows * hd / 4);
-      DFOT_CHECK_HIP(hipGetLastError());
+      if ((rc = tr_gemm_bf16(h->hbuf, b.mh, b.w_fc2, (int)rows, hd, b.mh, p + b.o_fc2_b, b.y, hd, s))) return rc;
+      if ((rc = combine(b.y, b.mod2 + 2 * hd, next))) return rc;
     }
   }
   return launch_final_layer(h->x_fin, h->mod_table, h->idx, h->ldt, h->mod_final, p + h->o_fin_w, p + h->o_fin_b, out, hd, P, (int)rows, c.eps,
@@ -714,8 +968,10 @@ int dfot_dit_train_backward(dfot_dit_train_t h, const float* d_out, void* stream
   DFOT_REQUIRE(h && d_out, DFOT_ERR_ARG, "train_backward: null argument");
   DFOT_REQUIRE(h->batch > 0 && h->x_saved, DFOT_ERR_STATE, "train_backward: no forward to differentiate");
   const dfot_dit_config& c = h->cfg;
+  const bool facmat = c.variant == 1;
   const int batch = h->batch, tokens = h->tokens, n = tokens * h->P, hd = c.hidden_size, P = h->P, frames = batch * tokens, nd = c.noise_dim;
-  const int fp = h->fp;
+  const int fp = h->fp, E = c.embed_col_dim;
+  const int seq = facmat ? P : n, nseq = facmat ? frames : batch;
   hipStream_t s = (hipStream_t)stream;
   const long rows = (long)batch * n;
   const float* p = h->params_f32;
@@ -746,13 +1002,28 @@ int dfot_dit_train_backward(dfot_dit_train_t h, const float* d_out, void* stream
     std::swap(dY, dN);
     return DFOT_OK;
   };
+  auto gate_bwd = [&](const bf16* a, long gate_off, float* dbias) -> int {  // h->da = dY * gate, dgate into dmod, row sums of da into dbias
+    hipLaunchKernelGGL(gate_bwd_kernel, fgrid, dim3(256), 0, s, dY, a, h->mod_table, h->ldt, gate_off, h->da, h->dmod, dbias, hd, P);
+    DFOT_CHECK_HIP(hipGetLastError());
+    return DFOT_OK;
+  };
+  auto frames_sum = [&](const bf16* src, float* dst, long per_frame) -> int {
+    hipLaunchKernelGGL(frames_sum_bf16_kernel, dim3(cdiv(per_frame / 4, 256)), dim3(256), 0, s, src, dst, frames, per_frame);
+    DFOT_CHECK_HIP(hipGetLastError());
+    return DFOT_OK;
+  };
+  auto permute = [&](const bf16* src, bf16* dst, int R) -> int {  // [frames][R][hd] -> [R][frames][hd]
+    hipLaunchKernelGGL(permute_frames_kernel, dim3(cdiv((long)frames * R * (hd / 8), 256)), dim3(256), 0, s, src, dst, frames, R, hd);
+    DFOT_CHECK_HIP(hipGetLastError());
+    return DFOT_OK;
+  };
   if ((rc = ln_bwd(h->x_fin, h->mod_final))) return rc;
 
   // ---- blocks, last to first ----
   for (int bi = (int)h->blocks.size() - 1; bi >= 0; --bi) {
     TrainBlock& b = h->blocks[bi];
-    if (const int mh = c.mlp_hidden) {  // out = m2 + gate2 * y, y = GELU(m2 W1^T + b1) W2^T + b2
-      hipLaunchKernelGGL(gate_bwd_kernel, fgrid, dim3(256), 0, s, dY, b.y, h->mod_table, h->ldt, b.mod2 + 2 * hd, h->da, h->dmod, G + b.o_fc2_b, hd, P);
+    if (const int mh = b.mh) {  // out = m2 + gate2 * y, y = GELU(m2 W1^T + b1) W2^T + b2
+      if ((rc = gate_bwd(b.y, b.mod2 + 2 * hd, G + b.o_fc2_b))) return rc;
       hipLaunchKernelGGL(gelu_kernel, dim3(cdiv(rows * mh / 8, 256)), dim3(256), 0, s, b.u, h->hbuf, (bf16*)nullptr, rows * mh / 8);  // h again
       DFOT_CHECK_HIP(hipGetLastError());
       if ((rc = tr_gemm_bf16(h->da, hd, b.w_fc2T, (int)rows, mh, hd, nullptr, h->dh, mh, s))) return rc;        // dh = dy W2
@@ -766,20 +1037,57 @@ int dfot_dit_train_backward(dfot_dit_train_t h, const float* d_out, void* stream
       if ((rc = tr_wgrad(h->T1, h->T2, mh, hd, (int)rows, G + b.o_fc1_w, s))) return rc;                           // dW1 = du^T m2
       if ((rc = ln_bwd(b.x_mid, b.mod2))) return rc;
     }
-    hipLaunchKernelGGL(gate_bwd_kernel, fgrid, dim3(256), 0, s, dY, b.a, h->mod_table, h->ldt, b.mod + 2 * hd, h->da, h->dmod, G + b.o_proj_b, hd, P);
-    DFOT_CHECK_HIP(hipGetLastError());
-    if ((rc = tr_gemm_bf16(h->da, hd, b.w_projT, (int)rows, hd, hd, nullptr, h->dO, hd, s))) return rc;      // dO = da Wp
-    if ((rc = tr_transpose(h->da, h->T1, (int)rows, hd, s)) || (rc = tr_transpose(b.o, h->T2, (int)rows, hd, s))) return rc;
-    if ((rc = tr_wgrad(h->T1, h->T2, hd, hd, (int)rows, G + b.o_proj_w, s))) return rc;  // dWp = da^T o
-    if ((rc = launch_attention_bwd_delta(b.o, h->dO, hd, h->delta, batch, c.num_heads, n, h->d, s))) return rc;
-    if ((rc = launch_attention_bwd(b.q, b.k, b.v, h->dO, hd, b.lse, h->delta, h->dq, h->dk, h->dv, batch, c.num_heads, n, h->d, s))) return rc;
-    hipLaunchKernelGGL(qkv_grad_pack_kernel, dim3(cdiv(rows * (3 * hd / 8), 256)), dim3(256), 0, s, h->dq, h->dk, h->dv, h->rope_cs, h->dqkv, rows, n,
-                       c.num_heads, h->d, h->dstride);
-    hipLaunchKernelGGL(colsum_bf16_kernel, dim3(cdiv(3 * hd, 256), cdiv(rows, 128)), dim3(256), 0, s, h->dqkv, G + b.o_qkv_b, rows, 3 * hd, (long)3 * hd);
-    DFOT_CHECK_HIP(hipGetLastError());
-    if ((rc = tr_gemm_f32(h->dqkv, 3 * hd, b.w_qkvT, (int)rows, hd, 3 * hd, dY, hd, dY, s))) return rc;       // dm = dY + dqkv Wqkv (in place)
-    if ((rc = tr_transpose(h->dqkv, h->T1, (int)rows, 3 * hd, s)) || (rc = tr_transpose(b.m, h->T2, (int)rows, hd, s))) return rc;
-    if ((rc = tr_wgrad(h->T1, h->T2, 3 * hd, hd, (int)rows, G + b.o_qkv_w, s))) return rc;  // dWqkv = dqkv^T m
+    if (!b.matrix) {
+      if ((rc = gate_bwd(b.a, b.mod + 2 * hd, G + b.o_proj_b))) return rc;
+      if ((rc = tr_gemm_bf16(h->da, hd, b.w_projT, (int)rows, hd, hd, nullptr, h->dO, hd, s))) return rc;      // dO = da Wp
+      if ((rc = tr_transpose(h->da, h->T1, (int)rows, hd, s)) || (rc = tr_transpose(b.o, h->T2, (int)rows, hd, s))) return rc;
+      if ((rc = tr_wgrad(h->T1, h->T2, hd, hd, (int)rows, G + b.o_proj_w, s))) return rc;  // dWp = da^T o
+      if ((rc = launch_attention_bwd_delta(b.o, h->dO, hd, h->delta, nseq, c.num_heads, seq, h->d, s))) return rc;
+      if ((rc = launch_attention_bwd(b.q, b.k, b.v, h->dO, hd, b.lse, h->delta, h->dq, h->dk, h->dv, nseq, c.num_heads, seq, h->d, s))) return rc;
+      hipLaunchKernelGGL(qkv_grad_pack_kernel, dim3(cdiv(rows * (3 * hd / 8), 256)), dim3(256), 0, s, h->dq, h->dk, h->dv,
+                         facmat ? (const float*)nullptr : h->rope_cs, h->dqkv, rows, seq, c.num_heads, h->d, h->dstride);
+      hipLaunchKernelGGL(colsum_bf16_kernel, dim3(cdiv(3 * hd, 256), cdiv(rows, 128)), dim3(256), 0, s, h->dqkv, G + b.o_qkv_b, rows, 3 * hd, (long)3 * hd);
+      DFOT_CHECK_HIP(hipGetLastError());
+      if ((rc = tr_gemm_f32(h->dqkv, 3 * hd, b.w_qkvT, (int)rows, hd, 3 * hd, dY, hd, dY, s))) return rc;       // dm = dY + dqkv Wqkv (in place)
+      if ((rc = tr_transpose(h->dqkv, h->T1, (int)rows, 3 * hd, s)) || (rc = tr_transpose(b.m, h->T2, (int)rows, hd, s))) return rc;
+      if ((rc = tr_wgrad(h->T1, h->T2, 3 * hd, hd, (int)rows, G + b.o_qkv_w, s))) return rc;  // dWqkv = dqkv^T m
+    } else {
+      const bool bias = b.o_qkv_bias >= 0;
+      const int fe = frames * E;
+      const long fk = (long)frames * hd;  // contraction length of the left-factor gradients
+      // a = s V' + bias'[p] ; s[f][p][d] = sum_e U'[e][p] o[f][e][d]
+      if ((rc = gate_bwd(b.a, b.mod + 2 * hd, h->scratch_f))) return rc;
+      if (bias && (rc = frames_sum(h->da, G + b.o_proj_bias, (long)P * hd))) return rc;
+      if ((rc = tr_gemm_bf16(h->da, hd, b.pv_s, (int)rows, hd, hd, nullptr, h->dO, hd, s))) return rc;            // ds = da V'^T  (V' stored (in, out))
+      if ((rc = tr_transpose(b.sfac, h->T1, (int)rows, hd, s)) || (rc = tr_transpose(h->da, h->T2, (int)rows, hd, s))) return rc;
+      if ((rc = tr_wgrad(h->T1, h->T2, hd, hd, (int)rows, G + b.o_proj_v, s))) return rc;                          // dV'[in][out] = s^T da
+      if ((rc = tr_transpose(h->dO, h->mt, P, hd, s, frames))) return rc;                                        // ds^T per frame [hd][P]
+      if ((rc = tr_gemm_bf16(h->mt, P, b.pu_s, frames * hd, E, P, nullptr, h->do2, E, s, 0, hd))) return rc;       // do[f][e][d] = sum_p U'[e][p] ds[f][p][d]
+      // dU'[e][p] = sum_{f,d} o[f][e][d] ds[f][p][d]: operands regrouped to [e][(f,d)] / [p][(f,d)]; E rows padded to 128
+      DFOT_CHECK_HIP(hipMemsetAsync(h->perm_a, 0, (size_t)128 * fk * sizeof(bf16), s));
+      if ((rc = permute(b.o2, h->perm_a, E)) || (rc = permute(h->dO, h->perm_b, P))) return rc;
+      if ((rc = tr_gemm_f32(h->perm_a, fk, h->perm_b, 128, P, (int)fk, h->dwf, P, nullptr, s))) return rc;
+      DFOT_CHECK_HIP(hipMemcpyAsync(G + b.o_proj_u, h->dwf, (size_t)E * P * sizeof(float), hipMemcpyDeviceToDevice, s));
+      // attention over the frames
+      {
+        const int hn = E / c.num_col_heads, hdr = hd / c.num_row_heads;
+        hipLaunchKernelGGL(matrix_attn_bwd_kernel, dim3(batch * c.num_col_heads * c.num_row_heads), dim3(256), 0, s, b.z, h->do2, h->dz, tokens, E, hd,
+                           c.num_col_heads, c.num_row_heads, 1.0f / sqrtf((float)hn * (float)hdr));
+        DFOT_CHECK_HIP(hipGetLastError());
+      }
+      // z = w1 V + bias[e] ; w1[f][e][d] = sum_p U[p][e] m[f][p][d]
+      if (bias && (rc = frames_sum(h->dz, G + b.o_qkv_bias, (long)E * 3 * hd))) return rc;
+      if ((rc = tr_gemm_bf16(h->dz, 3 * hd, b.v_s, fe, hd, 3 * hd, nullptr, h->dw1, hd, s))) return rc;           // dw1 = dz V^T  (V stored (in, out))
+      if ((rc = tr_transpose(b.w1, h->T1, fe, hd, s)) || (rc = tr_transpose(h->dz, h->dqkv, fe, 3 * hd, s))) return rc;
+      if ((rc = tr_wgrad(h->T1, h->dqkv, hd, 3 * hd, fe, G + b.o_qkv_v, s))) return rc;                            // dV[in][out] = w1^T dz
+      if ((rc = tr_transpose(h->dw1, h->mt, E, hd, s, frames))) return rc;                                       // dw1^T per frame [hd][E]
+      if ((rc = tr_gemm_bf16(h->mt, E, b.u_s, frames * hd, P, E, nullptr, h->dO, P, s, 0, hd))) return rc;         // dm[f][p][d] = sum_e U[p][e] dw1[f][e][d]
+      hipLaunchKernelGGL(add_bf16_kernel, dim3(cdiv(rows * hd / 4, 256)), dim3(256), 0, s, dY, h->dO, rows * hd / 4);
+      DFOT_CHECK_HIP(hipGetLastError());
+      // dU[p][e] = sum_{f,d} m[f][p][d] dw1[f][e][d]
+      if ((rc = permute(b.m, h->perm_a, P)) || (rc = permute(h->dw1, h->perm_b, E))) return rc;
+      if ((rc = tr_gemm_f32(h->perm_a, fk, h->perm_b, P, E, (int)fk, G + b.o_qkv_u, E, nullptr, s))) return rc;
+    }
     if ((rc = ln_bwd(b.x_in, b.mod))) return rc;
   }
 
@@ -803,15 +1111,16 @@ int dfot_dit_train_backward(dfot_dit_train_t h, const float* d_out, void* stream
   };
   for (TrainBlock& b : h->blocks) {
     if ((rc = scatter(b.mod, 3 * hd, b.o_mod_w, b.o_mod_b))) return rc;
-    if (c.mlp_hidden && (rc = scatter(b.mod2, 3 * hd, b.o_mod2_w, b.o_mod2_b))) return rc;
+    if (b.mh && (rc = scatter(b.mod2, 3 * hd, b.o_mod2_w, b.o_mod2_b))) return rc;
   }
   if ((rc = scatter(h->mod_final, 2 * hd, h->o_fmod_w, h->o_fmod_b))) return rc;
   DFOT_CHECK_HIP(hipMemsetAsync(h->dsemb, 0, (size_t)fp * hd * sizeof(float), s));
-  if ((rc = tr_gemm_f32(h->dmod_bf, h->ldt, h->w_modT, fp, hd, (int)h->ldt, h->dsemb, hd, nullptr, s, GEMM_DMA_128, 16))) return rc;  // d SiLU(c)
+  if ((rc = tr_gemm_f32(h->dmod_bf, h->ldt, h->w_modT, fp, hd, (int)h->ldt, h->dsemb, hd, nullptr, s))) return rc;  // d SiLU(c)
 
   // ---- noise-level embedding MLP (frames x hidden, fp32) ----
   const long fh = (long)frames * hd;
   hipLaunchKernelGGL(silu_bwd_kernel, dim3(cdiv(fh, 256)), dim3(256), 0, s, h->dsemb, h->cemb, h->dc, fh);
+  if (facmat) hipLaunchKernelGGL(diff_grad_kernel, dim3(cdiv(2 * hd, 256)), dim3(256), 0, s, h->dc, G + h->o_diff, frames, tokens, hd);
   hipLaunchKernelGGL(small_wgrad_kernel, dim3(cdiv((long)hd * hd, 256)), dim3(256), 0, s, h->dc, h->a1, G + h->o_t_w2, G + h->o_t_b2, frames, hd, hd);
   hipLaunchKernelGGL(small_dgrad_kernel, dim3(cdiv(fh, 256)), dim3(256), 0, s, h->dc, p + h->o_t_w2, h->da1, frames, hd, hd);
   hipLaunchKernelGGL(silu_bwd_kernel, dim3(cdiv(fh, 256)), dim3(256), 0, s, h->da1, h->h1, h->dh1, fh);

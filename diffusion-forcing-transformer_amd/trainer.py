@@ -27,21 +27,37 @@ class DiT3DTrainer:
                  diffusion: Optional[DiffusionConfig] = None, lr: float = 5e-5, weight_decay: float = 0.01,
                  betas: Tuple[float, float] = (0.9, 0.99), eps: float = 1e-8, max_grad_norm: Optional[float] = 1.0,
                  loss_weighting: Optional[Dict] = None):
-        if _get(cfg, "variant", "full") != "full" or _get(cfg, "pos_emb_type", "rope_3d") != "rope_3d":
-            raise ValueError("DiT3DTrainer builds the 'full' / rope_3d DiT3D")
         self.x_shape = tuple(int(v) for v in x_shape)
         c = capi.DiTConfig()
-        c.hidden_size = int(_get(cfg, "hidden_size"))
         c.depth = int(_get(cfg, "depth"))
         c.num_heads = int(_get(cfg, "num_heads"))
         c.patch_size = int(_get(cfg, "patch_size", 2))
         c.in_channels, c.height, c.width = self.x_shape
-        c.max_tokens = int(max_tokens)
-        c.noise_dim, c.timesteps, c.rope_theta, c.eps, c.variant = 256, int(timesteps), 10000.0, 1e-6, 0
+        c.noise_dim, c.timesteps, c.rope_theta, c.eps = 256, int(timesteps), 10000.0, 1e-6
         ratio = _get(cfg, "spatial_mlp_ratio", None)
+        variant = _get(cfg, "variant", "full")
+        if variant == "full":  # DiT3D (dit3d.yaml)
+            if _get(cfg, "pos_emb_type", "rope_3d") != "rope_3d":
+                raise ValueError("DiT3DTrainer builds the 'full' DiT3D with pos_emb_type='rope_3d'")
+            c.variant, c.hidden_size, c.max_tokens = 0, int(_get(cfg, "hidden_size")), int(max_tokens)
+        elif variant == "factorized_matrix_attention":  # DifferenceDiT3D (bash/k600): as dit_backbone.DifferenceDiT3D._configure
+            if _get(cfg, "pos_emb_type") != "sinusoidal_2d" or _get(cfg, "merge_type", "interleaved") != "interleaved":
+                raise ValueError("the difference model trains with pos_emb_type='sinusoidal_2d' and merge_type='interleaved'")
+            if _get(cfg, "matrix_block", "matrix") != "matrix" or _get(cfg, "matrix_multi_token", False) or _get(cfg, "fixed_u", None):
+                raise ValueError("only matrix_block='matrix' with learned factors and multi_token=False is supported")
+            if ratio is None:
+                raise AssertionError("spatial_mlp_ratio must be specified for matrix attention")
+            tratio = _get(cfg, "mlp_ratio", None)
+            c.variant, c.hidden_size, c.max_tokens = 1, int(_get(cfg, "embed_row_dim")), 2 * int(max_tokens)
+            c.embed_col_dim = int(_get(cfg, "embed_col_dim"))
+            c.num_col_heads, c.num_row_heads = int(_get(cfg, "num_col_heads")), int(_get(cfg, "num_row_heads"))
+            c.temporal_mlp_hidden = int(c.hidden_size * tratio) if tratio else 0
+            c.use_bias = int(bool(_get(cfg, "use_bias")))
+        else:
+            raise ValueError(f"no training path for DiT variant {variant!r}")
         c.mlp_hidden = int(c.hidden_size * ratio) if ratio else 0
         self._ccfg = c
-        self.max_tokens = int(max_tokens)
+        self.max_tokens = int(c.max_tokens)
         self._handle = C.c_void_p()
         capi.check(capi.lib.dfot_dit_train_create(C.byref(c), C.byref(self._handle)))
         lib, h = capi.lib, self._handle
