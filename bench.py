@@ -80,9 +80,16 @@ def bench_train_k600(args, rank, world, dist):
     independent noise levels -> noised forward -> fused-min-SNR v-loss -> hand-written backward -> all-reduce of the flat gradient
     buffer over the ranks (RCCL) -> global-norm clip + AdamW -> bf16 weight refresh.  `--batch` videos per GPU (weak scaling)."""
     import dfot_amd
-    from dfot_amd import DiT3D, DiT3DTrainer
-    xl = dict(name="dit3d", variant="full", pos_emb_type="rope_3d", patch_size=1, hidden_size=1152, depth=28, num_heads=16)
-    init = DiT3D(xl, x_shape=(16, 16, 16), max_tokens=5)
+    from dfot_amd import DifferenceDiT3D, DiT3D, DiT3DTrainer
+    diff = args.workload == "train_k600diff"  # the model bash/k600/*.sh train: DifferenceDiT3D factorized matrix attention XL-64-1
+    if diff:
+        xl = dict(name="difference_dit3d", variant="factorized_matrix_attention", pos_emb_type="sinusoidal_2d", merge_type="interleaved",
+                  patch_size=1, hidden_size=None, embed_col_dim=64, embed_row_dim=1152, num_heads=12, num_col_heads=1, num_row_heads=16,
+                  depth=28, mlp_ratio=4.0, spatial_mlp_ratio=4.0, use_bias=True, matrix_block="matrix")
+        init = DifferenceDiT3D(xl, x_shape=(16, 16, 16), max_tokens=5)
+    else:
+        xl = dict(name="dit3d", variant="full", pos_emb_type="rope_3d", patch_size=1, hidden_size=1152, depth=28, num_heads=16)
+        init = DiT3D(xl, x_shape=(16, 16, 16), max_tokens=5)
     init.init_random(seed=0)  # same seed on every rank: replicas start identical
     tr = DiT3DTrainer(xl, x_shape=(16, 16, 16), max_tokens=5, lr=5e-5, weight_decay=0.01, betas=(0.9, 0.99), max_grad_norm=1.0)
     tr.load_state_dict({k: v.detach() for k, v in init.state_dict().items()}, strict=True)
@@ -90,10 +97,22 @@ def bench_train_k600(args, rank, world, dist):
     b = args.batch
     g = torch.Generator().manual_seed(100 + rank)
     xs = torch.randn(b, 5, 16, 16, 16, generator=g).cuda()
-    noise = torch.randn(b, 5, 16, 16, 16, generator=g).cuda()
-    tn = dfot_amd.TrainingNoise(noise_level="random_independent", is_continuous=False, n_context_tokens=2)
+    noise = torch.randn(b, 10 if diff else 5, 16, 16, 16, generator=g).cuda()
+    if diff:  # bash/k600: noise_level random_uniform, variable_context enabled
+        tn = dfot_amd.TrainingNoise(noise_level="random_uniform", is_continuous=False, n_context_tokens=2,
+                                    variable_context=dfot_amd.ContextTraining(enabled=True, prob=0.25, dropout=0.3))
+    else:
+        tn = dfot_amd.TrainingNoise(noise_level="random_independent", is_continuous=False, n_context_tokens=2)
     masks = torch.ones(b, 5, dtype=torch.bool)
     levels = [tn.sample(b, 5, masks, g, training=True) for _ in range(args.steps + args.warmup)]
+
+    def train_step(i):
+        if diff:
+            loss = tr.difference_loss_and_grads(xs, levels[i][0], noise, levels[i][1])
+        else:
+            loss = tr.loss_and_grads(xs, levels[i][0], noise, levels[i][1])
+        tr.optimizer_step(world)
+        return loss
 
     def barrier():
         if dist is not None:
@@ -102,11 +121,11 @@ def bench_train_k600(args, rank, world, dist):
 
     losses = []
     for i in range(args.warmup):
-        tr.training_step(xs, levels[i][0], noise, levels[i][1], world_size=world)
+        train_step(i)
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        losses.append(tr.training_step(xs, levels[args.warmup + i][0], noise, levels[args.warmup + i][1], world_size=world))
+        losses.append(train_step(args.warmup + i))
     barrier()
     dt = time.perf_counter() - t0
     losses = [float(l.item()) for l in losses]
@@ -118,15 +137,24 @@ def bench_train_k600(args, rank, world, dist):
     if rank == 0:
         n, d, heads = 1280, 72, 16
         video_flop = 28 * (2.0 * n * 1152 * 3456 + 2.0 * n * 1152 * 1152 + 4.0 * n * n * d * heads)
+        if diff:  # as bench_k600: 10 merged tokens x 256 patches; spatial block + matrix block per depth
+            n, hh, e = 2560, 1152, 64
+            lin = lambda rows, k, nn: 2.0 * rows * k * nn
+            spatial = lin(n, hh, 3 * hh) + lin(n, hh, hh) + 4.0 * 256 * 256 * 96 * 12 * 10 + 2 * lin(n, hh, 4 * hh)
+            matrix = (lin(10 * hh, 256, e) + lin(10 * e, hh, 3 * hh) + 4.0 * 10 * 10 * e * hh + lin(10 * hh, e, 256) + lin(n, hh, hh)
+                      + 2 * lin(n, hh, 4 * hh))
+            video_flop = 28 * (spatial + matrix)
         step_flop = 3.0 * video_flop * b  # forward + backward (2x), algorithmic
         line = {
-            "metric": "training samples/sec, DFoT K600 DiT/XL (per-token independent noise levels, AdamW, data parallel)",
+            "metric": "training samples/sec, DFoT K600 %s (AdamW, data parallel)" % ("DifferenceDiT3D FacMat XL-64-1 (bash/k600)" if diff else "DiT/XL (per-token independent noise levels)"),
             "value": b * args.steps * world / dt, "unit": "videos/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
             "data": "synthetic latents, seeded random-init weights",
-            "config": {"workload": f"DFoT K600 @DiT/XL training step: {b} videos per GPU, latents 16x16x16, 5 tokens, random_independent levels, "
+            "config": {"workload": (f"DFoT K600 bash/k600 difference_dit3d factorized_matrix_attention XL-64-1 training step: {b} videos per GPU, latents "
+                                    "16x16x16, 5 frames -> 10 merged (difference, frame) tokens, random_uniform levels + variable context, " if diff else
+                                    f"DFoT K600 @DiT/XL training step: {b} videos per GPU, latents 16x16x16, 5 tokens, random_independent levels, ") +
                                    "fused_min_snr v-loss, AdamW lr 5e-5 wd 0.01 betas (0.9, 0.99), grad clip 1.0, fp32 master weights / bf16 compute; "
-                                   "one all-reduce of the 1.06 GB flat gradient buffer per step", "parameters": tr.numel},
+                                   "one all-reduce of the flat fp32 gradient buffer per step", "parameters": tr.numel},
             "losses": losses, "model_tflops": step_flop * args.steps / dt / 1e12,
             "roofline": {"bound": "mfma", "kernel": "whole training step (3 x forward FLOPs: GEMM dgrad/wgrad + attention backward); per-kernel split in profiles/",
                          "achieved": step_flop * args.steps / dt / 1e12, "peak": 2500.0, "unit": "TFLOP/s", "frac": step_flop * args.steps / dt / 1e12 / 2500.0,
@@ -258,7 +286,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", action="store_true", help="replay one hipGraph-captured DDIM step (no in-run attention timing)")
     ap.add_argument("--batch", type=int, default=8, help="k600: videos per GPU (bash/k600 validation.batch_size)")
-    ap.add_argument("--workload", choices=["8f", "200f", "k600", "k600diff", "train_k600"], default="8f",
+    ap.add_argument("--workload", choices=["8f", "200f", "k600", "k600diff", "train_k600", "train_k600diff"], default="8f",
                     help="8f: BASELINE config 2 (default, the metric's single-GPU configuration); 200f: config 3, the "
                          "200-frame rollout (keyframe density 0.0625, stabilized HG 4.0/0.02 + interpolation HG 1.5, batches of "
                          "4 windows), interpolation windows sharded over ranks")
@@ -276,7 +304,7 @@ def main():
     import dfot_amd
     from dfot_amd import DFoTVideoPoseSampler, DiffusionConfig, SamplerConfig, UViT3DPose
 
-    if args.workload == "train_k600":
+    if args.workload in ("train_k600", "train_k600diff"):
         return bench_train_k600(args, rank, world, dist if world > 1 else None)
     if args.workload in ("k600", "k600diff"):
         return bench_k600(args, rank, world, dist if world > 1 else None)

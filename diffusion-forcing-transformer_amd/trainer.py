@@ -80,6 +80,8 @@ class DiT3DTrainer:
         self.schedule = Schedule(diffusion or DiffusionConfig(beta_schedule="cosine", is_continuous=False, timesteps=timesteps))
         self.loss_weighting = dict(loss_weighting or {})
         self._reserved = 0
+        self._acc: Optional[torch.Tensor] = None
+        self._acc_n = 0
         self._dirty = True
         self._last: Optional[dict] = None
 
@@ -166,8 +168,32 @@ class DiT3DTrainer:
         self.backward(dv)
         return (per_token * torch.from_numpy(mk).cuda()).mean()
 
+    def difference_loss_and_grads(self, frames: torch.Tensor, k: torch.Tensor, noise: torch.Tensor, masks: Optional[torch.Tensor] = None):
+        """DifferenceDFoTVideo.training_step (difference_dfot_video.py:80-105): frame differences (first frame against itself) are
+        interleaved with the frames (difference first), noise levels and loss masks are doubled the same way, then the ordinary
+        denoising loss on the 2T merged tokens.  frames (B,T,C,H,W), k / masks (B,T), noise (B,2T,C,H,W)."""
+        if self._ccfg.variant != 1:
+            raise ValueError("difference_loss_and_grads needs the difference model (variant factorized_matrix_attention)")
+        fr = frames.to(device="cuda", dtype=torch.float32)
+        diff = torch.diff(fr, dim=1, prepend=fr[:, :1])
+        merge = lambda a, b: torch.stack([a, b], dim=2).flatten(1, 2)
+        kk = k.to("cuda")
+        mk = None if masks is None else merge(masks.to("cuda"), masks.to("cuda"))
+        return self.loss_and_grads(merge(diff, fr), merge(kk, kk), noise, mk)
+
+    def accumulate(self) -> None:
+        """accumulate_grad_batches: add the gradients of the last backward to the running sum used by the next optimizer_step"""
+        if self._acc is None:
+            self._acc = torch.zeros_like(self.grads)
+        self._acc.add_(self.grads)
+        self._acc_n += 1
+
     def optimizer_step(self, world_size: int = 1) -> None:
         """[all-reduce + average the flat gradient buffer] -> global-norm clip -> AdamW -> refresh the bf16 compute weights"""
+        if self._acc_n:
+            self.grads.copy_(self._acc).mul_(1.0 / self._acc_n)
+            self._acc.zero_()
+            self._acc_n = 0
         if world_size > 1:
             parallel.allreduce_mean_(self.grads)
         self.step_count += 1
