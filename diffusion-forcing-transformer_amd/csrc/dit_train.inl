@@ -441,6 +441,14 @@ __global__ void permute_frames_kernel(const bf16* __restrict__ src, bf16* __rest
   const long f = i / ((long)c8 * R);
   *reinterpret_cast<bf16x8*>(dst + ((long)rrow * frames + f) * C + cc * 8) = *reinterpret_cast<const bf16x8*>(src + i * 8);
 }
+// out = sum of S partial outputs (split-K GEMM slices, plain stores)
+__global__ void slices_sum_kernel(const float* __restrict__ ws, float* __restrict__ out, long n4, int slices, long stride) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  float4v a = *reinterpret_cast<const float4v*>(ws + i * 4);
+  for (int s = 1; s < slices; ++s) a += *reinterpret_cast<const float4v*>(ws + s * stride + i * 4);
+  *reinterpret_cast<float4v*>(out + i * 4) = a;
+}
 // y (fp32) += x (bf16)
 __global__ void add_bf16_kernel(float* __restrict__ y, const bf16* __restrict__ x, long n4) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -513,6 +521,8 @@ struct dfot_dit_train_s {
              *T2 = nullptr, *dmod_bf = nullptr, *dmodT = nullptr, *sembT = nullptr, *dyp = nullptr, *dyt = nullptr, *mfin = nullptr, *hbuf = nullptr,
              *dh = nullptr;
   // matrix-block workspace
+  float* wg_ws = nullptr;  // partial outputs of split-K weight-gradient GEMMs
+  size_t wg_ws_floats = 0;
   dfot::bf16 *mt = nullptr, *do2 = nullptr, *dz = nullptr, *dw1 = nullptr, *perm_a = nullptr, *perm_b = nullptr;
 };
 
@@ -563,9 +573,46 @@ int tr_gemm_f32(const bf16* A, long lda, const bf16* W, int M, int N, int K, flo
 // A/B (same box, DiT/XL, 8 videos): splitting K over workgroups with atomic accumulation (DFOT_TRAIN_WGRAD_WGS = target number of
 // workgroups) fills the chip for the 81-tile out-projection gradient but the 8 M fp32 atomics per GEMM cost more than that gains:
 // 42.3 ms/step at 512 workgroups, 46.0 at 768, 48.8 at 1024 vs 40.9 unsplit -- off by default.
-int tr_wgrad(const bf16* A, const bf16* W, int M, int N, int K, float* out, hipStream_t s) {
+// What does pay for the long-K shapes whose 256x192 tiling leaves CUs idle (MLP weights: 4608 x 1152 -> 108 tiles): K split in
+// two with each slice storing its partial tile to a workspace (plain stores) and one pass summing the slices (`ws`, `ws_floats`).
+int tr_wgrad(const bf16* A, const bf16* W, int M, int N, int K, float* out, hipStream_t s, float* ws = nullptr, size_t ws_floats = 0) {
   static const int variant = tuning_flag("TRAIN_WGRAD_VARIANT", GEMM_AUTO);
   static const int target = tuning_flag("TRAIN_WGRAD_WGS", 0);
+  static const int big = tuning_flag("TRAIN_WGRAD_BIGTILE", 1);
+  if (big && ws && target == 0 && variant == GEMM_AUTO) {
+    const long t192 = (long)(M / 256) * (N / 192);
+    if (M % 256 == 0 && N % 192 == 0 && t192 >= 64 && t192 < 160 && K >= 4096) {
+      const int split = t192 <= 85 ? 3 : 2;
+      if ((size_t)split * M * N <= ws_floats) {
+        GemmArgs g;
+        g.A = A; g.lda = K; g.W = W; g.M = M; g.N = N; g.K = K; g.out_f32 = ws; g.ldo = N; g.ksplit = split; g.slice_stride = (long)M * N;
+        int rc = launch_gemm(A_DENSE, E_F32, GEMM_DMA_256x192, g, s);
+        if (rc) return rc;
+        hipLaunchKernelGGL(slices_sum_kernel, dim3(cdiv((long)M * N / 4, 256)), dim3(256), 0, s, ws, out, (long)M * N / 4, split, (long)M * N);
+        DFOT_CHECK_HIP(hipGetLastError());
+        return DFOT_OK;
+      }
+    }
+    const long t128x192 = (long)(M / 128) * (N / 192);
+    if (M % 256 != 0 && N % 192 == 0 && t128x192 >= 160 && t128x192 <= 256 && K >= 4096)  // one round of 128x192 tiles
+      return tr_gemm_f32(A, K, W, M, N, K, out, N, nullptr, s, GEMM_DMA_128x192, 1);
+    // few 128x128 tiles and a long K (out-projection weights: 81 tiles; matrix factors U, U': 2 tiles over K = frames x hidden)
+    const long t128 = (long)(M / 128) * ((N + 127) / 128);
+    if (t128 <= 128 && K >= 2048) {
+      int split = (int)(256 / t128);
+      split = split > 64 ? 64 : split;
+      while (split > 1 && K / 64 < 4 * split) --split;
+      if (split > 1 && (size_t)split * M * N <= ws_floats) {
+        GemmArgs g;
+        g.A = A; g.lda = K; g.W = W; g.M = M; g.N = N; g.K = K; g.out_f32 = ws; g.ldo = N; g.ksplit = split; g.slice_stride = (long)M * N;
+        int rc = launch_gemm(A_DENSE, E_F32, GEMM_DMA_128, g, s);
+        if (rc) return rc;
+        hipLaunchKernelGGL(slices_sum_kernel, dim3(cdiv((long)M * N / 4, 256)), dim3(256), 0, s, ws, out, (long)M * N / 4, split, (long)M * N);
+        DFOT_CHECK_HIP(hipGetLastError());
+        return DFOT_OK;
+      }
+    }
+  }
   int split = 1;
   if (target > 0) {
     const long tiles = (long)(M / 128) * ((N + 127) / 128);
@@ -862,6 +909,8 @@ int dfot_dit_train_reserve(dfot_dit_train_t h, int max_batch) {
     if (b.mh) { WS(b.x_mid, rows * hd); WS(b.m2, rows * hd); WS(b.u, rows * b.mh); WS(b.y, rows * hd); any_mlp = true; }
   }
   if (any_mlp) { WS(h->hbuf, rows * widest); WS(h->dh, rows * widest); }
+  h->wg_ws_floats = (size_t)3 * widest * hd;
+  WS(h->wg_ws, h->wg_ws_floats);
   WS(h->dX, rows * hd); WS(h->dX2, rows * hd); WS(h->stats, rows * 2); WS(h->delta, bhn);
   WS(h->dmod, (size_t)fp * h->ldt); WS(h->dmod_bf, (size_t)fp * h->ldt); WS(h->dmodT, (size_t)fp * h->ldt); WS(h->dbmod, (size_t)h->ldt);
   WS(h->dwmod, (size_t)h->ldt * hd); WS(h->dsemb, (size_t)fp * hd); WS(h->dwf, (size_t)256 * hd > (size_t)128 * h->P ? (size_t)256 * hd : (size_t)128 * h->P);
@@ -1028,20 +1077,20 @@ int dfot_dit_train_backward(dfot_dit_train_t h, const float* d_out, void* stream
       DFOT_CHECK_HIP(hipGetLastError());
       if ((rc = tr_gemm_bf16(h->da, hd, b.w_fc2T, (int)rows, mh, hd, nullptr, h->dh, mh, s))) return rc;        // dh = dy W2
       if ((rc = tr_transpose(h->da, h->T2, (int)rows, hd, s)) || (rc = tr_transpose(h->hbuf, h->T1, (int)rows, mh, s))) return rc;
-      if ((rc = tr_wgrad(h->T2, h->T1, hd, mh, (int)rows, G + b.o_fc2_w, s))) return rc;                           // dW2 = dy^T h
+      if ((rc = tr_wgrad(h->T2, h->T1, hd, mh, (int)rows, G + b.o_fc2_w, s, h->wg_ws, h->wg_ws_floats))) return rc;                           // dW2 = dy^T h
       hipLaunchKernelGGL(gelu_kernel, dim3(cdiv(rows * mh / 8, 256)), dim3(256), 0, s, b.u, (bf16*)nullptr, h->dh, rows * mh / 8);  // du
       hipLaunchKernelGGL(colsum_bf16_kernel, dim3(cdiv(mh, 256), cdiv(rows, 128)), dim3(256), 0, s, h->dh, G + b.o_fc1_b, rows, mh, (long)mh);
       DFOT_CHECK_HIP(hipGetLastError());
       if ((rc = tr_gemm_f32(h->dh, mh, b.w_fc1T, (int)rows, hd, mh, dY, hd, dY, s))) return rc;                    // dm2 = dY + du W1
       if ((rc = tr_transpose(h->dh, h->T1, (int)rows, mh, s)) || (rc = tr_transpose(b.m2, h->T2, (int)rows, hd, s))) return rc;
-      if ((rc = tr_wgrad(h->T1, h->T2, mh, hd, (int)rows, G + b.o_fc1_w, s))) return rc;                           // dW1 = du^T m2
+      if ((rc = tr_wgrad(h->T1, h->T2, mh, hd, (int)rows, G + b.o_fc1_w, s, h->wg_ws, h->wg_ws_floats))) return rc;                           // dW1 = du^T m2
       if ((rc = ln_bwd(b.x_mid, b.mod2))) return rc;
     }
     if (!b.matrix) {
       if ((rc = gate_bwd(b.a, b.mod + 2 * hd, G + b.o_proj_b))) return rc;
       if ((rc = tr_gemm_bf16(h->da, hd, b.w_projT, (int)rows, hd, hd, nullptr, h->dO, hd, s))) return rc;      // dO = da Wp
       if ((rc = tr_transpose(h->da, h->T1, (int)rows, hd, s)) || (rc = tr_transpose(b.o, h->T2, (int)rows, hd, s))) return rc;
-      if ((rc = tr_wgrad(h->T1, h->T2, hd, hd, (int)rows, G + b.o_proj_w, s))) return rc;  // dWp = da^T o
+      if ((rc = tr_wgrad(h->T1, h->T2, hd, hd, (int)rows, G + b.o_proj_w, s, h->wg_ws, h->wg_ws_floats))) return rc;  // dWp = da^T o
       if ((rc = launch_attention_bwd_delta(b.o, h->dO, hd, h->delta, nseq, c.num_heads, seq, h->d, s))) return rc;
       if ((rc = launch_attention_bwd(b.q, b.k, b.v, h->dO, hd, b.lse, h->delta, h->dq, h->dk, h->dv, nseq, c.num_heads, seq, h->d, s))) return rc;
       hipLaunchKernelGGL(qkv_grad_pack_kernel, dim3(cdiv(rows * (3 * hd / 8), 256)), dim3(256), 0, s, h->dq, h->dk, h->dv,
@@ -1050,7 +1099,7 @@ int dfot_dit_train_backward(dfot_dit_train_t h, const float* d_out, void* stream
       DFOT_CHECK_HIP(hipGetLastError());
       if ((rc = tr_gemm_f32(h->dqkv, 3 * hd, b.w_qkvT, (int)rows, hd, 3 * hd, dY, hd, dY, s))) return rc;       // dm = dY + dqkv Wqkv (in place)
       if ((rc = tr_transpose(h->dqkv, h->T1, (int)rows, 3 * hd, s)) || (rc = tr_transpose(b.m, h->T2, (int)rows, hd, s))) return rc;
-      if ((rc = tr_wgrad(h->T1, h->T2, 3 * hd, hd, (int)rows, G + b.o_qkv_w, s))) return rc;  // dWqkv = dqkv^T m
+      if ((rc = tr_wgrad(h->T1, h->T2, 3 * hd, hd, (int)rows, G + b.o_qkv_w, s, h->wg_ws, h->wg_ws_floats))) return rc;  // dWqkv = dqkv^T m
     } else {
       const bool bias = b.o_qkv_bias >= 0;
       const int fe = frames * E;
@@ -1060,13 +1109,13 @@ int dfot_dit_train_backward(dfot_dit_train_t h, const float* d_out, void* stream
       if (bias && (rc = frames_sum(h->da, G + b.o_proj_bias, (long)P * hd))) return rc;
       if ((rc = tr_gemm_bf16(h->da, hd, b.pv_s, (int)rows, hd, hd, nullptr, h->dO, hd, s))) return rc;            // ds = da V'^T  (V' stored (in, out))
       if ((rc = tr_transpose(b.sfac, h->T1, (int)rows, hd, s)) || (rc = tr_transpose(h->da, h->T2, (int)rows, hd, s))) return rc;
-      if ((rc = tr_wgrad(h->T1, h->T2, hd, hd, (int)rows, G + b.o_proj_v, s))) return rc;                          // dV'[in][out] = s^T da
+      if ((rc = tr_wgrad(h->T1, h->T2, hd, hd, (int)rows, G + b.o_proj_v, s, h->wg_ws, h->wg_ws_floats))) return rc;                          // dV'[in][out] = s^T da
       if ((rc = tr_transpose(h->dO, h->mt, P, hd, s, frames))) return rc;                                        // ds^T per frame [hd][P]
       if ((rc = tr_gemm_bf16(h->mt, P, b.pu_s, frames * hd, E, P, nullptr, h->do2, E, s, 0, hd))) return rc;       // do[f][e][d] = sum_p U'[e][p] ds[f][p][d]
       // dU'[e][p] = sum_{f,d} o[f][e][d] ds[f][p][d]: operands regrouped to [e][(f,d)] / [p][(f,d)]; E rows padded to 128
       DFOT_CHECK_HIP(hipMemsetAsync(h->perm_a, 0, (size_t)128 * fk * sizeof(bf16), s));
       if ((rc = permute(b.o2, h->perm_a, E)) || (rc = permute(h->dO, h->perm_b, P))) return rc;
-      if ((rc = tr_gemm_f32(h->perm_a, fk, h->perm_b, 128, P, (int)fk, h->dwf, P, nullptr, s))) return rc;
+      if ((rc = tr_wgrad(h->perm_a, h->perm_b, 128, P, (int)fk, h->dwf, s, h->wg_ws, h->wg_ws_floats))) return rc;
       DFOT_CHECK_HIP(hipMemcpyAsync(G + b.o_proj_u, h->dwf, (size_t)E * P * sizeof(float), hipMemcpyDeviceToDevice, s));
       // attention over the frames
       {
@@ -1079,14 +1128,14 @@ int dfot_dit_train_backward(dfot_dit_train_t h, const float* d_out, void* stream
       if (bias && (rc = frames_sum(h->dz, G + b.o_qkv_bias, (long)E * 3 * hd))) return rc;
       if ((rc = tr_gemm_bf16(h->dz, 3 * hd, b.v_s, fe, hd, 3 * hd, nullptr, h->dw1, hd, s))) return rc;           // dw1 = dz V^T  (V stored (in, out))
       if ((rc = tr_transpose(b.w1, h->T1, fe, hd, s)) || (rc = tr_transpose(h->dz, h->dqkv, fe, 3 * hd, s))) return rc;
-      if ((rc = tr_wgrad(h->T1, h->dqkv, hd, 3 * hd, fe, G + b.o_qkv_v, s))) return rc;                            // dV[in][out] = w1^T dz
+      if ((rc = tr_wgrad(h->T1, h->dqkv, hd, 3 * hd, fe, G + b.o_qkv_v, s, h->wg_ws, h->wg_ws_floats))) return rc;                            // dV[in][out] = w1^T dz
       if ((rc = tr_transpose(h->dw1, h->mt, E, hd, s, frames))) return rc;                                       // dw1^T per frame [hd][E]
       if ((rc = tr_gemm_bf16(h->mt, E, b.u_s, frames * hd, P, E, nullptr, h->dO, P, s, 0, hd))) return rc;         // dm[f][p][d] = sum_e U[p][e] dw1[f][e][d]
       hipLaunchKernelGGL(add_bf16_kernel, dim3(cdiv(rows * hd / 4, 256)), dim3(256), 0, s, dY, h->dO, rows * hd / 4);
       DFOT_CHECK_HIP(hipGetLastError());
       // dU[p][e] = sum_{f,d} m[f][p][d] dw1[f][e][d]
       if ((rc = permute(b.m, h->perm_a, P)) || (rc = permute(h->dw1, h->perm_b, E))) return rc;
-      if ((rc = tr_gemm_f32(h->perm_a, fk, h->perm_b, P, E, (int)fk, G + b.o_qkv_u, E, nullptr, s))) return rc;
+      if ((rc = tr_wgrad(h->perm_a, h->perm_b, P, E, (int)fk, G + b.o_qkv_u, s, h->wg_ws, h->wg_ws_floats))) return rc;
     }
     if ((rc = ln_bwd(b.x_in, b.mod))) return rc;
   }

@@ -58,6 +58,9 @@ struct GemmArgs {
   // tile to out_f32 with atomics: out must already hold the value to add to -- zeros, or the residual when resid == out_f32
   // (in-place residual GEMMs); the bias is added by slice 0.  For few output tiles and a long K
   int ksplit = 1;
+  // slice_stride > 0 (elements): slice s stores its partial tile with plain stores to out_f32 + s * slice_stride instead of
+  // atomics (the caller reduces the S partial outputs afterwards); no bias / residual / gate then
+  long slice_stride = 0;
 };
 
 enum GemmVariant {

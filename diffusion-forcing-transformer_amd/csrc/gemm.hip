@@ -360,14 +360,14 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int tile_inde
           const int r = p * 4 + (lane >> 4);
           f32x4 v = *reinterpret_cast<const f32x4*>(ep + r * EP_LD + cw) + b0;
           if (bias2d) v += *reinterpret_cast<const f32x4*>(g.bias + (long)((unsigned)(mw + r) % (unsigned)g.bias_rows) * g.N + col);
-          const long off = (mw + r) * g.ldo + col;
+          const long off = (mw + r) * g.ldo + col + (ksplit > 1 ? (long)kslice * g.slice_stride : 0L);
           if (has_gate) {
             long gr = (unsigned)(mw + r) / (unsigned)g.gate_rows;  // 32-bit division (a 64-bit one costs ~100 instructions)
             if (g.gate_index) gr = g.gate_index[gr];
             v *= *reinterpret_cast<const f32x4*>(g.gate + gr * g.ldg + col);
           }
           if (has_res && ksplit == 1) v += *reinterpret_cast<const f32x4*>(g.resid + off);
-          if (ksplit > 1) {  // out already holds the residual (resid == out, checked by the launcher) or zeros
+          if (ksplit > 1 && g.slice_stride == 0) {  // out already holds the residual (resid == out, checked by the launcher) or zeros
 #pragma unroll
             for (int j = 0; j < 4; ++j) atomicAdd(g.out_f32 + off + j, v[j]);
           } else {
@@ -736,6 +736,8 @@ int launch_gemm(int amode, int epi, int variant, const GemmArgs& g, hipStream_t 
     DFOT_REQUIRE(epi == E_F32 && g.gate_rows > 0 && g.M % g.gate_rows == 0 && g.ldg % 4 == 0, DFOT_ERR_SHAPE,
                  "gemm: gate needs the fp32 epilogue, gate_rows dividing M and ldg %% 4 == 0");
   }
+  if (g.ksplit > 1 && g.slice_stride > 0)
+    DFOT_REQUIRE(!g.bias && !g.resid, DFOT_ERR_ARG, "gemm: split-K into partial outputs takes no bias / residual");
   if (g.ksplit > 1)
     DFOT_REQUIRE(epi == E_F32 && amode == A_DENSE && !g.bias_rows && (!g.resid || g.resid == g.out_f32) && !g.gate && !g.gn_part &&
                      g.K / BK >= 2 * g.ksplit, DFOT_ERR_ARG,

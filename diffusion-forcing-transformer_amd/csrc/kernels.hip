@@ -935,11 +935,13 @@ int launch_vloss_grad(const float* x, const float* noise, const float* v, const 
   return DFOT_OK;
 }
 
-// out[0] += sum x^2 (caller zeroes out); grid-stride, one atomic per workgroup
-__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, long n, float* __restrict__ out) {
+// out[0] = sum x^2, bit-reproducible for a given input (data-parallel replicas must compute the SAME clip coefficient from the
+// same all-reduced gradients, or they drift apart): fixed grid, per-workgroup partials, one workgroup adds them in a fixed order
+constexpr int SUMSQ_BLOCKS = 1024;
+__global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restrict__ x, long n, float* __restrict__ part) {
   __shared__ float red[4];
   float acc = 0.f;
-  for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (long)gridDim.x * 1024) {
+  for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (long)SUMSQ_BLOCKS * 1024) {
     if (i + 3 < n) {
       const float4v v = *reinterpret_cast<const float4v*>(x + i);
       acc += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
@@ -951,11 +953,24 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x,
   for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(out, (red[0] + red[1]) + (red[2] + red[3]));
+  if (threadIdx.x == 0) part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ __launch_bounds__(256) void sumsq_final_kernel(const float* __restrict__ part, float* __restrict__ out) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < SUMSQ_BLOCKS; i += 256) acc += part[i];
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) out[0] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 int launch_sumsq(const float* x, long n, float* out, hipStream_t s) {
   DFOT_REQUIRE(((uintptr_t)x & 15) == 0, DFOT_ERR_ARG, "sumsq: buffer must be 16-byte aligned");
-  hipLaunchKernelGGL(sumsq_kernel, dim3(cdiv(n, 1024) < 2048 ? cdiv(n, 1024) : 2048), dim3(256), 0, s, x, n, out);
+  static float* part = nullptr;  // one per process (one stream of optimizer steps)
+  if (!part) DFOT_CHECK_HIP(hipMalloc(&part, SUMSQ_BLOCKS * sizeof(float)));
+  hipLaunchKernelGGL(sumsq_partial_kernel, dim3(SUMSQ_BLOCKS), dim3(256), 0, s, x, n, part);
+  hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, s, part, out);
   DFOT_CHECK_HIP(hipGetLastError());
   return DFOT_OK;
 }
