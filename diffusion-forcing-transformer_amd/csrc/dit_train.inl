@@ -321,22 +321,26 @@ __global__ __launch_bounds__(256) void pe_wgrad_kernel(const float* __restrict__
 }
 
 // ---- MatrixDiTBlock (factorized matrix attention, variant 1) ------------------------------------------------------------
-// backward of matrix_attn_kernel: z [B*L*E][3h] (q|k|v), d_o [B*L*E][h] -> dz [B*L*E][3h].  One workgroup per (video, c, r):
-// pass A: S = scale <q_l, k_l'> and dP = <do_l, v_l'> over the head's hn*hd entries (a wave per pair), softmax, dS = P (dP - sum P dP) scale
-// pass B: dq_l = sum_l' dS[l][l'] k_l', dk_l' = sum_l dS[l][l'] q_l, dv_l' = sum_l P[l][l'] do_l   (operands re-read: L2 hits)
-__global__ __launch_bounds__(256) void matrix_attn_bwd_kernel(const bf16* __restrict__ z, const bf16* __restrict__ d_o, bf16* __restrict__ dz,
-                                                              int L, int E, int h, int cc, int rr, float scale) {
-  __shared__ float sS[32 * 32], sP[32 * 32];
+// backward of matrix_attn_kernel: z [B*L*E][3h] (q|k|v), d_o [B*L*E][h] -> dz [B*L*E][3h].  The hn*hd entries of one (video, c, r)
+// head are split over MA_CHUNKS workgroups:
+// pass A (matrix_attn_bwd_scores): partial S = <q_l, k_l'> and dP = <do_l, v_l'> of the chunk, added into sc[head][2][L*L]
+// pass B (matrix_attn_bwd_apply): softmax and dS = P (dP - sum P dP) scale from sc (L x L, recomputed per workgroup), then
+//   dq_l = sum_l' dS[l][l'] k_l', dk_l' = sum_l dS[l][l'] q_l, dv_l' = sum_l P[l][l'] do_l for the chunk's entries (L2 hits)
+constexpr int MA_CHUNKS = 8;
+__global__ __launch_bounds__(256) void matrix_attn_bwd_scores_kernel(const bf16* __restrict__ z, const bf16* __restrict__ d_o, float* __restrict__ sc,
+                                                                     int L, int E, int h, int cc, int rr) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int b = blockIdx.x / (cc * rr), c = (blockIdx.x / rr) % cc, r = blockIdx.x % rr;
+  const int head = blockIdx.x, chunk = blockIdx.y;
+  const int b = head / (cc * rr), c = (head / rr) % cc, r = head % rr;
   const int hn = E / cc, hd = h / rr, ne = hn * hd / 4;
+  const int per = (ne + MA_CHUNKS - 1) / MA_CHUNKS, e0 = chunk * per, e1 = e0 + per < ne ? e0 + per : ne;
   const long ldz = 3L * h;
   auto zoff = [&](int l, int n) { return (((long)b * L + l) * E + c * hn + n) * ldz + r * hd; };
   auto ooff = [&](int l, int n) { return (((long)b * L + l) * E + c * hn + n) * (long)h + r * hd; };
   for (int pi = wave; pi < L * L; pi += 4) {
     const int l = pi / L, l2 = pi % L;
     float as = 0.f, ap = 0.f;
-    for (int e = lane; e < ne; e += 64) {
+    for (int e = e0 + lane; e < e1; e += 64) {
       const int n = (e * 4) / hd, d = (e * 4) % hd;
       const bf16x4 q4 = *reinterpret_cast<const bf16x4*>(z + zoff(l, n) + d);
       const bf16x4 k4 = *reinterpret_cast<const bf16x4*>(z + zoff(l2, n) + h + d);
@@ -351,9 +355,24 @@ __global__ __launch_bounds__(256) void matrix_attn_bwd_kernel(const bf16* __rest
     as = wave_sum(as);
     ap = wave_sum(ap);
     if (lane == 0) {
-      sS[pi] = as * scale;
-      sP[pi] = ap;  // dP for now
+      atomicAdd(sc + ((long)head * 2) * L * L + pi, as);
+      atomicAdd(sc + ((long)head * 2 + 1) * L * L + pi, ap);
     }
+  }
+}
+__global__ __launch_bounds__(256) void matrix_attn_bwd_apply_kernel(const bf16* __restrict__ z, const bf16* __restrict__ d_o, const float* __restrict__ sc,
+                                                                    bf16* __restrict__ dz, int L, int E, int h, int cc, int rr, float scale) {
+  __shared__ float sS[32 * 32], sP[32 * 32];
+  const int head = blockIdx.x, chunk = blockIdx.y;
+  const int b = head / (cc * rr), c = (head / rr) % cc, r = head % rr;
+  const int hn = E / cc, hd = h / rr, ne = hn * hd / 4;
+  const int per = (ne + MA_CHUNKS - 1) / MA_CHUNKS, e0 = chunk * per, e1 = e0 + per < ne ? e0 + per : ne;
+  const long ldz = 3L * h;
+  auto zoff = [&](int l, int n) { return (((long)b * L + l) * E + c * hn + n) * ldz + r * hd; };
+  auto ooff = [&](int l, int n) { return (((long)b * L + l) * E + c * hn + n) * (long)h + r * hd; };
+  for (int i = threadIdx.x; i < L * L; i += 256) {
+    sS[i] = sc[((long)head * 2) * L * L + i] * scale;
+    sP[i] = sc[((long)head * 2 + 1) * L * L + i];
   }
   __syncthreads();
   if (threadIdx.x < L) {
@@ -379,7 +398,7 @@ __global__ __launch_bounds__(256) void matrix_attn_bwd_kernel(const bf16* __rest
     }
   }
   __syncthreads();
-  for (int e = threadIdx.x; e < ne; e += 256) {
+  for (int e = e0 + threadIdx.x; e < e1; e += 256) {
     const int n = (e * 4) / hd, d = (e * 4) % hd;
     for (int l = 0; l < L; ++l) {  // dq_l
       float a[4] = {0.f, 0.f, 0.f, 0.f};
@@ -515,12 +534,13 @@ struct dfot_dit_train_s {
   const float* x_saved = nullptr;  // the forward's input (caller keeps it alive until backward)
   float *feat = nullptr, *h1 = nullptr, *a1 = nullptr, *cemb = nullptr, *mod_table = nullptr, *X = nullptr, *x_fin = nullptr;
   dfot::bf16* semb = nullptr;
-  float *dX = nullptr, *dX2 = nullptr, *stats = nullptr, *delta = nullptr, *dmod = nullptr, *dwmod = nullptr, *dsemb = nullptr, *dwf = nullptr;
+  float *dX = nullptr, *dX2 = nullptr, *stats = nullptr, *delta = nullptr, *dmod = nullptr, *dsemb = nullptr, *dwf = nullptr;
   float *dc = nullptr, *da1 = nullptr, *dh1 = nullptr, *dbmod = nullptr, *scratch_f = nullptr;
   dfot::bf16 *da = nullptr, *dO = nullptr, *dq = nullptr, *dk = nullptr, *dv = nullptr, *dqkv = nullptr, *T1 = nullptr,
              *T2 = nullptr, *dmod_bf = nullptr, *dmodT = nullptr, *sembT = nullptr, *dyp = nullptr, *dyt = nullptr, *mfin = nullptr, *hbuf = nullptr,
              *dh = nullptr;
   // matrix-block workspace
+  float* ma_sc = nullptr;  // matrix attention backward: per-head (S, dP) [L*L] partial sums
   float* wg_ws = nullptr;  // partial outputs of split-K weight-gradient GEMMs
   size_t wg_ws_floats = 0;
   dfot::bf16 *mt = nullptr, *do2 = nullptr, *dz = nullptr, *dw1 = nullptr, *perm_a = nullptr, *perm_b = nullptr;
@@ -913,12 +933,13 @@ int dfot_dit_train_reserve(dfot_dit_train_t h, int max_batch) {
   WS(h->wg_ws, h->wg_ws_floats);
   WS(h->dX, rows * hd); WS(h->dX2, rows * hd); WS(h->stats, rows * 2); WS(h->delta, bhn);
   WS(h->dmod, (size_t)fp * h->ldt); WS(h->dmod_bf, (size_t)fp * h->ldt); WS(h->dmodT, (size_t)fp * h->ldt); WS(h->dbmod, (size_t)h->ldt);
-  WS(h->dwmod, (size_t)h->ldt * hd); WS(h->dsemb, (size_t)fp * hd); WS(h->dwf, (size_t)256 * hd > (size_t)128 * h->P ? (size_t)256 * hd : (size_t)128 * h->P);
+  WS(h->dsemb, (size_t)fp * hd); WS(h->dwf, (size_t)256 * hd > (size_t)128 * h->P ? (size_t)256 * hd : (size_t)128 * h->P);
   WS(h->dc, (size_t)frames * hd); WS(h->da1, (size_t)frames * hd); WS(h->dh1, (size_t)frames * hd); WS(h->scratch_f, (size_t)hd);
   WS(h->da, rows * hd); WS(h->dO, rows * hd); WS(h->dq, qsz); WS(h->dk, qsz); WS(h->dv, qsz);
   WS(h->dqkv, rows * 3 * hd); WS(h->T1, rows * widest); WS(h->T2, rows * hd); WS(h->dyp, rows * 64); WS(h->dyt, (size_t)256 * rows);
   WS(h->mfin, rows * hd);
   if (facmat) {
+    WS(h->ma_sc, (size_t)max_batch * c.num_col_heads * c.num_row_heads * 2 * c.max_tokens * c.max_tokens);
     WS(h->mt, rows * hd); WS(h->do2, fe * hd); WS(h->dz, fe * 3 * hd); WS(h->dw1, fe * hd);
     WS(h->perm_a, (size_t)(h->P > 128 ? h->P : 128) * frames * hd); WS(h->perm_b, (size_t)(h->P > 128 ? h->P : 128) * frames * hd);
   }
@@ -1120,7 +1141,11 @@ int dfot_dit_train_backward(dfot_dit_train_t h, const float* d_out, void* stream
       // attention over the frames
       {
         const int hn = E / c.num_col_heads, hdr = hd / c.num_row_heads;
-        hipLaunchKernelGGL(matrix_attn_bwd_kernel, dim3(batch * c.num_col_heads * c.num_row_heads), dim3(256), 0, s, b.z, h->do2, h->dz, tokens, E, hd,
+        const int nheads = batch * c.num_col_heads * c.num_row_heads;
+        DFOT_CHECK_HIP(hipMemsetAsync(h->ma_sc, 0, (size_t)nheads * 2 * tokens * tokens * sizeof(float), s));
+        hipLaunchKernelGGL(matrix_attn_bwd_scores_kernel, dim3(nheads, MA_CHUNKS), dim3(256), 0, s, b.z, h->do2, h->ma_sc, tokens, E, hd,
+                           c.num_col_heads, c.num_row_heads);
+        hipLaunchKernelGGL(matrix_attn_bwd_apply_kernel, dim3(nheads, MA_CHUNKS), dim3(256), 0, s, b.z, h->do2, h->ma_sc, h->dz, tokens, E, hd,
                            c.num_col_heads, c.num_row_heads, 1.0f / sqrtf((float)hn * (float)hdr));
         DFOT_CHECK_HIP(hipGetLastError());
       }
@@ -1152,9 +1177,11 @@ int dfot_dit_train_backward(dfot_dit_train_t h, const float* d_out, void* stream
   hipLaunchKernelGGL(pack_transpose_kernel, dim3(cdiv((long)fp * h->ldt, 256)), dim3(256), 0, s, h->dmod, h->dmodT, fp, (int)h->ldt);
   DFOT_CHECK_HIP(hipGetLastError());
   if ((rc = tr_transpose(h->semb, h->sembT, fp, hd, s))) return rc;
-  if ((rc = tr_gemm_f32(h->dmodT, fp, h->sembT, (int)h->ldt, hd, fp, h->dwmod, hd, nullptr, s))) return rc;   // dW_mod = dmod^T SiLU(c)
+  // dW_mod = dmod^T SiLU(c), one GEMM per modulation Linear written straight into its gradient tensor (K = frames is short: the
+  // fp32 output dominates, so it is written once, where it belongs)
   auto scatter = [&](long col, int nrow, long o_w, long o_b) -> int {
-    DFOT_CHECK_HIP(hipMemcpyAsync(G + o_w, h->dwmod + col * hd, (size_t)nrow * hd * sizeof(float), hipMemcpyDeviceToDevice, s));
+    int r = tr_gemm_f32(h->dmodT + col * fp, fp, h->sembT, nrow, hd, fp, G + o_w, hd, nullptr, s);
+    if (r) return r;
     DFOT_CHECK_HIP(hipMemcpyAsync(G + o_b, h->dbmod + col, (size_t)nrow * sizeof(float), hipMemcpyDeviceToDevice, s));
     return DFOT_OK;
   };
