@@ -230,3 +230,39 @@ def test_difference_dit_backward_matches_autograd(name):
     print(f"DifferenceDiT3D backward ({name}): worst gradient rel-L2 {worst[1]:.2e} at {worst[0]}")
     for n, t in ps.items():
         assert rel(grads[n], t.grad) < 5e-2, (n, rel(grads[n], t.grad))
+
+
+def test_difference_training_step_loss_and_accumulation():
+    """DifferenceDFoTVideo.training_step front end (torch.diff + interleaved merge, doubled levels / masks) -> loss vs the oracle's
+    discrete loss on the merged tokens; accumulate() over two micro-batches equals one backward over both"""
+    import dfot_amd
+    from oracle import dit as odit, sampler as osm, schedule as sch
+    ocfg = odit.DiffDiTConfig(hidden_size=128, depth=1, num_heads=4, in_channels=4, resolution=(16, 8), embed_col_dim=64, num_row_heads=4)
+    params = odit.diff_seeded_params(ocfg, 11)
+    cfg = dict(variant="factorized_matrix_attention", pos_emb_type="sinusoidal_2d", merge_type="interleaved", patch_size=1, embed_col_dim=64,
+               embed_row_dim=128, num_heads=4, num_col_heads=1, num_row_heads=4, depth=1, mlp_ratio=4.0, spatial_mlp_ratio=4.0, use_bias=True)
+    tr = dfot_amd.DiT3DTrainer(cfg, x_shape=(4, 16, 8), max_tokens=5, loss_weighting=dict(strategy="fused_min_snr", cum_snr_decay=0.9))
+    tr.load_state_dict(params, strict=True)
+    g = torch.Generator().manual_seed(6)
+    frames = torch.randn(4, 5, 4, 16, 8, generator=g)
+    k = torch.randint(0, 1000, (4, 5), generator=g)
+    noise = torch.randn(4, 10, 4, 16, 8, generator=g)
+    masks = torch.ones(4, 5)
+    masks[0, 4] = 0
+    loss = float(tr.difference_loss_and_grads(frames, k, noise, masks).item())
+    full = tr.grads.clone()
+    # oracle: the reference's merge (difference first) and DiscreteDiffusion.forward on the merged tokens
+    merge = lambda a, b: torch.stack([a, b], dim=2).flatten(1, 2)
+    xs = merge(torch.diff(frames, dim=1, prepend=frames[:, :1]), frames)
+    kk, mm = merge(k, k), merge(masks, masks)
+    model = lambda x, lv, c, m: odit.diff_forward(params, ocfg, x, lv)
+    _, per_el = osm.discrete_training_loss(model, sch.build_tables(beta_schedule="cosine"), xs, kk, noise.clamp(-20, 20), strategy="fused_min_snr",
+                                           cum_snr_decay=0.9)
+    ref = float((per_el * mm[..., None, None, None]).mean())
+    assert abs(loss - ref) < 2e-2 * abs(ref), (loss, ref)
+    # two micro-batches of 2 videos, accumulated, = the mean of their gradients = the gradient of the 4-video batch
+    for sl in (slice(0, 2), slice(2, 4)):
+        tr.difference_loss_and_grads(frames[sl], k[sl], noise[sl], masks[sl])
+        tr.accumulate()
+    acc = tr._acc / tr._acc_n
+    assert rel(acc.cpu(), full.cpu()) < 2e-2
