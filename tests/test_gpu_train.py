@@ -266,3 +266,44 @@ def test_difference_training_step_loss_and_accumulation():
         tr.accumulate()
     acc = tr._acc / tr._acc_n
     assert rel(acc.cpu(), full.cpu()) < 2e-2
+
+
+@pytest.mark.parametrize("tag", ["dit", "diff"])
+def test_training_gradients_vs_reference_fixture(tag):
+    """loss and gradients of the reference's own training step (tests/golden/training_grads.npz, differentiated by the reference's
+    autograd on CPU) vs the engine: gradient norm of every parameter and the stored gradient tensors"""
+    import os
+    import dfot_amd
+    from conftest import GOLDEN
+    from oracle import dit as odit
+    g = np.load(os.path.join(GOLDEN, "training_grads.npz"))
+    xs, k, masks = (torch.from_numpy(g[n]) for n in ("xs", "k", "masks"))
+    lw = dict(strategy="fused_min_snr", cum_snr_decay=0.96)
+    if tag == "dit":
+        ocfg, params, tr = _tiny_trainer(depth=2, seed=2)
+        tr.loss_weighting = lw
+        loss = tr.loss_and_grads(xs, k, torch.from_numpy(g["dit_noise"]), masks)
+    else:
+        ocfg = odit.DiffDiTConfig(hidden_size=128, depth=2, num_heads=4, in_channels=4, resolution=(16, 8), embed_col_dim=64, num_row_heads=4)
+        params = odit.diff_seeded_params(ocfg, 3)
+        cfg = dict(variant="factorized_matrix_attention", pos_emb_type="sinusoidal_2d", merge_type="interleaved", patch_size=1, embed_col_dim=64,
+                   embed_row_dim=128, num_heads=4, num_col_heads=1, num_row_heads=4, depth=2, mlp_ratio=4.0, spatial_mlp_ratio=4.0, use_bias=True)
+        tr = dfot_amd.DiT3DTrainer(cfg, x_shape=(4, 16, 8), max_tokens=5, loss_weighting=lw)
+        tr.load_state_dict(params, strict=True)
+        loss = tr.difference_loss_and_grads(xs, k, torch.from_numpy(g["diff_noise"]), masks)
+    ref_loss = float(g[f"{tag}_loss"])
+    assert abs(float(loss.item()) - ref_loss) < 2e-2 * abs(ref_loss)
+    grads = {n: t.cpu() for n, t in tr.grad_dict().items()}
+    names = [str(n) for n in g[f"{tag}_names"]]
+    assert names == list(grads)
+    for n, ref_norm in zip(names, g[f"{tag}_norms"]):
+        assert abs(float(grads[n].norm()) - ref_norm) <= 3e-2 * ref_norm + 1e-7, (n, float(grads[n].norm()), ref_norm)
+    worst = 0.0
+    for key in g.files:
+        if key.startswith(f"{tag}_grad/"):
+            n = key.split("/", 1)[1]
+            ref = torch.from_numpy(g[key])
+            if float(ref.norm()) > 1e-6:
+                worst = max(worst, rel(grads[n], ref))
+    print(f"{tag}: worst stored-gradient rel-L2 vs the reference {worst:.2e}")
+    assert worst < 5e-2

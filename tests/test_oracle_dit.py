@@ -226,3 +226,35 @@ def test_refinement_sampler_vs_reference_fixture():
     nfn = osm.default_noise_fn(torch.Generator().manual_seed(0))
     out4 = osm.Sampler(cfg, diff, None, nfn).sample_sequence_refine(2, 2, 2, T(g["xs"])[:, :4], T(g["mask"])[:, :4], None, scheme, length=4)
     assert torch.isnan(out4).any()
+
+
+def test_training_gradients_vs_reference_fixture():
+    """the reference's own training loss (diffusion_model(xs, None, k) -> _reweight_loss with masks) differentiated by the reference:
+    the oracle's restatement under autograd reproduces the loss, every gradient norm and the stored gradients (both K600 families)"""
+    g = load("training_grads.npz")
+    xs, k, masks = T(g["xs"]), T(g["k"]), T(g["masks"])
+    tb = sch.build_tables(beta_schedule="cosine")
+    merge = lambda a, b: torch.stack([a, b], dim=2).flatten(1, 2)
+    for tag in ("dit", "diff"):
+        if tag == "dit":
+            params, fwd = odit.seeded_params(SMALL, 2), lambda ps, x, lv: odit.forward(ps, SMALL, x, lv)
+            x_in, k_in, m_in = xs, k, masks
+        else:
+            params, fwd = odit.diff_seeded_params(DIFF_TINY, 3), lambda ps, x, lv: odit.diff_forward(ps, DIFF_TINY, x, lv)
+            x_in, k_in, m_in = merge(torch.diff(xs, dim=1, prepend=xs[:, :1]), xs), merge(k, k), merge(masks, masks)
+        assert digest(params) == str(g[f"{tag}_digest"])
+        ps = {n: t.clone().requires_grad_() for n, t in params.items()}
+        _, per_el = osm.discrete_training_loss(lambda x, lv, c, m: fwd(ps, x, lv), tb, x_in, k_in, T(g[f"{tag}_noise"]).clamp(-20, 20),
+                                               strategy="fused_min_snr", cum_snr_decay=0.96)
+        loss = (per_el * m_in[..., None, None, None]).mean()
+        loss.backward()
+        assert abs(loss.item() - float(g[f"{tag}_loss"])) < 1e-5 * abs(float(g[f"{tag}_loss"]))
+        names = [str(n) for n in g[f"{tag}_names"]]
+        assert names == list(ps)
+        for n, ref_norm in zip(names, g[f"{tag}_norms"]):
+            assert abs(float(ps[n].grad.norm()) - ref_norm) <= 2e-4 * ref_norm + 1e-9, (tag, n)
+        stored = [key for key in g.files if key.startswith(f"{tag}_grad/")]
+        assert len(stored) >= 8
+        for key in stored:
+            n = key.split("/", 1)[1]
+            torch.testing.assert_close(ps[n].grad, T(g[key]), rtol=2e-3, atol=1e-6 + 2e-4 * float(T(g[key]).abs().max()))

@@ -24,6 +24,9 @@ loaded strictly into the reference module and re-created bit-identically by the 
   sampler_refine.npz  DFoTVideo._sample_sequence_refine (refinement ladder: DDIM steps + q_sample_from_x_k re-noising), small DiT,
                     RE10K schedule, 6 DDIM indices, goback_length 2, n_goback 2, conditional guidance (+ the fact that the
                     reference returns NaN for a padded window)
+  training_grads.npz  gradients of the reference's own training loss: DFoTVideo (small DiT, cosine / pred_v / fused_min_snr) and
+                    DifferenceDFoTVideo (tiny difference model): diffusion_model(xs, None, k) with recorded noise -> _reweight_loss with
+                    masks -> backward(); stored: the loss, the L2 norm of every parameter gradient and the full gradient of a few tensors
   sampler_k600.npz  DFoTVideo._predict_videos with DiscreteDiffusion (cosine, pred_v, integer levels): 5 tokens,
                     context 2, 4 DDIM steps, vanilla history guidance 2.0 (small DiT) with the injected noise
 """
@@ -202,6 +205,55 @@ def hg_temporal_fixture(R):
     save("hg_temporal.npz", **out)
 
 
+@torch.enable_grad()
+def training_grads_fixture(R):
+    print("training grads")
+    A = R["AttrDict"]
+    out = {}
+    small = odit.DiTConfig(hidden_size=128, depth=2, num_heads=4, patch_size=1, in_channels=4, resolution=(16, 8), max_tokens=5)
+    algo = R["DFoTVideo"](video_cfg(A, small, sampling_steps=4, hg=dict(name="conditional"))).train()
+    ps = odit.seeded_params(small, 2)
+    algo.diffusion_model.model.load_state_dict(ps, strict=True)
+    oc = odit.DiffDiTConfig(**DIFF_TINY)
+    cfg = video_cfg(A, small, sampling_steps=3, hg=dict(name="conditional"))
+    cfg["backbone"] = A(dict(name="difference_dit3d", variant="factorized_matrix_attention", pos_emb_type="sinusoidal_2d",
+                             merge_type="interleaved", patch_size=1, hidden_size=None, embed_col_dim=oc.embed_col_dim,
+                             embed_row_dim=oc.hidden_size, num_heads=oc.num_heads, num_col_heads=1, num_row_heads=oc.num_row_heads,
+                             depth=oc.depth, mlp_ratio=4.0, spatial_mlp_ratio=4.0, use_bias=True, matrix_block="matrix",
+                             flatten_matrix_rope=False, matrix_multi_token=False, use_gradient_checkpointing=False))
+    dalgo = R["DifferenceDFoTVideo"](cfg).train()
+    dps = odit.diff_seeded_params(oc, 3)
+    dalgo.diffusion_model.model.load_state_dict(dps, strict=True)
+    g = torch.Generator().manual_seed(21)
+    xs = torch.randn(2, 5, 4, 16, 8, generator=g)
+    k = torch.randint(0, 1000, (2, 5), generator=g)
+    masks = torch.ones(2, 5)
+    masks[1, 3] = 0
+    for tag, al, weights in (("dit", algo, ps), ("diff", dalgo, dps)):
+        model = al.diffusion_model.model
+        for p_ in model.parameters():
+            p_.grad = None
+        if tag == "diff":  # DifferenceDFoTVideo.training_step: differences interleaved with the frames, doubled levels and masks
+            x_in = al.merge_tensors(torch.diff(xs, dim=1, prepend=xs[:, :1]), xs)
+            k_in, m_in = al.merge_tensors(k, k), al.merge_tensors(masks, masks)
+        else:
+            x_in, k_in, m_in = xs, k, masks
+        with RandnRecorder() as rec:
+            _, loss = al.diffusion_model(x_in, None, k=k_in)
+        loss = al._reweight_loss(loss, m_in)
+        loss.backward()
+        grads = {n: p_.grad.detach().clone() for n, p_ in model.named_parameters()}
+        out[f"{tag}_loss"] = loss.detach()
+        out[f"{tag}_noise"] = rec.draws[0]
+        out[f"{tag}_names"] = np.array(list(grads))
+        out[f"{tag}_norms"] = np.array([float(v.norm()) for v in grads.values()], np.float64)
+        for n, v in grads.items():
+            if v.numel() <= 4096 or n.endswith(("attn.qkv_u", "attn.proj_u")):
+                out[f"{tag}_grad/{n}"] = v
+        out[f"{tag}_digest"] = np.array(weights_digest(weights))
+    save("training_grads.npz", xs=xs, k=k, masks=masks, **out)
+
+
 @torch.no_grad()
 def refine_fixture(R):
     print("sampler refine")
@@ -264,6 +316,8 @@ def main():
     A = R["AttrDict"]
     if os.environ.get("ONLY") == "refine":
         return refine_fixture(R)
+    if os.environ.get("ONLY") == "training_grads":
+        return training_grads_fixture(R)
 
     print("dit tiny")
     tiny = odit.DiTConfig(hidden_size=128, depth=3, num_heads=4, patch_size=1, in_channels=4, resolution=(16, 8), max_tokens=5)
@@ -327,6 +381,7 @@ def main():
          alphas_cumprod=dm.alphas_cumprod, sqrt_alphas_cumprod=dm.sqrt_alphas_cumprod,
          sqrt_one_minus_alphas_cumprod=dm.sqrt_one_minus_alphas_cumprod, **arrays)
     refine_fixture(R)
+    training_grads_fixture(R)
     diff_sampler_fixture(R)
     hg_temporal_fixture(R)
     training_noise_fixture(R)
