@@ -173,7 +173,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16* __restrict
 
 // ---------------------------------------------------------------------------------------------------------------
 template <int D, int DC = D, int DW = D>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K,
+__global__ __launch_bounds__(256, (DC <= 96 ? 2 : 1)) void attn_bwd_dkv_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K,
                                                            const bf16* __restrict__ V, const bf16* __restrict__ dO, long ldo,
                                                            const float* __restrict__ L2, const float* __restrict__ delta,
                                                            bf16* __restrict__ dK, bf16* __restrict__ dV, int N, int heads, int d,
