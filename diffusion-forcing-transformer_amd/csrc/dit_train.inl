@@ -28,7 +28,7 @@ struct TrainBlock {
   long o_mod2_w = 0, o_mod2_b = 0, o_fc1_w = 0, o_fc1_b = 0, o_fc2_w = 0, o_fc2_b = 0, mod2 = 0;
   bf16 *w_fc1 = nullptr, *w_fc1T = nullptr, *w_fc2 = nullptr, *w_fc2T = nullptr;
   float* x_mid = nullptr;
-  bf16 *m2 = nullptr, *u = nullptr, *y = nullptr;
+  bf16 *m2 = nullptr, *u = nullptr, *hact = nullptr, *y = nullptr;
   // MatrixDiTBlock: qkv = U^T m V + bias[E][3h] per frame, o = attention over the frames, a = U'^T o V' + bias'[P][h]
   // parameters are stored (in, out): qkv_u [P][E], qkv_v [h][3h], proj_u [E][P], proj_v [h][h]
   long o_qkv_u = 0, o_qkv_v = 0, o_qkv_bias = -1, o_proj_u = 0, o_proj_v = 0, o_proj_bias = -1;
@@ -537,8 +537,7 @@ struct dfot_dit_train_s {
   float *dX = nullptr, *dX2 = nullptr, *stats = nullptr, *delta = nullptr, *dmod = nullptr, *dsemb = nullptr, *dwf = nullptr;
   float *dc = nullptr, *da1 = nullptr, *dh1 = nullptr, *dbmod = nullptr, *scratch_f = nullptr;
   dfot::bf16 *da = nullptr, *dO = nullptr, *dq = nullptr, *dk = nullptr, *dv = nullptr, *dqkv = nullptr, *T1 = nullptr,
-             *T2 = nullptr, *dmod_bf = nullptr, *dmodT = nullptr, *sembT = nullptr, *dyp = nullptr, *dyt = nullptr, *mfin = nullptr, *hbuf = nullptr,
-             *dh = nullptr;
+             *T2 = nullptr, *dmod_bf = nullptr, *dmodT = nullptr, *sembT = nullptr, *dyp = nullptr, *dyt = nullptr, *mfin = nullptr, *dh = nullptr;
   // matrix-block workspace
   float* ma_sc = nullptr;  // matrix attention backward: per-head (S, dP) [L*L] partial sums
   float* wg_ws = nullptr;  // partial outputs of split-K weight-gradient GEMMs
@@ -926,9 +925,9 @@ int dfot_dit_train_reserve(dfot_dit_train_t h, int max_batch) {
     } else {
       WS(b.w1, fe * hd); WS(b.z, fe * 3 * hd); WS(b.o2, fe * hd); WS(b.sfac, rows * hd);
     }
-    if (b.mh) { WS(b.x_mid, rows * hd); WS(b.m2, rows * hd); WS(b.u, rows * b.mh); WS(b.y, rows * hd); any_mlp = true; }
+    if (b.mh) { WS(b.x_mid, rows * hd); WS(b.m2, rows * hd); WS(b.u, rows * b.mh); WS(b.hact, rows * b.mh); WS(b.y, rows * hd); any_mlp = true; }
   }
-  if (any_mlp) { WS(h->hbuf, rows * widest); WS(h->dh, rows * widest); }
+  if (any_mlp) { WS(h->dh, rows * widest); }
   h->wg_ws_floats = (size_t)3 * widest * hd;
   WS(h->wg_ws, h->wg_ws_floats);
   WS(h->dX, rows * hd); WS(h->dX2, rows * hd); WS(h->stats, rows * 2); WS(h->delta, bhn);
@@ -1022,10 +1021,13 @@ int dfot_dit_train_forward(dfot_dit_train_t h, const float* x, const int32_t* no
     if ((rc = combine(b.a, b.mod + 2 * hd, after_attn))) return rc;
     if (b.mh) {
       if ((rc = launch_ln_mod(b.x_mid, h->X, b.m2, h->mod_table, h->idx, h->ldt, b.mod2, hd, P, (int)rows, c.eps, frames - 1, s))) return rc;
-      if ((rc = tr_gemm_bf16(b.m2, hd, b.w_fc1, (int)rows, b.mh, hd, p + b.o_fc1_b, b.u, b.mh, s))) return rc;
-      hipLaunchKernelGGL(gelu_kernel, dim3(cdiv(rows * b.mh / 8, 256)), dim3(256), 0, s, b.u, h->hbuf, (bf16*)nullptr, rows * b.mh / 8);
-      DFOT_CHECK_HIP(hipGetLastError());
-      if ((rc = tr_gemm_bf16(h->hbuf, b.mh, b.w_fc2, (int)rows, hd, b.mh, p + b.o_fc2_b, b.y, hd, s))) return rc;
+      {
+        GemmArgs g;  // h = GELU(u), u = m2 W1^T + b1: both kept (u for GELU', h for the fc2 weight gradient)
+        g.A = b.m2; g.lda = hd; g.W = b.w_fc1; g.M = (int)rows; g.N = b.mh; g.K = hd; g.bias = p + b.o_fc1_b; g.out_bf16 = b.hact; g.ldo = b.mh;
+        g.act = 1; g.pre_act = b.u;
+        if ((rc = launch_gemm(A_DENSE, E_BF16, GEMM_AUTO, g, s))) return rc;
+      }
+      if ((rc = tr_gemm_bf16(b.hact, b.mh, b.w_fc2, (int)rows, hd, b.mh, p + b.o_fc2_b, b.y, hd, s))) return rc;
       if ((rc = combine(b.y, b.mod2 + 2 * hd, next))) return rc;
     }
   }
@@ -1094,10 +1096,8 @@ int dfot_dit_train_backward(dfot_dit_train_t h, const float* d_out, void* stream
     TrainBlock& b = h->blocks[bi];
     if (const int mh = b.mh) {  // out = m2 + gate2 * y, y = GELU(m2 W1^T + b1) W2^T + b2
       if ((rc = gate_bwd(b.y, b.mod2 + 2 * hd, G + b.o_fc2_b))) return rc;
-      hipLaunchKernelGGL(gelu_kernel, dim3(cdiv(rows * mh / 8, 256)), dim3(256), 0, s, b.u, h->hbuf, (bf16*)nullptr, rows * mh / 8);  // h again
-      DFOT_CHECK_HIP(hipGetLastError());
       if ((rc = tr_gemm_bf16(h->da, hd, b.w_fc2T, (int)rows, mh, hd, nullptr, h->dh, mh, s))) return rc;        // dh = dy W2
-      if ((rc = tr_transpose(h->da, h->T2, (int)rows, hd, s)) || (rc = tr_transpose(h->hbuf, h->T1, (int)rows, mh, s))) return rc;
+      if ((rc = tr_transpose(h->da, h->T2, (int)rows, hd, s)) || (rc = tr_transpose(b.hact, h->T1, (int)rows, mh, s))) return rc;
       if ((rc = tr_wgrad(h->T2, h->T1, hd, mh, (int)rows, G + b.o_fc2_w, s, h->wg_ws, h->wg_ws_floats))) return rc;                           // dW2 = dy^T h
       hipLaunchKernelGGL(gelu_kernel, dim3(cdiv(rows * mh / 8, 256)), dim3(256), 0, s, b.u, (bf16*)nullptr, h->dh, rows * mh / 8);  // du
       hipLaunchKernelGGL(colsum_bf16_kernel, dim3(cdiv(mh, 256), cdiv(rows, 128)), dim3(256), 0, s, h->dh, G + b.o_fc1_b, rows, mh, (long)mh);

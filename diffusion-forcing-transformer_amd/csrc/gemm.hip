@@ -398,6 +398,16 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int tile_inde
         }
       }
       if constexpr (EPI == E_BF16) {
+        if (g.act == 1 && g.pre_act && live) {  // training: keep the pre-activation too (same shape and row stride as the output)
+#pragma unroll
+          for (int p = 0; p < 2; ++p) {
+            const int r = p * 8 + (lane >> 3);
+            bf16x8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = f2bf(vals[p][j]);
+            *reinterpret_cast<bf16x8*>(g.pre_act + (mw + r) * g.ldo + col) = o;
+          }
+        }
         if (g.act == 1) {  // GELU, tanh approximation (timm Mlp act of the DiT blocks)
 #pragma unroll
           for (int p = 0; p < 2; ++p)
