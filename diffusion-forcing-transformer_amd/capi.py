@@ -89,7 +89,7 @@ SIGNATURES = {
     "dfot_dit_train_backward": (_I, [_P, _P, _P]),
     "dfot_vloss_grad": (_I, [_P] * 7 + [_I, _I, _L, _I, _P]),
     "dfot_sumsq": (_I, [_P, _L, _P, _P]),
-    "dfot_adamw_step": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _P, _F, _P]),
+    "dfot_adamw_step": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _P, _F, _P, _F, _P]),
     "dfot_ray_encode": (_I, [_P, _P, _I, _I, _I, _P]),
     "dfot_ray_encode_normalized": (_I, [_P, _P, _I, _I, _I, _P]),
     "dfot_hg_prepare": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _L, _P]),

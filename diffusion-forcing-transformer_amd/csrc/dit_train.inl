@@ -1217,10 +1217,11 @@ int dfot_sumsq(const float* x, int64_t n, float* out, void* stream) {
   return launch_sumsq(x, n, out, (hipStream_t)stream);
 }
 int dfot_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1, float beta2,
-                    float eps, float weight_decay, int step, const float* grad_sumsq, float max_grad_norm, void* stream) {
+                    float eps, float weight_decay, int step, const float* grad_sumsq, float max_grad_norm, float* ema, float ema_decay,
+                    void* stream) {
   DFOT_REQUIRE(params && grads && exp_avg && exp_avg_sq && n > 0, DFOT_ERR_ARG, "adamw_step: bad argument");
-  return launch_adamw(params, grads, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, step, grad_sumsq, max_grad_norm,
-                      (hipStream_t)stream);
+  return launch_adamw(params, grads, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, step, grad_sumsq, max_grad_norm, ema,
+                      ema_decay, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -57,7 +57,7 @@ int launch_vloss_grad(const float* x, const float* noise, const float* v, const 
                       int bt, long f, bool vspace, hipStream_t s);
 int launch_sumsq(const float* x, long n, float* out, hipStream_t s);
 int launch_adamw(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps, float wd, int step,
-                 const float* sumsq, float max_norm, hipStream_t s);
+                 const float* sumsq, float max_norm, float* ema, float ema_decay, hipStream_t s);
 // ---- casts / weight packing ----
 int launch_f32_to_bf16(const float* src, bf16* dst, long n, hipStream_t s);
 int launch_bf16_to_f32(const bf16* src, float* dst, long n, hipStream_t s);

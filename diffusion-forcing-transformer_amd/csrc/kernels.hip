@@ -979,7 +979,7 @@ int launch_sumsq(const float* x, long n, float* out, hipStream_t s) {
 // min(1, max_norm / (sqrt(*sumsq) + 1e-6)) when sumsq is given (clip_grad_norm_ without a host round trip).
 __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long n,
                              float lr, float b1, float b2, float eps, float wd, float c1, float c2, const float* __restrict__ sumsq,
-                             float max_norm) {
+                             float max_norm, float* __restrict__ ema, float ema_decay) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   float clip = 1.f;
@@ -990,13 +990,15 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
   m[i] = mv;
   v[i] = vv;
   const float pv = p[i] * (1.f - lr * wd);
-  p[i] = pv - (lr / c1) * mv / (sqrtf(vv) / sqrtf(c2) + eps);
+  const float pn = pv - (lr / c1) * mv / (sqrtf(vv) / sqrtf(c2) + eps);
+  p[i] = pn;
+  if (ema) ema[i] = ema_decay * ema[i] + (1.f - ema_decay) * pn;  // EMAModel.step (algorithms/common/ema.py:22-32), same pass
 }
 int launch_adamw(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps, float wd, int step,
-                 const float* sumsq, float max_norm, hipStream_t s) {
+                 const float* sumsq, float max_norm, float* ema, float ema_decay, hipStream_t s) {
   DFOT_REQUIRE(step >= 1, DFOT_ERR_ARG, "adamw: step counts from 1");
   const float c1 = 1.f - powf(b1, (float)step), c2 = 1.f - powf(b2, (float)step);
-  hipLaunchKernelGGL(adamw_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, p, g, m, v, n, lr, b1, b2, eps, wd, c1, c2, sumsq, max_norm);
+  hipLaunchKernelGGL(adamw_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, p, g, m, v, n, lr, b1, b2, eps, wd, c1, c2, sumsq, max_norm, ema, ema_decay);
   DFOT_CHECK_HIP(hipGetLastError());
   return DFOT_OK;
 }

@@ -80,6 +80,8 @@ class DiT3DTrainer:
         self.schedule = Schedule(diffusion or DiffusionConfig(beta_schedule="cosine", is_continuous=False, timesteps=timesteps))
         self.loss_weighting = dict(loss_weighting or {})
         self._reserved = 0
+        self.ema: Optional[torch.Tensor] = None  # EMAModel shadow weights (flat), updated inside the optimizer kernel
+        self.ema_decay = 0.0
         self._acc: Optional[torch.Tensor] = None
         self._acc_n = 0
         self._dirty = True
@@ -204,7 +206,7 @@ class DiT3DTrainer:
             sumsq = self._sumsq
         capi.check(capi.lib.dfot_adamw_step(capi.ptr(self.params), capi.ptr(self.grads), capi.ptr(self.exp_avg), capi.ptr(self.exp_avg_sq),
                                             self.numel, self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay, self.step_count,
-                                            capi.ptr(sumsq), float(self.max_grad_norm or 0.0), s()))
+                                            capi.ptr(sumsq), float(self.max_grad_norm or 0.0), capi.ptr(self.ema), float(self.ema_decay), s()))
         self._dirty = True
 
     def training_step(self, xs: torch.Tensor, k: torch.Tensor, noise: torch.Tensor, masks: Optional[torch.Tensor] = None,
@@ -212,6 +214,39 @@ class DiT3DTrainer:
         loss = self.loss_and_grads(xs, k, noise, masks)
         self.optimizer_step(world_size)
         return loss
+
+    # ------------------------------------------------------------------ EMA and optimizer state (checkpoint / resume)
+    def enable_ema(self, decay: float) -> None:
+        """experiment.ema (algorithms/common/ema.py): shadow weights start as a copy of the parameters"""
+        self.ema, self.ema_decay = self.params.clone(), float(decay)
+
+    def ema_state_dict(self) -> Dict[str, torch.Tensor]:
+        if self.ema is None:
+            raise RuntimeError("EMA is not enabled")
+        return {k: self.view(k, self.ema).detach().clone() for k in self.layout}
+
+    def optimizer_state_dict(self) -> Dict:
+        """torch.optim.AdamW.state_dict() layout (parameter index = position in the reference's parameter order)"""
+        state = {i: {"step": torch.tensor(float(self.step_count)), "exp_avg": self.view(k, self.exp_avg).clone(),
+                     "exp_avg_sq": self.view(k, self.exp_avg_sq).clone()} for i, k in enumerate(self.layout)} if self.step_count else {}
+        group = dict(lr=self.lr, betas=self.betas, eps=self.eps, weight_decay=self.weight_decay, amsgrad=False,
+                     params=list(range(len(self.layout))))
+        return {"state": state, "param_groups": [group]}
+
+    def load_optimizer_state_dict(self, sd: Dict) -> None:
+        names = list(self.layout)
+        steps = set()
+        for i, st in sd.get("state", {}).items():
+            k = names[int(i)]
+            self.view(k, self.exp_avg).copy_(st["exp_avg"].to("cuda"))
+            self.view(k, self.exp_avg_sq).copy_(st["exp_avg_sq"].to("cuda"))
+            steps.add(int(float(st["step"])))
+        if len(steps) > 1:
+            raise ValueError("per-parameter step counts differ: the flat optimizer keeps one")
+        self.step_count = steps.pop() if steps else 0
+        if sd.get("param_groups"):
+            g0 = sd["param_groups"][0]
+            self.lr, self.betas, self.eps, self.weight_decay = g0["lr"], tuple(g0["betas"]), g0["eps"], g0["weight_decay"]
 
     def grad_norm(self) -> float:
         capi.check(capi.lib.dfot_sumsq(capi.ptr(self.grads), self.numel, capi.ptr(self._sumsq), capi.stream_ptr()))

@@ -193,9 +193,11 @@ int dfot_vloss_grad(const float* x, const float* noise, const float* v, const fl
                     int batch, int tokens, int64_t frame_elems, int vspace, void* stream);
 /* out[0] = sum x^2 (device scalar) */
 int dfot_sumsq(const float* x, int64_t n, float* out, void* stream);
-/* torch.optim.AdamW on flat buffers; grad_sumsq (optional device scalar): clip the gradient to max_grad_norm first */
+/* torch.optim.AdamW on flat buffers; grad_sumsq (optional device scalar): clip the gradient to max_grad_norm first;
+ * ema (optional): shadow = ema_decay * shadow + (1 - ema_decay) * new parameter, in the same pass (algorithms/common/ema.py:22-32) */
 int dfot_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1, float beta2,
-                    float eps, float weight_decay, int step, const float* grad_sumsq, float max_grad_norm, void* stream);
+                    float eps, float weight_decay, int step, const float* grad_sumsq, float max_grad_norm, float* ema, float ema_decay,
+                    void* stream);
 
 /* ---- camera-pose front end ------------------------------------------------------------------- */
 /* raw poses [B,T,16] (fx,fy,px,py | 3x4 RT) -> ray encoding [B,T,180,res,res] fp32, normalised by frame 0 */

@@ -307,3 +307,28 @@ def test_training_gradients_vs_reference_fixture(tag):
                 worst = max(worst, rel(grads[n], ref))
     print(f"{tag}: worst stored-gradient rel-L2 vs the reference {worst:.2e}")
     assert worst < 5e-2
+
+
+def test_ema_and_optimizer_state_round_trip():
+    """EMA shadow weights follow EMAModel.step; the optimizer state exports in torch.optim.AdamW's layout, reloads into a fresh
+    trainer, and both then take the same next step"""
+    ocfg, params, tr = _tiny_trainer(depth=1)
+    tr.lr = 1e-3
+    tr.enable_ema(0.9)
+    g = torch.Generator().manual_seed(8)
+    xs = torch.randn(2, 5, 4, 16, 8, generator=g)
+    k = torch.randint(0, 1000, (2, 5), generator=g)
+    noise = torch.randn(2, 5, 4, 16, 8, generator=g)
+    p0 = tr.params.clone()
+    tr.training_step(xs, k, noise)
+    torch.testing.assert_close(tr.ema, 0.9 * p0 + 0.1 * tr.params, rtol=1e-6, atol=1e-7)
+    sd = tr.optimizer_state_dict()
+    assert len(sd["state"]) == len(tr.layout) and sd["param_groups"][0]["betas"] == (0.9, 0.99)
+    torch.optim.AdamW([torch.nn.Parameter(torch.zeros(s)) for _, s in tr.layout.values()]).load_state_dict(sd)  # torch accepts it
+    _, _, tr2 = _tiny_trainer(depth=1)
+    tr2.load_state_dict(tr.state_dict())
+    tr2.load_optimizer_state_dict(sd)
+    assert tr2.step_count == 1 and tr2.lr == 1e-3
+    tr.training_step(xs, k, noise)
+    tr2.training_step(xs, k, noise)
+    torch.testing.assert_close(tr2.params, tr.params, rtol=1e-5, atol=1e-6)
