@@ -1068,3 +1068,4 @@ int dfot_op_attention_padded(const void* q, const void* k, const void* v, void* 
 }  // extern "C"
 
 #include "dit_train.inl"
+#include "uvit_train.inl"

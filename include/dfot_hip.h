@@ -268,6 +268,11 @@ int dfot_op_attention_padded(const void* q, const void* k, const void* v, void* 
  * (algorithms/dfot/backbones/dit/dit_blocks.py:21-44,100-123). */
 int dfot_op_attention_bwd(const void* q, const void* k, const void* v, const void* d_o, void* o, int ldo, void* dq, void* dk, void* dv,
                           int batch, int heads, int n, int d, void* stream);
+/* training path of the UViT3DPose ResBlocks / resamplers, test entry: gradients of y = conv3x3(x, w, padding 1) + b for the upstream
+ * gradient dy: x [BT,H,W,Cin] and dy [BT,H,W,Cout] bf16 channels-last, w fp32 [Cout][Cin][3][3]; dx fp32 [BT,H,W,Cin], dw fp32 like w,
+ * db fp32 [Cout].  Channel counts multiples of 64.  Replaces autograd through F.conv2d (u_vit_blocks.py:16-93). */
+int dfot_op_conv3x3_bwd(const void* x, const void* dy, const float* w, float* dx, float* dw, float* db, int bt, int h, int w_, int cin, int cout,
+                        void* stream);
 /* fp32 <-> bf16 helpers for tests */
 int dfot_op_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);
 int dfot_op_bf16_to_f32(const void* src, float* dst, int64_t n, void* stream);

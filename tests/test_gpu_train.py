@@ -332,3 +332,28 @@ def test_ema_and_optimizer_state_round_trip():
     tr.training_step(xs, k, noise)
     tr2.training_step(xs, k, noise)
     torch.testing.assert_close(tr2.params, tr.params, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("bt,h,w,cin,cout", [(2, 16, 16, 128, 128), (3, 8, 16, 64, 192), (1, 32, 32, 256, 128)])
+def test_conv3x3_backward(bt, h, w, cin, cout):
+    """dx / dW / db of the channels-last 3x3 convolution (UViT ResBlocks, resamplers) vs torch autograd on the bf16-rounded operands"""
+    from dfot_amd import capi
+    g = torch.Generator().manual_seed(cin + cout)
+    x = torch.randn(bt, h, w, cin, generator=g).to(torch.bfloat16)
+    dy = torch.randn(bt, h, w, cout, generator=g).to(torch.bfloat16)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(9 * cin)
+    xd, dyd, wd = x.cuda().contiguous(), dy.cuda().contiguous(), wt.cuda().contiguous()
+    dx = torch.full((bt, h, w, cin), float("nan"), device="cuda")
+    dw = torch.full((cout, cin, 3, 3), float("nan"), device="cuda")
+    db = torch.full((cout,), float("nan"), device="cuda")
+    capi.check(capi.lib.dfot_op_conv3x3_bwd(capi.ptr(xd), capi.ptr(dyd), capi.ptr(wd), capi.ptr(dx), capi.ptr(dw), capi.ptr(db), bt, h, w, cin, cout,
+                                            capi.stream_ptr()))
+    torch.cuda.synchronize()
+    xr = x.float().permute(0, 3, 1, 2).requires_grad_()
+    wr = wt.to(torch.bfloat16).float().requires_grad_()  # the data gradient uses bf16 weights
+    br = torch.zeros(cout, requires_grad=True)
+    y = torch.nn.functional.conv2d(xr, wr, br, padding=1)
+    y.backward(dy.float().permute(0, 3, 1, 2))
+    r = (rel(dx.cpu(), xr.grad.permute(0, 2, 3, 1)), rel(dw.cpu(), wr.grad), rel(db.cpu(), br.grad))
+    print(f"conv3x3 backward {cin}->{cout}: rel dx {r[0]:.2e} dW {r[1]:.2e} db {r[2]:.2e}")
+    assert max(r) < 1e-2, r
