@@ -104,6 +104,7 @@ SIGNATURES = {
     "dfot_op_attention_padded": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "dfot_op_attention_bwd": (_I, [_P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _P]),
     "dfot_op_conv3x3_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "dfot_op_gn_silu_bwd": (_I, [_P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _I, _I, _I, _P]),
     "dfot_op_f32_to_bf16": (_I, [_P, _P, _L, _P]),
     "dfot_op_bf16_to_f32": (_I, [_P, _P, _L, _P]),
 }

@@ -136,3 +136,153 @@ int dfot_op_conv3x3_bwd(const void* x, const void* dy, const float* w, float* dx
 }
 
 }  // extern "C"
+
+// ---- GroupNorm(32) [+ FiLM] + SiLU backward (ResBlock in_layers / out_norm, u_vit_blocks.py:57-93) -------------------------------
+// forward: xhat = (x - mean_g) rstd_g per (image, group) ; g = xhat gamma + beta ; z = FILM ? g (1 + scale) + shift : g ; y = SiLU(z)
+// backward for dy: dz = dy SiLU'(z) ; FILM: dscale = dz g, dshift = dz, dg = dz (1 + scale) ; dgamma = sum dg xhat, dbeta = sum dg ;
+//   dxhat = dg gamma ; dx = rstd (dxhat - mean_grp(dxhat) - xhat mean_grp(dxhat xhat))
+// x, dy, dx fp32 channels-last [BT][P][C]; film / dfilm bf16 [BT*P][2C] (scale | shift); stats [BT][32][2] = (mean, rstd).
+namespace dfot {
+namespace {
+
+__device__ __forceinline__ float silu_grad(float z) {
+  const float sg = 1.0f / (1.0f + __expf(-z));
+  return sg * (1.0f + z * (1.0f - sg));
+}
+
+// pass 1: sums[bt][grp] += (sum dxhat, sum dxhat xhat) over a chunk of pixels; dgamma / dbeta += per-channel sums.  One workgroup =
+// one (image, pixel chunk); a thread owns one channel and walks the chunk's pixels (coalesced over channels)
+template <bool FILM>
+__global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ stats,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            const bf16* __restrict__ film, float* __restrict__ sums, float* __restrict__ dgamma,
+                                                            float* __restrict__ dbeta, int P, int C, int chunk) {
+  const int bt = blockIdx.x, p0 = blockIdx.y * chunk;
+  const int cpg = C / 32;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const int grp = c / cpg;
+    const float mean = stats[((long)bt * 32 + grp) * 2], rstd = stats[((long)bt * 32 + grp) * 2 + 1];
+    const float ga = gamma[c], be = beta[c];
+    float s1 = 0.f, s2 = 0.f, dgm = 0.f, dbt = 0.f;
+    for (int p = p0; p < p0 + chunk && p < P; ++p) {
+      const long e = ((long)bt * P + p) * C + c;
+      const float xh = (x[e] - mean) * rstd;
+      const float gv = xh * ga + be;
+      float z = gv, mul = 1.f;
+      if (FILM) {
+        const long f = ((long)bt * P + p) * 2 * C + c;
+        mul = 1.0f + bf2f(film[f]);
+        z = gv * mul + bf2f(film[f + C]);
+      }
+      const float dg = dy[e] * silu_grad(z) * mul;
+      dgm += dg * xh;
+      dbt += dg;
+      s1 += dg * ga;
+      s2 += dg * ga * xh;
+    }
+    atomicAdd(dgamma + c, dgm);
+    atomicAdd(dbeta + c, dbt);
+    atomicAdd(sums + ((long)bt * 32 + grp) * 2, s1);
+    atomicAdd(sums + ((long)bt * 32 + grp) * 2 + 1, s2);
+  }
+}
+
+// pass 2: dx (+= when accumulate) and the FiLM gradients
+template <bool FILM>
+__global__ void gn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ stats,
+                                    const float* __restrict__ gamma, const float* __restrict__ beta, const bf16* __restrict__ film,
+                                    const float* __restrict__ sums, float* __restrict__ dx, bf16* __restrict__ dfilm, long total, int P, int C,
+                                    int accumulate) {
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= total) return;
+  const int c = (int)(e % C);
+  const long row = e / C;
+  const int bt = (int)(row / P);
+  const int cpg = C / 32, grp = c / cpg;
+  const float mean = stats[((long)bt * 32 + grp) * 2], rstd = stats[((long)bt * 32 + grp) * 2 + 1];
+  const float inv_n = 1.0f / ((float)P * (float)cpg);
+  const float xh = (x[e] - mean) * rstd, ga = gamma[c];
+  const float gv = xh * ga + beta[c];
+  float z = gv, mul = 1.f;
+  if (FILM) {
+    mul = 1.0f + bf2f(film[row * 2 * C + c]);
+    z = gv * mul + bf2f(film[row * 2 * C + C + c]);
+  }
+  const float dz = dy[e] * silu_grad(z);
+  if (FILM) {
+    dfilm[row * 2 * C + c] = f2bf(dz * gv);
+    dfilm[row * 2 * C + C + c] = f2bf(dz);
+  }
+  const float dxh = dz * mul * ga;
+  const float s1 = sums[((long)bt * 32 + grp) * 2] * inv_n, s2 = sums[((long)bt * 32 + grp) * 2 + 1] * inv_n;
+  const float v = rstd * (dxh - s1 - xh * s2);
+  dx[e] = accumulate ? dx[e] + v : v;
+}
+
+// sums [BT][32][2] scratch; dgamma / dbeta must be zeroed by the caller (they accumulate)
+int gn_silu_backward(const float* x, const float* dy, const float* stats, const float* gamma, const float* beta, const bf16* film, float* sums,
+                     float* dx, bf16* dfilm, float* dgamma, float* dbeta, int bt, int P, int C, bool accumulate, hipStream_t s) {
+  DFOT_REQUIRE(C % 32 == 0 && (film == nullptr) == (dfilm == nullptr), DFOT_ERR_ARG, "gn_silu_backward: bad argument");
+  DFOT_CHECK_HIP(hipMemsetAsync(sums, 0, (size_t)bt * 64 * sizeof(float), s));
+  const int chunk = 64;
+  const dim3 grid(bt, cdiv(P, chunk));
+  const long total = (long)bt * P * C;
+  if (film) {
+    hipLaunchKernelGGL(gn_bwd_reduce_kernel<true>, grid, dim3(256), 0, s, x, dy, stats, gamma, beta, film, sums, dgamma, dbeta, P, C, chunk);
+    hipLaunchKernelGGL(gn_bwd_apply_kernel<true>, dim3(cdiv(total, 256)), dim3(256), 0, s, x, dy, stats, gamma, beta, film, sums, dx, dfilm, total, P, C,
+                       accumulate ? 1 : 0);
+  } else {
+    hipLaunchKernelGGL(gn_bwd_reduce_kernel<false>, grid, dim3(256), 0, s, x, dy, stats, gamma, beta, film, sums, dgamma, dbeta, P, C, chunk);
+    hipLaunchKernelGGL(gn_bwd_apply_kernel<false>, dim3(cdiv(total, 256)), dim3(256), 0, s, x, dy, stats, gamma, beta, film, sums, dx, dfilm, total, P, C,
+                       accumulate ? 1 : 0);
+  }
+  DFOT_CHECK_HIP(hipGetLastError());
+  return DFOT_OK;
+}
+
+// GroupNorm statistics (mean, rstd) of x [BT][P][C] fp32 per (image, group): one workgroup per (image, group)
+__global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__ x, float* __restrict__ stats, int P, int C, float eps) {
+  __shared__ float red[2][4];
+  const int bt = blockIdx.x, grp = blockIdx.y, cpg = C / 32;
+  const long n = (long)P * cpg;
+  float s = 0.f, q = 0.f;
+  for (long i = threadIdx.x; i < n; i += 256) {
+    const float v = x[((long)bt * P + i / cpg) * C + grp * cpg + i % cpg];
+    s += v;
+    q += v * v;
+  }
+  s = wave_sum(s);
+  q = wave_sum(q);
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s; red[1][threadIdx.x >> 6] = q; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float sum = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]), sq = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+    const float mean = sum / (float)n;
+    const float var = fmaxf(sq / (float)n - mean * mean, 0.f);
+    stats[((long)bt * 32 + grp) * 2] = mean;
+    stats[((long)bt * 32 + grp) * 2 + 1] = rsqrtf(var + eps);
+  }
+}
+
+}  // namespace
+}  // namespace dfot
+
+extern "C" {
+using namespace dfot;
+// test entry: x, dy, dx fp32 [BT][P][C]; film (optional) bf16 [BT*P][2C] -> dfilm; dgamma / dbeta fp32 [C]
+int dfot_op_gn_silu_bwd(const float* x, const float* dy, const float* gamma, const float* beta, const void* film, float eps, float* dx, void* dfilm,
+                        float* dgamma, float* dbeta, int bt, int pixels, int channels, void* stream) {
+  DFOT_REQUIRE(x && dy && gamma && beta && dx && dgamma && dbeta, DFOT_ERR_ARG, "op_gn_silu_bwd: null argument");
+  hipStream_t s = (hipStream_t)stream;
+  float *stats = nullptr, *sums = nullptr;
+  DFOT_CHECK_HIP(hipMalloc(&stats, (size_t)bt * 64 * sizeof(float)));
+  DFOT_CHECK_HIP(hipMalloc(&sums, (size_t)bt * 64 * sizeof(float)));
+  DFOT_CHECK_HIP(hipMemsetAsync(dgamma, 0, (size_t)channels * sizeof(float), s));
+  DFOT_CHECK_HIP(hipMemsetAsync(dbeta, 0, (size_t)channels * sizeof(float), s));
+  hipLaunchKernelGGL(gn_stats_kernel, dim3(bt, 32), dim3(256), 0, s, x, stats, pixels, channels, eps);
+  int rc = gn_silu_backward(x, dy, stats, gamma, beta, (const bf16*)film, sums, dx, (bf16*)dfilm, dgamma, dbeta, bt, pixels, channels, false, s);
+  (void)hipStreamSynchronize(s);
+  (void)hipFree(stats); (void)hipFree(sums);
+  return rc;
+}
+}  // extern "C"

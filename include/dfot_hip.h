@@ -273,6 +273,10 @@ int dfot_op_attention_bwd(const void* q, const void* k, const void* v, const voi
  * db fp32 [Cout].  Channel counts multiples of 64.  Replaces autograd through F.conv2d (u_vit_blocks.py:16-93). */
 int dfot_op_conv3x3_bwd(const void* x, const void* dy, const float* w, float* dx, float* dw, float* db, int bt, int h, int w_, int cin, int cout,
                         void* stream);
+/* test entry: backward of y = SiLU(FiLM(GroupNorm32(x))) (ResBlock in_layers: film NULL; out_norm: film [BT*P][2C] bf16 = scale | shift,
+ * u_vit_blocks.py:57-93): x, dy, dx fp32 [BT][P][C]; dfilm bf16 like film; dgamma / dbeta fp32 [C] */
+int dfot_op_gn_silu_bwd(const float* x, const float* dy, const float* gamma, const float* beta, const void* film, float eps, float* dx, void* dfilm,
+                        float* dgamma, float* dbeta, int bt, int pixels, int channels, void* stream);
 /* fp32 <-> bf16 helpers for tests */
 int dfot_op_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);
 int dfot_op_bf16_to_f32(const void* src, float* dst, int64_t n, void* stream);

@@ -357,3 +357,34 @@ def test_conv3x3_backward(bt, h, w, cin, cout):
     r = (rel(dx.cpu(), xr.grad.permute(0, 2, 3, 1)), rel(dw.cpu(), wr.grad), rel(db.cpu(), br.grad))
     print(f"conv3x3 backward {cin}->{cout}: rel dx {r[0]:.2e} dW {r[1]:.2e} db {r[2]:.2e}")
     assert max(r) < 1e-2, r
+
+
+@pytest.mark.parametrize("film", [False, True])
+@pytest.mark.parametrize("bt,pix,c", [(3, 256, 128), (2, 64, 256)])
+def test_groupnorm_silu_backward(film, bt, pix, c):
+    """backward of SiLU(GN32(x) [* (1 + scale) + shift]) -- both norm layers of a UViT ResBlock -- vs torch autograd"""
+    from dfot_amd import capi
+    F = torch.nn.functional
+    g = torch.Generator().manual_seed(c + pix)
+    x = torch.randn(bt, pix, c, generator=g) * 1.5 + 0.3
+    dy = torch.randn(bt, pix, c, generator=g)
+    gamma, beta = torch.randn(c, generator=g) * 0.5 + 1, torch.randn(c, generator=g) * 0.2
+    fl = (torch.randn(bt * pix, 2 * c, generator=g) * 0.5).to(torch.bfloat16) if film else None
+    dx = torch.full((bt, pix, c), float("nan"), device="cuda")
+    dfl = torch.empty(bt * pix, 2 * c, dtype=torch.bfloat16, device="cuda") if film else None
+    dga, dbe = torch.empty(c, device="cuda"), torch.empty(c, device="cuda")
+    xd, dyd, gd, bd, fd = x.cuda(), dy.cuda(), gamma.cuda(), beta.cuda(), (fl.cuda() if film else None)  # keep the device copies alive
+    capi.check(capi.lib.dfot_op_gn_silu_bwd(capi.ptr(xd), capi.ptr(dyd), capi.ptr(gd), capi.ptr(bd), capi.ptr(fd), 1e-6, capi.ptr(dx), capi.ptr(dfl), capi.ptr(dga), capi.ptr(dbe),
+                                            bt, pix, c, capi.stream_ptr()))
+    torch.cuda.synchronize()
+    xr, gr, br = x.clone().requires_grad_(), gamma.clone().requires_grad_(), beta.clone().requires_grad_()
+    h = F.group_norm(xr.permute(0, 2, 1), 32, gr, br, 1e-6).permute(0, 2, 1)
+    if film:
+        fr = fl.float().view(bt, pix, 2 * c).requires_grad_()
+        h = h * (1 + fr[..., :c]) + fr[..., c:]
+    F.silu(h).backward(dy)
+    rs = [rel(dx.cpu(), xr.grad), rel(dga.cpu(), gr.grad), rel(dbe.cpu(), br.grad)]
+    if film:
+        rs.append(rel(dfl.float().cpu().view(bt, pix, 2 * c), fr.grad))
+    print(f"GN+SiLU backward film={film} C={c}: " + " ".join(f"{r:.1e}" for r in rs))
+    assert max(rs[:3]) < 1e-4 and (not film or rs[3] < 5e-3)
