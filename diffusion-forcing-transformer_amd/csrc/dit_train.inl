@@ -618,13 +618,16 @@ int tr_wgrad(const bf16* A, const bf16* W, int M, int N, int K, float* out, hipS
     // few 128x128 tiles and a long K (out-projection weights: 81 tiles; matrix factors U, U': 2 tiles over K = frames x hidden)
     const long t128 = (long)(M / 128) * ((N + 127) / 128);
     if (t128 <= 128 && K >= 2048) {
-      int split = (int)(256 / t128);
+      static const int wide = tuning_flag("TRAIN_WGRAD_128X192", 1);  // A/B: 128x192 tiles where N allows (PMC: 0.21 vs 0.15 MFMA utilisation)
+      const bool use192 = wide && N % 192 == 0;
+      const long tiles = use192 ? (long)(M / 128) * (N / 192) : t128;
+      int split = (int)(256 / tiles);
       split = split > 64 ? 64 : split;
       while (split > 1 && K / 64 < 4 * split) --split;
       if (split > 1 && (size_t)split * M * N <= ws_floats) {
         GemmArgs g;
         g.A = A; g.lda = K; g.W = W; g.M = M; g.N = N; g.K = K; g.out_f32 = ws; g.ldo = N; g.ksplit = split; g.slice_stride = (long)M * N;
-        int rc = launch_gemm(A_DENSE, E_F32, GEMM_DMA_128, g, s);
+        int rc = launch_gemm(A_DENSE, E_F32, use192 ? GEMM_DMA_128x192 : GEMM_DMA_128, g, s);
         if (rc) return rc;
         hipLaunchKernelGGL(slices_sum_kernel, dim3(cdiv((long)M * N / 4, 256)), dim3(256), 0, s, ws, out, (long)M * N / 4, split, (long)M * N);
         DFOT_CHECK_HIP(hipGetLastError());
