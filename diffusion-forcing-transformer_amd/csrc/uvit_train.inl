@@ -286,3 +286,192 @@ int dfot_op_gn_silu_bwd(const float* x, const float* dy, const float* gamma, con
   return rc;
 }
 }  // extern "C"
+
+// ---- TransformerBlock pieces (u_vit_blocks.py:96-116,192-281; normalization.py:5-53) ------------------------------------------------
+// NormalizeWithCond: xn = RMSNorm(x; w) (1 + scale) + shift, (scale | shift) = film [rows][2C] bf16 (Linear of the token's embedding).
+// backward for dxn: dshift = dxn, dscale = dxn y (y = x r w, r = rsqrt(mean x^2 + eps)), g = dxn (1 + scale) w,
+//   dx = r (g - x r^2 mean(g x)), dw[c] += sum_rows dxn (1 + scale) x r.   One wave per token row; dw through per-wave partial sums.
+namespace dfot {
+namespace {
+
+template <int VEC, int CNT>
+__global__ __launch_bounds__(256) void rms_film_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dxn, const float* __restrict__ w,
+                                                           const bf16* __restrict__ film, float* __restrict__ dx, bf16* __restrict__ dfilm,
+                                                           float* __restrict__ dw, long rows, float eps, int accumulate) {
+  typedef typename VecT<VEC>::type V;
+  constexpr int C = 64 * VEC * CNT;
+  const int lane = threadIdx.x & 63;
+  const long wave0 = (long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long)gridDim.x * 4;
+  float dwacc[CNT * VEC];
+#pragma unroll
+  for (int i = 0; i < CNT * VEC; ++i) dwacc[i] = 0.f;
+  for (long row = wave0; row < rows; row += nwaves) {
+    const float* xr = x + row * C;
+    const float* gr = dxn + row * C;
+    const bf16* fr = film + row * 2 * C;
+    V xv[CNT], gv[CNT];
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < CNT; ++i) {
+      xv[i] = *reinterpret_cast<const V*>(xr + (i * 64 + lane) * VEC);
+      ss += vdot<VEC>(xv[i], xv[i]);
+    }
+    const float r = rsqrtf(wave_sum(ss) / (float)C + eps);
+    float gx = 0.f;
+    bf16* dfr = dfilm + row * 2 * C;
+#pragma unroll
+    for (int i = 0; i < CNT; ++i) {
+      const int c0 = (i * 64 + lane) * VEC;
+      const V d = *reinterpret_cast<const V*>(gr + c0);
+      const V wv = *reinterpret_cast<const V*>(w + c0);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        float dj, wj, xj;
+        if constexpr (VEC == 1) { dj = d; wj = wv; xj = xv[i]; } else { dj = d[j]; wj = wv[j]; xj = xv[i][j]; }
+        const float sc = bf2f(fr[c0 + j]);
+        const float y = xj * r * wj;
+        dfr[c0 + j] = f2bf(dj * y);       // dscale
+        dfr[C + c0 + j] = f2bf(dj);       // dshift
+        const float dy = dj * (1.0f + sc);
+        dwacc[i * VEC + j] += dy * xj * r;
+        const float g = dy * wj;
+        if constexpr (VEC == 1) gv[i] = g; else gv[i][j] = g;
+        gx += g * xj;
+      }
+    }
+    const float m = wave_sum(gx) / (float)C * r * r;
+    float* orow = dx + row * C;
+#pragma unroll
+    for (int i = 0; i < CNT; ++i) {
+      const int c0 = (i * 64 + lane) * VEC;
+      V o = (gv[i] - xv[i] * m) * r;
+      if (accumulate) o += *reinterpret_cast<const V*>(orow + c0);
+      *reinterpret_cast<V*>(orow + c0) = o;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < CNT; ++i)
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) atomicAdd(dw + (i * 64 + lane) * VEC + j, dwacc[i * VEC + j]);
+}
+
+// dw must be zeroed by the caller
+int rms_film_backward(const float* x, const float* dxn, const float* w, const bf16* film, float* dx, bf16* dfilm, float* dw, long rows, int hidden,
+                      float eps, bool accumulate, hipStream_t s) {
+  const int grid = (int)(rows / 4 < 2048 ? (rows + 3) / 4 : 2048);
+#define CALL(V, C) \
+  hipLaunchKernelGGL((rms_film_bwd_kernel<V, C>), dim3(grid), dim3(256), 0, s, x, dxn, w, film, dx, dfilm, dw, rows, eps, accumulate ? 1 : 0)
+  DIT_LN_DISPATCH(CALL)
+#undef CALL
+  DFOT_CHECK_HIP(hipGetLastError());
+  return DFOT_OK;
+}
+
+// q / k of the fused projection: per head RMSNorm (weights qw / kw [d]) then RoPE (then q *= qscale, folded into the attention backward's
+// "gradient of the unscaled q").  Given the attention backward's dq / dk / dv [B][heads][ntok][d] (d = 64 or 128, no padding) and the
+// saved projection output fused [rows][ld] (q | k | v head-major in the first 3C columns):
+//   g = rope^T(dq) ; dq_pre = r (g qw - qh mean_d(g qw qh) ...) with qh = q r, r = rsqrt(mean q^2 + eps) ; dqw[e] += sum g qh
+// writes d_fused [rows][ldo] columns [0, 3C) (v: plain copy).  One wave per (row, head); a lane owns d/64 consecutive elements.
+template <int EPL>  // elements per lane: 1 (d = 64) or 2 (d = 128)
+__global__ __launch_bounds__(256) void qknorm_rope_bwd_kernel(const bf16* __restrict__ fused, long ld, const bf16* __restrict__ dq,
+                                                              const bf16* __restrict__ dk, const bf16* __restrict__ dv, const float* __restrict__ qw,
+                                                              const float* __restrict__ kw, const float* __restrict__ rope_cs,
+                                                              bf16* __restrict__ dfused, long ldo, float* __restrict__ dqw, float* __restrict__ dkw,
+                                                              long rows, int ntok, int heads, float eps) {
+  constexpr int D = 64 * EPL;
+  const int lane = threadIdx.x & 63;
+  const long wave0 = (long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long)gridDim.x * 4;
+  const int C = heads * D;
+  float wacc[2][EPL];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int j = 0; j < EPL; ++j) wacc[a][j] = 0.f;
+  for (long item = wave0; item < rows * heads; item += nwaves) {
+    const long row = item / heads;
+    const int head = (int)(item % heads);
+    const long b = row / ntok;
+    const int tok = (int)(row % ntok);
+    const long goff = ((b * heads + head) * ntok + tok) * (long)D + lane * EPL;
+#pragma unroll
+    for (int which = 0; which < 2; ++which) {
+      const bf16* src = fused + row * ld + (long)which * C + head * D + lane * EPL;
+      const bf16* gsrc = (which == 0 ? dq : dk) + goff;
+      const float* wt = (which == 0 ? qw : kw) + lane * EPL;
+      float xv[EPL], gv[EPL];
+#pragma unroll
+      for (int j = 0; j < EPL; ++j) { xv[j] = bf2f(src[j]); gv[j] = bf2f(gsrc[j]); }
+      // transpose of the forward rotation (x0 c - x1 s, x1 c + x0 s) on the pair (2i, 2i+1)
+      if constexpr (EPL == 2) {
+        const float* cs = rope_cs + ((long)tok * (D / 2) + lane) * 2;
+        const float g0 = gv[0], g1 = gv[1];
+        gv[0] = g0 * cs[0] + g1 * cs[1];
+        gv[1] = g1 * cs[0] - g0 * cs[1];
+      } else {
+        const float* cs = rope_cs + ((long)tok * (D / 2) + (lane >> 1)) * 2;
+        const float other = __shfl_xor(gv[0], 1);
+        gv[0] = (lane & 1) ? (gv[0] * cs[0] - other * cs[1]) : (gv[0] * cs[0] + other * cs[1]);
+      }
+      float ss = 0.f;
+#pragma unroll
+      for (int j = 0; j < EPL; ++j) ss += xv[j] * xv[j];
+      const float r = rsqrtf(wave_sum(ss) / (float)D + eps);
+      float gx = 0.f, gw[EPL];
+#pragma unroll
+      for (int j = 0; j < EPL; ++j) {
+        wacc[which][j] += gv[j] * xv[j] * r;
+        gw[j] = gv[j] * wt[j];
+        gx += gw[j] * xv[j];
+      }
+      const float m = wave_sum(gx) / (float)D * r * r;
+      bf16* dst = dfused + row * ldo + (long)which * C + head * D + lane * EPL;
+#pragma unroll
+      for (int j = 0; j < EPL; ++j) dst[j] = f2bf((gw[j] - xv[j] * m) * r);
+    }
+    bf16* vdst = dfused + row * ldo + 2L * C + head * D + lane * EPL;
+#pragma unroll
+    for (int j = 0; j < EPL; ++j) vdst[j] = dv[goff + j];
+  }
+#pragma unroll
+  for (int j = 0; j < EPL; ++j) {
+    atomicAdd(dqw + lane * EPL + j, wacc[0][j]);
+    atomicAdd(dkw + lane * EPL + j, wacc[1][j]);
+  }
+}
+
+int qknorm_rope_backward(const bf16* fused, long ld, const bf16* dq, const bf16* dk, const bf16* dv, const float* qw, const float* kw,
+                         const float* rope_cs, bf16* dfused, long ldo, float* dqw, float* dkw, long rows, int ntok, int heads, int d, float eps,
+                         hipStream_t s) {
+  DFOT_REQUIRE(d == 64 || d == 128, DFOT_ERR_SHAPE, "qknorm_rope_backward: head dim %d not in {64,128}", d);
+  const long items = rows * heads;
+  const int grid = (int)(items / 4 < 4096 ? (items + 3) / 4 : 4096);
+  if (d == 64)
+    hipLaunchKernelGGL(qknorm_rope_bwd_kernel<1>, dim3(grid), dim3(256), 0, s, fused, ld, dq, dk, dv, qw, kw, rope_cs, dfused, ldo, dqw, dkw, rows, ntok, heads, eps);
+  else
+    hipLaunchKernelGGL(qknorm_rope_bwd_kernel<2>, dim3(grid), dim3(256), 0, s, fused, ld, dq, dk, dv, qw, kw, rope_cs, dfused, ldo, dqw, dkw, rows, ntok, heads, eps);
+  DFOT_CHECK_HIP(hipGetLastError());
+  return DFOT_OK;
+}
+
+}  // namespace
+}  // namespace dfot
+
+extern "C" {
+using namespace dfot;
+// test entries (dw / dqw / dkw are zeroed here)
+int dfot_op_rms_film_bwd(const float* x, const float* dxn, const float* w, const void* film, float eps, float* dx, void* dfilm, float* dw,
+                         int64_t rows, int channels, void* stream) {
+  DFOT_REQUIRE(x && dxn && w && film && dx && dfilm && dw, DFOT_ERR_ARG, "op_rms_film_bwd: null argument");
+  DFOT_CHECK_HIP(hipMemsetAsync(dw, 0, (size_t)channels * sizeof(float), (hipStream_t)stream));
+  return rms_film_backward(x, dxn, w, (const bf16*)film, dx, (bf16*)dfilm, dw, (long)rows, channels, eps, false, (hipStream_t)stream);
+}
+int dfot_op_qknorm_rope_bwd(const void* fused, int ld, const void* dq, const void* dk, const void* dv, const float* qw, const float* kw,
+                            const float* rope_cs, float eps, void* dfused, int ldo, float* dqw, float* dkw, int64_t rows, int ntok, int heads, int d,
+                            void* stream) {
+  DFOT_REQUIRE(fused && dq && dk && dv && qw && kw && rope_cs && dfused && dqw && dkw, DFOT_ERR_ARG, "op_qknorm_rope_bwd: null argument");
+  DFOT_CHECK_HIP(hipMemsetAsync(dqw, 0, (size_t)d * sizeof(float), (hipStream_t)stream));
+  DFOT_CHECK_HIP(hipMemsetAsync(dkw, 0, (size_t)d * sizeof(float), (hipStream_t)stream));
+  return qknorm_rope_backward((const bf16*)fused, ld, (const bf16*)dq, (const bf16*)dk, (const bf16*)dv, qw, kw, rope_cs, (bf16*)dfused, ldo, dqw, dkw,
+                              (long)rows, ntok, heads, d, eps, (hipStream_t)stream);
+}
+}  // extern "C"

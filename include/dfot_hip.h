@@ -277,6 +277,15 @@ int dfot_op_conv3x3_bwd(const void* x, const void* dy, const float* w, float* dx
  * u_vit_blocks.py:57-93): x, dy, dx fp32 [BT][P][C]; dfilm bf16 like film; dgamma / dbeta fp32 [C] */
 int dfot_op_gn_silu_bwd(const float* x, const float* dy, const float* gamma, const float* beta, const void* film, float eps, float* dx, void* dfilm,
                         float* dgamma, float* dbeta, int bt, int pixels, int channels, void* stream);
+/* test entries of the UViT TransformerBlock backward pieces (u_vit_blocks.py:96-116,192-281):
+ * NormalizeWithCond: xn = RMSNorm(x; w) (1 + scale) + shift with film [rows][2C] bf16 = (scale | shift): dx fp32, dfilm bf16, dw fp32 [C] */
+int dfot_op_rms_film_bwd(const float* x, const float* dxn, const float* w, const void* film, float eps, float* dx, void* dfilm, float* dw,
+                         int64_t rows, int channels, void* stream);
+/* per-head q / k RMSNorm + RoPE (rope_cs [ntok][d/2][2] = cos, sin): fused [rows][ld] bf16 holds (q | k | v) head-major in its first 3C
+ * columns, dq / dk / dv [B][heads][ntok][d] bf16 are the attention backward's outputs; writes dfused [rows][ldo] columns [0, 3C), dqw / dkw [d] */
+int dfot_op_qknorm_rope_bwd(const void* fused, int ld, const void* dq, const void* dk, const void* dv, const float* qw, const float* kw,
+                            const float* rope_cs, float eps, void* dfused, int ldo, float* dqw, float* dkw, int64_t rows, int ntok, int heads, int d,
+                            void* stream);
 /* fp32 <-> bf16 helpers for tests */
 int dfot_op_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);
 int dfot_op_bf16_to_f32(const void* src, float* dst, int64_t n, void* stream);

@@ -388,3 +388,56 @@ def test_groupnorm_silu_backward(film, bt, pix, c):
         rs.append(rel(dfl.float().cpu().view(bt, pix, 2 * c), fr.grad))
     print(f"GN+SiLU backward film={film} C={c}: " + " ".join(f"{r:.1e}" for r in rs))
     assert max(rs[:3]) < 1e-4 and (not film or rs[3] < 5e-3)
+
+
+@pytest.mark.parametrize("rows,c", [(512, 576), (300, 1152), (64, 128)])
+def test_rms_film_backward(rows, c):
+    """backward of RMSNorm(x; w) * (1 + scale) + shift (NormalizeWithCond of the UViT TransformerBlock) vs torch autograd"""
+    from dfot_amd import capi
+    from oracle import uvit as ouvit
+    g = torch.Generator().manual_seed(rows + c)
+    x, dxn = torch.randn(rows, c, generator=g) * 2, torch.randn(rows, c, generator=g)
+    w = torch.randn(c, generator=g) * 0.3 + 1
+    film = (torch.randn(rows, 2 * c, generator=g) * 0.5).to(torch.bfloat16)
+    xd, gd, wd, fd = x.cuda(), dxn.cuda(), w.cuda(), film.cuda()
+    dx, dw = torch.full((rows, c), float("nan"), device="cuda"), torch.empty(c, device="cuda")
+    dfilm = torch.empty(rows, 2 * c, dtype=torch.bfloat16, device="cuda")
+    capi.check(capi.lib.dfot_op_rms_film_bwd(capi.ptr(xd), capi.ptr(gd), capi.ptr(wd), capi.ptr(fd), 1e-6, capi.ptr(dx), capi.ptr(dfilm), capi.ptr(dw),
+                                             rows, c, capi.stream_ptr()))
+    torch.cuda.synchronize()
+    xr, wr, fr = x.clone().requires_grad_(), w.clone().requires_grad_(), film.float().requires_grad_()
+    (ouvit.rms_norm(xr, wr, 1e-6) * (1 + fr[:, :c]) + fr[:, c:]).backward(dxn)
+    rs = (rel(dx.cpu(), xr.grad), rel(dw.cpu(), wr.grad), rel(dfilm.float().cpu(), fr.grad))
+    print(f"RMSNorm-FiLM backward C={c}: " + " ".join(f"{r:.1e}" for r in rs))
+    assert rs[0] < 1e-5 and rs[1] < 1e-4 and rs[2] < 5e-3
+
+
+@pytest.mark.parametrize("d,heads,ntok,batch", [(64, 9, 256, 2), (128, 3, 128, 1)])
+def test_qknorm_rope_backward(d, heads, ntok, batch):
+    """backward of the per-head q / k RMSNorm + RoPE of the fused projection vs torch autograd through the oracle's rms_norm / apply_rope"""
+    from dfot_amd import capi
+    from oracle import uvit as ouvit
+    g = torch.Generator().manual_seed(d)
+    c, rows = heads * d, batch * ntok
+    fused = (torch.randn(rows, 7 * c, generator=g)).to(torch.bfloat16)
+    dq, dk, dv = ((torch.randn(batch, heads, ntok, d, generator=g)).to(torch.bfloat16) for _ in range(3))
+    qw, kw = torch.randn(d, generator=g) * 0.3 + 1, torch.randn(d, generator=g) * 0.3 + 1
+    ang = torch.rand(ntok, d // 2, generator=g) * 6.28
+    cs = torch.stack([ang.cos(), ang.sin()], -1).contiguous()
+    dev = [t.cuda().contiguous() for t in (fused, dq, dk, dv, qw, kw, cs)]
+    dfused = torch.zeros(rows, 7 * c, dtype=torch.bfloat16, device="cuda")
+    dqw, dkw = torch.empty(d, device="cuda"), torch.empty(d, device="cuda")
+    capi.check(capi.lib.dfot_op_qknorm_rope_bwd(capi.ptr(dev[0]), 7 * c, capi.ptr(dev[1]), capi.ptr(dev[2]), capi.ptr(dev[3]), capi.ptr(dev[4]),
+                                                capi.ptr(dev[5]), capi.ptr(dev[6]), 1e-6, capi.ptr(dfused), 7 * c, capi.ptr(dqw), capi.ptr(dkw),
+                                                rows, ntok, heads, d, capi.stream_ptr()))
+    torch.cuda.synchronize()
+    fr = fused.float().requires_grad_()
+    qwr, kwr = qw.clone().requires_grad_(), kw.clone().requires_grad_()
+    q, k, v = fr[:, :3 * c].view(batch, ntok, 3, heads, d).permute(2, 0, 3, 1, 4)
+    full = ang.repeat_interleave(2, dim=-1)
+    qn = ouvit.apply_rope(ouvit.rms_norm(q, qwr, 1e-6), full)
+    kn = ouvit.apply_rope(ouvit.rms_norm(k, kwr, 1e-6), full)
+    ((qn * dq.float()).sum() + (kn * dk.float()).sum() + (v * dv.float()).sum()).backward()
+    rs = (rel(dfused.float().cpu()[:, :3 * c], fr.grad[:, :3 * c]), rel(dqw.cpu(), qwr.grad), rel(dkw.cpu(), kwr.grad))
+    print(f"q/k norm + RoPE backward d={d}: " + " ".join(f"{r:.1e}" for r in rs))
+    assert rs[0] < 5e-3 and rs[1] < 1e-4 and rs[2] < 1e-4
