@@ -536,7 +536,7 @@ struct dfot_dit_train_s {
   dfot::bf16* semb = nullptr;
   float *dX = nullptr, *dX2 = nullptr, *stats = nullptr, *delta = nullptr, *dmod = nullptr, *dsemb = nullptr, *dwf = nullptr;
   float *dc = nullptr, *da1 = nullptr, *dh1 = nullptr, *dbmod = nullptr, *scratch_f = nullptr;
-  dfot::bf16 *da = nullptr, *dO = nullptr, *dq = nullptr, *dk = nullptr, *dv = nullptr, *dqkv = nullptr, *T1 = nullptr,
+  dfot::bf16 *da = nullptr, *dO = nullptr, *dq = nullptr, *dk = nullptr, *dv = nullptr, *dqkv = nullptr, *dqkvT = nullptr, *T1 = nullptr,
              *T2 = nullptr, *dmod_bf = nullptr, *dmodT = nullptr, *sembT = nullptr, *dyp = nullptr, *dyt = nullptr, *mfin = nullptr, *dh = nullptr;
   // matrix-block workspace
   float* ma_sc = nullptr;  // matrix attention backward: per-head (S, dP) [L*L] partial sums
@@ -642,6 +642,23 @@ int tr_wgrad(const bf16* A, const bf16* W, int M, int N, int K, float* out, hipS
     split = split < 1 ? 1 : (split > 16 ? 16 : split);
   }
   return tr_gemm_f32(A, K, W, M, N, K, out, N, nullptr, s, split > 1 && variant == GEMM_AUTO ? (int)GEMM_DMA_128 : variant, split);
+}
+// dW[M][N] = dY^T X over `rows` tokens with both operands in their own layout (wgrad.hip): no transposed copies.  Returns
+// DFOT_ERR_STATE (and does nothing) when the shape is not covered, so the caller falls back to transposes + tr_wgrad.
+int tr_wgrad_nt(const bf16* dy, long ldy, const bf16* x, long ldx, int M, int N, long rows, float* out, hipStream_t s, float* ws, size_t ws_floats) {
+  static const int enabled = tuning_flag("TRAIN_WGRAD_NT", 1);
+  static const int target = tuning_flag("TRAIN_WGRAD_NT_WGS", 512);
+  if (!enabled || M % 128 != 0 || N % 128 != 0 || rows % 64 != 0) return DFOT_ERR_STATE;
+  const long tiles = (long)(M / 128) * (N / 128);
+  int slices = (int)(target / tiles);
+  slices = slices < 1 ? 1 : (slices > 64 ? 64 : slices);
+  while (slices > 1 && (rows / 64 < 4L * slices || (size_t)slices * M * N > ws_floats)) --slices;
+  if (slices == 1) return launch_wgrad_nt(dy, ldy, x, ldx, out, M, N, rows, 1, s);
+  int rc = launch_wgrad_nt(dy, ldy, x, ldx, ws, M, N, rows, slices, s);
+  if (rc) return rc;
+  hipLaunchKernelGGL(slices_sum_kernel, dim3(cdiv((long)M * N / 4, 256)), dim3(256), 0, s, ws, out, (long)M * N / 4, slices, (long)M * N);
+  DFOT_CHECK_HIP(hipGetLastError());
+  return DFOT_OK;
 }
 int tr_gemm_bf16(const bf16* A, long lda, const bf16* W, int M, int N, int K, const float* bias, bf16* out, long ldo, hipStream_t s,
                  int bias_rows = 0, int tr_rows = 0) {
@@ -938,7 +955,7 @@ int dfot_dit_train_reserve(dfot_dit_train_t h, int max_batch) {
   WS(h->dsemb, (size_t)fp * hd); WS(h->dwf, (size_t)256 * hd > (size_t)128 * h->P ? (size_t)256 * hd : (size_t)128 * h->P);
   WS(h->dc, (size_t)frames * hd); WS(h->da1, (size_t)frames * hd); WS(h->dh1, (size_t)frames * hd); WS(h->scratch_f, (size_t)hd);
   WS(h->da, rows * hd); WS(h->dO, rows * hd); WS(h->dq, qsz); WS(h->dk, qsz); WS(h->dv, qsz);
-  WS(h->dqkv, rows * 3 * hd); WS(h->T1, rows * widest); WS(h->T2, rows * hd); WS(h->dyp, rows * 64); WS(h->dyt, (size_t)256 * rows);
+  WS(h->dqkv, rows * 3 * hd); WS(h->dqkvT, rows * widest); WS(h->T1, rows * widest); WS(h->T2, rows * hd); WS(h->dyp, rows * 64); WS(h->dyt, (size_t)256 * rows);
   WS(h->mfin, rows * hd);
   if (facmat) {
     WS(h->ma_sc, (size_t)max_batch * c.num_col_heads * c.num_row_heads * 2 * c.max_tokens * c.max_tokens);
@@ -1092,6 +1109,13 @@ int dfot_dit_train_backward(dfot_dit_train_t h, const float* d_out, void* stream
     DFOT_CHECK_HIP(hipGetLastError());
     return DFOT_OK;
   };
+  // dW[M][N] = dy^T x over `nrows` tokens: operands in place when the shape allows, else through transposed copies
+  auto wgrad = [&](const bf16* dyp, int M, const bf16* xp, int N, long nrows, float* outp) -> int {
+    int r = tr_wgrad_nt(dyp, M, xp, N, M, N, nrows, outp, s, h->wg_ws, h->wg_ws_floats);
+    if (r != DFOT_ERR_STATE) return r;
+    if ((r = tr_transpose(dyp, h->T1, (int)nrows, M, s)) || (r = tr_transpose(xp, h->dqkvT, (int)nrows, N, s))) return r;
+    return tr_wgrad(h->T1, h->dqkvT, M, N, (int)nrows, outp, s, h->wg_ws, h->wg_ws_floats);
+  };
   if ((rc = ln_bwd(h->x_fin, h->mod_final))) return rc;
 
   // ---- blocks, last to first ----
@@ -1100,21 +1124,18 @@ int dfot_dit_train_backward(dfot_dit_train_t h, const float* d_out, void* stream
     if (const int mh = b.mh) {  // out = m2 + gate2 * y, y = GELU(m2 W1^T + b1) W2^T + b2
       if ((rc = gate_bwd(b.y, b.mod2 + 2 * hd, G + b.o_fc2_b))) return rc;
       if ((rc = tr_gemm_bf16(h->da, hd, b.w_fc2T, (int)rows, mh, hd, nullptr, h->dh, mh, s))) return rc;        // dh = dy W2
-      if ((rc = tr_transpose(h->da, h->T2, (int)rows, hd, s)) || (rc = tr_transpose(b.hact, h->T1, (int)rows, mh, s))) return rc;
-      if ((rc = tr_wgrad(h->T2, h->T1, hd, mh, (int)rows, G + b.o_fc2_w, s, h->wg_ws, h->wg_ws_floats))) return rc;                           // dW2 = dy^T h
+      if ((rc = wgrad(h->da, hd, b.hact, mh, rows, G + b.o_fc2_w))) return rc;                                   // dW2 = dy^T h
       hipLaunchKernelGGL(gelu_kernel, dim3(cdiv(rows * mh / 8, 256)), dim3(256), 0, s, b.u, (bf16*)nullptr, h->dh, rows * mh / 8);  // du
       hipLaunchKernelGGL(colsum_bf16_kernel, dim3(cdiv(mh, 256), cdiv(rows, 128)), dim3(256), 0, s, h->dh, G + b.o_fc1_b, rows, mh, (long)mh);
       DFOT_CHECK_HIP(hipGetLastError());
       if ((rc = tr_gemm_f32(h->dh, mh, b.w_fc1T, (int)rows, hd, mh, dY, hd, dY, s))) return rc;                    // dm2 = dY + du W1
-      if ((rc = tr_transpose(h->dh, h->T1, (int)rows, mh, s)) || (rc = tr_transpose(b.m2, h->T2, (int)rows, hd, s))) return rc;
-      if ((rc = tr_wgrad(h->T1, h->T2, mh, hd, (int)rows, G + b.o_fc1_w, s, h->wg_ws, h->wg_ws_floats))) return rc;                           // dW1 = du^T m2
+      if ((rc = wgrad(h->dh, mh, b.m2, hd, rows, G + b.o_fc1_w))) return rc;                                    // dW1 = du^T m2
       if ((rc = ln_bwd(b.x_mid, b.mod2))) return rc;
     }
     if (!b.matrix) {
       if ((rc = gate_bwd(b.a, b.mod + 2 * hd, G + b.o_proj_b))) return rc;
       if ((rc = tr_gemm_bf16(h->da, hd, b.w_projT, (int)rows, hd, hd, nullptr, h->dO, hd, s))) return rc;      // dO = da Wp
-      if ((rc = tr_transpose(h->da, h->T1, (int)rows, hd, s)) || (rc = tr_transpose(b.o, h->T2, (int)rows, hd, s))) return rc;
-      if ((rc = tr_wgrad(h->T1, h->T2, hd, hd, (int)rows, G + b.o_proj_w, s, h->wg_ws, h->wg_ws_floats))) return rc;  // dWp = da^T o
+      if ((rc = wgrad(h->da, hd, b.o, hd, rows, G + b.o_proj_w))) return rc;  // dWp = da^T o
       if ((rc = launch_attention_bwd_delta(b.o, h->dO, hd, h->delta, nseq, c.num_heads, seq, h->d, s))) return rc;
       if ((rc = launch_attention_bwd(b.q, b.k, b.v, h->dO, hd, b.lse, h->delta, h->dq, h->dk, h->dv, nseq, c.num_heads, seq, h->d, s))) return rc;
       hipLaunchKernelGGL(qkv_grad_pack_kernel, dim3(cdiv(rows * (3 * hd / 8), 256)), dim3(256), 0, s, h->dq, h->dk, h->dv,
@@ -1122,8 +1143,7 @@ int dfot_dit_train_backward(dfot_dit_train_t h, const float* d_out, void* stream
       hipLaunchKernelGGL(colsum_bf16_kernel, dim3(cdiv(3 * hd, 256), cdiv(rows, 128)), dim3(256), 0, s, h->dqkv, G + b.o_qkv_b, rows, 3 * hd, (long)3 * hd);
       DFOT_CHECK_HIP(hipGetLastError());
       if ((rc = tr_gemm_f32(h->dqkv, 3 * hd, b.w_qkvT, (int)rows, hd, 3 * hd, dY, hd, dY, s))) return rc;       // dm = dY + dqkv Wqkv (in place)
-      if ((rc = tr_transpose(h->dqkv, h->T1, (int)rows, 3 * hd, s)) || (rc = tr_transpose(b.m, h->T2, (int)rows, hd, s))) return rc;
-      if ((rc = tr_wgrad(h->T1, h->T2, 3 * hd, hd, (int)rows, G + b.o_qkv_w, s, h->wg_ws, h->wg_ws_floats))) return rc;  // dWqkv = dqkv^T m
+      if ((rc = wgrad(h->dqkv, 3 * hd, b.m, hd, rows, G + b.o_qkv_w))) return rc;  // dWqkv = dqkv^T m
     } else {
       const bool bias = b.o_qkv_bias >= 0;
       const int fe = frames * E;
@@ -1132,8 +1152,7 @@ int dfot_dit_train_backward(dfot_dit_train_t h, const float* d_out, void* stream
       if ((rc = gate_bwd(b.a, b.mod + 2 * hd, h->scratch_f))) return rc;
       if (bias && (rc = frames_sum(h->da, G + b.o_proj_bias, (long)P * hd))) return rc;
       if ((rc = tr_gemm_bf16(h->da, hd, b.pv_s, (int)rows, hd, hd, nullptr, h->dO, hd, s))) return rc;            // ds = da V'^T  (V' stored (in, out))
-      if ((rc = tr_transpose(b.sfac, h->T1, (int)rows, hd, s)) || (rc = tr_transpose(h->da, h->T2, (int)rows, hd, s))) return rc;
-      if ((rc = tr_wgrad(h->T1, h->T2, hd, hd, (int)rows, G + b.o_proj_v, s, h->wg_ws, h->wg_ws_floats))) return rc;                          // dV'[in][out] = s^T da
+      if ((rc = wgrad(b.sfac, hd, h->da, hd, rows, G + b.o_proj_v))) return rc;                                  // dV'[in][out] = s^T da
       if ((rc = tr_transpose(h->dO, h->mt, P, hd, s, frames))) return rc;                                        // ds^T per frame [hd][P]
       if ((rc = tr_gemm_bf16(h->mt, P, b.pu_s, frames * hd, E, P, nullptr, h->do2, E, s, 0, hd))) return rc;       // do[f][e][d] = sum_p U'[e][p] ds[f][p][d]
       // dU'[e][p] = sum_{f,d} o[f][e][d] ds[f][p][d]: operands regrouped to [e][(f,d)] / [p][(f,d)]; E rows padded to 128
@@ -1155,8 +1174,7 @@ int dfot_dit_train_backward(dfot_dit_train_t h, const float* d_out, void* stream
       // z = w1 V + bias[e] ; w1[f][e][d] = sum_p U[p][e] m[f][p][d]
       if (bias && (rc = frames_sum(h->dz, G + b.o_qkv_bias, (long)E * 3 * hd))) return rc;
       if ((rc = tr_gemm_bf16(h->dz, 3 * hd, b.v_s, fe, hd, 3 * hd, nullptr, h->dw1, hd, s))) return rc;           // dw1 = dz V^T  (V stored (in, out))
-      if ((rc = tr_transpose(b.w1, h->T1, fe, hd, s)) || (rc = tr_transpose(h->dz, h->dqkv, fe, 3 * hd, s))) return rc;
-      if ((rc = tr_wgrad(h->T1, h->dqkv, hd, 3 * hd, fe, G + b.o_qkv_v, s, h->wg_ws, h->wg_ws_floats))) return rc;                            // dV[in][out] = w1^T dz
+      if ((rc = wgrad(b.w1, hd, h->dz, 3 * hd, fe, G + b.o_qkv_v))) return rc;                                   // dV[in][out] = w1^T dz
       if ((rc = tr_transpose(h->dw1, h->mt, E, hd, s, frames))) return rc;                                       // dw1^T per frame [hd][E]
       if ((rc = tr_gemm_bf16(h->mt, E, b.u_s, frames * hd, P, E, nullptr, h->dO, P, s, 0, hd))) return rc;         // dm[f][p][d] = sum_e U[p][e] dw1[f][e][d]
       hipLaunchKernelGGL(add_bf16_kernel, dim3(cdiv(rows * hd / 4, 256)), dim3(256), 0, s, dY, h->dO, rows * hd / 4);

@@ -475,3 +475,23 @@ int dfot_op_qknorm_rope_bwd(const void* fused, int ld, const void* dq, const voi
                               (long)rows, ntok, heads, d, eps, (hipStream_t)stream);
 }
 }  // extern "C"
+
+extern "C" {
+using namespace dfot;
+// test entry: out [M][N] fp32 = a^T b with a [rows][lda], b [rows][ldb] bf16 (the weight gradient dY^T X in the activations' own layout)
+int dfot_op_wgrad_nt(const void* a, int lda, const void* b, int ldb, float* out, int m, int n, int64_t rows, int slices, void* stream) {
+  DFOT_REQUIRE(a && b && out && slices >= 1, DFOT_ERR_ARG, "op_wgrad_nt: bad argument");
+  hipStream_t s = (hipStream_t)stream;
+  if (slices == 1) return launch_wgrad_nt((const bf16*)a, lda, (const bf16*)b, ldb, out, m, n, (long)rows, 1, s);
+  float* ws = nullptr;
+  DFOT_CHECK_HIP(hipMalloc(&ws, (size_t)slices * m * n * sizeof(float)));
+  int rc = launch_wgrad_nt((const bf16*)a, lda, (const bf16*)b, ldb, ws, m, n, (long)rows, slices, s);
+  if (!rc) {
+    hipLaunchKernelGGL(slices_sum_kernel, dim3(cdiv((long)m * n / 4, 256)), dim3(256), 0, s, ws, out, (long)m * n / 4, slices, (long)m * n);
+    if (hipGetLastError() != hipSuccess) rc = DFOT_ERR_HIP;
+  }
+  (void)hipStreamSynchronize(s);
+  (void)hipFree(ws);
+  return rc;
+}
+}  // extern "C"

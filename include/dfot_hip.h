@@ -286,6 +286,9 @@ int dfot_op_rms_film_bwd(const float* x, const float* dxn, const float* w, const
 int dfot_op_qknorm_rope_bwd(const void* fused, int ld, const void* dq, const void* dk, const void* dv, const float* qw, const float* kw,
                             const float* rope_cs, float eps, void* dfused, int ldo, float* dqw, float* dkw, int64_t rows, int ntok, int heads, int d,
                             void* stream);
+/* test entry of the token-axis weight-gradient GEMM: out [M][N] fp32 = a^T b, a [rows][lda] and b [rows][ldb] bf16 in the activations'
+ * own (feature-contiguous) layout; M, N multiples of 128, rows of 64; slices = K split (partial buffers are summed inside) */
+int dfot_op_wgrad_nt(const void* a, int lda, const void* b, int ldb, float* out, int m, int n, int64_t rows, int slices, void* stream);
 /* fp32 <-> bf16 helpers for tests */
 int dfot_op_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);
 int dfot_op_bf16_to_f32(const void* src, float* dst, int64_t n, void* stream);

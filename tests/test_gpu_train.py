@@ -441,3 +441,21 @@ def test_qknorm_rope_backward(d, heads, ntok, batch):
     rs = (rel(dfused.float().cpu()[:, :3 * c], fr.grad[:, :3 * c]), rel(dqw.cpu(), qwr.grad), rel(dkw.cpu(), kwr.grad))
     print(f"q/k norm + RoPE backward d={d}: " + " ".join(f"{r:.1e}" for r in rs))
     assert rs[0] < 5e-3 and rs[1] < 1e-4 and rs[2] < 1e-4
+
+
+@pytest.mark.parametrize("m,n,rows,slices", [(128, 128, 256, 1), (384, 256, 1280, 3), (1152, 128, 640, 2), (256, 1152, 4096, 4)])
+def test_wgrad_nt_gemm(m, n, rows, slices):
+    """dW = dY^T X over the token axis with both operands in their own layout (transposed LDS fragment reads), incl. K slices and
+    operands that are column blocks of wider matrices (row strides > M, N)"""
+    from dfot_amd import capi
+    g = torch.Generator().manual_seed(m + n)
+    a = torch.randn(rows, m + 64, generator=g).to(torch.bfloat16)
+    b = torch.randn(rows, n + 128, generator=g).to(torch.bfloat16)
+    ad, bd = a.cuda(), b.cuda()
+    out = torch.full((m, n), float("nan"), device="cuda")
+    capi.check(capi.lib.dfot_op_wgrad_nt(capi.ptr(ad), m + 64, capi.ptr(bd), n + 128, capi.ptr(out), m, n, rows, slices, capi.stream_ptr()))
+    torch.cuda.synchronize()
+    ref = a[:, :m].float().T @ b[:, :n].float()
+    r = rel(out.cpu(), ref)
+    print(f"wgrad_nt {m}x{n} K={rows} slices={slices}: rel {r:.2e}")
+    assert r < 1e-5
