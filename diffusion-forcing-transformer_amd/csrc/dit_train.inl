@@ -1083,7 +1083,7 @@ int dfot_dit_train_backward(dfot_dit_train_t h, const float* d_out, void* stream
   float *dY = h->dX, *dN = h->dX2;  // gradient of the current block's output / scratch for the next one
   if ((rc = launch_ln_mod(h->x_fin, dN, h->mfin, h->mod_table, h->idx, h->ldt, h->mod_final, hd, P, (int)rows, c.eps, frames - 1, s))) return rc;
   if ((rc = tr_transpose(h->mfin, h->T2, (int)rows, hd, s))) return rc;                                   // mfin^T [hd][rows]
-  if ((rc = tr_gemm_f32(h->dyt, rows, h->T2, 256, hd, (int)rows, h->dwf, hd, nullptr, s))) return rc;       // dWf in the first oc rows
+  if ((rc = tr_wgrad(h->dyt, h->T2, 256, hd, (int)rows, h->dwf, s, h->wg_ws, h->wg_ws_floats))) return rc;   // dWf in the first oc rows (18 tiles: K split)
   DFOT_CHECK_HIP(hipMemcpyAsync(G + h->o_fin_w, h->dwf, (size_t)h->oc * hd * sizeof(float), hipMemcpyDeviceToDevice, s));
   if ((rc = tr_gemm_f32(h->dyp, 64, h->wfT, (int)rows, hd, 64, dY, hd, nullptr, s))) return rc;             // d mfin
   auto ln_bwd = [&](const float* x_in, long off) -> int {  // dY holds dm; leaves dx in dY
@@ -1211,8 +1211,8 @@ int dfot_dit_train_backward(dfot_dit_train_t h, const float* d_out, void* stream
     if (b.mh && (rc = scatter(b.mod2, 3 * hd, b.o_mod2_w, b.o_mod2_b))) return rc;
   }
   if ((rc = scatter(h->mod_final, 2 * hd, h->o_fmod_w, h->o_fmod_b))) return rc;
-  DFOT_CHECK_HIP(hipMemsetAsync(h->dsemb, 0, (size_t)fp * hd * sizeof(float), s));
-  if ((rc = tr_gemm_f32(h->dmod_bf, h->ldt, h->w_modT, fp, hd, (int)h->ldt, h->dsemb, hd, nullptr, s))) return rc;  // d SiLU(c)
+  // d SiLU(c) = dmod W_mod: 256 x hidden output over K = every modulation column (99072 for DiT/XL): K split into partial buffers
+  if ((rc = tr_wgrad(h->dmod_bf, h->w_modT, fp, hd, (int)h->ldt, h->dsemb, s, h->wg_ws, h->wg_ws_floats))) return rc;
 
   // ---- noise-level embedding MLP (frames x hidden, fp32) ----
   const long fh = (long)frames * hd;
