@@ -105,9 +105,18 @@ SIGNATURES = {
     "dfot_op_attention_bwd": (_I, [_P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _P]),
     "dfot_op_conv3x3_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "dfot_op_gn_silu_bwd": (_I, [_P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _I, _I, _I, _P]),
-    "dfot_op_rms_film_bwd": (_I, [_P, _P, _P, _P, _F, _P, _P, _P, _L, _I, _P]),
+    "dfot_op_rms_film_bwd": (_I, [_P, _P, _P, _P, _F, _P, _P, _P, _L, _I, _I, _P]),
     "dfot_op_qknorm_rope_bwd": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _F, _P, _I, _P, _P, _L, _I, _I, _I, _P]),
     "dfot_op_wgrad_nt": (_I, [_P, _I, _P, _I, _P, _I, _I, _L, _I, _P]),
+    "dfot_op_gemm_bf16": (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "dfot_op_gemm_f32": (_I, [_P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "dfot_op_transpose_bf16": (_I, [_P, _P, _I, _I, _P]),
+    "dfot_op_colsum_bf16": (_I, [_P, _I, _P, _L, _I, _P]),
+    "dfot_op_rms_film_fwd": (_I, [_P, _P, _P, _F, _P, _L, _I, _P]),
+    "dfot_op_qknorm_rope_fwd": (_I, [_P, _I, _P, _P, _P, _F, _F, _P, _P, _P, _L, _I, _I, _I, _P]),
+    "dfot_op_silu_cols": (_I, [_P, _I, _I, _P, _I, _I, _P, _I, _I, _L, _I, _P]),
+    "dfot_op_attention_fwd_lse": (_I, [_P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _P]),
+    "dfot_op_attention_bwd_lse": (_I, [_P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "dfot_op_f32_to_bf16": (_I, [_P, _P, _L, _P]),
     "dfot_op_bf16_to_f32": (_I, [_P, _P, _L, _P]),
 }

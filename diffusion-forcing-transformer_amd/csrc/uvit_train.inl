@@ -460,10 +460,10 @@ extern "C" {
 using namespace dfot;
 // test entries (dw / dqw / dkw are zeroed here)
 int dfot_op_rms_film_bwd(const float* x, const float* dxn, const float* w, const void* film, float eps, float* dx, void* dfilm, float* dw,
-                         int64_t rows, int channels, void* stream) {
+                         int64_t rows, int channels, int accumulate_dx, void* stream) {
   DFOT_REQUIRE(x && dxn && w && film && dx && dfilm && dw, DFOT_ERR_ARG, "op_rms_film_bwd: null argument");
   DFOT_CHECK_HIP(hipMemsetAsync(dw, 0, (size_t)channels * sizeof(float), (hipStream_t)stream));
-  return rms_film_backward(x, dxn, w, (const bf16*)film, dx, (bf16*)dfilm, dw, (long)rows, channels, eps, false, (hipStream_t)stream);
+  return rms_film_backward(x, dxn, w, (const bf16*)film, dx, (bf16*)dfilm, dw, (long)rows, channels, eps, accumulate_dx != 0, (hipStream_t)stream);
 }
 int dfot_op_qknorm_rope_bwd(const void* fused, int ld, const void* dq, const void* dk, const void* dv, const float* qw, const float* kw,
                             const float* rope_cs, float eps, void* dfused, int ldo, float* dqw, float* dkw, int64_t rows, int ntok, int heads, int d,
@@ -493,5 +493,185 @@ int dfot_op_wgrad_nt(const void* a, int lda, const void* b, int ldb, float* out,
   (void)hipStreamSynchronize(s);
   (void)hipFree(ws);
   return rc;
+}
+}  // extern "C"
+
+// ---- forward passes in training form (values the backward needs are kept: no fused norm / activation epilogues) and generic op
+// entry points, so that a UViT training driver can be written over the C ABI op by op -------------------------------------------
+namespace dfot {
+namespace {
+
+template <int VEC, int CNT>
+__global__ __launch_bounds__(256) void rms_film_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const bf16* __restrict__ film,
+                                                           bf16* __restrict__ out, long rows, float eps) {
+  typedef typename VecT<VEC>::type V;
+  constexpr int C = 64 * VEC * CNT;
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* xr = x + row * C;
+  const bf16* fr = film + row * 2 * C;
+  V xv[CNT];
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < CNT; ++i) {
+    xv[i] = *reinterpret_cast<const V*>(xr + (i * 64 + lane) * VEC);
+    ss += vdot<VEC>(xv[i], xv[i]);
+  }
+  const float r = rsqrtf(wave_sum(ss) / (float)C + eps);
+#pragma unroll
+  for (int i = 0; i < CNT; ++i) {
+    const int c0 = (i * 64 + lane) * VEC;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      float xj;
+      if constexpr (VEC == 1) xj = xv[i]; else xj = xv[i][j];
+      out[row * C + c0 + j] = f2bf(xj * r * w[c0 + j] * (1.0f + bf2f(fr[c0 + j])) + bf2f(fr[C + c0 + j]));
+    }
+  }
+}
+
+// fused [rows][ld] (q | k | v head-major) -> q (RMSNorm, RoPE, * qscale), k (RMSNorm, RoPE), v in the attention layout [B][heads][ntok][d]
+template <int EPL>
+__global__ __launch_bounds__(256) void qknorm_rope_fwd_kernel(const bf16* __restrict__ fused, long ld, const float* __restrict__ qw,
+                                                              const float* __restrict__ kw, const float* __restrict__ rope_cs, bf16* __restrict__ q,
+                                                              bf16* __restrict__ k, bf16* __restrict__ v, long rows, int ntok, int heads, float eps,
+                                                              float qscale) {
+  constexpr int D = 64 * EPL;
+  const int lane = threadIdx.x & 63;
+  const long item = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (item >= rows * heads) return;
+  const long row = item / heads;
+  const int head = (int)(item % heads);
+  const long b = row / ntok;
+  const int tok = (int)(row % ntok);
+  const int C = heads * D;
+  const long ooff = ((b * heads + head) * ntok + tok) * (long)D + lane * EPL;
+#pragma unroll
+  for (int which = 0; which < 2; ++which) {
+    const bf16* src = fused + row * ld + (long)which * C + head * D + lane * EPL;
+    const float* wt = (which == 0 ? qw : kw) + lane * EPL;
+    float xv[EPL];
+    float ss = 0.f;
+#pragma unroll
+    for (int j = 0; j < EPL; ++j) { xv[j] = bf2f(src[j]); ss += xv[j] * xv[j]; }
+    const float r = rsqrtf(wave_sum(ss) / (float)D + eps);
+#pragma unroll
+    for (int j = 0; j < EPL; ++j) xv[j] = xv[j] * r * wt[j];
+    const float mul = which == 0 ? qscale : 1.f;
+    bf16* dst = (which == 0 ? q : k) + ooff;
+    if constexpr (EPL == 2) {
+      const float* cs = rope_cs + ((long)tok * (D / 2) + lane) * 2;
+      dst[0] = f2bf((xv[0] * cs[0] - xv[1] * cs[1]) * mul);
+      dst[1] = f2bf((xv[1] * cs[0] + xv[0] * cs[1]) * mul);
+    } else {
+      const float* cs = rope_cs + ((long)tok * (D / 2) + (lane >> 1)) * 2;
+      const float other = __shfl_xor(xv[0], 1);
+      dst[0] = f2bf(((lane & 1) ? (xv[0] * cs[0] + other * cs[1]) : (xv[0] * cs[0] - other * cs[1])) * mul);
+    }
+  }
+  const bf16* vs = fused + row * ld + 2L * C + head * D + lane * EPL;
+#pragma unroll
+  for (int j = 0; j < EPL; ++j) v[ooff + j] = vs[j];
+}
+
+// dst[r][dcol0 + c] = SiLU(src[r][scol0 + c])            (grad == nullptr)
+// dst[r][dcol0 + c] = grad[r][gcol0 + c] * SiLU'(src...)  (grad != nullptr);   8 columns per thread
+__global__ void silu_cols_kernel(const bf16* __restrict__ src, long lds_, int scol0, const bf16* __restrict__ grad, long ldg, int gcol0,
+                                 bf16* __restrict__ dst, long ldd, int dcol0, long rows, int ncols) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int c8 = ncols / 8;
+  if (i >= rows * c8) return;
+  const long r = i / c8;
+  const int c = (int)(i % c8) * 8;
+  const bf16x8 xv = *reinterpret_cast<const bf16x8*>(src + r * lds_ + scol0 + c);
+  bf16x8 o;
+  if (grad) {
+    const bf16x8 gv = *reinterpret_cast<const bf16x8*>(grad + r * ldg + gcol0 + c);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = f2bf(bf2f(gv[j]) * silu_grad(bf2f(xv[j])));
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = f2bf(silu_f(bf2f(xv[j])));
+  }
+  *reinterpret_cast<bf16x8*>(dst + r * ldd + dcol0 + c) = o;
+}
+
+}  // namespace
+}  // namespace dfot
+
+extern "C" {
+using namespace dfot;
+
+int dfot_op_gemm_bf16(const void* a, int lda, const void* w, const float* bias, void* out, int ldo, int m, int n, int k, void* stream) {
+  DFOT_REQUIRE(a && w && out, DFOT_ERR_ARG, "op_gemm_bf16: null argument");
+  return tr_gemm_bf16((const bf16*)a, lda, (const bf16*)w, m, n, k, bias, (bf16*)out, ldo, (hipStream_t)stream);
+}
+int dfot_op_gemm_f32(const void* a, int lda, const void* w, const float* bias, const float* resid, float* out, int ldo, int m, int n, int k,
+                     void* stream) {
+  DFOT_REQUIRE(a && w && out, DFOT_ERR_ARG, "op_gemm_f32: null argument");
+  GemmArgs g;
+  g.A = (const bf16*)a; g.lda = lda; g.W = (const bf16*)w; g.M = m; g.N = n; g.K = k; g.bias = bias; g.out_f32 = out; g.ldo = ldo; g.resid = resid;
+  return launch_gemm(A_DENSE, E_F32, GEMM_AUTO, g, (hipStream_t)stream);
+}
+int dfot_op_transpose_bf16(const void* src, void* dst, int rows, int cols, void* stream) {
+  DFOT_REQUIRE(src && dst, DFOT_ERR_ARG, "op_transpose_bf16: null argument");
+  return tr_transpose((const bf16*)src, (bf16*)dst, rows, cols, (hipStream_t)stream);
+}
+int dfot_op_colsum_bf16(const void* src, int ld, float* out, int64_t rows, int n, void* stream) {
+  DFOT_REQUIRE(src && out, DFOT_ERR_ARG, "op_colsum_bf16: null argument");
+  hipStream_t s = (hipStream_t)stream;
+  DFOT_CHECK_HIP(hipMemsetAsync(out, 0, (size_t)n * sizeof(float), s));
+  hipLaunchKernelGGL(colsum_bf16_kernel, dim3(cdiv(n, 256), cdiv(rows, 128)), dim3(256), 0, s, (const bf16*)src, out, (long)rows, n, (long)ld);
+  DFOT_CHECK_HIP(hipGetLastError());
+  return DFOT_OK;
+}
+int dfot_op_rms_film_fwd(const float* x, const float* w, const void* film, float eps, void* out, int64_t rows, int channels, void* stream) {
+  DFOT_REQUIRE(x && w && film && out, DFOT_ERR_ARG, "op_rms_film_fwd: null argument");
+  hipStream_t s = (hipStream_t)stream;
+  const int hidden = channels;
+#define CALL(V, C) \
+  hipLaunchKernelGGL((rms_film_fwd_kernel<V, C>), dim3(cdiv(rows, 4)), dim3(256), 0, s, x, w, (const bf16*)film, (bf16*)out, (long)rows, eps)
+  DIT_LN_DISPATCH(CALL)
+#undef CALL
+  DFOT_CHECK_HIP(hipGetLastError());
+  return DFOT_OK;
+}
+int dfot_op_qknorm_rope_fwd(const void* fused, int ld, const float* qw, const float* kw, const float* rope_cs, float eps, float qscale, void* q,
+                            void* k, void* v, int64_t rows, int ntok, int heads, int d, void* stream) {
+  DFOT_REQUIRE(fused && qw && kw && rope_cs && q && k && v && (d == 64 || d == 128), DFOT_ERR_ARG, "op_qknorm_rope_fwd: bad argument");
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 grid(cdiv((long)rows * heads, 4));
+  if (d == 64)
+    hipLaunchKernelGGL(qknorm_rope_fwd_kernel<1>, grid, dim3(256), 0, s, (const bf16*)fused, (long)ld, qw, kw, rope_cs, (bf16*)q, (bf16*)k, (bf16*)v,
+                       (long)rows, ntok, heads, eps, qscale);
+  else
+    hipLaunchKernelGGL(qknorm_rope_fwd_kernel<2>, grid, dim3(256), 0, s, (const bf16*)fused, (long)ld, qw, kw, rope_cs, (bf16*)q, (bf16*)k, (bf16*)v,
+                       (long)rows, ntok, heads, eps, qscale);
+  DFOT_CHECK_HIP(hipGetLastError());
+  return DFOT_OK;
+}
+// grad == NULL: dst[:, dcol0:+ncols] = SiLU(src[:, scol0:+ncols]); else dst = grad[:, gcol0:+ncols] * SiLU'(src[:, scol0:+ncols])
+int dfot_op_silu_cols(const void* src, int lds_, int scol0, const void* grad, int ldg, int gcol0, void* dst, int ldd, int dcol0, int64_t rows,
+                      int ncols, void* stream) {
+  DFOT_REQUIRE(src && dst && ncols % 8 == 0 && scol0 % 8 == 0 && dcol0 % 8 == 0 && gcol0 % 8 == 0, DFOT_ERR_ARG, "op_silu_cols: bad argument");
+  hipLaunchKernelGGL(silu_cols_kernel, dim3(cdiv((long)rows * (ncols / 8), 256)), dim3(256), 0, (hipStream_t)stream, (const bf16*)src, (long)lds_, scol0,
+                     (const bf16*)grad, (long)ldg, gcol0, (bf16*)dst, (long)ldd, dcol0, (long)rows, ncols);
+  DFOT_CHECK_HIP(hipGetLastError());
+  return DFOT_OK;
+}
+// attention with the log-sum-exp kept (lse [B][heads][N] fp32) and its backward from saved q / k / v / o / lse (delta: scratch like lse)
+int dfot_op_attention_fwd_lse(const void* q, const void* k, const void* v, void* o, int ldo, float* lse, int batch, int heads, int n, int d,
+                              void* stream) {
+  return launch_attention_padded((const bf16*)q, (const bf16*)k, (const bf16*)v, (bf16*)o, ldo, batch, heads, n, d, (hipStream_t)stream, lse);
+}
+int dfot_op_attention_bwd_lse(const void* q, const void* k, const void* v, const void* o, const void* d_o, int ldo, const float* lse, float* delta,
+                              void* dq, void* dk, void* dv, int batch, int heads, int n, int d, void* stream) {
+  DFOT_REQUIRE(q && k && v && o && d_o && lse && delta && dq && dk && dv, DFOT_ERR_ARG, "op_attention_bwd_lse: null argument");
+  hipStream_t s = (hipStream_t)stream;
+  int rc = launch_attention_bwd_delta((const bf16*)o, (const bf16*)d_o, ldo, delta, batch, heads, n, d, s);
+  if (rc) return rc;
+  return launch_attention_bwd((const bf16*)q, (const bf16*)k, (const bf16*)v, (const bf16*)d_o, ldo, lse, delta, (bf16*)dq, (bf16*)dk, (bf16*)dv, batch,
+                              heads, n, d, s);
 }
 }  // extern "C"

@@ -280,7 +280,7 @@ int dfot_op_gn_silu_bwd(const float* x, const float* dy, const float* gamma, con
 /* test entries of the UViT TransformerBlock backward pieces (u_vit_blocks.py:96-116,192-281):
  * NormalizeWithCond: xn = RMSNorm(x; w) (1 + scale) + shift with film [rows][2C] bf16 = (scale | shift): dx fp32, dfilm bf16, dw fp32 [C] */
 int dfot_op_rms_film_bwd(const float* x, const float* dxn, const float* w, const void* film, float eps, float* dx, void* dfilm, float* dw,
-                         int64_t rows, int channels, void* stream);
+                         int64_t rows, int channels, int accumulate_dx, void* stream);
 /* per-head q / k RMSNorm + RoPE (rope_cs [ntok][d/2][2] = cos, sin): fused [rows][ld] bf16 holds (q | k | v) head-major in its first 3C
  * columns, dq / dk / dv [B][heads][ntok][d] bf16 are the attention backward's outputs; writes dfused [rows][ldo] columns [0, 3C), dqw / dkw [d] */
 int dfot_op_qknorm_rope_bwd(const void* fused, int ld, const void* dq, const void* dk, const void* dv, const float* qw, const float* kw,
@@ -289,6 +289,23 @@ int dfot_op_qknorm_rope_bwd(const void* fused, int ld, const void* dq, const voi
 /* test entry of the token-axis weight-gradient GEMM: out [M][N] fp32 = a^T b, a [rows][lda] and b [rows][ldb] bf16 in the activations'
  * own (feature-contiguous) layout; M, N multiples of 128, rows of 64; slices = K split (partial buffers are summed inside) */
 int dfot_op_wgrad_nt(const void* a, int lda, const void* b, int ldb, float* out, int m, int n, int64_t rows, int slices, void* stream);
+/* op-level entry points a training driver composes (all on device pointers, bf16 activations unless noted):
+ * out = a w^T (+ bias) in bf16 / fp32 (+ resid); transposes; column sums; the training-form forwards of the UViT TransformerBlock pieces
+ * (values the backward needs are kept: no fused norm / activation epilogues); attention with its log-sum-exp and the backward from it */
+int dfot_op_gemm_bf16(const void* a, int lda, const void* w, const float* bias, void* out, int ldo, int m, int n, int k, void* stream);
+int dfot_op_gemm_f32(const void* a, int lda, const void* w, const float* bias, const float* resid, float* out, int ldo, int m, int n, int k,
+                     void* stream);
+int dfot_op_transpose_bf16(const void* src, void* dst, int rows, int cols, void* stream);
+int dfot_op_colsum_bf16(const void* src, int ld, float* out, int64_t rows, int n, void* stream);
+int dfot_op_rms_film_fwd(const float* x, const float* w, const void* film, float eps, void* out, int64_t rows, int channels, void* stream);
+int dfot_op_qknorm_rope_fwd(const void* fused, int ld, const float* qw, const float* kw, const float* rope_cs, float eps, float qscale, void* q,
+                            void* k, void* v, int64_t rows, int ntok, int heads, int d, void* stream);
+int dfot_op_silu_cols(const void* src, int lds_, int scol0, const void* grad, int ldg, int gcol0, void* dst, int ldd, int dcol0, int64_t rows,
+                      int ncols, void* stream);
+int dfot_op_attention_fwd_lse(const void* q, const void* k, const void* v, void* o, int ldo, float* lse, int batch, int heads, int n, int d,
+                              void* stream);
+int dfot_op_attention_bwd_lse(const void* q, const void* k, const void* v, const void* o, const void* d_o, int ldo, const float* lse, float* delta,
+                              void* dq, void* dk, void* dv, int batch, int heads, int n, int d, void* stream);
 /* fp32 <-> bf16 helpers for tests */
 int dfot_op_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);
 int dfot_op_bf16_to_f32(const void* src, float* dst, int64_t n, void* stream);

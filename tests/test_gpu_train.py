@@ -403,7 +403,7 @@ def test_rms_film_backward(rows, c):
     dx, dw = torch.full((rows, c), float("nan"), device="cuda"), torch.empty(c, device="cuda")
     dfilm = torch.empty(rows, 2 * c, dtype=torch.bfloat16, device="cuda")
     capi.check(capi.lib.dfot_op_rms_film_bwd(capi.ptr(xd), capi.ptr(gd), capi.ptr(wd), capi.ptr(fd), 1e-6, capi.ptr(dx), capi.ptr(dfilm), capi.ptr(dw),
-                                             rows, c, capi.stream_ptr()))
+                                             rows, c, 0, capi.stream_ptr()))
     torch.cuda.synchronize()
     xr, wr, fr = x.clone().requires_grad_(), w.clone().requires_grad_(), film.float().requires_grad_()
     (ouvit.rms_norm(xr, wr, 1e-6) * (1 + fr[:, :c]) + fr[:, c:]).backward(dxn)
@@ -459,3 +459,43 @@ def test_wgrad_nt_gemm(m, n, rows, slices):
     r = rel(out.cpu(), ref)
     print(f"wgrad_nt {m}x{n} K={rows} slices={slices}: rel {r:.2e}")
     assert r < 1e-5
+
+
+@pytest.mark.parametrize("c,heads", [(1152, 9), (576, 9)])
+def test_uvit_transformer_block_train_unit(c, heads):
+    """forward + hand-written backward of one UViT TransformerBlock (level 3: C = 1152, d = 128; level 2: C = 576, d = 64) composed over the
+    C ABI vs torch autograd through the oracle's transformer_block: output, dx, d(embedding) and every parameter gradient"""
+    from dfot_amd import uvit_train as ut
+    from oracle import uvit as ouvit
+    e, batch, sizes = 256, 2, (2, 8, 8)
+    ntok = sizes[0] * sizes[1] * sizes[2]
+    d = c // heads
+    g = torch.Generator().manual_seed(c)
+    shapes = ouvit._tr_block_shapes("blk", c, e, heads)
+    params = {}
+    for n, shp in shapes.items():
+        if n.endswith("norm.weight") or n.endswith("q_norm.weight") or n.endswith("k_norm.weight"):
+            params[n] = 1 + 0.1 * torch.randn(shp, generator=g)
+        elif n.endswith("bias"):
+            params[n] = 0.05 * torch.randn(shp, generator=g)
+        else:
+            params[n] = torch.randn(shp, generator=g) / math.sqrt(shp[-1])
+    x = torch.randn(batch, ntok, c, generator=g)
+    emb = (torch.randn(batch, ntok, e, generator=g) * 0.5).to(torch.bfloat16)
+    dy = torch.randn(batch, ntok, c, generator=g)
+    blk = ut.TransformerBlockTrain(params, "blk", c, heads, ut.rope_table(d, sizes))
+    y = blk.forward(x.view(-1, c).cuda(), emb.view(-1, e).cuda().contiguous(), batch)
+    dx, demb = blk.backward(dy.view(-1, c).cuda())
+    torch.cuda.synchronize()
+    ps = {n: t.clone().requires_grad_() for n, t in params.items()}
+    xr, er = x.clone().requires_grad_(), emb.float().requires_grad_()
+    cfg = ouvit.UViTConfig(num_heads=heads)
+    ang = ouvit.rope3d_angles(d, sizes, cfg.rope_theta)
+    ref = ouvit.transformer_block(ps, "blk", xr, er, ang, cfg)
+    ref.backward(dy)
+    rs = {"y": rel(y.cpu().view_as(ref), ref.detach()), "dx": rel(dx.cpu().view_as(x), xr.grad), "demb": rel(demb.cpu().view_as(er), er.grad)}
+    for n in blk.grads:
+        rs[n] = rel(blk.grads[n].cpu(), ps["blk." + n].grad)
+    worst = max(rs, key=rs.get)
+    print(f"UViT TransformerBlock unit C={c}: worst rel-L2 {rs[worst]:.2e} at {worst}; y {rs['y']:.1e} dx {rs['dx']:.1e} demb {rs['demb']:.1e}")
+    assert rs["y"] < 1e-2 and max(rs.values()) < 3e-2, rs
