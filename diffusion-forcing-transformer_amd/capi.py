@@ -117,6 +117,24 @@ SIGNATURES = {
     "dfot_op_silu_cols": (_I, [_P, _I, _I, _P, _I, _I, _P, _I, _I, _L, _I, _P]),
     "dfot_op_attention_fwd_lse": (_I, [_P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _P]),
     "dfot_op_attention_bwd_lse": (_I, [_P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "dfot_op_gn_silu_fwd": (_I, [_P, _P, _P, _P, _F, _P, _P, _I, _I, _I, _P]),
+    "dfot_op_gn_silu_bwd2": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "dfot_op_pack_conv3": (_I, [_P, _P, _I, _I, _I, _P]),
+    "dfot_op_conv3x3_f32": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "dfot_op_pool2_bf16": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "dfot_op_pool2_bwd": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "dfot_op_sub_bf16": (_I, [_P, _P, _P, _L, _P]),
+    "dfot_op_upsample_add": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
+    "dfot_op_upsample_bwd": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "dfot_op_axpy": (_I, [_P, _P, _F, _L, _P]),
+    "dfot_op_emb_combine": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "dfot_op_emb_pyramid": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
+    "dfot_op_rows_sum": (_I, [_P, _P, _I, _I, _I, _P]),
+    "dfot_op_cond_repack": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "dfot_op_embed_input": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "dfot_op_embed_input_wgrad": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "dfot_op_project_output": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "dfot_op_outgrad_gather": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "dfot_op_f32_to_bf16": (_I, [_P, _P, _L, _P]),
     "dfot_op_bf16_to_f32": (_I, [_P, _P, _L, _P]),
 }

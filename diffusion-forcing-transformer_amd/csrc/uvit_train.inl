@@ -675,3 +675,204 @@ int dfot_op_attention_bwd_lse(const void* q, const void* k, const void* v, const
                               heads, n, d, s);
 }
 }  // extern "C"
+
+// ---- ResBlock / resampler / embedding pieces for the UViT training driver ------------------------------------------------------------
+namespace dfot {
+namespace {
+
+// out bf16 = SiLU(GN(x) [* (1 + scale) + shift])   (x fp32 [BT][P][C], stats [BT][32][2], film bf16 [BT*P][2C] or null)
+__global__ void gn_silu_fwd_kernel(const float* __restrict__ x, const float* __restrict__ stats, const float* __restrict__ gamma,
+                                   const float* __restrict__ beta, const bf16* __restrict__ film, bf16* __restrict__ out, long total, int P, int C) {
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= total) return;
+  const int c = (int)(e % C);
+  const long row = e / C;
+  const int bt = (int)(row / P), grp = c / (C / 32);
+  const float mean = stats[((long)bt * 32 + grp) * 2], rstd = stats[((long)bt * 32 + grp) * 2 + 1];
+  float z = (x[e] - mean) * rstd * gamma[c] + beta[c];
+  if (film) z = z * (1.0f + bf2f(film[row * 2 * C + c])) + bf2f(film[row * 2 * C + C + c]);
+  out[e] = f2bf(silu_f(z));
+}
+
+// dx[bt][2y+a][2x+b][c] += dp[bt][y][x][c] / 4   (adjoint of the 2x2 average pool; dx fp32 [BT][H][W][C], dp fp32 [BT][H/2][W/2][C])
+__global__ void pool2_bwd_kernel(const float* __restrict__ dp, float* __restrict__ dx, long total, int H, int W, int C) {
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= total) return;
+  const int c = (int)(e % C);
+  const long pix = e / C;
+  const int x = (int)(pix % W), y = (int)((pix / W) % H);
+  const long bt = pix / ((long)W * H);
+  dx[e] += 0.25f * dp[((bt * (H / 2) + y / 2) * (W / 2) + x / 2) * C + c];
+}
+// ds[bt][y][x][c] = sum of the 2x2 block of dy (adjoint of the nearest-neighbour upsample; dy fp32 [BT][H][W][C])
+__global__ void upsample_bwd_kernel(const float* __restrict__ dy, float* __restrict__ ds, long total, int H, int W, int C) {
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= total) return;  // total = BT * (H/2) * (W/2) * C
+  const int c = (int)(e % C);
+  const long pix = e / C;
+  const int x = (int)(pix % (W / 2)), y = (int)((pix / (W / 2)) % (H / 2));
+  const long bt = pix / ((long)(W / 2) * (H / 2));
+  const float* b = dy + ((bt * H + 2 * y) * W + 2 * x) * C + c;
+  ds[e] = (b[0] + b[C]) + (b[(long)W * C] + b[(long)W * C + C]);
+}
+// y = a + alpha * b  (fp32, in place on a)
+__global__ void axpy_kernel(float* __restrict__ a, const float* __restrict__ b, float alpha, long n) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) a[i] += alpha * b[i];
+}
+// emb0[row][e] = bf16((masked ? 0 : pose[row][e]) + nemb[row / P][e])
+__global__ void emb_combine_kernel(const bf16* __restrict__ pose, const float* __restrict__ nemb, const uint8_t* __restrict__ mask, bf16* __restrict__ out,
+                                   long total, int P, int E, int tokens) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const long row = i / E;
+  const int e = (int)(i % E);
+  const long bt = row / P;
+  const bool drop = mask && mask[bt / tokens];
+  out[i] = f2bf((drop ? 0.f : bf2f(pose[i])) + nemb[bt * E + e]);
+}
+// fine[bt][2y+a][2x+b][e] += coarse[bt][y][x][e] / 4   (adjoint of one level of the embedding pyramid's average pool), fp32
+// == pool2_bwd_kernel; dnemb[bt][e] = sum_p demb0[bt][p][e] is frames-style column sum over P rows:
+__global__ void rows_sum_kernel(const float* __restrict__ src, float* __restrict__ out, int P, int E) {
+  const int bt = blockIdx.y;
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  float acc = 0.f;
+  for (int p = 0; p < P; ++p) acc += src[((long)bt * P + p) * E + e];
+  out[(long)bt * E + e] = acc;
+}
+// gradient of the ConvTranspose(k = s = p) output [BT][Co][R][R] gathered per input pixel: dpatch [pix][64] bf16, column (co, py, px)
+__global__ void outgrad_gather_kernel(const float* __restrict__ dout, bf16* __restrict__ dpatch, long pix, int R, int co, int ps) {
+  const int n = co * ps * ps;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= pix * n) return;
+  const long p = i / n;
+  const int col = (int)(i % n);
+  const int o = col / (ps * ps), py = (col / ps) % ps, px = col % ps;
+  const int g = R / ps;
+  const int x = (int)(p % g), y = (int)((p / g) % g);
+  const long bt = p / ((long)g * g);
+  dpatch[p * 64 + col] = f2bf(dout[((bt * co + o) * R + y * ps + py) * R + x * ps + px]);
+}
+
+}  // namespace
+}  // namespace dfot
+
+extern "C" {
+using namespace dfot;
+
+int dfot_op_gn_silu_fwd(const float* x, const float* gamma, const float* beta, const void* film, float eps, void* out, float* stats, int bt,
+                        int pixels, int channels, void* stream) {
+  DFOT_REQUIRE(x && gamma && beta && out && stats && channels % 32 == 0, DFOT_ERR_ARG, "op_gn_silu_fwd: bad argument");
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(gn_stats_kernel, dim3(bt, 32), dim3(256), 0, s, x, stats, pixels, channels, eps);
+  const long total = (long)bt * pixels * channels;
+  hipLaunchKernelGGL(gn_silu_fwd_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, x, stats, gamma, beta, (const bf16*)film, (bf16*)out, total, pixels,
+                     channels);
+  DFOT_CHECK_HIP(hipGetLastError());
+  return DFOT_OK;
+}
+// backward with saved statistics; dx += when accumulate_dx; dgamma / dbeta are zeroed here
+int dfot_op_gn_silu_bwd2(const float* x, const float* dy, const float* stats, const float* gamma, const float* beta, const void* film, float* dx,
+                         void* dfilm, float* dgamma, float* dbeta, int bt, int pixels, int channels, int accumulate_dx, void* stream) {
+  DFOT_REQUIRE(x && dy && stats && gamma && beta && dx && dgamma && dbeta, DFOT_ERR_ARG, "op_gn_silu_bwd2: null argument");
+  hipStream_t s = (hipStream_t)stream;
+  float* sums = nullptr;
+  DFOT_CHECK_HIP(hipMalloc(&sums, (size_t)bt * 64 * sizeof(float)));
+  DFOT_CHECK_HIP(hipMemsetAsync(dgamma, 0, (size_t)channels * sizeof(float), s));
+  DFOT_CHECK_HIP(hipMemsetAsync(dbeta, 0, (size_t)channels * sizeof(float), s));
+  int rc = gn_silu_backward(x, dy, stats, gamma, beta, (const bf16*)film, sums, dx, (bf16*)dfilm, dgamma, dbeta, bt, pixels, channels, accumulate_dx != 0, s);
+  (void)hipStreamSynchronize(s);
+  (void)hipFree(sums);
+  return rc;
+}
+// w fp32 [Co][Ci][3][3] -> the forward kernel's layout [Co][tap][Ci] bf16 (dgrad = 0) or the data-gradient weights [Ci][tap'][Co] (dgrad = 1)
+int dfot_op_pack_conv3(const float* w, void* out, int co, int ci, int dgrad, void* stream) {
+  DFOT_REQUIRE(w && out, DFOT_ERR_ARG, "op_pack_conv3: null argument");
+  if (!dgrad) return launch_pack_conv3(w, (bf16*)out, co, ci, (hipStream_t)stream);
+  hipLaunchKernelGGL(pack_conv3_dgrad_kernel, dim3(cdiv((long)co * ci * 9, 256)), dim3(256), 0, (hipStream_t)stream, w, (bf16*)out, co, ci);
+  DFOT_CHECK_HIP(hipGetLastError());
+  return DFOT_OK;
+}
+// y fp32 [BT,H,W,Cout] = conv3x3(a bf16 [BT,H,W,Cin], w packed [Cout][9*Cin]) + bias (+ resid)
+int dfot_op_conv3x3_f32(const void* a, const void* w, const float* bias, const float* resid, float* y, int bt, int hh, int ww, int cin, int cout,
+                        void* stream) {
+  DFOT_REQUIRE(a && w && y, DFOT_ERR_ARG, "op_conv3x3_f32: null argument");
+  static bf16* zeros = nullptr;
+  if (!zeros) {
+    DFOT_CHECK_HIP(hipMalloc(&zeros, 256));
+    DFOT_CHECK_HIP(hipMemset(zeros, 0, 256));
+  }
+  GemmArgs g;
+  g.zeros = zeros;
+  g.A = (const bf16*)a; g.W = (const bf16*)w; g.M = bt * hh * ww; g.N = cout; g.K = 9 * cin; g.H = hh; g.Wd = ww; g.Cin = cin;
+  g.bias = bias; g.resid = resid; g.out_f32 = y; g.ldo = cout;
+  return launch_gemm(A_CONV3, E_F32, GEMM_AUTO, g, (hipStream_t)stream);
+}
+int dfot_op_pool2_bf16(const float* x, void* out, int bt, int h, int w, int c, void* stream) { return launch_pool2_bf16(x, (bf16*)out, bt, h, w, c, (hipStream_t)stream); }
+int dfot_op_pool2_bwd(const float* dp, float* dx, int bt, int h, int w, int c, void* stream) {
+  const long total = (long)bt * h * w * c;
+  hipLaunchKernelGGL(pool2_bwd_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, dp, dx, total, h, w, c);
+  DFOT_CHECK_HIP(hipGetLastError());
+  return DFOT_OK;
+}
+int dfot_op_sub_bf16(const float* a, const float* b, void* out, int64_t n, void* stream) { return launch_sub_bf16(a, b, (bf16*)out, (long)n, (hipStream_t)stream); }
+int dfot_op_upsample_add(const float* t, const float* skip, float* out, int bt, int h, int w, int c, void* stream) {
+  return launch_upsample_add(t, skip, out, bt, h, w, c, (hipStream_t)stream);
+}
+int dfot_op_upsample_bwd(const float* dy, float* ds, int bt, int h, int w, int c, void* stream) {
+  const long total = (long)bt * (h / 2) * (w / 2) * c;
+  hipLaunchKernelGGL(upsample_bwd_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, dy, ds, total, h, w, c);
+  DFOT_CHECK_HIP(hipGetLastError());
+  return DFOT_OK;
+}
+int dfot_op_axpy(float* a, const float* b, float alpha, int64_t n, void* stream) {
+  hipLaunchKernelGGL(axpy_kernel, dim3(cdiv((long)n, 256)), dim3(256), 0, (hipStream_t)stream, a, b, alpha, (long)n);
+  DFOT_CHECK_HIP(hipGetLastError());
+  return DFOT_OK;
+}
+int dfot_op_emb_combine(const void* pose, const float* nemb, const uint8_t* mask, void* out, int bt, int pixels, int e, int tokens, void* stream) {
+  const long total = (long)bt * pixels * e;
+  hipLaunchKernelGGL(emb_combine_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16*)pose, nemb, mask, (bf16*)out, total, pixels, e,
+                     tokens);
+  DFOT_CHECK_HIP(hipGetLastError());
+  return DFOT_OK;
+}
+int dfot_op_emb_pyramid(const void* emb0, void* emb1, void* emb2, void* emb3, int bt, int r0, int e, void* stream) {
+  return launch_emb_pyramid((const bf16*)emb0, (bf16*)emb1, (bf16*)emb2, (bf16*)emb3, bt, r0, e, (hipStream_t)stream);
+}
+int dfot_op_rows_sum(const float* src, float* out, int bt, int pixels, int e, void* stream) {
+  hipLaunchKernelGGL(rows_sum_kernel, dim3(cdiv(e, 256), bt), dim3(256), 0, (hipStream_t)stream, src, out, pixels, e);
+  DFOT_CHECK_HIP(hipGetLastError());
+  return DFOT_OK;
+}
+int dfot_op_cond_repack(const float* cond, void* a, int bt, int res, int cdim, int kpad, void* stream) {
+  return launch_cond_repack(cond, (bf16*)a, bt, res, cdim, kpad, (hipStream_t)stream);
+}
+int dfot_op_embed_input(const float* x, const float* w, const float* b, float* out, int bt, int res, int cin, int c0, void* stream) {
+  return launch_embed_input(x, w, b, out, bt, res, cin, c0, (hipStream_t)stream);
+}
+// dW [C0][Cin][p][p] += , db [C0] += of the k = s = p patch embedding (dx0 fp32 [pix][C0], x fp32 [BT][Cin][R][R]); outputs zeroed here
+int dfot_op_embed_input_wgrad(const float* dx0, const float* x, float* dw, float* db, int bt, int res, int cin, int c0, int ps, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  const long rows = (long)bt * (res / ps) * (res / ps);
+  const int kdim = cin * ps * ps;
+  DFOT_CHECK_HIP(hipMemsetAsync(dw, 0, (size_t)c0 * kdim * sizeof(float), s));
+  DFOT_CHECK_HIP(hipMemsetAsync(db, 0, (size_t)c0 * sizeof(float), s));
+  hipLaunchKernelGGL(pe_wgrad_kernel, dim3(cdiv(c0, 256), cdiv(rows, 64)), dim3(256), 64 * kdim * sizeof(float), s, dx0, x, dw, db, cin, res, res, ps, c0, rows);
+  DFOT_CHECK_HIP(hipGetLastError());
+  return DFOT_OK;
+}
+int dfot_op_project_output(const float* x0, const float* w, const float* b, float* out, int bt, int res, int c0, int cout, void* stream) {
+  return launch_project_output(x0, w, b, out, bt, res, c0, cout, (hipStream_t)stream);
+}
+int dfot_op_outgrad_gather(const float* dout, void* dpatch, int bt, int res, int cout, int ps, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  const long pix = (long)bt * (res / ps) * (res / ps);
+  DFOT_REQUIRE(cout * ps * ps <= 64, DFOT_ERR_SHAPE, "outgrad_gather: more than 64 output values per pixel");
+  DFOT_CHECK_HIP(hipMemsetAsync(dpatch, 0, (size_t)pix * 64 * sizeof(bf16), s));
+  hipLaunchKernelGGL(outgrad_gather_kernel, dim3(cdiv(pix * cout * ps * ps, 256)), dim3(256), 0, s, dout, (bf16*)dpatch, pix, res, cout, ps);
+  DFOT_CHECK_HIP(hipGetLastError());
+  return DFOT_OK;
+}
+}  // extern "C"

@@ -163,3 +163,81 @@ class TransformerBlockTrain:
             "mlp_out.2.bias": db_out.clone(),
         }
         return dx, demb
+
+
+def conv3x3(a: torch.Tensor, w_packed: torch.Tensor, bias: torch.Tensor, bt: int, h: int, w: int, cin: int, cout: int,
+            resid: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """a bf16 [BT*H*W][Cin] channels-last -> fp32 [BT*H*W][Cout] (+ resid)"""
+    out = torch.empty(bt * h * w, cout, dtype=torch.float32, device="cuda")
+    capi.check(capi.lib.dfot_op_conv3x3_f32(_P(a), _P(w_packed), _P(bias), _P(resid), _P(out), bt, h, w, cin, cout, _S()))
+    return out
+
+
+def conv3x3_backward(x: torch.Tensor, dy: torch.Tensor, w: torch.Tensor, bt: int, h: int, wd: int, cin: int, cout: int):
+    """x bf16 [pix][Cin], dy bf16 [pix][Cout], w fp32 [Cout][Cin][3][3] -> (dx fp32 [pix][Cin], dW fp32, db fp32)"""
+    dx = torch.empty(bt * h * wd, cin, dtype=torch.float32, device="cuda")
+    dw, db = torch.empty_like(w), torch.empty(cout, dtype=torch.float32, device="cuda")
+    capi.check(capi.lib.dfot_op_conv3x3_bwd(_P(x), _P(dy), _P(w), _P(dx), _P(dw), _P(db), bt, h, wd, cin, cout, _S()))
+    return dx, dw, db
+
+
+def pack_conv(w: torch.Tensor) -> torch.Tensor:
+    co, ci = w.shape[:2]
+    out = torch.empty(co, 9 * ci, dtype=BF, device="cuda")
+    capi.check(capi.lib.dfot_op_pack_conv3(_P(w), _P(out), co, ci, 0, _S()))
+    return out
+
+
+class ResBlockTrain:
+    """One UViT ResBlock (u_vit_blocks.py:57-93) on channels-last streams: GN-SiLU-conv, per-pixel FiLM, GN-FiLM-SiLU-conv, residual."""
+
+    NAMES = ("emb_layer.weight", "emb_layer.bias", "in_layers.0.weight", "in_layers.0.bias", "in_layers.2.weight", "in_layers.2.bias",
+             "out_norm.weight", "out_norm.bias", "out_rest.1.weight", "out_rest.1.bias")
+
+    def __init__(self, params: Dict[str, torch.Tensor], prefix: str, channels: int, eps: float = 1e-6):
+        self.c, self.eps = channels, eps
+        self.p = {n: params[f"{prefix}.{n}"].detach().to(device="cuda", dtype=torch.float32).contiguous() for n in self.NAMES}
+        self.grads: Dict[str, torch.Tensor] = {}
+        self.sync()
+
+    def sync(self) -> None:
+        p = self.p
+        self.w_e = _bf(p["emb_layer.weight"].flatten(1))  # 1x1 conv = Linear over the embedding channels
+        self.w_eT = transpose(self.w_e)
+        self.w1, self.w2 = pack_conv(p["in_layers.2.weight"]), pack_conv(p["out_rest.1.weight"])
+
+    def forward(self, x: torch.Tensor, emb: torch.Tensor, bt: int, h: int, w: int) -> torch.Tensor:
+        """x fp32 [BT*H*W][C], emb bf16 [BT*H*W][E]"""
+        c, p, lib, P = self.c, self.p, capi.lib, h * w
+        st1, st2 = (torch.empty(bt, 32, 2, dtype=torch.float32, device="cuda") for _ in range(2))
+        h1 = torch.empty(bt * P, c, dtype=BF, device="cuda")
+        capi.check(lib.dfot_op_gn_silu_fwd(_P(x), _P(p["in_layers.0.weight"]), _P(p["in_layers.0.bias"]), None, self.eps, _P(h1), _P(st1), bt, P, c, _S()))
+        c1 = conv3x3(h1, self.w1, p["in_layers.2.bias"], bt, h, w, c, c)
+        film = gemm_bf16(emb, self.w_e, p["emb_layer.bias"])
+        h2 = torch.empty(bt * P, c, dtype=BF, device="cuda")
+        capi.check(lib.dfot_op_gn_silu_fwd(_P(c1), _P(p["out_norm.weight"]), _P(p["out_norm.bias"]), _P(film), self.eps, _P(h2), _P(st2), bt, P, c, _S()))
+        y = conv3x3(h2, self.w2, p["out_rest.1.bias"], bt, h, w, c, c, resid=x)
+        self.saved = dict(x=x, emb=emb, h1=h1, c1=c1, film=film, h2=h2, st1=st1, st2=st2, geom=(bt, h, w))
+        return y
+
+    def backward(self, dy: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        s, c, p, lib = self.saved, self.c, self.p, capi.lib
+        bt, h, w = s["geom"]
+        P = h * w
+        dh2, dw2, db2 = conv3x3_backward(s["h2"], _bf(dy), p["out_rest.1.weight"], bt, h, w, c, c)
+        dc1 = torch.empty(bt * P, c, dtype=torch.float32, device="cuda")
+        dfilm = torch.empty(bt * P, 2 * c, dtype=BF, device="cuda")
+        dg2, dbe2, dg1, dbe1 = (torch.empty(c, dtype=torch.float32, device="cuda") for _ in range(4))
+        capi.check(lib.dfot_op_gn_silu_bwd2(_P(s["c1"]), _P(dh2), _P(s["st2"]), _P(p["out_norm.weight"]), _P(p["out_norm.bias"]), _P(s["film"]), _P(dc1),
+                                            _P(dfilm), _P(dg2), _P(dbe2), bt, P, c, 0, _S()))
+        demb = gemm_f32(dfilm, self.w_eT)
+        dh1, dw1, db1 = conv3x3_backward(s["h1"], _bf(dc1), p["in_layers.2.weight"], bt, h, w, c, c)
+        dx = dy.clone()
+        capi.check(lib.dfot_op_gn_silu_bwd2(_P(s["x"]), _P(dh1), _P(s["st1"]), _P(p["in_layers.0.weight"]), _P(p["in_layers.0.bias"]), None, _P(dx), None,
+                                            _P(dg1), _P(dbe1), bt, P, c, 1, _S()))
+        self.grads = {
+            "emb_layer.weight": wgrad(dfilm, s["emb"]).view_as(p["emb_layer.weight"]), "emb_layer.bias": colsum(dfilm),
+            "in_layers.0.weight": dg1, "in_layers.0.bias": dbe1, "in_layers.2.weight": dw1, "in_layers.2.bias": db1,
+            "out_norm.weight": dg2, "out_norm.bias": dbe2, "out_rest.1.weight": dw2, "out_rest.1.bias": db2,
+        }
+        return dx, demb

@@ -306,6 +306,28 @@ int dfot_op_attention_fwd_lse(const void* q, const void* k, const void* v, void*
                               void* stream);
 int dfot_op_attention_bwd_lse(const void* q, const void* k, const void* v, const void* o, const void* d_o, int ldo, const float* lse, float* delta,
                               void* dq, void* dk, void* dv, int batch, int heads, int n, int d, void* stream);
+/* ResBlock / resampler / embedding pieces of the UViT training driver (channels-last fp32 streams, bf16 GEMM operands) */
+int dfot_op_gn_silu_fwd(const float* x, const float* gamma, const float* beta, const void* film, float eps, void* out, float* stats, int bt,
+                        int pixels, int channels, void* stream);
+int dfot_op_gn_silu_bwd2(const float* x, const float* dy, const float* stats, const float* gamma, const float* beta, const void* film, float* dx,
+                         void* dfilm, float* dgamma, float* dbeta, int bt, int pixels, int channels, int accumulate_dx, void* stream);
+int dfot_op_pack_conv3(const float* w, void* out, int co, int ci, int dgrad, void* stream);
+int dfot_op_conv3x3_f32(const void* a, const void* w, const float* bias, const float* resid, float* y, int bt, int h, int w_, int cin, int cout,
+                        void* stream);
+int dfot_op_pool2_bf16(const float* x, void* out, int bt, int h, int w, int c, void* stream);
+int dfot_op_pool2_bwd(const float* dp, float* dx, int bt, int h, int w, int c, void* stream);
+int dfot_op_sub_bf16(const float* a, const float* b, void* out, int64_t n, void* stream);
+int dfot_op_upsample_add(const float* t, const float* skip, float* out, int bt, int h, int w, int c, void* stream);
+int dfot_op_upsample_bwd(const float* dy, float* ds, int bt, int h, int w, int c, void* stream);
+int dfot_op_axpy(float* a, const float* b, float alpha, int64_t n, void* stream);
+int dfot_op_emb_combine(const void* pose, const float* nemb, const uint8_t* mask, void* out, int bt, int pixels, int e, int tokens, void* stream);
+int dfot_op_emb_pyramid(const void* emb0, void* emb1, void* emb2, void* emb3, int bt, int r0, int e, void* stream);
+int dfot_op_rows_sum(const float* src, float* out, int bt, int pixels, int e, void* stream);
+int dfot_op_cond_repack(const float* cond, void* a, int bt, int res, int cdim, int kpad, void* stream);
+int dfot_op_embed_input(const float* x, const float* w, const float* b, float* out, int bt, int res, int cin, int c0, void* stream);
+int dfot_op_embed_input_wgrad(const float* dx0, const float* x, float* dw, float* db, int bt, int res, int cin, int c0, int ps, void* stream);
+int dfot_op_project_output(const float* x0, const float* w, const float* b, float* out, int bt, int res, int c0, int cout, void* stream);
+int dfot_op_outgrad_gather(const float* dout, void* dpatch, int bt, int res, int cout, int ps, void* stream);
 /* fp32 <-> bf16 helpers for tests */
 int dfot_op_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);
 int dfot_op_bf16_to_f32(const void* src, float* dst, int64_t n, void* stream);

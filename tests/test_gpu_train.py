@@ -499,3 +499,37 @@ def test_uvit_transformer_block_train_unit(c, heads):
     worst = max(rs, key=rs.get)
     print(f"UViT TransformerBlock unit C={c}: worst rel-L2 {rs[worst]:.2e} at {worst}; y {rs['y']:.1e} dx {rs['dx']:.1e} demb {rs['demb']:.1e}")
     assert rs["y"] < 1e-2 and max(rs.values()) < 3e-2, rs
+
+
+@pytest.mark.parametrize("c,e,bt,h,w", [(128, 128, 2, 16, 16), (256, 256, 2, 8, 16)])
+def test_uvit_res_block_train_unit(c, e, bt, h, w):
+    """forward + hand-written backward of one UViT ResBlock composed over the C ABI vs torch autograd through the oracle's res_block"""
+    from dfot_amd import uvit_train as ut
+    from oracle import uvit as ouvit
+    g = torch.Generator().manual_seed(c + h)
+    params = {}
+    for n, shp in ouvit._res_block_shapes("blk", c, e).items():
+        if n.endswith(("0.weight", "out_norm.weight")):
+            params[n] = 1 + 0.1 * torch.randn(shp, generator=g)
+        elif n.endswith("bias"):
+            params[n] = 0.05 * torch.randn(shp, generator=g)
+        else:
+            params[n] = torch.randn(shp, generator=g) / math.sqrt(float(np.prod(shp[1:])))
+    x = torch.randn(bt, c, h, w, generator=g)
+    emb = (torch.randn(bt, e, h, w, generator=g) * 0.5).to(torch.bfloat16)
+    dy = torch.randn(bt, c, h, w, generator=g)
+    cl = lambda t: t.permute(0, 2, 3, 1).reshape(bt * h * w, -1).contiguous()  # channels-last rows
+    blk = ut.ResBlockTrain(params, "blk", c)
+    y = blk.forward(cl(x).cuda(), cl(emb).cuda(), bt, h, w)
+    dx, demb = blk.backward(cl(dy).cuda())
+    torch.cuda.synchronize()
+    ps = {n: t.clone().requires_grad_() for n, t in params.items()}
+    xr, er = x.clone().requires_grad_(), emb.float().requires_grad_()
+    ref = ouvit.res_block(ps, "blk", xr, er, ouvit.UViTConfig())
+    ref.backward(dy)
+    rs = {"y": rel(y.cpu(), cl(ref.detach())), "dx": rel(dx.cpu(), cl(xr.grad)), "demb": rel(demb.cpu(), cl(er.grad))}
+    for n in blk.grads:
+        rs[n] = rel(blk.grads[n].cpu(), ps["blk." + n].grad)
+    worst = max(rs, key=rs.get)
+    print(f"UViT ResBlock unit C={c}: worst rel-L2 {rs[worst]:.2e} at {worst}; y {rs['y']:.1e} dx {rs['dx']:.1e} demb {rs['demb']:.1e}")
+    assert rs["y"] < 1e-2 and max(rs.values()) < 3e-2, rs
