@@ -241,3 +241,184 @@ class ResBlockTrain:
             "out_norm.weight": dg2, "out_norm.bias": dbe2, "out_rest.1.weight": dw2, "out_rest.1.bias": db2,
         }
         return dx, demb
+
+
+def _axpy(a: torch.Tensor, b: torch.Tensor, alpha: float = 1.0) -> None:
+    capi.check(capi.lib.dfot_op_axpy(_P(a), _P(b), alpha, a.numel(), _S()))
+
+
+def _silu(src: torch.Tensor, grad: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """bf16 [rows][n]: SiLU(src), or grad * SiLU'(src)"""
+    rows, n = src.shape
+    out = torch.empty_like(src)
+    capi.check(capi.lib.dfot_op_silu_cols(_P(src), n, 0, _P(grad), n, 0, _P(out), n, 0, rows, n, _S()))
+    return out
+
+
+class UViT3DPoseTrainer:
+    """Forward with saved activations and hand-written backward of the whole UViT3DPose backbone
+    (algorithms/dfot/backbones/u_vit/u_vit3d_pose.py:63-131, u_vit3d.py:30-185), composed op by op over the C ABI.
+    `cfg` carries the fields of u_vit3d_pose.yaml (channels, emb_channels, patch_size 2, block_types, num_updown_blocks, num_mid_blocks,
+    num_heads, resolution, max_tokens, in_channels 3, cond_dim 180, noise_dim 256); four levels, as the embedding pyramid assumes."""
+
+    def __init__(self, params: Dict[str, torch.Tensor], cfg):
+        g = lambda k, d=None: (cfg[k] if isinstance(cfg, dict) else getattr(cfg, k, d)) if (k in cfg if isinstance(cfg, dict) else hasattr(cfg, k)) else d
+        self.ch = list(g("channels"))
+        self.e, self.ps, self.heads = int(g("emb_channels")), int(g("patch_size", 2)), int(g("num_heads"))
+        self.types, self.nud, self.nmid = list(g("block_types")), list(g("num_updown_blocks")), int(g("num_mid_blocks"))
+        self.cin, self.res, self.T = int(g("in_channels", 3)), int(g("resolution")), int(g("max_tokens"))
+        self.cdim, self.ndim, self.eps, theta = int(g("cond_dim", 180)), int(g("noise_dim", 256)), float(g("eps", 1e-6)), float(g("rope_theta", 10000.0))
+        if len(self.ch) != 4 or self.ps != 2:
+            raise ValueError("UViT3DPoseTrainer: four levels and patch size 2 (u_vit3d_pose.yaml)")
+        self.r = [self.res // self.ps // (2 ** l) for l in range(4)]
+        self.names = [n for n in params if not n.endswith(("timesteps.freqs", "timesteps.phases"))]
+        self.p = {n: t.detach().to(device="cuda", dtype=torch.float32).contiguous() for n, t in params.items()}
+        rope = {l: rope_table(self.ch[l] // self.heads, (self.T, self.r[l], self.r[l]), theta) for l in range(4) if self.types[l] == "TransformerBlock"}
+
+        def block(prefix, lvl):
+            if self.types[lvl] == "ResBlock":
+                return ResBlockTrain(self.p, prefix, self.ch[lvl], self.eps)
+            return TransformerBlockTrain(self.p, prefix, self.ch[lvl], self.heads, rope[lvl], self.eps)
+        self.down = [[block(f"down_blocks.{l}.{i}", l) for i in range(n)] for l, n in enumerate(self.nud)]
+        self.mid = [block(f"mid_blocks.{i}", 3) for i in range(self.nmid)]
+        self.up = [[block(f"up_blocks.{j}.{i + 1}", l) for i in range(self.nud[l])] for j, l in enumerate((2, 1, 0))]
+        self.grads: Dict[str, torch.Tensor] = {}
+        self.sync()
+
+    def sync(self) -> None:
+        p, e = self.p, self.e
+        ne = "noise_level_pos_embedding.embedding."
+        self.w1, self.w2 = _bf(p[ne + "linear_1.weight"]), _bf(p[ne + "linear_2.weight"])
+        self.w2T = transpose(self.w2)
+        self.kpad = -(-self.cdim * 4 // 64) * 64
+        wp = torch.zeros(e, self.kpad, device="cuda")
+        wp[:, : self.cdim * 4] = p["external_cond_embedding.patch_embedder.proj.weight"].flatten(1)
+        self.wp = _bf(wp)
+        wo = torch.zeros(self.ch[0], 64, device="cuda")
+        wo[:, : self.cin * 4] = p["project_output.proj.weight"].flatten(1)
+        self.wo = _bf(wo)                    # [C0][64]: data gradient of the ConvTranspose as a GEMM with K = 64
+        self.wd = [pack_conv(p[f"down_blocks.{l}.{n}.conv.weight"]) for l, n in enumerate(self.nud)]
+        self.wu = [pack_conv(p[f"up_blocks.{j}.0.conv.weight"]) for j in range(3)]
+        for b in self._blocks():
+            b.sync()
+
+    def _blocks(self):
+        return [b for lv in self.down for b in lv] + self.mid + [b for lv in self.up for b in lv]
+
+    def _run(self, blocks, x, lvl):
+        for b in blocks:
+            x = b.forward(x, self.emb[lvl], self.bt, self.r[lvl], self.r[lvl]) if isinstance(b, ResBlockTrain) else b.forward(x, self.emb[lvl], self.B)
+        return x
+
+    def forward(self, x: torch.Tensor, noise_levels: torch.Tensor, cond: torch.Tensor) -> torch.Tensor:
+        lib, p, e, r, ch = capi.lib, self.p, self.e, self.r, self.ch
+        self.B, t = x.shape[:2]
+        bt = self.bt = self.B * t
+        if t != self.T:
+            raise AssertionError(f"temporal length must be {self.T}, got {t}")
+        if cond is None:
+            raise AssertionError("camera-pose conditioning is required")
+        xd = self.x_in = x.to(device="cuda", dtype=torch.float32).reshape(bt, self.cin, self.res, self.res).contiguous()
+        # noise-level embedding (bt rows, padded to the GEMM's 128): Fourier features -> Linear -> SiLU -> Linear
+        pre = "noise_level_pos_embedding."
+        k = noise_levels.to(device="cuda", dtype=torch.float32).reshape(bt, 1)
+        feats = torch.zeros(128 * -(-bt // 128), self.ndim, device="cuda")
+        feats[:bt] = (k * p[pre + "timesteps.freqs"] + p[pre + "timesteps.phases"]).cos() * math.sqrt(2.0)
+        self.feats = _bf(feats)
+        self.l1 = gemm_bf16(self.feats, self.w1, p[pre + "embedding.linear_1.bias"])
+        self.a1 = _silu(self.l1)
+        nemb = gemm_f32(self.a1, self.w2, p[pre + "embedding.linear_2.bias"])[:bt].contiguous()
+        # pose patch embedding + embedding pyramid
+        P0 = r[0] * r[0]
+        self.patches = torch.zeros(bt * P0, self.kpad, dtype=BF, device="cuda")
+        cd = cond.to(device="cuda", dtype=torch.float32).reshape(bt, self.cdim, self.res, self.res).contiguous()
+        capi.check(lib.dfot_op_cond_repack(_P(cd), _P(self.patches), bt, self.res, self.cdim, self.kpad, _S()))
+        pose = gemm_bf16(self.patches, self.wp, p["external_cond_embedding.patch_embedder.proj.bias"])
+        self.emb = [torch.empty(bt * r[l] * r[l], e, dtype=BF, device="cuda") for l in range(4)]
+        capi.check(lib.dfot_op_emb_combine(_P(pose), _P(nemb), None, _P(self.emb[0]), bt, P0, e, t, _S()))
+        capi.check(lib.dfot_op_emb_pyramid(_P(self.emb[0]), _P(self.emb[1]), _P(self.emb[2]), _P(self.emb[3]), bt, r[0], e, _S()))
+        # input embedding and the U
+        h = torch.empty(bt * P0, ch[0], dtype=torch.float32, device="cuda")
+        capi.check(lib.dfot_op_embed_input(_P(xd), _P(p["embed_input.proj.weight"]), _P(p["embed_input.proj.bias"]), _P(h), bt, self.res, self.cin, ch[0], _S()))
+        self.before, self.after, self.pooled, self.hsub = [], [], [], [None] * 3
+        for l, n in enumerate(self.nud):
+            h = self._run(self.down[l], h, l)
+            self.before.append(h)
+            pooled = torch.empty(bt * r[l + 1] * r[l + 1], ch[l], dtype=BF, device="cuda")
+            capi.check(lib.dfot_op_pool2_bf16(_P(h), _P(pooled), bt, r[l], r[l], ch[l], _S()))
+            self.pooled.append(pooled)
+            h = conv3x3(pooled, self.wd[l], p[f"down_blocks.{l}.{n}.conv.bias"], bt, r[l + 1], r[l + 1], ch[l], ch[l + 1])
+            self.after.append(h)
+        h = self._run(self.mid, h, 3)
+        for j, l in enumerate((2, 1, 0)):
+            hs = torch.empty(bt * r[l + 1] * r[l + 1], ch[l + 1], dtype=BF, device="cuda")
+            capi.check(lib.dfot_op_sub_bf16(_P(h), _P(self.after[l]), _P(hs), hs.numel(), _S()))
+            self.hsub[j] = hs
+            tmp = conv3x3(hs, self.wu[j], p[f"up_blocks.{j}.0.conv.bias"], bt, r[l + 1], r[l + 1], ch[l + 1], ch[l])
+            h = torch.empty(bt * r[l] * r[l], ch[l], dtype=torch.float32, device="cuda")
+            capi.check(lib.dfot_op_upsample_add(_P(tmp), _P(self.before[l]), _P(h), bt, r[l + 1], r[l + 1], ch[l], _S()))  # (h, w) = the coarse map's size
+            h = self._run(self.up[j], h, l)
+        self.h_final = h
+        out = torch.empty(bt, self.cin, self.res, self.res, dtype=torch.float32, device="cuda")
+        capi.check(lib.dfot_op_project_output(_P(h), _P(p["project_output.proj.weight"]), _P(p["project_output.proj.bias"]), _P(out), bt, self.res, ch[0],
+                                              self.cin, _S()))
+        return out.view(self.B, t, self.cin, self.res, self.res)
+
+    def backward(self, d_out: torch.Tensor) -> Dict[str, torch.Tensor]:
+        lib, p, e, r, ch, bt = capi.lib, self.p, self.e, self.r, self.ch, self.bt
+        G: Dict[str, torch.Tensor] = {}
+        demb = [torch.zeros(bt * r[l] * r[l], e, dtype=torch.float32, device="cuda") for l in range(4)]
+
+        def run_back(blocks, prefix_fn, dh, lvl):
+            for i in reversed(range(len(blocks))):
+                dh, de = blocks[i].backward(dh)
+                _axpy(demb[lvl], de)
+                for n, gv in blocks[i].grads.items():
+                    G[f"{prefix_fn(i)}.{n}"] = gv
+            return dh
+        # output projection (ConvTranspose k = s = 2): per input pixel a Linear C0 -> (co, py, px)
+        dout = d_out.to(device="cuda", dtype=torch.float32).reshape(bt, self.cin, self.res, self.res).contiguous()
+        P0 = r[0] * r[0]
+        dpatch = torch.empty(bt * P0, 64, dtype=BF, device="cuda")
+        capi.check(lib.dfot_op_outgrad_gather(_P(dout), _P(dpatch), bt, self.res, self.cin, self.ps, _S()))
+        n_out = self.cin * self.ps * self.ps
+        G["project_output.proj.weight"] = wgrad(_bf(self.h_final), dpatch)[:, :n_out].reshape(ch[0], self.cin, self.ps, self.ps).contiguous()
+        G["project_output.proj.bias"] = colsum(dpatch)[:n_out].view(self.cin, -1).sum(1)
+        dh = gemm_f32(dpatch, self.wo)
+        dbefore, dsub = [None] * 3, [None] * 3
+        for j, l in reversed(list(enumerate((2, 1, 0)))):
+            dh = run_back(self.up[j], lambda i, j=j: f"up_blocks.{j}.{i + 1}", dh, l)
+            dbefore[l] = dh                                           # skip connection: + before[l]
+            dt = torch.empty(bt * r[l + 1] * r[l + 1], ch[l], dtype=torch.float32, device="cuda")
+            capi.check(lib.dfot_op_upsample_bwd(_P(dh), _P(dt), bt, r[l], r[l], ch[l], _S()))
+            dh, G[f"up_blocks.{j}.0.conv.weight"], G[f"up_blocks.{j}.0.conv.bias"] = conv3x3_backward(
+                self.hsub[j], _bf(dt), p[f"up_blocks.{j}.0.conv.weight"], bt, r[l + 1], r[l + 1], ch[l + 1], ch[l])
+            dsub[l] = dh                                              # d(h - after[l]): -> h, and minus -> after[l]
+        dh = run_back(self.mid, lambda i: f"mid_blocks.{i}", dh, 3)
+        for l in (2, 1, 0):
+            n = self.nud[l]
+            _axpy(dh, dsub[l], -1.0)                                  # after[l] also fed the subtraction on the way up
+            dpool, G[f"down_blocks.{l}.{n}.conv.weight"], G[f"down_blocks.{l}.{n}.conv.bias"] = conv3x3_backward(
+                self.pooled[l], _bf(dh), p[f"down_blocks.{l}.{n}.conv.weight"], bt, r[l + 1], r[l + 1], ch[l], ch[l + 1])
+            dh = dbefore[l].clone()
+            capi.check(lib.dfot_op_pool2_bwd(_P(dpool), _P(dh), bt, r[l], r[l], ch[l], _S()))
+            dh = run_back(self.down[l], lambda i, l=l: f"down_blocks.{l}.{i}", dh, l)
+        dw, db = torch.empty_like(p["embed_input.proj.weight"]), torch.empty(ch[0], device="cuda")
+        capi.check(lib.dfot_op_embed_input_wgrad(_P(dh), _P(self.x_in), _P(dw), _P(db), bt, self.res, self.cin, ch[0], self.ps, _S()))
+        G["embed_input.proj.weight"], G["embed_input.proj.bias"] = dw, db
+        # embedding pyramid (successive 2x2 average pools), pose patch embedding, noise-level MLP
+        for l in (2, 1, 0):
+            capi.check(lib.dfot_op_pool2_bwd(_P(demb[l + 1]), _P(demb[l]), bt, r[l], r[l], e, _S()))
+        dpose = _bf(demb[0])
+        pe = "external_cond_embedding.patch_embedder.proj."
+        G[pe + "weight"] = wgrad(dpose, self.patches)[:, : self.cdim * 4].reshape(e, self.cdim, self.ps, self.ps).contiguous()
+        G[pe + "bias"] = colsum(dpose)
+        dn = torch.zeros(self.feats.shape[0], e, device="cuda")
+        capi.check(lib.dfot_op_rows_sum(_P(demb[0]), _P(dn), bt, P0, e, _S()))
+        dnb = _bf(dn)
+        ne = "noise_level_pos_embedding.embedding."
+        G[ne + "linear_2.weight"], G[ne + "linear_2.bias"] = wgrad(dnb, self.a1), colsum(dnb)
+        dl1 = _silu(self.l1, gemm_bf16(dnb, self.w2T))
+        G[ne + "linear_1.weight"], G[ne + "linear_1.bias"] = wgrad(dl1, self.feats), colsum(dl1)
+        self.grads = G
+        return G

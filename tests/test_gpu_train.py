@@ -533,3 +533,36 @@ def test_uvit_res_block_train_unit(c, e, bt, h, w):
     worst = max(rs, key=rs.get)
     print(f"UViT ResBlock unit C={c}: worst rel-L2 {rs[worst]:.2e} at {worst}; y {rs['y']:.1e} dx {rs['dx']:.1e} demb {rs['demb']:.1e}")
     assert rs["y"] < 1e-2 and max(rs.values()) < 3e-2, rs
+
+
+def test_uvit3d_pose_backward_matches_autograd():
+    """the whole UViT3DPose backbone (ResBlock levels, down / up convolutions with the skip arithmetic, transformer levels, pose patch
+    embedding + embedding pyramid, noise-level MLP, input / output projections): forward and EVERY parameter gradient vs torch autograd
+    through the oracle restatement, on a reduced model (channels 128/128/128/256, 2 heads: d = 64 / 128, 128x128 frames, 2 tokens)"""
+    from dfot_amd import uvit_train as ut
+    from oracle import pose as opose, uvit as ouvit
+    cfg = ouvit.UViTConfig(channels=(128, 128, 128, 256), emb_channels=128, num_updown_blocks=(1, 1, 1), num_mid_blocks=2, num_heads=2, resolution=128,
+                           max_tokens=2)
+    params = ouvit.seeded_params(cfg, seed=4)
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(1, 2, 3, 128, 128, generator=g)
+    k = torch.randn(1, 2, generator=g)
+    poses = torch.eye(3, 4).reshape(1, 1, 12).repeat(1, 2, 1)
+    poses[..., 3] = torch.linspace(0, 0.3, 2)
+    cond = opose.ray_encoding(torch.cat([torch.tensor([0.5, 0.9, 0.5, 0.5]).repeat(1, 2, 1), poses], -1), 128)
+    d_out = torch.randn(1, 2, 3, 128, 128, generator=g)
+    tr = ut.UViT3DPoseTrainer(params, dict(channels=cfg.channels, emb_channels=cfg.emb_channels, patch_size=2, block_types=cfg.block_types,
+                                           num_updown_blocks=cfg.num_updown_blocks, num_mid_blocks=cfg.num_mid_blocks, num_heads=cfg.num_heads,
+                                           resolution=128, max_tokens=2))
+    out = tr.forward(x, k, cond).cpu()
+    grads = {n: t.cpu() for n, t in tr.backward(d_out).items()}
+    ps = {n: t.clone().requires_grad_(not n.endswith(("freqs", "phases"))) for n, t in params.items()}
+    ref = ouvit.forward(ps, cfg, x, k, cond)
+    r_out = rel(out, ref.detach())
+    (ref * d_out).sum().backward()
+    names = [n for n in ps if ps[n].requires_grad]
+    assert sorted(grads) == sorted(names)
+    rs = {n: rel(grads[n], ps[n].grad) for n in names}
+    worst = max(rs, key=rs.get)
+    print(f"UViT3DPose backward: forward rel-L2 {r_out:.2e}; worst gradient rel-L2 {rs[worst]:.2e} at {worst}")
+    assert r_out < 2e-2 and rs[worst] < 6e-2, (r_out, worst, rs[worst])
