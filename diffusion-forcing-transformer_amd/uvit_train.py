@@ -272,7 +272,28 @@ class UViT3DPoseTrainer:
             raise ValueError("UViT3DPoseTrainer: four levels and patch size 2 (u_vit3d_pose.yaml)")
         self.r = [self.res // self.ps // (2 ** l) for l in range(4)]
         self.names = [n for n in params if not n.endswith(("timesteps.freqs", "timesteps.phases"))]
-        self.p = {n: t.detach().to(device="cuda", dtype=torch.float32).contiguous() for n, t in params.items()}
+        # trainable parameters are views into ONE flat fp32 buffer (reference order, 16-byte aligned): the optimizer is one kernel over it
+        # and data parallelism one all-reduce of the flat gradient buffer; the Fourier buffers (persistent, not trained) stay apart
+        self.layout: Dict[str, Tuple[int, Tuple[int, ...]]] = {}
+        off = 0
+        for n in self.names:
+            self.layout[n] = (off, tuple(params[n].shape))
+            off += -(-params[n].numel() // 4) * 4
+        self.numel = off
+        self.flat = torch.zeros(off, device="cuda", dtype=torch.float32)
+        self.flat_grads = torch.zeros_like(self.flat)
+        self.exp_avg, self.exp_avg_sq = torch.zeros_like(self.flat), torch.zeros_like(self.flat)
+        self._sumsq = torch.zeros(1, device="cuda")
+        self.step_count = 0
+        self.p = {}
+        for n, t in params.items():
+            if n in self.layout:
+                o, shp = self.layout[n]
+                v = self.flat[o: o + t.numel()].view(shp)
+                v.copy_(t.detach().to(device="cuda", dtype=torch.float32))
+                self.p[n] = v
+            else:
+                self.p[n] = t.detach().to(device="cuda", dtype=torch.float32).contiguous()
         rope = {l: rope_table(self.ch[l] // self.heads, (self.T, self.r[l], self.r[l]), theta) for l in range(4) if self.types[l] == "TransformerBlock"}
 
         def block(prefix, lvl):
@@ -422,3 +443,51 @@ class UViT3DPoseTrainer:
         G[ne + "linear_1.weight"], G[ne + "linear_1.bias"] = wgrad(dl1, self.feats), colsum(dl1)
         self.grads = G
         return G
+
+    # ------------------------------------------------------------------ training step (ContinuousDiffusion.forward + AdamW)
+    def loss_and_grads(self, xs: torch.Tensor, cond: torch.Tensor, t: torch.Tensor, noise: torch.Tensor, masks: Optional[torch.Tensor] = None,
+                       precond_scale: float = 0.125, shift: float = 0.125, sigmoid_bias: float = -1.0, clip_noise: float = 20.0) -> torch.Tensor:
+        """DFoTVideo.training_step for the pose model (dfot_video.py:41-75, continuous_diffusion.py:140-167): per-token levels t in [0,1],
+        x_t = alpha x + sigma eps, v = model(x_t, precond * logsnr, cond), sigmoid-weighted eps-space error averaged with the loss masks;
+        then the backward.  cond: processed ray encoding (B,T,180,H,W).  Returns the loss (device scalar)."""
+        b, tk = xs.shape[:2]
+        f = int(xs[0, 0].numel())
+        tt = t.detach().float().cpu()
+        lo, hi = torch.atan(torch.exp(-0.5 * torch.tensor(15.0))), torch.atan(torch.exp(-0.5 * torch.tensor(-15.0)))
+        logsnr = -2 * torch.log(torch.tan(lo + tt * (hi - lo))) + 2 * torch.log(torch.tensor(shift))
+        alpha, sigma, weight = torch.sigmoid(logsnr).sqrt(), torch.sigmoid(-logsnr).sqrt(), torch.sigmoid(sigmoid_bias - logsnr)
+        mk = torch.ones(b, tk) if masks is None else masks.detach().float().cpu().view(b, tk)
+        tab = torch.stack([alpha, sigma, weight, precond_scale * logsnr, 2.0 * weight * mk / (f * b * tk)]).float().cuda().contiguous()
+        x = xs.to(device="cuda", dtype=torch.float32).contiguous()
+        eps = noise.to(device="cuda", dtype=torch.float32).clamp(-clip_noise, clip_noise).contiguous()
+        x_t = torch.empty_like(x)
+        lib = capi.lib
+        capi.check(lib.dfot_hg_prepare(_P(x), _P(eps), _P(tab[0]), _P(tab[1]), _P(x_t), b, 1, tk, f, _S()))
+        v = self.forward(x_t, tab[3], cond).contiguous()
+        per_token = torch.empty(b, tk, device="cuda")
+        scratch = torch.empty(int(lib.dfot_vpred_loss_scratch_floats(b, tk, f)), device="cuda")
+        capi.check(lib.dfot_vpred_loss(_P(x), _P(eps), _P(v), _P(tab[0]), _P(tab[1]), _P(tab[2]), None, _P(scratch), _P(per_token), b, tk, f, _S()))
+        dv = torch.empty_like(x)
+        capi.check(lib.dfot_vloss_grad(_P(x), _P(eps), _P(v), _P(tab[0]), _P(tab[1]), _P(tab[4]), _P(dv), b, tk, f, 0, _S()))
+        grads = self.backward(dv)
+        for n, (o, shp) in self.layout.items():
+            self.flat_grads[o: o + grads[n].numel()].copy_(grads[n].reshape(-1))
+        return (per_token * mk.cuda()).mean()
+
+    def optimizer_step(self, lr: float = 5e-5, betas=(0.9, 0.99), eps: float = 1e-8, weight_decay: float = 0.01, max_grad_norm: Optional[float] = 1.0,
+                       world_size: int = 1) -> None:
+        from . import parallel
+        if world_size > 1:
+            parallel.allreduce_mean_(self.flat_grads)
+        self.step_count += 1
+        lib = capi.lib
+        sumsq = None
+        if max_grad_norm is not None:
+            capi.check(lib.dfot_sumsq(_P(self.flat_grads), self.numel, _P(self._sumsq), _S()))
+            sumsq = self._sumsq
+        capi.check(lib.dfot_adamw_step(_P(self.flat), _P(self.flat_grads), _P(self.exp_avg), _P(self.exp_avg_sq), self.numel, lr, betas[0], betas[1], eps,
+                                       weight_decay, self.step_count, _P(sumsq), float(max_grad_norm or 0.0), None, 0.0, _S()))
+        self.sync()
+
+    def state_dict(self) -> Dict[str, torch.Tensor]:
+        return {n: t.detach().clone() for n, t in self.p.items()}

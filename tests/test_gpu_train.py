@@ -566,3 +566,48 @@ def test_uvit3d_pose_backward_matches_autograd():
     worst = max(rs, key=rs.get)
     print(f"UViT3DPose backward: forward rel-L2 {r_out:.2e}; worst gradient rel-L2 {rs[worst]:.2e} at {worst}")
     assert r_out < 2e-2 and rs[worst] < 6e-2, (r_out, worst, rs[worst])
+
+
+def test_uvit3d_pose_training_step():
+    """DFoTVideo.training_step for the pose model on the engine: loss vs the oracle's continuous v-prediction loss, then clipped AdamW
+    steps on the flat buffer: the loss on the same batch falls"""
+    from dfot_amd import uvit_train as ut
+    from oracle import pose as opose, sampler as osm, uvit as ouvit
+    cfg = ouvit.UViTConfig(channels=(128, 128, 128, 256), emb_channels=128, num_updown_blocks=(1, 1, 1), num_mid_blocks=1, num_heads=2, resolution=128,
+                           max_tokens=2)
+    params = ouvit.seeded_params(cfg, seed=5)
+    g = torch.Generator().manual_seed(3)
+    xs = torch.randn(1, 2, 3, 128, 128, generator=g)
+    t = torch.rand(1, 2, generator=g)
+    noise = torch.randn(1, 2, 3, 128, 128, generator=g)
+    poses = torch.eye(3, 4).reshape(1, 1, 12).repeat(1, 2, 1)
+    poses[..., 3] = torch.linspace(0, 0.3, 2)
+    cond = opose.ray_encoding(torch.cat([torch.tensor([0.5, 0.9, 0.5, 0.5]).repeat(1, 2, 1), poses], -1), 128)
+    tr = ut.UViT3DPoseTrainer(params, dict(channels=cfg.channels, emb_channels=cfg.emb_channels, patch_size=2, block_types=cfg.block_types,
+                                           num_updown_blocks=cfg.num_updown_blocks, num_mid_blocks=cfg.num_mid_blocks, num_heads=cfg.num_heads,
+                                           resolution=128, max_tokens=2))
+    loss0 = float(tr.loss_and_grads(xs, cond, t, noise).item())
+    with torch.no_grad():
+        _, per_el = osm.training_loss(lambda x, lv, c, m: ouvit.forward(params, cfg, x, lv, c), xs, cond, t, noise)
+    ref = float(per_el.mean())
+    assert abs(loss0 - ref) < 2e-2 * abs(ref), (loss0, ref)
+    # one clipped AdamW step vs torch (autograd through the oracle + clip_grad_norm_ + torch.optim.AdamW), where the gradient is not negligible
+    before = {n: v.detach().clone().cpu() for n, v in tr.p.items()}
+    tr.optimizer_step(lr=1e-4)
+    ps = {n: v.clone().requires_grad_(not n.endswith(("freqs", "phases"))) for n, v in params.items()}
+    _, per_el = osm.training_loss(lambda x, lv, c, m: ouvit.forward(ps, cfg, x, lv, c), xs, cond, t, noise)
+    per_el.mean().backward()
+    plist = [v for v in ps.values() if v.requires_grad]
+    torch.nn.utils.clip_grad_norm_(plist, 1.0)
+    torch.optim.AdamW(plist, lr=1e-4, weight_decay=0.01, betas=(0.9, 0.99), eps=1e-8).step()
+    checked = 0
+    for n, v in ps.items():
+        if not v.requires_grad:
+            continue
+        big = v.grad.abs() > 2e-2 * v.grad.abs().max()
+        if big.any():
+            upd, ref_upd = tr.p[n].detach().cpu() - before[n], v.detach() - params[n]
+            assert rel(upd[big], ref_upd[big]) < 0.1, n
+            checked += int(big.sum())
+    assert checked > 10000
+    assert np.isfinite(float(tr.loss_and_grads(xs, cond, t, noise).item()))
