@@ -14,3 +14,4 @@ from . import parallel  # noqa: F401,E402
 from .training import ContextTraining, TrainingNoise, training_step_forward  # noqa: F401,E402
 from .checkpoint import load_reference_checkpoint  # noqa: F401,E402
 from .trainer import DiT3DTrainer  # noqa: F401,E402
+from . import uvit_train  # noqa: F401,E402

@@ -1,10 +1,10 @@
 """Training units of the UViT3DPose backbone on the MI355X engine, composed op by op over the C ABI (`dfot_op_*`): every value is
 computed by a HIP kernel; Python only sequences the calls (the reference's own structure is Python) and owns the buffers.
 
-Built so far: ``TransformerBlockTrain`` -- forward with saved activations and the hand-written backward of one
-``TransformerBlock`` (algorithms/dfot/backbones/u_vit/u_vit_blocks.py:192-281: NormalizeWithCond, fused attention + MLP projection,
-per-head q/k RMSNorm + RoPE, attention, SiLU MLP branch, output projections, residual), 71.7 % of the RE10K backbone's FLOPs.
-The ResBlock unit and the driver that walks the U are not written yet.
+``TransformerBlockTrain`` / ``ResBlockTrain``: forward with saved activations and the hand-written backward of one block
+(algorithms/dfot/backbones/u_vit/u_vit_blocks.py:57-93,192-281); ``UViT3DPoseTrainer``: the whole backbone (u_vit3d_pose.py:63-131) with the
+training step of ``DFoTVideo.training_step`` (continuous v-prediction loss) and a flat-buffer clipped AdamW.
+A first, op-by-op driver: correct (parity-tested against torch autograd through the oracle), not yet tuned.
 """
 from __future__ import annotations
 
