@@ -648,7 +648,7 @@ int tr_wgrad(const bf16* A, const bf16* W, int M, int N, int K, float* out, hipS
 int tr_wgrad_nt(const bf16* dy, long ldy, const bf16* x, long ldx, int M, int N, long rows, float* out, hipStream_t s, float* ws, size_t ws_floats) {
   static const int enabled = tuning_flag("TRAIN_WGRAD_NT", 1);
   static const int target = tuning_flag("TRAIN_WGRAD_NT_WGS", 512);
-  if (!enabled || M % 128 != 0 || N % 128 != 0 || rows % 64 != 0) return DFOT_ERR_STATE;
+  if (!enabled || M % 128 != 0 || N % 128 != 0 || rows % 64 != 0) return DFOT_ERR_STATE;  // (the kernel also takes ragged M / N; not needed here)
   const long tiles = (long)(M / 128) * (N / 128);
   int slices = (int)(target / tiles);
   slices = slices < 1 ? 1 : (slices > 64 ? 64 : slices);

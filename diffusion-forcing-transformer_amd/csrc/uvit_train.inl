@@ -72,35 +72,56 @@ int conv3_backward(const bf16* x, const bf16* dy, const bf16* w_dgrad, float* dx
     g.A = dy; g.W = w_dgrad; g.M = (int)pix; g.N = ci; g.K = 9 * co; g.H = H; g.Wd = W; g.Cin = co; g.out_f32 = dx; g.ldo = ci;
     if ((rc = launch_gemm(A_CONV3, E_F32, GEMM_AUTO, g, s))) return rc;
   }
-  if ((rc = tr_transpose(dy, sc.dyT, (int)pix, co, s))) return rc;
   if (db) {
     hipLaunchKernelGGL(colsum_bf16_kernel, dim3(cdiv(co, 256), cdiv(pix, 128)), dim3(256), 0, s, dy, db, pix, co, (long)co);
     DFOT_CHECK_HIP(hipGetLastError());
   }
-  const int mpad = (co + 127) / 128 * 128;  // GEMM rows come in 128s: dyT is allocated (and zero) up to mpad rows
+  // weight gradient: one token-axis GEMM per tap, both operands read in place (wgrad.hip conv mode: x rows shifted by the tap, zero outside
+  // the image); few output tiles, K = pixels: split over workgroups into partial buffers
+  const long tiles = (long)((co + 127) / 128) * ((ci + 127) / 128);
+  int split = (int)(512 / tiles);
+  split = split < 1 ? 1 : (split > 256 ? 256 : split);
+  while (split > 1 && (pix / 64 < 4L * split || (size_t)split * co * ci > sc.ws_floats)) --split;
   for (int tap = 0; tap < 9; ++tap) {
-    hipLaunchKernelGGL(transpose_shift_kernel, dim3(ci / 64, (int)(pix / 64)), dim3(256), 0, s, x, sc.xT, pix, H, W, ci, tap / 3 - 1, tap % 3 - 1);
-    DFOT_CHECK_HIP(hipGetLastError());
-    // few output tiles, K = pixels: split over workgroups into partial buffers
-    const long tiles = (long)(mpad / 128) * ((ci + 127) / 128);
-    int split = (int)(256 / tiles);
-    split = split < 1 ? 1 : (split > 256 ? 256 : split);
-    while (split > 1 && pix / 64 < 4L * split) --split;
-    while (split > 1 && (size_t)split * mpad * ci > sc.ws_floats) --split;
-    GemmArgs g;
-    g.A = sc.dyT; g.lda = pix; g.W = sc.xT; g.M = mpad; g.N = ci; g.K = (int)pix; g.ldo = ci;
     float* out = sc.taps + (long)tap * co * ci;
-    DFOT_REQUIRE((size_t)split * mpad * ci <= sc.ws_floats, DFOT_ERR_STATE, "conv3_backward: split-K workspace too small");
-    g.out_f32 = sc.ws; g.ksplit = split; g.slice_stride = (long)mpad * ci;  // partial tiles (padded rows included) land in the workspace
-    if ((rc = launch_gemm(A_DENSE, E_F32, GEMM_DMA_128, g, s))) return rc;
-    hipLaunchKernelGGL(slices_sum_kernel, dim3(cdiv((long)co * ci / 4, 256)), dim3(256), 0, s, sc.ws, out, (long)co * ci / 4, split, (long)mpad * ci);
-    DFOT_CHECK_HIP(hipGetLastError());
+    if (split == 1) {
+      if ((rc = launch_wgrad_nt(dy, co, x, ci, out, co, ci, pix, 1, s, H, W, tap / 3 - 1, tap % 3 - 1))) return rc;
+    } else {
+      if ((rc = launch_wgrad_nt(dy, co, x, ci, sc.ws, co, ci, pix, split, s, H, W, tap / 3 - 1, tap % 3 - 1))) return rc;
+      hipLaunchKernelGGL(slices_sum_kernel, dim3(cdiv((long)co * ci / 4, 256)), dim3(256), 0, s, sc.ws, out, (long)co * ci / 4, split, (long)co * ci);
+      DFOT_CHECK_HIP(hipGetLastError());
+    }
   }
   hipLaunchKernelGGL(conv_wgrad_repack_kernel, dim3(cdiv((long)co * ci * 9, 256)), dim3(256), 0, s, sc.taps, dw, co, ci);
   DFOT_CHECK_HIP(hipGetLastError());
   return DFOT_OK;
 }
 
+}  // namespace
+}  // namespace dfot
+
+namespace dfot {
+namespace {
+// Grow-only device scratch of the op entry points (one buffer per slot, process lifetime): the ops run on one stream in program order, so a
+// slot is free again when the next op that uses it is enqueued.  Replaces per-call hipMalloc / synchronize / hipFree.
+int op_scratch(int slot, size_t bytes, void** out) {
+  static void* buf[8] = {nullptr};
+  static size_t cap[8] = {0};
+  if (cap[slot] < bytes) {
+    if (buf[slot]) {
+      DFOT_CHECK_HIP(hipDeviceSynchronize());
+      (void)hipFree(buf[slot]);
+      buf[slot] = nullptr;
+      cap[slot] = 0;
+    }
+    const size_t want = bytes + bytes / 4;
+    DFOT_CHECK_HIP(hipMalloc(&buf[slot], want));
+    DFOT_CHECK_HIP(hipMemset(buf[slot], 0, want));
+    cap[slot] = want;
+  }
+  *out = buf[slot];
+  return DFOT_OK;
+}
 }  // namespace
 }  // namespace dfot
 
@@ -112,27 +133,18 @@ int dfot_op_conv3x3_bwd(const void* x, const void* dy, const float* w, float* dx
                         void* stream) {
   DFOT_REQUIRE(x && dy && w && dx && dw && db, DFOT_ERR_ARG, "op_conv3x3_bwd: null argument");
   hipStream_t s = (hipStream_t)stream;
-  const long pix = (long)bt * hh * ww;
-  const int mpad = (cout + 127) / 128 * 128;
   ConvBwdScratch sc;
-  bf16* wd = nullptr;
-  void* zeros = nullptr;
-  sc.ws_floats = (size_t)64 * mpad * cin;
-  DFOT_CHECK_HIP(hipMalloc(&sc.dyT, (size_t)mpad * pix * sizeof(bf16)));
-  DFOT_CHECK_HIP(hipMalloc(&sc.xT, (size_t)cin * pix * sizeof(bf16)));
-  DFOT_CHECK_HIP(hipMalloc(&sc.taps, (size_t)9 * cout * cin * sizeof(float)));
-  DFOT_CHECK_HIP(hipMalloc(&sc.ws, sc.ws_floats * sizeof(float)));
-  DFOT_CHECK_HIP(hipMalloc(&wd, (size_t)9 * cout * cin * sizeof(bf16)));
-  DFOT_CHECK_HIP(hipMalloc(&zeros, 256));
-  DFOT_CHECK_HIP(hipMemsetAsync(zeros, 0, 256, s));
-  DFOT_CHECK_HIP(hipMemsetAsync(sc.dyT, 0, (size_t)mpad * pix * sizeof(bf16), s));
+  void *taps = nullptr, *ws = nullptr, *wd = nullptr, *zeros = nullptr;
+  sc.ws_floats = (size_t)256 * cout * cin;
+  int rc = 0;
+  if ((rc = op_scratch(0, (size_t)9 * cout * cin * sizeof(float), &taps)) || (rc = op_scratch(1, sc.ws_floats * sizeof(float), &ws)) ||
+      (rc = op_scratch(2, (size_t)9 * cout * cin * sizeof(bf16), &wd)) || (rc = op_scratch(3, 256, &zeros)))
+    return rc;
+  sc.taps = (float*)taps; sc.ws = (float*)ws; sc.zeros = (const bf16*)zeros;  // slot 3 is only ever zero
   DFOT_CHECK_HIP(hipMemsetAsync(db, 0, (size_t)cout * sizeof(float), s));
-  sc.zeros = (const bf16*)zeros;
-  hipLaunchKernelGGL(pack_conv3_dgrad_kernel, dim3(cdiv((long)cout * cin * 9, 256)), dim3(256), 0, s, w, wd, cout, cin);
-  int rc = conv3_backward((const bf16*)x, (const bf16*)dy, wd, dx, dw, db, bt, hh, ww, cin, cout, sc, s);
-  (void)hipStreamSynchronize(s);
-  (void)hipFree(sc.dyT); (void)hipFree(sc.xT); (void)hipFree(sc.taps); (void)hipFree(sc.ws); (void)hipFree(wd); (void)hipFree(zeros);
-  return rc;
+  hipLaunchKernelGGL(pack_conv3_dgrad_kernel, dim3(cdiv((long)cout * cin * 9, 256)), dim3(256), 0, s, w, (bf16*)wd, cout, cin);
+  DFOT_CHECK_HIP(hipGetLastError());
+  return conv3_backward((const bf16*)x, (const bf16*)dy, (const bf16*)wd, dx, dw, db, bt, hh, ww, cin, cout, sc, s);
 }
 
 }  // extern "C"
@@ -483,16 +495,14 @@ int dfot_op_wgrad_nt(const void* a, int lda, const void* b, int ldb, float* out,
   DFOT_REQUIRE(a && b && out && slices >= 1, DFOT_ERR_ARG, "op_wgrad_nt: bad argument");
   hipStream_t s = (hipStream_t)stream;
   if (slices == 1) return launch_wgrad_nt((const bf16*)a, lda, (const bf16*)b, ldb, out, m, n, (long)rows, 1, s);
-  float* ws = nullptr;
-  DFOT_CHECK_HIP(hipMalloc(&ws, (size_t)slices * m * n * sizeof(float)));
-  int rc = launch_wgrad_nt((const bf16*)a, lda, (const bf16*)b, ldb, ws, m, n, (long)rows, slices, s);
-  if (!rc) {
-    hipLaunchKernelGGL(slices_sum_kernel, dim3(cdiv((long)m * n / 4, 256)), dim3(256), 0, s, ws, out, (long)m * n / 4, slices, (long)m * n);
-    if (hipGetLastError() != hipSuccess) rc = DFOT_ERR_HIP;
-  }
-  (void)hipStreamSynchronize(s);
-  (void)hipFree(ws);
-  return rc;
+  void* wsv = nullptr;
+  int rc = op_scratch(5, (size_t)slices * m * n * sizeof(float), &wsv);
+  if (rc) return rc;
+  float* ws = (float*)wsv;
+  if ((rc = launch_wgrad_nt((const bf16*)a, lda, (const bf16*)b, ldb, ws, m, n, (long)rows, slices, s))) return rc;
+  hipLaunchKernelGGL(slices_sum_kernel, dim3(cdiv((long)m * n / 4, 256)), dim3(256), 0, s, ws, out, (long)m * n / 4, slices, (long)m * n);
+  DFOT_CHECK_HIP(hipGetLastError());
+  return DFOT_OK;
 }
 }  // extern "C"
 
@@ -777,14 +787,13 @@ int dfot_op_gn_silu_bwd2(const float* x, const float* dy, const float* stats, co
                          void* dfilm, float* dgamma, float* dbeta, int bt, int pixels, int channels, int accumulate_dx, void* stream) {
   DFOT_REQUIRE(x && dy && stats && gamma && beta && dx && dgamma && dbeta, DFOT_ERR_ARG, "op_gn_silu_bwd2: null argument");
   hipStream_t s = (hipStream_t)stream;
-  float* sums = nullptr;
-  DFOT_CHECK_HIP(hipMalloc(&sums, (size_t)bt * 64 * sizeof(float)));
+  void* sums = nullptr;
+  int rc = op_scratch(4, (size_t)bt * 64 * sizeof(float), &sums);
+  if (rc) return rc;
   DFOT_CHECK_HIP(hipMemsetAsync(dgamma, 0, (size_t)channels * sizeof(float), s));
   DFOT_CHECK_HIP(hipMemsetAsync(dbeta, 0, (size_t)channels * sizeof(float), s));
-  int rc = gn_silu_backward(x, dy, stats, gamma, beta, (const bf16*)film, sums, dx, (bf16*)dfilm, dgamma, dbeta, bt, pixels, channels, accumulate_dx != 0, s);
-  (void)hipStreamSynchronize(s);
-  (void)hipFree(sums);
-  return rc;
+  return gn_silu_backward(x, dy, stats, gamma, beta, (const bf16*)film, (float*)sums, dx, (bf16*)dfilm, dgamma, dbeta, bt, pixels, channels,
+                          accumulate_dx != 0, s);
 }
 // w fp32 [Co][Ci][3][3] -> the forward kernel's layout [Co][tap][Ci] bf16 (dgrad = 0) or the data-gradient weights [Ci][tap'][Co] (dgrad = 1)
 int dfot_op_pack_conv3(const float* w, void* out, int co, int ci, int dgrad, void* stream) {

@@ -35,12 +35,16 @@ __device__ __forceinline__ bf16x8 wg_frag(const char* tile, int c0, int kt2, int
   return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
 
+// conv mode (img_h > 0): B row r is taken from pixel r shifted by (sdy, sdx) inside its img_h x img_w image (rows are pixels, row-major per
+// image), zero outside -- the operand of tap (sdy, sdx) of a 3x3 convolution's weight gradient, read in place.
+// M / N need only be multiples of 8: tiles are guarded (loads beyond M / N read as zero, stores are skipped).
 __global__ __launch_bounds__(256) void wgrad_nt_kernel(const bf16* __restrict__ A, long lda, const bf16* __restrict__ B, long ldb,
-                                                       float* __restrict__ out, int M, int N, long rows, int slices) {
+                                                       float* __restrict__ out, int M, int N, long rows, int slices, int img_h, int img_w, int sdy,
+                                                       int sdx) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lq = lane & 31, lh = lane >> 5;
-  const int tiles_n = N / WG_F;
+  const int tiles_n = (N + WG_F - 1) / WG_F;
   const int tile = blockIdx.x / slices, slice = blockIdx.x % slices;
   const int m0 = (tile / tiles_n) * WG_F, n0 = (tile % tiles_n) * WG_F;
   const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
@@ -48,8 +52,10 @@ __global__ __launch_bounds__(256) void wgrad_nt_kernel(const bf16* __restrict__ 
   const long nt_all = rows / WG_TR;
   const long per = nt_all / slices, rem = nt_all % slices;
   const long t0 = slice * per + (slice < rem ? slice : rem), nt = per + (slice < rem ? 1 : 0);
-  const bf16* Ab = A + t0 * WG_TR * lda + m0;
-  const bf16* Bb = B + t0 * WG_TR * ldb + n0;
+  const bf16* Ab = A + m0;
+  const bf16* Bb = B + n0;
+  const bf16 zb = f2bf(0.f);
+  const bf16x8 zero8 = bf16x8{zb, zb, zb, zb, zb, zb, zb, zb};
 
   f32x16 acc[2][2];
 #pragma unroll
@@ -64,8 +70,16 @@ __global__ __launch_bounds__(256) void wgrad_nt_kernel(const bf16* __restrict__ 
 #pragma unroll
     for (int i = 0; i < WG_PER_THREAD; ++i) {
       const int c = tid + i * 256, row = c / (WG_F / 8), col = (c % (WG_F / 8)) * 8;
-      ra[i] = *reinterpret_cast<const bf16x8*>(Ab + (t * WG_TR + row) * lda + col);
-      rb[i] = *reinterpret_cast<const bf16x8*>(Bb + (t * WG_TR + row) * ldb + col);
+      const long r = (t0 + t) * WG_TR + row;
+      ra[i] = (m0 + col < M) ? *reinterpret_cast<const bf16x8*>(Ab + r * lda + col) : zero8;
+      long rs = r;
+      bool ok = n0 + col < N;
+      if (img_h > 0) {
+        const int x = (int)(r % img_w) + sdx, y = (int)((r / img_w) % img_h) + sdy;
+        ok = ok && x >= 0 && x < img_w && y >= 0 && y < img_h;
+        rs = r + (long)sdy * img_w + sdx;
+      }
+      rb[i] = ok ? *reinterpret_cast<const bf16x8*>(Bb + rs * ldb + col) : zero8;
     }
   };
   auto store = [&](int stage) {
@@ -112,25 +126,30 @@ __global__ __launch_bounds__(256) void wgrad_nt_kernel(const bf16* __restrict__ 
 #pragma unroll
       for (int g = 0; g < 4; ++g)
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          o[(long)(m0 + wm + 32 * i + 8 * g + 4 * lh + r) * N + n0 + wn + 32 * j + lq] = acc[i][j][4 * g + r];
+        for (int r = 0; r < 4; ++r) {
+          const int mm = m0 + wm + 32 * i + 8 * g + 4 * lh + r, nn = n0 + wn + 32 * j + lq;
+          if (mm < M && nn < N) o[(long)mm * N + nn] = acc[i][j][4 * g + r];
+        }
 }
 
 }  // namespace
 
-// out [slices][M][N] fp32 partial products (slices >= 1; the caller sums them); M, N multiples of 128, rows a multiple of 64
-int launch_wgrad_nt(const bf16* a, long lda, const bf16* b, long ldb, float* out, int m, int n, long rows, int slices, hipStream_t s) {
+// out [slices][M][N] fp32 partial products (slices >= 1; the caller sums them); M, N multiples of 8, rows a multiple of 64.
+// img_h > 0: conv mode, see the kernel.
+int launch_wgrad_nt(const bf16* a, long lda, const bf16* b, long ldb, float* out, int m, int n, long rows, int slices, hipStream_t s, int img_h,
+                    int img_w, int sdy, int sdx) {
   DFOT_REQUIRE(a && b && out, DFOT_ERR_ARG, "wgrad_nt: null pointer");
-  DFOT_REQUIRE(m > 0 && n > 0 && m % WG_F == 0 && n % WG_F == 0 && rows > 0 && rows % WG_TR == 0 && lda % 8 == 0 && ldb % 8 == 0 && slices >= 1 &&
-                   slices <= rows / WG_TR,
-               DFOT_ERR_SHAPE, "wgrad_nt: M=%d N=%d must be multiples of 128, rows=%ld of 64", m, n, rows);
+  DFOT_REQUIRE(m > 0 && n > 0 && m % 8 == 0 && n % 8 == 0 && rows > 0 && rows % WG_TR == 0 && lda % 8 == 0 && ldb % 8 == 0 && slices >= 1 &&
+                   slices <= rows / WG_TR && (img_h == 0 || (img_w > 0 && rows % ((long)img_h * img_w) == 0)),
+               DFOT_ERR_SHAPE, "wgrad_nt: M=%d N=%d must be multiples of 8, rows=%ld of 64 (and whole images in conv mode)", m, n, rows);
   const int lds = 4 * WG_TILE;
   static bool attr_set = false;
   if (!attr_set) {
     DFOT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_nt_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     attr_set = true;
   }
-  hipLaunchKernelGGL(wgrad_nt_kernel, dim3((m / WG_F) * (n / WG_F) * slices), dim3(256), lds, s, a, lda, b, ldb, out, m, n, rows, slices);
+  hipLaunchKernelGGL(wgrad_nt_kernel, dim3(((m + WG_F - 1) / WG_F) * ((n + WG_F - 1) / WG_F) * slices), dim3(256), lds, s, a, lda, b, ldb, out, m, n,
+                     rows, slices, img_h, img_w, sdy, sdx);
   DFOT_CHECK_HIP(hipGetLastError());
   return DFOT_OK;
 }

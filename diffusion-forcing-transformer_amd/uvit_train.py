@@ -43,9 +43,12 @@ def gemm_bf16(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = N
     return out
 
 
-def gemm_f32(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, resid: Optional[torch.Tensor] = None) -> torch.Tensor:
+def gemm_f32(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, resid: Optional[torch.Tensor] = None,
+             out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """fp32 [M][N] = a w^T (+ bias) (+ resid); out may be resid itself (accumulate in place)"""
     m, k = a.shape
-    out = torch.empty(m, w.shape[0], dtype=torch.float32, device="cuda")
+    if out is None:
+        out = torch.empty(m, w.shape[0], dtype=torch.float32, device="cuda")
     capi.check(capi.lib.dfot_op_gemm_f32(_P(a), a.stride(0), _P(w), _P(bias), _P(resid), _P(out), out.stride(0), m, w.shape[0], k, _S()))
     return out
 
@@ -60,14 +63,11 @@ def wgrad(dy: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
     """dW [M][N] fp32 = dy^T x over the token axis; dy [rows][M], x [rows][N] bf16"""
     rows, m = dy.shape
     n = x.shape[1]
-    if m % 128 == 0 and n % 128 == 0:
-        tiles = (m // 128) * (n // 128)
-        slices = max(1, min(64, 512 // tiles, rows // 256))
-        out = torch.empty(m, n, dtype=torch.float32, device="cuda")
-        capi.check(capi.lib.dfot_op_wgrad_nt(_P(dy), dy.stride(0), _P(x), x.stride(0), _P(out), m, n, rows, slices, _S()))
-        return out
-    # feature counts that are not multiples of 128 (C = 576): transposed copies (rows padded to the GEMM's 128) + the generic GEMM
-    return gemm_f32(transpose(dy.contiguous(), 128), transpose(x.contiguous()))[:m]
+    tiles = -(-m // 128) * -(-n // 128)
+    slices = max(1, min(64, 512 // tiles, rows // 256))
+    out = torch.empty(m, n, dtype=torch.float32, device="cuda")
+    capi.check(capi.lib.dfot_op_wgrad_nt(_P(dy), dy.stride(0), _P(x), x.stride(0), _P(out), m, n, rows, slices, _S()))
+    return out
 
 
 def rope_table(head_dim: int, sizes: Tuple[int, int, int], theta: float = 10000.0) -> torch.Tensor:
@@ -130,8 +130,9 @@ class TransformerBlockTrain:
         self.saved = dict(x=x, emb=emb, film=film, xn=xn, fused=fused, q=q, k=k, v=v, cat=cat, lse=lse, batch=batch)
         return y
 
-    def backward(self, dy: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
-        """dy fp32 [B*N][C] -> (dx fp32, demb fp32 [B*N][E]); parameter gradients in self.grads (reference names)"""
+    def backward(self, dy: torch.Tensor, demb_acc: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+        """dy fp32 [B*N][C] -> (dx fp32, demb fp32 [B*N][E]); parameter gradients in self.grads (reference names).
+        demb_acc: the level's embedding-gradient accumulator, added to in the GEMM epilogue (no separate pass)"""
         s, c, hds, d, p, lib = self.saved, self.c, self.heads, self.d, self.p, capi.lib
         rows, batch = dy.shape[0], s["batch"]
         ntok = rows // batch
@@ -155,7 +156,7 @@ class TransformerBlockTrain:
         dnw = torch.empty(c, device="cuda")
         capi.check(lib.dfot_op_rms_film_bwd(_P(s["x"]), _P(dxn), _P(p["norm.norm.weight"]), _P(s["film"]), self.eps, _P(dx), _P(dfilm), _P(dnw),
                                             rows, c, 1, _S()))
-        demb = gemm_f32(dfilm, self.w_eT)                                    # [rows][E]
+        demb = gemm_f32(dfilm, self.w_eT, resid=demb_acc, out=demb_acc)      # [rows][E]
         self.grads = {
             "norm.emb_layer.weight": wgrad(dfilm, s["emb"]), "norm.emb_layer.bias": colsum(dfilm), "norm.norm.weight": dnw,
             "fused_attn_mlp_proj.weight": dw_f, "fused_attn_mlp_proj.bias": db_f, "q_norm.weight": dqw, "k_norm.weight": dkw,
@@ -220,7 +221,7 @@ class ResBlockTrain:
         self.saved = dict(x=x, emb=emb, h1=h1, c1=c1, film=film, h2=h2, st1=st1, st2=st2, geom=(bt, h, w))
         return y
 
-    def backward(self, dy: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    def backward(self, dy: torch.Tensor, demb_acc: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
         s, c, p, lib = self.saved, self.c, self.p, capi.lib
         bt, h, w = s["geom"]
         P = h * w
@@ -230,7 +231,7 @@ class ResBlockTrain:
         dg2, dbe2, dg1, dbe1 = (torch.empty(c, dtype=torch.float32, device="cuda") for _ in range(4))
         capi.check(lib.dfot_op_gn_silu_bwd2(_P(s["c1"]), _P(dh2), _P(s["st2"]), _P(p["out_norm.weight"]), _P(p["out_norm.bias"]), _P(s["film"]), _P(dc1),
                                             _P(dfilm), _P(dg2), _P(dbe2), bt, P, c, 0, _S()))
-        demb = gemm_f32(dfilm, self.w_eT)
+        demb = gemm_f32(dfilm, self.w_eT, resid=demb_acc, out=demb_acc)
         dh1, dw1, db1 = conv3x3_backward(s["h1"], _bf(dc1), p["in_layers.2.weight"], bt, h, w, c, c)
         dx = dy.clone()
         capi.check(lib.dfot_op_gn_silu_bwd2(_P(s["x"]), _P(dh1), _P(s["st1"]), _P(p["in_layers.0.weight"]), _P(p["in_layers.0.bias"]), None, _P(dx), None,
@@ -392,8 +393,7 @@ class UViT3DPoseTrainer:
 
         def run_back(blocks, prefix_fn, dh, lvl):
             for i in reversed(range(len(blocks))):
-                dh, de = blocks[i].backward(dh)
-                _axpy(demb[lvl], de)
+                dh, _ = blocks[i].backward(dh, demb[lvl])  # the block adds its embedding gradient into the level's accumulator
                 for n, gv in blocks[i].grads.items():
                     G[f"{prefix_fn(i)}.{n}"] = gv
             return dh
