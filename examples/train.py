@@ -3,6 +3,7 @@
 
   python examples/train.py k600     [--ckpt K600.ckpt] [--steps 100] [--batch 8] [--save out.ckpt]
   python examples/train.py k600diff [--accumulate 2]                                  # the model bash/k600/*.sh train
+  python examples/train.py re10k    [--batch 8]                                       # RE10K UViT3DPose (BASELINE config 5), synthetic frames + poses
   python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 examples/train.py k600   # data parallel, one rank per GPU
 
 Data are synthetic latents (no dataset offline); everything else is the reference's recipe: per-token noise levels from
@@ -23,7 +24,7 @@ import dfot_amd  # noqa: E402
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("model", choices=["k600", "k600diff"])
+    ap.add_argument("model", choices=["k600", "k600diff", "re10k"])
     ap.add_argument("--ckpt")
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--batch", type=int, default=8)
@@ -37,6 +38,8 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", torch.cuda.current_device()))
+    if a.model == "re10k":
+        return train_re10k(a, rank, world)
     diff = a.model == "k600diff"
     if diff:
         cfg = dict(name="difference_dit3d", variant="factorized_matrix_attention", pos_emb_type="sinusoidal_2d", merge_type="interleaved",
@@ -74,6 +77,39 @@ def main():
         torch.save({"state_dict": {"diffusion_model.model." + k: v.cpu() for k, v in trainer.state_dict().items()}}, a.save)
         print("saved", a.save)
     if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def train_re10k(a, rank, world):
+    """DFoTVideoPose training on the op-by-op UViT3DPose driver: per-token independent continuous levels, sigmoid-weighted v-loss"""
+    from bench import RE10K, synth_poses
+    from dfot_amd.uvit_train import UViT3DPoseTrainer
+    init = dfot_amd.UViT3DPose(RE10K, x_shape=(3, 256, 256), max_tokens=8)
+    if a.ckpt:
+        dfot_amd.load_reference_checkpoint(init, a.ckpt)
+    else:
+        init.init_random(seed=0)
+    trainer = UViT3DPoseTrainer({k: v.detach() for k, v in init.state_dict().items()}, dict(RE10K, resolution=256, max_tokens=8))
+    del init
+    sampling = dfot_amd.TrainingNoise(noise_level="random_independent", is_continuous=True, n_context_tokens=1)
+    g = torch.Generator().manual_seed(1000 + rank)
+    masks = torch.ones(a.batch, 8, dtype=torch.bool)
+    t0 = time.perf_counter()
+    for step in range(a.steps):
+        frames = torch.randn(a.batch, 8, 3, 256, 256, generator=g)
+        noise = torch.randn(a.batch, 8, 3, 256, 256, generator=g)
+        cond = torch.ops.dfot.ray_encoding(synth_poses(a.batch, 8, 7 * step + rank), 256)
+        levels, loss_masks = sampling.sample(a.batch, 8, masks, g, training=True)
+        loss = trainer.loss_and_grads(frames, cond, levels, noise, loss_masks)
+        trainer.optimizer_step(lr=a.lr, world_size=world)
+        if rank == 0 and (step % 5 == 0 or step == a.steps - 1):
+            print(f"step {step:4d}  loss {float(loss.item()):.4f}  {(time.perf_counter() - t0) / (step + 1) * 1e3:.1f} ms/step", flush=True)
+    if a.save and rank == 0:
+        torch.save({"state_dict": {"diffusion_model.model." + k: v.cpu() for k, v in trainer.state_dict().items()}}, a.save)
+        print("saved", a.save)
+    if world > 1:
+        import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()
 
