@@ -411,8 +411,12 @@ __global__ __launch_bounds__(256) void qknorm_rope_bwd_kernel(const bf16* __rest
       const bf16* gsrc = (which == 0 ? dq : dk) + goff;
       const float* wt = (which == 0 ? qw : kw) + lane * EPL;
       float xv[EPL], gv[EPL];
-#pragma unroll
-      for (int j = 0; j < EPL; ++j) { xv[j] = bf2f(src[j]); gv[j] = bf2f(gsrc[j]); }
+      if constexpr (EPL == 2) {  // one 4-byte load per operand instead of two 2-byte ones
+        const bf16x2 x2 = *reinterpret_cast<const bf16x2*>(src), g2 = *reinterpret_cast<const bf16x2*>(gsrc);
+        xv[0] = bf2f(x2[0]); xv[1] = bf2f(x2[1]); gv[0] = bf2f(g2[0]); gv[1] = bf2f(g2[1]);
+      } else {
+        xv[0] = bf2f(src[0]); gv[0] = bf2f(gsrc[0]);
+      }
       // transpose of the forward rotation (x0 c - x1 s, x1 c + x0 s) on the pair (2i, 2i+1)
       if constexpr (EPL == 2) {
         const float* cs = rope_cs + ((long)tok * (D / 2) + lane) * 2;
@@ -437,12 +441,15 @@ __global__ __launch_bounds__(256) void qknorm_rope_bwd_kernel(const bf16* __rest
       }
       const float m = wave_sum(gx) / (float)D * r * r;
       bf16* dst = dfused + row * ldo + (long)which * C + head * D + lane * EPL;
-#pragma unroll
-      for (int j = 0; j < EPL; ++j) dst[j] = f2bf((gw[j] - xv[j] * m) * r);
+      if constexpr (EPL == 2) {
+        *reinterpret_cast<bf16x2*>(dst) = bf16x2{f2bf((gw[0] - xv[0] * m) * r), f2bf((gw[1] - xv[1] * m) * r)};
+      } else {
+        dst[0] = f2bf((gw[0] - xv[0] * m) * r);
+      }
     }
     bf16* vdst = dfused + row * ldo + 2L * C + head * D + lane * EPL;
-#pragma unroll
-    for (int j = 0; j < EPL; ++j) vdst[j] = dv[goff + j];
+    if constexpr (EPL == 2) *reinterpret_cast<bf16x2*>(vdst) = *reinterpret_cast<const bf16x2*>(dv + goff);
+    else vdst[0] = dv[goff];
   }
 #pragma unroll
   for (int j = 0; j < EPL; ++j) {
