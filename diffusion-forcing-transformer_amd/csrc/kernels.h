@@ -54,7 +54,7 @@ int launch_vloss(const float* x, const float* noise, const float* v, const float
                  float* x_pred, float* partial, float* loss, int bt, long f, bool vspace, hipStream_t s);
 // ---- weight-gradient GEMM over the token axis (wgrad.hip): out[slices][M][N] = partial sums of A^T B, A [rows][lda], B [rows][ldb] ----
 int launch_wgrad_nt(const bf16* a, long lda, const bf16* b, long ldb, float* out, int m, int n, long rows, int slices, hipStream_t s, int img_h = 0,
-                    int img_w = 0, int sdy = 0, int sdx = 0);
+                    int img_w = 0, int sdy = 0, int sdx = 0, int all_taps = 0);
 // ---- training: loss gradient, gradient norm, AdamW (flat fp32 buffers) ----
 int launch_vloss_grad(const float* x, const float* noise, const float* v, const float* a, const float* sg, const float* coef, float* dv,
                       int bt, long f, bool vspace, hipStream_t s);

@@ -78,19 +78,17 @@ int conv3_backward(const bf16* x, const bf16* dy, const bf16* w_dgrad, float* dx
   }
   // weight gradient: one token-axis GEMM per tap, both operands read in place (wgrad.hip conv mode: x rows shifted by the tap, zero outside
   // the image); few output tiles, K = pixels: split over workgroups into partial buffers
-  const long tiles = (long)((co + 127) / 128) * ((ci + 127) / 128);
-  int split = (int)(512 / tiles);
-  split = split < 1 ? 1 : (split > 256 ? 256 : split);
-  while (split > 1 && (pix / 64 < 4L * split || (size_t)split * co * ci > sc.ws_floats)) --split;
-  for (int tap = 0; tap < 9; ++tap) {
-    float* out = sc.taps + (long)tap * co * ci;
-    if (split == 1) {
-      if ((rc = launch_wgrad_nt(dy, co, x, ci, out, co, ci, pix, 1, s, H, W, tap / 3 - 1, tap % 3 - 1))) return rc;
-    } else {
-      if ((rc = launch_wgrad_nt(dy, co, x, ci, sc.ws, co, ci, pix, split, s, H, W, tap / 3 - 1, tap % 3 - 1))) return rc;
-      hipLaunchKernelGGL(slices_sum_kernel, dim3(cdiv((long)co * ci / 4, 256)), dim3(256), 0, s, sc.ws, out, (long)co * ci / 4, split, (long)co * ci);
-      DFOT_CHECK_HIP(hipGetLastError());
-    }
+  // all nine taps in one launch (grid.y = tap): 9x the workgroups in flight, partial outputs [slice][tap][Co][Ci], one reduce pass
+  const long tiles = 9L * ((co + 127) / 128) * ((ci + 127) / 128);
+  int split = (int)(1024 / tiles);
+  split = split < 1 ? 1 : (split > 128 ? 128 : split);
+  while (split > 1 && (pix / 64 < 4L * split || (size_t)split * 9 * co * ci > sc.ws_floats)) --split;
+  if (split == 1) {
+    if ((rc = launch_wgrad_nt(dy, co, x, ci, sc.taps, co, ci, pix, 1, s, H, W, 0, 0, 1))) return rc;
+  } else {
+    if ((rc = launch_wgrad_nt(dy, co, x, ci, sc.ws, co, ci, pix, split, s, H, W, 0, 0, 1))) return rc;
+    hipLaunchKernelGGL(slices_sum_kernel, dim3(cdiv(9L * co * ci / 4, 256)), dim3(256), 0, s, sc.ws, sc.taps, 9L * co * ci / 4, split, 9L * co * ci);
+    DFOT_CHECK_HIP(hipGetLastError());
   }
   hipLaunchKernelGGL(conv_wgrad_repack_kernel, dim3(cdiv((long)co * ci * 9, 256)), dim3(256), 0, s, sc.taps, dw, co, ci);
   DFOT_CHECK_HIP(hipGetLastError());

@@ -40,7 +40,12 @@ __device__ __forceinline__ bf16x8 wg_frag(const char* tile, int c0, int kt2, int
 // M / N need only be multiples of 8: tiles are guarded (loads beyond M / N read as zero, stores are skipped).
 __global__ __launch_bounds__(256) void wgrad_nt_kernel(const bf16* __restrict__ A, long lda, const bf16* __restrict__ B, long ldb,
                                                        float* __restrict__ out, int M, int N, long rows, int slices, int img_h, int img_w, int sdy,
-                                                       int sdx) {
+                                                       int sdx, int all_taps) {
+  // all_taps: blockIdx.y = tap of a 3x3 convolution (shift (tap / 3 - 1, tap % 3 - 1)); partial outputs are laid out [slice][tap][M][N]
+  if (all_taps) {
+    sdy = (int)blockIdx.y / 3 - 1;
+    sdx = (int)blockIdx.y % 3 - 1;
+  }
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lq = lane & 31, lh = lane >> 5;
@@ -118,7 +123,7 @@ __global__ __launch_bounds__(256) void wgrad_nt_kernel(const bf16* __restrict__ 
     cur ^= 1;
   }
   // C lane layout: column n = lq, rows m = 8g + 4h + j in register 4g + j
-  float* o = out + (long)slice * M * N;
+  float* o = out + ((long)slice * (all_taps ? 9 : 1) + (all_taps ? (long)blockIdx.y : 0L)) * M * N;
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -137,7 +142,7 @@ __global__ __launch_bounds__(256) void wgrad_nt_kernel(const bf16* __restrict__ 
 // out [slices][M][N] fp32 partial products (slices >= 1; the caller sums them); M, N multiples of 8, rows a multiple of 64.
 // img_h > 0: conv mode, see the kernel.
 int launch_wgrad_nt(const bf16* a, long lda, const bf16* b, long ldb, float* out, int m, int n, long rows, int slices, hipStream_t s, int img_h,
-                    int img_w, int sdy, int sdx) {
+                    int img_w, int sdy, int sdx, int all_taps) {
   DFOT_REQUIRE(a && b && out, DFOT_ERR_ARG, "wgrad_nt: null pointer");
   DFOT_REQUIRE(m > 0 && n > 0 && m % 8 == 0 && n % 8 == 0 && rows > 0 && rows % WG_TR == 0 && lda % 8 == 0 && ldb % 8 == 0 && slices >= 1 &&
                    slices <= rows / WG_TR && (img_h == 0 || (img_w > 0 && rows % ((long)img_h * img_w) == 0)),
@@ -148,8 +153,9 @@ int launch_wgrad_nt(const bf16* a, long lda, const bf16* b, long ldb, float* out
     DFOT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_nt_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     attr_set = true;
   }
-  hipLaunchKernelGGL(wgrad_nt_kernel, dim3(((m + WG_F - 1) / WG_F) * ((n + WG_F - 1) / WG_F) * slices), dim3(256), lds, s, a, lda, b, ldb, out, m, n,
-                     rows, slices, img_h, img_w, sdy, sdx);
+  DFOT_REQUIRE(!all_taps || img_h > 0, DFOT_ERR_ARG, "wgrad_nt: all_taps needs conv mode");
+  hipLaunchKernelGGL(wgrad_nt_kernel, dim3(((m + WG_F - 1) / WG_F) * ((n + WG_F - 1) / WG_F) * slices, all_taps ? 9 : 1), dim3(256), lds, s, a, lda, b,
+                     ldb, out, m, n, rows, slices, img_h, img_w, sdy, sdx, all_taps);
   DFOT_CHECK_HIP(hipGetLastError());
   return DFOT_OK;
 }
