@@ -359,16 +359,19 @@ __global__ __launch_bounds__(256) void rms_film_bwd_kernel(const float* __restri
       *reinterpret_cast<V*>(orow + c0) = o;
     }
   }
+  __shared__ float red[4][C];
 #pragma unroll
   for (int i = 0; i < CNT; ++i)
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) atomicAdd(dw + (i * 64 + lane) * VEC + j, dwacc[i * VEC + j]);
+    for (int j = 0; j < VEC; ++j) red[threadIdx.x >> 6][(i * 64 + lane) * VEC + j] = dwacc[i * VEC + j];
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) atomicAdd(dw + c, (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]));
 }
 
 // dw must be zeroed by the caller
 int rms_film_backward(const float* x, const float* dxn, const float* w, const bf16* film, float* dx, bf16* dfilm, float* dw, long rows, int hidden,
                       float eps, bool accumulate, hipStream_t s) {
-  const int grid = (int)(rows / 4 < 2048 ? (rows + 3) / 4 : 2048);
+  const int grid = (int)(rows / 4 < 512 ? (rows + 3) / 4 : 512);
 #define CALL(V, C) \
   hipLaunchKernelGGL((rms_film_bwd_kernel<V, C>), dim3(grid), dim3(256), 0, s, x, dxn, w, film, dx, dfilm, dw, rows, eps, accumulate ? 1 : 0)
   DIT_LN_DISPATCH(CALL)
@@ -449,10 +452,17 @@ __global__ __launch_bounds__(256) void qknorm_rope_bwd_kernel(const bf16* __rest
     if constexpr (EPL == 2) *reinterpret_cast<bf16x2*>(vdst) = *reinterpret_cast<const bf16x2*>(dv + goff);
     else vdst[0] = dv[goff];
   }
+  // weight-gradient partials: the workgroup's four waves are summed in LDS, then one atomic per element and workgroup
+  __shared__ float red[4][2][64 * EPL];
 #pragma unroll
   for (int j = 0; j < EPL; ++j) {
-    atomicAdd(dqw + lane * EPL + j, wacc[0][j]);
-    atomicAdd(dkw + lane * EPL + j, wacc[1][j]);
+    red[threadIdx.x >> 6][0][lane * EPL + j] = wacc[0][j];
+    red[threadIdx.x >> 6][1][lane * EPL + j] = wacc[1][j];
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * 64 * EPL; i += 256) {
+    const int a = i / (64 * EPL), e = i % (64 * EPL);
+    atomicAdd((a == 0 ? dqw : dkw) + e, (red[0][a][e] + red[1][a][e]) + (red[2][a][e] + red[3][a][e]));
   }
 }
 
@@ -461,7 +471,7 @@ int qknorm_rope_backward(const bf16* fused, long ld, const bf16* dq, const bf16*
                          hipStream_t s) {
   DFOT_REQUIRE(d == 64 || d == 128, DFOT_ERR_SHAPE, "qknorm_rope_backward: head dim %d not in {64,128}", d);
   const long items = rows * heads;
-  const int grid = (int)(items / 4 < 4096 ? (items + 3) / 4 : 4096);
+  const int grid = (int)(items / 4 < 1024 ? (items + 3) / 4 : 1024);
   if (d == 64)
     hipLaunchKernelGGL(qknorm_rope_bwd_kernel<1>, dim3(grid), dim3(256), 0, s, fused, ld, dq, dk, dv, qw, kw, rope_cs, dfused, ldo, dqw, dkw, rows, ntok, heads, eps);
   else
@@ -748,13 +758,14 @@ __global__ void emb_combine_kernel(const bf16* __restrict__ pose, const float* _
 }
 // fine[bt][2y+a][2x+b][e] += coarse[bt][y][x][e] / 4   (adjoint of one level of the embedding pyramid's average pool), fp32
 // == pool2_bwd_kernel; dnemb[bt][e] = sum_p demb0[bt][p][e] is frames-style column sum over P rows:
-__global__ void rows_sum_kernel(const float* __restrict__ src, float* __restrict__ out, int P, int E) {
+__global__ void rows_sum_kernel(const float* __restrict__ src, float* __restrict__ out, int P, int E) {  // out must be zero (accumulates)
   const int bt = blockIdx.y;
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= E) return;
+  const int per = (P + gridDim.z - 1) / gridDim.z, p0 = blockIdx.z * per, p1 = p0 + per < P ? p0 + per : P;
   float acc = 0.f;
-  for (int p = 0; p < P; ++p) acc += src[((long)bt * P + p) * E + e];
-  out[(long)bt * E + e] = acc;
+  for (int p = p0; p < p1; ++p) acc += src[((long)bt * P + p) * E + e];
+  atomicAdd(out + (long)bt * E + e, acc);
 }
 // gradient of the ConvTranspose(k = s = p) output [BT][Co][R][R] gathered per input pixel: dpatch [pix][64] bf16, column (co, py, px)
 __global__ void outgrad_gather_kernel(const float* __restrict__ dout, bf16* __restrict__ dpatch, long pix, int R, int co, int ps) {
@@ -856,7 +867,8 @@ int dfot_op_emb_pyramid(const void* emb0, void* emb1, void* emb2, void* emb3, in
   return launch_emb_pyramid((const bf16*)emb0, (bf16*)emb1, (bf16*)emb2, (bf16*)emb3, bt, r0, e, (hipStream_t)stream);
 }
 int dfot_op_rows_sum(const float* src, float* out, int bt, int pixels, int e, void* stream) {
-  hipLaunchKernelGGL(rows_sum_kernel, dim3(cdiv(e, 256), bt), dim3(256), 0, (hipStream_t)stream, src, out, pixels, e);
+  DFOT_CHECK_HIP(hipMemsetAsync(out, 0, (size_t)bt * e * sizeof(float), (hipStream_t)stream));
+  hipLaunchKernelGGL(rows_sum_kernel, dim3(cdiv(e, 256), bt, pixels >= 2048 ? 64 : 1), dim3(256), 0, (hipStream_t)stream, src, out, pixels, e);
   DFOT_CHECK_HIP(hipGetLastError());
   return DFOT_OK;
 }
