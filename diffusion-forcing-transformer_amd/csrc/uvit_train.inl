@@ -234,7 +234,7 @@ int gn_silu_backward(const float* x, const float* dy, const float* stats, const 
                      float* dx, bf16* dfilm, float* dgamma, float* dbeta, int bt, int P, int C, bool accumulate, hipStream_t s) {
   DFOT_REQUIRE(C % 32 == 0 && (film == nullptr) == (dfilm == nullptr), DFOT_ERR_ARG, "gn_silu_backward: bad argument");
   DFOT_CHECK_HIP(hipMemsetAsync(sums, 0, (size_t)bt * 64 * sizeof(float), s));
-  const int chunk = 64;
+  const int chunk = P >= 4096 ? 512 : 64;  // pixels per workgroup: every thread ends with 4 atomics, so few, long chunks on the big maps
   const dim3 grid(bt, cdiv(P, chunk));
   const long total = (long)bt * P * C;
   if (film) {
