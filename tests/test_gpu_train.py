@@ -611,3 +611,70 @@ def test_uvit3d_pose_training_step():
             checked += int(big.sum())
     assert checked > 10000
     assert np.isfinite(float(tr.loss_and_grads(xs, cond, t, noise).item()))
+
+
+def _uvit_small():
+    from oracle import pose as opose, uvit as ouvit
+    cfg = ouvit.UViTConfig(channels=(128, 128, 128, 256), emb_channels=128, num_updown_blocks=(1, 1, 1), num_mid_blocks=1, num_heads=2, resolution=128,
+                           max_tokens=2)
+    params = ouvit.seeded_params(cfg, seed=5)
+    g = torch.Generator().manual_seed(3)
+    xs = torch.randn(2, 2, 3, 128, 128, generator=g)
+    t = torch.rand(2, 2, generator=g)
+    noise = torch.randn(2, 2, 3, 128, 128, generator=g)
+    poses = torch.eye(3, 4).reshape(1, 1, 12).repeat(2, 2, 1)
+    poses[..., 3] = torch.linspace(0, 0.3, 2)
+    poses[1, :, 7] = 0.1
+    cond = opose.ray_encoding(torch.cat([torch.tensor([0.5, 0.9, 0.5, 0.5]).repeat(2, 2, 1), poses], -1), 128)
+    tcfg = dict(channels=cfg.channels, emb_channels=cfg.emb_channels, patch_size=2, block_types=cfg.block_types, num_updown_blocks=cfg.num_updown_blocks,
+                num_mid_blocks=cfg.num_mid_blocks, num_heads=cfg.num_heads, resolution=128, max_tokens=2)
+    return params, tcfg, xs, t, noise, cond
+
+
+def _uvit_ddp_worker(rank, world, port, q):
+    import os
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from dfot_amd import uvit_train as ut
+        params, tcfg, xs, t, noise, cond = _uvit_small()
+        tr = ut.UViT3DPoseTrainer(params, tcfg)
+        sl = slice(rank, rank + 1)
+        loss = tr.loss_and_grads(xs[sl], cond[sl], t[sl], noise[sl])
+        tr.optimizer_step(lr=1e-4, world_size=world)
+        q.put((rank, float(loss.item()), tr.flat_grads.cpu().numpy(), tr.flat.cpu().numpy()))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_uvit_data_parallel_step_equals_single_process_step():
+    """BASELINE config 5's data parallelism on the pose model: two ranks with one video each (flat-gradient all-reduce, mean) take the same
+    optimizer step as one process with both videos"""
+    import socket
+    import torch.multiprocessing as mp
+    from dfot_amd import uvit_train as ut
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_uvit_ddp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=480) for _ in procs), key=lambda v: v[0])
+    for p in procs:
+        p.join(60)
+    params, tcfg, xs, t, noise, cond = _uvit_small()
+    tr = ut.UViT3DPoseTrainer(params, tcfg)
+    loss = float(tr.loss_and_grads(xs, cond, t, noise).item())
+    tr.optimizer_step(lr=1e-4)
+    grads, new = tr.flat_grads.cpu().numpy(), tr.flat.cpu().numpy()
+    assert np.array_equal(res[0][2], res[1][2]) and np.array_equal(res[0][3], res[1][3])  # replicas stay identical
+    assert abs(0.5 * (res[0][1] + res[1][1]) - loss) < 1e-3 * abs(loss)
+    gr = np.linalg.norm(res[0][2] - grads) / np.linalg.norm(grads)
+    print(f"UViT data-parallel vs single-process gradient rel-L2 {gr:.2e}")
+    assert gr < 2e-2
