@@ -756,6 +756,12 @@ __global__ void emb_combine_kernel(const bf16* __restrict__ pose, const float* _
   const bool drop = mask && mask[bt / tokens];
   out[i] = f2bf((drop ? 0.f : bf2f(pose[i])) + nemb[bt * E + e]);
 }
+// out bf16 = src fp32 with the rows of masked videos zeroed (gradient of the dropped pose embedding)
+__global__ void masked_cast_kernel(const float* __restrict__ src, const uint8_t* __restrict__ mask, bf16* __restrict__ out, long total, long per_video) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  out[i] = (mask && mask[i / per_video]) ? f2bf(0.f) : f2bf(src[i]);
+}
 // fine[bt][2y+a][2x+b][e] += coarse[bt][y][x][e] / 4   (adjoint of one level of the embedding pyramid's average pool), fp32
 // == pool2_bwd_kernel; dnemb[bt][e] = sum_p demb0[bt][p][e] is frames-style column sum over P rows:
 __global__ void rows_sum_kernel(const float* __restrict__ src, float* __restrict__ out, int P, int E) {  // out must be zero (accumulates)
@@ -860,6 +866,11 @@ int dfot_op_emb_combine(const void* pose, const float* nemb, const uint8_t* mask
   const long total = (long)bt * pixels * e;
   hipLaunchKernelGGL(emb_combine_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16*)pose, nemb, mask, (bf16*)out, total, pixels, e,
                      tokens);
+  DFOT_CHECK_HIP(hipGetLastError());
+  return DFOT_OK;
+}
+int dfot_op_masked_cast(const float* src, const uint8_t* mask, void* out, int64_t total, int64_t per_video, void* stream) {
+  hipLaunchKernelGGL(masked_cast_kernel, dim3(cdiv((long)total, 256)), dim3(256), 0, (hipStream_t)stream, src, mask, (bf16*)out, (long)total, (long)per_video);
   DFOT_CHECK_HIP(hipGetLastError());
   return DFOT_OK;
 }

@@ -332,8 +332,11 @@ class UViT3DPoseTrainer:
             x = b.forward(x, self.emb[lvl], self.bt, self.r[lvl], self.r[lvl]) if isinstance(b, ResBlockTrain) else b.forward(x, self.emb[lvl], self.B)
         return x
 
-    def forward(self, x: torch.Tensor, noise_levels: torch.Tensor, cond: torch.Tensor) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, noise_levels: torch.Tensor, cond: torch.Tensor, cond_drop: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """cond_drop: bool (B,), True = this video's pose embedding is zeroed -- RandomDropoutPatchEmbed's per-video dropout in training
+        (external_cond_dropout, embeddings.py:390-428); the caller draws it (torch.rand(B) < p)"""
         lib, p, e, r, ch = capi.lib, self.p, self.e, self.r, self.ch
+        self.drop = None if cond_drop is None else cond_drop.to(device="cuda", dtype=torch.uint8).contiguous()
         self.B, t = x.shape[:2]
         bt = self.bt = self.B * t
         if t != self.T:
@@ -357,7 +360,7 @@ class UViT3DPoseTrainer:
         capi.check(lib.dfot_op_cond_repack(_P(cd), _P(self.patches), bt, self.res, self.cdim, self.kpad, _S()))
         pose = gemm_bf16(self.patches, self.wp, p["external_cond_embedding.patch_embedder.proj.bias"])
         self.emb = [torch.empty(bt * r[l] * r[l], e, dtype=BF, device="cuda") for l in range(4)]
-        capi.check(lib.dfot_op_emb_combine(_P(pose), _P(nemb), None, _P(self.emb[0]), bt, P0, e, t, _S()))
+        capi.check(lib.dfot_op_emb_combine(_P(pose), _P(nemb), _P(self.drop), _P(self.emb[0]), bt, P0, e, t, _S()))
         capi.check(lib.dfot_op_emb_pyramid(_P(self.emb[0]), _P(self.emb[1]), _P(self.emb[2]), _P(self.emb[3]), bt, r[0], e, _S()))
         # input embedding and the U
         h = torch.empty(bt * P0, ch[0], dtype=torch.float32, device="cuda")
@@ -430,7 +433,8 @@ class UViT3DPoseTrainer:
         # embedding pyramid (successive 2x2 average pools), pose patch embedding, noise-level MLP
         for l in (2, 1, 0):
             capi.check(lib.dfot_op_pool2_bwd(_P(demb[l + 1]), _P(demb[l]), bt, r[l], r[l], e, _S()))
-        dpose = _bf(demb[0])
+        dpose = torch.empty(bt * P0, e, dtype=BF, device="cuda")  # the pose embedding of dropped videos was replaced by zero: no gradient
+        capi.check(lib.dfot_op_masked_cast(_P(demb[0]), _P(self.drop), _P(dpose), dpose.numel(), self.T * P0 * e, _S()))
         pe = "external_cond_embedding.patch_embedder.proj."
         G[pe + "weight"] = wgrad(dpose, self.patches)[:, : self.cdim * 4].reshape(e, self.cdim, self.ps, self.ps).contiguous()
         G[pe + "bias"] = colsum(dpose)
@@ -446,7 +450,8 @@ class UViT3DPoseTrainer:
 
     # ------------------------------------------------------------------ training step (ContinuousDiffusion.forward + AdamW)
     def loss_and_grads(self, xs: torch.Tensor, cond: torch.Tensor, t: torch.Tensor, noise: torch.Tensor, masks: Optional[torch.Tensor] = None,
-                       precond_scale: float = 0.125, shift: float = 0.125, sigmoid_bias: float = -1.0, clip_noise: float = 20.0) -> torch.Tensor:
+                       precond_scale: float = 0.125, shift: float = 0.125, sigmoid_bias: float = -1.0, clip_noise: float = 20.0,
+                       cond_drop: Optional[torch.Tensor] = None) -> torch.Tensor:
         """DFoTVideo.training_step for the pose model (dfot_video.py:41-75, continuous_diffusion.py:140-167): per-token levels t in [0,1],
         x_t = alpha x + sigma eps, v = model(x_t, precond * logsnr, cond), sigmoid-weighted eps-space error averaged with the loss masks;
         then the backward.  cond: processed ray encoding (B,T,180,H,W).  Returns the loss (device scalar)."""
@@ -463,7 +468,7 @@ class UViT3DPoseTrainer:
         x_t = torch.empty_like(x)
         lib = capi.lib
         capi.check(lib.dfot_hg_prepare(_P(x), _P(eps), _P(tab[0]), _P(tab[1]), _P(x_t), b, 1, tk, f, _S()))
-        v = self.forward(x_t, tab[3], cond).contiguous()
+        v = self.forward(x_t, tab[3], cond, cond_drop).contiguous()
         per_token = torch.empty(b, tk, device="cuda")
         scratch = torch.empty(int(lib.dfot_vpred_loss_scratch_floats(b, tk, f)), device="cuda")
         capi.check(lib.dfot_vpred_loss(_P(x), _P(eps), _P(v), _P(tab[0]), _P(tab[1]), _P(tab[2]), None, _P(scratch), _P(per_token), b, tk, f, _S()))

@@ -678,3 +678,27 @@ def test_uvit_data_parallel_step_equals_single_process_step():
     gr = np.linalg.norm(res[0][2] - grads) / np.linalg.norm(grads)
     print(f"UViT data-parallel vs single-process gradient rel-L2 {gr:.2e}")
     assert gr < 2e-2
+
+
+def test_uvit_pose_dropout_mask():
+    """per-video pose-embedding dropout (external_cond_dropout): forward and gradients with one of two videos dropped vs autograd through the
+    oracle with the same external_cond_mask"""
+    from dfot_amd import uvit_train as ut
+    from oracle import uvit as ouvit
+    params, tcfg, xs, t, noise, cond = _uvit_small()
+    cfg = ouvit.UViTConfig(channels=(128, 128, 128, 256), emb_channels=128, num_updown_blocks=(1, 1, 1), num_mid_blocks=1, num_heads=2, resolution=128,
+                           max_tokens=2)
+    drop = torch.tensor([False, True])
+    g = torch.Generator().manual_seed(1)
+    d_out = torch.randn(2, 2, 3, 128, 128, generator=g)
+    tr = ut.UViT3DPoseTrainer(params, tcfg)
+    out = tr.forward(xs, t, cond, drop).cpu()
+    grads = {n: v.cpu() for n, v in tr.backward(d_out).items()}
+    ps = {n: v.clone().requires_grad_(not n.endswith(("freqs", "phases"))) for n, v in params.items()}
+    ref = ouvit.forward(ps, cfg, xs, t, cond, drop)
+    assert rel(out, ref.detach()) < 2e-2
+    (ref * d_out).sum().backward()
+    pe = "external_cond_embedding.patch_embedder.proj.weight"
+    worst = max(rel(grads[n], ps[n].grad) for n in grads)
+    print(f"UViT pose dropout: worst gradient rel-L2 {worst:.2e}; pose-embedding weight {rel(grads[pe], ps[pe].grad):.2e}")
+    assert worst < 6e-2
