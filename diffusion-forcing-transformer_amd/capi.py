@@ -128,6 +128,7 @@ SIGNATURES = {
     "dfot_op_upsample_bwd": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "dfot_op_axpy": (_I, [_P, _P, _F, _L, _P]),
     "dfot_op_emb_combine": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "dfot_op_mul_cols": (_I, [_P, _I, _I, _P, _L, _I, _P]),
     "dfot_op_masked_cast": (_I, [_P, _P, _P, _L, _L, _P]),
     "dfot_op_emb_pyramid": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
     "dfot_op_rows_sum": (_I, [_P, _P, _I, _I, _I, _P]),

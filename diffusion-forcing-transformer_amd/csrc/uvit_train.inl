@@ -756,6 +756,19 @@ __global__ void emb_combine_kernel(const bf16* __restrict__ pose, const float* _
   const bool drop = mask && mask[bt / tokens];
   out[i] = f2bf((drop ? 0.f : bf2f(pose[i])) + nemb[bt * E + e]);
 }
+// dst[r][dcol0 + c] *= mask[r][c]   (dropout: mask holds 0 or 1 / (1 - p)); 8 columns per thread
+__global__ void mul_cols_kernel(bf16* __restrict__ dst, long ldd, int dcol0, const bf16* __restrict__ mask, long rows, int ncols) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int c8 = ncols / 8;
+  if (i >= rows * c8) return;
+  const long r = i / c8;
+  const int c = (int)(i % c8) * 8;
+  bf16x8 v = *reinterpret_cast<bf16x8*>(dst + r * ldd + dcol0 + c);
+  const bf16x8 m = *reinterpret_cast<const bf16x8*>(mask + r * ncols + c);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] = f2bf(bf2f(v[j]) * bf2f(m[j]));
+  *reinterpret_cast<bf16x8*>(dst + r * ldd + dcol0 + c) = v;
+}
 // out bf16 = src fp32 with the rows of masked videos zeroed (gradient of the dropped pose embedding)
 __global__ void masked_cast_kernel(const float* __restrict__ src, const uint8_t* __restrict__ mask, bf16* __restrict__ out, long total, long per_video) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -866,6 +879,13 @@ int dfot_op_emb_combine(const void* pose, const float* nemb, const uint8_t* mask
   const long total = (long)bt * pixels * e;
   hipLaunchKernelGGL(emb_combine_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16*)pose, nemb, mask, (bf16*)out, total, pixels, e,
                      tokens);
+  DFOT_CHECK_HIP(hipGetLastError());
+  return DFOT_OK;
+}
+int dfot_op_mul_cols(void* dst, int ldd, int dcol0, const void* mask, int64_t rows, int ncols, void* stream) {
+  DFOT_REQUIRE(dst && mask && ncols % 8 == 0 && dcol0 % 8 == 0, DFOT_ERR_ARG, "op_mul_cols: bad argument");
+  hipLaunchKernelGGL(mul_cols_kernel, dim3(cdiv((long)rows * (ncols / 8), 256)), dim3(256), 0, (hipStream_t)stream, (bf16*)dst, (long)ldd, dcol0,
+                     (const bf16*)mask, (long)rows, ncols);
   DFOT_CHECK_HIP(hipGetLastError());
   return DFOT_OK;
 }

@@ -109,8 +109,9 @@ class TransformerBlockTrain:
         self.b_out = (p["attn_out.bias"] + p["mlp_out.2.bias"]).contiguous()
         self.w_eT, self.w_fT, self.w_outT = transpose(self.w_e), transpose(self.w_f), transpose(self.w_out)
 
-    def forward(self, x: torch.Tensor, emb: torch.Tensor, batch: int) -> torch.Tensor:
-        """x fp32 [B*N][C] (residual stream), emb bf16 [B*N][E] (per-token conditioning embedding); returns y fp32"""
+    def forward(self, x: torch.Tensor, emb: torch.Tensor, batch: int, mlp_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """x fp32 [B*N][C] (residual stream), emb bf16 [B*N][E] (per-token conditioning embedding); returns y fp32.
+        mlp_mask: bf16 [B*N][4C] holding 0 or 1 / (1 - p): the nn.Dropout(p) after the MLP branch's SiLU (u_vit_blocks.py:230-234, training)"""
         c, hds, d, p = self.c, self.heads, self.d, self.p
         rows = x.shape[0]
         ntok = rows // batch
@@ -126,8 +127,10 @@ class TransformerBlockTrain:
         lse = torch.empty(batch, hds, ntok, dtype=torch.float32, device="cuda")
         capi.check(lib.dfot_op_attention_fwd_lse(_P(q), _P(k), _P(v), _P(cat), 5 * c, _P(lse), batch, hds, ntok, d, _S()))
         capi.check(lib.dfot_op_silu_cols(_P(fused), 7 * c, 3 * c, None, 0, 0, _P(cat), 5 * c, c, rows, 4 * c, _S()))
+        if mlp_mask is not None:
+            capi.check(lib.dfot_op_mul_cols(_P(cat), 5 * c, c, _P(mlp_mask), rows, 4 * c, _S()))
         y = gemm_f32(cat, self.w_out, self.b_out, resid=x)
-        self.saved = dict(x=x, emb=emb, film=film, xn=xn, fused=fused, q=q, k=k, v=v, cat=cat, lse=lse, batch=batch)
+        self.saved = dict(x=x, emb=emb, film=film, xn=xn, fused=fused, q=q, k=k, v=v, cat=cat, lse=lse, batch=batch, mlp_mask=mlp_mask)
         return y
 
     def backward(self, dy: torch.Tensor, demb_acc: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
@@ -148,6 +151,8 @@ class TransformerBlockTrain:
         dqw, dkw = torch.empty(d, device="cuda"), torch.empty(d, device="cuda")
         capi.check(lib.dfot_op_qknorm_rope_bwd(_P(s["fused"]), 7 * c, _P(dq), _P(dk), _P(dv), _P(p["q_norm.weight"]), _P(p["k_norm.weight"]),
                                                _P(self.rope), self.eps, _P(dfused), 7 * c, _P(dqw), _P(dkw), rows, ntok, hds, d, _S()))
+        if s["mlp_mask"] is not None:  # d(dropout): the same mask on the gradient of the dropped activations
+            capi.check(lib.dfot_op_mul_cols(_P(dcat), 5 * c, c, _P(s["mlp_mask"]), rows, 4 * c, _S()))
         capi.check(lib.dfot_op_silu_cols(_P(s["fused"]), 7 * c, 3 * c, _P(dcat), 5 * c, c, _P(dfused), 7 * c, 3 * c, rows, 4 * c, _S()))
         dxn = gemm_f32(dfused, self.w_fT)                                    # [rows][C]
         dw_f, db_f = wgrad(dfused, s["xn"]), colsum(dfused)
@@ -305,6 +310,9 @@ class UViT3DPoseTrainer:
         self.mid = [block(f"mid_blocks.{i}", 3) for i in range(self.nmid)]
         self.up = [[block(f"up_blocks.{j}.{i + 1}", l) for i in range(self.nud[l])] for j, l in enumerate((2, 1, 0))]
         self.grads: Dict[str, torch.Tensor] = {}
+        # block_dropouts of u_vit3d_pose.yaml ([0, 0, 0.1, 0.1]); applied only when a CUDA generator is set (training with dropout on)
+        self.block_dropouts = list(g("block_dropouts", [0.0] * 4))
+        self.dropout_generator: Optional[torch.Generator] = None
         self.sync()
 
     def sync(self) -> None:
@@ -328,8 +336,16 @@ class UViT3DPoseTrainer:
         return [b for lv in self.down for b in lv] + self.mid + [b for lv in self.up for b in lv]
 
     def _run(self, blocks, x, lvl):
+        p = self.block_dropouts[lvl] if self.dropout_generator is not None else 0.0
         for b in blocks:
-            x = b.forward(x, self.emb[lvl], self.bt, self.r[lvl], self.r[lvl]) if isinstance(b, ResBlockTrain) else b.forward(x, self.emb[lvl], self.B)
+            if isinstance(b, ResBlockTrain):
+                x = b.forward(x, self.emb[lvl], self.bt, self.r[lvl], self.r[lvl])
+            else:
+                mask = None
+                if p > 0:  # nn.Dropout(p) of the MLP branch: keep with probability 1 - p, scale by 1 / (1 - p)
+                    keep = torch.rand(x.shape[0], 4 * self.ch[lvl], device="cuda", generator=self.dropout_generator) >= p
+                    mask = (keep.to(torch.float32) / (1.0 - p)).to(BF)
+                x = b.forward(x, self.emb[lvl], self.B, mask)
         return x
 
     def forward(self, x: torch.Tensor, noise_levels: torch.Tensor, cond: torch.Tensor, cond_drop: Optional[torch.Tensor] = None) -> torch.Tensor:

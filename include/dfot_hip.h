@@ -321,6 +321,7 @@ int dfot_op_upsample_add(const float* t, const float* skip, float* out, int bt, 
 int dfot_op_upsample_bwd(const float* dy, float* ds, int bt, int h, int w, int c, void* stream);
 int dfot_op_axpy(float* a, const float* b, float alpha, int64_t n, void* stream);
 int dfot_op_emb_combine(const void* pose, const float* nemb, const uint8_t* mask, void* out, int bt, int pixels, int e, int tokens, void* stream);
+int dfot_op_mul_cols(void* dst, int ldd, int dcol0, const void* mask, int64_t rows, int ncols, void* stream);
 int dfot_op_masked_cast(const float* src, const uint8_t* mask, void* out, int64_t total, int64_t per_video, void* stream);
 int dfot_op_emb_pyramid(const void* emb0, void* emb1, void* emb2, void* emb3, int bt, int r0, int e, void* stream);
 int dfot_op_rows_sum(const float* src, float* out, int bt, int pixels, int e, void* stream);

@@ -200,7 +200,8 @@ def res_block(p: Params, pre: str, x: torch.Tensor, emb: torch.Tensor, cfg: UViT
 
 
 def transformer_block(p: Params, pre: str, x: torch.Tensor, emb: torch.Tensor, ang: torch.Tensor,
-                      cfg: UViTConfig, taps: Optional[dict] = None) -> torch.Tensor:
+                      cfg: UViTConfig, taps: Optional[dict] = None, mlp_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """mlp_mask (training only): the realised nn.Dropout mask of mlp_out (u_vit_blocks.py:230-234), 0 or 1 / (1 - p) per element"""
     b, n, c = x.shape
     hds = cfg.num_heads
     d = c // hds
@@ -220,7 +221,8 @@ def transformer_block(p: Params, pre: str, x: torch.Tensor, emb: torch.Tensor, a
     if taps is not None:
         taps.update(xn=xn, q=q, k=k, v=v, att=att, mlp_h=mlp_h)
     y = x + F.linear(att, p[pre + ".attn_out.weight"], p[pre + ".attn_out.bias"])
-    return y + F.linear(F.silu(mlp_h), p[pre + ".mlp_out.2.weight"], p[pre + ".mlp_out.2.bias"])
+    act = F.silu(mlp_h) if mlp_mask is None else F.silu(mlp_h) * mlp_mask
+    return y + F.linear(act, p[pre + ".mlp_out.2.weight"], p[pre + ".mlp_out.2.bias"])
 
 
 # --------------------------------------------------------------------------- #

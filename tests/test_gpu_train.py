@@ -484,14 +484,16 @@ def test_uvit_transformer_block_train_unit(c, heads):
     emb = (torch.randn(batch, ntok, e, generator=g) * 0.5).to(torch.bfloat16)
     dy = torch.randn(batch, ntok, c, generator=g)
     blk = ut.TransformerBlockTrain(params, "blk", c, heads, ut.rope_table(d, sizes))
-    y = blk.forward(x.view(-1, c).cuda(), emb.view(-1, e).cuda().contiguous(), batch)
+    # the MLP branch's nn.Dropout(0.1), realised mask shared with the oracle
+    mask = ((torch.rand(batch * ntok, 4 * c, generator=g) >= 0.1).float() / 0.9).to(torch.bfloat16)
+    y = blk.forward(x.view(-1, c).cuda(), emb.view(-1, e).cuda().contiguous(), batch, mask.cuda())
     dx, demb = blk.backward(dy.view(-1, c).cuda())
     torch.cuda.synchronize()
     ps = {n: t.clone().requires_grad_() for n, t in params.items()}
     xr, er = x.clone().requires_grad_(), emb.float().requires_grad_()
     cfg = ouvit.UViTConfig(num_heads=heads)
     ang = ouvit.rope3d_angles(d, sizes, cfg.rope_theta)
-    ref = ouvit.transformer_block(ps, "blk", xr, er, ang, cfg)
+    ref = ouvit.transformer_block(ps, "blk", xr, er, ang, cfg, mlp_mask=mask.float().view(batch, ntok, 4 * c))
     ref.backward(dy)
     rs = {"y": rel(y.cpu().view_as(ref), ref.detach()), "dx": rel(dx.cpu().view_as(x), xr.grad), "demb": rel(demb.cpu().view_as(er), er.grad)}
     for n in blk.grads:
