@@ -9,7 +9,7 @@ Mirrors the reference's plugin contract for this path:
     ``load_state_dict``.
 Parameters live here as fp32 ``nn.Parameter``s (the reference layout); the C library keeps
 packed bf16 copies that are refreshed whenever a parameter changes.  Inference only
-(the engine has no backward yet): call under ``torch.no_grad()``.
+(this inference module has no backward; training goes through uvit_train.UViT3DPoseTrainer): call under ``torch.no_grad()``.
 """
 from __future__ import annotations
 

@@ -1,5 +1,5 @@
-// Backward building blocks for the UViT3DPose backbone (training path of BASELINE config 5, built op by op; the orchestration of a
-// whole UViT training step is not written yet).  Included at the end of dit.hip (shares the training helpers of dit_train.inl).
+// Backward kernels and op entry points for the UViT3DPose backbone (training path of BASELINE config 5); the training step itself is
+// sequenced by diffusion-forcing-transformer_amd/uvit_train.py over these entry points.  Included at the end of dit.hip (shares the training helpers of dit_train.inl).
 //
 // conv3x3 (padding 1, channels-last activations [BT][H][W][C] bf16), y = conv(x, W) + b with W [Co][Ci][3][3]:
 //   dx = conv(dy, W')         W'[ci][2-ky][2-kx][co] = W[co][ci][ky][kx]      -> the forward's implicit-GEMM kernel on repacked weights
