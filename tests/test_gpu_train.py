@@ -704,3 +704,34 @@ def test_uvit_pose_dropout_mask():
     worst = max(rel(grads[n], ps[n].grad) for n in grads)
     print(f"UViT pose dropout: worst gradient rel-L2 {worst:.2e}; pose-embedding weight {rel(grads[pe], ps[pe].grad):.2e}")
     assert worst < 6e-2
+
+
+def test_uvit_training_gradients_vs_reference_fixture():
+    """loss and gradients of the reference's own pose-model training step (tests/golden/training_grads_uvit.npz, differentiated by the
+    reference's autograd on CPU: UViT3DPose at reduced widths, 8 tokens of 128x128) vs the engine's training driver"""
+    import os
+    from conftest import GOLDEN
+    from dfot_amd import uvit_train as ut
+    from oracle import pose as opose, uvit as ouvit
+    g = np.load(os.path.join(GOLDEN, "training_grads_uvit.npz"))
+    cfg = ouvit.UViTConfig(channels=(128, 128, 128, 256), emb_channels=128, num_updown_blocks=(1, 1, 1), num_mid_blocks=1, num_heads=2, resolution=128)
+    params = ouvit.seeded_params(cfg, 6)
+    tr = ut.UViT3DPoseTrainer(params, dict(channels=cfg.channels, emb_channels=128, patch_size=2, block_types=cfg.block_types,
+                                           num_updown_blocks=cfg.num_updown_blocks, num_mid_blocks=1, num_heads=2, resolution=128, max_tokens=8))
+    cond = opose.ray_encoding(torch.from_numpy(g["poses"]), 128)
+    loss = tr.loss_and_grads(torch.from_numpy(g["xs"]), cond, torch.from_numpy(g["k"]), torch.from_numpy(g["noise"]), torch.from_numpy(g["masks"]))
+    ref_loss = float(g["loss"])
+    assert abs(float(loss.item()) - ref_loss) < 2e-2 * abs(ref_loss), (float(loss.item()), ref_loss)
+    grads = {n: v.cpu() for n, v in tr.grads.items()}
+    names = [str(n) for n in g["names"]]
+    assert sorted(names) == sorted(grads)
+    for n, ref_norm in zip(names, g["norms"]):
+        assert abs(float(grads[n].norm()) - ref_norm) <= 5e-2 * ref_norm + 1e-7, (n, float(grads[n].norm()), ref_norm)
+    worst = 0.0
+    for key in g.files:
+        if key.startswith("grad/"):
+            ref = torch.from_numpy(g[key])
+            if float(ref.norm()) > 1e-6:
+                worst = max(worst, rel(grads[key[5:]], ref))
+    print(f"UViT3DPose: worst stored-gradient rel-L2 vs the reference {worst:.2e}")
+    assert worst < 8e-2

@@ -174,11 +174,48 @@ def save(name, **arrays):
     print(f"  wrote {name}: {os.path.getsize(path) / 1e6:.2f} MB")
 
 
+TRAIN = dict(channels=[128, 128, 128, 256], emb_channels=128, num_updown_blocks=[1, 1, 1], num_mid_blocks=1, num_heads=2)
+
+
+@torch.enable_grad()
+def training_grads_uvit(R):
+    """training_grads_uvit.npz: the reference's own training loss for the pose model -- ContinuousDiffusion.forward (per-token levels in [0,1],
+    v-prediction, sigmoid weighting) through UViT3DPose (reduced widths, 128x128 frames, 8 tokens, dropout off) -> _reweight_loss with
+    masks -> backward(): loss, the L2 norm of every parameter gradient and the full gradient of the small tensors"""
+    print("training grads (UViT3DPose)")
+    A = R["AttrDict"]
+    cfg = algo_cfg(A, 128, TRAIN)
+    algo, ocfg, params = build_algo(R, cfg, seed=6)
+    g = torch.Generator().manual_seed(31)
+    xs = torch.randn(1, 8, 3, 128, 128, generator=g)
+    k = torch.rand(1, 8, generator=g)
+    masks = torch.ones(1, 8)
+    masks[0, 5] = 0
+    poses = synth_poses(1, 8, seed=2)
+    model = algo.diffusion_model.model
+    for p_ in model.parameters():
+        p_.grad = None
+    cond = algo._process_conditions(poses.clone())
+    with RandnRecorder() as rec:
+        _, loss = algo.diffusion_model(xs, cond, k=k)
+    loss = algo._reweight_loss(loss, masks)
+    loss.backward()
+    grads = {n: p_.grad.detach().clone() for n, p_ in model.named_parameters() if p_.grad is not None}
+    out = {"loss": loss.detach(), "noise": rec.draws[0], "names": np.array(list(grads)),
+           "norms": np.array([float(v.norm()) for v in grads.values()], np.float64)}
+    for n, v in grads.items():
+        if v.numel() <= 4096:
+            out["grad/" + n] = v
+    save("training_grads_uvit.npz", xs=xs, k=k, masks=masks, poses=poses, digest=np.array(weights_digest(params)), **out)
+
+
 @torch.no_grad()
 def main():
     os.makedirs(OUT, exist_ok=True)
     R = ref_loader.install()
     A = R["AttrDict"]
+    if os.environ.get("ONLY") == "training_grads_uvit":
+        return training_grads_uvit(R)
 
     # ---------------------------------------------------------------- schedule + scheduling matrices
     print("schedule")
