@@ -209,6 +209,13 @@ class UViT3DPose(nn.Module):
             raise ValueError(f"external_cond has shape {tuple(external_cond.shape)}")
         if external_cond_mask is not None:
             assert external_cond_mask.ndim == 1, "embedding mask should be of shape (B,)"
+        if tuple(noise_levels.shape) != (b, self.temporal_length):
+            raise ValueError(f"noise_levels has shape {tuple(noise_levels.shape)}, expected {(b, self.temporal_length)}")
+        dev = next(self.parameters()).device
+        if dev.type != "cuda":
+            raise RuntimeError(f"the backbone's parameters are on {dev}; move the module to the GPU first (there is no CPU path)")
+        # the kernels dereference raw pointers: a host tensor must be refused before anything is launched
+        capi.require_device(dev, x=x, noise_levels=noise_levels, external_cond=external_cond, external_cond_mask=external_cond_mask)
         self.sync_weights()
         self.reserve(b)
         xf = x.detach().to(torch.float32).contiguous()
@@ -220,12 +227,13 @@ class UViT3DPose(nn.Module):
         if key != self._cond_key:
             cf = external_cond.detach().to(torch.float32).contiguous()
             mf = None if external_cond_mask is None else external_cond_mask.to(torch.uint8).contiguous()
-            capi.check(capi.lib.dfot_uvit_set_conditions(self._handle, capi.ptr(cf), capi.ptr(mf), b, capi.stream_ptr()))
+            capi.check(capi.lib.dfot_uvit_set_conditions(self._handle, capi.ptr(cf, torch.float32, "external_cond"),
+                                                         capi.ptr(mf, torch.uint8, "external_cond_mask"), b, capi.stream_ptr()))
             self._cond_key = key
             self._cond_refs = (external_cond, external_cond_mask)  # keep the keyed tensors alive
         out = torch.empty_like(xf)
-        capi.check(capi.lib.dfot_uvit_forward_cached(self._handle, capi.ptr(xf), capi.ptr(kf), capi.ptr(out), b,
-                                                     capi.stream_ptr()))
+        capi.check(capi.lib.dfot_uvit_forward_cached(self._handle, capi.ptr(xf, torch.float32, "x"),
+                                                     capi.ptr(kf, torch.float32, "noise_levels"), capi.ptr(out), b, capi.stream_ptr()))
         return out.to(x.dtype)
 
     def read_tap(self, name: str, channels: int, level: int, batch: int) -> torch.Tensor:

@@ -166,9 +166,25 @@ def check(code: int) -> None:
         raise DfotError(code, (lib.dfot_last_error() or b"").decode())
 
 
-def ptr(t) -> C.c_void_p:
-    """Device pointer of a torch tensor (None -> NULL)."""
-    return C.c_void_p(0 if t is None else t.data_ptr())
+def ptr(t, dtype=None, name: str = "tensor") -> C.c_void_p:
+    """Device pointer of a torch tensor (None -> NULL).  The kernels dereference it on the GPU, so a host tensor, a strided
+    view or (when the caller states one) a wrong element type is refused HERE: a bad pointer would be a GPU memory fault."""
+    if t is None:
+        return C.c_void_p(0)
+    if not t.is_cuda:
+        raise ValueError(f"{name} is on {t.device}: libdfot_hip takes GPU memory only (there is no CPU path)")
+    if not t.is_contiguous():
+        raise ValueError(f"{name} with shape {tuple(t.shape)} and strides {tuple(t.stride())} is not contiguous")
+    if dtype is not None and t.dtype != dtype:
+        raise ValueError(f"{name} has dtype {t.dtype}, expected {dtype}")
+    return C.c_void_p(t.data_ptr())
+
+
+def require_device(dev, **tensors) -> None:
+    """Every given tensor (None entries skipped) must live on `dev`; raises ValueError naming the first that does not."""
+    for name, t in tensors.items():
+        if t is not None and t.device != dev:
+            raise ValueError(f"{name} is on {t.device} but the backbone's parameters are on {dev}")
 
 
 def stream_ptr() -> C.c_void_p:

@@ -179,12 +179,17 @@ class DiT3D(nn.Module):
             raise ValueError(f"noise_levels has shape {tuple(noise_levels.shape)}, expected {(b, t)}")
         if noise_levels.is_floating_point():
             raise TypeError("DiT3D takes integer noise levels (DiscreteDiffusion passes the level index)")
+        dev = next(self.parameters()).device
+        if dev.type != "cuda":
+            raise RuntimeError(f"the backbone's parameters are on {dev}; move the module to the GPU first (there is no CPU path)")
+        capi.require_device(dev, x=x, noise_levels=noise_levels)
         self.sync_weights()
         self.reserve(b)
         xf = x.detach().to(torch.float32).contiguous()
         kf = noise_levels.detach().to(torch.int32).contiguous()
         out = torch.empty_like(xf)
-        capi.check(capi.lib.dfot_dit_forward(self._handle, capi.ptr(xf), capi.ptr(kf), capi.ptr(out), b, t, capi.stream_ptr()))
+        capi.check(capi.lib.dfot_dit_forward(self._handle, capi.ptr(xf, torch.float32, "x"), capi.ptr(kf, torch.int32, "noise_levels"),
+                                             capi.ptr(out), b, t, capi.stream_ptr()))
         return out.to(x.dtype)
 
     def read_tap(self, name: str, rows: int) -> torch.Tensor:

@@ -86,9 +86,15 @@ def _(raw_poses, resolution, normalized=False):
 def hg_prepare(x: Tensor, noise: Optional[Tensor], qa: Tensor, qb: Tensor, nfe: int) -> Tensor:
     b, t = x.shape[:2]
     f = x[0, 0].numel()
+    F32 = torch.float32
+    for name, tab in (("qa", qa), ("qb", qb)):
+        if tuple(tab.shape) != (b * nfe, t):
+            raise ValueError(f"{name} has shape {tuple(tab.shape)}, expected {(b * nfe, t)}")
+    if noise is not None and tuple(noise.shape) != (b * nfe, *x.shape[1:]):
+        raise ValueError(f"noise has shape {tuple(noise.shape)}, expected {(b * nfe, *x.shape[1:])}")
+    px, pn, pa, pb = capi.ptr(x, F32, "x"), capi.ptr(noise, F32, "noise"), capi.ptr(qa, F32, "qa"), capi.ptr(qb, F32, "qb")
     x_in = torch.empty(b * nfe, *x.shape[1:], device=x.device, dtype=torch.float32)
-    capi.check(capi.lib.dfot_hg_prepare(capi.ptr(x), capi.ptr(noise), capi.ptr(qa), capi.ptr(qb), capi.ptr(x_in), b, nfe, t, f,
-                                        capi.stream_ptr()))
+    capi.check(capi.lib.dfot_hg_prepare(px, pn, pa, pb, capi.ptr(x_in), b, nfe, t, f, capi.stream_ptr()))
     return x_in
 
 
@@ -102,10 +108,25 @@ def ddim_hg_step(x: Tensor, x_in: Tensor, v: Tensor, sa: Tensor, s1: Tensor, an:
                  weight: Tensor, gen: Tensor, nfe: int) -> Tensor:
     b, t = x.shape[:2]
     f = x[0, 0].numel()
+    F32 = torch.float32
+    for name, big in (("x_in", x_in), ("v", v)):
+        if tuple(big.shape) != (b * nfe, *x.shape[1:]):
+            raise ValueError(f"{name} has shape {tuple(big.shape)}, expected {(b * nfe, *x.shape[1:])}")
+    tabs = dict(sa=sa, s1=s1, an=an, cn=cn, keep=keep)
+    for name, tab in tabs.items():
+        if tuple(tab.shape) != (b * nfe, t):
+            raise ValueError(f"{name} has shape {tuple(tab.shape)}, expected {(b * nfe, t)}")
+    if tuple(gen.shape) != (b, t):
+        raise ValueError(f"gen has shape {tuple(gen.shape)}, expected {(b, t)}")
+    tokw = weight.ndim == 2
+    if (tokw and tuple(weight.shape) != (nfe, t)) or (not tokw and tuple(weight.shape) != (nfe,)):
+        raise ValueError(f"weight has shape {tuple(weight.shape)}, expected {(nfe,)} or {(nfe, t)}")
+    ptrs = [capi.ptr(x, F32, "x"), capi.ptr(x_in, F32, "x_in"), capi.ptr(v, F32, "v")]
+    ptrs += [capi.ptr(tab, F32, name) for name, tab in tabs.items()]
+    ptrs += [capi.ptr(weight, F32, "weight"), capi.ptr(gen, torch.uint8, "gen")]
     x_next = torch.empty_like(x)
-    fn = capi.lib.dfot_ddim_compose_tokw if weight.ndim == 2 else capi.lib.dfot_ddim_compose
-    capi.check(fn(capi.ptr(x), capi.ptr(x_in), capi.ptr(v), capi.ptr(sa), capi.ptr(s1), capi.ptr(an), capi.ptr(cn), capi.ptr(keep),
-                  capi.ptr(weight), capi.ptr(gen), capi.ptr(x_next), b, nfe, t, f, capi.stream_ptr()))
+    fn = capi.lib.dfot_ddim_compose_tokw if tokw else capi.lib.dfot_ddim_compose
+    capi.check(fn(*ptrs, capi.ptr(x_next), b, nfe, t, f, capi.stream_ptr()))
     return x_next
 
 

@@ -31,12 +31,16 @@ def gather_windows(local: torch.Tensor, n_windows: int, group=None) -> torch.Ten
     if world == 1:
         return local
     per = (n_windows + world - 1) // world
-    pad = local.new_zeros((per, *local.shape[1:]))
-    pad[: local.shape[0]] = local
-    out = [torch.empty_like(pad) for _ in range(world)]
-    dist.all_gather(out, pad.contiguous(), group=group)
-    stacked = torch.stack(out, dim=1)          # [per, world, ...]: window id = i*world + r
-    return stacked.reshape(per * world, *local.shape[1:])[:n_windows].contiguous()
+    if local.shape[0] == per:
+        pad = local.contiguous()
+    else:
+        pad = local.new_zeros((per, *local.shape[1:]))
+        pad[: local.shape[0]] = local
+    # one collective straight into one buffer [world][per][...] (no per-rank list + stack copies)
+    out = pad.new_empty((world * per, *local.shape[1:]))
+    dist.all_gather_into_tensor(out, pad, group=group)
+    # rank-major [world][per] -> window id = i*world + r
+    return out.view(world, per, *local.shape[1:]).transpose(0, 1).reshape(per * world, *local.shape[1:])[:n_windows].contiguous()
 
 
 class WindowKeyedNoise:
@@ -53,7 +57,10 @@ class WindowKeyedNoise:
 
     def __call__(self, tag: str, shape: tuple) -> torch.Tensor:
         rows = shape[0]
-        per = max(rows // len(self.keys), 1)
+        if rows % len(self.keys) != 0:
+            raise ValueError(f"WindowKeyedNoise: a draw of {rows} rows cannot be split over the {len(self.keys)} window keys set by "
+                             "set_windows (stale keys from another batch?)")
+        per = rows // len(self.keys)
         out = torch.empty(shape, device=self.device, dtype=torch.float32)
         tag_id = {"init": 1, "q_sample": 2, "excluded": 3, "ddim": 4}.get(tag, 9)
         for i, key in enumerate(self.keys):

@@ -71,6 +71,8 @@ class DFoTVideoPoseSampler:
         self.trace: List[dict] = []
         self.window_forwards = 0
         self.shard_windows = False  # True: shard interpolation windows over torch.distributed ranks (parallel.py)
+        self.device = "cuda"        # where the rollout state lives; "cpu" only together with dry_run (planner inspection / host tests)
+        self.dry_run = False        # True: plan every window (trace, noise draws in the reference's order) but launch nothing
         self.use_graph = False      # True: capture one DDIM step in a hipGraph and replay it (see _run_steps_graph)
         self.graph_replays = 0
         self.graph_captures = 0
@@ -224,17 +226,20 @@ class DFoTVideoPoseSampler:
         horizon = self.max_tokens
         padding = horizon - length
         f = int(np.prod(x_shape))
-        xs = self.noise_fn("init", (batch_size, horizon, *x_shape)).to(device="cuda", dtype=torch.float32)
+        dev = self.device
+        if dev != "cuda" and not self.dry_run:
+            raise RuntimeError("the sampler runs on the GPU; device='cpu' is only valid together with dry_run (no CPU fallback)")
+        xs = self.noise_fn("init", (batch_size, horizon, *x_shape)).to(device=dev, dtype=torch.float32)
         xs = xs.clamp(-cfg.diffusion.clip_noise, cfg.diffusion.clip_noise)
         if context is None:
             mask = np.zeros((batch_size, horizon), np.int64)
         else:
             mask = context_mask.detach().cpu().numpy().astype(np.int64)
-            ctx = context.to(device="cuda", dtype=torch.float32)
+            ctx = context.to(device=dev, dtype=torch.float32)
             if padding > 0:
                 ctx = torch.cat([ctx, ctx.new_zeros(batch_size, padding, *x_shape)], 1)
                 mask = np.concatenate([mask, -np.ones((batch_size, padding), np.int64)], 1)
-            keep = torch.from_numpy(mask >= 1).cuda().view(batch_size, horizon, 1, 1, 1)
+            keep = torch.from_numpy(mask >= 1).to(dev).view(batch_size, horizon, 1, 1, 1)
             xs = torch.where(keep, ctx, xs)
         if history_guidance is None:
             history_guidance = HistoryGuidance.conditional(timesteps=self.timesteps)
@@ -295,6 +300,47 @@ class DFoTVideoPoseSampler:
                               cmask=None if plan.cond_masked is None else np.tile(plan.cond_masked, batch_size)))
         if not plans:
             return (xs[:, :-padding] if padding > 0 else xs), None
+        strict = bool(getattr(self.noise_fn, "strict_order", False))
+
+        def draw_noise(p_):
+            """noise for re-noised history tokens; with a strict-order noise source (golden replay) every draw the
+            reference makes is consumed, used or not (history_guidance.py:505,530; discrete_diffusion.py:525)"""
+            nfe, bm, need = p_["nfe"], p_["bm"], p_["need_noise"]
+            noise = None
+            if history_guidance.is_simple:
+                if nfe == 2 and (need or strict):
+                    drawn = self.noise_fn("q_sample", (batch_size, horizon, *x_shape))
+                    noise = torch.zeros(batch_size, 2, horizon, *x_shape, device=dev, dtype=torch.float32)
+                    noise[:, 0] = drawn.to(device=dev, dtype=torch.float32)
+            else:
+                g = p_["plan"].n_gen
+                bh = bm // g  # the reference draws the history noise per (sample, history branch), before the gen-segment split
+                if need or strict:
+                    noise = self.noise_fn("q_sample", (bh, horizon, *x_shape)).to(device=dev, dtype=torch.float32)
+                    if g > 1:
+                        noise = noise.repeat_interleave(g, dim=0)
+                if strict or p_["excl"] is not None:
+                    fresh = self.noise_fn("excluded", (bh, g, horizon, *x_shape))
+                    if p_["excl"] is not None:  # torch.randn_like(x) for the excluded gen tokens (:529-533), not clamped
+                        fresh = fresh.to(device=dev, dtype=torch.float32).reshape(bm, horizon, *x_shape)
+                        em = torch.from_numpy(p_["excl"]).to(dev).view(bm, horizon, *([1] * len(x_shape)))
+                        noise = torch.where(em, fresh, noise if noise is not None else torch.zeros_like(fresh))
+            return None if noise is None else noise.contiguous().view(bm, horizon, *x_shape)
+
+        if self.dry_run:
+            # planner inspection: every host decision of the window has been taken (trace, per-step plans); consume the noise
+            # draws in the order the device path would and hand back the context-filled window -- nothing is launched
+            for p_ in plans:
+                if p_.get("renoise"):
+                    self.noise_fn("renoise", (batch_size, horizon, *x_shape))
+                    continue
+                draw_noise(p_)
+                if strict:
+                    self.noise_fn("ddim", (p_["bm"], horizon, *x_shape))
+                    if _refine is not None:
+                        self.noise_fn("refine_context", (batch_size, horizon, *x_shape))
+            self.window_forwards += sum(p_["bm"] for p_ in plans if not p_.get("renoise"))
+            return (xs[:, :-padding] if padding > 0 else xs), None
         flat_dev = torch.from_numpy(np.concatenate([p_["tables"].ravel() for p_ in plans])).cuda()
         gens_dev = torch.from_numpy(np.stack([p_["gen"] for p_ in plans])).cuda()
         off = 0
@@ -340,33 +386,6 @@ class DFoTVideoPoseSampler:
                 self._interpolate_masked_poses = False
         xs = xs.contiguous()
         s = capi.stream_ptr
-        strict = bool(getattr(self.noise_fn, "strict_order", False))
-
-        def draw_noise(p_):
-            """noise for re-noised history tokens; with a strict-order noise source (golden replay) every draw the
-            reference makes is consumed, used or not (history_guidance.py:505,530; discrete_diffusion.py:525)"""
-            nfe, bm, need = p_["nfe"], p_["bm"], p_["need_noise"]
-            noise = None
-            if history_guidance.is_simple:
-                if nfe == 2 and (need or strict):
-                    drawn = self.noise_fn("q_sample", (batch_size, horizon, *x_shape))
-                    noise = torch.zeros(batch_size, 2, horizon, *x_shape, device="cuda", dtype=torch.float32)
-                    noise[:, 0] = drawn.to(device="cuda", dtype=torch.float32)
-            else:
-                g = p_["plan"].n_gen
-                bh = bm // g  # the reference draws the history noise per (sample, history branch), before the gen-segment split
-                if need or strict:
-                    noise = self.noise_fn("q_sample", (bh, horizon, *x_shape)).to(device="cuda", dtype=torch.float32)
-                    if g > 1:
-                        noise = noise.repeat_interleave(g, dim=0)
-                if strict or p_["excl"] is not None:
-                    fresh = self.noise_fn("excluded", (bh, g, horizon, *x_shape))
-                    if p_["excl"] is not None:  # torch.randn_like(x) for the excluded gen tokens (:529-533), not clamped
-                        fresh = fresh.to(device="cuda", dtype=torch.float32).reshape(bm, horizon, *x_shape)
-                        em = torch.from_numpy(p_["excl"]).cuda().view(bm, horizon, *([1] * len(x_shape)))
-                        noise = torch.where(em, fresh, noise if noise is not None else torch.zeros_like(fresh))
-            return None if noise is None else noise.contiguous().view(bm, horizon, *x_shape)
-
         def step(p_, xs, noise, tables, gen_dev, xs_next=None):
             nonlocal cond_rep, cond_nfe
             nfe, bm = p_["nfe"], p_["bm"]
@@ -520,8 +539,9 @@ class DFoTVideoPoseSampler:
             raise ValueError("sliding_context_len is expected to be >= length of initial context,"
                              f"got {sliding_context_len}. If you are trying to use max context, "
                              "consider specifying sliding_context_len=-1.")
-        xs = context.to(device="cuda", dtype=torch.float32)
+        xs = context.to(device=self.device, dtype=torch.float32)
         cur = gt_len
+        n_window = 0
         while cur < length:
             c = min(sliding_context_len, cur)
             h = min(length - cur, mt - c)
@@ -532,6 +552,11 @@ class DFoTVideoPoseSampler:
                 cmask[:, -generated:] = 2
             cmask = torch.cat([cmask, torch.zeros(batch_size, h, dtype=torch.long)], 1)
             cond = None if conditions is None else conditions[:, cur - c: cur - c + mt]
+            if hasattr(self.noise_fn, "set_windows"):
+                # key-frame windows are replicated on every rank: key their noise by the sliding-window index (rank-independent),
+                # never by whatever the previous interpolation batch of this rank left behind
+                self.noise_fn.set_windows([n_window])
+            n_window += 1
             new, _ = self._window_sampler()(batch_size, length=c + h, context=window, context_mask=cmask,
                                            conditions=cond, history_guidance=history_guidance)
             xs = torch.cat([xs, new[:, -h:]], 1)
@@ -579,7 +604,7 @@ class DFoTVideoPoseSampler:
             context_mask = context_mask.detach().cpu().bool()
             assert bool(context_mask[:, [0, -1]].all()), "The first and last frames must be known to interpolate."
         hg = HistoryGuidance.from_config(cfg.interpolation_guidance, timesteps=self.timesteps)
-        xs = context.to(device="cuda", dtype=torch.float32).clone()
+        xs = context.to(device=self.device, dtype=torch.float32).clone()
         known = context_mask.clone()
         for si, stage in enumerate(self._interpolation_plan(context_mask[0].numpy())):
             ctx = torch.cat([self._pad_to_max_tokens(xs[:, w]) for w in stage], 0)
@@ -611,7 +636,7 @@ class DFoTVideoPoseSampler:
     def _predict_videos(self, xs: torch.Tensor, n_context_tokens: int,
                         conditions: Optional[torch.Tensor] = None) -> torch.Tensor:
         cfg = self.cfg
-        out = xs.to(device="cuda", dtype=torch.float32).clone()
+        out = xs.to(device=self.device, dtype=torch.float32).clone()
         hg = HistoryGuidance.from_config(cfg.prediction_guidance, timesteps=self.timesteps)
         density = cfg.keyframe_density or 1
         if density > 1:
@@ -622,7 +647,7 @@ class DFoTVideoPoseSampler:
         kc = None if conditions is None else conditions[:, keys]
         pred, _ = self._predict_sequence(out[:, :n_context_tokens], length=len(keys), conditions=kc, history_guidance=hg,
                                          sliding_context_len=cfg.sliding_context_len or self.max_tokens // 2)
-        out[:, keys.cuda()] = pred
+        out[:, keys.to(self.device)] = pred
         if len(keys) < n:
             known = torch.zeros(out.shape[0], n, dtype=torch.bool)
             known[:, keys] = True

@@ -59,11 +59,12 @@ def psnr(a, b):
     return 10 * math.log10(peak * peak / max(mse, 1e-20))
 
 
-def run_pair(pred_hg, n_frames, steps, density=None, interp_hg=None, max_batch=None, seed=5, scheduling="full_sequence"):
+def run_pair(pred_hg, n_frames, steps, density=None, interp_hg=None, max_batch=None, seed=5, scheduling="full_sequence",
+             blocks=(1, 1, 2), mid=3):
     import dfot_amd
     from oracle import pose as opose, sampler as osm, schedule as sch, uvit as ouvit
     res = 64
-    ocfg, params, model = build()
+    ocfg, params, model = build(blocks=blocks, mid=mid)
     g = torch.Generator().manual_seed(seed)
     xs = torch.randn(1, n_frames, 3, res, res, generator=g)
     cnd = poses(1, n_frames, seed)
@@ -108,6 +109,22 @@ def test_sliding_window_stabilized_and_interpolation():
     p = psnr(out, ref)
     print(f"24f stabilized + interpolation: PSNR {p:.1f} dB")
     assert torch.isfinite(out).all() and p >= 35.0
+
+
+def test_200_frame_rollout_plan_on_the_hip_path():
+    """BASELINE config 3 on the HIP path: 200 frames, keyframe_density 0.0625 (12 key frames: two sequential sliding windows under
+    stabilized History Guidance), then the two interpolation stages -- 11 Case-1 windows (8 frames spread by linspace between
+    two key frames, mask [1,0x6,1]) and 35 chunk windows with per-sample masks -- in batches of 4 under vanilla(1.5); 64x64 frames,
+    reduced depth, 2 DDIM steps so the fp32 oracle finishes in a minute.  Same 14 sampler calls, masks and noise draws as the
+    oracle (which reproduces the reference's recorded run, tests/test_oracle_golden.py), result PSNR >= 35 dB."""
+    out, ref, xs = run_pair(dict(name="stabilized_vanilla", guidance_scale=4.0, stabilization_level=0.02), 200, 2,
+                            density=0.0625, interp_hg=dict(name="vanilla", guidance_scale=1.5), max_batch=4,
+                            blocks=(1, 1, 1), mid=1)
+    assert torch.equal(out[:, :1], xs[:, :1].float())
+    p = psnr(out, ref)
+    worst = min(psnr(out[:, i], ref[:, i]) for i in range(1, 200))
+    print(f"200f stabilized key frames + 11/35 interpolation windows: PSNR {p:.1f} dB (worst frame {worst:.1f} dB)")
+    assert torch.isfinite(out).all() and p >= 35.0 and worst >= 30.0
 
 
 def test_sampler_contract_errors():

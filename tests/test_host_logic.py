@@ -215,3 +215,126 @@ def test_refine_scheduling_matrix_matches_reference():
     g = np.load(os.path.join(GOLDEN, "schedule_extra.npz"))
     s = Schedule(DiffusionConfig(sampling_timesteps=50))
     assert np.array_equal(s.refine_scheduling_matrix(5, goback_length=20, n_goback=2, padding=3), g["refine50_5_3"])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# BASELINE config 3: the PRODUCT planner (sliding key-frame windows + interpolation stages + batching) against the plan
+# recorded from the reference's own `_predict_videos` run (dfot_video.py:114-179,181-360,362-514)
+# ---------------------------------------------------------------------------------------------------------------------
+class _RecordingNoise:
+    """strict-order noise source: the sampler consumes every draw the reference makes; shapes are logged like the fixture"""
+    strict_order = True
+
+    def __init__(self):
+        self.shapes = []
+
+    def __call__(self, tag, shape):
+        import torch
+        self.shapes.append(list(shape) + [0] * (6 - len(shape)))
+        return torch.zeros(shape)
+
+
+def _dry_sampler(noise_fn, **kw):
+    import dfot_amd
+    cfg = dfot_amd.SamplerConfig(
+        x_shape=(3, 16, 16), diffusion=DiffusionConfig(sampling_timesteps=2), keyframe_density=0.0625,
+        prediction_guidance=dict(name="stabilized_vanilla", guidance_scale=4.0, stabilization_level=0.02),
+        interpolation_guidance=dict(name="vanilla", guidance_scale=1.5), interpolation_max_batch_size=4, **kw)
+    s = dfot_amd.DFoTVideoPoseSampler(cfg, backbone=None, noise_fn=noise_fn)
+    s.device, s.dry_run = "cpu", True   # plan everything, launch nothing
+    return s
+
+
+def test_product_planner_200_frames_equals_reference_plan():
+    import torch
+    g = load("sampler_200f.npz")
+    rec = _RecordingNoise()
+    s = _dry_sampler(rec)
+    out = s._predict_videos(torch.from_numpy(g["xs"]), 1, torch.from_numpy(g["conds"]))
+    assert out.shape == g["out"].shape
+    # 14 sampler calls: 2 sequential key-frame windows, then 11 windows (3 batches) and 35 windows (9 batches)
+    assert [t["batch"] for t in s.trace] == g["call_batches"].tolist()
+    masks = np.concatenate([t["context_mask"] for t in s.trace], 0)
+    assert np.array_equal(masks, g["call_masks"])
+    # every noise draw of the reference run, in order, with its shape
+    assert np.array_equal(np.array(rec.shapes), g["draw_shapes"])
+    # window-forwards: 48 windows x NFE 2 x 2 DDIM steps (SURVEY.md 8d: 96 per step)
+    assert s.window_forwards == 96 * 2
+
+
+def test_interpolation_plan_windows_for_200_frames():
+    """window index sets of the two plan stages: stage 1 = Case-1 windows (8 frames spread by linspace between two key frames,
+    mask [1,0x6,1]), stage 2 = chunk windows over the remaining gaps (dfot_video.py:219-261)"""
+    import torch
+    s = _dry_sampler(_RecordingNoise())
+    n = 200
+    keys = torch.linspace(0, n - 1, round(0.0625 * n)).round().long()
+    known = np.zeros(n, bool)
+    known[keys.numpy()] = True
+    plan = s._interpolation_plan(known)
+    assert [len(st) for st in plan] == [11, 35]
+    for w, (l, r) in zip(plan[0], zip(keys[:-1].tolist(), keys[1:].tolist())):
+        assert np.array_equal(w, torch.linspace(l, r, 8).round().long().numpy())
+    covered = known.copy()
+    for st in plan:
+        for w in st:
+            assert len(w) <= 8 and np.all(np.diff(w) > 0)
+            covered[w] = True
+    assert covered.all()
+
+
+def test_keyframe_noise_keys_do_not_depend_on_the_previous_batch_or_rank(monkeypatch):
+    """with WindowKeyedNoise the replicated key-frame windows must draw the same noise on every rank and on every
+    call of one sampler (their key is the sliding-window index, not what the last interpolation batch left behind)."""
+    import torch
+    from dfot_amd import parallel
+    g = load("sampler_200f.npz")
+    xs, conds = torch.from_numpy(g["xs"]), torch.from_numpy(g["conds"])
+
+    def run(world, rank):
+        log = []
+
+        class Logged(parallel.WindowKeyedNoise):
+            def __call__(self, tag, shape):
+                t = super().__call__(tag, shape)
+                if max(self.keys) < 100000:  # key-frame windows
+                    log.append((self.keys, tag, tuple(shape), float(t.double().sum())))
+                return t
+
+        s = _dry_sampler(Logged(7, device="cpu"))
+        s.shard_windows = world > 1
+        monkeypatch.setattr(parallel, "world_info", lambda group=None: (world, rank))
+        monkeypatch.setattr(parallel, "gather_windows",
+                            lambda local, n, group=None: local.new_zeros((n, *local.shape[1:])))
+        s._predict_videos(xs, 1, conds)
+        first = list(log)
+        del log[:]
+        s._predict_videos(xs, 1, conds)   # second call on the SAME sampler (what bench.py --workload 200f does)
+        return first, list(log)
+
+    single = run(1, 0)
+    r0, r1 = run(2, 0), run(2, 1)
+    assert len(single[0]) > 0
+    for call in (0, 1):
+        assert r0[call] == r1[call] == single[call]
+    # a draw whose rows cannot be split over the current keys is an error, not a silent re-use of stale keys
+    nz = parallel.WindowKeyedNoise(1, device="cpu")
+    nz.set_windows([1, 2, 3])
+    with pytest.raises(ValueError):
+        nz("init", (4, 8, 3, 4, 4))
+
+
+def test_host_tensors_are_refused_before_any_launch():
+    """the Python boundary never hands a host pointer (or a strided view / wrong dtype) to a kernel"""
+    import torch
+    from dfot_amd import capi
+    with pytest.raises(ValueError, match="GPU memory only"):
+        capi.ptr(torch.zeros(4), name="x")
+    assert capi.ptr(None).value in (None, 0)
+    with pytest.raises(ValueError, match="noise_levels is on cpu"):
+        capi.require_device(torch.device("cuda", 0), noise_levels=torch.zeros(2, 8))
+    x = torch.zeros(2, 8, 3, 4, 4)
+    with pytest.raises(ValueError):
+        torch.ops.dfot.hg_prepare(x, None, torch.zeros(4, 8), torch.zeros(4, 8), 2)
+    with pytest.raises(ValueError):   # wrong table shape is caught before the device check
+        torch.ops.dfot.hg_prepare(x, None, torch.zeros(2, 8), torch.zeros(4, 8), 2)
