@@ -15,6 +15,7 @@
 // Scores are in the exp2 domain: the caller folds log2(e)/sqrt(d) into q.
 #include "common.h"
 #include "dfot_hip.h"
+#include "kernels.h"
 
 namespace dfot {
 
@@ -443,6 +444,11 @@ int launch_attention(const bf16* q, const bf16* k, const bf16* v, bf16* o, long 
   DFOT_REQUIRE(d == 64 || d == 128, DFOT_ERR_SHAPE, "attention: head dim %d not in {64,128}", d);
   DFOT_REQUIRE(n > 0 && n % 128 == 0, DFOT_ERR_SHAPE, "attention: N=%d must be a multiple of 128", n);
   DFOT_REQUIRE(ldo % 4 == 0, DFOT_ERR_SHAPE, "attention: output row stride %ld must be a multiple of 4", ldo);
+  if ((variant == 5 || variant == 6) && d == 64 && n % 256 == 0)  // 64 query rows per wave, balanced tail; 6: no running max
+    return launch_attention_v3(q, k, v, o, ldo, batch, heads, n, variant == 6, stream);
+  if (variant >= 7 && variant <= 12 && d == 64 && n % 512 == 0)  // 8-wave ping-pong, no running max; odd: priority raised in MFMA phases
+    return launch_attention_pp(q, k, v, o, ldo, batch, heads, n, (variant & 1) | (((variant - 7) >> 1) << 1), stream);
+  if (variant >= 5 && variant <= 12) variant = 2;
   if (variant == 2) {  // tuned kernel; K/V ring depth chosen by measurement: 3 stages (48 KiB) at d = 64, 2 stages at d = 128
     return d == 64 ? launch_attn_v2<64, 3>(q, k, v, o, ldo, batch, heads, n, stream)
                    : launch_attn_v2<128, 2>(q, k, v, o, ldo, batch, heads, n, stream);

@@ -76,6 +76,21 @@ int launch_bf16_nhwc_to_nchw(const bf16* src, float* dst, int bt, int p, int c, 
 
 int launch_attention(const bf16* q, const bf16* k, const bf16* v, bf16* o, long ldo, int batch, int heads, int n, int d,
                      int variant, hipStream_t stream);
+// attention_v3.hip: d = 64, 64 query rows per wave, balanced tail (key-split left-over tiles + merge); nomax = caller bounds |score|
+int launch_attention_v3(const bf16* q, const bf16* k, const bf16* v, bf16* o, long ldo, int batch, int heads, int n, bool nomax,
+                        hipStream_t stream);
+int attention_v3_reserve(int batch, int heads, int n);
+// attention_pp.hip: the same products as an 8-wave ping-pong (SIMD partners alternate MFMA and softmax phases); no running max
+int launch_attention_pp(const bf16* q, const bf16* k, const bf16* v, bf16* o, long ldo, int batch, int heads, int n, int flags,
+                        hipStream_t stream);
+// shared by the two: balanced tail (left-over query tiles split over the key axis) + merge of the fp32 partials
+struct AttnSplit {
+  int tiles, full, rem, nsplit;
+};
+AttnSplit attn_plan_split(int batch, int heads, int n, int qrows, int wgs_per_cu);
+int attn_partials(const AttnSplit& sp, int qrows, float** po, float** pml);
+int attn_launch_merge(const AttnSplit& sp, int qrows, const float* po, const float* pml, bf16* o, long ldo, int n, int heads,
+                      hipStream_t stream);
 int attention_dstride(int d);
 // lse (optional, training): [B][heads][N] fp32, log2-domain log-sum-exp of every query row
 int launch_attention_padded(const bf16* q, const bf16* k, const bf16* v, bf16* o, long ldo, int batch, int heads, int n, int d,

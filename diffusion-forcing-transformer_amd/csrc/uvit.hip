@@ -53,6 +53,9 @@ struct TrW {
   bf16 *w_film = nullptr, *w_fused = nullptr, *w_out = nullptr;
   float *b_film_raw = nullptr, *b_film = nullptr, *nw = nullptr, *b_fused = nullptr, *qw = nullptr, *kw = nullptr,
         *b_attn = nullptr, *b_mlp = nullptr, *b_out = nullptr;
+  // bound of |q.k| * log2(e)/sqrt(d) after the per-head RMSNorm of q and k (u_vit_blocks.py:257-259): sqrt(d) * max|w_q| * max|w_k|
+  // * log2(e); set at finalize.  Small enough => softmax needs no running max (attention_v3.hip, NOMAX)
+  float score_bound = INFINITY;
 };
 struct ConvW {
   int cin = 0, cout = 0;
@@ -402,7 +405,11 @@ static int run_tr_block(dfot_uvit_s* h, const TrW& w, int lvl, int batch, hipStr
   if ((rc = launch_gemm(A_DENSE, E_QKV, h->gemm_variant, p, s))) return rc;
   const bool timed = h->time_attn && lvl == 2 && h->ev_used < h->ev_start.size();
   if (timed) DFOT_CHECK_HIP(hipEventRecord(h->ev_start[h->ev_used], s));
-  if ((rc = launch_attention(h->q, h->k, h->v, h->cat, 5 * c, batch, h->heads, n, d, h->attn_variant, s))) return rc;
+  // default (2): level 2 (d = 64) runs the 64-rows-per-wave kernel with the balanced tail; without a running max when the
+  // QK-norm weights bound the scores far inside the fp32 / bf16 exponent range (2^64 * N keys << 2^127), else with it
+  int av = h->attn_variant;
+  if (av == 2 && d == 64 && n % 256 == 0) av = w.score_bound < 64.0f ? 6 : 5;
+  if ((rc = launch_attention(h->q, h->k, h->v, h->cat, 5 * c, batch, h->heads, n, d, av, s))) return rc;
   if (timed) DFOT_CHECK_HIP(hipEventRecord(h->ev_stop[h->ev_used++], s));
   GemmArgs o;
   o.A = h->cat; o.lda = 5 * c; o.W = w.w_out; o.M = m; o.N = c; o.K = 5 * c; o.bias = w.b_out; o.out_f32 = x; o.resid = x;
@@ -530,6 +537,21 @@ int dfot_uvit_finalize(dfot_uvit_t h, void* stream) {
   for (int l = 2; l < 4; ++l)
     if (!h->rope_cs[l] && (rc = build_rope(h, l))) return rc;
   DFOT_CHECK_HIP(hipStreamSynchronize(s));
+  auto bound = [&](std::vector<TrW>& v) -> int {
+    std::vector<float> qk;
+    for (TrW& w : v) {
+      const int d = w.c / h->heads;
+      qk.resize(2 * d);
+      DFOT_CHECK_HIP(hipMemcpy(qk.data(), w.qw, d * sizeof(float), hipMemcpyDeviceToHost));
+      DFOT_CHECK_HIP(hipMemcpy(qk.data() + d, w.kw, d * sizeof(float), hipMemcpyDeviceToHost));
+      float mq = 0.f, mk = 0.f;
+      for (int i = 0; i < d; ++i) mq = fmaxf(mq, fabsf(qk[i])), mk = fmaxf(mk, fabsf(qk[d + i]));
+      w.score_bound = sqrtf((float)d) * mq * mk * 1.4426950408889634f;
+      if (!(w.score_bound == w.score_bound)) w.score_bound = INFINITY;  // NaN weights: keep the general kernel
+    }
+    return DFOT_OK;
+  };
+  if ((rc = bound(h->down_tr)) || (rc = bound(h->mid_tr)) || (rc = bound(h->up_tr))) return rc;
   h->finalized = true;
   return DFOT_OK;
 }
@@ -600,6 +622,10 @@ int dfot_uvit_reserve(dfot_uvit_t h, int max_batch) {
   if ((rc = dev_alloc(h, &h->q, mc, true))) return rc;
   if ((rc = dev_alloc(h, &h->k, mc, true))) return rc;
   if ((rc = dev_alloc(h, &h->v, mc, true))) return rc;
+  // key-split partial buffers of the level-2 attention's balanced tail, for every batch this workspace can serve (so that
+  // nothing is allocated inside forward / stream capture)
+  for (int b = 1; b <= max_batch; ++b)
+    if ((rc = attention_v3_reserve(b, h->heads, h->T * h->r[2] * h->r[2]))) return rc;
   h->max_batch = max_batch;
   return DFOT_OK;
 }
