@@ -95,6 +95,7 @@ SIGNATURES = {
     "dfot_hg_prepare": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _L, _P]),
     "dfot_ddim_compose": (_I, [_P] * 11 + [_I, _I, _I, _L, _P]),
     "dfot_ddim_compose_tokw": (_I, [_P] * 11 + [_I, _I, _I, _L, _P]),
+    "dfot_ddim_noise": (_I, [_P] * 5 + [_I, _I, _I, _L, _I, _P]),
     "dfot_vpred_loss": (_I, [_P] * 9 + [_I, _I, _L, _P]),
     "dfot_vpred_loss_scratch_floats": (_L, [_I, _I, _L]),
     "dfot_vspace_loss": (_I, [_P] * 9 + [_I, _I, _L, _P]),

@@ -48,6 +48,8 @@ int launch_hg_prepare(const float* x, const float* noise, const float* qa, const
 int launch_ddim_compose(const float* x, const float* x_in, const float* v, const float* sa, const float* s1,
                         const float* an, const float* cn, const float* keep, const float* weight, const uint8_t* gen,
                         float* x_next, int batch, int nfe, int tokens, long f, bool weight_per_token, hipStream_t s);
+int launch_ddim_noise(const float* noise, const float* sigma, const float* weight, const uint8_t* gen, float* x_next, int batch, int nfe,
+                      int tokens, long f, bool weight_per_token, hipStream_t s);
 // v-prediction loss: partial = scratch [bt][vloss_chunks(f)], loss[bt] = mean over the frame of w*(eps_hat-eps)^2
 int vloss_chunks(long f);
 int launch_vloss(const float* x, const float* noise, const float* v, const float* a, const float* sg, const float* w,

@@ -762,6 +762,40 @@ int launch_ddim_compose(const float* x, const float* x_in, const float* v, const
   return DFOT_OK;
 }
 
+// stochastic part of a sampling step (ddim_sample_step with eta > 0, discrete_diffusion.py:515-538; ddpm_sample_step, :441-449):
+// every branch adds sigma * noise to its prediction BEFORE composition, and composition is linear, so
+//   x_next[b,t] += sum_h w_h * sigma[b*nfe+h, t] * noise[b*nfe+h, t]   on generated tokens
+// (sigma = 0 rows -- kept tokens, level 0, next level < 0 -- are set by the host).  noise is already clamped.
+__global__ void ddim_noise_kernel(const float* __restrict__ noise, const float* __restrict__ sigma, const float* __restrict__ weight,
+                                  const uint8_t* __restrict__ gen, float* __restrict__ x_next, long total4, int nfe, int tokens,
+                                  long f4, int wstride) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total4) return;
+  const unsigned iu = (unsigned)idx, fu = (unsigned)f4;
+  const long e = iu % fu;
+  const long bt = iu / fu;
+  if (!gen[bt]) return;
+  const int tk = (int)((unsigned)bt % (unsigned)tokens);
+  const long b = (unsigned)bt / (unsigned)tokens;
+  float4v o = *reinterpret_cast<const float4v*>(x_next + idx * 4);
+  for (int h = 0; h < nfe; ++h) {
+    const long row = (b * nfe + h) * tokens + tk;
+    const float c = sigma[row] * weight[wstride ? h * wstride + tk : h];
+    if (c != 0.f) o += *reinterpret_cast<const float4v*>(noise + (row * f4 + e) * 4) * c;
+  }
+  *reinterpret_cast<float4v*>(x_next + idx * 4) = o;
+}
+int launch_ddim_noise(const float* noise, const float* sigma, const float* weight, const uint8_t* gen, float* x_next, int batch, int nfe,
+                      int tokens, long f, bool weight_per_token, hipStream_t s) {
+  DFOT_REQUIRE(f % 4 == 0, DFOT_ERR_SHAPE, "ddim_noise: frame elements %ld must be a multiple of 4", f);
+  const long total4 = (long)batch * tokens * (f / 4);
+  DFOT_REQUIRE(total4 < (1L << 31), DFOT_ERR_SHAPE, "ddim_noise: %ld work items exceed the 32-bit index range", total4);
+  hipLaunchKernelGGL(ddim_noise_kernel, dim3(cdiv(total4, 256)), dim3(256), 0, s, noise, sigma, weight, gen, x_next, total4, nfe, tokens,
+                     f / 4, weight_per_token ? tokens : 0);
+  DFOT_CHECK_HIP(hipGetLastError());
+  return DFOT_OK;
+}
+
 // --------------------------------------------------------------------------------------------
 // continuous-time v-prediction loss of one noised forward (ContinuousDiffusion.forward, continuous_diffusion.py:140-167;
 // used by training_step and by the validation denoising loss): x_t = a x + s eps ; eps_hat = a v + s x_t ;

@@ -812,6 +812,12 @@ int dfot_ddim_compose_tokw(const float* x, const float* x_in, const float* v, co
                              (hipStream_t)stream);
 }
 
+int dfot_ddim_noise(const float* noise, const float* sigma, const float* weight, const uint8_t* gen, float* x_next, int batch, int nfe,
+                    int tokens, int64_t frame_elems, int weight_per_token, void* stream) {
+  DFOT_REQUIRE(noise && sigma && weight && gen && x_next, DFOT_ERR_ARG, "ddim_noise: null argument");
+  return launch_ddim_noise(noise, sigma, weight, gen, x_next, batch, nfe, tokens, (long)frame_elems, weight_per_token != 0, (hipStream_t)stream);
+}
+
 int dfot_vpred_loss(const float* x, const float* noise, const float* v, const float* alpha, const float* sigma,
                     const float* weight, float* x_pred, float* scratch, float* loss, int batch, int tokens, int64_t frame_elems,
                     void* stream) {

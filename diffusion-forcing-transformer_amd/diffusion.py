@@ -6,6 +6,7 @@ Mirrors (host logic only; the arithmetic on frames runs in libdfot_hip.so):
   * ddim_idx_to_noise_level                         discrete_diffusion.py:379-384
   * ContinuousDiffusion.model_predictions (level -> 0.125*logsnr[k])   continuous_diffusion.py:118-121
   * ddim_sample_step coefficient algebra            discrete_diffusion.py:454-483,527-536
+  * posterior q(x_{k-1}|x_k,x_0) tables, ddpm_sample_step   discrete_diffusion.py:137-158,423-452
   * q_sample coefficients                           discrete_diffusion.py:242-250
   * _generate_scheduling_matrix                     algorithms/common/base_pytorch_video_algo.py:877-913
 Everything here is numpy on the host, evaluated once per sampling call; the device kernels
@@ -68,6 +69,16 @@ class Schedule:
         self.snr = (abar / (1.0 - abar)).astype(np.float32)  # float64 quotient, like the reference's buffer
         with np.errstate(divide="ignore"):  # the plain cosine schedule ends at abar = 0 (zero terminal SNR)
             self.logsnr = np.log(abar / (1.0 - abar)).astype(np.float32)
+        # posterior q(x_{k-1} | x_k, x_0): DDPM sampling (sampling_timesteps == timesteps)
+        abar_prev = np.concatenate([[1.0], abar[:-1]])
+        post_var = betas * (1.0 - abar_prev) / (1.0 - abar)
+        self.posterior_mean_coef1 = (betas * np.sqrt(abar_prev) / (1.0 - abar)).astype(np.float32)
+        self.posterior_mean_coef2 = ((1.0 - abar_prev) * np.sqrt(1.0 - betas) / (1.0 - abar)).astype(np.float32)
+        self.posterior_log_variance_clipped = np.log(np.maximum(post_var, 1e-20)).astype(np.float32)
+
+    @property
+    def is_ddim_sampling(self) -> bool:  # discrete_diffusion.py:108
+        return self.cfg.sampling_timesteps < self.cfg.timesteps
 
     # ---- index tables ---------------------------------------------------------------------
     def ddim_idx_to_noise_level(self, indices: np.ndarray) -> np.ndarray:
@@ -149,6 +160,17 @@ class Schedule:
         return (self.sqrt_alphas_cumprod[kc], self.sqrt_one_minus_alphas_cumprod[kc], np.sqrt(alpha_next).astype(f32),
                 cn, (curr == nxt).astype(f32), sigma)
 
+
+    def ddpm_coef(self, curr: np.ndarray):
+        """ddpm_sample_step in the ddim_coef form: with x0 = sa*x - s1*v and eps = sa*v + s1*x one has x = sa*x0 + s1*eps, so the
+        posterior mean coef1*x0 + coef2*x = (coef1 + coef2*sa)*x0 + (coef2*s1)*eps.  keep = tokens at level -1 (clean);
+        sigma = sqrt(posterior variance), 0 at level 0 (no noise there)."""
+        f32 = np.float32
+        kc = np.clip(curr, 0, None)
+        sa, s1 = self.sqrt_alphas_cumprod[kc], self.sqrt_one_minus_alphas_cumprod[kc]
+        c1, c2 = self.posterior_mean_coef1[kc], self.posterior_mean_coef2[kc]
+        sigma = np.where(kc > 0, np.exp(f32(0.5) * self.posterior_log_variance_clipped[kc]), f32(0)).astype(f32)
+        return sa, s1, (c1 + c2 * sa).astype(f32), (c2 * s1).astype(f32), (curr == -1).astype(f32), sigma
 
     # ---- training-loss weights of DiscreteDiffusion (compute_loss_weights, discrete_diffusion.py:274-343), objective pred_v ----
     def loss_weights(self, k: np.ndarray, strategy: str = "fused_min_snr", snr_clip: float = 5.0, cum_snr_decay: float = 0.9,

@@ -78,8 +78,8 @@ class DFoTVideoPoseSampler:
         self.graph_captures = 0
         self._graphs: Dict[tuple, dict] = {}
         self._graphs_generation = 0
-        if cfg.diffusion.ddim_sampling_eta != 0:
-            raise NotImplementedError("only deterministic DDIM (eta = 0) is implemented on the device path")
+        if cfg.diffusion.sampling_timesteps > cfg.diffusion.timesteps:
+            raise ValueError("sampling_timesteps must be <= timesteps")
 
     # ------------------------------------------------------------------ conditions
     @torch.no_grad()
@@ -293,9 +293,13 @@ class DFoTVideoPoseSampler:
             if plan.excluded is not None:  # gen tokens outside the branch's gen segment: x_in = fresh (unclamped) noise
                 excl = plan.excluded.reshape(bm, horizon)
                 qa, qb = np.where(excl, np.float32(0), qa), np.where(excl, np.float32(1), qb)
-            sa, s1, an, cn, keepf, _sigma = sch.ddim_coef(lv, tl)
+            # deterministic DDIM (eta = 0, the BASELINE configs), stochastic DDIM (eta > 0) or DDPM (sampling_timesteps == timesteps):
+            # the same fused step with other coefficients; the stochastic ones add sigma * noise per branch (dfot_ddim_noise)
+            sa, s1, an, cn, keepf, sigma = sch.ddim_coef(lv, tl) if sch.is_ddim_sampling else sch.ddpm_coef(lv)
+            sigma = np.where(keepf != 0, np.float32(0), sigma).astype(np.float32)
             tables = np.stack([qa, qb, sa, s1, an, cn, keepf, sch.model_level(lv)]).astype(np.float32)
             plans.append(dict(plan=plan, nfe=plan.nfe, bm=bm, need_noise=bool(repl.any()) or excl is not None, excl=excl, tables=tables,
+                              sigma=sigma if bool((sigma != 0).any()) else None,
                               gen=(mask == 0).astype(np.uint8),
                               cmask=None if plan.cond_masked is None else np.tile(plan.cond_masked, batch_size)))
         if not plans:
@@ -335,7 +339,7 @@ class DFoTVideoPoseSampler:
                     self.noise_fn("renoise", (batch_size, horizon, *x_shape))
                     continue
                 draw_noise(p_)
-                if strict:
+                if strict or p_["sigma"] is not None:
                     self.noise_fn("ddim", (p_["bm"], horizon, *x_shape))
                     if _refine is not None:
                         self.noise_fn("refine_context", (batch_size, horizon, *x_shape))
@@ -359,6 +363,7 @@ class DFoTVideoPoseSampler:
                 weight_cache[wkey] = torch.from_numpy(np.ascontiguousarray(wsrc, dtype=np.float32)).cuda()
             p_["weights_dev"] = weight_cache[wkey]
             p_["tokw"] = p_["plan"].tok_weights is not None
+            p_["sigma_dev"] = None if p_["sigma"] is None else torch.from_numpy(p_["sigma"]).cuda()
             p_["cmask_dev"] = None
             if p_["cmask"] is not None:
                 # one device tensor per distinct mask pattern: the backbone keys its per-window pose caches on the
@@ -400,8 +405,9 @@ class DFoTVideoPoseSampler:
             # discrete diffusion hands the backbone integer level indices (exact in the float32 table)
             lvl = tables[7] if cfg.diffusion.is_continuous else tables[7].to(torch.int32)
             v = self.model(x_in, lvl, cond_rep, p_["cmask_dev"])
-            if strict:
-                self.noise_fn("ddim", (bm, horizon, *x_shape))  # multiplied by sigma = 0 in the reference
+            step_noise = None
+            if strict or p_["sigma"] is not None:  # the reference draws it every step; with sigma = 0 it is multiplied by 0
+                step_noise = self.noise_fn("ddim", (bm, horizon, *x_shape))
             if xs_next is None:
                 xs_next = torch.empty_like(xs)
             compose = capi.lib.dfot_ddim_compose_tokw if p_["tokw"] else capi.lib.dfot_ddim_compose
@@ -409,6 +415,10 @@ class DFoTVideoPoseSampler:
                                                   capi.ptr(tables[3]), capi.ptr(tables[4]), capi.ptr(tables[5]),
                                                   capi.ptr(tables[6]), capi.ptr(p_["weights_dev"]), capi.ptr(gen_dev),
                                                   capi.ptr(xs_next), batch_size, nfe, horizon, f, s()))
+            if p_["sigma"] is not None:
+                nz = step_noise.to(device="cuda", dtype=torch.float32).clamp(-cfg.diffusion.clip_noise, cfg.diffusion.clip_noise).contiguous()
+                capi.check(capi.lib.dfot_ddim_noise(capi.ptr(nz), capi.ptr(p_["sigma_dev"]), capi.ptr(p_["weights_dev"]), capi.ptr(gen_dev),
+                                                    capi.ptr(xs_next), batch_size, nfe, horizon, f, int(p_["tokw"]), s()))
             return xs_next
 
         def renoise(p_, xs):
@@ -431,7 +441,7 @@ class DFoTVideoPoseSampler:
             return (xs[:, :-padding] if padding > 0 else xs), None
         uniform = all(p_["bm"] == plans[0]["bm"] and p_["cmask_dev"] is plans[0]["cmask_dev"]
                       and p_["weights_dev"] is plans[0]["weights_dev"] for p_ in plans)
-        if self.use_graph and uniform and not strict and len(plans) > 2:
+        if self.use_graph and uniform and not strict and len(plans) > 2 and all(p_["sigma"] is None for p_ in plans):
             xs = self._run_steps_graph(plans, xs, draw_noise, step, flat_dev, gens_dev, horizon)
         else:
             for p_ in plans:

@@ -228,6 +228,14 @@ int dfot_ddim_compose_tokw(const float* x, const float* x_in, const float* v, co
                            const float* an, const float* cn, const float* keep, const float* weight, const uint8_t* gen,
                            float* x_next, int batch, int nfe, int tokens, int64_t frame_elems, void* stream);
 
+/* stochastic part of a sampling step -- the `sigma * noise` term of ddim_sample_step for eta > 0
+ * (algorithms/dfot/diffusion/discrete_diffusion.py:468-472,515-527) and the posterior-variance term of ddpm_sample_step
+ * (:441-449; the DDPM mean is the dfot_ddim_compose form with an = coef1 + coef2*sa, cn = coef2*s1).  Composition is linear:
+ *   x_next[b,t] += sum_h weight[h (,t)] * sigma[b*NFE+h,t] * noise[b*NFE+h,t]     where gen[b,t]
+ * sigma[B*NFE][T] fp32 with 0 for kept tokens; noise[B*NFE,T,F] fp32, clamped by the caller; weight_per_token selects weight[NFE][T]. */
+int dfot_ddim_noise(const float* noise, const float* sigma, const float* weight, const uint8_t* gen, float* x_next, int batch,
+                    int nfe, int tokens, int64_t frame_elems, int weight_per_token, void* stream);
+
 /* ---- denoising loss of one noised forward (training_step / validation denoising loss) -------------------------- */
 /* replaces ContinuousDiffusion.forward's frame arithmetic (diffusion/continuous_diffusion.py:140-167):
  *   x_t = alpha*x + sigma*noise ; eps_hat = alpha*v + sigma*x_t ; loss[b,t] = mean_frame( weight*(eps_hat-noise)^2 ) ;

@@ -89,6 +89,17 @@ class Diffusion:
             out = out + _ext(sigma, x.ndim) * noise
         return torch.where(_ext(curr == nxt, x.ndim), x, out)
 
+    def ddpm_step(self, x, curr, cond, cond_mask, noise):
+        """ddpm_sample_step (discrete_diffusion.py:423-452): posterior mean of (x0 prediction, x) + sqrt(posterior variance) * noise;
+        no noise at level 0; tokens at level -1 (clean) are kept.  Chosen when sampling_timesteps == timesteps (:395-420)."""
+        t = self.tables
+        kc = curr.clamp(min=0)
+        _, x0, _ = self.predictions(x, kc, cond, cond_mask)
+        mean = _ext(t.posterior_mean_coef1[kc], x.ndim) * x0 + _ext(t.posterior_mean_coef2[kc], x.ndim) * x
+        nz = torch.where(_ext(kc > 0, x.ndim), noise, torch.zeros_like(noise)).clamp(-self.clip_noise, self.clip_noise)
+        out = mean + torch.exp(0.5 * _ext(t.posterior_log_variance_clipped[kc], x.ndim)) * nz
+        return torch.where(_ext(curr == -1, x.ndim), x, out)
+
 
 @dataclass
 class SamplerConfig:
@@ -159,7 +170,10 @@ class Sampler:
                 # dfot_video_pose.py:75-83: under temporal guidance the pose processing also sees the branch's noise levels
                 cond = self.cond_fn(rep, f_in) if getattr(self, "cond_uses_levels", False) else self.cond_fn(rep)
             step_noise = self.noise_fn("ddim", tuple(x_in.shape))
-            x_out = self.diff.ddim_step(x_in, f_in, t_in, cond, cmask, step_noise)
+            if self.diff.sampling_timesteps < self.diff.tables.timesteps:  # is_ddim_sampling (discrete_diffusion.py:108)
+                x_out = self.diff.ddim_step(x_in, f_in, t_in, cond, cmask, step_noise)
+            else:
+                x_out = self.diff.ddpm_step(x_in, f_in, cond, cmask, step_noise)
             xs = g.compose(x_out)
             xs = torch.where(_ext(context_mask, nd) == 0, xs, prev)
         return xs[:, :length] if padding > 0 else xs

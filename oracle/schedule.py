@@ -28,6 +28,10 @@ class ScheduleTables:
     logsnr: torch.Tensor
     timesteps: int
     snr: torch.Tensor = None  # alphas_cumprod / (1 - alphas_cumprod) formed in float64 like the reference's buffer
+    # posterior q(x_{k-1} | x_k, x_0) of DDPM sampling (discrete_diffusion.py:137-158), formed in float64 like the reference's buffers
+    posterior_mean_coef1: torch.Tensor = None
+    posterior_mean_coef2: torch.Tensor = None
+    posterior_log_variance_clipped: torch.Tensor = None
 
 
 def _alphas_cumprod_cosine_simple(timesteps: int, logsnr_min: float, logsnr_max: float,
@@ -68,7 +72,12 @@ def build_tables(timesteps: int = 1000, beta_schedule: str = "cosine_simple_diff
     ac = torch.cumprod(1.0 - betas, dim=0)
     snr = ac / (1.0 - ac)
     f32 = torch.float32
+    ac_prev = torch.cat([torch.ones(1, dtype=ac.dtype), ac[:-1]])
+    post_var = betas * (1.0 - ac_prev) / (1.0 - ac)
     return ScheduleTables(
+        posterior_mean_coef1=(betas * torch.sqrt(ac_prev) / (1.0 - ac)).to(f32),
+        posterior_mean_coef2=((1.0 - ac_prev) * torch.sqrt(1.0 - betas) / (1.0 - ac)).to(f32),
+        posterior_log_variance_clipped=torch.log(post_var.clamp(min=1e-20)).to(f32),
         alphas_cumprod=ac.to(f32),
         sqrt_alphas_cumprod=torch.sqrt(ac).to(f32),
         sqrt_one_minus_alphas_cumprod=torch.sqrt(1.0 - ac).to(f32),

@@ -127,6 +127,45 @@ def test_200_frame_rollout_plan_on_the_hip_path():
     assert torch.isfinite(out).all() and p >= 35.0 and worst >= 30.0
 
 
+@pytest.mark.parametrize("tag", ["eta", "ddpm"])
+def test_stochastic_sampling_steps(tag):
+    """DDIM with eta = 0.5 and DDPM (sampling_timesteps == timesteps) on the HIP path vs the oracle (which reproduces the reference's
+    recorded runs, tests/test_oracle_golden.py) on identical replayed noise: the sigma * noise term of every branch enters through
+    dfot_ddim_noise after the fused compose"""
+    import dfot_amd
+    from oracle import pose as opose, sampler as osm, schedule as sch, uvit as ouvit
+    res = 64
+    ocfg, params, model = build(blocks=(1, 1, 1), mid=1)
+    g = torch.Generator().manual_seed(17)
+    xs = torch.randn(1, 8, 3, res, res, generator=g)
+    cnd = poses(1, 8, 17)
+    hgc = dict(name="vanilla", guidance_scale=4.0)
+    if tag == "eta":
+        ts, steps, eta = 1000, 4, 0.5
+    else:
+        ts, steps, eta = 6, 6, 0.0
+    r1 = Replay(7, "cpu")
+    diff = osm.Diffusion(sch.build_tables(timesteps=ts), lambda x, k, c, m: ouvit.forward(params, ocfg, x, k, c, m), sampling_timesteps=steps, eta=eta)
+    osamp = osm.Sampler(osm.SamplerConfig(x_shape=(3, res, res), timesteps=ts, sampling_timesteps=steps, prediction_guidance=hgc), diff,
+                        lambda c: opose.ray_encoding(c, res), r1)
+    with torch.no_grad():
+        ref = osamp.predict_videos(xs, 1, cnd)
+    r2 = Replay(7, "cuda")
+    cfg = dfot_amd.SamplerConfig(x_shape=(3, res, res), prediction_guidance=hgc,
+                                 diffusion=dfot_amd.DiffusionConfig(timesteps=ts, sampling_timesteps=steps, ddim_sampling_eta=eta))
+    samp = dfot_amd.DFoTVideoPoseSampler(cfg, model, r2)
+    out = samp._predict_videos(xs, n_context_tokens=1, conditions=cnd).cpu()
+    assert r1.log == r2.log
+    p = psnr(out, ref)
+    print(f"stochastic sampling ({tag}): PSNR {p:.1f} dB")
+    assert torch.isfinite(out).all() and p >= 35.0
+    # the noise term is really there: the deterministic sampler gives a different result
+    if tag == "eta":
+        cfg0 = dfot_amd.SamplerConfig(x_shape=(3, res, res), prediction_guidance=hgc, diffusion=dfot_amd.DiffusionConfig(sampling_timesteps=steps))
+        det = dfot_amd.DFoTVideoPoseSampler(cfg0, model, Replay(7, "cuda"))._predict_videos(xs, n_context_tokens=1, conditions=cnd).cpu()
+        assert psnr(det, ref) < p - 10
+
+
 def test_sampler_contract_errors():
     import dfot_amd
     _, _, model = build(blocks=(1, 1, 1), mid=1)

@@ -338,3 +338,33 @@ def test_host_tensors_are_refused_before_any_launch():
         torch.ops.dfot.hg_prepare(x, None, torch.zeros(4, 8), torch.zeros(4, 8), 2)
     with pytest.raises(ValueError):   # wrong table shape is caught before the device check
         torch.ops.dfot.hg_prepare(x, None, torch.zeros(2, 8), torch.zeros(4, 8), 2)
+
+
+@pytest.mark.parametrize("tag", ["eta", "ddpm"])
+def test_stochastic_sampling_plan_vs_reference_run(tag):
+    """eta > 0 DDIM / DDPM (discrete_diffusion.py:423-452,515-538): the product's schedule tables equal the reference's buffers and
+    the planner consumes exactly the reference's normal draws (count, order, shapes) -- golden recorded from the reference run"""
+    import torch
+    import dfot_amd
+    g = load("sampler_stochastic.npz")
+    dcfg = DiffusionConfig(sampling_timesteps=3, ddim_sampling_eta=0.5) if tag == "eta" else DiffusionConfig(timesteps=6, sampling_timesteps=6)
+    s = Schedule(dcfg)
+    assert s.is_ddim_sampling == (tag == "eta")
+    if tag == "ddpm":
+        np.testing.assert_allclose(s.alphas_cumprod, g["ddpm_alphas_cumprod"], rtol=1e-6)
+        np.testing.assert_allclose(s.posterior_mean_coef1, g["ddpm_coef1"], rtol=1e-5, atol=1e-9)
+        np.testing.assert_allclose(s.posterior_mean_coef2, g["ddpm_coef2"], rtol=1e-5, atol=1e-9)
+        np.testing.assert_allclose(s.posterior_log_variance_clipped, g["ddpm_log_var"], rtol=1e-5, atol=1e-6)
+        # the fused-step form of the posterior mean: (c1 + c2*sa) x0 + (c2*s1) eps == c1 x0 + c2 x with x = sa x0 + s1 eps
+        k = np.arange(6)[None]
+        sa, s1, an, cn, keep, sigma = s.ddpm_coef(k)
+        x0, eps = 0.7, -1.3
+        np.testing.assert_allclose(an * x0 + cn * eps, s.posterior_mean_coef1[k] * x0 + s.posterior_mean_coef2[k] * (sa * x0 + s1 * eps), rtol=1e-5)
+        assert sigma[0, 0] == 0 and (sigma[0, 1:] > 0).all() and not keep.any()
+    rec = _RecordingNoise()
+    cfg = dfot_amd.SamplerConfig(x_shape=(3, 16, 16), diffusion=dcfg, prediction_guidance=dict(name="vanilla", guidance_scale=4.0))
+    smp = dfot_amd.DFoTVideoPoseSampler(cfg, backbone=None, noise_fn=rec)
+    smp.device, smp.dry_run = "cpu", True
+    smp._predict_videos(torch.from_numpy(g[f"{tag}_xs"]), 1, torch.from_numpy(g[f"{tag}_conds"]))
+    ref_shapes = [list(g[f"{tag}_noise{i}"].shape) for i in range(int(g[f"{tag}_n_noise"]))]
+    assert [sh[:len(r)] for sh, r in zip(rec.shapes, ref_shapes)] == ref_shapes and len(rec.shapes) == len(ref_shapes)

@@ -212,3 +212,29 @@ def test_uvit_training_gradients_vs_reference_fixture():
     for key in stored:
         ref = T(g[key])
         torch.testing.assert_close(ps[key[5:]].grad, ref, rtol=5e-3, atol=1e-7 + 1e-3 * float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("tag", ["eta", "ddpm"])
+def test_stochastic_sampling_steps_vs_reference_runs(tag):
+    """eta > 0 DDIM and DDPM sampling (discrete_diffusion.py:423-452, 515-538): the reference's own `_predict_videos` runs with every
+    normal draw recorded; the oracle replays the draws and must reproduce the result"""
+    g = load("sampler_stochastic.npz")
+    p, model = tiny_model()
+    assert digest(p) == str(g["digest"])
+    noise = [T(g[f"{tag}_noise{i}"]) for i in range(int(g[f"{tag}_n_noise"]))]
+    nfn = osm.replay_noise_fn(noise)
+    if tag == "eta":
+        tables, steps, ts, eta = sch.build_tables(), 3, 1000, 0.5
+    else:
+        tables, steps, ts, eta = sch.build_tables(timesteps=6), 6, 6, 0.0
+        np.testing.assert_allclose(tables.alphas_cumprod.numpy(), g["ddpm_alphas_cumprod"], rtol=1e-6)
+        np.testing.assert_allclose(tables.posterior_mean_coef1.numpy(), g["ddpm_coef1"], rtol=1e-5, atol=1e-9)
+        np.testing.assert_allclose(tables.posterior_mean_coef2.numpy(), g["ddpm_coef2"], rtol=1e-5, atol=1e-9)
+        np.testing.assert_allclose(tables.posterior_log_variance_clipped.numpy(), g["ddpm_log_var"], rtol=1e-5, atol=1e-6)
+    cfg = osm.SamplerConfig(x_shape=(3, 16, 16), timesteps=ts, sampling_timesteps=steps,
+                            prediction_guidance=dict(name="vanilla", guidance_scale=4.0))
+    diff = osm.Diffusion(tables, model, sampling_timesteps=steps, eta=eta)
+    s = osm.Sampler(cfg, diff, lambda c: opose.ray_encoding(c, 16), nfn)
+    out = s.predict_videos(T(g[f"{tag}_xs"]), 1, T(g[f"{tag}_conds"]))
+    assert not nfn.queue
+    np.testing.assert_allclose(out.numpy(), g[f"{tag}_out"], rtol=1e-3, atol=2e-3)

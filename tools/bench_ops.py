@@ -86,6 +86,8 @@ def main():
         for name, (b, hd, n, d) in {"L2": (2, 9, 8192, 64), "L3": (2, 9, 2048, 128), "L2 Bm8": (8, 9, 8192, 64)}.items():
             if os.environ.get("ONLY") and os.environ["ONLY"] != name:
                 continue
+            if os.environ.get("ONLY") and os.environ["ONLY"] != name:
+                continue
             for v in [int(x) for x in os.environ.get("ATTN_VARIANTS", "0").split(",")]:
                 ms, tf = attn(b, hd, n, d, v)
                 print(f"attn {name:7s} B={b} H={hd} N={n} d={d} variant={v}: {ms*1e3:8.1f} us  {tf:7.1f} TF/s", flush=True)

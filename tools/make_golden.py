@@ -209,6 +209,36 @@ def training_grads_uvit(R):
     save("training_grads_uvit.npz", xs=xs, k=k, masks=masks, poses=poses, digest=np.array(weights_digest(params)), **out)
 
 
+def stochastic_samplers(R):
+    """The stochastic sampling steps of the reference run by the reference itself (discrete_diffusion.py:423-452 ddpm_sample_step,
+    :454-538 ddim_sample_step with eta > 0): full `_predict_videos` runs of the tiny pose model under vanilla History Guidance with
+    every normal draw recorded.  (a) DDIM, eta = 0.5, 3 sampling steps of 1000; (b) DDPM: a 6-level schedule sampled with all 6
+    levels (sampling_timesteps == timesteps selects ddpm_sample_step)."""
+    A = R["AttrDict"]
+    out = {}
+    for tag, mod in (("eta", dict(ddim_sampling_eta=0.5, sampling_timesteps=3)), ("ddpm", dict(timesteps=6, sampling_timesteps=6))):
+        cfg = algo_cfg(A, 16, TINY, sampling_steps=3, pred_hg=dict(name="vanilla", guidance_scale=4.0))
+        for k, v in mod.items():
+            cfg.diffusion[k] = v
+        algo, _, p = build_algo(R, cfg)
+        assert algo.diffusion_model.is_ddim_sampling == (tag == "eta")
+        g = torch.Generator().manual_seed(61)
+        vid = torch.randn(1, 8, 3, 16, 16, generator=g)
+        cnd = synth_poses(1, 8, seed=9)
+        algo.generator = torch.Generator().manual_seed(0)
+        with RandnRecorder() as rec:
+            res = algo._predict_videos(vid.clone(), n_context_tokens=1, conditions=cnd.clone())
+        assert torch.isfinite(res).all()
+        out.update({f"{tag}_xs": vid, f"{tag}_conds": cnd, f"{tag}_out": res, f"{tag}_n_noise": np.array(len(rec.draws))})
+        out.update({f"{tag}_noise{i}": d for i, d in enumerate(rec.draws)})
+        dm = algo.diffusion_model
+        if tag == "ddpm":
+            out.update(ddpm_alphas_cumprod=dm.alphas_cumprod, ddpm_coef1=dm.posterior_mean_coef1, ddpm_coef2=dm.posterior_mean_coef2,
+                       ddpm_log_var=dm.posterior_log_variance_clipped)
+        out["digest"] = np.array(weights_digest(p))
+    save("sampler_stochastic.npz", **out)
+
+
 @torch.no_grad()
 def main():
     os.makedirs(OUT, exist_ok=True)
@@ -216,6 +246,8 @@ def main():
     A = R["AttrDict"]
     if os.environ.get("ONLY") == "training_grads_uvit":
         return training_grads_uvit(R)
+    if os.environ.get("ONLY") == "stochastic":
+        return stochastic_samplers(R)
 
     # ---------------------------------------------------------------- schedule + scheduling matrices
     print("schedule")
