@@ -387,6 +387,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="8f only: skip the short runs of the other BASELINE configs appended under 'extra'")
     ap.add_argument("--graph", action="store_true", help="replay one hipGraph-captured DDIM step (no in-run attention timing)")
+    ap.add_argument("--eager", action="store_true", help="force the eager step loop (A/B against the default)")
     ap.add_argument("--batch", type=int, default=8, help="k600: videos per GPU (bash/k600 validation.batch_size)")
     ap.add_argument("--workload", choices=["8f", "200f", "k600", "k600diff", "train_k600", "train_k600diff", "train_re10k"], default="8f",
                     help="8f: BASELINE config 2 (default, the metric's single-GPU configuration); 200f: config 3, the "
@@ -400,8 +401,20 @@ def main():
     extras = None
     if world == 1 and args.workload == "8f" and not args.no_extras and args.res == 256:
         # the other BASELINE configs, short and clearly labelled, inside the same driver-timed run (the headline stays config 2).
-        # They run as child processes BEFORE this process touches the GPU (nothing is exec'ed from a GPU-initialised process).
-        extras = run_extras(args)
+        # This process never touches the GPU: the headline runs first, as a child of its own on the fresh device, then the extras;
+        # the one JSON line is assembled here.
+        import subprocess
+        cmd = [sys.executable, os.path.abspath(__file__), "--no-extras", "--steps", str(args.steps), "--warmup", str(args.warmup),
+               "--sampling-steps", str(args.sampling_steps)] + (["--no-cpu-baseline"] if args.no_cpu_baseline else []) + (["--eager"] if args.eager else [])
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        rows = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        if r.returncode != 0 or not rows:
+            sys.stderr.write(r.stderr)
+            raise SystemExit(r.returncode or 1)
+        line = json.loads(rows[-1])
+        line["extra"] = run_extras(args)
+        print(json.dumps(line), flush=True)
+        return
     torch.cuda.set_device(local)
     if world > 1:
         import torch.distributed as dist

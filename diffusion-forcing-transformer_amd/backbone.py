@@ -8,8 +8,11 @@ Mirrors the reference's plugin contract for this path:
   * state-dict key names / shapes, so reference checkpoints load with
     ``load_state_dict``.
 Parameters live here as fp32 ``nn.Parameter``s (the reference layout); the C library keeps
-packed bf16 copies that are refreshed whenever a parameter changes.  Inference only
-(this inference module has no backward; training goes through uvit_train.UViT3DPoseTrainer): call under ``torch.no_grad()``.
+packed bf16 copies that are refreshed whenever a parameter changes.
+Under ``torch.no_grad()`` (sampling) ``forward`` runs the fused inference engine (per-window pose / FiLM caches).  With gradients
+enabled and trainable parameters it runs the training form -- saved-activation forward + hand-written backward
+(uvit_train.UViT3DPoseTrainer) behind ``dfot::uvit3d_pose_forward_train`` -- so ``loss.backward()`` / ``accelerator.backward(loss)``
+fill ``param.grad`` exactly as the reference's autograd does (continuous_diffusion.py:154, simple_video_generation.py:260-270).
 """
 from __future__ import annotations
 
@@ -85,6 +88,10 @@ class UViT3DPose(nn.Module):
         self._op_key: Optional[int] = None
         self._cond_key = None
         self._cond_refs = None
+        self._train_names = None     # parameter names in named_parameters() order (operator input order of the training form)
+        self._trainer = None         # uvit_train.UViT3DPoseTrainer on this module's weights, built at the first training forward
+        self._trainer_sig = None
+        self._dropout_generator: Optional[torch.Generator] = None  # set a CUDA generator to enable the MLP-branch nn.Dropout in train()
 
     # ------------------------------------------------------------------ module tree
     def _register(self, name: str, shape: Tuple[int, ...]) -> None:
@@ -193,15 +200,74 @@ class UViT3DPose(nn.Module):
         assert external_cond is not None, "External condition (camera pose) is required for U-ViT3DPose model."
         if self._op_key is None:
             self._op_key = ops.register_model(self)
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            if self._train_names is None:
+                self._train_names = [n for n, _ in self.named_parameters()]
+            params = [p for _, p in self.named_parameters()]
+            return torch.ops.dfot.uvit3d_pose_forward_train(x, noise_levels, external_cond, external_cond_mask, params, self._op_key)
         return torch.ops.dfot.uvit3d_pose_forward(x, noise_levels, external_cond, external_cond_mask, self._op_key)
+
+    # ------------------------------------------------------------------ training form (autograd)
+    def _train_engine(self, params):
+        """The saved-activation engine on the module's CURRENT weights: built once, its flat parameter buffer refreshed (and the
+        bf16 operand copies re-packed) whenever a parameter changed since the last training forward."""
+        from . import uvit_train
+        sig = tuple((t.data_ptr(), t._version) for t in params) + tuple((b.data_ptr(), b._version) for _, b in self.named_buffers())
+        if self._trainer is None:
+            cfg = dict(channels=list(self._ccfg.channels), emb_channels=int(self._ccfg.emb_channels), patch_size=2,
+                       block_types=["ResBlock", "ResBlock", "TransformerBlock", "TransformerBlock"],
+                       num_updown_blocks=list(self._ccfg.num_updown_blocks), num_mid_blocks=int(self._ccfg.num_mid_blocks),
+                       num_heads=int(self._ccfg.num_heads), in_channels=int(self._ccfg.in_channels), resolution=int(self._ccfg.resolution),
+                       max_tokens=self.max_tokens, cond_dim=self.external_cond_dim, noise_dim=int(self._ccfg.noise_dim),
+                       eps=float(self._ccfg.eps), rope_theta=float(self._ccfg.rope_theta),
+                       block_dropouts=list(_get(self.cfg, "block_dropouts", [0.0] * 4) or [0.0] * 4))
+            # the reference's parameter order (names as registered) + the persistent Fourier buffers
+            sd = {n: t for n, t in zip(self._train_names, params)}
+            sd.update(dict(self.named_buffers()))
+            ordered = {n: sd[n] for n in self._names}
+            self._trainer = uvit_train.UViT3DPoseTrainer(ordered, cfg)
+            self._trainer_sig = sig
+        elif sig != self._trainer_sig:
+            with torch.no_grad():
+                for n, t in zip(self._train_names, params):
+                    self._trainer.p[n].copy_(t)
+                for n, b in self.named_buffers():
+                    self._trainer.p[n].copy_(b)
+            self._trainer.sync()
+            self._trainer_sig = sig
+        return self._trainer
+
+    def _train_forward_impl(self, x, noise_levels, external_cond, external_cond_mask, params):
+        assert x.shape[1] == self.temporal_length, (
+            f"Temporal length of U-ViT is set to {self.temporal_length}, but input has temporal length {x.shape[1]}.")
+        dev = params[0].device
+        if dev.type != "cuda":
+            raise RuntimeError(f"the backbone's parameters are on {dev}; move the module to the GPU first (there is no CPU path)")
+        capi.require_device(dev, x=x, noise_levels=noise_levels, external_cond=external_cond, external_cond_mask=external_cond_mask)
+        eng = self._train_engine(params)
+        # training-time pose dropout (RandomDropoutPatchEmbed, embeddings.py:390-428): per-video Bernoulli(external_cond_dropout) while
+        # the module is in train() mode; an explicit mask (inference-style call under grad) is honoured as given
+        drop = external_cond_mask
+        pdrop = float(_get(self.cfg, "external_cond_dropout", 0.0) or 0.0)
+        if drop is None and self.training and pdrop > 0:
+            drop = torch.rand(x.shape[0], device=dev) < pdrop
+        eng.dropout_generator = self._dropout_generator if self.training else None
+        with torch.no_grad():
+            return eng.forward(x, noise_levels, external_cond, drop).to(x.dtype)
+
+    def _train_backward_impl(self, grad_out, params):
+        eng = self._trainer
+        if eng is None:
+            raise RuntimeError("backward without a training forward")
+        with torch.no_grad():
+            grads = eng.backward(grad_out)
+        return [grads[n].to(p.dtype).reshape(p.shape) if n in grads else torch.zeros_like(p) for n, p in zip(self._train_names, params)]
 
     def _forward_impl(self, x: torch.Tensor, noise_levels: torch.Tensor, external_cond: Optional[torch.Tensor] = None,
                       external_cond_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
         assert x.shape[1] == self.temporal_length, (
             f"Temporal length of U-ViT is set to {self.temporal_length}, but input has temporal length {x.shape[1]}.")
         assert external_cond is not None, "External condition (camera pose) is required for U-ViT3DPose model."
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()) and x.requires_grad:
-            raise RuntimeError("the HIP engine is inference-only; call under torch.no_grad()")
         b = x.shape[0]
         if tuple(x.shape[2:]) != self.x_shape:
             raise ValueError(f"x has frame shape {tuple(x.shape[2:])}, expected {self.x_shape}")

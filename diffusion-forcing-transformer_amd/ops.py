@@ -5,6 +5,7 @@ shim over one C-ABI call of libdfot_hip.so (``capi``) with a fake ("meta") imple
 FakeTensor tracing, ``torch.compile`` graphs and stream capture treat the HIP kernels as opaque ops:
 
     dfot::uvit3d_pose_forward(x, noise_levels, external_cond, external_cond_mask?, model) -> v      [dfot_uvit_forward]
+    dfot::uvit3d_pose_forward_train(x, noise_levels, external_cond, mask?, params[], model) -> v    [autograd: dfot_op_* forward/backward]
     dfot::dit3d_forward(x, noise_levels, model) -> v                                                [dfot_dit_forward]
     dfot::ray_encoding(raw_poses, resolution) -> cond                                               [dfot_ray_encode]
     dfot::hg_prepare(x, noise?, qa, qb, nfe) -> x_in                                                [dfot_hg_prepare]
@@ -19,7 +20,7 @@ for a host that drives the step itself.
 from __future__ import annotations
 
 import weakref
-from typing import Optional
+from typing import List, Optional
 
 import torch
 from torch import Tensor
@@ -52,6 +53,46 @@ def uvit3d_pose_forward(x: Tensor, noise_levels: Tensor, external_cond: Tensor, 
 @uvit3d_pose_forward.register_fake
 def _(x, noise_levels, external_cond, external_cond_mask, model):
     return torch.empty_like(x)
+
+
+# ---- training form: the same backbone under autograd -------------------------------------------------------------------
+# `params` are the module's trainable tensors in `model._train_names` order; they are operator inputs so that autograd hands
+# their gradients back (torch.library.register_autograd).  Forward = the saved-activation forward of uvit_train.UViT3DPoseTrainer
+# on the module's current weights, backward = its hand-written backward: what `accelerator.backward(loss)` walks into when the
+# reference's training_step calls `self.model(x_t, precond_scale * logsnr, external_cond)` (continuous_diffusion.py:154,
+# experiments/simple_video_generation.py:260-270).  No input gradient: the reference never differentiates w.r.t. x_t here.
+@custom_op("dfot::uvit3d_pose_forward_train", mutates_args=())
+def uvit3d_pose_forward_train(x: Tensor, noise_levels: Tensor, external_cond: Tensor, external_cond_mask: Optional[Tensor],
+                              params: List[Tensor], model: int) -> Tensor:
+    return _model(model)._train_forward_impl(x, noise_levels, external_cond, external_cond_mask, params)
+
+
+@uvit3d_pose_forward_train.register_fake
+def _(x, noise_levels, external_cond, external_cond_mask, params, model):
+    return torch.empty_like(x)
+
+
+@custom_op("dfot::uvit3d_pose_backward", mutates_args=())
+def uvit3d_pose_backward(grad_out: Tensor, params: List[Tensor], model: int) -> List[Tensor]:
+    return _model(model)._train_backward_impl(grad_out, params)
+
+
+@uvit3d_pose_backward.register_fake
+def _(grad_out, params, model):
+    return [torch.empty_like(p) for p in params]
+
+
+def _train_setup_context(ctx, inputs, output):
+    ctx.params = inputs[4]
+    ctx.model = inputs[5]
+
+
+def _train_backward(ctx, grad_out):
+    grads = torch.ops.dfot.uvit3d_pose_backward(grad_out.contiguous(), ctx.params, ctx.model)
+    return None, None, None, None, grads, None
+
+
+uvit3d_pose_forward_train.register_autograd(_train_backward, setup_context=_train_setup_context)
 
 
 @custom_op("dfot::dit3d_forward", mutates_args=())

@@ -102,3 +102,61 @@ def allreduce_mean_(flat: torch.Tensor, group=None, bucket_numel: int = 1 << 26)
         w.wait()
     flat.mul_(1.0 / world)
     return flat
+
+
+class OverlappedGradReducer:
+    """Gradient averaging OVERLAPPED with the backward pass: gradients are handed over as the backward produces
+    them (deepest levels last), packed into buckets of `bucket_numel` elements and all-reduced asynchronously while the backward of
+    the next blocks runs; `finish()` waits, scales by 1/world and scatters the means into the destination views (the trainer's flat
+    gradient buffer).  Few large buckets (xGMI is point-to-point: a ring all-reduce is bound per link).  Summation order per
+    element is that of one all-reduce, so the result equals `allreduce_mean_` on the whole flat buffer bit for bit."""
+
+    def __init__(self, bucket_numel: int = 1 << 25, group=None):
+        self.bucket_numel, self.group = int(bucket_numel), group
+        self.world, _ = world_info(group)
+        self._pending: List[tuple] = []   # (dest view, source gradient) of the bucket being filled
+        self._pending_numel = 0
+        self._inflight: List[tuple] = []  # (work, bucket buffer, [(dest, numel)])
+
+    def add(self, dest: torch.Tensor, grad: torch.Tensor) -> None:
+        """dest: flat view that must finally hold the mean of `grad` over the ranks"""
+        if self.world == 1:
+            dest.copy_(grad.reshape(-1))
+            return
+        self._pending.append((dest, grad))
+        self._pending_numel += grad.numel()
+        if self._pending_numel >= self.bucket_numel:
+            self.flush()
+
+    def flush(self) -> None:
+        if not self._pending:
+            return
+        buf = torch.cat([g.reshape(-1).to(torch.float32) for _, g in self._pending])
+        work = dist.all_reduce(buf, group=self.group, async_op=True)
+        self._inflight.append((work, buf, [(d, g.numel()) for d, g in self._pending]))
+        self._pending, self._pending_numel = [], 0
+
+    def finish(self) -> None:
+        self.flush()
+        for work, buf, dests in self._inflight:
+            work.wait()
+            buf.mul_(1.0 / self.world)
+            off = 0
+            for d, n in dests:
+                d.copy_(buf[off: off + n])
+                off += n
+        self._inflight = []
+
+
+def exchange_branches(v_local: torch.Tensor, nfe: int, group=None) -> torch.Tensor:
+    """History-Guidance branch parallelism for the sequential key-frame windows (the branches of a step are
+    independent forwards combined only by compose, history_guidance.py:545-568,978-982).  Rank r has evaluated branch r % nfe of
+    every sample: v_local [B, T, ...].  One all-gather returns v [B * nfe, T, ...] in the sampler's (sample, branch) row order."""
+    world, rank = world_info(group)
+    if world < nfe:
+        raise ValueError(f"branch parallelism needs at least {nfe} ranks, have {world}")
+    out = v_local.new_empty((world * v_local.shape[0], *v_local.shape[1:]))
+    dist.all_gather_into_tensor(out, v_local.contiguous(), group=group)
+    b = v_local.shape[0]
+    per_rank = out.view(world, b, *v_local.shape[1:])[:nfe]          # ranks 0..nfe-1 hold branches 0..nfe-1
+    return per_rank.transpose(0, 1).reshape(b * nfe, *v_local.shape[1:]).contiguous()

@@ -71,6 +71,10 @@ class DFoTVideoPoseSampler:
         self.trace: List[dict] = []
         self.window_forwards = 0
         self.shard_windows = False  # True: shard interpolation windows over torch.distributed ranks (parallel.py)
+        # True: the History-Guidance branches of the (sequential, replicated) key-frame windows are split over ranks -- rank r runs
+        # branch r % NFE of every sample and one all-gather per step returns all branches (parallel.exchange_branches)
+        self.branch_parallel = False
+        self._branch_split_active = False
         self.device = "cuda"        # where the rollout state lives; "cpu" only together with dry_run (planner inspection / host tests)
         self.dry_run = False        # True: plan every window (trace, noise draws in the reference's order) but launch nothing
         self.use_graph = False      # True: capture one DDIM step in a hipGraph and replay it (see _run_steps_graph)
@@ -391,6 +395,8 @@ class DFoTVideoPoseSampler:
                 self._interpolate_masked_poses = False
         xs = xs.contiguous()
         s = capi.stream_ptr
+        branch_cache: Dict[tuple, tuple] = {}
+
         def step(p_, xs, noise, tables, gen_dev, xs_next=None):
             nonlocal cond_rep, cond_nfe
             nfe, bm = p_["nfe"], p_["bm"]
@@ -404,7 +410,22 @@ class DFoTVideoPoseSampler:
                 cond_rep = p_["cond"]
             # discrete diffusion hands the backbone integer level indices (exact in the float32 table)
             lvl = tables[7] if cfg.diffusion.is_continuous else tables[7].to(torch.int32)
-            v = self.model(x_in, lvl, cond_rep, p_["cmask_dev"])
+            world, rank = parallel.world_info()
+            if self._branch_split_active and nfe > 1 and world >= nfe:
+                # this rank's branch only; the conditioning slices are cached per window so that the backbone's pose cache (keyed on
+                # tensor identity) still hits on every step
+                hb = rank % nfe
+                key = (id(cond_rep), id(p_["cmask_dev"]), hb)
+                if key not in branch_cache:
+                    c_h = None if cond_rep is None else cond_rep.view(batch_size, nfe, *cond_rep.shape[1:])[:, hb].contiguous()
+                    m_h = None if p_["cmask_dev"] is None else p_["cmask_dev"].view(batch_size, nfe)[:, hb].contiguous()
+                    branch_cache[key] = (c_h, m_h, cond_rep, p_["cmask_dev"])  # keep the keyed tensors alive
+                c_h, m_h = branch_cache[key][:2]
+                x_h = x_in.view(batch_size, nfe, horizon, *x_shape)[:, hb].contiguous()
+                l_h = lvl.view(batch_size, nfe, horizon)[:, hb].contiguous()
+                v = parallel.exchange_branches(self.model(x_h, l_h, c_h, m_h), nfe)
+            else:
+                v = self.model(x_in, lvl, cond_rep, p_["cmask_dev"])
             step_noise = None
             if strict or p_["sigma"] is not None:  # the reference draws it every step; with sigma = 0 it is multiplied by 0
                 step_noise = self.noise_fn("ddim", (bm, horizon, *x_shape))
@@ -441,7 +462,7 @@ class DFoTVideoPoseSampler:
             return (xs[:, :-padding] if padding > 0 else xs), None
         uniform = all(p_["bm"] == plans[0]["bm"] and p_["cmask_dev"] is plans[0]["cmask_dev"]
                       and p_["weights_dev"] is plans[0]["weights_dev"] for p_ in plans)
-        if self.use_graph and uniform and not strict and len(plans) > 2 and all(p_["sigma"] is None for p_ in plans):
+        if self.use_graph and uniform and not strict and len(plans) > 2 and all(p_["sigma"] is None for p_ in plans) and not self._branch_split_active:
             xs = self._run_steps_graph(plans, xs, draw_noise, step, flat_dev, gens_dev, horizon)
         else:
             for p_ in plans:
@@ -655,8 +676,12 @@ class DFoTVideoPoseSampler:
         keys = torch.linspace(0, n - 1, round(density * n)).round().long()
         keys = torch.cat([torch.arange(n_context_tokens), keys]).unique()
         kc = None if conditions is None else conditions[:, keys]
-        pred, _ = self._predict_sequence(out[:, :n_context_tokens], length=len(keys), conditions=kc, history_guidance=hg,
-                                         sliding_context_len=cfg.sliding_context_len or self.max_tokens // 2)
+        self._branch_split_active = bool(self.branch_parallel)  # key-frame windows are replicated on every rank: split their branches
+        try:
+            pred, _ = self._predict_sequence(out[:, :n_context_tokens], length=len(keys), conditions=kc, history_guidance=hg,
+                                             sliding_context_len=cfg.sliding_context_len or self.max_tokens // 2)
+        finally:
+            self._branch_split_active = False  # interpolation windows are sharded whole (both branches on one GPU)
         out[:, keys.to(self.device)] = pred
         if len(keys) < n:
             known = torch.zeros(out.shape[0], n, dtype=torch.bool)

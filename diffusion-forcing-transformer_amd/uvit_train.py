@@ -405,9 +405,21 @@ class UViT3DPoseTrainer:
                                               self.cin, _S()))
         return out.view(self.B, t, self.cin, self.res, self.res)
 
-    def backward(self, d_out: torch.Tensor) -> Dict[str, torch.Tensor]:
+    def backward(self, d_out: torch.Tensor, reducer=None) -> Dict[str, torch.Tensor]:
+        """reducer (parallel.OverlappedGradReducer): gradients are handed over level by level as they are produced, so their
+        all-reduce overlaps the rest of the backward; without it they are only returned"""
         lib, p, e, r, ch, bt = capi.lib, self.p, self.e, self.r, self.ch, self.bt
         G: Dict[str, torch.Tensor] = {}
+        handed = set()
+
+        def hand_over():
+            if reducer is None:
+                return
+            for n, gv in G.items():
+                if n not in handed:
+                    handed.add(n)
+                    o, shp = self.layout[n]
+                    reducer.add(self.flat_grads[o: o + gv.numel()], gv)
         demb = [torch.zeros(bt * r[l] * r[l], e, dtype=torch.float32, device="cuda") for l in range(4)]
 
         def run_back(blocks, prefix_fn, dh, lvl):
@@ -434,7 +446,9 @@ class UViT3DPoseTrainer:
             dh, G[f"up_blocks.{j}.0.conv.weight"], G[f"up_blocks.{j}.0.conv.bias"] = conv3x3_backward(
                 self.hsub[j], _bf(dt), p[f"up_blocks.{j}.0.conv.weight"], bt, r[l + 1], r[l + 1], ch[l + 1], ch[l])
             dsub[l] = dh                                              # d(h - after[l]): -> h, and minus -> after[l]
+            hand_over()
         dh = run_back(self.mid, lambda i: f"mid_blocks.{i}", dh, 3)
+        hand_over()
         for l in (2, 1, 0):
             n = self.nud[l]
             _axpy(dh, dsub[l], -1.0)                                  # after[l] also fed the subtraction on the way up
@@ -443,6 +457,7 @@ class UViT3DPoseTrainer:
             dh = dbefore[l].clone()
             capi.check(lib.dfot_op_pool2_bwd(_P(dpool), _P(dh), bt, r[l], r[l], ch[l], _S()))
             dh = run_back(self.down[l], lambda i, l=l: f"down_blocks.{l}.{i}", dh, l)
+            hand_over()
         dw, db = torch.empty_like(p["embed_input.proj.weight"]), torch.empty(ch[0], device="cuda")
         capi.check(lib.dfot_op_embed_input_wgrad(_P(dh), _P(self.x_in), _P(dw), _P(db), bt, self.res, self.cin, ch[0], self.ps, _S()))
         G["embed_input.proj.weight"], G["embed_input.proj.bias"] = dw, db
@@ -461,13 +476,14 @@ class UViT3DPoseTrainer:
         G[ne + "linear_2.weight"], G[ne + "linear_2.bias"] = wgrad(dnb, self.a1), colsum(dnb)
         dl1 = _silu(self.l1, gemm_bf16(dnb, self.w2T))
         G[ne + "linear_1.weight"], G[ne + "linear_1.bias"] = wgrad(dl1, self.feats), colsum(dl1)
+        hand_over()
         self.grads = G
         return G
 
     # ------------------------------------------------------------------ training step (ContinuousDiffusion.forward + AdamW)
     def loss_and_grads(self, xs: torch.Tensor, cond: torch.Tensor, t: torch.Tensor, noise: torch.Tensor, masks: Optional[torch.Tensor] = None,
                        precond_scale: float = 0.125, shift: float = 0.125, sigmoid_bias: float = -1.0, clip_noise: float = 20.0,
-                       cond_drop: Optional[torch.Tensor] = None) -> torch.Tensor:
+                       cond_drop: Optional[torch.Tensor] = None, reducer=None) -> torch.Tensor:
         """DFoTVideo.training_step for the pose model (dfot_video.py:41-75, continuous_diffusion.py:140-167): per-token levels t in [0,1],
         x_t = alpha x + sigma eps, v = model(x_t, precond * logsnr, cond), sigmoid-weighted eps-space error averaged with the loss masks;
         then the backward.  cond: processed ray encoding (B,T,180,H,W).  Returns the loss (device scalar)."""
@@ -490,15 +506,20 @@ class UViT3DPoseTrainer:
         capi.check(lib.dfot_vpred_loss(_P(x), _P(eps), _P(v), _P(tab[0]), _P(tab[1]), _P(tab[2]), None, _P(scratch), _P(per_token), b, tk, f, _S()))
         dv = torch.empty_like(x)
         capi.check(lib.dfot_vloss_grad(_P(x), _P(eps), _P(v), _P(tab[0]), _P(tab[1]), _P(tab[4]), _P(dv), b, tk, f, 0, _S()))
-        grads = self.backward(dv)
-        for n, (o, shp) in self.layout.items():
-            self.flat_grads[o: o + grads[n].numel()].copy_(grads[n].reshape(-1))
+        grads = self.backward(dv, reducer)
+        if reducer is not None:  # data parallel with the exchange overlapped: the flat buffer receives the MEANS over the ranks
+            reducer.finish()
+            self._grads_reduced = True
+        else:
+            for n, (o, shp) in self.layout.items():
+                self.flat_grads[o: o + grads[n].numel()].copy_(grads[n].reshape(-1))
+            self._grads_reduced = False
         return (per_token * mk.cuda()).mean()
 
     def optimizer_step(self, lr: float = 5e-5, betas=(0.9, 0.99), eps: float = 1e-8, weight_decay: float = 0.01, max_grad_norm: Optional[float] = 1.0,
                        world_size: int = 1) -> None:
         from . import parallel
-        if world_size > 1:
+        if world_size > 1 and not getattr(self, "_grads_reduced", False):
             parallel.allreduce_mean_(self.flat_grads)
         self.step_count += 1
         lib = capi.lib

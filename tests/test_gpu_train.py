@@ -735,3 +735,65 @@ def test_uvit_training_gradients_vs_reference_fixture():
                 worst = max(worst, rel(grads[key[5:]], ref))
     print(f"UViT3DPose: worst stored-gradient rel-L2 vs the reference {worst:.2e}")
     assert worst < 8e-2
+
+
+def test_drop_in_backbone_is_trainable_through_autograd():
+    """the reference trains by calling `self.model(x_t, precond_scale * logsnr, external_cond)` under autograd and
+    `accelerator.backward(loss)` (continuous_diffusion.py:154, simple_video_generation.py:260-270).  The drop-in nn.Module does the
+    same: with gradients enabled its forward dispatches `dfot::uvit3d_pose_forward_train`, whose registered backward fills
+    `param.grad` with the hand-written backward's result -- equal to UViT3DPoseTrainer.backward on the same weights / inputs, and
+    within the stated tolerance of torch autograd through the oracle.  A plain torch optimizer then trains the module."""
+    import dfot_amd
+    from dfot_amd import uvit_train as ut
+    from oracle import pose as opose, uvit as ouvit
+    cfg = ouvit.UViTConfig(channels=(128, 128, 128, 256), emb_channels=128, num_updown_blocks=(1, 1, 1), num_mid_blocks=1, num_heads=2, resolution=128,
+                           max_tokens=2)
+    params = ouvit.seeded_params(cfg, seed=8)
+    bcfg = dict(channels=list(cfg.channels), emb_channels=cfg.emb_channels, patch_size=2, block_types=list(cfg.block_types),
+                num_updown_blocks=list(cfg.num_updown_blocks), num_mid_blocks=cfg.num_mid_blocks, num_heads=cfg.num_heads, pos_emb_type="rope",
+                use_fourier_noise_embedding=True, conditioning=dict(dim=180))
+    model = dfot_amd.UViT3DPose(bcfg, x_shape=(3, 128, 128), max_tokens=2).cuda()
+    model.load_state_dict(params, strict=True)
+    model.train()
+    g = torch.Generator().manual_seed(10)
+    x = torch.randn(1, 2, 3, 128, 128, generator=g).cuda()
+    k = torch.randn(1, 2, generator=g).cuda()
+    pz = torch.eye(3, 4).reshape(1, 1, 12).repeat(1, 2, 1)
+    pz[..., 3] = torch.linspace(0, 0.3, 2)
+    cond = opose.ray_encoding(torch.cat([torch.tensor([0.5, 0.9, 0.5, 0.5]).repeat(1, 2, 1), pz], -1), 128).cuda()
+    w = torch.randn(1, 2, 3, 128, 128, generator=g).cuda()
+    v = model(x, k, cond)                      # gradients enabled, parameters trainable -> training form
+    assert v.requires_grad
+    loss = (v * w).sum()
+    loss.backward()
+    # (1) identical to the trainer's own backward
+    tr = ut.UViT3DPoseTrainer(params, dict(channels=cfg.channels, emb_channels=cfg.emb_channels, patch_size=2, block_types=cfg.block_types,
+                                           num_updown_blocks=cfg.num_updown_blocks, num_mid_blocks=cfg.num_mid_blocks, num_heads=cfg.num_heads,
+                                           resolution=128, max_tokens=2))
+    out = tr.forward(x, k, cond)
+    assert torch.equal(out, v.detach())
+    tg = tr.backward(w)
+    named = dict(model.named_parameters())
+    assert sorted(tg) == sorted(named)
+    for n, p in named.items():
+        assert p.grad is not None and torch.equal(p.grad, tg[n].reshape(p.shape)), n
+    # (2) within tolerance of autograd through the oracle
+    ps = {n: t.clone().requires_grad_(not n.endswith(("freqs", "phases"))) for n, t in params.items()}
+    ref = ouvit.forward(ps, cfg, x.cpu(), k.cpu(), cond.cpu())
+    (ref * w.cpu()).sum().backward()
+    rs = {n: rel(p.grad.cpu(), ps[n].grad) for n, p in named.items()}
+    worst = max(rs, key=rs.get)
+    print(f"drop-in autograd: forward rel-L2 {rel(v.detach().cpu(), ref.detach()):.2e}; worst gradient rel-L2 {rs[worst]:.2e} at {worst}")
+    assert rs[worst] < 6e-2
+    # (3) under no_grad the same module still runs the fused inference engine, and a torch optimizer step changes its output
+    with torch.no_grad():
+        before = model(x, k, cond)
+    assert not before.requires_grad and rel(before.cpu(), ref.detach()) < 2e-2
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-3)
+    opt.step()
+    opt.zero_grad()
+    v2 = model(x, k, cond)                     # picks the updated weights up (parameter versions changed)
+    with torch.no_grad():
+        after = model(x, k, cond)
+    assert not torch.equal(v2.detach(), v.detach())
+    assert rel(after, v2.detach()) < 2e-2      # inference engine and training form agree on the new weights

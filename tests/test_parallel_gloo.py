@@ -146,3 +146,46 @@ def test_flat_gradient_allreduce_mean_world2():
     for p in procs:
         p.join(60)
     assert all(ok for _, ok in res), res
+
+
+def _overlap_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from dfot_amd import parallel
+    g = torch.Generator().manual_seed(11)
+    sizes = [37, 1000, 4, 512, 129, 64]
+    all_grads = [[torch.randn(n, generator=g) for n in sizes] for _ in range(world)]  # every rank builds all, keeps its own
+    flat = torch.zeros(sum(sizes))
+    red = parallel.OverlappedGradReducer(bucket_numel=600)   # several ragged buckets, flushed while "the backward" goes on
+    off = 0
+    for gr in all_grads[rank]:
+        red.add(flat[off: off + gr.numel()], gr)
+        off += gr.numel()
+    red.finish()
+    ref = torch.cat([torch.stack([all_grads[r][i] for r in range(world)]).mean(0) for i in range(len(sizes))])
+    whole = torch.cat(all_grads[rank]).clone()
+    parallel.allreduce_mean_(whole, bucket_numel=256)
+    # branch exchange: rank r evaluated branch r of 3 samples
+    v_local = torch.full((3, 8, 2), float(rank)) + torch.arange(3).view(3, 1, 1) * 10
+    v = parallel.exchange_branches(v_local, nfe=2)
+    ok_v = v.shape == (6, 8, 2) and all(float(v[b * 2 + h, 0, 0]) == h + 10 * b for b in range(3) for h in range(2))
+    q.put((rank, bool(torch.allclose(flat, ref, atol=1e-6)), bool(torch.equal(flat, whole)), ok_v))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_overlapped_gradient_reducer_and_branch_exchange_world2():
+    """gradients handed over piecewise during the backward and all-reduced per bucket == the one-shot flat all-reduce (bit for bit);
+    the History-Guidance branch exchange returns rows in the sampler's (sample, branch) order"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_overlap_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(60)
+    assert all(a and b and c for _, a, b, c in res), res
