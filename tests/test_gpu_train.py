@@ -799,3 +799,38 @@ def test_drop_in_backbone_is_trainable_through_autograd():
         after = model(x, k, cond)
     assert not torch.equal(v2.detach(), v.detach())
     assert rel(after, v2.detach()) < 2e-2      # inference engine and training form agree on the new weights
+
+
+def test_uvit3d_pose_backward_at_re10k_widths():
+    """whole-model backward at the REAL RE10K widths -- channels 128/256/576/1152, 9 heads (d = 64 at level 2,
+    d = 128 at level 3), emb 1024 -- with reduced depth (1+1+1 blocks, 1 mid) and 64x64 frames, 8 tokens: forward and every
+    parameter gradient vs torch autograd through the fp32 oracle."""
+    from dfot_amd import uvit_train as ut
+    from oracle import pose as opose, uvit as ouvit
+    cfg = ouvit.UViTConfig(num_updown_blocks=(1, 1, 1), num_mid_blocks=1, resolution=64)   # default widths = RE10K
+    assert tuple(cfg.channels) == (128, 256, 576, 1152) and cfg.num_heads == 9 and cfg.emb_channels == 1024
+    params = ouvit.seeded_params(cfg, seed=12)
+    g = torch.Generator().manual_seed(13)
+    x = torch.randn(1, 8, 3, 64, 64, generator=g)
+    k = torch.randn(1, 8, generator=g)
+    pz = torch.eye(3, 4).reshape(1, 1, 12).repeat(1, 8, 1)
+    pz[..., 3] = torch.linspace(0, 0.4, 8)
+    cond = opose.ray_encoding(torch.cat([torch.tensor([0.5, 0.9, 0.5, 0.5]).repeat(1, 8, 1), pz], -1), 64)
+    d_out = torch.randn(1, 8, 3, 64, 64, generator=g)
+    tr = ut.UViT3DPoseTrainer(params, dict(channels=cfg.channels, emb_channels=cfg.emb_channels, patch_size=2, block_types=cfg.block_types,
+                                           num_updown_blocks=cfg.num_updown_blocks, num_mid_blocks=cfg.num_mid_blocks, num_heads=cfg.num_heads,
+                                           resolution=64, max_tokens=8))
+    out = tr.forward(x, k, cond).cpu()
+    grads = {n: t.cpu() for n, t in tr.backward(d_out).items()}
+    ps = {n: t.clone().requires_grad_(not n.endswith(("freqs", "phases"))) for n, t in params.items()}
+    ref = ouvit.forward(ps, cfg, x, k, cond)
+    r_out = rel(out, ref.detach())
+    (ref * d_out).sum().backward()
+    names = [n for n in ps if ps[n].requires_grad]
+    assert sorted(grads) == sorted(names)
+    rs = {n: rel(grads[n], ps[n].grad) for n in names}
+    worst = max(rs, key=rs.get)
+    over = {n: round(v, 4) for n, v in rs.items() if v >= 3e-2}
+    print(f"UViT3DPose backward at RE10K widths: forward rel-L2 {r_out:.2e}; worst gradient rel-L2 {rs[worst]:.2e} at {worst}; "
+          f"median {sorted(rs.values())[len(rs) // 2]:.2e}; above 3e-2: {over}")
+    assert r_out < 2e-2 and rs[worst] < 3e-2, (r_out, over)

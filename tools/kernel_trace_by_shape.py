@@ -13,8 +13,10 @@ from collections import defaultdict
 def main():
     d = sys.argv[1]
     acc = defaultdict(lambda: [0, 0.0])
+    spans = []
     for path in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
         for row in csv.DictReader(open(path)):
+            spans.append((int(row["Start_Timestamp"]), int(row["End_Timestamp"])))
             name = re.sub(r"^void ", "", row["Kernel_Name"]).split("(")[0].replace("dfot::", "").replace("(anonymous namespace)::", "")
             grid = int(row["Grid_Size_X"]) // max(int(row["Workgroup_Size_X"]), 1)
             a = acc[(name[:100], grid, int(row["Workgroup_Size_X"]))]
@@ -29,6 +31,23 @@ def main():
         open(sys.argv[2], "w").write(text)
     print("\n".join(l[:220] for l in lines[:45]))
     print("total ms", tot / 1e6)
+    # timeline of the busiest second half of the run (the timed steps): busy time, wall span and the gaps between kernels
+    spans.sort()
+    half = spans[len(spans) // 2:]
+    busy, gaps, end = 0, [], half[0][0]
+    for a, b in half:
+        if a > end:
+            gaps.append(a - end)
+        busy += max(0, b - max(a, end))
+        end = max(end, b)
+    span = end - half[0][0]
+    big = [x for x in gaps if x > 20000]
+    summary = ("timeline (second half of the dispatches): %d kernels, span %.2f ms, busy %.2f ms (%.1f %%), %d gaps avg %.2f us, "
+               "%d gaps > 20 us totalling %.2f ms" % (len(half), span / 1e6, busy / 1e6, 100.0 * busy / span, len(gaps),
+                                                     (sum(gaps) / max(len(gaps), 1)) / 1e3, len(big), sum(big) / 1e6))
+    print(summary)
+    if len(sys.argv) > 2:
+        open(sys.argv[2], "a").write("# " + summary + "\n")
 
 
 if __name__ == "__main__":
