@@ -495,7 +495,7 @@ def main():
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "r02_pmc_hbm_traffic_8f.json")
         if os.path.exists(pmc) and res == 256 and not long_rollout:
-            ks = [v for n, v in json.load(open(pmc))["kernels"].items() if "attn64_kernel_v3" in n]
+            ks = [v for n, v in json.load(open(pmc))["kernels"].items() if "attn64_kernel_v5" in n]
             traffic = ks[0]["hbm_bytes_per_launch_corrected"] if ks else None
         line = {
             "metric": "denoised latent frames/sec, DFoT RE10K 8f & 200f rollout @1/2/4/8 GPU",
@@ -510,7 +510,7 @@ def main():
                        "window_forwards_per_step": fwd // args.steps, "frames_per_step": frames_per_sample},
             "window_forward_ms": dt / fwd * 1e3,
             "model_tflops": WINDOW_FLOP * (res / 256.0) ** 2 * fwd / dt / 1e12 if res == 256 else None,
-            "roofline": {"bound": "mfma", "kernel": "attn64_kernel_v3 + attn64_merge_kernel (level-2 flash attention, N=%d, d=64; the event pair "
+            "roofline": {"bound": "mfma", "kernel": "attn64_kernel_v5 + attn64_merge_kernel (level-2 flash attention, N=%d, d=64; the event pair "
                                                    "brackets both launches)" % n2,
                          "achieved": achieved, "peak": 2500.0, "unit": "TFLOP/s",
                          "frac": achieved / 2500.0 if achieved else None, "traffic": traffic,

@@ -82,6 +82,9 @@ int launch_attention(const bf16* q, const bf16* k, const bf16* v, bf16* o, long 
 int launch_attention_v3(const bf16* q, const bf16* k, const bf16* v, bf16* o, long ldo, int batch, int heads, int n, bool nomax,
                         hipStream_t stream);
 int attention_v3_reserve(int batch, int heads, int n);
+// attention_v5.hip: attention_v3's NOMAX kernel with the key loop software-pipelined at half-tile granularity inside each wave
+int launch_attention_v5(const bf16* q, const bf16* k, const bf16* v, bf16* o, long ldo, int batch, int heads, int n, hipStream_t stream,
+                        int vpm = 3);
 // attention_pp.hip: the same products as an 8-wave ping-pong (SIMD partners alternate MFMA and softmax phases); no running max
 int launch_attention_pp(const bf16* q, const bf16* k, const bf16* v, bf16* o, long ldo, int batch, int heads, int n, int flags,
                         hipStream_t stream);

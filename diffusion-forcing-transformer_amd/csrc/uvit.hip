@@ -408,7 +408,7 @@ static int run_tr_block(dfot_uvit_s* h, const TrW& w, int lvl, int batch, hipStr
   // default (2): level 2 (d = 64) runs the 64-rows-per-wave kernel with the balanced tail; without a running max when the
   // QK-norm weights bound the scores far inside the fp32 / bf16 exponent range (2^64 * N keys << 2^127), else with it
   int av = h->attn_variant;
-  if (av == 2 && d == 64 && n % 256 == 0) av = w.score_bound < 64.0f ? 6 : 5;
+  if (av == 2 && d == 64 && n % 256 == 0) av = w.score_bound < 64.0f ? 14 : 5;  // 14: attention_v5.hip (software-pipelined, no running max)
   if ((rc = launch_attention(h->q, h->k, h->v, h->cat, 5 * c, batch, h->heads, n, d, av, s))) return rc;
   if (timed) DFOT_CHECK_HIP(hipEventRecord(h->ev_stop[h->ev_used++], s));
   GemmArgs o;
