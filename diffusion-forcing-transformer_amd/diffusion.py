@@ -37,6 +37,27 @@ class DiffusionConfig:
     # False: DiscreteDiffusion (the backbone receives the integer level index, discrete_diffusion.py:173-174);
     # True: ContinuousDiffusion (precond_scale * logsnr[k])
     is_continuous: bool = True
+    # continuous training schedule and loss weighting (cfg.training_schedule {name: cosine, shift}, cfg.loss_weighting {strategy: sigmoid,
+    # sigmoid_bias}; continuous_diffusion.py:53-74,106-116) -- read by the training / validation loss paths; the cosine logSNR limits
+    # are logsnr_min / logsnr_max above
+    training_schedule_name: str = "cosine"
+    training_schedule_shift: float = 0.125
+    loss_weighting_strategy: str = "sigmoid"
+    loss_sigmoid_bias: float = -1.0
+
+    def training_logsnr_tables(self, t):
+        """t in [0,1] (torch tensor, any shape) -> (logsnr, alpha, sigma, loss weight) of ContinuousDiffusion.forward in fp32 torch, from
+        THIS config (a schedule the engine does not implement raises instead of silently training on another one)"""
+        import torch
+        if self.training_schedule_name != "cosine":
+            raise ValueError(f"unsupported training schedule '{self.training_schedule_name}' (only 'cosine')")
+        if self.loss_weighting_strategy != "sigmoid":
+            raise ValueError(f"unsupported continuous loss weighting '{self.loss_weighting_strategy}' (only 'sigmoid')")
+        tt = t.detach().float().cpu()
+        lo = torch.atan(torch.exp(-0.5 * torch.tensor(float(self.logsnr_max))))
+        hi = torch.atan(torch.exp(-0.5 * torch.tensor(float(self.logsnr_min))))
+        logsnr = -2 * torch.log(torch.tan(lo + tt * (hi - lo))) + 2 * torch.log(torch.tensor(float(self.training_schedule_shift)))
+        return logsnr, torch.sigmoid(logsnr).sqrt(), torch.sigmoid(-logsnr).sqrt(), torch.sigmoid(float(self.loss_sigmoid_bias) - logsnr)
 
 
 class Schedule:

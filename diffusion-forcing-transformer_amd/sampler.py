@@ -109,8 +109,7 @@ class DFoTVideoPoseSampler:
     # ------------------------------------------------------------------ denoising loss (no backward)
     @torch.no_grad()
     def denoising_loss(self, xs: torch.Tensor, conditions: Optional[torch.Tensor], t: torch.Tensor,
-                       noise: Optional[torch.Tensor] = None, masks: Optional[torch.Tensor] = None,
-                       shift: float = 0.125, sigmoid_bias: float = -1.0):
+                       noise: Optional[torch.Tensor] = None, masks: Optional[torch.Tensor] = None):
         """One noised forward + sigmoid-weighted v-prediction loss: ``ContinuousDiffusion.forward``
         (diffusion/continuous_diffusion.py:140-167) followed by ``_reweight_loss``
         (algorithms/common/base_pytorch_video_algo.py:684-693) -- what ``training_step`` and the validation
@@ -118,14 +117,9 @@ class DFoTVideoPoseSampler:
         Returns (x_pred, loss scalar, per-token loss (B,T))."""
         b, tk = xs.shape[:2]
         f = int(np.prod(xs.shape[2:]))
-        tt = t.detach().float().cpu()
-        # cosine logSNR schedule of the reference in fp32 (CosineNoiseSchedule, continuous_diffusion.py:46-92)
-        lo = torch.atan(torch.exp(-0.5 * torch.tensor(15.0)))
-        hi = torch.atan(torch.exp(-0.5 * torch.tensor(-15.0)))
-        logsnr = -2 * torch.log(torch.tan(lo + tt * (hi - lo))) + 2 * torch.log(torch.tensor(shift))
-        alpha = torch.sigmoid(logsnr).sqrt()
-        sigma = torch.sigmoid(-logsnr).sqrt()
-        weight = torch.sigmoid(sigmoid_bias - logsnr)
+        # cosine logSNR schedule of the reference in fp32 (CosineNoiseSchedule, continuous_diffusion.py:46-92), limits / shift / loss
+        # weighting from the DiffusionConfig this sampler was built with (the same object the sampling Schedule honours)
+        logsnr, alpha, sigma, weight = self.cfg.diffusion.training_logsnr_tables(t)
         tab = torch.stack([alpha, sigma, weight, self.cfg.diffusion.precond_scale * logsnr]).float().cuda().contiguous()
         x = xs.to(device="cuda", dtype=torch.float32).contiguous()
         if noise is None:

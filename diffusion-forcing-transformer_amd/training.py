@@ -96,3 +96,23 @@ def training_step_forward(sampler, xs: torch.Tensor, masks: torch.Tensor, noise_
         x_pred, _, per_token = sampler.discrete_denoising_loss(xs, levels, noise=noise, loss_weighting=loss_weighting)
     per_token = per_token * lm.to(per_token.device)
     return {"loss": per_token.mean(), "xs_pred": x_pred, "noise_levels": levels, "per_token": per_token}
+
+
+def lr_at_step(step: int, base_lr: float, name: str = "constant_with_warmup", num_warmup_steps: int = 10000, num_training_steps: int = 0) -> float:
+    """Learning rate of optimizer step `step` (0-based) under the reference's schedulers (`transformers.get_scheduler(name=cfg.lr_scheduler.name,
+    num_warmup_steps=...)` stepped once per optimizer step: experiments/simple_video_generation.py:271, realestate10k_video_generation.yaml:19-22
+    `constant_with_warmup`, 10000 warm-up steps): linear warm-up from 0, then constant / linear decay / cosine decay."""
+    import math
+    warm = min(1.0, (step + 1) / max(1, num_warmup_steps)) if num_warmup_steps > 0 else 1.0
+    if name in ("constant", "constant_with_warmup"):
+        return base_lr * (warm if name == "constant_with_warmup" else 1.0)
+    if step < num_warmup_steps:
+        return base_lr * warm
+    if num_training_steps <= num_warmup_steps:
+        raise ValueError("lr schedule: num_training_steps must exceed num_warmup_steps for a decaying schedule")
+    prog = (step - num_warmup_steps) / (num_training_steps - num_warmup_steps)
+    if name == "linear":
+        return base_lr * max(0.0, 1.0 - prog)
+    if name == "cosine":
+        return base_lr * max(0.0, 0.5 * (1.0 + math.cos(math.pi * prog)))
+    raise ValueError(f"unknown lr scheduler '{name}'")

@@ -482,17 +482,18 @@ class UViT3DPoseTrainer:
 
     # ------------------------------------------------------------------ training step (ContinuousDiffusion.forward + AdamW)
     def loss_and_grads(self, xs: torch.Tensor, cond: torch.Tensor, t: torch.Tensor, noise: torch.Tensor, masks: Optional[torch.Tensor] = None,
-                       precond_scale: float = 0.125, shift: float = 0.125, sigmoid_bias: float = -1.0, clip_noise: float = 20.0,
-                       cond_drop: Optional[torch.Tensor] = None, reducer=None) -> torch.Tensor:
+                       diffusion=None, cond_drop: Optional[torch.Tensor] = None, reducer=None) -> torch.Tensor:
         """DFoTVideo.training_step for the pose model (dfot_video.py:41-75, continuous_diffusion.py:140-167): per-token levels t in [0,1],
         x_t = alpha x + sigma eps, v = model(x_t, precond * logsnr, cond), sigmoid-weighted eps-space error averaged with the loss masks;
-        then the backward.  cond: processed ray encoding (B,T,180,H,W).  Returns the loss (device scalar)."""
+        then the backward.  cond: processed ray encoding (B,T,180,H,W).  `diffusion`: the DiffusionConfig whose training schedule
+        (logsnr_min/max, training_schedule_shift), loss weighting (loss_sigmoid_bias), precond_scale and clip_noise apply (default: the
+        reference's RE10K values).  Returns the loss (device scalar)."""
+        from .diffusion import DiffusionConfig
+        dcfg = diffusion if diffusion is not None else DiffusionConfig()  # schedule limits / shift / loss weighting / preconditioning from the config
+        precond_scale, clip_noise = float(dcfg.precond_scale), float(dcfg.clip_noise)
         b, tk = xs.shape[:2]
         f = int(xs[0, 0].numel())
-        tt = t.detach().float().cpu()
-        lo, hi = torch.atan(torch.exp(-0.5 * torch.tensor(15.0))), torch.atan(torch.exp(-0.5 * torch.tensor(-15.0)))
-        logsnr = -2 * torch.log(torch.tan(lo + tt * (hi - lo))) + 2 * torch.log(torch.tensor(shift))
-        alpha, sigma, weight = torch.sigmoid(logsnr).sqrt(), torch.sigmoid(-logsnr).sqrt(), torch.sigmoid(sigmoid_bias - logsnr)
+        logsnr, alpha, sigma, weight = dcfg.training_logsnr_tables(t)
         mk = torch.ones(b, tk) if masks is None else masks.detach().float().cpu().view(b, tk)
         tab = torch.stack([alpha, sigma, weight, precond_scale * logsnr, 2.0 * weight * mk / (f * b * tk)]).float().cuda().contiguous()
         x = xs.to(device="cuda", dtype=torch.float32).contiguous()

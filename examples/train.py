@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--accumulate", type=int, default=1)
     ap.add_argument("--lr", type=float, default=5e-5)
+    ap.add_argument("--warmup-steps", type=int, default=10000, help="re10k: linear lr warm-up (constant_with_warmup, realestate10k_video_generation.yaml)")
     ap.add_argument("--save")
     a = ap.parse_args()
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
@@ -84,7 +85,10 @@ def main():
 def train_re10k(a, rank, world):
     """DFoTVideoPose training on the op-by-op UViT3DPose driver: per-token independent continuous levels, sigmoid-weighted v-loss"""
     from bench import RE10K, synth_poses
+    from dfot_amd import parallel
+    from dfot_amd.training import lr_at_step
     from dfot_amd.uvit_train import UViT3DPoseTrainer
+    dcfg = dfot_amd.DiffusionConfig()  # training schedule (cosine, shift 0.125), sigmoid loss weighting (bias -1), precond_scale 0.125
     init = dfot_amd.UViT3DPose(RE10K, x_shape=(3, 256, 256), max_tokens=8)
     if a.ckpt:
         dfot_amd.load_reference_checkpoint(init, a.ckpt)
@@ -101,8 +105,10 @@ def train_re10k(a, rank, world):
         noise = torch.randn(a.batch, 8, 3, 256, 256, generator=g)
         cond = torch.ops.dfot.ray_encoding(synth_poses(a.batch, 8, 7 * step + rank), 256)
         levels, loss_masks = sampling.sample(a.batch, 8, masks, g, training=True)
-        loss = trainer.loss_and_grads(frames, cond, levels, noise, loss_masks)
-        trainer.optimizer_step(lr=a.lr, world_size=world)
+        reducer = parallel.OverlappedGradReducer() if world > 1 else None   # gradient all-reduce overlapped with the backward
+        loss = trainer.loss_and_grads(frames, cond, levels, noise, loss_masks, diffusion=dcfg, reducer=reducer)
+        lr = lr_at_step(step, a.lr, "constant_with_warmup", a.warmup_steps)  # realestate10k_video_generation.yaml:19-22
+        trainer.optimizer_step(lr=lr, world_size=world)
         if rank == 0 and (step % 5 == 0 or step == a.steps - 1):
             print(f"step {step:4d}  loss {float(loss.item()):.4f}  {(time.perf_counter() - t0) / (step + 1) * 1e3:.1f} ms/step", flush=True)
     if a.save and rank == 0:

@@ -368,3 +368,27 @@ def test_stochastic_sampling_plan_vs_reference_run(tag):
     smp._predict_videos(torch.from_numpy(g[f"{tag}_xs"]), 1, torch.from_numpy(g[f"{tag}_conds"]))
     ref_shapes = [list(g[f"{tag}_noise{i}"].shape) for i in range(int(g[f"{tag}_n_noise"]))]
     assert [sh[:len(r)] for sh, r in zip(rec.shapes, ref_shapes)] == ref_shapes and len(rec.shapes) == len(ref_shapes)
+
+
+def test_training_schedule_comes_from_the_config_and_lr_warmup():
+    """the training / validation loss reads logsnr limits, shift, loss-weight bias from DiffusionConfig (and refuses what the
+    engine does not implement); the reference's constant_with_warmup lr schedule"""
+    import torch
+    from dfot_amd.training import lr_at_step
+    t = torch.linspace(0, 1, 9).view(1, 9)
+    base = DiffusionConfig().training_logsnr_tables(t)
+    g = load("schedule.npz")   # train_logsnr: the reference's training_schedule at 33 points of [0, 1]
+    ref = DiffusionConfig().training_logsnr_tables(torch.from_numpy(g["train_t"]))[0].numpy()
+    np.testing.assert_allclose(ref, g["train_logsnr"], rtol=1e-5, atol=1e-5)
+    other = DiffusionConfig(logsnr_min=-10.0, logsnr_max=12.0, training_schedule_shift=0.5, loss_sigmoid_bias=0.0).training_logsnr_tables(t)
+    assert not torch.allclose(base[0], other[0]) and not torch.allclose(base[3], other[3])
+    torch.testing.assert_close(base[1] ** 2 + base[2] ** 2, torch.ones_like(base[1]))
+    with pytest.raises(ValueError):
+        DiffusionConfig(training_schedule_name="cosine_interpolated").training_logsnr_tables(t)
+    with pytest.raises(ValueError):
+        DiffusionConfig(loss_weighting_strategy="min_snr").training_logsnr_tables(t)
+    assert lr_at_step(0, 5e-5, "constant_with_warmup", 10) == pytest.approx(5e-6)
+    assert lr_at_step(9, 5e-5, "constant_with_warmup", 10) == pytest.approx(5e-5)
+    assert lr_at_step(500, 5e-5, "constant_with_warmup", 10) == pytest.approx(5e-5)
+    assert lr_at_step(55, 1.0, "linear", 10, 100) == pytest.approx(0.5)
+    assert lr_at_step(55, 1.0, "cosine", 10, 100) == pytest.approx(0.5)
