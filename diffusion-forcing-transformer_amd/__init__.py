@@ -15,3 +15,4 @@ from .training import ContextTraining, TrainingNoise, training_step_forward  # n
 from .checkpoint import load_reference_checkpoint  # noqa: F401,E402
 from .trainer import DiT3DTrainer  # noqa: F401,E402
 from . import uvit_train  # noqa: F401,E402
+from .vae import VideoVAEDecoder, decode_latents  # noqa: F401,E402

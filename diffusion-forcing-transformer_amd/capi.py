@@ -138,6 +138,11 @@ SIGNATURES = {
     "dfot_op_embed_input_wgrad": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "dfot_op_project_output": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "dfot_op_outgrad_gather": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "dfot_op_groupnorm_scratch_floats": (_L, [_I, _I]),
+    "dfot_op_groupnorm": (_I, [_P, _P, _P, _F, _P, _P, _I, _I, _I, _I, _P]),
+    "dfot_op_frame_shift": (_I, [_P, _P, _I, _I, _L, _I, _P]),
+    "dfot_op_upsample3d": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "dfot_op_softmax_rows": (_I, [_P, _P, _L, _I, _F, _P]),
     "dfot_op_f32_to_bf16": (_I, [_P, _P, _L, _P]),
     "dfot_op_bf16_to_f32": (_I, [_P, _P, _L, _P]),
 }

@@ -448,9 +448,8 @@ int launch_attention(const bf16* q, const bf16* k, const bf16* v, bf16* o, long 
     return launch_attention_v3(q, k, v, o, ldo, batch, heads, n, variant == 6, stream);
   if (variant >= 7 && variant <= 12 && d == 64 && n % 512 == 0)  // 8-wave ping-pong, no running max; odd: priority raised in MFMA phases
     return launch_attention_pp(q, k, v, o, ldo, batch, heads, n, (variant & 1) | (((variant - 7) >> 1) << 1), stream);
-  if (variant >= 14 && variant <= 17 && d == 64 && n % 256 == 0)  // pipelined, no running max; 14..17: 3, 4, 5, 2 vector instructions per MFMA
-    return launch_attention_v5(q, k, v, o, ldo, batch, heads, n, stream, variant == 17 ? 2 : variant - 11);
-  if (variant >= 5 && variant <= 17 && variant != 13) variant = 2;
+  if (variant == 14 && d == 64 && n % 256 == 0) return launch_attention_v5(q, k, v, o, ldo, batch, heads, n, stream);  // pipelined, no running max
+  if ((variant >= 5 && variant <= 12) || variant == 14) variant = 2;
   if (variant == 2) {  // tuned kernel; K/V ring depth chosen by measurement: 3 stages (48 KiB) at d = 64, 2 stages at d = 128
     return d == 64 ? launch_attn_v2<64, 3>(q, k, v, o, ldo, batch, heads, n, stream)
                    : launch_attn_v2<128, 2>(q, k, v, o, ldo, batch, heads, n, stream);

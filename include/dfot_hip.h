@@ -342,6 +342,22 @@ int dfot_op_outgrad_gather(const float* dout, void* dpatch, int bt, int res, int
 int dfot_op_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);
 int dfot_op_bf16_to_f32(const void* src, float* dst, int64_t n, void* stream);
 
+/* ---- VideoVAE decoder pieces (algorithms/vae/video_vae/model.py:130-281, algorithms/vae/common/modules/{conv,resnet,attention,
+ * updownsample,normalize}.py; called from BaseVideoAlgo._decode, algorithms/common/base_pytorch_video_algo.py:600-629).  Channels-last
+ * activations [B][T][H][W][C]; the 3x3(x3) convolutions and 1x1x1 projections go through dfot_op_conv3x3_f32 / dfot_op_gemm_*. ------- */
+/* GroupNorm(32 groups, eps) over the `pixels` (= T*H*W of one video) positions of each of the bt items, then optional SiLU: fp32 -> bf16.
+ * scratch: dfot_op_groupnorm_scratch_floats(bt, pixels) floats.  channels in {128, 256, 512, 1024}. */
+int64_t dfot_op_groupnorm_scratch_floats(int bt, int pixels);
+int dfot_op_groupnorm(const float* x, const float* gamma, const float* beta, float eps, void* out, float* scratch, int bt, int pixels,
+                      int channels, int silu, void* stream);
+/* out[b][t] = x[b][max(t - shift, 0)] (bf16, frame_elems per frame): the first-frame-replicating causal pad of PaddedConv3D (conv.py:104-109) */
+int dfot_op_frame_shift(const void* x, void* out, int batch, int frames, int64_t frame_elems, int shift, void* stream);
+/* fp32 [B][T][H][W][C] -> [B][T'][2H][2W][C]; mode 0: nearest in (H, W), T' = T (SpatialUpsample2x, updownsample.py:77-83); mode 1: the
+ * causal trilinear upsample of Spatial2xTime2x3DUpsample (:143-150), T' = 1 + 2 (T - 1) */
+int dfot_op_upsample3d(const float* x, float* out, int batch, int frames, int h, int w, int channels, int mode, void* stream);
+/* probs[r][:] = softmax(scale * scores[r][:]) (fp32 -> bf16): the frame-wise single-head attention of AttnBlock3D (attention.py:127-129) */
+int dfot_op_softmax_rows(const float* scores, void* probs, int64_t rows, int n, float scale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -239,9 +239,32 @@ def stochastic_samplers(R):
     save("sampler_stochastic.npz", **out)
 
 
+def vae_decode_golden():
+    """The reference's own VideoVAE (default causal module choice, K600 latent geometry: 16 latent channels, 4x temporal / 8x spatial)
+    with seeded random weights decodes seeded latents: `VideoVAE.decode(z, desired_length)` and the `_decode` convention `* 0.5 + 0.5`.
+    Reduced size so that the CPU oracle test stays short: hidden 128 (widths 128/256/512/512 as the default), latent 3 x 16 x 8 -> 9
+    frames of 128 x 64."""
+    VideoVAE = ref_loader.install_vae()
+    torch.manual_seed(0)
+    vae = VideoVAE(hidden_size=128, z_channels=16, embed_dim=16, resolution=128, temporal_length=9, num_res_blocks=2).eval()
+    from oracle import vae as ovae
+    g = torch.Generator().manual_seed(71)
+    sd = {n: ovae.seeded_tensor(n, t.shape) for n, t in vae.state_dict().items() if n.startswith(("decoder.", "post_quant_conv."))}
+    missing, unexpected = vae.load_state_dict(sd, strict=False)
+    assert not unexpected and all(m.startswith(("encoder.", "quant_conv.")) for m in missing)
+    z = torch.randn(2, 16, 3, 16, 8, generator=g)
+    with torch.no_grad():
+        full = vae.decode(z)
+        last = vae.decode(z, 7)
+    assert full.shape == (2, 3, 9, 128, 64) and torch.equal(last, full[:, :, -7:])
+    save("vae_decode.npz", z=z, frames=full, seed=np.array(71), names=np.array(sorted(sd)), shapes=np.array([str(tuple(sd[n].shape)) for n in sorted(sd)]))
+
+
 @torch.no_grad()
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if os.environ.get("ONLY") == "vae":
+        return vae_decode_golden()
     R = ref_loader.install()
     A = R["AttrDict"]
     if os.environ.get("ONLY") == "training_grads_uvit":

@@ -248,3 +248,19 @@ def install():
         "DifferenceDiT3D": diffdit.DifferenceDiT3D, "DifferenceDFoTVideo": diff_algo.DifferenceDFoTVideo,
         "geometry": geo, "AttrDict": AttrDict,
     }
+
+
+def install_vae():
+    """The reference's VideoVAE (algorithms/vae/video_vae/model.py and algorithms/vae/common/modules/*) importable on its own: namespace
+    packages skip algorithms/vae/__init__.py and video_vae/__init__.py (they pull trainers / lightning / lpips), utils.ckpt_utils (wandb /
+    huggingface download helpers, only used by from_pretrained) is a four-name stand-in.  Returns the VideoVAE class."""
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    sys.dont_write_bytecode = True
+    for name, rel in [("algorithms", "algorithms"), ("algorithms.vae", "algorithms/vae"), ("algorithms.vae.video_vae", "algorithms/vae/video_vae"),
+                      ("utils", "utils")]:
+        _ns(name, f"{REF}/{rel}")
+    _mod("utils.ckpt_utils", is_wandb_run_path=lambda p: False, is_hf_path=lambda p: False, wandb_to_local_path=lambda p: p,
+         download_pretrained=lambda p: p)
+    model = importlib.import_module("algorithms.vae.video_vae.model")   # imports algorithms.vae.common(.modules) for real
+    return model.VideoVAE
