@@ -80,6 +80,9 @@ enum GemmVariant {
   // 6-15 % SLOWER than the two-stage BK = 64 loop on every model shape (twice the barriers per K), never auto-picked
   GEMM_DMA4_256x256_BK32 = 11,
   GEMM_DMA4_256x256_W128_BK32 = 12,  // as 11 with 8 waves of 128x64 (42.7 FLOP per LDS byte, 2 waves per SIMD): equal to variant 7, slower than 4
+  // 256x144 tile (12 waves of 64x48), 2 stages, dense A, plain epilogues: N = multiples of 144 (576, 1152) give M/256 x N/144 tiles =
+  // exactly one per CU for the level-2 out-projection (256) and, with two K slices, for the level-3 one (128 x 2)
+  GEMM_DMA_256x144 = 13,
   GEMM_AUTO = -1      // pick by shape (gemm_pick_variant)
 };
 int gemm_pick_variant(int amode, int m, int n, int k);

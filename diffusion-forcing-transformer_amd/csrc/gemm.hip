@@ -16,6 +16,10 @@
 namespace dfot {
 
 constexpr int BK = 64;
+// a wave owns WTM x 64 of the tile, or WTM x 48 when the tile width is a multiple of 48 but not of 64 (BN_T = 144: N = 576 and
+// 1152 split into 4 / 8 column tiles, so M / 256 x N / 144 = 256 / 128 workgroups for the two out-projections of the model)
+constexpr int wave_cols(int bn) { return bn % 64 == 0 ? 64 : 48; }
+constexpr int tile_threads(int bm, int bn, int wtm, int ks) { return (bm / wtm) * (bn / wave_cols(bn)) * 64 * ks; }
 constexpr int EP_LD = 68;  // fp32 row stride of the per-wave epilogue scratch (64 + 4: rows shift by 4 banks)
 
 // BM_T = 128: 256 threads (waves 2x2), BM_T = 256: 512 threads (waves 4x2); every wave owns a 64x64 output block.
@@ -46,8 +50,12 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int tile_inde
   constexpr int CPR = BKT / 8;                  // 16-byte chunks per LDS row
   constexpr int RPI = 64 / CPR;                 // rows staged by one wave instruction (1 KiB)
   constexpr int ROWB = BKT * 2;                 // bytes per LDS row
-  constexpr int MI = WTM / 16;                  // 16-row MFMA tiles per wave along M (wave tile = WTM x 64)
-  constexpr int WN = BN_T / 64;                 // waves along N
+  constexpr int MI = WTM / 16;                  // 16-row MFMA tiles per wave along M (wave tile = WTM x WTN)
+  constexpr int WTN = wave_cols(BN_T);          // columns per wave: 64, or 48 for BN_T = 144
+  constexpr int NI = WTN / 16;                  // 16-column MFMA tiles per wave along N
+  constexpr int WN = BN_T / WTN;                // waves along N
+  static_assert(WTN == 64 || (EPI == E_F32 || EPI == E_BF16), "48-column wave tiles: plain epilogues only");
+  static_assert(WTN == 64 || KS == 1, "48-column wave tiles: no intra-workgroup split-K");
   constexpr int NW = (BM_T / WTM) * WN;         // waves per k-group
   constexpr int NT = NW * 64;                   // threads per k-group
   // one wave instruction stages 8 rows (1 KiB) of a tile; AINS/WINS of them per k-tile are dealt round-robin to the NW
@@ -189,11 +197,11 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int tile_inde
     for (int i = 0; i < WCH; ++i) *reinterpret_cast<bf16x8*>(sw + (NW * i + wave) * 1024 + lane * 16) = rw[i];
   };
 
-  f32x4 acc[MI][4];
+  f32x4 acc[MI][NI];
 #pragma unroll
   for (int i = 0; i < MI; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int frow = lane & 15, fk = lane >> 4;
   auto compute = [&](int stage) {
@@ -201,7 +209,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int tile_inde
     const char* sw = sa + A_BYTES;
 #pragma unroll
     for (int ks = 0; ks < BKT / 32; ++ks) {
-      bf16x8 af[MI], wf[4];
+      bf16x8 af[MI], wf[NI];
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi) {
         const int r = wm * WTM + mi * 16 + frow;
@@ -209,15 +217,15 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int tile_inde
         af[mi] = *reinterpret_cast<const bf16x8*>(sa + r * ROWB + pos * 16);
       }
 #pragma unroll
-      for (int ni = 0; ni < 4; ++ni) {
-        const int r = wn * 64 + ni * 16 + frow;
+      for (int ni = 0; ni < NI; ++ni) {
+        const int r = wn * WTN + ni * 16 + frow;
         const int pos = (ks * 4 + fk) ^ swz(r);
         wf[ni] = *reinterpret_cast<const bf16x8*>(sw + r * ROWB + pos * 16);
       }
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni)
+        for (int ni = 0; ni < NI; ++ni)
           acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mi], wf[ni], acc[mi][ni], 0, 0, 0);
     }
   };
@@ -308,7 +316,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int tile_inde
   // (with split-K the scratch sits behind the reduction area, which other waves of group 0 may still be reading)
   float* ep = reinterpret_cast<float*>(smem_all) + (KS == 2 ? NW * MI * 16 * 64 : 0) + wave * (16 * EP_LD);
   const int colq = lane & 15, rowq = (lane >> 4) * 4;
-  const int nw = n0 + wn * 64;
+  const int nw = n0 + wn * WTN;
   [[maybe_unused]] const bool has_res = g.resid != nullptr;
   [[maybe_unused]] const bool has_gate = g.gate != nullptr;
   // fused GroupNorm partial sums of this wave's 64 rows: (gsum,gsq) = lane's first 4 columns, (gsum2,gsq2) = next 4
@@ -316,7 +324,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int tile_inde
   // lane geometry of the read-back: fp32 output = 4 columns x rows p*4 + lane/16; bf16 outputs = 8 columns x rows p*8 + lane/8
   const int cw = EPI == E_F32 ? (lane & 15) * 4 : (lane & 7) * 8;
   const int col = nw + cw;
-  const bool live = col < g.N;  // N is a multiple of the lane's column count, so a lane is entirely in or out
+  const bool live = col < g.N && cw < WTN;  // N is a multiple of the lane's column count, so a lane is entirely in or out
   f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = {0.f, 0.f, 0.f, 0.f};
   [[maybe_unused]] const bool bias2d = g.bias_rows > 0;  // bias[(row % bias_rows)][col] (MatrixAttention qkv_bias / proj_bias)
   if (g.bias && live && !bias2d && kslice == 0) {  // split-K: slice 0 alone adds the bias
@@ -333,7 +341,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int tile_inde
         const long frame = row / (unsigned)g.tr_rows;
         const int rin = (int)(row % (unsigned)g.tr_rows);
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) {
+        for (int ni = 0; ni < NI; ++ni) {
           const int c = nw + ni * 16 + colq;
           if (c < g.N) {
             bf16x4 o;
@@ -349,7 +357,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int tile_inde
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
-    for (int ni = 0; ni < 4; ++ni)
+    for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
       for (int j = 0; j < 4; ++j) ep[(rowq + j) * EP_LD + ni * 16 + colq] = acc[mi][ni][j];
     const long mw = (long)m0 + wm * WTM + mi * 16;
@@ -590,7 +598,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int tile_inde
 // One tile per workgroup.  (Wrapping this body in a tile loop costs the 16-wave kernels, which sit at the 128-VGPR cap, up to 35
 // spilled VGPRs -- the fused QKV GEMM went from 96.7 to 117.6 us -- so the loop lives in a separate kernel below.)
 template <int BM_T, int BN_T, int WTM, int NST, int AMODE, int EPI, bool DMA, int KS = 1, int BKT = BK>
-__global__ __launch_bounds__((BM_T / WTM) * (BN_T / 64) * 64 * KS) void gemm_kernel(GemmArgs g) {
+__global__ __launch_bounds__(tile_threads(BM_T, BN_T, WTM, KS)) void gemm_kernel(GemmArgs g) {
   gemm_tile<BM_T, BN_T, WTM, NST, AMODE, EPI, DMA, KS, BKT>(g, blockIdx.x, gridDim.x);
 }
 
@@ -598,7 +606,7 @@ __global__ __launch_bounds__((BM_T / WTM) * (BN_T / 64) * 64 * KS) void gemm_ker
 // a CU, and the stores of one tile drain while the next tile's first loads are in flight.  gridDim.x is a multiple of 8, so a
 // tile keeps the XCD its index implies (xcd_remap).  Only instantiated for kernels of <= 12 waves (>= 168 VGPRs per wave).
 template <int BM_T, int BN_T, int WTM, int NST, int AMODE, int EPI, bool DMA, int KS = 1, int BKT = BK>
-__global__ __launch_bounds__((BM_T / WTM) * (BN_T / 64) * 64 * KS) void gemm_kernel_persistent(GemmArgs g, int tile_count) {
+__global__ __launch_bounds__(tile_threads(BM_T, BN_T, WTM, KS)) void gemm_kernel_persistent(GemmArgs g, int tile_count) {
   for (int tile = blockIdx.x; tile < tile_count; tile += gridDim.x) {
     gemm_tile<BM_T, BN_T, WTM, NST, AMODE, EPI, DMA, KS, BKT>(g, tile, tile_count);
     if (tile + (int)gridDim.x < tile_count) __syncthreads();  // the next tile's staging re-uses this tile's epilogue scratch
@@ -607,7 +615,7 @@ __global__ __launch_bounds__((BM_T / WTM) * (BN_T / 64) * 64 * KS) void gemm_ker
 
 template <int BM_T, int BN_T, int WTM, int NST, int AMODE, int EPI, bool DMA, int KS = 1, int BKT = BK>
 static int launch_t(const GemmArgs& g, hipStream_t stream) {
-  constexpr int nthreads = (BM_T / WTM) * (BN_T / 64) * 64 * KS;
+  constexpr int nthreads = tile_threads(BM_T, BN_T, WTM, KS);
   constexpr int stage_lds = KS * NST * (BM_T + BN_T) * BKT * 2;
   constexpr int ep_lds = (nthreads / 64) * 16 * EP_LD * 4 + 2 * (nthreads / 64) * 16 * 4 +
                          (KS == 2 ? (nthreads / 128) * (WTM / 16) * 16 * 64 * 4 : 0);
@@ -660,6 +668,12 @@ static int launch_v(int variant, const GemmArgs& g, hipStream_t s) {
     case GEMM_DMA_256x192:
       if constexpr (AMODE != A_DENSE) break;
       else return launch_t<256, 192, 64, 2, AMODE, EPI, true>(g, s);
+    case GEMM_DMA_256x144:
+      if constexpr (AMODE != A_DENSE || (EPI != E_F32 && EPI != E_BF16)) break;
+      else {
+        if (g.gn_part) break;
+        return launch_t<256, 144, 64, 2, AMODE, EPI, true>(g, s);
+      }
     case GEMM_DMA4_256x256_BK32:
       if constexpr (AMODE != A_DENSE) break;
       else return launch_t<256, 256, 64, 4, AMODE, EPI, true, 1, 32>(g, s);
@@ -720,7 +734,7 @@ int launch_gemm(int amode, int epi, int variant, const GemmArgs& g, hipStream_t 
   if (variant == GEMM_DMA_128_KS2 && epi == E_QKV) variant = GEMM_DMA_128;  // the QKV epilogue has workgroup barriers
   if (variant == GEMM_DMA_128x192 && epi == E_QKV) variant = GEMM_DMA_128;
   if (variant == GEMM_DMA_256x192 && epi == E_QKV) variant = GEMM_DMA_256x256;  // its head pairing needs 128-aligned tiles
-  const int bm = variant == GEMM_DMA_512x128 ? 512 : (variant == GEMM_DMA3_256 || variant == GEMM_DMA_256x256 || variant == GEMM_DMA_256x128 || variant == GEMM_DMA_256x256_W128 || variant == GEMM_DMA_256x192 || variant == GEMM_DMA4_256x256_BK32 || variant == GEMM_DMA4_256x256_W128_BK32) ? 256 : 128;
+  const int bm = variant == GEMM_DMA_512x128 ? 512 : (variant == GEMM_DMA3_256 || variant == GEMM_DMA_256x256 || variant == GEMM_DMA_256x128 || variant == GEMM_DMA_256x256_W128 || variant == GEMM_DMA_256x192 || variant == GEMM_DMA4_256x256_BK32 || variant == GEMM_DMA4_256x256_W128_BK32 || variant == GEMM_DMA_256x144) ? 256 : 128;
   DFOT_REQUIRE(g.M > 0 && g.M % bm == 0, DFOT_ERR_SHAPE, "gemm: M=%d must be a positive multiple of %d", g.M, bm);
   DFOT_REQUIRE(g.K > 0 && g.K % BK == 0, DFOT_ERR_SHAPE, "gemm: K=%d must be a positive multiple of %d", g.K, BK);
   DFOT_REQUIRE(g.N > 0 && g.N % (epi == E_F32 ? 4 : 8) == 0, DFOT_ERR_SHAPE, "gemm: N=%d must be a multiple of %d", g.N, epi == E_F32 ? 4 : 8);

@@ -109,6 +109,8 @@ struct dfot_uvit_s {
   int cond_batch = 0;            // batch the pose caches were built for (0 = none)
   bf16 *acond = nullptr, *emb[4] = {nullptr, nullptr, nullptr, nullptr}, *s1 = nullptr, *hbf = nullptr,
        *cat = nullptr, *q = nullptr, *k = nullptr, *v = nullptr;
+  float* out_part = nullptr;  // two fp32 partial slices of an out-projection (K split, see run_tr_block)
+  size_t out_part_elems = 0;  // its capacity in floats: the split path is taken only when 2 * M * N fits
   int last_batch = 0;
   int gemm_variant = GEMM_AUTO;
   int attn_variant = 2;
@@ -389,6 +391,16 @@ static int run_res_block(dfot_uvit_s* h, const ResW& w, int lvl, int bt, hipStre
   return DFOT_OK;
 }
 
+// x += bias + slice0 + slice1 (fp32, 4 elements per thread): the reduce pass of the two-slice out-projection
+__global__ void out_reduce_kernel(float* __restrict__ x, const float* __restrict__ bias, const float* __restrict__ s0,
+                                  const float* __restrict__ s1, long total4, int cq) {
+  typedef __attribute__((ext_vector_type(4))) float f4;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total4) return;
+  const f4 b = reinterpret_cast<const f4*>(bias)[i % cq];
+  reinterpret_cast<f4*>(x)[i] += b + reinterpret_cast<const f4*>(s0)[i] + reinterpret_cast<const f4*>(s1)[i];
+}
+
 static int run_tr_block(dfot_uvit_s* h, const TrW& w, int lvl, int batch, hipStream_t s) {
   const int c = w.c, rr = h->r[lvl], n = h->T * rr * rr, d = c / h->heads;
   const int m = batch * n;
@@ -417,6 +429,19 @@ static int run_tr_block(dfot_uvit_s* h, const TrW& w, int lvl, int batch, hipStr
   // A/B: K split over workgroups where the out-projection has fewer tiles than CUs (level 3: 96 tiles of 256x192)
   static const int l3_split = tuning_flag("UVIT_OUT_KSPLIT", 1);
   if (l3_split > 1 && (long)(m / 256) * ((c + 191) / 192) < 200) o.ksplit = l3_split;
+  // level 3 at small model batch: 256x144 tiles give M/256 x N/144 = 128 workgroups for 256 CUs; two K slices into partial
+  // buffers make it 256, and one pass adds slices + bias into the fp32 residual stream (out_reduce_kernel)
+  static const int split144 = tuning_flag("UVIT_OUT_SPLIT144", 1);
+  if (split144 && h->gemm_variant == GEMM_AUTO && h->out_part && (size_t)2 * m * c <= h->out_part_elems && m % 256 == 0 && c % 144 == 0 &&
+      (long)(m / 256) * (c / 144) * 2 <= 256 && (5 * c / 64) >= 8) {
+    GemmArgs p2 = o;
+    p2.bias = nullptr; p2.resid = nullptr; p2.out_f32 = h->out_part; p2.ksplit = 2; p2.slice_stride = (long)m * c;
+    if ((rc = launch_gemm(A_DENSE, E_F32, GEMM_DMA_256x144, p2, s))) return rc;
+    const long total4 = (long)m * c / 4;
+    hipLaunchKernelGGL(out_reduce_kernel, dim3(cdiv(total4, 256)), dim3(256), 0, s, x, w.b_out, h->out_part, h->out_part + (long)m * c, total4, c / 4);
+    DFOT_CHECK_HIP(hipGetLastError());
+    return DFOT_OK;
+  }
   return launch_gemm(A_DENSE, E_F32, h->gemm_variant, o, s);
 }
 
@@ -563,6 +588,8 @@ int dfot_uvit_reserve(dfot_uvit_t h, int max_batch) {
   h->ws_owned.clear();
   h->ws_bytes = 0;
   h->max_batch = 0;
+  h->out_part = nullptr;
+  h->out_part_elems = 0;
   const size_t bt = (size_t)max_batch * h->T;
   size_t pix[4];
   for (int l = 0; l < 4; ++l) pix[l] = (size_t)h->r[l] * h->r[l];
@@ -622,6 +649,11 @@ int dfot_uvit_reserve(dfot_uvit_t h, int max_batch) {
   if ((rc = dev_alloc(h, &h->q, mc, true))) return rc;
   if ((rc = dev_alloc(h, &h->k, mc, true))) return rc;
   if ((rc = dev_alloc(h, &h->v, mc, true))) return rc;
+  {  // both transformer levels may take the two-slice out-projection at small sizes: room for the larger of their outputs, twice
+    const size_t e2 = bt * pix[2] * h->ch[2], e3 = bt * pix[3] * h->ch[3];
+    h->out_part_elems = 2 * (e2 > e3 ? e2 : e3);
+    if ((rc = dev_alloc(h, &h->out_part, h->out_part_elems, true))) return rc;
+  }
   // key-split partial buffers of the level-2 attention's balanced tail, for every batch this workspace can serve (so that
   // nothing is allocated inside forward / stream capture)
   for (int b = 1; b <= max_batch; ++b)
