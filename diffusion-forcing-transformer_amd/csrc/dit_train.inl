@@ -262,6 +262,69 @@ __global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16* __restrict
   for (long r = r0; r < r0 + 128 && r < rows; ++r) acc += bf2f(src[r * ld + c]);
   atomicAdd(out + c, acc);
 }
+// the streaming form: a workgroup owns 128 rows x (LANES * 8) columns; LANES lanes cover one row with 16-byte loads, the 256 / LANES
+// row groups take alternate rows (8 independent loads in flight per thread), the groups are summed through LDS and the workgroup adds
+// its LANES * 8 column sums once.  n, ld multiples of 8, src 16-byte aligned (launcher)
+template <int LANES>
+__global__ __launch_bounds__(256) void colsum_bf16_kernel8(const bf16* __restrict__ src, float* __restrict__ out, long rows, int n, long ld,
+                                                           int iters) {
+  constexpr int GROUPS = 256 / LANES;
+  __shared__ float sm[GROUPS][LANES * 8 + 4];
+  const int lane = threadIdx.x % LANES, grp = threadIdx.x / LANES;
+  const int c = (blockIdx.x * LANES + lane) * 8;
+  float acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+  if (c < n) {
+    const bf16* p = src + c;
+    for (int it = 0; it < iters; ++it) {
+      const long r0 = ((long)blockIdx.y * iters + it) * 128;
+      if (r0 + 128 <= rows) {
+        bf16x8 v[128 / GROUPS];
+#pragma unroll
+        for (int i = 0; i < 128 / GROUPS; ++i) v[i] = *reinterpret_cast<const bf16x8*>(p + (r0 + grp + (long)i * GROUPS) * ld);
+#pragma unroll
+        for (int i = 0; i < 128 / GROUPS; ++i)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) acc[j] += bf2f(v[i][j]);
+      } else {
+        for (long r = r0 + grp; r < rows; r += GROUPS) {
+          const bf16x8 v = *reinterpret_cast<const bf16x8*>(p + r * ld);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) acc[j] += bf2f(v[j]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) sm[grp][lane * 8 + j] = acc[j];
+  __syncthreads();
+  if (threadIdx.x < LANES * 8) {
+    const int cc = blockIdx.x * LANES * 8 + threadIdx.x;
+    if (cc < n) {
+      float t = 0.f;
+#pragma unroll
+      for (int g = 0; g < GROUPS; ++g) t += sm[g][threadIdx.x];
+      atomicAdd(out + cc, t);
+    }
+  }
+}
+static void launch_colsum_bf16(const bf16* src, float* out, long rows, int n, long ld, hipStream_t s) {
+  if (n % 8 == 0 && ld % 8 == 0 && ((uintptr_t)src & 15) == 0) {
+    // every workgroup ends in LANES * 8 atomics on the same addresses: with more than ~2048 row blocks per column block the atomics of
+    // one address (serialised in L2) outlast the streaming, so long inputs give a workgroup several 128-row blocks
+    const int xb = n <= 128 ? cdiv(n, 128) : cdiv(n, 256);
+    const long yb = cdiv(rows, 128);
+    int iters = 1;
+    while (iters < 16 && yb / iters * xb > 2048) iters *= 2;
+    if (n <= 128)
+      hipLaunchKernelGGL(colsum_bf16_kernel8<16>, dim3(xb, cdiv(yb, iters)), dim3(256), 0, s, src, out, rows, n, ld, iters);
+    else
+      hipLaunchKernelGGL(colsum_bf16_kernel8<32>, dim3(xb, cdiv(yb, iters)), dim3(256), 0, s, src, out, rows, n, ld, iters);
+  } else {
+    hipLaunchKernelGGL(colsum_bf16_kernel, dim3(cdiv(n, 256), cdiv(rows, 128)), dim3(256), 0, s, src, out, rows, n, ld);
+  }
+}
 
 // gradient of the unpatchified output [BT][C][H][W] gathered per token: dyp [rows][64] bf16 (columns >= oc stay zero) and its
 // transpose dyt [.. >= oc rows][rows] (rows >= oc stay zero)
@@ -280,44 +343,90 @@ __global__ void final_gather_kernel(const float* __restrict__ dout, bf16* __rest
   dyt[(long)o * rows + row] = v;
 }
 
-// PatchEmbed weight gradient: dW[o][kk] += sum_rows dx0[row][o] patch[row][kk], db[o] += sum_rows dx0[row][o]; 64 rows per workgroup
+// PatchEmbed weight gradient: dW[o][kk] += sum_rows dx0[row][o] patch[row][kk], db[o] += sum_rows dx0[row][o].  One workgroup owns
+// 64 * chunks consecutive rows, staged 64 at a time through LDS; for kdim <= 16 (every model here: 3..4 channels x 2x2 patches) the
+// products stay in registers over all chunks, so a workgroup issues hidden * (kdim + 1) atomics once (a 64-row workgroup per launch
+// put 25 M atomics on the 1536 addresses of the 128-wide RE10K embedding: 4.9 ms).  hidden < 256 dividing 256: the 256 / hidden
+// thread groups take alternate rows.
 __global__ __launch_bounds__(256) void pe_wgrad_kernel(const float* __restrict__ dx0, const float* __restrict__ x, float* __restrict__ dW,
-                                                       float* __restrict__ db, int c, int hh, int ww, int ps, int hidden, long rows) {
+                                                       float* __restrict__ db, int c, int hh, int ww, int ps, int hidden, long rows, int chunks) {
   extern __shared__ float patch[];  // [64][kdim]
   const int gh = hh / ps, gw = ww / ps, kdim = c * ps * ps;
-  const long row0 = (long)blockIdx.y * 64;
-  for (int i = threadIdx.x; i < 64 * kdim; i += 256) {
-    const long row = row0 + i / kdim;
-    const int kk = i % kdim;
-    float v = 0.f;
-    if (row < rows) {
-      const long bt = row / (gh * gw);
-      const int g = (int)(row % (gh * gw)), gy = g / gw, gx = g % gw;
-      const int ci = kk / (ps * ps), py = (kk / ps) % ps, px = kk % ps;
-      v = x[((bt * c + ci) * hh + gy * ps + py) * ww + gx * ps + px];
+  const int nsub = (hidden < 256 && 256 % hidden == 0) ? 256 / hidden : 1;
+  const int sub = nsub > 1 ? threadIdx.x / hidden : 0;
+  const int o = nsub > 1 ? threadIdx.x % hidden : blockIdx.x * 256 + threadIdx.x;
+  const bool live = o < hidden;
+  const bool keep = kdim <= 16;  // accumulate over the chunks in registers
+  float acc[16], bsum = 0.f;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+  for (int ch = 0; ch < chunks; ++ch) {
+    const long row0 = ((long)blockIdx.y * chunks + ch) * 64;
+    if (row0 >= rows) break;
+    __syncthreads();
+    for (int i = threadIdx.x; i < 64 * kdim; i += 256) {
+      const long row = row0 + i / kdim;
+      const int kk = i % kdim;
+      float v = 0.f;
+      if (row < rows) {
+        const long bt = row / (gh * gw);
+        const int g = (int)(row % (gh * gw)), gy = g / gw, gx = g % gw;
+        const int ci = kk / (ps * ps), py = (kk / ps) % ps, px = kk % ps;
+        v = x[((bt * c + ci) * hh + gy * ps + py) * ww + gx * ps + px];
+      }
+      patch[i] = v;
     }
-    patch[i] = v;
+    __syncthreads();
+    if (!live) continue;
+    for (int k0 = 0; k0 < kdim; k0 += 16) {
+      if (!keep) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+      }
+      if (row0 + 64 <= rows && (64 / nsub) % 8 == 0) {
+        // whole chunk: eight gradient loads in flight per thread
+        for (int r8 = 0; r8 < 64 / nsub; r8 += 8) {
+          float g[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) g[u] = dx0[(row0 + sub + (r8 + u) * nsub) * hidden + o];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int r = sub + (r8 + u) * nsub;
+            if (k0 == 0) bsum += g[u];
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+              if (k0 + j < kdim) acc[j] += g[u] * patch[r * kdim + k0 + j];
+          }
+        }
+      } else {
+        for (int r = sub; r < 64 && row0 + r < rows; r += nsub) {
+          const float g = dx0[(row0 + r) * hidden + o];
+          if (k0 == 0) bsum += g;
+#pragma unroll
+          for (int j = 0; j < 16; ++j)
+            if (k0 + j < kdim) acc[j] += g * patch[r * kdim + k0 + j];
+        }
+      }
+      if (!keep) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+          if (k0 + j < kdim) atomicAdd(dW + (long)o * kdim + k0 + j, acc[j]);
+      }
+    }
   }
-  __syncthreads();
-  const int o = blockIdx.x * 256 + threadIdx.x;
-  if (o >= hidden) return;
-  float bsum = 0.f;
-  for (int k0 = 0; k0 < kdim; k0 += 16) {
-    float acc[16];
-#pragma unroll
-    for (int j = 0; j < 16; ++j) acc[j] = 0.f;
-    for (int r = 0; r < 64 && row0 + r < rows; ++r) {
-      const float g = dx0[(row0 + r) * hidden + o];
-      if (k0 == 0) bsum += g;
-#pragma unroll
-      for (int j = 0; j < 16; ++j)
-        if (k0 + j < kdim) acc[j] += g * patch[r * kdim + k0 + j];
-    }
+  if (!live) return;
+  if (keep) {
 #pragma unroll
     for (int j = 0; j < 16; ++j)
-      if (k0 + j < kdim) atomicAdd(dW + (long)o * kdim + k0 + j, acc[j]);
+      if (j < kdim) atomicAdd(dW + (long)o * kdim + j, acc[j]);
   }
   atomicAdd(db + o, bsum);
+}
+static void launch_pe_wgrad(const float* dx0, const float* x, float* dW, float* db, int c, int hh, int ww, int ps, int hidden, long rows, hipStream_t s) {
+  const int kdim = c * ps * ps;
+  const int chunks = rows >= 64L * 16 * 512 ? 16 : (rows >= 64L * 4 * 512 ? 4 : 1);  // keep >= 512 workgroups
+  hipLaunchKernelGGL(pe_wgrad_kernel, dim3(cdiv(hidden, 256), cdiv(rows, 64L * chunks)), dim3(256), 64 * kdim * sizeof(float), s, dx0, x, dW, db, c, hh, ww,
+                     ps, hidden, rows, chunks);
 }
 
 // ---- MatrixDiTBlock (factorized matrix attention, variant 1) ------------------------------------------------------------
@@ -1078,7 +1187,7 @@ int dfot_dit_train_backward(dfot_dit_train_t h, const float* d_out, void* stream
   DFOT_CHECK_HIP(hipMemsetAsync(h->dyt, 0, (size_t)256 * rows * sizeof(bf16), s));
   hipLaunchKernelGGL(final_gather_kernel, dim3(cdiv(rows * h->oc, 256)), dim3(256), 0, s, d_out, h->dyp, h->dyt, rows, c.in_channels, c.height,
                      c.width, c.patch_size);
-  hipLaunchKernelGGL(colsum_bf16_kernel, dim3(1, cdiv(rows, 128)), dim3(256), 0, s, h->dyp, G + h->o_fin_b, rows, h->oc, 64L);
+  launch_colsum_bf16(h->dyp, G + h->o_fin_b, rows, h->oc, 64L, s);
   DFOT_CHECK_HIP(hipGetLastError());
   float *dY = h->dX, *dN = h->dX2;  // gradient of the current block's output / scratch for the next one
   if ((rc = launch_ln_mod(h->x_fin, dN, h->mfin, h->mod_table, h->idx, h->ldt, h->mod_final, hd, P, (int)rows, c.eps, frames - 1, s))) return rc;
@@ -1126,7 +1235,7 @@ int dfot_dit_train_backward(dfot_dit_train_t h, const float* d_out, void* stream
       if ((rc = tr_gemm_bf16(h->da, hd, b.w_fc2T, (int)rows, mh, hd, nullptr, h->dh, mh, s))) return rc;        // dh = dy W2
       if ((rc = wgrad(h->da, hd, b.hact, mh, rows, G + b.o_fc2_w))) return rc;                                   // dW2 = dy^T h
       hipLaunchKernelGGL(gelu_kernel, dim3(cdiv(rows * mh / 8, 256)), dim3(256), 0, s, b.u, (bf16*)nullptr, h->dh, rows * mh / 8);  // du
-      hipLaunchKernelGGL(colsum_bf16_kernel, dim3(cdiv(mh, 256), cdiv(rows, 128)), dim3(256), 0, s, h->dh, G + b.o_fc1_b, rows, mh, (long)mh);
+      launch_colsum_bf16(h->dh, G + b.o_fc1_b, rows, mh, (long)mh, s);
       DFOT_CHECK_HIP(hipGetLastError());
       if ((rc = tr_gemm_f32(h->dh, mh, b.w_fc1T, (int)rows, hd, mh, dY, hd, dY, s))) return rc;                    // dm2 = dY + du W1
       if ((rc = wgrad(h->dh, mh, b.m2, hd, rows, G + b.o_fc1_w))) return rc;                                    // dW1 = du^T m2
@@ -1140,7 +1249,7 @@ int dfot_dit_train_backward(dfot_dit_train_t h, const float* d_out, void* stream
       if ((rc = launch_attention_bwd(b.q, b.k, b.v, h->dO, hd, b.lse, h->delta, h->dq, h->dk, h->dv, nseq, c.num_heads, seq, h->d, s))) return rc;
       hipLaunchKernelGGL(qkv_grad_pack_kernel, dim3(cdiv(rows * (3 * hd / 8), 256)), dim3(256), 0, s, h->dq, h->dk, h->dv,
                          facmat ? (const float*)nullptr : h->rope_cs, h->dqkv, rows, seq, c.num_heads, h->d, h->dstride);
-      hipLaunchKernelGGL(colsum_bf16_kernel, dim3(cdiv(3 * hd, 256), cdiv(rows, 128)), dim3(256), 0, s, h->dqkv, G + b.o_qkv_b, rows, 3 * hd, (long)3 * hd);
+      launch_colsum_bf16(h->dqkv, G + b.o_qkv_b, rows, 3 * hd, (long)3 * hd, s);
       DFOT_CHECK_HIP(hipGetLastError());
       if ((rc = tr_gemm_f32(h->dqkv, 3 * hd, b.w_qkvT, (int)rows, hd, 3 * hd, dY, hd, dY, s))) return rc;       // dm = dY + dqkv Wqkv (in place)
       if ((rc = wgrad(h->dqkv, 3 * hd, b.m, hd, rows, G + b.o_qkv_w))) return rc;  // dWqkv = dqkv^T m
@@ -1187,8 +1296,7 @@ int dfot_dit_train_backward(dfot_dit_train_t h, const float* d_out, void* stream
   }
 
   // ---- patch embedding ----
-  hipLaunchKernelGGL(pe_wgrad_kernel, dim3(cdiv(hd, 256), cdiv(rows, 64)), dim3(256), 64 * h->kpatch * sizeof(float), s, dY, h->x_saved,
-                     G + h->o_pe_w, G + h->o_pe_b, c.in_channels, c.height, c.width, c.patch_size, hd, rows);
+  launch_pe_wgrad(dY, h->x_saved, G + h->o_pe_w, G + h->o_pe_b, c.in_channels, c.height, c.width, c.patch_size, hd, rows, s);
   DFOT_CHECK_HIP(hipGetLastError());
 
   // ---- modulation Linears: table = SiLU(c) W_mod^T + b_mod over the frames ----

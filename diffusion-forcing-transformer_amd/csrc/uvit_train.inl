@@ -73,7 +73,7 @@ int conv3_backward(const bf16* x, const bf16* dy, const bf16* w_dgrad, float* dx
     if ((rc = launch_gemm(A_CONV3, E_F32, GEMM_AUTO, g, s))) return rc;
   }
   if (db) {
-    hipLaunchKernelGGL(colsum_bf16_kernel, dim3(cdiv(co, 256), cdiv(pix, 128)), dim3(256), 0, s, dy, db, pix, co, (long)co);
+    launch_colsum_bf16(dy, db, pix, co, (long)co, s);
     DFOT_CHECK_HIP(hipGetLastError());
   }
   // weight gradient: one token-axis GEMM per tap, both operands read in place (wgrad.hip conv mode: x rows shifted by the tap, zero outside
@@ -647,7 +647,7 @@ int dfot_op_colsum_bf16(const void* src, int ld, float* out, int64_t rows, int n
   DFOT_REQUIRE(src && out, DFOT_ERR_ARG, "op_colsum_bf16: null argument");
   hipStream_t s = (hipStream_t)stream;
   DFOT_CHECK_HIP(hipMemsetAsync(out, 0, (size_t)n * sizeof(float), s));
-  hipLaunchKernelGGL(colsum_bf16_kernel, dim3(cdiv(n, 256), cdiv(rows, 128)), dim3(256), 0, s, (const bf16*)src, out, (long)rows, n, (long)ld);
+  launch_colsum_bf16((const bf16*)src, out, (long)rows, n, (long)ld, s);
   DFOT_CHECK_HIP(hipGetLastError());
   return DFOT_OK;
 }
@@ -720,41 +720,67 @@ __global__ void gn_silu_fwd_kernel(const float* __restrict__ x, const float* __r
 }
 
 // dx[bt][2y+a][2x+b][c] += dp[bt][y][x][c] / 4   (adjoint of the 2x2 average pool; dx fp32 [BT][H][W][C], dp fp32 [BT][H/2][W/2][C])
+// 4 channels per thread (C % 4 == 0: launcher); total = elements / 4
 __global__ void pool2_bwd_kernel(const float* __restrict__ dp, float* __restrict__ dx, long total, int H, int W, int C) {
+  typedef __attribute__((ext_vector_type(4))) float f4;
   const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= total) return;
-  const int c = (int)(e % C);
-  const long pix = e / C;
+  const int cq = C / 4;
+  const int c = (int)(e % cq) * 4;
+  const long pix = e / cq;
   const int x = (int)(pix % W), y = (int)((pix / W) % H);
   const long bt = pix / ((long)W * H);
-  dx[e] += 0.25f * dp[((bt * (H / 2) + y / 2) * (W / 2) + x / 2) * C + c];
+  const f4 v = *reinterpret_cast<const f4*>(dp + ((bt * (H / 2) + y / 2) * (W / 2) + x / 2) * C + c);
+  *reinterpret_cast<f4*>(dx + pix * C + c) += v * 0.25f;
 }
 // ds[bt][y][x][c] = sum of the 2x2 block of dy (adjoint of the nearest-neighbour upsample; dy fp32 [BT][H][W][C])
+// 4 channels per thread (C % 4 == 0: launcher)
 __global__ void upsample_bwd_kernel(const float* __restrict__ dy, float* __restrict__ ds, long total, int H, int W, int C) {
+  typedef __attribute__((ext_vector_type(4))) float f4;
   const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= total) return;  // total = BT * (H/2) * (W/2) * C
-  const int c = (int)(e % C);
-  const long pix = e / C;
+  if (e >= total) return;  // total = BT * (H/2) * (W/2) * C / 4
+  const int cq = C / 4;
+  const int c = (int)(e % cq) * 4;
+  const long pix = e / cq;
   const int x = (int)(pix % (W / 2)), y = (int)((pix / (W / 2)) % (H / 2));
   const long bt = pix / ((long)(W / 2) * (H / 2));
   const float* b = dy + ((bt * H + 2 * y) * W + 2 * x) * C + c;
-  ds[e] = (b[0] + b[C]) + (b[(long)W * C] + b[(long)W * C + C]);
+  auto ld = [&](long off) { return *reinterpret_cast<const f4*>(b + off); };
+  *reinterpret_cast<f4*>(ds + pix * C + c) = (ld(0) + ld(C)) + (ld((long)W * C) + ld((long)W * C + C));
 }
 // y = a + alpha * b  (fp32, in place on a)
 __global__ void axpy_kernel(float* __restrict__ a, const float* __restrict__ b, float alpha, long n) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) a[i] += alpha * b[i];
 }
+__global__ void axpy_kernel4(float* __restrict__ a, const float* __restrict__ b, float alpha, long n4) {
+  typedef __attribute__((ext_vector_type(4))) float f4;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n4) reinterpret_cast<f4*>(a)[i] += reinterpret_cast<const f4*>(b)[i] * alpha;
+}
 // emb0[row][e] = bf16((masked ? 0 : pose[row][e]) + nemb[row / P][e])
+// 8 embedding channels per thread (E % 8 == 0: launcher); total = elements / 8
 __global__ void emb_combine_kernel(const bf16* __restrict__ pose, const float* __restrict__ nemb, const uint8_t* __restrict__ mask, bf16* __restrict__ out,
                                    long total, int P, int E, int tokens) {
+  typedef __attribute__((ext_vector_type(4))) float f4;
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
-  const long row = i / E;
-  const int e = (int)(i % E);
+  const int eq = E / 8;
+  const long row = i / eq;
+  const int e = (int)(i % eq) * 8;
   const long bt = row / P;
   const bool drop = mask && mask[bt / tokens];
-  out[i] = f2bf((drop ? 0.f : bf2f(pose[i])) + nemb[bt * E + e]);
+  const f4 n0 = *reinterpret_cast<const f4*>(nemb + bt * E + e), n1 = *reinterpret_cast<const f4*>(nemb + bt * E + e + 4);
+  bf16x8 o;
+  if (drop) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = f2bf(n0[j]), o[4 + j] = f2bf(n1[j]);
+  } else {
+    const bf16x8 pv = *reinterpret_cast<const bf16x8*>(pose + row * E + e);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = f2bf(bf2f(pv[j]) + n0[j]), o[4 + j] = f2bf(bf2f(pv[4 + j]) + n1[j]);
+  }
+  *reinterpret_cast<bf16x8*>(out + row * E + e) = o;
 }
 // dst[r][dcol0 + c] *= mask[r][c]   (dropout: mask holds 0 or 1 / (1 - p)); 8 columns per thread
 __global__ void mul_cols_kernel(bf16* __restrict__ dst, long ldd, int dcol0, const bf16* __restrict__ mask, long rows, int ncols) {
@@ -770,10 +796,21 @@ __global__ void mul_cols_kernel(bf16* __restrict__ dst, long ldd, int dcol0, con
   *reinterpret_cast<bf16x8*>(dst + r * ldd + dcol0 + c) = v;
 }
 // out bf16 = src fp32 with the rows of masked videos zeroed (gradient of the dropped pose embedding)
-__global__ void masked_cast_kernel(const float* __restrict__ src, const uint8_t* __restrict__ mask, bf16* __restrict__ out, long total, long per_video) {
+// 8 elements per thread (total, per_video multiples of 8: launcher); total8 = elements / 8
+__global__ void masked_cast_kernel(const float* __restrict__ src, const uint8_t* __restrict__ mask, bf16* __restrict__ out, long total8, long per_video) {
+  typedef __attribute__((ext_vector_type(4))) float f4;
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= total) return;
-  out[i] = (mask && mask[i / per_video]) ? f2bf(0.f) : f2bf(src[i]);
+  if (i >= total8) return;
+  bf16x8 o;
+  if (mask && mask[(i * 8) / per_video]) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = f2bf(0.f);
+  } else {
+    const f4 a = reinterpret_cast<const f4*>(src)[2 * i], b = reinterpret_cast<const f4*>(src)[2 * i + 1];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = f2bf(a[j]), o[4 + j] = f2bf(b[j]);
+  }
+  reinterpret_cast<bf16x8*>(out)[i] = o;
 }
 // fine[bt][2y+a][2x+b][e] += coarse[bt][y][x][e] / 4   (adjoint of one level of the embedding pyramid's average pool), fp32
 // == pool2_bwd_kernel; dnemb[bt][e] = sum_p demb0[bt][p][e] is frames-style column sum over P rows:
@@ -855,7 +892,8 @@ int dfot_op_conv3x3_f32(const void* a, const void* w, const float* bias, const f
 }
 int dfot_op_pool2_bf16(const float* x, void* out, int bt, int h, int w, int c, void* stream) { return launch_pool2_bf16(x, (bf16*)out, bt, h, w, c, (hipStream_t)stream); }
 int dfot_op_pool2_bwd(const float* dp, float* dx, int bt, int h, int w, int c, void* stream) {
-  const long total = (long)bt * h * w * c;
+  DFOT_REQUIRE(c % 4 == 0, DFOT_ERR_SHAPE, "op_pool2_bwd: channels %d must be a multiple of 4", c);
+  const long total = (long)bt * h * w * (c / 4);
   hipLaunchKernelGGL(pool2_bwd_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, dp, dx, total, h, w, c);
   DFOT_CHECK_HIP(hipGetLastError());
   return DFOT_OK;
@@ -865,18 +903,22 @@ int dfot_op_upsample_add(const float* t, const float* skip, float* out, int bt, 
   return launch_upsample_add(t, skip, out, bt, h, w, c, (hipStream_t)stream);
 }
 int dfot_op_upsample_bwd(const float* dy, float* ds, int bt, int h, int w, int c, void* stream) {
-  const long total = (long)bt * (h / 2) * (w / 2) * c;
+  DFOT_REQUIRE(c % 4 == 0, DFOT_ERR_SHAPE, "op_upsample_bwd: channels %d must be a multiple of 4", c);
+  const long total = (long)bt * (h / 2) * (w / 2) * (c / 4);
   hipLaunchKernelGGL(upsample_bwd_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, dy, ds, total, h, w, c);
   DFOT_CHECK_HIP(hipGetLastError());
   return DFOT_OK;
 }
 int dfot_op_axpy(float* a, const float* b, float alpha, int64_t n, void* stream) {
-  hipLaunchKernelGGL(axpy_kernel, dim3(cdiv((long)n, 256)), dim3(256), 0, (hipStream_t)stream, a, b, alpha, (long)n);
+  const long n4 = ((((uintptr_t)a | (uintptr_t)b) & 15) == 0) ? (long)n / 4 : 0;
+  if (n4) hipLaunchKernelGGL(axpy_kernel4, dim3(cdiv(n4, 256)), dim3(256), 0, (hipStream_t)stream, a, b, alpha, n4);
+  if (n - 4 * n4) hipLaunchKernelGGL(axpy_kernel, dim3(cdiv((long)n - 4 * n4, 256)), dim3(256), 0, (hipStream_t)stream, a + 4 * n4, b + 4 * n4, alpha, (long)n - 4 * n4);
   DFOT_CHECK_HIP(hipGetLastError());
   return DFOT_OK;
 }
 int dfot_op_emb_combine(const void* pose, const float* nemb, const uint8_t* mask, void* out, int bt, int pixels, int e, int tokens, void* stream) {
-  const long total = (long)bt * pixels * e;
+  DFOT_REQUIRE(e % 8 == 0, DFOT_ERR_SHAPE, "op_emb_combine: embedding width %d must be a multiple of 8", e);
+  const long total = (long)bt * pixels * (e / 8);
   hipLaunchKernelGGL(emb_combine_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16*)pose, nemb, mask, (bf16*)out, total, pixels, e,
                      tokens);
   DFOT_CHECK_HIP(hipGetLastError());
@@ -890,7 +932,9 @@ int dfot_op_mul_cols(void* dst, int ldd, int dcol0, const void* mask, int64_t ro
   return DFOT_OK;
 }
 int dfot_op_masked_cast(const float* src, const uint8_t* mask, void* out, int64_t total, int64_t per_video, void* stream) {
-  hipLaunchKernelGGL(masked_cast_kernel, dim3(cdiv((long)total, 256)), dim3(256), 0, (hipStream_t)stream, src, mask, (bf16*)out, (long)total, (long)per_video);
+  DFOT_REQUIRE(total % 8 == 0 && per_video % 8 == 0, DFOT_ERR_SHAPE, "op_masked_cast: sizes must be multiples of 8");
+  hipLaunchKernelGGL(masked_cast_kernel, dim3(cdiv((long)total / 8, 256)), dim3(256), 0, (hipStream_t)stream, src, mask, (bf16*)out, (long)total / 8,
+                     (long)per_video);
   DFOT_CHECK_HIP(hipGetLastError());
   return DFOT_OK;
 }
@@ -916,7 +960,7 @@ int dfot_op_embed_input_wgrad(const float* dx0, const float* x, float* dw, float
   const int kdim = cin * ps * ps;
   DFOT_CHECK_HIP(hipMemsetAsync(dw, 0, (size_t)c0 * kdim * sizeof(float), s));
   DFOT_CHECK_HIP(hipMemsetAsync(db, 0, (size_t)c0 * sizeof(float), s));
-  hipLaunchKernelGGL(pe_wgrad_kernel, dim3(cdiv(c0, 256), cdiv(rows, 64)), dim3(256), 64 * kdim * sizeof(float), s, dx0, x, dw, db, cin, res, res, ps, c0, rows);
+  launch_pe_wgrad(dx0, x, dw, db, cin, res, res, ps, c0, rows, s);
   DFOT_CHECK_HIP(hipGetLastError());
   return DFOT_OK;
 }

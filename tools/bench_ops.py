@@ -83,7 +83,10 @@ def main():
                 ms, tf = conv(bt, h, w, ci, co, v)
                 print(f"conv {name:8s} {bt}x{h}x{w} {ci}->{co} variant={v}: {ms*1e3:8.1f} us  {tf:7.1f} TF/s", flush=True)
     if "attn" in what:
-        for name, (b, hd, n, d) in {"L2": (2, 9, 8192, 64), "L3": (2, 9, 2048, 128), "L2 Bm8": (8, 9, 8192, 64)}.items():
+        shapes = {"L2": (2, 9, 8192, 64), "L3": (2, 9, 2048, 128), "L2 Bm8": (8, 9, 8192, 64)}
+        if os.environ.get("ATTN_SHAPE"):  # e.g. ATTN_SHAPE=2,8,2048,128: one extra shape (workgroup-count experiments)
+            shapes = {"custom": tuple(int(x) for x in os.environ["ATTN_SHAPE"].split(","))}
+        for name, (b, hd, n, d) in shapes.items():
             if os.environ.get("ONLY") and os.environ["ONLY"] != name:
                 continue
             if os.environ.get("ONLY") and os.environ["ONLY"] != name:

@@ -17,7 +17,7 @@ def main():
     for path in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
         for row in csv.DictReader(open(path)):
             spans.append((int(row["Start_Timestamp"]), int(row["End_Timestamp"])))
-            name = re.sub(r"^void ", "", row["Kernel_Name"]).split("(")[0].replace("dfot::", "").replace("(anonymous namespace)::", "")
+            name = re.sub(r"^void ", "", row["Kernel_Name"]).replace("dfot::", "").replace("(anonymous namespace)::", "").split("(")[0]
             grid = int(row["Grid_Size_X"]) // max(int(row["Workgroup_Size_X"]), 1)
             a = acc[(name[:100], grid, int(row["Workgroup_Size_X"]))]
             a[0] += 1
