@@ -84,11 +84,51 @@ __global__ __launch_bounds__(256) void embed_input_kernel(const float* __restric
   *reinterpret_cast<float4v*>(out + (long)pix * c0 + c4) = acc;
 }
 
+// the same with the 4 x (CIN * 4) weights of the thread's channel quad in registers: the thread count is a multiple of c0 / 4, so a
+// thread keeps its channels over the grid-stride loop and no workgroup stages the weights through LDS (32768 workgroups each
+// re-reading 6 KiB of weights and synchronising was most of the 94 us this took for 134 MB of output)
+template <int CIN>
+__global__ __launch_bounds__(256) void embed_input_reg_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                              const float* __restrict__ b, float* __restrict__ out, unsigned total4,
+                                                              int res, int c0) {
+  constexpr int TAPS = CIN * 4;
+  const unsigned q = c0 / 4, r0 = res / 2;
+  const unsigned nthreads = gridDim.x * 256u;
+  unsigned iu = blockIdx.x * 256u + threadIdx.x;
+  const int c4 = (int)(iu % q) * 4;
+  float4v wt[TAPS];
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) wt[t][j] = w[(long)(c4 + j) * TAPS + t];
+  const float4v bias = *reinterpret_cast<const float4v*>(b + c4);
+  for (; iu < total4; iu += nthreads) {
+    const unsigned pix = iu / q;
+    const int px = (int)(pix % r0), py = (int)((pix / r0) % r0);
+    const long bt = pix / (r0 * r0);
+    float4v acc = bias;
+#pragma unroll
+    for (int ci = 0; ci < CIN; ++ci) {
+      const float* xp = x + ((bt * CIN + ci) * res + 2 * py) * (long)res + 2 * px;
+      const float2v top = *reinterpret_cast<const float2v*>(xp);
+      const float2v bot = *reinterpret_cast<const float2v*>(xp + res);
+      acc += wt[ci * 4] * top[0] + wt[ci * 4 + 1] * top[1] + wt[ci * 4 + 2] * bot[0] + wt[ci * 4 + 3] * bot[1];
+    }
+    *reinterpret_cast<float4v*>(out + (long)pix * c0 + c4) = acc;
+  }
+}
+
 int launch_embed_input(const float* x, const float* w, const float* b, float* out, int bt, int res, int cin, int c0,
                        hipStream_t s) {
   DFOT_REQUIRE(c0 % 4 == 0 && res % 2 == 0, DFOT_ERR_SHAPE, "embed_input: channels %d / resolution %d unsupported", c0, res);
   const long total4 = (long)bt * (res / 2) * (res / 2) * (c0 / 4);
   DFOT_REQUIRE(total4 < (1L << 31), DFOT_ERR_SHAPE, "embed_input: %ld work items exceed the 32-bit index range", total4);
+  if (cin == 3 && 256 % (c0 / 4) == 0) {
+    const long wgs = cdiv(total4, 256);
+    hipLaunchKernelGGL(embed_input_reg_kernel<3>, dim3((unsigned)(wgs < 4096 ? wgs : 4096)), dim3(256), 0, s, x, w, b, out, (unsigned)total4, res, c0);
+    DFOT_CHECK_HIP(hipGetLastError());
+    return DFOT_OK;
+  }
   hipLaunchKernelGGL(embed_input_kernel, dim3(cdiv(total4, 256)), dim3(256), (size_t)cin * 4 * c0 * sizeof(float), s, x, w, b,
                      out, total4, res, cin, c0);
   DFOT_CHECK_HIP(hipGetLastError());
@@ -228,11 +268,75 @@ __global__ __launch_bounds__(256) void project_output_kernel(const float* __rest
     }
 }
 
+// one step of a transposed reduction: lanes whose bit BIT is set keep values W..2W-1, the others 0..W-1, and each adds its
+// partner's copy of what it keeps -- W values per lane remain, each summed over one more lane bit
+template <int W, int BIT>
+__device__ __forceinline__ void halve_exchange(float* acc, int lane) {
+  const bool hi = lane & BIT;
+#pragma unroll
+  for (int j = 0; j < W; ++j) {
+    const float keep = hi ? acc[j + W] : acc[j], send = hi ? acc[j] : acc[j + W];
+    acc[j] = keep + __shfl_xor(send, BIT);
+  }
+}
+
+// C0 = 128: sixteen lanes share a pixel, each with 8 of its channels (one coalesced 512-byte row per pixel instead of 64 lanes
+// striding 512 bytes apart) and the 8 x (COUT * 4) weights of those channels in registers; the COUT * 4 <= 16 partial sums are
+// reduced over the 16 lanes with a halving exchange (15 shuffles), which leaves output o = lane % 16 in its lane
+template <int COUT>
+__global__ __launch_bounds__(256) void project_output_c128_kernel(const float* __restrict__ x0, const float* __restrict__ w,
+                                                                  const float* __restrict__ b, float* __restrict__ out, unsigned npix,
+                                                                  int res) {
+  constexpr int NO = COUT * 4;
+  const int lane = threadIdx.x & 63, sub = lane & 15;
+  float wt[8][NO];
+#pragma unroll
+  for (int c = 0; c < 8; ++c)
+#pragma unroll
+    for (int o = 0; o < NO; ++o) wt[c][o] = w[(sub * 8 + c) * NO + o];
+  const float bias = sub < NO ? b[sub >> 2] : 0.f;
+  const unsigned r0 = res / 2;
+  const unsigned group = (blockIdx.x * 256u + threadIdx.x) >> 4, ngroups = gridDim.x * 16u;
+  const unsigned iters = (npix + ngroups - 1) / ngroups;  // the same trip count for every lane: the shuffles need whole waves
+  for (unsigned it = 0; it < iters; ++it) {
+    const unsigned pix = group + it * ngroups;
+    const bool live = pix < npix;
+    float acc[16];
+#pragma unroll
+    for (int o = 0; o < 16; ++o) acc[o] = 0.f;
+    if (live) {
+      const float* xp = x0 + (long)pix * 128 + sub * 8;
+      const float4v a = *reinterpret_cast<const float4v*>(xp), c = *reinterpret_cast<const float4v*>(xp + 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int o = 0; o < NO; ++o) acc[o] += a[j] * wt[j][o] + c[j] * wt[4 + j][o];
+    }
+    // halve the value count while exchanging across lane bits 3, 2, 1, 0
+    halve_exchange<8, 8>(acc, lane);
+    halve_exchange<4, 4>(acc, lane);
+    halve_exchange<2, 2>(acc, lane);
+    halve_exchange<1, 1>(acc, lane);
+    if (live && sub < NO) {
+      const int px = (int)(pix % r0), py = (int)((pix / r0) % r0);
+      const long bt = pix / (r0 * r0);
+      const int co = sub >> 2, dy = (sub >> 1) & 1, dx = sub & 1;
+      out[((bt * COUT + co) * res + 2 * py + dy) * (long)res + 2 * px + dx] = acc[0] + bias;
+    }
+  }
+}
+
 int launch_project_output(const float* x0, const float* w, const float* b, float* out, int bt, int res, int c0, int cout,
                           hipStream_t s) {
   DFOT_REQUIRE(cout <= 3 && c0 % 4 == 0, DFOT_ERR_SHAPE, "project_output: cout=%d (<=3), c0=%d", cout, c0);
   const long npix = (long)bt * (res / 2) * (res / 2);
   DFOT_REQUIRE(npix < (1L << 31), DFOT_ERR_SHAPE, "project_output: %ld pixels exceed the 32-bit index range", npix);
+  if (c0 == 128 && cout == 3) {
+    const long wgs = cdiv(npix, 16);
+    hipLaunchKernelGGL(project_output_c128_kernel<3>, dim3((unsigned)(wgs < 4096 ? wgs : 4096)), dim3(256), 0, s, x0, w, b, out, (unsigned)npix, res);
+    DFOT_CHECK_HIP(hipGetLastError());
+    return DFOT_OK;
+  }
   hipLaunchKernelGGL(project_output_kernel, dim3(cdiv(npix, 256)), dim3(256), c0 * cout * 4 * sizeof(float), s, x0, w, b,
                      out, npix, res, c0, cout);
   DFOT_CHECK_HIP(hipGetLastError());
@@ -420,8 +524,73 @@ __global__ __launch_bounds__(256) void film_vec_kernel(const FilmChunk* __restri
     if (lane == 0) sv[ck.out_off + (long)bt * ck.rows + r] = acc + bias;
   }
 }
+// E % 256 == 0: the frames' embeddings are staged ONCE per workgroup in LDS (the form above has every wave re-read all of them from
+// L2: 64 K waves x 64 KiB = 4 GB for 132 MB of weights) and a wave takes two weight rows at a time, so one LDS read feeds
+// two rows; the 2 x 16 dot products of a pass live one per lane pair after a halving exchange over lane bits 5..1 (32 shuffles
+// per two rows instead of 96 per row).  Workgroup = 32 rows of a chunk (blockIdx.x = chunk * 2 + half), 16 frames per pass.
+template <int EQ>  // E / 256
+__global__ __launch_bounds__(256, 2) void film_vec_lds_kernel(const FilmChunk* __restrict__ table, const float* __restrict__ nemb,
+                                                           float* __restrict__ sv, int nbt) {
+  constexpr int E = EQ * 256;
+  __shared__ float4v ne[16][E / 4];
+  const FilmChunk ck = table[blockIdx.x >> 1];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int bt0 = 0; bt0 < nbt; bt0 += 16) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < 16 * (E / 4); i += 256) {
+      const int f = i / (E / 4);
+      float4v v = {0.f, 0.f, 0.f, 0.f};
+      if (bt0 + f < nbt) v = reinterpret_cast<const float4v*>(nemb + (long)(bt0 + f) * E)[i % (E / 4)];
+      ne[f][i % (E / 4)] = v;
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int pass = 0; pass < 4; ++pass) {
+      const int r0 = (blockIdx.x & 1) * 32 + pass * 8 + wave * 2;
+      float wv[2][EQ][4];
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int k = 0; k < EQ; ++k) {
+          const bf16x4 t = *reinterpret_cast<const bf16x4*>(ck.w + (long)(r0 + r) * E + k * 256 + lane * 4);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) wv[r][k][j] = bf2f(t[j]);
+        }
+      float acc[32];  // [row][frame]
+#pragma unroll
+      for (int f = 0; f < 16; ++f) {
+        float4v x[EQ];
+#pragma unroll
+        for (int k = 0; k < EQ; ++k) x[k] = ne[f][k * 64 + lane];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          float a = 0.f;
+#pragma unroll
+          for (int k = 0; k < EQ; ++k) a += wv[r][k][0] * x[k][0] + wv[r][k][1] * x[k][1] + wv[r][k][2] * x[k][2] + wv[r][k][3] * x[k][3];
+          acc[r * 16 + f] = a;
+        }
+        if ((f & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // at most four frames of LDS reads hoisted: all sixteen cost 256 VGPRs
+      }
+      halve_exchange<16, 32>(acc, lane);
+      halve_exchange<8, 16>(acc, lane);
+      halve_exchange<4, 8>(acc, lane);
+      halve_exchange<2, 4>(acc, lane);
+      halve_exchange<1, 2>(acc, lane);
+      const float v = acc[0] + __shfl_xor(acc[0], 1);
+      // lane >> 1 = row * 16 + frame
+      const int r = r0 + (lane >> 5), f = bt0 + ((lane >> 1) & 15);
+      if (f < nbt && (lane & 1) == 0) sv[ck.out_off + (long)f * ck.rows + r] = v + ck.b[r];
+    }
+  }
+}
 int launch_film_vec(const FilmChunk* table, int chunks, const float* nemb, float* sv, int bt, int e, hipStream_t s) {
   DFOT_REQUIRE(e % 8 == 0 && e <= 1024, DFOT_ERR_SHAPE, "film_vec: emb dim %d must be a multiple of 8 and <= 1024", e);
+  if (e == 1024 || e == 512) {
+    if (e == 1024) hipLaunchKernelGGL(film_vec_lds_kernel<4>, dim3(chunks * 2), dim3(256), 0, s, table, nemb, sv, bt);
+    else hipLaunchKernelGGL(film_vec_lds_kernel<2>, dim3(chunks * 2), dim3(256), 0, s, table, nemb, sv, bt);
+    DFOT_CHECK_HIP(hipGetLastError());
+    return DFOT_OK;
+  }
   hipLaunchKernelGGL(film_vec_kernel, dim3(chunks * 16), dim3(256), 0, s, table, nemb, sv, e, bt);
   DFOT_CHECK_HIP(hipGetLastError());
   return DFOT_OK;
