@@ -756,16 +756,12 @@ int tr_wgrad(const bf16* A, const bf16* W, int M, int N, int K, float* out, hipS
 // DFOT_ERR_STATE (and does nothing) when the shape is not covered, so the caller falls back to transposes + tr_wgrad.
 int tr_wgrad_nt(const bf16* dy, long ldy, const bf16* x, long ldx, int M, int N, long rows, float* out, hipStream_t s, float* ws, size_t ws_floats) {
   static const int enabled = tuning_flag("TRAIN_WGRAD_NT", 1);
-  static const int target = tuning_flag("TRAIN_WGRAD_NT_WGS", 512);
-  if (!enabled || M % 128 != 0 || N % 128 != 0 || rows % 64 != 0) return DFOT_ERR_STATE;  // (the kernel also takes ragged M / N; not needed here)
-  const long tiles = (long)(M / 128) * (N / 128);
-  int slices = (int)(target / tiles);
-  slices = slices < 1 ? 1 : (slices > 64 ? 64 : slices);
-  while (slices > 1 && (rows / 64 < 4L * slices || (size_t)slices * M * N > ws_floats)) --slices;
-  if (slices == 1) return launch_wgrad_nt(dy, ldy, x, ldx, out, M, N, rows, 1, s);
-  int rc = launch_wgrad_nt(dy, ldy, x, ldx, ws, M, N, rows, slices, s);
+  if (!enabled || M % 8 != 0 || N % 8 != 0 || rows % 64 != 0) return DFOT_ERR_STATE;
+  const WgradPlan plan = wgrad_plan(M, N, rows, ws ? (long)(ws_floats / ((size_t)M * N)) : 1);
+  if (plan.slices == 1) return launch_wgrad_nt_plan(dy, ldy, x, ldx, out, M, N, rows, plan, s);
+  int rc = launch_wgrad_nt_plan(dy, ldy, x, ldx, ws, M, N, rows, plan, s);
   if (rc) return rc;
-  hipLaunchKernelGGL(slices_sum_kernel, dim3(cdiv((long)M * N / 4, 256)), dim3(256), 0, s, ws, out, (long)M * N / 4, slices, (long)M * N);
+  hipLaunchKernelGGL(slices_sum_kernel, dim3(cdiv((long)M * N / 4, 256)), dim3(256), 0, s, ws, out, (long)M * N / 4, plan.slices, (long)M * N);
   DFOT_CHECK_HIP(hipGetLastError());
   return DFOT_OK;
 }

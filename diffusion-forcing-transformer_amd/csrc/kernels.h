@@ -33,8 +33,15 @@ int launch_film_vec(const FilmChunk* table, int chunks, const float* nemb, float
 int launch_gn_film_silu(const bf16* h, const float* stats, const float* gamma, const float* beta, const bf16* fcache,
                         const float* sv, const uint8_t* cond_mask, bf16* out, int bt, int pixels, int c, int tokens,
                         hipStream_t s);
+// a residual stream whose last out-projection is still two K-slice partials: x += bias[c] + s0 + s1 (run_tr_block, uvit.hip)
+struct RmsPending {
+  float* x;
+  const float* bias;
+  const float* s0;
+  const float* s1;
+};
 int launch_rms_film(const float* x, const float* w, const bf16* fcache, const float* sv, const uint8_t* cond_mask, bf16* out,
-                    long m, int c, int rows_per_bt, int tokens, float eps, hipStream_t s);
+                    long m, int c, int rows_per_bt, int tokens, float eps, hipStream_t s, const RmsPending* pend = nullptr);
 
 // ---- resampling / skips ----
 int launch_pool2_bf16(const float* x, bf16* out, int bt, int h, int w, int c, hipStream_t s);
@@ -57,6 +64,12 @@ int launch_vloss(const float* x, const float* noise, const float* v, const float
 // ---- weight-gradient GEMM over the token axis (wgrad.hip): out[slices][M][N] = partial sums of A^T B, A [rows][lda], B [rows][ldb] ----
 int launch_wgrad_nt(const bf16* a, long lda, const bf16* b, long ldb, float* out, int m, int n, long rows, int slices, hipStream_t s, int img_h = 0,
                     int img_w = 0, int sdy = 0, int sdx = 0, int all_taps = 0);
+// tile form (0: 128 x 128 / 4 waves; 1: 256 x 256 / 16; 2: 256 x 192 / 12; 3: 192 x 256 / 12) and K slices of one weight gradient
+struct WgradPlan {
+  int form, slices;
+};
+WgradPlan wgrad_plan(int m, int n, long rows, long max_slices);
+int launch_wgrad_nt_plan(const bf16* a, long lda, const bf16* b, long ldb, float* out, int m, int n, long rows, WgradPlan plan, hipStream_t s);
 // ---- training: loss gradient, gradient norm, AdamW (flat fp32 buffers) ----
 int launch_vloss_grad(const float* x, const float* noise, const float* v, const float* a, const float* sg, const float* coef, float* dv,
                       int bt, long f, bool vspace, hipStream_t s);

@@ -652,11 +652,15 @@ int launch_gn_film_silu(const bf16* h, const float* stats, const float* gamma, c
 }
 
 // TransformerBlock: xn = RMSNorm(x) * w * (1 + scale) + shift, fp32 stream in -> bf16 out; one wave per token
-template <int MAXCH>
-__global__ __launch_bounds__(256) void rms_film_kernel(const float* __restrict__ x, const float* __restrict__ w,
+// PEND: the residual stream still lacks the previous block's out-projection, left as two K-slice partials: x += bias + s0 + s1 is
+// applied here (and written back) instead of in a pass of its own
+template <int MAXCH, bool PEND>
+__global__ __launch_bounds__(256) void rms_film_kernel(const float* x, const float* __restrict__ w,
                                                        const bf16* __restrict__ fcache, const float* __restrict__ sv,
                                                        const uint8_t* __restrict__ cond_mask, bf16* __restrict__ out,
-                                                       long m, int c, int rows_per_bt, int tokens, float eps) {
+                                                       long m, int c, int rows_per_bt, int tokens, float eps, float* xw,
+                                                       const float* __restrict__ pbias, const float* __restrict__ p0,
+                                                       const float* __restrict__ p1) {
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= m) return;
   const int lane = threadIdx.x & 63;
@@ -672,6 +676,20 @@ __global__ __launch_bounds__(256) void rms_film_kernel(const float* __restrict__
       const float4v b = *reinterpret_cast<const float4v*>(src + ch * 8 + 4);
       v[k][0] = a[0]; v[k][1] = a[1]; v[k][2] = a[2]; v[k][3] = a[3];
       v[k][4] = b[0]; v[k][5] = b[1]; v[k][6] = b[2]; v[k][7] = b[3];
+      if constexpr (PEND) {
+        const long o = row * c + ch * 8;
+        float4v lo = a, hi = b;
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+          const float4v add = *reinterpret_cast<const float4v*>(pbias + ch * 8 + 4 * hf) + *reinterpret_cast<const float4v*>(p0 + o + 4 * hf) +
+                              *reinterpret_cast<const float4v*>(p1 + o + 4 * hf);
+          if (hf == 0) lo += add; else hi += add;
+        }
+        *reinterpret_cast<float4v*>(xw + o) = lo;
+        *reinterpret_cast<float4v*>(xw + o + 4) = hi;
+        v[k][0] = lo[0]; v[k][1] = lo[1]; v[k][2] = lo[2]; v[k][3] = lo[3];
+        v[k][4] = hi[0]; v[k][5] = hi[1]; v[k][6] = hi[2]; v[k][7] = hi[3];
+      }
 #pragma unroll
       for (int j = 0; j < 8; ++j) ss += v[k][j] * v[k][j];
     }
@@ -710,14 +728,18 @@ __global__ __launch_bounds__(256) void rms_film_kernel(const float* __restrict__
   }
 }
 int launch_rms_film(const float* x, const float* w, const bf16* fcache, const float* sv, const uint8_t* cond_mask, bf16* out,
-                    long m, int c, int rows_per_bt, int tokens, float eps, hipStream_t s) {
+                    long m, int c, int rows_per_bt, int tokens, float eps, hipStream_t s, const RmsPending* pend) {
   DFOT_REQUIRE(c % 8 == 0 && c <= 8 * 64 * 3, DFOT_ERR_SHAPE, "rms_film: channels %d unsupported", c);
-  if (c <= 8 * 64 * 2)
-    hipLaunchKernelGGL(rms_film_kernel<2>, dim3(cdiv(m, 4)), dim3(256), 0, s, x, w, fcache, sv, cond_mask, out, m, c,
-                       rows_per_bt, tokens, eps);
-  else
-    hipLaunchKernelGGL(rms_film_kernel<3>, dim3(cdiv(m, 4)), dim3(256), 0, s, x, w, fcache, sv, cond_mask, out, m, c,
-                       rows_per_bt, tokens, eps);
+#define RMS_CALL(MC, P)                                                                                                             \
+  hipLaunchKernelGGL((rms_film_kernel<MC, P>), dim3(cdiv(m, 4)), dim3(256), 0, s, x, w, fcache, sv, cond_mask, out, m, c, rows_per_bt, \
+                     tokens, eps, P ? pend->x : nullptr, P ? pend->bias : nullptr, P ? pend->s0 : nullptr, P ? pend->s1 : nullptr)
+  if (pend) {
+    DFOT_REQUIRE(pend->x == x && pend->bias && pend->s0 && pend->s1, DFOT_ERR_ARG, "rms_film: pending sum must target the normalised stream");
+    if (c <= 8 * 64 * 2) RMS_CALL(2, true); else RMS_CALL(3, true);
+  } else {
+    if (c <= 8 * 64 * 2) RMS_CALL(2, false); else RMS_CALL(3, false);
+  }
+#undef RMS_CALL
   DFOT_CHECK_HIP(hipGetLastError());
   return DFOT_OK;
 }

@@ -111,6 +111,11 @@ struct dfot_uvit_s {
        *cat = nullptr, *q = nullptr, *k = nullptr, *v = nullptr;
   float* out_part = nullptr;  // two fp32 partial slices of an out-projection (K split, see run_tr_block)
   size_t out_part_elems = 0;  // its capacity in floats: the split path is taken only when 2 * M * N fits
+  // the slices of the last out-projection not yet added to X[pend_lvl] (pend_bias != nullptr): the next block's norm kernel adds
+  // them while it reads the stream anyway; flush_pending() does it for every other reader
+  const float* pend_bias = nullptr;
+  int pend_lvl = 0, pend_c = 0;
+  long pend_m = 0;
   int last_batch = 0;
   int gemm_variant = GEMM_AUTO;
   int attn_variant = 2;
@@ -401,14 +406,27 @@ __global__ void out_reduce_kernel(float* __restrict__ x, const float* __restrict
   reinterpret_cast<f4*>(x)[i] += b + reinterpret_cast<const f4*>(s0)[i] + reinterpret_cast<const f4*>(s1)[i];
 }
 
+static int flush_pending(dfot_uvit_s* h, hipStream_t s) {
+  if (!h->pend_bias) return DFOT_OK;
+  const long total4 = h->pend_m * h->pend_c / 4;
+  hipLaunchKernelGGL(out_reduce_kernel, dim3(cdiv(total4, 256)), dim3(256), 0, s, h->X[h->pend_lvl], h->pend_bias, h->out_part,
+                     h->out_part + h->pend_m * h->pend_c, total4, h->pend_c / 4);
+  h->pend_bias = nullptr;
+  DFOT_CHECK_HIP(hipGetLastError());
+  return DFOT_OK;
+}
+
 static int run_tr_block(dfot_uvit_s* h, const TrW& w, int lvl, int batch, hipStream_t s) {
   const int c = w.c, rr = h->r[lvl], n = h->T * rr * rr, d = c / h->heads;
   const int m = batch * n;
   float* x = h->X[lvl];
   int rc = 0;
+  if (h->pend_bias && (h->pend_lvl != lvl || h->pend_m != m || h->pend_c != c) && (rc = flush_pending(h, s))) return rc;
+  RmsPending pend{x, h->pend_bias, h->out_part, h->out_part + (long)m * c};
   if ((rc = launch_rms_film(x, w.nw, w.fcache, h->sv + w.sv_off, h->have_mask ? h->cond_mask : nullptr, h->s1, m, c,
-                            rr * rr, h->T, h->cfg.eps, s)))
+                            rr * rr, h->T, h->cfg.eps, s, h->pend_bias ? &pend : nullptr)))
     return rc;
+  h->pend_bias = nullptr;
   GemmArgs p;
   p.A = h->s1; p.lda = c; p.W = w.w_fused; p.M = m; p.N = 7 * c; p.K = c; p.bias = w.b_fused;
   p.out2 = h->cat + c; p.ldo2 = 5 * c; p.split = 3 * c;
@@ -437,10 +455,10 @@ static int run_tr_block(dfot_uvit_s* h, const TrW& w, int lvl, int batch, hipStr
     GemmArgs p2 = o;
     p2.bias = nullptr; p2.resid = nullptr; p2.out_f32 = h->out_part; p2.ksplit = 2; p2.slice_stride = (long)m * c;
     if ((rc = launch_gemm(A_DENSE, E_F32, GEMM_DMA_256x144, p2, s))) return rc;
-    const long total4 = (long)m * c / 4;
-    hipLaunchKernelGGL(out_reduce_kernel, dim3(cdiv(total4, 256)), dim3(256), 0, s, x, w.b_out, h->out_part, h->out_part + (long)m * c, total4, c / 4);
-    DFOT_CHECK_HIP(hipGetLastError());
-    return DFOT_OK;
+    h->pend_bias = w.b_out;
+    h->pend_lvl = lvl; h->pend_m = m; h->pend_c = c;
+    static const int defer = tuning_flag("UVIT_OUT_DEFER", 1);  // A/B: 0 = reduce pass right away
+    return defer ? DFOT_OK : flush_pending(h, s);
   }
   return launch_gemm(A_DENSE, E_F32, h->gemm_variant, o, s);
 }
@@ -763,14 +781,18 @@ int dfot_uvit_forward_cached(dfot_uvit_t h, const float* x, const float* noise_l
       if ((rc = run_res_block(h, w, l, bt, s))) return rc;
     if ((rc = run_down(h, l, bt, s))) return rc;
   }
+  h->pend_bias = nullptr;
   for (const TrW& w : h->down_tr)
     if ((rc = run_tr_block(h, w, 2, batch, s))) return rc;
+  if ((rc = flush_pending(h, s))) return rc;
   if ((rc = run_down(h, 2, bt, s))) return rc;
   for (const TrW& w : h->mid_tr)
     if ((rc = run_tr_block(h, w, 3, batch, s))) return rc;
+  if ((rc = flush_pending(h, s))) return rc;
   if ((rc = run_up(h, 2, bt, s))) return rc;
   for (const TrW& w : h->up_tr)
     if ((rc = run_tr_block(h, w, 2, batch, s))) return rc;
+  if ((rc = flush_pending(h, s))) return rc;
   for (int l = 1; l >= 0; --l) {
     if ((rc = run_up(h, l, bt, s))) return rc;
     for (const ResW& w : h->up_res[l])

@@ -133,7 +133,9 @@ int dfot_op_conv3x3_bwd(const void* x, const void* dy, const float* w, float* dx
   hipStream_t s = (hipStream_t)stream;
   ConvBwdScratch sc;
   void *taps = nullptr, *ws = nullptr, *wd = nullptr, *zeros = nullptr;
+  // partial weight gradients of the K slices: up to 1024 / 9 slices of the nine taps for the 128-channel convolutions (9 output tiles)
   sc.ws_floats = (size_t)256 * cout * cin;
+  if ((size_t)1024 * cout * cin <= ((size_t)32 << 20)) sc.ws_floats = (size_t)1024 * cout * cin;
   int rc = 0;
   if ((rc = op_scratch(0, (size_t)9 * cout * cin * sizeof(float), &taps)) || (rc = op_scratch(1, sc.ws_floats * sizeof(float), &ws)) ||
       (rc = op_scratch(2, (size_t)9 * cout * cin * sizeof(bf16), &wd)) || (rc = op_scratch(3, 256, &zeros)))
@@ -306,8 +308,8 @@ namespace {
 
 template <int VEC, int CNT>
 __global__ __launch_bounds__(256) void rms_film_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dxn, const float* __restrict__ w,
-                                                           const bf16* __restrict__ film, float* __restrict__ dx, bf16* __restrict__ dfilm,
-                                                           float* __restrict__ dw, long rows, float eps, int accumulate) {
+                                                           const bf16* __restrict__ film, float* dx, bf16* __restrict__ dfilm,
+                                                           float* __restrict__ dw, long rows, float eps, int accumulate, const float* dres) {
   typedef typename VecT<VEC>::type V;
   constexpr int C = 64 * VEC * CNT;
   const int lane = threadIdx.x & 63;
@@ -351,11 +353,12 @@ __global__ __launch_bounds__(256) void rms_film_bwd_kernel(const float* __restri
     }
     const float m = wave_sum(gx) / (float)C * r * r;
     float* orow = dx + row * C;
+    const float* rrow = (dres ? dres : dx) + row * C;  // accumulate: dx = (dres or the present dx) + the norm's input gradient
 #pragma unroll
     for (int i = 0; i < CNT; ++i) {
       const int c0 = (i * 64 + lane) * VEC;
       V o = (gv[i] - xv[i] * m) * r;
-      if (accumulate) o += *reinterpret_cast<const V*>(orow + c0);
+      if (accumulate) o += *reinterpret_cast<const V*>(rrow + c0);
       *reinterpret_cast<V*>(orow + c0) = o;
     }
   }
@@ -370,10 +373,10 @@ __global__ __launch_bounds__(256) void rms_film_bwd_kernel(const float* __restri
 
 // dw must be zeroed by the caller
 int rms_film_backward(const float* x, const float* dxn, const float* w, const bf16* film, float* dx, bf16* dfilm, float* dw, long rows, int hidden,
-                      float eps, bool accumulate, hipStream_t s) {
+                      float eps, bool accumulate, hipStream_t s, const float* dres = nullptr) {
   const int grid = (int)(rows / 4 < 512 ? (rows + 3) / 4 : 512);
 #define CALL(V, C) \
-  hipLaunchKernelGGL((rms_film_bwd_kernel<V, C>), dim3(grid), dim3(256), 0, s, x, dxn, w, film, dx, dfilm, dw, rows, eps, accumulate ? 1 : 0)
+  hipLaunchKernelGGL((rms_film_bwd_kernel<V, C>), dim3(grid), dim3(256), 0, s, x, dxn, w, film, dx, dfilm, dw, rows, eps, accumulate ? 1 : 0, dres)
   DIT_LN_DISPATCH(CALL)
 #undef CALL
   DFOT_CHECK_HIP(hipGetLastError());
@@ -492,6 +495,13 @@ int dfot_op_rms_film_bwd(const float* x, const float* dxn, const float* w, const
   DFOT_CHECK_HIP(hipMemsetAsync(dw, 0, (size_t)channels * sizeof(float), (hipStream_t)stream));
   return rms_film_backward(x, dxn, w, (const bf16*)film, dx, (bf16*)dfilm, dw, (long)rows, channels, eps, accumulate_dx != 0, (hipStream_t)stream);
 }
+// the same with the residual-path gradient read from `dres` (not modified): dx = dres + the norm's input gradient, out of place
+int dfot_op_rms_film_bwd_res(const float* x, const float* dxn, const float* w, const void* film, float eps, const float* dres, float* dx, void* dfilm,
+                             float* dw, int64_t rows, int channels, void* stream) {
+  DFOT_REQUIRE(x && dxn && w && film && dres && dx && dfilm && dw && dres != dx, DFOT_ERR_ARG, "op_rms_film_bwd_res: null or aliased argument");
+  DFOT_CHECK_HIP(hipMemsetAsync(dw, 0, (size_t)channels * sizeof(float), (hipStream_t)stream));
+  return rms_film_backward(x, dxn, w, (const bf16*)film, dx, (bf16*)dfilm, dw, (long)rows, channels, eps, true, (hipStream_t)stream, dres);
+}
 int dfot_op_qknorm_rope_bwd(const void* fused, int ld, const void* dq, const void* dk, const void* dv, const float* qw, const float* kw,
                             const float* rope_cs, float eps, void* dfused, int ldo, float* dqw, float* dkw, int64_t rows, int ntok, int heads, int d,
                             void* stream) {
@@ -507,15 +517,17 @@ extern "C" {
 using namespace dfot;
 // test entry: out [M][N] fp32 = a^T b with a [rows][lda], b [rows][ldb] bf16 (the weight gradient dY^T X in the activations' own layout)
 int dfot_op_wgrad_nt(const void* a, int lda, const void* b, int ldb, float* out, int m, int n, int64_t rows, int slices, void* stream) {
-  DFOT_REQUIRE(a && b && out && slices >= 1, DFOT_ERR_ARG, "op_wgrad_nt: bad argument");
+  DFOT_REQUIRE(a && b && out && slices >= 0, DFOT_ERR_ARG, "op_wgrad_nt: bad argument");
   hipStream_t s = (hipStream_t)stream;
-  if (slices == 1) return launch_wgrad_nt((const bf16*)a, lda, (const bf16*)b, ldb, out, m, n, (long)rows, 1, s);
+  // slices == 0: tile form and K slices chosen by shape (wgrad_plan); slices >= 1: the 128 x 128 form with that many slices
+  const WgradPlan plan = slices == 0 ? wgrad_plan(m, n, (long)rows, 64) : WgradPlan{0, slices};
+  if (plan.slices == 1) return launch_wgrad_nt_plan((const bf16*)a, lda, (const bf16*)b, ldb, out, m, n, (long)rows, plan, s);
   void* wsv = nullptr;
-  int rc = op_scratch(5, (size_t)slices * m * n * sizeof(float), &wsv);
+  int rc = op_scratch(5, (size_t)plan.slices * m * n * sizeof(float), &wsv);
   if (rc) return rc;
   float* ws = (float*)wsv;
-  if ((rc = launch_wgrad_nt((const bf16*)a, lda, (const bf16*)b, ldb, ws, m, n, (long)rows, slices, s))) return rc;
-  hipLaunchKernelGGL(slices_sum_kernel, dim3(cdiv((long)m * n / 4, 256)), dim3(256), 0, s, ws, out, (long)m * n / 4, slices, (long)m * n);
+  if ((rc = launch_wgrad_nt_plan((const bf16*)a, lda, (const bf16*)b, ldb, ws, m, n, (long)rows, plan, s))) return rc;
+  hipLaunchKernelGGL(slices_sum_kernel, dim3(cdiv((long)m * n / 4, 256)), dim3(256), 0, s, ws, out, (long)m * n / 4, plan.slices, (long)m * n);
   DFOT_CHECK_HIP(hipGetLastError());
   return DFOT_OK;
 }

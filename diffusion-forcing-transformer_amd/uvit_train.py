@@ -63,10 +63,8 @@ def wgrad(dy: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
     """dW [M][N] fp32 = dy^T x over the token axis; dy [rows][M], x [rows][N] bf16"""
     rows, m = dy.shape
     n = x.shape[1]
-    tiles = -(-m // 128) * -(-n // 128)
-    slices = max(1, min(64, 512 // tiles, rows // 256))
     out = torch.empty(m, n, dtype=torch.float32, device="cuda")
-    capi.check(capi.lib.dfot_op_wgrad_nt(_P(dy), dy.stride(0), _P(x), x.stride(0), _P(out), m, n, rows, slices, _S()))
+    capi.check(capi.lib.dfot_op_wgrad_nt(_P(dy), dy.stride(0), _P(x), x.stride(0), _P(out), m, n, rows, 0, _S()))  # 0: tile form / K slices by shape
     return out
 
 
@@ -156,11 +154,11 @@ class TransformerBlockTrain:
         capi.check(lib.dfot_op_silu_cols(_P(s["fused"]), 7 * c, 3 * c, _P(dcat), 5 * c, c, _P(dfused), 7 * c, 3 * c, rows, 4 * c, _S()))
         dxn = gemm_f32(dfused, self.w_fT)                                    # [rows][C]
         dw_f, db_f = wgrad(dfused, s["xn"]), colsum(dfused)
-        dx = dy.clone()                                                      # residual path; the norm's input gradient is added in place
+        dx = torch.empty_like(dy)                                            # residual path + the norm's input gradient, one pass
         dfilm = torch.empty(rows, 2 * c, dtype=BF, device="cuda")
         dnw = torch.empty(c, device="cuda")
-        capi.check(lib.dfot_op_rms_film_bwd(_P(s["x"]), _P(dxn), _P(p["norm.norm.weight"]), _P(s["film"]), self.eps, _P(dx), _P(dfilm), _P(dnw),
-                                            rows, c, 1, _S()))
+        capi.check(lib.dfot_op_rms_film_bwd_res(_P(s["x"]), _P(dxn), _P(p["norm.norm.weight"]), _P(s["film"]), self.eps, _P(dy), _P(dx), _P(dfilm),
+                                                _P(dnw), rows, c, _S()))
         demb = gemm_f32(dfilm, self.w_eT, resid=demb_acc, out=demb_acc)      # [rows][E]
         self.grads = {
             "norm.emb_layer.weight": wgrad(dfilm, s["emb"]), "norm.emb_layer.bias": colsum(dfilm), "norm.norm.weight": dnw,

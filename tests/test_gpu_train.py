@@ -1,6 +1,7 @@
 """GPU parity of the training path (backward kernels, trainer) against torch autograd through the fp32 oracle restatement.
 Tolerances: bf16 operands / fp32 accumulation, relative L2 of each gradient tensor."""
 import math
+import os
 
 import numpy as np
 import pytest
@@ -441,6 +442,39 @@ def test_qknorm_rope_backward(d, heads, ntok, batch):
     rs = (rel(dfused.float().cpu()[:, :3 * c], fr.grad[:, :3 * c]), rel(dqw.cpu(), qwr.grad), rel(dkw.cpu(), kwr.grad))
     print(f"q/k norm + RoPE backward d={d}: " + " ".join(f"{r:.1e}" for r in rs))
     assert rs[0] < 5e-3 and rs[1] < 1e-4 and rs[2] < 1e-4
+
+
+@pytest.mark.parametrize("form", [-1, 0, 1, 2, 3])
+@pytest.mark.parametrize("m,n,rows", [(1152, 5760, 4096), (4032, 576, 8192), (576, 2880, 2048), (2304, 1024, 1024), (520, 264, 640), (128, 128, 8192)])
+def test_wgrad_nt_tile_forms(m, n, rows, form):
+    """the planned weight gradient (slices = 0) in every tile form -- 128 x 128 / 4 waves and the LDS-DMA 256 x 256, 256 x 192 and
+    192 x 256 ones -- on the model's shapes and on one whose M, N are no multiples of any tile (zero-filled edge chunks)"""
+    import subprocess, sys, textwrap
+    # DFOT_WGRAD_FORM is read once per process: one child per form
+    code = textwrap.dedent(f"""
+        import torch, sys
+        sys.path.insert(0, {os.path.dirname(os.path.dirname(os.path.abspath(__file__)))!r})
+        from dfot_amd import capi
+        rel = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm())
+        m, n, rows = {m}, {n}, {rows}
+        g = torch.Generator().manual_seed(m + n)
+        a = torch.randn(rows, m + 64, generator=g).to(torch.bfloat16)
+        b = torch.randn(rows, n + 128, generator=g).to(torch.bfloat16)
+        ad, bd = a.cuda(), b.cuda()
+        out = torch.full((m, n), float("nan"), device="cuda")
+        capi.check(capi.lib.dfot_op_wgrad_nt(capi.ptr(ad), m + 64, capi.ptr(bd), n + 128, capi.ptr(out), m, n, rows, 0, capi.stream_ptr()))
+        torch.cuda.synchronize()
+        ref = a[:, :m].float().T @ b[:, :n].float()
+        r = rel(out.cpu(), ref)
+        print(f"wgrad_nt form {form} {{m}}x{{n}} K={{rows}}: rel {{r:.2e}}")
+        assert r < 1e-5
+    """)
+    env = dict(os.environ)
+    if form >= 0:
+        env["DFOT_WGRAD_FORM"] = str(form)
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    print(r.stdout[-400:], r.stderr[-2000:] if r.returncode else "")
+    assert r.returncode == 0
 
 
 @pytest.mark.parametrize("m,n,rows,slices", [(128, 128, 256, 1), (384, 256, 1280, 3), (1152, 128, 640, 2), (256, 1152, 4096, 4)])
