@@ -69,6 +69,8 @@ struct WgradPlan {
   int form, slices;
 };
 WgradPlan wgrad_plan(int m, int n, long rows, long max_slices);
+int launch_wgrad_conv_taps(const bf16* dy, const bf16* x, float* out, int co, int ci, long pix, int slices, int img_h, int img_w, hipStream_t s);
+int wgrad_conv_tiles(int co, int ci, int* target);
 int launch_wgrad_nt_plan(const bf16* a, long lda, const bf16* b, long ldb, float* out, int m, int n, long rows, WgradPlan plan, hipStream_t s);
 // ---- training: loss gradient, gradient norm, AdamW (flat fp32 buffers) ----
 int launch_vloss_grad(const float* x, const float* noise, const float* v, const float* a, const float* sg, const float* coef, float* dv,

@@ -79,14 +79,15 @@ int conv3_backward(const bf16* x, const bf16* dy, const bf16* w_dgrad, float* dx
   // weight gradient: one token-axis GEMM per tap, both operands read in place (wgrad.hip conv mode: x rows shifted by the tap, zero outside
   // the image); few output tiles, K = pixels: split over workgroups into partial buffers
   // all nine taps in one launch (grid.y = tap): 9x the workgroups in flight, partial outputs [slice][tap][Co][Ci], one reduce pass
-  const long tiles = 9L * ((co + 127) / 128) * ((ci + 127) / 128);
-  int split = (int)(1024 / tiles);
+  int target = 0;
+  const long tiles = 9L * wgrad_conv_tiles(co, ci, &target);
+  int split = (int)(target / tiles);
   split = split < 1 ? 1 : (split > 128 ? 128 : split);
   while (split > 1 && (pix / 64 < 4L * split || (size_t)split * 9 * co * ci > sc.ws_floats)) --split;
   if (split == 1) {
-    if ((rc = launch_wgrad_nt(dy, co, x, ci, sc.taps, co, ci, pix, 1, s, H, W, 0, 0, 1))) return rc;
+    if ((rc = launch_wgrad_conv_taps(dy, x, sc.taps, co, ci, pix, 1, H, W, s))) return rc;
   } else {
-    if ((rc = launch_wgrad_nt(dy, co, x, ci, sc.ws, co, ci, pix, split, s, H, W, 0, 0, 1))) return rc;
+    if ((rc = launch_wgrad_conv_taps(dy, x, sc.ws, co, ci, pix, split, H, W, s))) return rc;
     hipLaunchKernelGGL(slices_sum_kernel, dim3(cdiv(9L * co * ci / 4, 256)), dim3(256), 0, s, sc.ws, sc.taps, 9L * co * ci / 4, split, 9L * co * ci);
     DFOT_CHECK_HIP(hipGetLastError());
   }
@@ -163,39 +164,67 @@ __device__ __forceinline__ float silu_grad(float z) {
 }
 
 // pass 1: sums[bt][grp] += (sum dxhat, sum dxhat xhat) over a chunk of pixels; dgamma / dbeta += per-channel sums.  One workgroup =
-// one (image, pixel chunk); a thread owns one channel and walks the chunk's pixels (coalesced over channels)
+// one (image, pixel chunk); C / 4 lanes cover a pixel row with 16-byte loads and the 256 / (C / 4) lane groups take alternate
+// pixels; the groups are summed through LDS before the atomics.  C a multiple of 128 and at most 1024 (launcher)
 template <bool FILM>
 __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ stats,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
                                                             const bf16* __restrict__ film, float* __restrict__ sums, float* __restrict__ dgamma,
                                                             float* __restrict__ dbeta, int P, int C, int chunk) {
+  typedef __attribute__((ext_vector_type(4))) float f4;
+  __shared__ f4 red[4][256];  // [quantity][thread]
   const int bt = blockIdx.x, p0 = blockIdx.y * chunk;
-  const int cpg = C / 32;
-  for (int c = threadIdx.x; c < C; c += 256) {
-    const int grp = c / cpg;
-    const float mean = stats[((long)bt * 32 + grp) * 2], rstd = stats[((long)bt * 32 + grp) * 2 + 1];
-    const float ga = gamma[c], be = beta[c];
-    float s1 = 0.f, s2 = 0.f, dgm = 0.f, dbt = 0.f;
-    for (int p = p0; p < p0 + chunk && p < P; ++p) {
+  const int cq = C / 4, cpg = C / 32;
+  const int passes = (cq + 255) / 256;            // > 1 only for C > 1024 (not used)
+  const int lanes = cq < 256 ? cq : 256, groups = 256 / lanes;
+  const int lane = threadIdx.x % lanes, rg = threadIdx.x / lanes;
+  (void)passes;
+  const int c = lane * 4, grp = c / cpg;
+  const float mean = stats[((long)bt * 32 + grp) * 2], rstd = stats[((long)bt * 32 + grp) * 2 + 1];
+  const f4 ga = *reinterpret_cast<const f4*>(gamma + c), be = *reinterpret_cast<const f4*>(beta + c);
+  f4 dgm = {0.f, 0.f, 0.f, 0.f}, dbt = dgm, s1 = dgm, s2 = dgm;
+  const int p1 = p0 + chunk < P ? p0 + chunk : P;
+  if (rg < groups) {
+#pragma unroll 4
+    for (int p = p0 + rg; p < p1; p += groups) {
       const long e = ((long)bt * P + p) * C + c;
-      const float xh = (x[e] - mean) * rstd;
-      const float gv = xh * ga + be;
-      float z = gv, mul = 1.f;
+      const f4 xv = *reinterpret_cast<const f4*>(x + e), dv = *reinterpret_cast<const f4*>(dy + e);
+      bf16x4 fs, fh;
       if (FILM) {
         const long f = ((long)bt * P + p) * 2 * C + c;
-        mul = 1.0f + bf2f(film[f]);
-        z = gv * mul + bf2f(film[f + C]);
+        fs = *reinterpret_cast<const bf16x4*>(film + f);
+        fh = *reinterpret_cast<const bf16x4*>(film + f + C);
       }
-      const float dg = dy[e] * silu_grad(z) * mul;
-      dgm += dg * xh;
-      dbt += dg;
-      s1 += dg * ga;
-      s2 += dg * ga * xh;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float xh = (xv[j] - mean) * rstd;
+        const float gv = xh * ga[j] + be[j];
+        float z = gv, mul = 1.f;
+        if (FILM) {
+          mul = 1.0f + bf2f(fs[j]);
+          z = gv * mul + bf2f(fh[j]);
+        }
+        const float dg = dv[j] * silu_grad(z) * mul;
+        dgm[j] += dg * xh;
+        dbt[j] += dg;
+        s1[j] += dg * ga[j];
+        s2[j] += dg * ga[j] * xh;
+      }
     }
-    atomicAdd(dgamma + c, dgm);
-    atomicAdd(dbeta + c, dbt);
-    atomicAdd(sums + ((long)bt * 32 + grp) * 2, s1);
-    atomicAdd(sums + ((long)bt * 32 + grp) * 2 + 1, s2);
+  }
+  red[0][threadIdx.x] = dgm; red[1][threadIdx.x] = dbt; red[2][threadIdx.x] = s1; red[3][threadIdx.x] = s2;
+  __syncthreads();
+  if (threadIdx.x < lanes) {
+    for (int g = 1; g < groups; ++g) {
+      dgm += red[0][g * lanes + lane]; dbt += red[1][g * lanes + lane]; s1 += red[2][g * lanes + lane]; s2 += red[3][g * lanes + lane];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      atomicAdd(dgamma + c + j, dgm[j]);
+      atomicAdd(dbeta + c + j, dbt[j]);
+    }
+    atomicAdd(sums + ((long)bt * 32 + grp) * 2, (s1[0] + s1[1]) + (s1[2] + s1[3]));
+    atomicAdd(sums + ((long)bt * 32 + grp) * 2 + 1, (s2[0] + s2[1]) + (s2[2] + s2[3]));
   }
 }
 
@@ -203,42 +232,61 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const float* __restr
 template <bool FILM>
 __global__ void gn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ stats,
                                     const float* __restrict__ gamma, const float* __restrict__ beta, const bf16* __restrict__ film,
-                                    const float* __restrict__ sums, float* __restrict__ dx, bf16* __restrict__ dfilm, long total, int P, int C,
+                                    const float* __restrict__ sums, float* __restrict__ dx, bf16* __restrict__ dfilm, long total4, int P, int C,
                                     int accumulate) {
-  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= total) return;
-  const int c = (int)(e % C);
-  const long row = e / C;
+  typedef __attribute__((ext_vector_type(4))) float f4;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;  // 4 channels of one pixel (they share a group: C / 32 >= 4)
+  if (i >= total4) return;
+  const unsigned cq = (unsigned)(C / 4);
+  const long row = i / cq;
+  const int c = (int)(i % cq) * 4;
   const int bt = (int)(row / P);
   const int cpg = C / 32, grp = c / cpg;
   const float mean = stats[((long)bt * 32 + grp) * 2], rstd = stats[((long)bt * 32 + grp) * 2 + 1];
   const float inv_n = 1.0f / ((float)P * (float)cpg);
-  const float xh = (x[e] - mean) * rstd, ga = gamma[c];
-  const float gv = xh * ga + beta[c];
-  float z = gv, mul = 1.f;
-  if (FILM) {
-    mul = 1.0f + bf2f(film[row * 2 * C + c]);
-    z = gv * mul + bf2f(film[row * 2 * C + C + c]);
-  }
-  const float dz = dy[e] * silu_grad(z);
-  if (FILM) {
-    dfilm[row * 2 * C + c] = f2bf(dz * gv);
-    dfilm[row * 2 * C + C + c] = f2bf(dz);
-  }
-  const float dxh = dz * mul * ga;
   const float s1 = sums[((long)bt * 32 + grp) * 2] * inv_n, s2 = sums[((long)bt * 32 + grp) * 2 + 1] * inv_n;
-  const float v = rstd * (dxh - s1 - xh * s2);
-  dx[e] = accumulate ? dx[e] + v : v;
+  const long e = row * C + c;
+  const f4 xv = *reinterpret_cast<const f4*>(x + e), dv = *reinterpret_cast<const f4*>(dy + e);
+  const f4 ga = *reinterpret_cast<const f4*>(gamma + c), be = *reinterpret_cast<const f4*>(beta + c);
+  bf16x4 fs, fh, ds, dh;
+  if (FILM) {
+    fs = *reinterpret_cast<const bf16x4*>(film + row * 2 * C + c);
+    fh = *reinterpret_cast<const bf16x4*>(film + row * 2 * C + C + c);
+  }
+  f4 v;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float xh = (xv[j] - mean) * rstd;
+    const float gv = xh * ga[j] + be[j];
+    float z = gv, mul = 1.f;
+    if (FILM) {
+      mul = 1.0f + bf2f(fs[j]);
+      z = gv * mul + bf2f(fh[j]);
+    }
+    const float dz = dv[j] * silu_grad(z);
+    if (FILM) {
+      ds[j] = f2bf(dz * gv);
+      dh[j] = f2bf(dz);
+    }
+    v[j] = rstd * (dz * mul * ga[j] - s1 - xh * s2);
+  }
+  if (FILM) {
+    *reinterpret_cast<bf16x4*>(dfilm + row * 2 * C + c) = ds;
+    *reinterpret_cast<bf16x4*>(dfilm + row * 2 * C + C + c) = dh;
+  }
+  if (accumulate) v += *reinterpret_cast<const f4*>(dx + e);
+  *reinterpret_cast<f4*>(dx + e) = v;
 }
 
 // sums [BT][32][2] scratch; dgamma / dbeta must be zeroed by the caller (they accumulate)
 int gn_silu_backward(const float* x, const float* dy, const float* stats, const float* gamma, const float* beta, const bf16* film, float* sums,
                      float* dx, bf16* dfilm, float* dgamma, float* dbeta, int bt, int P, int C, bool accumulate, hipStream_t s) {
-  DFOT_REQUIRE(C % 32 == 0 && (film == nullptr) == (dfilm == nullptr), DFOT_ERR_ARG, "gn_silu_backward: bad argument");
+  DFOT_REQUIRE(C % 128 == 0 && C <= 1024 && 256 % (C / 4 < 256 ? C / 4 : 256) == 0 && (film == nullptr) == (dfilm == nullptr), DFOT_ERR_ARG,
+               "gn_silu_backward: channels %d must be 128, 256, 512 or 1024", C);
   DFOT_CHECK_HIP(hipMemsetAsync(sums, 0, (size_t)bt * 64 * sizeof(float), s));
   const int chunk = P >= 4096 ? 512 : 64;  // pixels per workgroup: every thread ends with 4 atomics, so few, long chunks on the big maps
   const dim3 grid(bt, cdiv(P, chunk));
-  const long total = (long)bt * P * C;
+  const long total = (long)bt * P * (C / 4);
   if (film) {
     hipLaunchKernelGGL(gn_bwd_reduce_kernel<true>, grid, dim3(256), 0, s, x, dy, stats, gamma, beta, film, sums, dgamma, dbeta, P, C, chunk);
     hipLaunchKernelGGL(gn_bwd_apply_kernel<true>, dim3(cdiv(total, 256)), dim3(256), 0, s, x, dy, stats, gamma, beta, film, sums, dx, dfilm, total, P, C,
@@ -719,16 +767,29 @@ namespace {
 
 // out bf16 = SiLU(GN(x) [* (1 + scale) + shift])   (x fp32 [BT][P][C], stats [BT][32][2], film bf16 [BT*P][2C] or null)
 __global__ void gn_silu_fwd_kernel(const float* __restrict__ x, const float* __restrict__ stats, const float* __restrict__ gamma,
-                                   const float* __restrict__ beta, const bf16* __restrict__ film, bf16* __restrict__ out, long total, int P, int C) {
-  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= total) return;
-  const int c = (int)(e % C);
-  const long row = e / C;
+                                   const float* __restrict__ beta, const bf16* __restrict__ film, bf16* __restrict__ out, long total4, int P, int C) {
+  typedef __attribute__((ext_vector_type(4))) float f4;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;  // 4 channels of one pixel (one group: C / 32 >= 4)
+  if (i >= total4) return;
+  const unsigned cq = (unsigned)(C / 4);
+  const long row = i / cq;
+  const int c = (int)(i % cq) * 4;
   const int bt = (int)(row / P), grp = c / (C / 32);
   const float mean = stats[((long)bt * 32 + grp) * 2], rstd = stats[((long)bt * 32 + grp) * 2 + 1];
-  float z = (x[e] - mean) * rstd * gamma[c] + beta[c];
-  if (film) z = z * (1.0f + bf2f(film[row * 2 * C + c])) + bf2f(film[row * 2 * C + C + c]);
-  out[e] = f2bf(silu_f(z));
+  const f4 xv = *reinterpret_cast<const f4*>(x + row * C + c);
+  const f4 ga = *reinterpret_cast<const f4*>(gamma + c), be = *reinterpret_cast<const f4*>(beta + c);
+  bf16x4 fs, fh, o;
+  if (film) {
+    fs = *reinterpret_cast<const bf16x4*>(film + row * 2 * C + c);
+    fh = *reinterpret_cast<const bf16x4*>(film + row * 2 * C + C + c);
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    float z = (xv[j] - mean) * rstd * ga[j] + be[j];
+    if (film) z = z * (1.0f + bf2f(fs[j])) + bf2f(fh[j]);
+    o[j] = f2bf(silu_f(z));
+  }
+  *reinterpret_cast<bf16x4*>(out + row * C + c) = o;
 }
 
 // dx[bt][2y+a][2x+b][c] += dp[bt][y][x][c] / 4   (adjoint of the 2x2 average pool; dx fp32 [BT][H][W][C], dp fp32 [BT][H/2][W/2][C])
@@ -859,8 +920,16 @@ int dfot_op_gn_silu_fwd(const float* x, const float* gamma, const float* beta, c
                         int pixels, int channels, void* stream) {
   DFOT_REQUIRE(x && gamma && beta && out && stats && channels % 32 == 0, DFOT_ERR_ARG, "op_gn_silu_fwd: bad argument");
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(gn_stats_kernel, dim3(bt, 32), dim3(256), 0, s, x, stats, pixels, channels, eps);
-  const long total = (long)bt * pixels * channels;
+  DFOT_REQUIRE(channels % 128 == 0, DFOT_ERR_SHAPE, "op_gn_silu_fwd: channels %d must be a multiple of 128", channels);
+  // statistics: streaming partial sums over 64-pixel blocks of all channels + a deterministic finalize (the inference kernels); one
+  // workgroup per (image, group) read 16-byte slivers of every 512-byte pixel row
+  void* part = nullptr;
+  const int nblk = gn_partial_blocks(pixels);
+  int rc = op_scratch(6, (size_t)bt * nblk * 64 * sizeof(float), &part);
+  if (rc) return rc;
+  if ((rc = launch_gn_partial_f32(x, (float*)part, bt, pixels, channels, s))) return rc;
+  if ((rc = launch_gn_finalize((const float*)part, stats, bt, nblk, pixels, channels, eps, s))) return rc;
+  const long total = (long)bt * pixels * (channels / 4);
   hipLaunchKernelGGL(gn_silu_fwd_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, x, stats, gamma, beta, (const bf16*)film, (bf16*)out, total, pixels,
                      channels);
   DFOT_CHECK_HIP(hipGetLastError());

@@ -163,18 +163,20 @@ __device__ __forceinline__ bf16x8 w2_bf16x8(w2_u32x2 lo, w2_u32x2 hi) {
   const u32x4 v = {lo[0], lo[1], hi[0], hi[1]};
   return __builtin_bit_cast(bf16x8, v);
 }
-// chunk swizzle of a row of F features: 512-byte rows start on the same bank, so rows r, r+1, r+2, r+3 move by 64 bytes each;
+// chunk swizzle of a row of F features: 512- and 256-byte rows start on the same bank, so rows r, r+1, r+2, r+3 move by 64 bytes each;
 // 384-byte rows already alternate between the two bank halves, so only the row pairs move
 template <int F>
 __device__ __forceinline__ int w2_swz(int row, int chunk) {
-  if constexpr (F == 256) return chunk ^ ((row & 3) << 2);
+  if constexpr (F == 256 || F == 128) return chunk ^ ((row & 3) << 2);
   else return chunk ^ (((row >> 1) & 1) << 2);
 }
 
-template <int MW, int NW>
+// CONV: blockIdx.y = tap of a 3x3 convolution; B row r is pixel r shifted by (tap / 3 - 1, tap % 3 - 1) inside its img_h x img_w image,
+// zero outside (fetched from the zero buffer); partial outputs [slice][tap][M][N] -- as the all_taps mode of the form above
+template <int MW, int NW, bool CONV>
 __global__ __launch_bounds__(MW * NW * 64) void wgrad_nt_big_kernel(const bf16* __restrict__ A, long lda, const bf16* __restrict__ B, long ldb,
                                                                     float* __restrict__ out, int M, int N, long rows, int slices,
-                                                                    const bf16* __restrict__ zeros) {
+                                                                    const bf16* __restrict__ zeros, int img_h, int img_w) {
   constexpr int NWV = MW * NW, FA = MW * 64, FB = NW * 64, CPA = FA / 8, CPB = FB / 8;
   constexpr int RA = FA * 2, RB = FB * 2;             // LDS row pitch (bytes)
   constexpr int TA = 64 * RA, TB = 64 * RB, STG = TA + TB;
@@ -192,9 +194,12 @@ __global__ __launch_bounds__(MW * NW * 64) void wgrad_nt_big_kernel(const bf16* 
   const long t0 = slice * per + (slice < rem ? slice : rem), nt = per + (slice < rem ? 1 : 0);
 
   // DMA sources of this lane: instruction j of an operand fills LDS bytes [j * 1024, +1024) of its tile = linear chunks j * 64 + lane
+  const int sdy = CONV ? (int)blockIdx.y / 3 - 1 : 0, sdx = CONV ? (int)blockIdx.y % 3 - 1 : 0;
   const bf16* pa[PA];
   const bf16* pb[PB];
   long sa[PA], sb[PB];
+  long rb[PB];    // CONV: the pixel index of this lane's B row in the next tile to fetch
+  bool okb[PB];
 #pragma unroll
   for (int i = 0; i < PA; ++i) {
     const int q = (wave + i * NWV) * 64 + lane, row = q / CPA, col = w2_swz<FA>(row, q % CPA) * 8;
@@ -208,6 +213,9 @@ __global__ __launch_bounds__(MW * NW * 64) void wgrad_nt_big_kernel(const bf16* 
     const bool ok = n0 + col < N;
     pb[i] = ok ? B + (t0 * 64 + row) * ldb + n0 + col : zeros;
     sb[i] = ok ? 64 * ldb : 0;
+    rb[i] = t0 * 64 + row;
+    okb[i] = ok;
+    if constexpr (CONV) pb[i] = B + n0 + col;  // the row offset is applied per tile
   }
   auto issue = [&](int stage) {
     char* la = smem + stage * STG;
@@ -221,8 +229,17 @@ __global__ __launch_bounds__(MW * NW * 64) void wgrad_nt_big_kernel(const bf16* 
 #pragma unroll
     for (int i = 0; i < PB; ++i) {
       const int j = wave + i * NWV;
-      if (j < IB) __builtin_amdgcn_global_load_lds(DFOT_GLOBAL_PTR(pb[i]), DFOT_LDS_PTR(lb + j * 1024), 16, 0, 0);
-      pb[i] += sb[i];
+      if constexpr (CONV) {
+        const long r = rb[i];
+        const int x = (int)(r % img_w) + sdx, y = (int)((r / img_w) % img_h) + sdy;
+        const bool ok = okb[i] && x >= 0 && x < img_w && y >= 0 && y < img_h;
+        const bf16* src = ok ? pb[i] + (r + (long)sdy * img_w + sdx) * ldb : zeros;
+        if (j < IB) __builtin_amdgcn_global_load_lds(DFOT_GLOBAL_PTR(src), DFOT_LDS_PTR(lb + j * 1024), 16, 0, 0);
+        rb[i] = r + 64;
+      } else {
+        if (j < IB) __builtin_amdgcn_global_load_lds(DFOT_GLOBAL_PTR(pb[i]), DFOT_LDS_PTR(lb + j * 1024), 16, 0, 0);
+        pb[i] += sb[i];
+      }
     }
   };
 
@@ -287,7 +304,7 @@ __global__ __launch_bounds__(MW * NW * 64) void wgrad_nt_big_kernel(const bf16* 
 #undef W2_READ
 #undef W2_MMA
   // C lane layout: column n = lq, rows m = 8g + 4h + j in register 4g + j
-  float* o = out + (long)slice * M * N;
+  float* o = out + (CONV ? (long)slice * 9 + (long)blockIdx.y : (long)slice) * M * N;
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -303,10 +320,11 @@ __global__ __launch_bounds__(MW * NW * 64) void wgrad_nt_big_kernel(const bf16* 
 
 const bf16* g_w2_zeros = nullptr;
 
-template <int MW, int NW>
-int launch_big(const bf16* a, long lda, const bf16* b, long ldb, float* out, int m, int n, long rows, int slices, hipStream_t s) {
+template <int MW, int NW, bool CONV>
+int launch_big(const bf16* a, long lda, const bf16* b, long ldb, float* out, int m, int n, long rows, int slices, hipStream_t s, int img_h = 0,
+               int img_w = 0) {
   constexpr int FA = MW * 64, FB = NW * 64, LDS = 2 * 64 * (FA + FB) * 2;
-  auto kern = wgrad_nt_big_kernel<MW, NW>;
+  auto kern = wgrad_nt_big_kernel<MW, NW, CONV>;
   static bool attr_set = false;
   if (!attr_set) {
     DFOT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
@@ -319,7 +337,8 @@ int launch_big(const bf16* a, long lda, const bf16* b, long ldb, float* out, int
     g_w2_zeros = (const bf16*)z;
   }
   const int tiles = ((m + FA - 1) / FA) * ((n + FB - 1) / FB);
-  hipLaunchKernelGGL(kern, dim3(tiles * slices), dim3(MW * NW * 64), LDS, s, a, lda, b, ldb, out, m, n, rows, slices, g_w2_zeros);
+  hipLaunchKernelGGL(kern, dim3(tiles * slices, CONV ? 9 : 1), dim3(MW * NW * 64), LDS, s, a, lda, b, ldb, out, m, n, rows, slices, g_w2_zeros, img_h,
+                     img_w);
   DFOT_CHECK_HIP(hipGetLastError());
   return DFOT_OK;
 }
@@ -380,6 +399,26 @@ WgradPlan wgrad_plan(int m, int n, long rows, long max_slices) {
   return best;
 }
 
+// all nine taps of a 3x3 convolution's weight gradient in one launch (a = dy [pixels][co], b = x [pixels][ci], out [slices][9][co][ci]):
+// LDS-DMA form with a 128 x 128 (co, ci <= 128), 256 x 256 or the 128 x 128 register-staged tile (DFOT_WGRAD_CONV_DMA=0)
+int launch_wgrad_conv_taps(const bf16* dy, const bf16* x, float* out, int co, int ci, long pix, int slices, int img_h, int img_w, hipStream_t s) {
+  static const int dma = tuning_flag("WGRAD_CONV_DMA", 1);
+  if (!dma) return launch_wgrad_nt(dy, co, x, ci, out, co, ci, pix, slices, s, img_h, img_w, 0, 0, 1);
+  DFOT_REQUIRE(dy && x && out && co % 8 == 0 && ci % 8 == 0 && pix % 64 == 0 && slices >= 1 && slices <= pix / 64 && img_h > 0 && img_w > 0 &&
+                   pix % ((long)img_h * img_w) == 0,
+               DFOT_ERR_SHAPE, "wgrad_conv_taps: %d -> %d channels, %ld pixels unsupported", ci, co, pix);
+  if (co <= 128 && ci <= 128) return launch_big<2, 2, true>(dy, co, x, ci, out, co, ci, pix, slices, s, img_h, img_w);
+  return launch_big<4, 4, true>(dy, co, x, ci, out, co, ci, pix, slices, s, img_h, img_w);
+}
+// workgroups per tap and slice of launch_wgrad_conv_taps, and the workgroup count to aim for with K slices (two rounds of the
+// 128 x 128 forms, two resident per CU; one round of the 256 x 256 form, whose partial outputs are four times as large)
+int wgrad_conv_tiles(int co, int ci, int* target) {
+  static const int dma = tuning_flag("WGRAD_CONV_DMA", 1);
+  const int f = (!dma || (co <= 128 && ci <= 128)) ? 128 : 256;
+  if (target) *target = f == 128 ? 1024 : 256;
+  return ((co + f - 1) / f) * ((ci + f - 1) / f);
+}
+
 // out: [plan.slices][M][N] partial outputs (the caller sums them when slices > 1)
 int launch_wgrad_nt_plan(const bf16* a, long lda, const bf16* b, long ldb, float* out, int m, int n, long rows, WgradPlan plan, hipStream_t s) {
   if (plan.form == 0) return launch_wgrad_nt(a, lda, b, ldb, out, m, n, rows, plan.slices, s);
@@ -388,9 +427,9 @@ int launch_wgrad_nt_plan(const bf16* a, long lda, const bf16* b, long ldb, float
                    plan.slices <= rows / 64,
                DFOT_ERR_SHAPE, "wgrad_nt: M=%d N=%d must be multiples of 8, rows=%ld of 64", m, n, rows);
   switch (plan.form) {
-    case 1: return launch_big<4, 4>(a, lda, b, ldb, out, m, n, rows, plan.slices, s);
-    case 2: return launch_big<4, 3>(a, lda, b, ldb, out, m, n, rows, plan.slices, s);
-    case 3: return launch_big<3, 4>(a, lda, b, ldb, out, m, n, rows, plan.slices, s);
+    case 1: return launch_big<4, 4, false>(a, lda, b, ldb, out, m, n, rows, plan.slices, s);
+    case 2: return launch_big<4, 3, false>(a, lda, b, ldb, out, m, n, rows, plan.slices, s);
+    case 3: return launch_big<3, 4, false>(a, lda, b, ldb, out, m, n, rows, plan.slices, s);
   }
   DFOT_REQUIRE(false, DFOT_ERR_ARG, "wgrad_nt: unknown tile form %d", plan.form);
 }

@@ -335,7 +335,8 @@ def test_ema_and_optimizer_state_round_trip():
     torch.testing.assert_close(tr2.params, tr.params, rtol=1e-5, atol=1e-6)
 
 
-@pytest.mark.parametrize("bt,h,w,cin,cout", [(2, 16, 16, 128, 128), (3, 8, 16, 64, 192), (1, 32, 32, 256, 128)])
+@pytest.mark.parametrize("bt,h,w,cin,cout", [(2, 16, 16, 128, 128), (3, 8, 16, 64, 192), (1, 32, 32, 256, 128), (2, 16, 16, 256, 256),
+                                             (1, 16, 16, 576, 256), (8, 32, 32, 128, 128), (16, 32, 32, 256, 256)])
 def test_conv3x3_backward(bt, h, w, cin, cout):
     """dx / dW / db of the channels-last 3x3 convolution (UViT ResBlocks, resamplers) vs torch autograd on the bf16-rounded operands"""
     from dfot_amd import capi
