@@ -121,6 +121,7 @@ SIGNATURES = {
     "dfot_op_attention_bwd_lse": (_I, [_P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "dfot_op_gn_silu_fwd": (_I, [_P, _P, _P, _P, _F, _P, _P, _I, _I, _I, _P]),
     "dfot_op_gn_silu_bwd2": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "dfot_op_gn_silu_bwd3": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _L, _P]),
     "dfot_op_pack_conv3": (_I, [_P, _P, _I, _I, _I, _P]),
     "dfot_op_conv3x3_f32": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "dfot_op_pool2_bf16": (_I, [_P, _P, _I, _I, _I, _I, _P]),
@@ -182,6 +183,20 @@ def ptr(t, dtype=None, name: str = "tensor") -> C.c_void_p:
         raise ValueError(f"{name} is on {t.device}: libdfot_hip takes GPU memory only (there is no CPU path)")
     if not t.is_contiguous():
         raise ValueError(f"{name} with shape {tuple(t.shape)} and strides {tuple(t.stride())} is not contiguous")
+    if dtype is not None and t.dtype != dtype:
+        raise ValueError(f"{name} has dtype {t.dtype}, expected {dtype}")
+    return C.c_void_p(t.data_ptr())
+
+
+def ptr_rows(t, dtype=None, name: str = "tensor") -> C.c_void_p:
+    """Device pointer of a 2-D matrix whose rows are contiguous but may be a column block of a wider one (stride(0) >= shape[1]): for
+    the entry points that take a row stride next to the pointer.  Everything else as ptr()."""
+    if t is None:
+        return C.c_void_p(0)
+    if not t.is_cuda:
+        raise ValueError(f"{name} is on {t.device}: libdfot_hip takes GPU memory only (there is no CPU path)")
+    if t.dim() != 2 or t.stride(1) != 1 or t.stride(0) < t.shape[1]:
+        raise ValueError(f"{name} with shape {tuple(t.shape)} and strides {tuple(t.stride())} is not a row-strided matrix")
     if dtype is not None and t.dtype != dtype:
         raise ValueError(f"{name} has dtype {t.dtype}, expected {dtype}")
     return C.c_void_p(t.data_ptr())

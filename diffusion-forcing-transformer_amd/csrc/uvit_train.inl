@@ -233,7 +233,7 @@ template <bool FILM>
 __global__ void gn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ stats,
                                     const float* __restrict__ gamma, const float* __restrict__ beta, const bf16* __restrict__ film,
                                     const float* __restrict__ sums, float* __restrict__ dx, bf16* __restrict__ dfilm, long total4, int P, int C,
-                                    int accumulate) {
+                                    int accumulate, long ldf) {
   typedef __attribute__((ext_vector_type(4))) float f4;
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;  // 4 channels of one pixel (they share a group: C / 32 >= 4)
   if (i >= total4) return;
@@ -271,8 +271,8 @@ __global__ void gn_bwd_apply_kernel(const float* __restrict__ x, const float* __
     v[j] = rstd * (dz * mul * ga[j] - s1 - xh * s2);
   }
   if (FILM) {
-    *reinterpret_cast<bf16x4*>(dfilm + row * 2 * C + c) = ds;
-    *reinterpret_cast<bf16x4*>(dfilm + row * 2 * C + C + c) = dh;
+    *reinterpret_cast<bf16x4*>(dfilm + row * ldf + c) = ds;  // ldf: dfilm may be a column block of a wider matrix
+    *reinterpret_cast<bf16x4*>(dfilm + row * ldf + C + c) = dh;
   }
   if (accumulate) v += *reinterpret_cast<const f4*>(dx + e);
   *reinterpret_cast<f4*>(dx + e) = v;
@@ -280,7 +280,8 @@ __global__ void gn_bwd_apply_kernel(const float* __restrict__ x, const float* __
 
 // sums [BT][32][2] scratch; dgamma / dbeta must be zeroed by the caller (they accumulate)
 int gn_silu_backward(const float* x, const float* dy, const float* stats, const float* gamma, const float* beta, const bf16* film, float* sums,
-                     float* dx, bf16* dfilm, float* dgamma, float* dbeta, int bt, int P, int C, bool accumulate, hipStream_t s) {
+                     float* dx, bf16* dfilm, float* dgamma, float* dbeta, int bt, int P, int C, bool accumulate, hipStream_t s, long ldf = 0) {
+  if (ldf == 0) ldf = 2L * C;
   DFOT_REQUIRE(C % 128 == 0 && C <= 1024 && 256 % (C / 4 < 256 ? C / 4 : 256) == 0 && (film == nullptr) == (dfilm == nullptr), DFOT_ERR_ARG,
                "gn_silu_backward: channels %d must be 128, 256, 512 or 1024", C);
   DFOT_CHECK_HIP(hipMemsetAsync(sums, 0, (size_t)bt * 64 * sizeof(float), s));
@@ -290,11 +291,11 @@ int gn_silu_backward(const float* x, const float* dy, const float* stats, const 
   if (film) {
     hipLaunchKernelGGL(gn_bwd_reduce_kernel<true>, grid, dim3(256), 0, s, x, dy, stats, gamma, beta, film, sums, dgamma, dbeta, P, C, chunk);
     hipLaunchKernelGGL(gn_bwd_apply_kernel<true>, dim3(cdiv(total, 256)), dim3(256), 0, s, x, dy, stats, gamma, beta, film, sums, dx, dfilm, total, P, C,
-                       accumulate ? 1 : 0);
+                       accumulate ? 1 : 0, ldf);
   } else {
     hipLaunchKernelGGL(gn_bwd_reduce_kernel<false>, grid, dim3(256), 0, s, x, dy, stats, gamma, beta, film, sums, dgamma, dbeta, P, C, chunk);
     hipLaunchKernelGGL(gn_bwd_apply_kernel<false>, dim3(cdiv(total, 256)), dim3(256), 0, s, x, dy, stats, gamma, beta, film, sums, dx, dfilm, total, P, C,
-                       accumulate ? 1 : 0);
+                       accumulate ? 1 : 0, ldf);
   }
   DFOT_CHECK_HIP(hipGetLastError());
   return DFOT_OK;
@@ -947,6 +948,19 @@ int dfot_op_gn_silu_bwd2(const float* x, const float* dy, const float* stats, co
   DFOT_CHECK_HIP(hipMemsetAsync(dbeta, 0, (size_t)channels * sizeof(float), s));
   return gn_silu_backward(x, dy, stats, gamma, beta, (const bf16*)film, (float*)sums, dx, (bf16*)dfilm, dgamma, dbeta, bt, pixels, channels,
                           accumulate_dx != 0, s);
+}
+int dfot_op_gn_silu_bwd3(const float* x, const float* dy, const float* stats, const float* gamma, const float* beta, const void* film, float* dx,
+                         void* dfilm, float* dgamma, float* dbeta, int bt, int pixels, int channels, int accumulate_dx, int64_t dfilm_ld, void* stream) {
+  DFOT_REQUIRE(x && dy && stats && gamma && beta && dx && dgamma && dbeta && dfilm_ld >= 2 * channels && dfilm_ld % 4 == 0, DFOT_ERR_ARG,
+               "op_gn_silu_bwd3: bad argument");
+  hipStream_t s = (hipStream_t)stream;
+  void* sums = nullptr;
+  int rc = op_scratch(4, (size_t)bt * 64 * sizeof(float), &sums);
+  if (rc) return rc;
+  DFOT_CHECK_HIP(hipMemsetAsync(dgamma, 0, (size_t)channels * sizeof(float), s));
+  DFOT_CHECK_HIP(hipMemsetAsync(dbeta, 0, (size_t)channels * sizeof(float), s));
+  return gn_silu_backward(x, dy, stats, gamma, beta, (const bf16*)film, (float*)sums, dx, (bf16*)dfilm, dgamma, dbeta, bt, pixels, channels,
+                          accumulate_dx != 0, s, (long)dfilm_ld);
 }
 // w fp32 [Co][Ci][3][3] -> the forward kernel's layout [Co][tap][Ci] bf16 (dgrad = 0) or the data-gradient weights [Ci][tap'][Co] (dgrad = 1)
 int dfot_op_pack_conv3(const float* w, void* out, int co, int ci, int dgrad, void* stream) {

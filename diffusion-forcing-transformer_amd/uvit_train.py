@@ -9,7 +9,7 @@ A first, op-by-op driver: correct (parity-tested against torch autograd through 
 from __future__ import annotations
 
 import math
-from typing import Dict, Optional, Tuple
+from typing import Dict, List, Optional, Tuple
 
 import torch
 
@@ -18,6 +18,7 @@ from . import capi
 BF = torch.bfloat16
 _S = capi.stream_ptr
 _P = capi.ptr
+_PV = capi.ptr_rows  # matrices that may be column blocks of wider ones (the entry point takes the row stride)
 
 
 def _bf(t: torch.Tensor) -> torch.Tensor:
@@ -49,13 +50,13 @@ def gemm_f32(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = No
     m, k = a.shape
     if out is None:
         out = torch.empty(m, w.shape[0], dtype=torch.float32, device="cuda")
-    capi.check(capi.lib.dfot_op_gemm_f32(_P(a), a.stride(0), _P(w), _P(bias), _P(resid), _P(out), out.stride(0), m, w.shape[0], k, _S()))
+    capi.check(capi.lib.dfot_op_gemm_f32(_PV(a), a.stride(0), _P(w), _P(bias), _P(resid), _P(out), out.stride(0), m, w.shape[0], k, _S()))
     return out
 
 
 def colsum(x: torch.Tensor) -> torch.Tensor:
     out = torch.empty(x.shape[1], dtype=torch.float32, device="cuda")
-    capi.check(capi.lib.dfot_op_colsum_bf16(_P(x), x.stride(0), _P(out), x.shape[0], x.shape[1], _S()))
+    capi.check(capi.lib.dfot_op_colsum_bf16(_PV(x), x.stride(0), _P(out), x.shape[0], x.shape[1], _S()))
     return out
 
 
@@ -64,7 +65,7 @@ def wgrad(dy: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
     rows, m = dy.shape
     n = x.shape[1]
     out = torch.empty(m, n, dtype=torch.float32, device="cuda")
-    capi.check(capi.lib.dfot_op_wgrad_nt(_P(dy), dy.stride(0), _P(x), x.stride(0), _P(out), m, n, rows, 0, _S()))  # 0: tile form / K slices by shape
+    capi.check(capi.lib.dfot_op_wgrad_nt(_PV(dy), dy.stride(0), _PV(x), x.stride(0), _P(out), m, n, rows, 0, _S()))  # 0: tile form / K slices by shape
     return out
 
 
@@ -224,17 +225,20 @@ class ResBlockTrain:
         self.saved = dict(x=x, emb=emb, h1=h1, c1=c1, film=film, h2=h2, st1=st1, st2=st2, geom=(bt, h, w))
         return y
 
-    def backward(self, dy: torch.Tensor, demb_acc: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    def backward(self, dy: torch.Tensor, demb_acc: Optional[torch.Tensor] = None,
+                 dfilm_out: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+        """dfilm_out: a [rows][2C] bf16 column block of the level's FiLM-gradient matrix; the block then leaves the embedding gradient
+        (dfilm W_e over the level's concatenated K) to the caller instead of adding its own [rows][E] product to demb_acc"""
         s, c, p, lib = self.saved, self.c, self.p, capi.lib
         bt, h, w = s["geom"]
         P = h * w
         dh2, dw2, db2 = conv3x3_backward(s["h2"], _bf(dy), p["out_rest.1.weight"], bt, h, w, c, c)
         dc1 = torch.empty(bt * P, c, dtype=torch.float32, device="cuda")
-        dfilm = torch.empty(bt * P, 2 * c, dtype=BF, device="cuda")
+        dfilm = dfilm_out if dfilm_out is not None else torch.empty(bt * P, 2 * c, dtype=BF, device="cuda")
         dg2, dbe2, dg1, dbe1 = (torch.empty(c, dtype=torch.float32, device="cuda") for _ in range(4))
-        capi.check(lib.dfot_op_gn_silu_bwd2(_P(s["c1"]), _P(dh2), _P(s["st2"]), _P(p["out_norm.weight"]), _P(p["out_norm.bias"]), _P(s["film"]), _P(dc1),
-                                            _P(dfilm), _P(dg2), _P(dbe2), bt, P, c, 0, _S()))
-        demb = gemm_f32(dfilm, self.w_eT, resid=demb_acc, out=demb_acc)
+        capi.check(lib.dfot_op_gn_silu_bwd3(_P(s["c1"]), _P(dh2), _P(s["st2"]), _P(p["out_norm.weight"]), _P(p["out_norm.bias"]), _P(s["film"]), _P(dc1),
+                                            _PV(dfilm), _P(dg2), _P(dbe2), bt, P, c, 0, dfilm.stride(0), _S()))
+        demb = None if dfilm_out is not None else gemm_f32(dfilm, self.w_eT, resid=demb_acc, out=demb_acc)
         dh1, dw1, db1 = conv3x3_backward(s["h1"], _bf(dc1), p["in_layers.2.weight"], bt, h, w, c, c)
         dx = dy.clone()
         capi.check(lib.dfot_op_gn_silu_bwd2(_P(s["x"]), _P(dh1), _P(s["st1"]), _P(p["in_layers.0.weight"]), _P(p["in_layers.0.bias"]), None, _P(dx), None,
@@ -329,6 +333,17 @@ class UViT3DPoseTrainer:
         self.wu = [pack_conv(p[f"up_blocks.{j}.0.conv.weight"]) for j in range(3)]
         for b in self._blocks():
             b.sync()
+        # ResBlock levels: the column offset of every block in its level's FiLM-gradient matrix, and the matching [E][blocks * 2C]
+        # concatenation of the emb_layer weights (backward: one embedding-gradient GEMM per level)
+        self.res_cols: Dict[int, int] = {}
+        self.res_wcat: Dict[int, torch.Tensor] = {}
+        for l in range(4):
+            blocks = [b for b in (self.mid if l == 3 else self.down[l] + self.up[2 - l]) if isinstance(b, ResBlockTrain)]
+            if not blocks:
+                continue
+            for i, b in enumerate(blocks):
+                self.res_cols[id(b)] = i * 2 * self.ch[l]
+            self.res_wcat[l] = torch.cat([b.w_eT for b in blocks], dim=1).contiguous()
 
     def _blocks(self):
         return [b for lv in self.down for b in lv] + self.mid + [b for lv in self.up for b in lv]
@@ -418,11 +433,21 @@ class UViT3DPoseTrainer:
                     handed.add(n)
                     o, shp = self.layout[n]
                     reducer.add(self.flat_grads[o: o + gv.numel()], gv)
-        demb = [torch.zeros(bt * r[l] * r[l], e, dtype=torch.float32, device="cuda") for l in range(4)]
+        # embedding gradients.  Levels 2, 3 (transformer blocks): every block adds dfilm W_e into the level's fp32 accumulator in its GEMM
+        # epilogue.  Levels 0, 1 (ResBlocks, 1 M / 262 K pixel rows x 1024): a read-modify-write of that accumulator per block is 8 GB of
+        # traffic at level 0, so the blocks of a level write their FiLM gradients side by side into one [rows][blocks * 2C] matrix and ONE
+        # GEMM over the concatenated K produces the level's embedding gradient (res_cols / res_wcat: _sync_derived)
+        demb: List[Optional[torch.Tensor]] = [None if l in self.res_wcat else torch.zeros(bt * r[l] * r[l], e, dtype=torch.float32, device="cuda")
+                                              for l in range(4)]
+        dfilm_cat = {l: torch.empty(bt * r[l] * r[l], w.shape[1], dtype=BF, device="cuda") for l, w in self.res_wcat.items()}
 
         def run_back(blocks, prefix_fn, dh, lvl):
             for i in reversed(range(len(blocks))):
-                dh, _ = blocks[i].backward(dh, demb[lvl])  # the block adds its embedding gradient into the level's accumulator
+                if lvl in dfilm_cat:
+                    c0 = self.res_cols[id(blocks[i])]
+                    dh, _ = blocks[i].backward(dh, None, dfilm_cat[lvl][:, c0: c0 + 2 * ch[lvl]])
+                else:
+                    dh, _ = blocks[i].backward(dh, demb[lvl])  # the block adds its embedding gradient into the level's accumulator
                 for n, gv in blocks[i].grads.items():
                     G[f"{prefix_fn(i)}.{n}"] = gv
             return dh
@@ -460,6 +485,9 @@ class UViT3DPoseTrainer:
         capi.check(lib.dfot_op_embed_input_wgrad(_P(dh), _P(self.x_in), _P(dw), _P(db), bt, self.res, self.cin, ch[0], self.ps, _S()))
         G["embed_input.proj.weight"], G["embed_input.proj.bias"] = dw, db
         # embedding pyramid (successive 2x2 average pools), pose patch embedding, noise-level MLP
+        for l in sorted(dfilm_cat, reverse=True):
+            demb[l] = gemm_f32(dfilm_cat[l], self.res_wcat[l])
+        dfilm_cat.clear()
         for l in (2, 1, 0):
             capi.check(lib.dfot_op_pool2_bwd(_P(demb[l + 1]), _P(demb[l]), bt, r[l], r[l], e, _S()))
         dpose = torch.empty(bt * P0, e, dtype=BF, device="cuda")  # the pose embedding of dropped videos was replaced by zero: no gradient

@@ -322,6 +322,9 @@ int dfot_op_gn_silu_fwd(const float* x, const float* gamma, const float* beta, c
                         int pixels, int channels, void* stream);
 int dfot_op_gn_silu_bwd2(const float* x, const float* dy, const float* stats, const float* gamma, const float* beta, const void* film, float* dx,
                          void* dfilm, float* dgamma, float* dbeta, int bt, int pixels, int channels, int accumulate_dx, void* stream);
+/* the same, dfilm written at row stride dfilm_ld (elements): a column block of a wider matrix */
+int dfot_op_gn_silu_bwd3(const float* x, const float* dy, const float* stats, const float* gamma, const float* beta, const void* film, float* dx,
+                         void* dfilm, float* dgamma, float* dbeta, int bt, int pixels, int channels, int accumulate_dx, int64_t dfilm_ld, void* stream);
 int dfot_op_pack_conv3(const float* w, void* out, int co, int ci, int dgrad, void* stream);
 int dfot_op_conv3x3_f32(const void* a, const void* w, const float* bias, const float* resid, float* y, int bt, int h, int w_, int cin, int cout,
                         void* stream);
