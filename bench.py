@@ -219,8 +219,7 @@ def bench_train_re10k(args, rank, world, dist):
             "data": "synthetic frames and camera poses, seeded random-init weights",
             "config": {"workload": f"DFoT RE10K training step (BASELINE config 5): {b} videos x 8 frames x {args.res}x{args.res} per GPU, UViT3DPose "
                                    "(channels 128/256/576/1152, 3+3+6 / 20 blocks), random_independent continuous levels, sigmoid-weighted v-loss, AdamW lr 5e-5 "
-                                   "wd 0.01 betas (0.9, 0.99), grad clip 1.0, fp32 master weights / bf16 compute; first driver: op-by-op over the C ABI, "
-                                   "no fused epilogues", "parameters": tr.numel},
+                                   "wd 0.01 betas (0.9, 0.99), grad clip 1.0, fp32 master weights / bf16 compute; driver sequencing the C-ABI ops from Python", "parameters": tr.numel},
             "losses": losses, "model_tflops": tf,
             "roofline": {"bound": "mfma", "kernel": "whole training step (3 x forward FLOPs)", "achieved": tf, "peak": 2500.0, "unit": "TFLOP/s",
                          "frac": tf / 2500.0, "traffic": None},

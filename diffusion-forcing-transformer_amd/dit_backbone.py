@@ -64,6 +64,11 @@ class DiT3D(nn.Module):
         self._synced: Optional[Tuple] = None
         self._reserved = 0
         self._op_key: Optional[int] = None
+        # training form (autograd): the saved-activation engine of trainer.DiT3DTrainer, built at the first forward under grad
+        self._ctor = dict(max_tokens=int(max_tokens), timesteps=int(timesteps))
+        self._trainer = None
+        self._trainer_sig = None
+        self._train_names = [n for n, _ in self.named_parameters()]
 
     def _configure(self, c: "capi.DiTConfig", cfg, max_tokens: int) -> None:
         """dit3d.yaml keys -> engine config (variant 0)."""
@@ -167,7 +172,52 @@ class DiT3D(nn.Module):
             raise ValueError("this DiT3D was built without an external condition embedding")
         if self._op_key is None:
             self._op_key = ops.register_model(self)
+        params = [p for _, p in self.named_parameters()]
+        if torch.is_grad_enabled() and any(p.requires_grad for p in params):
+            # the reference's training_step differentiates through `self.model(...)` (discrete_diffusion.py model_predictions ->
+            # accelerator.backward): saved-activation forward + the hand-written backward, registered with autograd (ops.py)
+            return torch.ops.dfot.dit3d_forward_train(x, noise_levels, params, self._op_key)
         return torch.ops.dfot.dit3d_forward(x, noise_levels, self._op_key)
+
+    # ------------------------------------------------------------------ training form (autograd)
+    def _train_engine(self, params):
+        """trainer.DiT3DTrainer on the module's CURRENT weights: built once; its flat parameter buffer is refreshed (and the bf16
+        compute copies re-packed) whenever a parameter changed since the last training forward."""
+        from . import trainer as _trainer
+        sig = tuple((t.data_ptr(), t._version) for t in params)
+        if self._trainer is None:
+            self._trainer = _trainer.DiT3DTrainer(self.cfg, self.x_shape, self._ctor["max_tokens"], timesteps=self._ctor["timesteps"])
+            missing = [n for n in self._trainer.layout if n not in self._train_names]
+            if missing:
+                raise RuntimeError(f"the training engine expects parameters the module does not have: {missing[:4]}")
+        if sig != self._trainer_sig:
+            with torch.no_grad():
+                self._trainer.load_state_dict({n: t for n, t in zip(self._train_names, params) if n in self._trainer.layout})
+            self._trainer_sig = sig
+        return self._trainer
+
+    def _train_forward_impl(self, x, noise_levels, params):
+        if x.ndim != 5 or tuple(x.shape[2:]) != self.x_shape:
+            raise ValueError(f"x has shape {tuple(x.shape)}, expected (B, T, {', '.join(map(str, self.x_shape))})")
+        if tuple(noise_levels.shape) != tuple(x.shape[:2]):
+            raise ValueError(f"noise_levels has shape {tuple(noise_levels.shape)}, expected {tuple(x.shape[:2])}")
+        if noise_levels.is_floating_point():
+            raise TypeError("DiT3D takes integer noise levels (DiscreteDiffusion passes the level index)")
+        dev = params[0].device
+        if dev.type != "cuda":
+            raise RuntimeError(f"the backbone's parameters are on {dev}; move the module to the GPU first (there is no CPU path)")
+        capi.require_device(dev, x=x, noise_levels=noise_levels)
+        with torch.no_grad():
+            return self._train_engine(params).forward(x, noise_levels).to(x.dtype)
+
+    def _train_backward_impl(self, grad_out, params):
+        eng = self._trainer
+        if eng is None:
+            raise RuntimeError("backward without a training forward")
+        with torch.no_grad():
+            eng.backward(grad_out)
+            return [eng.view(n, eng.grads).to(p.dtype).clone() if n in eng.layout else torch.zeros_like(p)
+                    for n, p in zip(self._train_names, params)]
 
     def _forward_impl(self, x: torch.Tensor, noise_levels: torch.Tensor) -> torch.Tensor:
         if x.ndim != 5 or tuple(x.shape[2:]) != self.x_shape:

@@ -105,6 +105,40 @@ def _(x, noise_levels, model):
     return torch.empty_like(x)
 
 
+# DiT3D / DifferenceDiT3D under autograd: as uvit3d_pose_forward_train, backed by trainer.DiT3DTrainer (dfot_dit_train_*)
+@custom_op("dfot::dit3d_forward_train", mutates_args=())
+def dit3d_forward_train(x: Tensor, noise_levels: Tensor, params: List[Tensor], model: int) -> Tensor:
+    return _model(model)._train_forward_impl(x, noise_levels, params)
+
+
+@dit3d_forward_train.register_fake
+def _(x, noise_levels, params, model):
+    return torch.empty_like(x)
+
+
+@custom_op("dfot::dit3d_backward", mutates_args=())
+def dit3d_backward(grad_out: Tensor, params: List[Tensor], model: int) -> List[Tensor]:
+    return _model(model)._train_backward_impl(grad_out, params)
+
+
+@dit3d_backward.register_fake
+def _(grad_out, params, model):
+    return [torch.empty_like(p) for p in params]
+
+
+def _dit_train_setup_context(ctx, inputs, output):
+    ctx.params = inputs[2]
+    ctx.model = inputs[3]
+
+
+def _dit_train_backward(ctx, grad_out):
+    grads = torch.ops.dfot.dit3d_backward(grad_out.contiguous(), ctx.params, ctx.model)
+    return None, None, grads, None
+
+
+dit3d_forward_train.register_autograd(_dit_train_backward, setup_context=_dit_train_setup_context)
+
+
 @custom_op("dfot::ray_encoding", mutates_args=())
 def ray_encoding(raw_poses: Tensor, resolution: int, normalized: bool = False) -> Tensor:
     """normalized = False: poses are raw and become relative to frame 0 (the reference's default, normalize_by "first");

@@ -91,6 +91,56 @@ def test_dit_backward_matches_autograd(hidden, heads, depth, mlp, patch, res):
     print(f"DiT3D backward hidden={hidden}: worst gradient rel-L2 {worst:.2e}")
 
 
+def test_dit_drop_in_backbone_is_trainable_through_autograd():
+    """VERDICT r1 #6 for the Kinetics-600 backbone: `dfot_amd.DiT3D(...)` called with gradients enabled dispatches
+    `dfot::dit3d_forward_train`; `loss.backward()` fills `param.grad` with the hand-written backward's result (equal to
+    DiT3DTrainer.backward on the same weights, within tolerance of autograd through the oracle), a second backward gives the same
+    gradients (nothing accumulates inside the engine), and under no_grad the module still runs the fused inference engine."""
+    import dfot_amd
+    from oracle import dit as odit
+    ocfg, params, tr = _tiny_trainer(depth=2, hidden=128, heads=4)
+    model = dfot_amd.DiT3D(dict(variant="full", pos_emb_type="rope_3d", patch_size=1, hidden_size=128, depth=2, num_heads=4, spatial_mlp_ratio=None),
+                           x_shape=(4, 16, 8), max_tokens=5).cuda()
+    model.load_state_dict(params, strict=True)
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(2, 5, 4, 16, 8, generator=g).cuda()
+    k = torch.randint(0, 1000, (2, 5), generator=g).cuda()
+    w = torch.randn(2, 5, 4, 16, 8, generator=g).cuda()
+    v = model(x, k)
+    assert v.requires_grad
+    (v * w).sum().backward()
+    named = dict(model.named_parameters())
+    first = {n: p.grad.clone() for n, p in named.items()}
+    out = tr.forward(x, k)
+    assert torch.equal(out, v.detach())
+    tr.backward(w)
+    tg = tr.grad_dict()
+    assert sorted(tg) == sorted(named)
+    for n, p in named.items():
+        assert rel(p.grad, tg[n]) < 2e-2, (n, rel(p.grad, tg[n]))
+    ps = {n: t.clone().requires_grad_() for n, t in params.items()}
+    ref = odit.forward(ps, ocfg, x.cpu(), k.cpu())
+    (ref * w.cpu()).sum().backward()
+    rs = {n: rel(p.grad.cpu(), ps[n].grad) for n, p in named.items()}
+    worst = max(rs, key=rs.get)
+    print(f"DiT3D drop-in autograd: forward rel-L2 {rel(v.detach().cpu(), ref.detach()):.2e}; worst gradient rel-L2 {rs[worst]:.2e} at {worst}")
+    assert rs[worst] < 5e-2
+    model.zero_grad()
+    (model(x, k) * w).sum().backward()
+    for n, p in named.items():
+        assert rel(p.grad, first[n]) < 2e-2, n
+    with torch.no_grad():
+        before = model(x, k)
+    assert not before.requires_grad and rel(before.cpu(), ref.detach()) < 2e-2
+    opt = torch.optim.SGD(model.parameters(), lr=1e-2)
+    opt.step()
+    with torch.no_grad():
+        after = model(x, k)
+    assert rel(after, before) > 1e-4   # the inference engine picked the updated weights up
+    v2 = model(x, k)                  # ... and so does the training engine
+    assert rel(v2.detach(), after) < 2e-2
+
+
 def test_dit_training_step_matches_torch_adamw():
     """loss, clipped AdamW update of every parameter after one step vs torch (autograd + clip_grad_norm_ + torch.optim.AdamW)"""
     from oracle import dit as odit, sampler as osm, schedule as sch
