@@ -199,6 +199,8 @@ class DiT3D(nn.Module):
     def _train_forward_impl(self, x, noise_levels, params):
         if x.ndim != 5 or tuple(x.shape[2:]) != self.x_shape:
             raise ValueError(f"x has shape {tuple(x.shape)}, expected (B, T, {', '.join(map(str, self.x_shape))})")
+        if x.shape[1] > self.max_tokens:
+            raise ValueError(f"{x.shape[1]} tokens exceed max_tokens={self.max_tokens}")
         if tuple(noise_levels.shape) != tuple(x.shape[:2]):
             raise ValueError(f"noise_levels has shape {tuple(noise_levels.shape)}, expected {tuple(x.shape[:2])}")
         if noise_levels.is_floating_point():
