@@ -451,6 +451,9 @@ int launch_attention(const bf16* q, const bf16* k, const bf16* v, bf16* o, long 
   if (variant == 14 && d == 64 && n % 256 == 0) return launch_attention_v5(q, k, v, o, ldo, batch, heads, n, stream);  // pipelined, no running max
   if ((variant >= 5 && variant <= 12) || variant == 14) variant = 2;
   if (variant == 2) {  // tuned kernel; K/V ring depth chosen by measurement: 3 stages (48 KiB) at d = 64, 2 stages at d = 128
+    static const int rows64 = tuning_flag("ATTN_ROWS64_D128", 0);  // see launch_attention_padded
+    if (d == 128 && rows64 && n % 256 == 0 && (long)batch * heads * (n / 256) >= 256)
+      return launch_attention_rows64_d128(q, k, v, o, ldo, batch, heads, n, d, nullptr, stream);
     return d == 64 ? launch_attn_v2<64, 3>(q, k, v, o, ldo, batch, heads, n, stream)
                    : launch_attn_v2<128, 2>(q, k, v, o, ldo, batch, heads, n, stream);
   }
@@ -481,6 +484,12 @@ int launch_attention_padded(const bf16* q, const bf16* k, const bf16* v, bf16* o
   DFOT_REQUIRE(ldo % 4 == 0, DFOT_ERR_SHAPE, "attention: output row stride %ld must be a multiple of 4", ldo);
   if (d <= 32) return launch_attn_v2<64, 3, 32, 32>(q, k, v, o, ldo, batch, heads, n, stream, d, d, lse);
   if (d <= 64) return launch_attn_v2<64, 3>(q, k, v, o, ldo, batch, heads, n, stream, d, d, lse);
+  // A/B experiment, off by default (DFOT_ATTN_ROWS64_D128=1): 64 query rows per wave (attention_v3d.hip) where the launch has at least
+  // one full round of 256-row tiles.  Half the LDS bytes per FLOP, but its ~300-360 VGPRs leave ONE wave per SIMD and the loop is not
+  // software-pipelined: 225 vs 207 us at B*H = 72, N = 2048, d = 128; Kinetics-600 DiT3D 60.3 vs 63.1 latent frames/s (same box)
+  static const int rows64 = tuning_flag("ATTN_ROWS64_D128", 0);
+  if (rows64 && n % 256 == 0 && (long)batch * heads * (n / 256) >= 256)
+    return launch_attention_rows64_d128(q, k, v, o, ldo, batch, heads, n, d, lse, stream);
   if (d <= 80) return launch_attn_v2<128, 2, 80, 96>(q, k, v, o, ldo, batch, heads, n, stream, d, d, lse);
   if (d <= 96) return launch_attn_v2<128, 2, 96, 96>(q, k, v, o, ldo, batch, heads, n, stream, d, d, lse);
   return launch_attn_v2<128, 2>(q, k, v, o, ldo, batch, heads, n, stream, d, d, lse);

@@ -354,14 +354,15 @@ AttnSplit attn_plan_split(int batch, int heads, int n, int qrows, int wgs_per_cu
   return sp;
 }
 
-int attn_partials(const AttnSplit& sp, int qrows, float** po, float** pml) {
+// dcols: floats per partial output row (64; 128 for the 128-element-row kernels of attention_v3d.hip)
+int attn_partials(const AttnSplit& sp, int qrows, float** po, float** pml, int dcols) {
   *po = *pml = nullptr;
   if (sp.nsplit == 1) return DFOT_OK;
   const size_t rows = (size_t)sp.rem * sp.nsplit * qrows;
-  int rc = ensure_partials(rows * (D + 2) * sizeof(float));
+  int rc = ensure_partials(rows * (dcols + 2) * sizeof(float));
   if (rc) return rc;
   *po = g_part;
-  *pml = g_part + rows * D;
+  *pml = g_part + rows * dcols;
   return DFOT_OK;
 }
 

@@ -108,7 +108,11 @@ struct AttnSplit {
   int tiles, full, rem, nsplit;
 };
 AttnSplit attn_plan_split(int batch, int heads, int n, int qrows, int wgs_per_cu);
-int attn_partials(const AttnSplit& sp, int qrows, float** po, float** pml);
+int attn_partials(const AttnSplit& sp, int qrows, float** po, float** pml, int dcols = 64);
+// 64 query rows per wave for head dims 65..128 in 128-element rows (attention_v3d.hip)
+int launch_attention_rows64_d128(const bf16* q, const bf16* k, const bf16* v, bf16* o, long ldo, int batch, int heads, int n, int d, float* lse,
+                                 hipStream_t stream);
+int attention_rows64_d128_reserve(int batch, int heads, int n);
 int attn_launch_merge(const AttnSplit& sp, int qrows, const float* po, const float* pml, bf16* o, long ldo, int n, int heads,
                       hipStream_t stream);
 int attention_dstride(int d);

@@ -14,7 +14,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import GOLDEN
+from conftest import GOLDEN, ROOT
 
 pytestmark = pytest.mark.gpu
 
@@ -85,6 +85,55 @@ def test_attention_padded(d, heads, n, batch):
     got = o.float().cpu()
     assert torch.isfinite(got).all()
     assert rel(got, ref) < 1.5e-2
+
+
+@pytest.mark.parametrize("d,heads,n,batch,big", [(72, 16, 1280, 8, False), (128, 9, 2048, 8, False), (96, 16, 256, 16, False), (80, 8, 512, 20, True),
+                                                 (128, 5, 768, 21, False)])
+def test_attention_rows64_d128(d, heads, n, batch, big):
+    """the 64-rows-per-wave kernel for 128-element rows (attention_v3d.hip; an A/B experiment selected by DFOT_ATTN_ROWS64_D128=1 when
+    the launch has >= 256 tiles of 256 rows, hence a child process): full rounds only (256 tiles), full rounds + a key-split tail
+    merged from fp32 partials (640 / 576 / 320 / 315 tiles), the log-sum-exp output of the training entry, and scores far outside the
+    deferred-rescale threshold (`big`: |s| up to ~60 in the log2 domain, rising along the key axis so that the running max keeps
+    growing) -- vs fp32 softmax on the same bf16 q, k, v"""
+    import subprocess, sys, textwrap
+    assert batch * heads * (n // 256) >= 256
+    code = textwrap.dedent(f"""
+        import math, sys, torch
+        sys.path.insert(0, {ROOT!r})
+        from dfot_amd import capi
+        d, heads, n, batch, big = {d}, {heads}, {n}, {batch}, {big}
+        rel = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm())
+        g = torch.Generator().manual_seed(d + n)
+        q, k, v = (torch.randn(batch, heads, n, d, generator=g) for _ in range(3))
+        if big:
+            k = k * torch.linspace(0.5, 6.0, n).view(1, 1, n, 1)
+        scale = math.log2(math.e) / math.sqrt(d)
+        def pad(t, mul=1.0):
+            out = torch.zeros(batch, heads, n, 128, dtype=torch.bfloat16, device="cuda")
+            out[..., :d] = (t * mul).to(torch.bfloat16).cuda()
+            return out
+        qd, kd, vd = pad(q, scale), pad(k), pad(v)
+        o = torch.full((batch, n, heads * d), float("nan"), dtype=torch.bfloat16, device="cuda")
+        lse = torch.full((batch, heads, n), float("nan"), device="cuda")
+        capi.check(capi.lib.dfot_op_attention_fwd_lse(capi.ptr(qd), capi.ptr(kd), capi.ptr(vd), capi.ptr(o), heads * d, capi.ptr(lse), batch, heads,
+                                                      n, d, capi.stream_ptr()))
+        o2 = torch.full((batch, n, heads * d), float("nan"), dtype=torch.bfloat16, device="cuda")
+        capi.check(capi.lib.dfot_op_attention_padded(capi.ptr(qd), capi.ptr(kd), capi.ptr(vd), capi.ptr(o2), heads * d, batch, heads, n, d,
+                                                     capi.stream_ptr()))
+        torch.cuda.synchronize()
+        assert torch.equal(o, o2)
+        # reference on the GPU in fp32 from the operands the kernel saw (q carries the log2e / sqrt(d) factor: softmax in base 2)
+        s2 = qd[..., :d].float() @ kd[..., :d].float().transpose(-1, -2)
+        ref_lse = torch.logsumexp(s2 * math.log(2.0), -1) / math.log(2.0)
+        ref = (torch.softmax(s2 * math.log(2.0), -1) @ vd[..., :d].float()).transpose(1, 2).reshape(batch, n, heads * d)
+        assert torch.isfinite(o.float()).all() and torch.isfinite(lse).all()
+        r, rl = rel(o.float(), ref), float((lse - ref_lse).abs().max())
+        print(f"attention rows64 d={{d}} B*H={{batch * heads}} N={{n}}: rel-L2 {{r:.2e}}, max |lse - ref| {{rl:.2e}}")
+        assert r < 1e-2 and rl < 2e-2
+    """)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, DFOT_ATTN_ROWS64_D128="1"), capture_output=True, text=True, timeout=300)
+    print(r.stdout[-300:], r.stderr[-2000:] if r.returncode else "")
+    assert r.returncode == 0
 
 
 def test_noise_level_embedding_table():
