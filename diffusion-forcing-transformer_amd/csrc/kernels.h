@@ -113,6 +113,7 @@ int attn_partials(const AttnSplit& sp, int qrows, float** po, float** pml, int d
 int launch_attention_rows64_d128(const bf16* q, const bf16* k, const bf16* v, bf16* o, long ldo, int batch, int heads, int n, int d, float* lse,
                                  hipStream_t stream);
 int attention_rows64_d128_reserve(int batch, int heads, int n);
+int attention_v2_reserve(int batch, int heads, int n, int d);  // partial-output scratch of attn_kernel_v2<128>'s balanced tail
 int attn_launch_merge(const AttnSplit& sp, int qrows, const float* po, const float* pml, bf16* o, long ldo, int n, int heads,
                       hipStream_t stream);
 int attention_dstride(int d);

@@ -674,8 +674,10 @@ int dfot_uvit_reserve(dfot_uvit_t h, int max_batch) {
   }
   // key-split partial buffers of the level-2 attention's balanced tail, for every batch this workspace can serve (so that
   // nothing is allocated inside forward / stream capture)
-  for (int b = 1; b <= max_batch; ++b)
+  for (int b = 1; b <= max_batch; ++b) {
     if ((rc = attention_v3_reserve(b, h->heads, h->T * h->r[2] * h->r[2]))) return rc;
+    if ((rc = attention_v2_reserve(b, h->heads, h->T * h->r[3] * h->r[3], h->ch[3] / h->heads))) return rc;
+  }
   h->max_batch = max_batch;
   return DFOT_OK;
 }

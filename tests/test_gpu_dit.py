@@ -62,7 +62,8 @@ def tiny_cfgs():
     return tiny, tiny_mlp, small
 
 
-@pytest.mark.parametrize("d,heads,n,batch", [(72, 16, 1280, 2), (32, 4, 640, 3), (64, 2, 256, 1), (96, 2, 384, 1), (120, 1, 128, 2)])
+@pytest.mark.parametrize("d,heads,n,batch", [(72, 16, 1280, 2), (32, 4, 640, 3), (64, 2, 256, 1), (96, 2, 384, 1), (120, 1, 128, 2), (72, 16, 1280, 8),
+                                             (128, 9, 2048, 2)])
 def test_attention_padded(d, heads, n, batch):
     from dfot_amd import capi
     g = torch.Generator().manual_seed(d)
@@ -89,12 +90,14 @@ def test_attention_padded(d, heads, n, batch):
 
 @pytest.mark.parametrize("d,heads,n,batch,big", [(72, 16, 1280, 8, False), (128, 9, 2048, 8, False), (96, 16, 256, 16, False), (80, 8, 512, 20, True),
                                                  (128, 5, 768, 21, False)])
-def test_attention_rows64_d128(d, heads, n, batch, big):
-    """the 64-rows-per-wave kernel for 128-element rows (attention_v3d.hip; an A/B experiment selected by DFOT_ATTN_ROWS64_D128=1 when
-    the launch has >= 256 tiles of 256 rows, hence a child process): full rounds only (256 tiles), full rounds + a key-split tail
-    merged from fp32 partials (640 / 576 / 320 / 315 tiles), the log-sum-exp output of the training entry, and scores far outside the
-    deferred-rescale threshold (`big`: |s| up to ~60 in the log2 domain, rising along the key axis so that the running max keeps
-    growing) -- vs fp32 softmax on the same bf16 q, k, v"""
+@pytest.mark.parametrize("rows64", [0, 1])
+def test_attention_d128_rows_large_launches(d, heads, n, batch, big, rows64):
+    """attention over 128-element rows at launch sizes with a balanced key-split tail, output AND log-sum-exp (training entry):
+    rows64 = 0: `attn_kernel_v2<128>` with its balanced tail switched on (DFOT_ATTN_V2_SPLIT=1: whole rounds of two workgroups per
+    CU + left-over tiles split over the keys, merged from fp32 partials by `attn_merge_rows_kernel`; off by default); rows64 = 1: the 64-rows-per-wave experiment (attention_v3d.hip, selected by
+    DFOT_ATTN_ROWS64_D128=1, hence a child process).  Cases: full rounds only, full rounds + split tail (several split factors), and
+    scores far outside the deferred-rescale threshold (`big`: |s| up to ~60 in the log2 domain, rising along the key axis so that the
+    running max keeps growing) -- vs fp32 softmax on the same bf16 q, k, v"""
     import subprocess, sys, textwrap
     assert batch * heads * (n // 256) >= 256
     code = textwrap.dedent(f"""
@@ -131,7 +134,7 @@ def test_attention_rows64_d128(d, heads, n, batch, big):
         print(f"attention rows64 d={{d}} B*H={{batch * heads}} N={{n}}: rel-L2 {{r:.2e}}, max |lse - ref| {{rl:.2e}}")
         assert r < 1e-2 and rl < 2e-2
     """)
-    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, DFOT_ATTN_ROWS64_D128="1"), capture_output=True, text=True, timeout=300)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, DFOT_ATTN_ROWS64_D128=str(rows64), DFOT_ATTN_V2_SPLIT="1"), capture_output=True, text=True, timeout=300)
     print(r.stdout[-300:], r.stderr[-2000:] if r.returncode else "")
     assert r.returncode == 0
 
