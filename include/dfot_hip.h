@@ -297,8 +297,10 @@ int dfot_op_rms_film_bwd_res(const float* x, const float* dxn, const float* w, c
 int dfot_op_qknorm_rope_bwd(const void* fused, int ld, const void* dq, const void* dk, const void* dv, const float* qw, const float* kw,
                             const float* rope_cs, float eps, void* dfused, int ldo, float* dqw, float* dkw, int64_t rows, int ntok, int heads, int d,
                             void* stream);
-/* test entry of the token-axis weight-gradient GEMM: out [M][N] fp32 = a^T b, a [rows][lda] and b [rows][ldb] bf16 in the activations'
- * own (feature-contiguous) layout; M, N multiples of 128, rows of 64; slices = K split (partial buffers are summed inside) */
+/* token-axis weight-gradient GEMM: out [M][N] fp32 = a^T b, a [rows][lda] and b [rows][ldb] bf16 in the activations' own
+ * (feature-contiguous) layout (either may be a column block of a wider matrix); M, N multiples of 8, rows of 64.
+ * slices == 0: tile form (128x128 / 256x256 / 256x192 / 192x256, LDS-DMA staged) and K slices chosen by shape (wgrad_plan);
+ * slices >= 1: the 128x128 form with that many K slices.  Partial buffers are summed inside. */
 int dfot_op_wgrad_nt(const void* a, int lda, const void* b, int ldb, float* out, int m, int n, int64_t rows, int slices, void* stream);
 /* op-level entry points a training driver composes (all on device pointers, bf16 activations unless noted):
  * out = a w^T (+ bias) in bf16 / fp32 (+ resid); transposes; column sums; the training-form forwards of the UViT TransformerBlock pieces
@@ -317,7 +319,9 @@ int dfot_op_attention_fwd_lse(const void* q, const void* k, const void* v, void*
                               void* stream);
 int dfot_op_attention_bwd_lse(const void* q, const void* k, const void* v, const void* o, const void* d_o, int ldo, const float* lse, float* delta,
                               void* dq, void* dk, void* dv, int batch, int heads, int n, int d, void* stream);
-/* ResBlock / resampler / embedding pieces of the UViT training driver (channels-last fp32 streams, bf16 GEMM operands) */
+/* ResBlock / resampler / embedding pieces of the UViT training driver (channels-last fp32 streams, bf16 GEMM operands).
+ * Shape contract of the vectorised kernels: GroupNorm entries take 128, 256, 512 or 1024 channels; pool2_bwd / upsample_bwd channels
+ * % 4 == 0; emb_combine embedding width % 8 == 0; masked_cast total and per_video % 8 == 0 (anything else returns DFOT_ERR_SHAPE). */
 int dfot_op_gn_silu_fwd(const float* x, const float* gamma, const float* beta, const void* film, float eps, void* out, float* stats, int bt,
                         int pixels, int channels, void* stream);
 int dfot_op_gn_silu_bwd2(const float* x, const float* dy, const float* stats, const float* gamma, const float* beta, const void* film, float* dx,
