@@ -33,12 +33,13 @@ int launch_film_vec(const FilmChunk* table, int chunks, const float* nemb, float
 int launch_gn_film_silu(const bf16* h, const float* stats, const float* gamma, const float* beta, const bf16* fcache,
                         const float* sv, const uint8_t* cond_mask, bf16* out, int bt, int pixels, int c, int tokens,
                         hipStream_t s);
-// a residual stream whose last out-projection is still two K-slice partials: x += bias[c] + s0 + s1 (run_tr_block, uvit.hip)
+// a residual stream whose last out-projection is still two or three K-slice partials: x += bias[c] + s0 + s1 (+ s2) (run_tr_block, uvit.hip)
 struct RmsPending {
   float* x;
   const float* bias;
   const float* s0;
   const float* s1;
+  const float* s2;  // optional third slice
 };
 int launch_rms_film(const float* x, const float* w, const bf16* fcache, const float* sv, const uint8_t* cond_mask, bf16* out,
                     long m, int c, int rows_per_bt, int tokens, float eps, hipStream_t s, const RmsPending* pend = nullptr);

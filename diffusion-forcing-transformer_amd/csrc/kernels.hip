@@ -660,7 +660,7 @@ __global__ __launch_bounds__(256) void rms_film_kernel(const float* x, const flo
                                                        const uint8_t* __restrict__ cond_mask, bf16* __restrict__ out,
                                                        long m, int c, int rows_per_bt, int tokens, float eps, float* xw,
                                                        const float* __restrict__ pbias, const float* __restrict__ p0,
-                                                       const float* __restrict__ p1) {
+                                                       const float* __restrict__ p1, const float* __restrict__ p2) {
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= m) return;
   const int lane = threadIdx.x & 63;
@@ -681,8 +681,9 @@ __global__ __launch_bounds__(256) void rms_film_kernel(const float* x, const flo
         float4v lo = a, hi = b;
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
-          const float4v add = *reinterpret_cast<const float4v*>(pbias + ch * 8 + 4 * hf) + *reinterpret_cast<const float4v*>(p0 + o + 4 * hf) +
-                              *reinterpret_cast<const float4v*>(p1 + o + 4 * hf);
+          float4v add = *reinterpret_cast<const float4v*>(pbias + ch * 8 + 4 * hf) + *reinterpret_cast<const float4v*>(p0 + o + 4 * hf) +
+                        *reinterpret_cast<const float4v*>(p1 + o + 4 * hf);
+          if (p2) add += *reinterpret_cast<const float4v*>(p2 + o + 4 * hf);
           if (hf == 0) lo += add; else hi += add;
         }
         *reinterpret_cast<float4v*>(xw + o) = lo;
@@ -732,7 +733,7 @@ int launch_rms_film(const float* x, const float* w, const bf16* fcache, const fl
   DFOT_REQUIRE(c % 8 == 0 && c <= 8 * 64 * 3, DFOT_ERR_SHAPE, "rms_film: channels %d unsupported", c);
 #define RMS_CALL(MC, P)                                                                                                             \
   hipLaunchKernelGGL((rms_film_kernel<MC, P>), dim3(cdiv(m, 4)), dim3(256), 0, s, x, w, fcache, sv, cond_mask, out, m, c, rows_per_bt, \
-                     tokens, eps, P ? pend->x : nullptr, P ? pend->bias : nullptr, P ? pend->s0 : nullptr, P ? pend->s1 : nullptr)
+                     tokens, eps, P ? pend->x : nullptr, P ? pend->bias : nullptr, P ? pend->s0 : nullptr, P ? pend->s1 : nullptr, P ? pend->s2 : nullptr)
   if (pend) {
     DFOT_REQUIRE(pend->x == x && pend->bias && pend->s0 && pend->s1, DFOT_ERR_ARG, "rms_film: pending sum must target the normalised stream");
     if (c <= 8 * 64 * 2) RMS_CALL(2, true); else RMS_CALL(3, true);

@@ -114,7 +114,7 @@ struct dfot_uvit_s {
   // the slices of the last out-projection not yet added to X[pend_lvl] (pend_bias != nullptr): the next block's norm kernel adds
   // them while it reads the stream anyway; flush_pending() does it for every other reader
   const float* pend_bias = nullptr;
-  int pend_lvl = 0, pend_c = 0;
+  int pend_lvl = 0, pend_c = 0, pend_slices = 2;
   long pend_m = 0;
   int last_batch = 0;
   int gemm_variant = GEMM_AUTO;
@@ -398,19 +398,21 @@ static int run_res_block(dfot_uvit_s* h, const ResW& w, int lvl, int bt, hipStre
 
 // x += bias + slice0 + slice1 (fp32, 4 elements per thread): the reduce pass of the two-slice out-projection
 __global__ void out_reduce_kernel(float* __restrict__ x, const float* __restrict__ bias, const float* __restrict__ s0,
-                                  const float* __restrict__ s1, long total4, int cq) {
+                                  const float* __restrict__ s1, const float* __restrict__ s2, long total4, int cq) {
   typedef __attribute__((ext_vector_type(4))) float f4;
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total4) return;
-  const f4 b = reinterpret_cast<const f4*>(bias)[i % cq];
-  reinterpret_cast<f4*>(x)[i] += b + reinterpret_cast<const f4*>(s0)[i] + reinterpret_cast<const f4*>(s1)[i];
+  f4 b = reinterpret_cast<const f4*>(bias)[i % cq] + reinterpret_cast<const f4*>(s0)[i] + reinterpret_cast<const f4*>(s1)[i];
+  if (s2) b += reinterpret_cast<const f4*>(s2)[i];
+  reinterpret_cast<f4*>(x)[i] += b;
 }
 
 static int flush_pending(dfot_uvit_s* h, hipStream_t s) {
   if (!h->pend_bias) return DFOT_OK;
   const long total4 = h->pend_m * h->pend_c / 4;
   hipLaunchKernelGGL(out_reduce_kernel, dim3(cdiv(total4, 256)), dim3(256), 0, s, h->X[h->pend_lvl], h->pend_bias, h->out_part,
-                     h->out_part + h->pend_m * h->pend_c, total4, h->pend_c / 4);
+                     h->out_part + h->pend_m * h->pend_c, h->pend_slices == 3 ? h->out_part + 2 * h->pend_m * h->pend_c : nullptr, total4,
+                     h->pend_c / 4);
   h->pend_bias = nullptr;
   DFOT_CHECK_HIP(hipGetLastError());
   return DFOT_OK;
@@ -422,7 +424,7 @@ static int run_tr_block(dfot_uvit_s* h, const TrW& w, int lvl, int batch, hipStr
   float* x = h->X[lvl];
   int rc = 0;
   if (h->pend_bias && (h->pend_lvl != lvl || h->pend_m != m || h->pend_c != c) && (rc = flush_pending(h, s))) return rc;
-  RmsPending pend{x, h->pend_bias, h->out_part, h->out_part + (long)m * c};
+  RmsPending pend{x, h->pend_bias, h->out_part, h->out_part + (long)m * c, h->pend_slices == 3 ? h->out_part + 2L * m * c : nullptr};
   if ((rc = launch_rms_film(x, w.nw, w.fcache, h->sv + w.sv_off, h->have_mask ? h->cond_mask : nullptr, h->s1, m, c,
                             rr * rr, h->T, h->cfg.eps, s, h->pend_bias ? &pend : nullptr)))
     return rc;
@@ -449,15 +451,26 @@ static int run_tr_block(dfot_uvit_s* h, const TrW& w, int lvl, int batch, hipStr
   if (l3_split > 1 && (long)(m / 256) * ((c + 191) / 192) < 200) o.ksplit = l3_split;
   // level 3 at small model batch: 256x144 tiles give M/256 x N/144 = 128 workgroups for 256 CUs; two K slices into partial
   // buffers make it 256, and one pass adds slices + bias into the fp32 residual stream (out_reduce_kernel)
-  static const int split144 = tuning_flag("UVIT_OUT_SPLIT144", 1);
+  static const int split144 = tuning_flag("UVIT_OUT_SPLIT144", 2);  // 0: one GEMM with the residual epilogue; 1: 256x144 x 2 slices; 2: 256x256 x 3 slices
+  static const int defer = tuning_flag("UVIT_OUT_DEFER", 1);  // A/B: 0 = reduce pass right away
+  // default (2): 256x256 tiles (the best main loop: half the L2 -> LDS operand bytes per FLOP of 256x144; N padded to the tile: 5 column
+  // tiles for 1152) x three K slices = 240 workgroups for 256 CUs; +1.0 / +1.6 % frames/s over mode 1 in two same-box A/B pairs
+  if (split144 == 2 && h->gemm_variant == GEMM_AUTO && h->out_part && (size_t)3 * m * c <= h->out_part_elems && m % 256 == 0 &&
+      (long)(m / 256) * ((c + 255) / 256) * 3 <= 256 && (5 * c / 64) % 3 == 0 && (5 * c / 64) >= 12) {
+    GemmArgs p3 = o;
+    p3.bias = nullptr; p3.resid = nullptr; p3.out_f32 = h->out_part; p3.ksplit = 3; p3.slice_stride = (long)m * c;
+    if ((rc = launch_gemm(A_DENSE, E_F32, GEMM_DMA_256x256, p3, s))) return rc;
+    h->pend_bias = w.b_out;
+    h->pend_lvl = lvl; h->pend_m = m; h->pend_c = c; h->pend_slices = 3;
+    return defer ? DFOT_OK : flush_pending(h, s);
+  }
   if (split144 && h->gemm_variant == GEMM_AUTO && h->out_part && (size_t)2 * m * c <= h->out_part_elems && m % 256 == 0 && c % 144 == 0 &&
       (long)(m / 256) * (c / 144) * 2 <= 256 && (5 * c / 64) >= 8) {
     GemmArgs p2 = o;
     p2.bias = nullptr; p2.resid = nullptr; p2.out_f32 = h->out_part; p2.ksplit = 2; p2.slice_stride = (long)m * c;
     if ((rc = launch_gemm(A_DENSE, E_F32, GEMM_DMA_256x144, p2, s))) return rc;
     h->pend_bias = w.b_out;
-    h->pend_lvl = lvl; h->pend_m = m; h->pend_c = c;
-    static const int defer = tuning_flag("UVIT_OUT_DEFER", 1);  // A/B: 0 = reduce pass right away
+    h->pend_lvl = lvl; h->pend_m = m; h->pend_c = c; h->pend_slices = 2;
     return defer ? DFOT_OK : flush_pending(h, s);
   }
   return launch_gemm(A_DENSE, E_F32, h->gemm_variant, o, s);
@@ -669,7 +682,7 @@ int dfot_uvit_reserve(dfot_uvit_t h, int max_batch) {
   if ((rc = dev_alloc(h, &h->v, mc, true))) return rc;
   {  // both transformer levels may take the two-slice out-projection at small sizes: room for the larger of their outputs, twice
     const size_t e2 = bt * pix[2] * h->ch[2], e3 = bt * pix[3] * h->ch[3];
-    h->out_part_elems = 2 * (e2 > e3 ? e2 : e3);
+    h->out_part_elems = 3 * (e2 > e3 ? e2 : e3);
     if ((rc = dev_alloc(h, &h->out_part, h->out_part_elems, true))) return rc;
   }
   // key-split partial buffers of the level-2 attention's balanced tail, for every batch this workspace can serve (so that
