@@ -112,6 +112,14 @@ def test_host_inputs_are_refused_without_launching(w64):
     host = dfot_amd.UViT3DPose(model.cfg, x_shape=(3, 64, 64), max_tokens=8)
     with pytest.raises(RuntimeError, match="no CPU path"):
         host._forward_impl(x.cpu(), k.cpu(), c.cpu(), None)
+    # pointers of strided views: only row-strided matrices (column blocks) pass, through the entry points that take a row stride
+    from dfot_amd import capi
+    wide = torch.zeros(8, 16, device="cuda")
+    assert capi.ptr_rows(wide[:, 4:12]).value == wide.data_ptr() + 16
+    with pytest.raises(ValueError, match="not contiguous"):
+        capi.ptr(wide[:, 4:12])
+    with pytest.raises(ValueError, match="row-strided"):
+        capi.ptr_rows(wide.t())
 
 
 def test_mask_none_equals_all_false(w64):

@@ -338,6 +338,10 @@ def test_host_tensors_are_refused_before_any_launch():
         torch.ops.dfot.hg_prepare(x, None, torch.zeros(4, 8), torch.zeros(4, 8), 2)
     with pytest.raises(ValueError):   # wrong table shape is caught before the device check
         torch.ops.dfot.hg_prepare(x, None, torch.zeros(2, 8), torch.zeros(4, 8), 2)
+    # row-strided matrices (column blocks of wider ones) go through ptr_rows, which refuses host memory and anything else strided
+    with pytest.raises(ValueError, match="GPU memory only"):
+        capi.ptr_rows(torch.zeros(4, 8)[:, 2:6], name="dfilm")
+    assert capi.ptr_rows(None).value in (None, 0)
 
 
 @pytest.mark.parametrize("tag", ["eta", "ddpm"])
