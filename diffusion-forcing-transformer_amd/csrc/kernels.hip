@@ -141,32 +141,41 @@ int launch_embed_input(const float* x, const float* w, const float* b, float* ou
 // one workgroup = one patch row py and a chunk of CC channels; transposed through LDS
 // --------------------------------------------------------------------------------------------
 constexpr int RP_CC = 20;
+// workgroup = (20-channel chunk, patch row, frame): 16-byte loads along x (two patches' worth of one channel row), the patch rows
+// assembled in LDS (row pitch 84 elements: 8-byte aligned), 8-byte stores of the 80 contiguous K entries of every patch
+// (the scalar form of this kernel moved 0.43 TB/s: 1.8 ms per window at 16 frames)
 __global__ __launch_bounds__(256) void cond_repack_kernel(const float* __restrict__ cond, bf16* __restrict__ a, int res,
                                                           int cdim, int kpad) {
-  extern __shared__ bf16 tile[];  // [r0][RP_CC*4 + 2]
+  extern __shared__ __attribute__((aligned(16))) bf16 tile[];  // [r0][RP_CC*4 + 4]
   const int r0 = res / 2;
-  const int ld = RP_CC * 4 + 2;
+  constexpr int ld = RP_CC * 4 + 4;
   const int chunk = blockIdx.x, py = blockIdx.y, bt = blockIdx.z;
   const int c0 = chunk * RP_CC;
-  for (int e = threadIdx.x; e < RP_CC * 2 * res; e += blockDim.x) {
-    const int xx = e % res;
-    const int dy = (e / res) & 1;
-    const int cc = e / (2 * res);
-    const float v = cond[(((long)bt * cdim + c0 + cc) * res + 2 * py + dy) * res + xx];
-    tile[(xx >> 1) * ld + cc * 4 + dy * 2 + (xx & 1)] = f2bf(v);
+  const int xq = res / 4;  // float4 groups per image row
+  for (int e = threadIdx.x; e < RP_CC * 2 * xq; e += blockDim.x) {
+    const int x4 = e % xq;
+    const int dy = (e / xq) & 1;
+    const int cc = e / (2 * xq);
+    const float4v v = *reinterpret_cast<const float4v*>(cond + (((long)bt * cdim + c0 + cc) * res + 2 * py + dy) * res + x4 * 4);
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+    bf16x2 lo, hi;
+    lo[0] = f2bf(v[0]); lo[1] = f2bf(v[1]); hi[0] = f2bf(v[2]); hi[1] = f2bf(v[3]);
+    *reinterpret_cast<bf16x2*>(tile + (2 * x4) * ld + cc * 4 + dy * 2) = lo;
+    *reinterpret_cast<bf16x2*>(tile + (2 * x4 + 1) * ld + cc * 4 + dy * 2) = hi;
   }
   __syncthreads();
-  const int kk = RP_CC * 4;
-  for (int e = threadIdx.x; e < r0 * kk; e += blockDim.x) {
-    const int px = e / kk, k = e % kk;
-    a[((long)(bt * r0 + py) * r0 + px) * kpad + c0 * 4 + k] = tile[px * ld + k];
+  constexpr int kq = RP_CC;  // bf16x4 groups per patch
+  for (int e = threadIdx.x; e < r0 * kq; e += blockDim.x) {
+    const int px = e / kq, k4 = e % kq;
+    *reinterpret_cast<bf16x4*>(a + ((long)(bt * r0 + py) * r0 + px) * kpad + c0 * 4 + k4 * 4) = *reinterpret_cast<const bf16x4*>(tile + px * ld + k4 * 4);
   }
 }
 
 int launch_cond_repack(const float* cond, bf16* a, int bt, int res, int cdim, int kpad, hipStream_t s) {
-  DFOT_REQUIRE(cdim % RP_CC == 0, DFOT_ERR_SHAPE, "cond_repack: cond dim %d must be a multiple of %d", cdim, RP_CC);
+  DFOT_REQUIRE(cdim % RP_CC == 0 && res % 4 == 0 && kpad % 4 == 0, DFOT_ERR_SHAPE, "cond_repack: cond dim %d must be a multiple of %d (resolution %d, K %d of 4)",
+               cdim, RP_CC, res, kpad);
   const int r0 = res / 2;
-  const size_t lds = (size_t)r0 * (RP_CC * 4 + 2) * sizeof(bf16);
+  const size_t lds = (size_t)r0 * (RP_CC * 4 + 4) * sizeof(bf16);
   hipLaunchKernelGGL(cond_repack_kernel, dim3(cdim / RP_CC, r0, bt), dim3(256), lds, s, cond, a, res, cdim, kpad);
   DFOT_CHECK_HIP(hipGetLastError());
   return DFOT_OK;
