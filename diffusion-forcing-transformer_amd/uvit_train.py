@@ -538,8 +538,10 @@ class UViT3DPoseTrainer:
             reducer.finish()
             self._grads_reduced = True
         else:
-            for n, (o, shp) in self.layout.items():
-                self.flat_grads[o: o + grads[n].numel()].copy_(grads[n].reshape(-1))
+            # one multi-tensor copy instead of ~430 separate ones (18 us each: 4 ms of launch tails per step)
+            dst = [self.flat_grads[o: o + grads[n].numel()] for n, (o, shp) in self.layout.items()]
+            src = [grads[n].reshape(-1) for n in self.layout]
+            torch._foreach_copy_(dst, src)
             self._grads_reduced = False
         return (per_token * mk.cuda()).mean()
 
