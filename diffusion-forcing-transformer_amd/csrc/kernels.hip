@@ -826,13 +826,17 @@ int launch_upsample_add(const float* t, const float* skip, float* out, int bt, i
 // camera-ray encoding (geometry_utils.py:49-81,102-133,244-295): raw [B][T][16] -> [B][T][180][res][res]
 // thread = one output element; the per-frame 3x3 algebra is recomputed per thread (27 FMAs)
 // --------------------------------------------------------------------------------------------
-__global__ void ray_encode_kernel(const float* __restrict__ poses, float* __restrict__ out, long total, int t, int res,
+// thread = four consecutive x of one (frame, channel) row: one 16-byte store; the origin channels (the first 90) do not depend on
+// the pixel, so their sine is evaluated once per thread instead of once per element (accurate sinf with its range reduction is the
+// cost of this kernel: 5 ms for the 64 frames of a training batch in the one-element-per-thread form)
+__global__ void ray_encode_kernel(const float* __restrict__ poses, float* __restrict__ out, long total4, int t, int res,
                                   int normalized) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= total) return;
-  const int x = (int)(idx % res), y = (int)((idx / res) % res);
-  const int ch = (int)((idx / ((long)res * res)) % 180);
-  const long bt = idx / ((long)res * res * 180);
+  if (idx >= total4) return;
+  const int xq = res / 4;
+  const int x0 = (int)(idx % xq) * 4, y = (int)((idx / xq) % res);
+  const int ch = (int)((idx / ((long)xq * res)) % 180);
+  const long bt = idx / ((long)xq * res * 180);
   const long b = bt / t;
   const float* p = poses + bt * 16;
   const float* p0 = poses + b * t * 16;
@@ -861,26 +865,34 @@ __global__ void ray_encode_kernel(const float* __restrict__ poses, float* __rest
   const int rr = ch % 90;
   const int phase = rr / 45;   // 0: sin(arg), 1: sin(arg + pi/2)
   const int comp = (rr % 45) / 15, f = rr % 15;
-  float val;
+  const float scale = 3.14159265358979323846f * (float)(1 << f);
+  auto enc = [&](float val) {
+    float arg = __fmul_rn(val, scale);
+    if (phase) arg = __fadd_rn(arg, 0.5f * 3.14159265358979323846f);
+    return sinf(arg);
+  };
+  float4v o;
   if (which == 0) {
     float acc = 0.f;
     for (int j = 0; j < 3; ++j) acc = fmaf(r[j][comp], tr[j], acc);  // (R'^T T')[comp]
-    val = -acc;
+    const float v = enc(-acc);
+    o = float4v{v, v, v, v};
   } else {
     const float fres = (float)res;
-    const float cx = __fdiv_rn(__fsub_rn((float)x + 0.5f, __fmul_rn(p[2], fres)), __fmul_rn(p[0], fres));
     const float cy = __fdiv_rn(__fsub_rn((float)y + 0.5f, __fmul_rn(p[3], fres)), __fmul_rn(p[1], fres));
-    val = fmaf(r[2][comp], 1.f, fmaf(r[1][comp], cy, __fmul_rn(r[0][comp], cx)));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float cx = __fdiv_rn(__fsub_rn((float)(x0 + j) + 0.5f, __fmul_rn(p[2], fres)), __fmul_rn(p[0], fres));
+      o[j] = enc(fmaf(r[2][comp], 1.f, fmaf(r[1][comp], cy, __fmul_rn(r[0][comp], cx))));
+    }
   }
-  const float scale = 3.14159265358979323846f * (float)(1 << f);
-  float arg = __fmul_rn(val, scale);
-  if (phase) arg = __fadd_rn(arg, 0.5f * 3.14159265358979323846f);
-  out[idx] = sinf(arg);
+  *reinterpret_cast<float4v*>(out + idx * 4) = o;
 }
 
 int launch_ray_encode(const float* poses, float* out, int b, int t, int res, int normalized, hipStream_t s) {
-  const long total = (long)b * t * 180 * res * res;
-  hipLaunchKernelGGL(ray_encode_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, poses, out, total, t, res, normalized);
+  DFOT_REQUIRE(res % 4 == 0, DFOT_ERR_SHAPE, "ray_encode: resolution %d must be a multiple of 4", res);
+  const long total4 = (long)b * t * 180 * res * (res / 4);
+  hipLaunchKernelGGL(ray_encode_kernel, dim3(cdiv(total4, 256)), dim3(256), 0, s, poses, out, total4, t, res, normalized);
   DFOT_CHECK_HIP(hipGetLastError());
   return DFOT_OK;
 }
