@@ -107,7 +107,7 @@ SIGNATURES = {
     "dfot_op_conv3x3_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "dfot_op_gn_silu_bwd": (_I, [_P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _I, _I, _I, _P]),
     "dfot_op_rms_film_bwd": (_I, [_P, _P, _P, _P, _F, _P, _P, _P, _L, _I, _I, _P]),
-    "dfot_op_rms_film_bwd_res": (_I, [_P, _P, _P, _P, _F, _P, _P, _P, _P, _L, _I, _P]),
+    "dfot_op_rms_film_bwd_res": (_I, [_P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _L, _I, _P]),
     "dfot_op_qknorm_rope_bwd": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _F, _P, _I, _P, _P, _L, _I, _I, _I, _P]),
     "dfot_op_wgrad_nt": (_I, [_P, _I, _P, _I, _P, _I, _I, _L, _I, _P]),
     "dfot_op_gemm_bf16": (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _P]),

@@ -358,7 +358,8 @@ namespace {
 template <int VEC, int CNT>
 __global__ __launch_bounds__(256) void rms_film_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dxn, const float* __restrict__ w,
                                                            const bf16* __restrict__ film, float* dx, bf16* __restrict__ dfilm,
-                                                           float* __restrict__ dw, long rows, float eps, int accumulate, const float* dres) {
+                                                           float* __restrict__ dw, long rows, float eps, int accumulate, const float* dres,
+                                                           bf16* __restrict__ dx_bf) {
   typedef typename VecT<VEC>::type V;
   constexpr int C = 64 * VEC * CNT;
   const int lane = threadIdx.x & 63;
@@ -409,6 +410,14 @@ __global__ __launch_bounds__(256) void rms_film_bwd_kernel(const float* __restri
       V o = (gv[i] - xv[i] * m) * r;
       if (accumulate) o += *reinterpret_cast<const V*>(rrow + c0);
       *reinterpret_cast<V*>(orow + c0) = o;
+      if (dx_bf) {  // the next block's GEMM / weight-gradient operand, saving it a cast pass over dx
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+          float oj;
+          if constexpr (VEC == 1) oj = o; else oj = o[j];
+          dx_bf[row * C + c0 + j] = f2bf(oj);
+        }
+      }
     }
   }
   __shared__ float red[4][C];
@@ -422,10 +431,10 @@ __global__ __launch_bounds__(256) void rms_film_bwd_kernel(const float* __restri
 
 // dw must be zeroed by the caller
 int rms_film_backward(const float* x, const float* dxn, const float* w, const bf16* film, float* dx, bf16* dfilm, float* dw, long rows, int hidden,
-                      float eps, bool accumulate, hipStream_t s, const float* dres = nullptr) {
+                      float eps, bool accumulate, hipStream_t s, const float* dres = nullptr, bf16* dx_bf = nullptr) {
   const int grid = (int)(rows / 4 < 512 ? (rows + 3) / 4 : 512);
 #define CALL(V, C) \
-  hipLaunchKernelGGL((rms_film_bwd_kernel<V, C>), dim3(grid), dim3(256), 0, s, x, dxn, w, film, dx, dfilm, dw, rows, eps, accumulate ? 1 : 0, dres)
+  hipLaunchKernelGGL((rms_film_bwd_kernel<V, C>), dim3(grid), dim3(256), 0, s, x, dxn, w, film, dx, dfilm, dw, rows, eps, accumulate ? 1 : 0, dres, dx_bf)
   DIT_LN_DISPATCH(CALL)
 #undef CALL
   DFOT_CHECK_HIP(hipGetLastError());
@@ -545,11 +554,11 @@ int dfot_op_rms_film_bwd(const float* x, const float* dxn, const float* w, const
   return rms_film_backward(x, dxn, w, (const bf16*)film, dx, (bf16*)dfilm, dw, (long)rows, channels, eps, accumulate_dx != 0, (hipStream_t)stream);
 }
 // the same with the residual-path gradient read from `dres` (not modified): dx = dres + the norm's input gradient, out of place
-int dfot_op_rms_film_bwd_res(const float* x, const float* dxn, const float* w, const void* film, float eps, const float* dres, float* dx, void* dfilm,
-                             float* dw, int64_t rows, int channels, void* stream) {
+int dfot_op_rms_film_bwd_res(const float* x, const float* dxn, const float* w, const void* film, float eps, const float* dres, float* dx, void* dx_bf,
+                             void* dfilm, float* dw, int64_t rows, int channels, void* stream) {
   DFOT_REQUIRE(x && dxn && w && film && dres && dx && dfilm && dw && dres != dx, DFOT_ERR_ARG, "op_rms_film_bwd_res: null or aliased argument");
   DFOT_CHECK_HIP(hipMemsetAsync(dw, 0, (size_t)channels * sizeof(float), (hipStream_t)stream));
-  return rms_film_backward(x, dxn, w, (const bf16*)film, dx, (bf16*)dfilm, dw, (long)rows, channels, eps, true, (hipStream_t)stream, dres);
+  return rms_film_backward(x, dxn, w, (const bf16*)film, dx, (bf16*)dfilm, dw, (long)rows, channels, eps, true, (hipStream_t)stream, dres, (bf16*)dx_bf);
 }
 int dfot_op_qknorm_rope_bwd(const void* fused, int ld, const void* dq, const void* dk, const void* dv, const float* qw, const float* kw,
                             const float* rope_cs, float eps, void* dfused, int ldo, float* dqw, float* dkw, int64_t rows, int ntok, int heads, int d,

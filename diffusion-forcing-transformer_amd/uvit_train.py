@@ -132,13 +132,14 @@ class TransformerBlockTrain:
         self.saved = dict(x=x, emb=emb, film=film, xn=xn, fused=fused, q=q, k=k, v=v, cat=cat, lse=lse, batch=batch, mlp_mask=mlp_mask)
         return y
 
-    def backward(self, dy: torch.Tensor, demb_acc: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    def backward(self, dy: torch.Tensor, demb_acc: Optional[torch.Tensor] = None, dy_bf: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
         """dy fp32 [B*N][C] -> (dx fp32, demb fp32 [B*N][E]); parameter gradients in self.grads (reference names).
-        demb_acc: the level's embedding-gradient accumulator, added to in the GEMM epilogue (no separate pass)"""
+        demb_acc: the level's embedding-gradient accumulator, added to in the GEMM epilogue (no separate pass).
+        dy_bf: dy already in bf16 (the block above wrote it next to its dx: self.dx_bf), else it is cast here"""
         s, c, hds, d, p, lib = self.saved, self.c, self.heads, self.d, self.p, capi.lib
         rows, batch = dy.shape[0], s["batch"]
         ntok = rows // batch
-        dyb = _bf(dy)
+        dyb = dy_bf if dy_bf is not None else _bf(dy)
         dcat = gemm_bf16(dyb, self.w_outT)                                   # [rows][5C]
         dw_out = wgrad(dyb, s["cat"])                                        # [C][5C]
         db_out = colsum(dyb)
@@ -158,8 +159,9 @@ class TransformerBlockTrain:
         dx = torch.empty_like(dy)                                            # residual path + the norm's input gradient, one pass
         dfilm = torch.empty(rows, 2 * c, dtype=BF, device="cuda")
         dnw = torch.empty(c, device="cuda")
-        capi.check(lib.dfot_op_rms_film_bwd_res(_P(s["x"]), _P(dxn), _P(p["norm.norm.weight"]), _P(s["film"]), self.eps, _P(dy), _P(dx), _P(dfilm),
-                                                _P(dnw), rows, c, _S()))
+        self.dx_bf = torch.empty(rows, c, dtype=BF, device="cuda")
+        capi.check(lib.dfot_op_rms_film_bwd_res(_P(s["x"]), _P(dxn), _P(p["norm.norm.weight"]), _P(s["film"]), self.eps, _P(dy), _P(dx), _P(self.dx_bf),
+                                                _P(dfilm), _P(dnw), rows, c, _S()))
         demb = gemm_f32(dfilm, self.w_eT, resid=demb_acc, out=demb_acc)      # [rows][E]
         self.grads = {
             "norm.emb_layer.weight": wgrad(dfilm, s["emb"]), "norm.emb_layer.bias": colsum(dfilm), "norm.norm.weight": dnw,
@@ -442,12 +444,16 @@ class UViT3DPoseTrainer:
         dfilm_cat = {l: torch.empty(bt * r[l] * r[l], w.shape[1], dtype=BF, device="cuda") for l, w in self.res_wcat.items()}
 
         def run_back(blocks, prefix_fn, dh, lvl):
+            dh_bf = None
             for i in reversed(range(len(blocks))):
                 if lvl in dfilm_cat:
                     c0 = self.res_cols[id(blocks[i])]
                     dh, _ = blocks[i].backward(dh, None, dfilm_cat[lvl][:, c0: c0 + 2 * ch[lvl]])
                 else:
-                    dh, _ = blocks[i].backward(dh, demb[lvl])  # the block adds its embedding gradient into the level's accumulator
+                    # the block adds its embedding gradient into the level's accumulator; its input gradient also comes in bf16 for the block below
+                    dh, _ = blocks[i].backward(dh, demb[lvl], dh_bf)
+                    dh_bf = blocks[i].dx_bf
+                    blocks[i].dx_bf = None
                 for n, gv in blocks[i].grads.items():
                     G[f"{prefix_fn(i)}.{n}"] = gv
             return dh

@@ -289,9 +289,10 @@ int dfot_op_gn_silu_bwd(const float* x, const float* dy, const float* gamma, con
  * NormalizeWithCond: xn = RMSNorm(x; w) (1 + scale) + shift with film [rows][2C] bf16 = (scale | shift): dx fp32, dfilm bf16, dw fp32 [C] */
 int dfot_op_rms_film_bwd(const float* x, const float* dxn, const float* w, const void* film, float eps, float* dx, void* dfilm, float* dw,
                          int64_t rows, int channels, int accumulate_dx, void* stream);
-/* the same out of place: dx = dres + the norm's input gradient (dres is the gradient of the residual path, left untouched) */
-int dfot_op_rms_film_bwd_res(const float* x, const float* dxn, const float* w, const void* film, float eps, const float* dres, float* dx, void* dfilm,
-                             float* dw, int64_t rows, int channels, void* stream);
+/* the same out of place: dx = dres + the norm's input gradient (dres is the gradient of the residual path, left untouched);
+ * dx_bf (optional, bf16 [rows][channels]): a bf16 copy of dx, the GEMM operand of the block below */
+int dfot_op_rms_film_bwd_res(const float* x, const float* dxn, const float* w, const void* film, float eps, const float* dres, float* dx, void* dx_bf,
+                             void* dfilm, float* dw, int64_t rows, int channels, void* stream);
 /* per-head q / k RMSNorm + RoPE (rope_cs [ntok][d/2][2] = cos, sin): fused [rows][ld] bf16 holds (q | k | v) head-major in its first 3C
  * columns, dq / dk / dv [B][heads][ntok][d] bf16 are the attention backward's outputs; writes dfused [rows][ldo] columns [0, 3C), dqw / dkw [d] */
 int dfot_op_qknorm_rope_bwd(const void* fused, int ld, const void* dq, const void* dk, const void* dv, const float* qw, const float* kw,
