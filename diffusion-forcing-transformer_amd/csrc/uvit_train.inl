@@ -232,8 +232,8 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const float* __restr
 template <bool FILM>
 __global__ void gn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ stats,
                                     const float* __restrict__ gamma, const float* __restrict__ beta, const bf16* __restrict__ film,
-                                    const float* __restrict__ sums, float* __restrict__ dx, bf16* __restrict__ dfilm, long total4, int P, int C,
-                                    int accumulate, long ldf) {
+                                    const float* __restrict__ sums, float* dx, bf16* __restrict__ dfilm, long total4, int P, int C,
+                                    int accumulate, long ldf, const float* dres, bf16* __restrict__ dx_bf) {
   typedef __attribute__((ext_vector_type(4))) float f4;
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;  // 4 channels of one pixel (they share a group: C / 32 >= 4)
   if (i >= total4) return;
@@ -274,14 +274,24 @@ __global__ void gn_bwd_apply_kernel(const float* __restrict__ x, const float* __
     *reinterpret_cast<bf16x4*>(dfilm + row * ldf + c) = ds;  // ldf: dfilm may be a column block of a wider matrix
     *reinterpret_cast<bf16x4*>(dfilm + row * ldf + C + c) = dh;
   }
-  if (accumulate) v += *reinterpret_cast<const f4*>(dx + e);
-  *reinterpret_cast<f4*>(dx + e) = v;
+  // accumulate: dx = (dres, or the present dx) + v; dx / dx_bf: either output may be absent
+  if (accumulate) v += *reinterpret_cast<const f4*>((dres ? dres : dx) + e);
+  if (dx) *reinterpret_cast<f4*>(dx + e) = v;
+  if (dx_bf) {
+    bf16x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = f2bf(v[j]);
+    *reinterpret_cast<bf16x4*>(dx_bf + e) = o;
+  }
 }
 
 // sums [BT][32][2] scratch; dgamma / dbeta must be zeroed by the caller (they accumulate)
 int gn_silu_backward(const float* x, const float* dy, const float* stats, const float* gamma, const float* beta, const bf16* film, float* sums,
-                     float* dx, bf16* dfilm, float* dgamma, float* dbeta, int bt, int P, int C, bool accumulate, hipStream_t s, long ldf = 0) {
+                     float* dx, bf16* dfilm, float* dgamma, float* dbeta, int bt, int P, int C, bool accumulate, hipStream_t s, long ldf = 0,
+                     const float* dres = nullptr, bf16* dx_bf = nullptr) {
   if (ldf == 0) ldf = 2L * C;
+  DFOT_REQUIRE(dx || dx_bf, DFOT_ERR_ARG, "gn_silu_backward: no output");
+  DFOT_REQUIRE(!accumulate || dres || dx, DFOT_ERR_ARG, "gn_silu_backward: nothing to accumulate onto");
   DFOT_REQUIRE(C % 128 == 0 && C <= 1024 && 256 % (C / 4 < 256 ? C / 4 : 256) == 0 && (film == nullptr) == (dfilm == nullptr), DFOT_ERR_ARG,
                "gn_silu_backward: channels %d must be 128, 256, 512 or 1024", C);
   DFOT_CHECK_HIP(hipMemsetAsync(sums, 0, (size_t)bt * 64 * sizeof(float), s));
@@ -291,11 +301,11 @@ int gn_silu_backward(const float* x, const float* dy, const float* stats, const 
   if (film) {
     hipLaunchKernelGGL(gn_bwd_reduce_kernel<true>, grid, dim3(256), 0, s, x, dy, stats, gamma, beta, film, sums, dgamma, dbeta, P, C, chunk);
     hipLaunchKernelGGL(gn_bwd_apply_kernel<true>, dim3(cdiv(total, 256)), dim3(256), 0, s, x, dy, stats, gamma, beta, film, sums, dx, dfilm, total, P, C,
-                       accumulate ? 1 : 0, ldf);
+                       accumulate ? 1 : 0, ldf, dres, dx_bf);
   } else {
     hipLaunchKernelGGL(gn_bwd_reduce_kernel<false>, grid, dim3(256), 0, s, x, dy, stats, gamma, beta, film, sums, dgamma, dbeta, P, C, chunk);
     hipLaunchKernelGGL(gn_bwd_apply_kernel<false>, dim3(cdiv(total, 256)), dim3(256), 0, s, x, dy, stats, gamma, beta, film, sums, dx, dfilm, total, P, C,
-                       accumulate ? 1 : 0, ldf);
+                       accumulate ? 1 : 0, ldf, dres, dx_bf);
   }
   DFOT_CHECK_HIP(hipGetLastError());
   return DFOT_OK;
@@ -970,6 +980,23 @@ int dfot_op_gn_silu_bwd3(const float* x, const float* dy, const float* stats, co
   DFOT_CHECK_HIP(hipMemsetAsync(dbeta, 0, (size_t)channels * sizeof(float), s));
   return gn_silu_backward(x, dy, stats, gamma, beta, (const bf16*)film, (float*)sums, dx, (bf16*)dfilm, dgamma, dbeta, bt, pixels, channels,
                           accumulate_dx != 0, s, (long)dfilm_ld);
+}
+// the general form: dx = (dres ? dres : 0) + the norm's input gradient, written as fp32 (dx) and / or bf16 (dx_bf) -- the gradient that
+// only feeds a convolution's data / weight gradient is needed in bf16 alone, the one that continues down the residual stream in both
+int dfot_op_gn_silu_bwd4(const float* x, const float* dy, const float* stats, const float* gamma, const float* beta, const void* film, const float* dres,
+                         float* dx, void* dx_bf, void* dfilm, int64_t dfilm_ld, float* dgamma, float* dbeta, int bt, int pixels, int channels,
+                         void* stream) {
+  DFOT_REQUIRE(x && dy && stats && gamma && beta && (dx || dx_bf) && dgamma && dbeta && (!dres || dres != dx), DFOT_ERR_ARG,
+               "op_gn_silu_bwd4: null or aliased argument");
+  DFOT_REQUIRE(!dfilm || (dfilm_ld >= 2 * channels && dfilm_ld % 4 == 0), DFOT_ERR_ARG, "op_gn_silu_bwd4: bad dfilm row stride");
+  hipStream_t s = (hipStream_t)stream;
+  void* sums = nullptr;
+  int rc = op_scratch(4, (size_t)bt * 64 * sizeof(float), &sums);
+  if (rc) return rc;
+  DFOT_CHECK_HIP(hipMemsetAsync(dgamma, 0, (size_t)channels * sizeof(float), s));
+  DFOT_CHECK_HIP(hipMemsetAsync(dbeta, 0, (size_t)channels * sizeof(float), s));
+  return gn_silu_backward(x, dy, stats, gamma, beta, (const bf16*)film, (float*)sums, dx, (bf16*)dfilm, dgamma, dbeta, bt, pixels, channels,
+                          dres != nullptr, s, (long)dfilm_ld, dres, (bf16*)dx_bf);
 }
 // w fp32 [Co][Ci][3][3] -> the forward kernel's layout [Co][tap][Ci] bf16 (dgrad = 0) or the data-gradient weights [Ci][tap'][Co] (dgrad = 1)
 int dfot_op_pack_conv3(const float* w, void* out, int co, int ci, int dgrad, void* stream) {

@@ -228,23 +228,27 @@ class ResBlockTrain:
         return y
 
     def backward(self, dy: torch.Tensor, demb_acc: Optional[torch.Tensor] = None,
-                 dfilm_out: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+                 dfilm_out: Optional[torch.Tensor] = None, dy_bf: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
         """dfilm_out: a [rows][2C] bf16 column block of the level's FiLM-gradient matrix; the block then leaves the embedding gradient
-        (dfilm W_e over the level's concatenated K) to the caller instead of adding its own [rows][E] product to demb_acc"""
+        (dfilm W_e over the level's concatenated K) to the caller instead of adding its own [rows][E] product to demb_acc.
+        dy_bf: dy already in bf16 (the block above left it in self.dx_bf), else it is cast here"""
         s, c, p, lib = self.saved, self.c, self.p, capi.lib
         bt, h, w = s["geom"]
         P = h * w
-        dh2, dw2, db2 = conv3x3_backward(s["h2"], _bf(dy), p["out_rest.1.weight"], bt, h, w, c, c)
-        dc1 = torch.empty(bt * P, c, dtype=torch.float32, device="cuda")
+        dh2, dw2, db2 = conv3x3_backward(s["h2"], dy_bf if dy_bf is not None else _bf(dy), p["out_rest.1.weight"], bt, h, w, c, c)
         dfilm = dfilm_out if dfilm_out is not None else torch.empty(bt * P, 2 * c, dtype=BF, device="cuda")
         dg2, dbe2, dg1, dbe1 = (torch.empty(c, dtype=torch.float32, device="cuda") for _ in range(4))
-        capi.check(lib.dfot_op_gn_silu_bwd3(_P(s["c1"]), _P(dh2), _P(s["st2"]), _P(p["out_norm.weight"]), _P(p["out_norm.bias"]), _P(s["film"]), _P(dc1),
-                                            _PV(dfilm), _P(dg2), _P(dbe2), bt, P, c, 0, dfilm.stride(0), _S()))
+        # the gradient of the first convolution's output only feeds that convolution's data / weight gradients: bf16 alone
+        dc1 = torch.empty(bt * P, c, dtype=BF, device="cuda")
+        capi.check(lib.dfot_op_gn_silu_bwd4(_P(s["c1"]), _P(dh2), _P(s["st2"]), _P(p["out_norm.weight"]), _P(p["out_norm.bias"]), _P(s["film"]), None,
+                                            None, _P(dc1), _PV(dfilm), dfilm.stride(0), _P(dg2), _P(dbe2), bt, P, c, _S()))
         demb = None if dfilm_out is not None else gemm_f32(dfilm, self.w_eT, resid=demb_acc, out=demb_acc)
-        dh1, dw1, db1 = conv3x3_backward(s["h1"], _bf(dc1), p["in_layers.2.weight"], bt, h, w, c, c)
-        dx = dy.clone()
-        capi.check(lib.dfot_op_gn_silu_bwd2(_P(s["x"]), _P(dh1), _P(s["st1"]), _P(p["in_layers.0.weight"]), _P(p["in_layers.0.bias"]), None, _P(dx), None,
-                                            _P(dg1), _P(dbe1), bt, P, c, 1, _S()))
+        dh1, dw1, db1 = conv3x3_backward(s["h1"], dc1, p["in_layers.2.weight"], bt, h, w, c, c)
+        # dx = dy (residual path) + the first norm's input gradient, in fp32 for the stream and in bf16 for the block below
+        dx = torch.empty_like(dy)
+        self.dx_bf = torch.empty(bt * P, c, dtype=BF, device="cuda")
+        capi.check(lib.dfot_op_gn_silu_bwd4(_P(s["x"]), _P(dh1), _P(s["st1"]), _P(p["in_layers.0.weight"]), _P(p["in_layers.0.bias"]), None, _P(dy),
+                                            _P(dx), _P(self.dx_bf), None, 0, _P(dg1), _P(dbe1), bt, P, c, _S()))
         self.grads = {
             "emb_layer.weight": wgrad(dfilm, s["emb"]).view_as(p["emb_layer.weight"]), "emb_layer.bias": colsum(dfilm),
             "in_layers.0.weight": dg1, "in_layers.0.bias": dbe1, "in_layers.2.weight": dw1, "in_layers.2.bias": db1,
@@ -446,14 +450,16 @@ class UViT3DPoseTrainer:
         def run_back(blocks, prefix_fn, dh, lvl):
             dh_bf = None
             for i in reversed(range(len(blocks))):
+                # every block also leaves its input gradient in bf16 (dx_bf) for the block below
                 if lvl in dfilm_cat:
                     c0 = self.res_cols[id(blocks[i])]
-                    dh, _ = blocks[i].backward(dh, None, dfilm_cat[lvl][:, c0: c0 + 2 * ch[lvl]])
+                    dh, _ = blocks[i].backward(dh, None, dfilm_cat[lvl][:, c0: c0 + 2 * ch[lvl]], dh_bf)
+                elif isinstance(blocks[i], ResBlockTrain):
+                    dh, _ = blocks[i].backward(dh, demb[lvl], None, dh_bf)
                 else:
-                    # the block adds its embedding gradient into the level's accumulator; its input gradient also comes in bf16 for the block below
-                    dh, _ = blocks[i].backward(dh, demb[lvl], dh_bf)
-                    dh_bf = blocks[i].dx_bf
-                    blocks[i].dx_bf = None
+                    dh, _ = blocks[i].backward(dh, demb[lvl], dh_bf)  # adds its embedding gradient into the level's accumulator
+                dh_bf = blocks[i].dx_bf
+                blocks[i].dx_bf = None
                 for n, gv in blocks[i].grads.items():
                     G[f"{prefix_fn(i)}.{n}"] = gv
             return dh

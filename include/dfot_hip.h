@@ -330,6 +330,10 @@ int dfot_op_gn_silu_bwd2(const float* x, const float* dy, const float* stats, co
 /* the same, dfilm written at row stride dfilm_ld (elements): a column block of a wider matrix */
 int dfot_op_gn_silu_bwd3(const float* x, const float* dy, const float* stats, const float* gamma, const float* beta, const void* film, float* dx,
                          void* dfilm, float* dgamma, float* dbeta, int bt, int pixels, int channels, int accumulate_dx, int64_t dfilm_ld, void* stream);
+/* general form: dx = (dres ? dres : 0) + input gradient, as fp32 (dx) and / or bf16 (dx_bf); dfilm optional with its row stride */
+int dfot_op_gn_silu_bwd4(const float* x, const float* dy, const float* stats, const float* gamma, const float* beta, const void* film, const float* dres,
+                         float* dx, void* dx_bf, void* dfilm, int64_t dfilm_ld, float* dgamma, float* dbeta, int bt, int pixels, int channels,
+                         void* stream);
 int dfot_op_pack_conv3(const float* w, void* out, int co, int ci, int dgrad, void* stream);
 int dfot_op_conv3x3_f32(const void* a, const void* w, const float* bias, const float* resid, float* y, int bt, int h, int w_, int cin, int cout,
                         void* stream);
