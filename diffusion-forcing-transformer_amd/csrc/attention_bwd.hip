@@ -303,6 +303,348 @@ __global__ __launch_bounds__(256, (DC <= 96 ? 2 : 1)) void attn_bwd_dkv_kernel(c
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// LDS-DMA forms of the two kernels (default for the 128-element-row instances; DFOT_ATTN_BWD_DMA=0 / 2: never / always).
+// The streamed tiles are fetched by global_load_lds straight into an UNPADDED LDS image, two stages, the next tile in flight
+// while the present one is multiplied: no staging registers (32 VGPRs: the d = 128 instances drop under 256 and run two waves
+// per SIMD -- register-staged they were 266 / 280 VGPRs, one wave per SIMD, and the dk/dv kernel fetched its next tile AFTER the
+// products with nothing to overlap the latency: MFMA utilisation 0.22-0.25 against 0.50 at d = 64).  One XOR swizzle of the
+// 16-byte chunks, applied on the source side, keeps BOTH access patterns of a tile conflict-free:
+//   row reads (ds_read_b128, 16 rows at one chunk position): the swizzle is a bijection of the row's low bits;
+//   transposed reads (ds_read_b64_tr_b16, 4 rows x 64 contiguous bytes per half-wave): rows r..r+3 land in different 64-byte groups.
+template <int D>
+struct DmaCfg {
+  static constexpr int TR = 64, ROWB = D * 2, TILE = TR * ROWB, CH = D / 8;
+  static constexpr int RPI = 1024 / ROWB;        // rows per 1-KiB DMA instruction (8 or 4)
+  static constexpr int IPW = (TILE / 1024) / 4;  // DMA instructions per wave and tile (2 or 4)
+  __device__ static int swz(int row, int c) {
+    return D == 64 ? (c ^ ((((row >> 1) & 1) << 2) | ((row >> 2) & 3))) : (c ^ (((row & 3) << 2) | ((row >> 2) & 3)));
+  }
+};
+
+typedef __attribute__((ext_vector_type(2))) unsigned bw_u32x2;
+template <int OFF>
+__device__ __forceinline__ bw_u32x2 bw_read_tr16(unsigned addr) {
+  bw_u32x2 r;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
+  return r;
+}
+__device__ __forceinline__ void bw_wait(bw_u32x2& a, bw_u32x2& b, bw_u32x2& c, bw_u32x2& d, bw_u32x2& e, bw_u32x2& f, bw_u32x2& g, bw_u32x2& h) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h));
+}
+__device__ __forceinline__ bf16x8 bw_bf16x8(bw_u32x2 lo, bw_u32x2 hi) {
+  typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+  const u32x4 v = {lo[0], lo[1], hi[0], hi[1]};
+  return __builtin_bit_cast(bf16x8, v);
+}
+// byte offset inside a tile of this lane's transposed read for the feature block dvt (32 features) and row half h (rows 8h..): rows
+// 4 lh + 8 h + q4 (+ 16 s + 32 kt2 as an immediate: multiples of 16 rows leave the swizzle unchanged)
+template <int D>
+__device__ __forceinline__ unsigned bw_tr_off(int dvt, int h, int lane) {
+  using C = DmaCfg<D>;
+  const int lh = lane >> 5, q4 = (lane & 15) >> 2, p4 = lane & 3, g = (lane >> 4) & 1;
+  const int row = 4 * lh + 8 * h + q4;
+  const int chunk = 4 * dvt + 2 * g + (p4 >> 1);
+  return (unsigned)(row * C::ROWB + C::swz(row, chunk) * 16 + (p4 & 1) * 8);
+}
+// the four X^T fragments (kt2, s) of feature block dvt of one tile
+template <int D>
+__device__ __forceinline__ void bw_tr_frags(unsigned tile_addr, int dvt, int lane, bf16x8 (&f)[2][2]) {
+  using C = DmaCfg<D>;
+  const unsigned a0 = tile_addr + bw_tr_off<D>(dvt, 0, lane), a1 = tile_addr + bw_tr_off<D>(dvt, 1, lane);
+  bw_u32x2 r000 = bw_read_tr16<0 * C::ROWB>(a0), r001 = bw_read_tr16<0 * C::ROWB>(a1);
+  bw_u32x2 r010 = bw_read_tr16<16 * C::ROWB>(a0), r011 = bw_read_tr16<16 * C::ROWB>(a1);
+  bw_u32x2 r100 = bw_read_tr16<32 * C::ROWB>(a0), r101 = bw_read_tr16<32 * C::ROWB>(a1);
+  bw_u32x2 r110 = bw_read_tr16<48 * C::ROWB>(a0), r111 = bw_read_tr16<48 * C::ROWB>(a1);
+  bw_wait(r000, r001, r010, r011, r100, r101, r110, r111);
+  f[0][0] = bw_bf16x8(r000, r001);
+  f[0][1] = bw_bf16x8(r010, r011);
+  f[1][0] = bw_bf16x8(r100, r101);
+  f[1][1] = bw_bf16x8(r110, r111);
+}
+
+template <int D, int DC = D, int DW = D>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_dma_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K,
+                                                                 const bf16* __restrict__ V, const bf16* __restrict__ dO, long ldo,
+                                                                 const float* __restrict__ L2, const float* __restrict__ delta,
+                                                                 bf16* __restrict__ dQ, int N, int heads, int d, float sq) {
+  using C = DmaCfg<D>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lq = lane & 31, lh = lane >> 5;
+  const int qtiles = N / 128;
+  const int lin = xcd_remap(blockIdx.x, gridDim.x);
+  const int bh = lin / qtiles;
+  const long base = (long)bh * N * D;
+  const int q0 = (lin % qtiles) * 128 + wave * 32;
+  const bf16* Kb = K + base;
+  const bf16* Vb = V + base;
+
+  // per-lane DMA source offsets (elements) within a tile: LDS position (row, pos) receives source chunk swz(row, pos)
+  int toff[C::IPW];
+#pragma unroll
+  for (int i = 0; i < C::IPW; ++i) {
+    const int inst = wave * C::IPW + i;
+    const int row = inst * C::RPI + lane / C::CH, pos = lane % C::CH;
+    toff[i] = row * D + C::swz(row, pos) * 8;
+  }
+  auto issue = [&](int t, int stage) {
+    char* sk = smem + stage * 2 * C::TILE;
+    char* sv = sk + C::TILE;
+    const bf16* kt = Kb + (long)t * C::TR * D;
+    const bf16* vt = Vb + (long)t * C::TR * D;
+#pragma unroll
+    for (int i = 0; i < C::IPW; ++i) {
+      const int inst = wave * C::IPW + i;
+      __builtin_amdgcn_global_load_lds(DFOT_GLOBAL_PTR(kt + toff[i]), DFOT_LDS_PTR(sk + inst * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(DFOT_GLOBAL_PTR(vt + toff[i]), DFOT_LDS_PTR(sv + inst * 1024), 16, 0, 0);
+    }
+  };
+  issue(0, 0);
+
+  bf16x8 qf[DC / 16], dof[DC / 16];
+  // dO is read from the compact activation layout [B*N][ldo] (head hd at column hd*d); columns >= d belong to the next head: zero
+  const bf16* dorow = dO + ((long)(bh / heads) * N + q0 + lq) * ldo + (long)(bh % heads) * d;
+#pragma unroll
+  for (int ks = 0; ks < DC / 16; ++ks) {
+    qf[ks] = *reinterpret_cast<const bf16x8*>(Q + base + (long)(q0 + lq) * D + ks * 16 + lh * 8);
+    const int col = ks * 16 + lh * 8;
+    const bf16 z = f2bf(0.f);
+    dof[ks] = col < d ? *reinterpret_cast<const bf16x8*>(dorow + col) : bf16x8{z, z, z, z, z, z, z, z};
+  }
+  const float l2 = L2[(long)bh * N + q0 + lq], dl = delta[(long)bh * N + q0 + lq];
+
+  f32x16 acc[DW / 32];
+#pragma unroll
+  for (int i = 0; i < DW / 32; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+#pragma unroll
+  for (int ks = 0; ks < DC / 16; ++ks) asm volatile("" : "+v"(qf[ks]), "+v"(dof[ks]));  // see attn_bwd_dkv_dma_kernel
+  float l2v = l2, dlv = dl;
+  asm volatile("" : "+v"(l2v), "+v"(dlv));
+  const int nt = N / C::TR;
+  const unsigned lds0 = (unsigned)(size_t)DFOT_LDS_PTR(smem);
+  int cur = 0;
+  for (int t = 0; t < nt; ++t) {
+    const char* sk = smem + cur * 2 * C::TILE;
+    const char* sv = sk + C::TILE;
+    if (t + 1 < nt) issue(t + 1, cur ^ 1);
+    // the lane id is made opaque once per tile: the swizzled LDS offsets below are a few VALU operations each, but loop-invariant,
+    // and hoisted out of the tile loop they cost ~30 VGPRs (the d = 128 instances must stay under 256)
+    int lv = lane;
+    asm volatile("" : "+v"(lv));
+    const int lqv = lv & 31, lhv = lv >> 5;
+    bf16x8 dsf[2][2];
+#pragma unroll
+    for (int kt2 = 0; kt2 < 2; ++kt2) {
+      f32x16 sacc, pacc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { sacc[r] = -l2v; pacc[r] = -dlv; }
+      const int row = kt2 * 32 + lqv;
+#pragma unroll
+      for (int ks = 0; ks < DC / 16; ++ks) {
+        const int off = row * C::ROWB + C::swz(row, ks * 2 + lhv) * 16;
+        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sk + off);
+        sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sacc, 0, 0, 0);
+        const bf16x8 vf = *reinterpret_cast<const bf16x8*>(sv + off);
+        pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[ks], pacc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dsf[kt2][s][j] = f2bf(__builtin_amdgcn_exp2f(sacc[8 * s + j]) * pacc[8 * s + j]);
+    }
+    // dQ^T[c][q] += K^T[c][key] dS^T[key][q]
+    const unsigned ka = lds0 + cur * 2 * C::TILE;
+#pragma unroll
+    for (int dvt = 0; dvt < DW / 32; ++dvt) {
+      bf16x8 kt[2][2];
+      bw_tr_frags<D>(ka, dvt, lv, kt);
+#pragma unroll
+      for (int kt2 = 0; kt2 < 2; ++kt2)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) acc[dvt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kt[kt2][s], dsf[kt2][s], acc[dvt], 0, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    cur ^= 1;
+  }
+  bf16* orow = dQ + base + (long)(q0 + lq) * D;
+  if constexpr (DW < D) {  // pad columns beyond DW: zero (the caller's buffers are re-used across blocks)
+#pragma unroll
+    for (int c = DW + 4 * lh; c < D; c += 8) *reinterpret_cast<bf16x4*>(orow + c) = bf16x4{f2bf(0.f), f2bf(0.f), f2bf(0.f), f2bf(0.f)};
+  }
+#pragma unroll
+  for (int dvt = 0; dvt < DW / 32; ++dvt)
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      bf16x4 o4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o4[j] = f2bf(acc[dvt][4 * g4 + j] * sq);
+      *reinterpret_cast<bf16x4*>(orow + dvt * 32 + 8 * g4 + 4 * lh) = o4;
+    }
+}
+
+// (the d = 128 instance holds k, v fragments (64 VGPRs) and the dK, dV accumulators (128): 256 cannot be met, it keeps one wave per
+// SIMD -- what it gains is the prefetch of the next tile behind the products)
+template <int D, int DC = D, int DW = D>
+__global__ __launch_bounds__(256, (DC <= 96 ? 2 : 1)) void attn_bwd_dkv_dma_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K,
+                                                                  const bf16* __restrict__ V, const bf16* __restrict__ dO, long ldo,
+                                                                  const float* __restrict__ L2, const float* __restrict__ delta,
+                                                                  bf16* __restrict__ dK, bf16* __restrict__ dV, int N, int heads, int d,
+                                                                  float sk_scale, const bf16* __restrict__ zeros) {
+  using C = DmaCfg<D>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lq = lane & 31, lh = lane >> 5;
+  const int ktiles = N / 128;
+  const int lin = xcd_remap(blockIdx.x, gridDim.x);
+  const int bh = lin / ktiles;
+  const long base = (long)bh * N * D;
+  const int k0 = (lin % ktiles) * 128 + wave * 32;
+  const bf16* Qb = Q + base;
+  const bf16* Ob = dO + (long)(bh / heads) * N * ldo + (long)(bh % heads) * d;  // compact [B*N][ldo], this head's columns
+  const float* Lb = L2 + (long)bh * N;
+  const float* Db = delta + (long)bh * N;
+
+  // LDS: [stage][Q tile | dO tile | L2[64] | delta[64]]
+  constexpr int STAGE = 2 * C::TILE + 2 * C::TR * 4;
+  // per-lane DMA sources: Q rows have pitch D; dO rows pitch ldo, chunks at or beyond d (next head / padding) come from the zero buffer
+  int qoff[C::IPW];
+  long ooff[C::IPW];
+  bool ook[C::IPW];
+#pragma unroll
+  for (int i = 0; i < C::IPW; ++i) {
+    const int inst = wave * C::IPW + i;
+    const int row = inst * C::RPI + lane / C::CH, ch = C::swz(row, lane % C::CH);
+    qoff[i] = row * D + ch * 8;
+    ooff[i] = (long)row * ldo + ch * 8;
+    ook[i] = ch * 8 < d;
+  }
+  float rs = 0.f;
+  auto issue = [&](int t, int stage) {
+    char* sq = smem + stage * STAGE;
+    char* so = sq + C::TILE;
+    if (tid < 2 * C::TR) rs = tid < C::TR ? Lb[t * C::TR + tid] : Db[t * C::TR + tid - C::TR];  // before the DMAs: its wait leaves them in flight
+    const bf16* qt = Qb + (long)t * C::TR * D;
+    const bf16* ot = Ob + (long)t * C::TR * ldo;
+#pragma unroll
+    for (int i = 0; i < C::IPW; ++i) {
+      const int inst = wave * C::IPW + i;
+      __builtin_amdgcn_global_load_lds(DFOT_GLOBAL_PTR(qt + qoff[i]), DFOT_LDS_PTR(sq + inst * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(DFOT_GLOBAL_PTR(ook[i] ? ot + ooff[i] : zeros), DFOT_LDS_PTR(so + inst * 1024), 16, 0, 0);
+    }
+  };
+  auto store_stats = [&](int stage) {
+    if (tid < 2 * C::TR) reinterpret_cast<float*>(smem + stage * STAGE + 2 * C::TILE)[tid] = rs;
+  };
+  issue(0, 0);
+
+  bf16x8 kf[DC / 16], vf[DC / 16];
+#pragma unroll
+  for (int ks = 0; ks < DC / 16; ++ks) {
+    kf[ks] = *reinterpret_cast<const bf16x8*>(K + base + (long)(k0 + lq) * D + ks * 16 + lh * 8);
+    vf[ks] = *reinterpret_cast<const bf16x8*>(V + base + (long)(k0 + lq) * D + ks * 16 + lh * 8);
+  }
+  f32x16 dka[DW / 32], dva[DW / 32];
+#pragma unroll
+  for (int i = 0; i < DW / 32; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dka[i][r] = 0.f; dva[i][r] = 0.f; }
+
+  store_stats(0);
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  // the compiler does not see the wait above: without a use of the fragments HERE it puts its own `s_waitcnt vmcnt(0)` in front of
+  // their first use inside the loop, every iteration, which drains the tile prefetch that was just issued
+#pragma unroll
+  for (int ks = 0; ks < DC / 16; ++ks) asm volatile("" : "+v"(kf[ks]), "+v"(vf[ks]));
+  const int nt = N / C::TR;
+  const unsigned lds0 = (unsigned)(size_t)DFOT_LDS_PTR(smem);
+  int cur = 0;
+  for (int t = 0; t < nt; ++t) {
+    const char* sq = smem + cur * STAGE;
+    const char* so = sq + C::TILE;
+    const float* sl = reinterpret_cast<const float*>(sq + 2 * C::TILE);
+    const float* sd = sl + C::TR;
+    if (t + 1 < nt) issue(t + 1, cur ^ 1);
+    int lv = lane;  // opaque per tile: see attn_bwd_dq_dma_kernel
+    asm volatile("" : "+v"(lv));
+    const int lqv = lv & 31, lhv = lv >> 5;
+    bf16x8 pf[2][2], dsf[2][2];
+#pragma unroll
+    for (int kt2 = 0; kt2 < 2; ++kt2) {
+      f32x16 sacc, pacc;
+      // accumulators start at -L2[q] / -delta[q] of their row: q = kt2*32 + 8g + 4h + j
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 l4 = *reinterpret_cast<const f32x4*>(sl + kt2 * 32 + 8 * g + 4 * lhv);
+        const f32x4 d4 = *reinterpret_cast<const f32x4*>(sd + kt2 * 32 + 8 * g + 4 * lhv);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { sacc[4 * g + j] = -l4[j]; pacc[4 * g + j] = -d4[j]; }
+      }
+      const int row = kt2 * 32 + lqv;
+#pragma unroll
+      for (int ks = 0; ks < DC / 16; ++ks) {
+        const int off = row * C::ROWB + C::swz(row, ks * 2 + lhv) * 16;
+        const bf16x8 qa = *reinterpret_cast<const bf16x8*>(sq + off);
+        sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[ks], sacc, 0, 0, 0);
+        const bf16x8 oa = *reinterpret_cast<const bf16x8*>(so + off);
+        pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(oa, vf[ks], pacc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float p = __builtin_amdgcn_exp2f(sacc[8 * s + j]);
+          pf[kt2][s][j] = f2bf(p);
+          dsf[kt2][s][j] = f2bf(p * pacc[8 * s + j]);
+        }
+    }
+    const unsigned qa0 = lds0 + cur * STAGE, oa0 = qa0 + C::TILE;
+#pragma unroll
+    for (int dvt = 0; dvt < DW / 32; ++dvt) {
+      bf16x8 ft[2][2];
+      bw_tr_frags<D>(oa0, dvt, lv, ft);
+#pragma unroll
+      for (int kt2 = 0; kt2 < 2; ++kt2)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) dva[dvt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ft[kt2][s], pf[kt2][s], dva[dvt], 0, 0, 0);
+      bw_tr_frags<D>(qa0, dvt, lv, ft);
+#pragma unroll
+      for (int kt2 = 0; kt2 < 2; ++kt2)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) dka[dvt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ft[kt2][s], dsf[kt2][s], dka[dvt], 0, 0, 0);
+    }
+    if (t + 1 < nt) store_stats(cur ^ 1);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    cur ^= 1;
+  }
+  bf16* krow = dK + base + (long)(k0 + lq) * D;
+  bf16* vrow = dV + base + (long)(k0 + lq) * D;
+  if constexpr (DW < D) {
+#pragma unroll
+    for (int c = DW + 4 * lh; c < D; c += 8) {
+      *reinterpret_cast<bf16x4*>(krow + c) = bf16x4{f2bf(0.f), f2bf(0.f), f2bf(0.f), f2bf(0.f)};
+      *reinterpret_cast<bf16x4*>(vrow + c) = bf16x4{f2bf(0.f), f2bf(0.f), f2bf(0.f), f2bf(0.f)};
+    }
+  }
+#pragma unroll
+  for (int dvt = 0; dvt < DW / 32; ++dvt)
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      bf16x4 k4, v4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        k4[j] = f2bf(dka[dvt][4 * g4 + j] * sk_scale);
+        v4[j] = f2bf(dva[dvt][4 * g4 + j]);
+      }
+      *reinterpret_cast<bf16x4*>(krow + dvt * 32 + 8 * g4 + 4 * lh) = k4;
+      *reinterpret_cast<bf16x4*>(vrow + dvt * 32 + 8 * g4 + 4 * lh) = v4;
+    }
+}
+
 // delta[b][hd][n] = sum_c dO[row][hd*d + c] * O[row][hd*d + c]  (compact [B*N][ldo] activations, d % 8 == 0); thread per (row, head)
 __global__ __launch_bounds__(256) void attn_bwd_delta_kernel(const bf16* __restrict__ O, const bf16* __restrict__ dO, long ldo,
                                                              float* __restrict__ delta, long rows, int N, int heads, int d) {
@@ -332,9 +674,38 @@ int launch_attention_bwd_delta(const bf16* o, const bf16* d_o, long ldo, float* 
   return DFOT_OK;
 }
 
+const bf16* g_bwd_zeros = nullptr;
+
 template <int D, int DC = D, int DW = D>
 static int launch_bwd_t(const bf16* q, const bf16* k, const bf16* v, const bf16* d_o, long ldo, const float* l2, const float* delta, bf16* dq,
                         bf16* dk, bf16* dv, int batch, int heads, int n, int d, float sq, float sk, hipStream_t s) {
+  // 1 (default): LDS-DMA forms for the 128-element-row instances only; 2: for all; 0: register-staged everywhere.  Measured
+  // (RE10K step, same box): d = 128 dq 367 -> 253 us, dk/dv 567 -> 480 us; d = 64 dq 1782 -> 1782 us, dk/dv 2377 -> 2565 us (its
+  // 226 VGPRs leave two waves per SIMD where the register-staged form's 167 leave three)
+  static const int dma = tuning_flag("ATTN_BWD_DMA", 1);
+  const int grid = (n / 128) * batch * heads;
+  if (dma == 2 || (dma == 1 && D == 128)) {
+    using C = DmaCfg<D>;
+    const int lds1 = 4 * C::TILE, lds2 = 2 * (2 * C::TILE + 2 * C::TR * 4);
+    static bool attr_set = false;
+    if (!attr_set) {
+      DFOT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_dma_kernel<D, DC, DW>), hipFuncAttributeMaxDynamicSharedMemorySize, lds1));
+      DFOT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_dma_kernel<D, DC, DW>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2));
+      attr_set = true;
+    }
+    if (!g_bwd_zeros) {
+      void* z = nullptr;
+      DFOT_CHECK_HIP(hipMalloc(&z, 256));
+      DFOT_CHECK_HIP(hipMemset(z, 0, 256));
+      g_bwd_zeros = (const bf16*)z;
+    }
+    hipLaunchKernelGGL((attn_bwd_dq_dma_kernel<D, DC, DW>), dim3(grid), dim3(256), lds1, s, q, k, v, d_o, ldo, l2, delta, dq, n, heads, d, sq);
+    DFOT_CHECK_HIP(hipGetLastError());
+    hipLaunchKernelGGL((attn_bwd_dkv_dma_kernel<D, DC, DW>), dim3(grid), dim3(256), lds2, s, q, k, v, d_o, ldo, l2, delta, dk, dv, n, heads, d, sk,
+                       g_bwd_zeros);
+    DFOT_CHECK_HIP(hipGetLastError());
+    return DFOT_OK;
+  }
   using C = BwdCfg<D>;
   const int lds1 = 4 * C::TILE, lds2 = 2 * (2 * C::TILE + 2 * C::TR * 4);
   static bool attr_set = false;
@@ -343,7 +714,6 @@ static int launch_bwd_t(const bf16* q, const bf16* k, const bf16* v, const bf16*
     DFOT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_kernel<D, DC, DW>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2));
     attr_set = true;
   }
-  const int grid = (n / 128) * batch * heads;
   hipLaunchKernelGGL((attn_bwd_dq_kernel<D, DC, DW>), dim3(grid), dim3(256), lds1, s, q, k, v, d_o, ldo, l2, delta, dq, n, heads, d, sq);
   DFOT_CHECK_HIP(hipGetLastError());
   hipLaunchKernelGGL((attn_bwd_dkv_kernel<D, DC, DW>), dim3(grid), dim3(256), lds2, s, q, k, v, d_o, ldo, l2, delta, dk, dv, n, heads, d, sk);

@@ -52,6 +52,19 @@ def test_attention_backward(d, heads, n, batch):
         assert r < 2e-2, (name, r)
 
 
+@pytest.mark.parametrize("mode", [0, 2])
+def test_attention_backward_both_staging_forms(mode):
+    """the backward kernels exist register-staged and LDS-DMA-staged for every head-dim instance; the default mixes them (DMA for the
+    128-element rows).  DFOT_ATTN_BWD_DMA = 0 / 2 forces one form everywhere: the whole test_attention_backward matrix in a child"""
+    import subprocess, sys
+    if os.environ.get("DFOT_ATTN_BWD_DMA") is not None:
+        pytest.skip("already inside the forced-mode child")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x", "-k", "test_attention_backward and not both_staging"],
+                       env=dict(os.environ, DFOT_ATTN_BWD_DMA=str(mode)), capture_output=True, text=True, timeout=600)
+    print(r.stdout[-600:], r.stderr[-1500:] if r.returncode else "")
+    assert r.returncode == 0
+
+
 def _tiny_trainer(depth=2, hidden=128, heads=4, seed=3, res=(16, 8), chans=4, tokens=5, patch=1, mlp_ratio=None):
     import dfot_amd
     from oracle import dit as odit
