@@ -364,7 +364,7 @@ __device__ __forceinline__ void bw_tr_frags(unsigned tile_addr, int dvt, int lan
 }
 
 template <int D, int DC = D, int DW = D>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dq_dma_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K,
+__global__ __launch_bounds__(256, (D == 64 ? 3 : 2)) void attn_bwd_dq_dma_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K,
                                                                  const bf16* __restrict__ V, const bf16* __restrict__ dO, long ldo,
                                                                  const float* __restrict__ L2, const float* __restrict__ delta,
                                                                  bf16* __restrict__ dQ, int N, int heads, int d, float sq) {
