@@ -189,6 +189,22 @@ __global__ __launch_bounds__(256) void attn_kernel(const bf16* __restrict__ Q, c
     }
 }
 
+typedef __attribute__((ext_vector_type(2))) unsigned v2_u32x2;
+template <int OFF>
+__device__ __forceinline__ v2_u32x2 v2_read_tr16(unsigned addr) {
+  v2_u32x2 r;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
+  return r;
+}
+__device__ __forceinline__ void v2_lds_wait(v2_u32x2& a, v2_u32x2& b, v2_u32x2& c, v2_u32x2& d, v2_u32x2& e, v2_u32x2& f, v2_u32x2& g, v2_u32x2& h) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h));
+}
+__device__ __forceinline__ bf16x8 v2_bf16x8(v2_u32x2 lo, v2_u32x2 hi) {
+  typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+  const u32x4 v = {lo[0], lo[1], hi[0], hi[1]};
+  return __builtin_bit_cast(bf16x8, v);
+}
+
 // ---------------------------------------------------------------------------------------------
 // Tuned variant (default).  Same products and layouts as attn_kernel above, plus:
 //  * K/V tiles go global -> LDS by LDS-DMA (global_load_lds_dwordx4); the bank swizzles are involutions applied to
@@ -368,24 +384,44 @@ __global__ __launch_bounds__(256, QRELOAD ? 4 : 1) void attn_kernel_v2(const bf1
     l_i += rs;
 
     // ---- O^T += V^T P^T ----
+    // V^T fragments by ds_read_b64_tr_b16 through inline asm: hipcc puts `s_waitcnt vmcnt(0)` in front of the builtin form while an
+    // LDS-DMA is in flight (it cannot see that the prefetched stage is another one), which drained the K/V ring at this point of every
+    // tile.  The bank swizzle depends on q4 only, so one base address per lane and 32-column block; (kt2, s, +8) are immediate offsets.
     if (prio) __builtin_amdgcn_s_setprio(1);
+    if constexpr (QRELOAD) {  // the 128-VGPR experiment keeps the builtin reads (the asm form's eight live results cost it spills)
 #pragma unroll
-    for (int dvt = 0; dvt < DV / 32; ++dvt) {
+      for (int dvt = 0; dvt < DV / 32; ++dvt)
 #pragma unroll
-      for (int kt2 = 0; kt2 < 2; ++kt2) {
+        for (int kt2 = 0; kt2 < 2; ++kt2)
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-          const int kb = kt2 * 32 + 16 * s + 4 * lh;
-          const int q4 = (lane & 15) >> 2, p4 = lane & 3;
-          const int col = dvt * 32 + 16 * ((lane >> 4) & 1) + 4 * p4;
-          const int r0 = kb + q4, r1 = kb + 8 + q4;
-          const char* a0 = sv + r0 * C::ROWB + C::swz_v(r0, col >> 3) * 16 + (col & 7) * 2;
-          const char* a1 = sv + r1 * C::ROWB + C::swz_v(r1, col >> 3) * 16 + (col & 7) * 2;
-          const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(a0));
-          const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(a1));
-          const bf16x8 vf = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-          oacc[dvt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[kt2][s], oacc[dvt], 0, 0, 0);
-        }
+          for (int s = 0; s < 2; ++s) {
+            const int kb = kt2 * 32 + 16 * s + 4 * lh;
+            const int q4 = (lane & 15) >> 2, p4 = lane & 3;
+            const int col = dvt * 32 + 16 * ((lane >> 4) & 1) + 4 * p4;
+            const int r0 = kb + q4, r1 = kb + 8 + q4;
+            const char* a0 = sv + r0 * C::ROWB + C::swz_v(r0, col >> 3) * 16 + (col & 7) * 2;
+            const char* a1 = sv + r1 * C::ROWB + C::swz_v(r1, col >> 3) * 16 + (col & 7) * 2;
+            const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(a0));
+            const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(a1));
+            const bf16x8 vf = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            oacc[dvt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[kt2][s], oacc[dvt], 0, 0, 0);
+          }
+    } else {
+  #pragma unroll
+      for (int dvt = 0; dvt < DV / 32; ++dvt) {
+        const int q4 = (lane & 15) >> 2, p4 = lane & 3;
+        const int col = dvt * 32 + 16 * ((lane >> 4) & 1) + 4 * p4;
+        const int r0 = 4 * lh + q4;
+        const unsigned va = (unsigned)(size_t)DFOT_LDS_PTR(sv) + r0 * C::ROWB + C::swz_v(r0, col >> 3) * 16 + (col & 7) * 2;
+        v2_u32x2 r000 = v2_read_tr16<0 * C::ROWB>(va), r001 = v2_read_tr16<8 * C::ROWB>(va);
+        v2_u32x2 r010 = v2_read_tr16<16 * C::ROWB>(va), r011 = v2_read_tr16<24 * C::ROWB>(va);
+        v2_u32x2 r100 = v2_read_tr16<32 * C::ROWB>(va), r101 = v2_read_tr16<40 * C::ROWB>(va);
+        v2_u32x2 r110 = v2_read_tr16<48 * C::ROWB>(va), r111 = v2_read_tr16<56 * C::ROWB>(va);
+        v2_lds_wait(r000, r001, r010, r011, r100, r101, r110, r111);
+        oacc[dvt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v2_bf16x8(r000, r001), pf[0][0], oacc[dvt], 0, 0, 0);
+        oacc[dvt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v2_bf16x8(r010, r011), pf[0][1], oacc[dvt], 0, 0, 0);
+        oacc[dvt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v2_bf16x8(r100, r101), pf[1][0], oacc[dvt], 0, 0, 0);
+        oacc[dvt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v2_bf16x8(r110, r111), pf[1][1], oacc[dvt], 0, 0, 0);
       }
     }
     if (prio) __builtin_amdgcn_s_setprio(0);
