@@ -173,14 +173,17 @@ __device__ __forceinline__ int w2_swz(int row, int chunk) {
 
 // CONV: blockIdx.y = tap of a 3x3 convolution; B row r is pixel r shifted by (tap / 3 - 1, tap % 3 - 1) inside its img_h x img_w image,
 // zero outside (fetched from the zero buffer); partial outputs [slice][tap][M][N] -- as the all_taps mode of the form above
-template <int MW, int NW, bool CONV>
+// KT: token rows per staged K tile (64; 32 for the 4-wave 128 x 128 form: half the LDS per workgroup, so four of them -- 16 waves --
+// are resident per CU instead of two; at 8 waves per CU that form ran at 0.18 MFMA utilisation against 0.45 for the 16-wave forms)
+template <int MW, int NW, bool CONV, int KT = 64>
 __global__ __launch_bounds__(MW * NW * 64) void wgrad_nt_big_kernel(const bf16* __restrict__ A, long lda, const bf16* __restrict__ B, long ldb,
                                                                     float* __restrict__ out, int M, int N, long rows, int slices,
                                                                     const bf16* __restrict__ zeros, int img_h, int img_w) {
   constexpr int NWV = MW * NW, FA = MW * 64, FB = NW * 64, CPA = FA / 8, CPB = FB / 8;
   constexpr int RA = FA * 2, RB = FB * 2;             // LDS row pitch (bytes)
-  constexpr int TA = 64 * RA, TB = 64 * RB, STG = TA + TB;
-  constexpr int IA = CPA, IB = CPB;                   // 1-KiB DMA instructions per tile (64 rows x CP chunks / 64 lanes)
+  static_assert(KT == 64 || KT == 32, "K tile rows");
+  constexpr int TA = KT * RA, TB = KT * RB, STG = TA + TB;
+  constexpr int IA = KT * CPA / 64, IB = KT * CPB / 64;  // 1-KiB DMA instructions per tile (KT rows x CP chunks / 64 lanes)
   constexpr int PA = (IA + NWV - 1) / NWV, PB = (IB + NWV - 1) / NWV;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -189,7 +192,7 @@ __global__ __launch_bounds__(MW * NW * 64) void wgrad_nt_big_kernel(const bf16* 
   const int tile = blockIdx.x / slices, slice = blockIdx.x % slices;
   const int m0 = (tile / tiles_n) * FA, n0 = (tile % tiles_n) * FB;
   const int wm = (wave / NW) * 64, wn = (wave % NW) * 64;
-  const long nt_all = rows / 64;
+  const long nt_all = rows / KT;
   const long per = nt_all / slices, rem = nt_all % slices;
   const long t0 = slice * per + (slice < rem ? slice : rem), nt = per + (slice < rem ? 1 : 0);
 
@@ -204,16 +207,16 @@ __global__ __launch_bounds__(MW * NW * 64) void wgrad_nt_big_kernel(const bf16* 
   for (int i = 0; i < PA; ++i) {
     const int q = (wave + i * NWV) * 64 + lane, row = q / CPA, col = w2_swz<FA>(row, q % CPA) * 8;
     const bool ok = m0 + col < M;
-    pa[i] = ok ? A + (t0 * 64 + row) * lda + m0 + col : zeros;
-    sa[i] = ok ? 64 * lda : 0;
+    pa[i] = ok ? A + (t0 * KT + row) * lda + m0 + col : zeros;
+    sa[i] = ok ? KT * lda : 0;
   }
 #pragma unroll
   for (int i = 0; i < PB; ++i) {
     const int q = (wave + i * NWV) * 64 + lane, row = q / CPB, col = w2_swz<FB>(row, q % CPB) * 8;
     const bool ok = n0 + col < N;
-    pb[i] = ok ? B + (t0 * 64 + row) * ldb + n0 + col : zeros;
-    sb[i] = ok ? 64 * ldb : 0;
-    rb[i] = t0 * 64 + row;
+    pb[i] = ok ? B + (t0 * KT + row) * ldb + n0 + col : zeros;
+    sb[i] = ok ? KT * ldb : 0;
+    rb[i] = t0 * KT + row;
     okb[i] = ok;
     if constexpr (CONV) pb[i] = B + n0 + col;  // the row offset is applied per tile
   }
@@ -231,11 +234,16 @@ __global__ __launch_bounds__(MW * NW * 64) void wgrad_nt_big_kernel(const bf16* 
       const int j = wave + i * NWV;
       if constexpr (CONV) {
         const long r = rb[i];
-        const int x = (int)(r % img_w) + sdx, y = (int)((r / img_w) % img_h) + sdy;
+        // pixel (x, y) of row r: 32-bit arithmetic (launcher: pixels < 2^31), shifts / masks for power-of-two image sizes (64-bit
+        // divisions here were two ~100-instruction sequences per DMA instruction and tile, next to 16 MFMAs)
+        const unsigned ru = (unsigned)r, uw = (unsigned)img_w, uh = (unsigned)img_h;
+        const bool p2w = (uw & (uw - 1)) == 0, p2h = (uh & (uh - 1)) == 0;
+        const unsigned rowq = p2w ? ru >> (31 - __builtin_clz(uw)) : ru / uw;
+        const int x = (int)(p2w ? (ru & (uw - 1)) : ru - rowq * uw) + sdx, y = (int)(p2h ? (rowq & (uh - 1)) : rowq % uh) + sdy;
         const bool ok = okb[i] && x >= 0 && x < img_w && y >= 0 && y < img_h;
         const bf16* src = ok ? pb[i] + (r + (long)sdy * img_w + sdx) * ldb : zeros;
         if (j < IB) __builtin_amdgcn_global_load_lds(DFOT_GLOBAL_PTR(src), DFOT_LDS_PTR(lb + j * 1024), 16, 0, 0);
-        rb[i] = r + 64;
+        rb[i] = r + KT;
       } else {
         if (j < IB) __builtin_amdgcn_global_load_lds(DFOT_GLOBAL_PTR(pb[i]), DFOT_LDS_PTR(lb + j * 1024), 16, 0, 0);
         pb[i] += sb[i];
@@ -293,12 +301,14 @@ __global__ __launch_bounds__(MW * NW * 64) void wgrad_nt_big_kernel(const bf16* 
     W2_READ(1, 1, so)
     W2_MMA(0)
     w2_wait(fa[1], fb[1]);
-    W2_READ(2, 0, so)
-    W2_MMA(1)
-    w2_wait(fa[0], fb[0]);
-    W2_READ(3, 1, so)
-    W2_MMA(0)
-    w2_wait(fa[1], fb[1]);
+    if constexpr (KT == 64) {
+      W2_READ(2, 0, so)
+      W2_MMA(1)
+      w2_wait(fa[0], fb[0]);
+      W2_READ(3, 1, so)
+      W2_MMA(0)
+      w2_wait(fa[1], fb[1]);
+    }
     W2_MMA(1)
   }
 #undef W2_READ
@@ -320,11 +330,11 @@ __global__ __launch_bounds__(MW * NW * 64) void wgrad_nt_big_kernel(const bf16* 
 
 const bf16* g_w2_zeros = nullptr;
 
-template <int MW, int NW, bool CONV>
+template <int MW, int NW, bool CONV, int KT = 64>
 int launch_big(const bf16* a, long lda, const bf16* b, long ldb, float* out, int m, int n, long rows, int slices, hipStream_t s, int img_h = 0,
                int img_w = 0) {
-  constexpr int FA = MW * 64, FB = NW * 64, LDS = 2 * 64 * (FA + FB) * 2;
-  auto kern = wgrad_nt_big_kernel<MW, NW, CONV>;
+  constexpr int FA = MW * 64, FB = NW * 64, LDS = 2 * KT * (FA + FB) * 2;
+  auto kern = wgrad_nt_big_kernel<MW, NW, CONV, KT>;
   static bool attr_set = false;
   if (!attr_set) {
     DFOT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
@@ -404,10 +414,16 @@ WgradPlan wgrad_plan(int m, int n, long rows, long max_slices) {
 int launch_wgrad_conv_taps(const bf16* dy, const bf16* x, float* out, int co, int ci, long pix, int slices, int img_h, int img_w, hipStream_t s) {
   static const int dma = tuning_flag("WGRAD_CONV_DMA", 1);
   if (!dma) return launch_wgrad_nt(dy, co, x, ci, out, co, ci, pix, slices, s, img_h, img_w, 0, 0, 1);
-  DFOT_REQUIRE(dy && x && out && co % 8 == 0 && ci % 8 == 0 && pix % 64 == 0 && slices >= 1 && slices <= pix / 64 && img_h > 0 && img_w > 0 &&
+  DFOT_REQUIRE(dy && x && out && co % 8 == 0 && ci % 8 == 0 && pix % 64 == 0 && pix < (1L << 31) && slices >= 1 && slices <= pix / 64 && img_h > 0 && img_w > 0 &&
                    pix % ((long)img_h * img_w) == 0,
                DFOT_ERR_SHAPE, "wgrad_conv_taps: %d -> %d channels, %ld pixels unsupported", ci, co, pix);
-  if (co <= 128 && ci <= 128) return launch_big<2, 2, true>(dy, co, x, ci, out, co, ci, pix, slices, s, img_h, img_w);
+  // A/B (off): 32-row K tiles, four resident workgroups per CU.  No gain (273.5 ms/step either way): the 128-channel convolution's
+  // weight gradient is bound by operand traffic, not occupancy -- 128 x 128 tiles read both operands once per tap, 4.7 GB per call
+  // through L2 at 6.7 TB/s (MFMA utilisation 0.18); sharing one dy tile between taps (128 x 256 tiles) is the remaining lever
+  static const int kt32 = tuning_flag("WGRAD_CONV_KT32", 0);
+  if (co <= 128 && ci <= 128)
+    return kt32 ? launch_big<2, 2, true, 32>(dy, co, x, ci, out, co, ci, pix, slices, s, img_h, img_w)
+                : launch_big<2, 2, true>(dy, co, x, ci, out, co, ci, pix, slices, s, img_h, img_w);
   return launch_big<4, 4, true>(dy, co, x, ci, out, co, ci, pix, slices, s, img_h, img_w);
 }
 // workgroups per tap and slice of launch_wgrad_conv_taps, and the workgroup count to aim for with K slices (two rounds of the

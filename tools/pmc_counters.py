@@ -24,7 +24,7 @@ def main():
     for d in dirs:
         for path in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
             for row in csv.DictReader(open(path)):
-                name = re.sub(r"^void ", "", row["Kernel_Name"]).split("(")[0].replace("dfot::", "").replace("(anonymous namespace)::", "")
+                name = re.sub(r"^void ", "", row["Kernel_Name"]).replace("dfot::", "").replace("(anonymous namespace)::", "").split("(")[0]
                 if "at::native" in name or name.startswith("__amd"):
                     continue
                 a = acc[name][row["Counter_Name"]]
