@@ -32,6 +32,7 @@ RE10K = dict(channels=[128, 256, 576, 1152], emb_channels=1024, patch_size=2,
              num_updown_blocks=[3, 3, 6], num_mid_blocks=20, num_heads=9, pos_emb_type="rope",
              use_fourier_noise_embedding=True, conditioning=dict(dim=180))
 WINDOW_FLOP = 6.63e12  # per 8-frame window-forward
+GRAPH_DEFAULT = False  # sampler mode of the headline line: hipGraph when it measures >= eager on the same box
 
 
 def synth_poses(b: int, t: int, seed: int) -> torch.Tensor:
@@ -193,7 +194,9 @@ def bench_train_re10k(args, rank, world, dist):
         torch.cuda.synchronize()
 
     def step(i):
-        loss = tr.loss_and_grads(xs, cond, levels[i][0], noise, levels[i][1])
+        # data parallel: the gradient all-reduce overlaps the backward (ranges of the flat buffer reduced in place as levels finish)
+        reducer = dfot_amd.parallel.OverlappedGradReducer(flat=tr.flat_grads) if world > 1 else None
+        loss = tr.loss_and_grads(xs, cond, levels[i][0], noise, levels[i][1], reducer=reducer)
         tr.optimizer_step(lr=5e-5, betas=(0.9, 0.99), weight_decay=0.01, max_grad_norm=1.0, world_size=world)
         return loss
     for i in range(args.warmup):
@@ -350,6 +353,10 @@ def run_extras(args):
         "k600diff": ["--workload", "k600diff", "--steps", "1", "--warmup", "1"],               # config 4, bash/k600 model
         "train_re10k": ["--workload", "train_re10k", "--batch", "8", "--steps", "2", "--warmup", "1"],  # config 5
         "train_k600": ["--workload", "train_k600", "--steps", "3", "--warmup", "1"],
+        "8f_eager" if args.graph_default else "8f_graph": ["--workload", "8f", "--no-extras", "--steps", "2", "--warmup", "1"] + (["--eager"] if args.graph_default else ["--graph"]),
+        # what a checkpoint whose q_norm / k_norm weights exceed the no-running-max bound would get: level-2 attention on attention_v3 (variant 5)
+        "8f_safe_attention": ["--workload", "8f", "--no-extras", "--steps", "2", "--warmup", "1", "--attn-safe"],
+        "vae_decode": ["--workload", "vae_decode", "--steps", "3", "--warmup", "1"],
     }
     out = {}
     for name, extra_args in jobs.items():
@@ -364,7 +371,7 @@ def run_extras(args):
             j = json.loads(rows[-1])
             keep = {k: j[k] for k in ("metric", "value", "unit", "steps", "ms_per_step", "dtype") if k in j}
             keep["workload"] = j.get("config", {}).get("workload")
-            for k in ("model_tflops", "window_forward_ms", "video_forward_ms"):
+            for k in ("model_tflops", "window_forward_ms", "video_forward_ms", "sampler_mode", "attention_kernel", "hbm_gbps"):
                 if j.get(k) is not None:
                     keep[k] = j[k]
             if "roofline" in j:
@@ -376,6 +383,66 @@ def run_extras(args):
     return out
 
 
+def bench_vae_decode(args):
+    """K600 latents -> frames, the step after the sampler for latent datasets (base_pytorch_video_algo.py:553-629 `_decode`):
+    VideoVAE decoder (default widths 128 x (1, 2, 4, 4), 2 ResBlocks per level, z 16), `--batch` videos of 5 latent tokens
+    (16 x 16) -> 17 frames of 128 x 128.  Reports ms per video and the algorithmic HBM bytes of the GroupNorm / upsample passes."""
+    import dfot_amd
+    dec = dfot_amd.VideoVAEDecoder(z_channels=16, hidden_size=128, embed_dim=16).cuda()
+    dec.init_random(seed=0)
+    b = min(args.batch, 2)  # vae.batch_size of the K600 configs
+    z = torch.randn(b, 5, 16, 16, 16, generator=torch.Generator().manual_seed(0)).cuda()
+    run = lambda: dfot_amd.decode_latents(dec, z, n_frames=17, vae_batch_size=b)
+    for _ in range(args.warmup):
+        out = run()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = run()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.steps
+    assert torch.isfinite(out).all() and tuple(out.shape) == (b, 17, 3, 128, 128)
+    line = {"metric": "VideoVAE decode, K600 latents -> 17 frames of 128x128", "value": b * 17 / dt, "unit": "pixel frames/s", "n_gpus": 1,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic latents, seeded random-init weights",
+            "config": {"workload": f"VideoVAE decoder: {b} videos x 5 latent tokens (16x16x16) -> 17 frames 128x128 per call", "ms_per_video": dt * 1e3 / b}}
+    print(json.dumps(line), flush=True)
+
+
+def spawn_ranks(args, argv):
+    """`python bench.py --gpus N` without a launcher: this parent (which never touches the GPU) starts N fresh child processes, one
+    per GPU, with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set -- what `accelerate launch --multi_gpu --num_processes N`
+    does for the reference (configurations/cluster/a2i2_multigpu.yaml:45-57) -- forwards rank 0's JSON line and exits non-zero if any
+    child does.  A child that dies takes the others down instead of leaving them in a collective."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    failed = None
+    while failed is None and any(p.poll() is None for p in procs[1:]) and procs[0].poll() is None:
+        time.sleep(0.2)
+        failed = next((p for p in procs if p.poll() not in (None, 0)), None)
+    if failed is not None:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    out0 = procs[0].stdout.read() if procs[0].stdout else ""
+    rcs = [p.wait() for p in procs]
+    for l in out0.splitlines():
+        if l.startswith("{"):
+            print(l, flush=True)
+    if any(rcs):
+        sys.stderr.write(f"bench.py: rank exit codes {rcs}\n")
+        raise SystemExit(next(rc for rc in rcs if rc) if any(rc > 0 for rc in rcs) else 1)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -385,26 +452,33 @@ def main():
     ap.add_argument("--sampling-steps", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="8f only: skip the short runs of the other BASELINE configs appended under 'extra'")
-    ap.add_argument("--graph", action="store_true", help="replay one hipGraph-captured DDIM step (no in-run attention timing)")
+    ap.add_argument("--graph", action="store_true", help="all remaining DDIM steps of a window as ONE hipGraph, one replay per window")
     ap.add_argument("--eager", action="store_true", help="force the eager step loop (A/B against the default)")
+    ap.add_argument("--attn-safe", action="store_true", help="level-2 attention on the running-max kernel (what weights beyond the QK-norm bound get)")
+    ap.add_argument("--dry-run", action="store_true", help="host plumbing only (CPU, gloo): plans, shards and gathers every window but launches nothing")
     ap.add_argument("--batch", type=int, default=8, help="k600: videos per GPU (bash/k600 validation.batch_size)")
-    ap.add_argument("--workload", choices=["8f", "200f", "k600", "k600diff", "train_k600", "train_k600diff", "train_re10k"], default="8f",
+    ap.add_argument("--workload", choices=["8f", "200f", "k600", "k600diff", "train_k600", "train_k600diff", "train_re10k", "vae_decode"], default="8f",
                     help="8f: BASELINE config 2 (default, the metric's single-GPU configuration); 200f: config 3, the "
                          "200-frame rollout (keyframe density 0.0625, stabilized HG 4.0/0.02 + interpolation HG 1.5, batches of "
                          "4 windows), interpolation windows sharded over ranks")
     args = ap.parse_args()
+    args.graph_default = GRAPH_DEFAULT
+    use_graph = (GRAPH_DEFAULT or args.graph) and not args.eager
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(args, sys.argv[1:])
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     extras = None
-    if world == 1 and args.workload == "8f" and not args.no_extras and args.res == 256:
+    if world == 1 and args.workload == "8f" and not args.no_extras and args.res == 256 and not args.dry_run:
         # the other BASELINE configs, short and clearly labelled, inside the same driver-timed run (the headline stays config 2).
         # This process never touches the GPU: the headline runs first, as a child of its own on the fresh device, then the extras;
         # the one JSON line is assembled here.
         import subprocess
         cmd = [sys.executable, os.path.abspath(__file__), "--no-extras", "--steps", str(args.steps), "--warmup", str(args.warmup),
-               "--sampling-steps", str(args.sampling_steps)] + (["--no-cpu-baseline"] if args.no_cpu_baseline else []) + (["--eager"] if args.eager else [])
+               "--sampling-steps", str(args.sampling_steps)] + (["--no-cpu-baseline"] if args.no_cpu_baseline else []) + (["--eager"] if args.eager else []) + \
+              (["--graph"] if args.graph else []) + (["--attn-safe"] if args.attn_safe else [])
         r = subprocess.run(cmd, capture_output=True, text=True)
         rows = [l for l in r.stdout.splitlines() if l.startswith("{")]
         if r.returncode != 0 or not rows:
@@ -414,15 +488,25 @@ def main():
         line["extra"] = run_extras(args)
         print(json.dumps(line), flush=True)
         return
-    torch.cuda.set_device(local)
+    dev = "cpu" if args.dry_run else "cuda"
+    if not args.dry_run:
+        torch.cuda.set_device(local)
+    dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if args.dry_run:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
     import dfot_amd
     from dfot_amd import DFoTVideoPoseSampler, DiffusionConfig, SamplerConfig, UViT3DPose
 
+    if args.dry_run and args.workload not in ("8f", "200f"):
+        raise SystemExit("--dry-run covers the sampler workloads (8f, 200f)")
+    if args.workload == "vae_decode":
+        return bench_vae_decode(args)
     if args.workload == "train_re10k":
         return bench_train_re10k(args, rank, world, dist if world > 1 else None)
     if args.workload in ("train_k600", "train_k600diff"):
@@ -430,8 +514,12 @@ def main():
     if args.workload in ("k600", "k600diff"):
         return bench_k600(args, rank, world, dist if world > 1 else None)
     res = args.res
-    model = UViT3DPose(RE10K, x_shape=(3, res, res), max_tokens=8).cuda()
-    model.init_random(seed=0)
+    model = None
+    if not args.dry_run:
+        model = UViT3DPose(RE10K, x_shape=(3, res, res), max_tokens=8).cuda()
+        model.init_random(seed=0)
+        if args.attn_safe:
+            model.set_option("attn_force_safe", 1)
     long_rollout = args.workload == "200f"
     if long_rollout:
         n_frames = 200
@@ -441,30 +529,38 @@ def main():
                             interpolation_guidance=dict(name="vanilla", guidance_scale=1.5), keyframe_density=0.0625,
                             interpolation_max_batch_size=4)
         # every rank works on the SAME video; noise is keyed by window so replicated key-frame windows agree bitwise
-        sampler = DFoTVideoPoseSampler(cfg, model, dfot_amd.parallel.WindowKeyedNoise(1234))
+        sampler = DFoTVideoPoseSampler(cfg, model, dfot_amd.parallel.WindowKeyedNoise(1234, device=dev))
         sampler.shard_windows = world > 1
-        xs = torch.randn(1, n_frames, 3, res, res, generator=torch.Generator().manual_seed(0)).cuda()
-        conds = synth_poses(1, n_frames, 100).cuda()
+        # the sequential key-frame windows: History-Guidance branches split over rank pairs (one all-gather of v per step)
+        sampler.branch_parallel = world > 1
+        xs = torch.randn(1, n_frames, 3, res, res, generator=torch.Generator().manual_seed(0)).to(dev)
+        conds = synth_poses(1, n_frames, 100).to(dev)
     else:
         n_frames = 8
         cfg = SamplerConfig(x_shape=(3, res, res), max_tokens=8,
                             diffusion=DiffusionConfig(sampling_timesteps=args.sampling_steps),
                             prediction_guidance=dict(name="vanilla", guidance_scale=4.0))
-        gen = torch.Generator(device="cuda").manual_seed(1234 + rank)
-        sampler = DFoTVideoPoseSampler(cfg, model, dfot_amd.device_noise_fn(gen))
-        xs = torch.randn(1, n_frames, 3, res, res, generator=torch.Generator().manual_seed(rank)).cuda()
-        conds = synth_poses(1, n_frames, 100 + rank).cuda()
+        gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+        sampler = DFoTVideoPoseSampler(cfg, model, dfot_amd.device_noise_fn(gen) if not args.dry_run else
+                                       (lambda tag, shape: torch.randn(shape, generator=gen)))
+        xs = torch.randn(1, n_frames, 3, res, res, generator=torch.Generator().manual_seed(rank)).to(dev)
+        conds = synth_poses(1, n_frames, 100 + rank).to(dev)
+    if args.dry_run:
+        sampler.device, sampler.dry_run = "cpu", True
 
     def barrier():
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        if not args.dry_run:
+            torch.cuda.synchronize()
 
+    sampler.use_graph = use_graph and not args.dry_run
     for _ in range(args.warmup):
         sampler._predict_videos(xs, n_context_tokens=1, conditions=conds)
-    sampler.use_graph = args.graph
-    attn_per_sample = 0 if args.graph else args.sampling_steps * 12 * (14 if long_rollout else 1)
-    model.set_option("time_attn", attn_per_sample * args.steps if rank == 0 else 0)
+    timed_attn = not sampler.use_graph and not args.dry_run
+    attn_per_sample = args.sampling_steps * 12 * (14 if long_rollout else 1) if timed_attn else 0
+    if model is not None:
+        model.set_option("time_attn", attn_per_sample * args.steps if rank == 0 else 0)
     sampler.window_forwards = 0
     barrier()
     t0 = time.perf_counter()
@@ -473,17 +569,25 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     assert torch.isfinite(out).all()
+    ranks_identical = None
     if world > 1:
-        tmax = torch.tensor([dt], device="cuda")
+        tmax = torch.tensor([dt], device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
+        if long_rollout:  # all ranks cooperate on ONE video: every rank must end with the same 200 frames, bit for bit
+            ref = out.clone()
+            dist.broadcast(ref, 0)
+            same = torch.tensor([1.0 if torch.equal(ref, out) else 0.0], device=dev)
+            dist.all_reduce(same, op=dist.ReduceOp.MIN)
+            ranks_identical = bool(same.item() == 1.0)
+            assert ranks_identical, "200f: the ranks ended with different rollouts"
     frames_per_sample = n_frames - 1
     # 8f: one video per rank (weak scaling); 200f: all ranks cooperate on one video (strong scaling)
     total_frames = frames_per_sample * args.steps * (1 if long_rollout else world)
     fwd = sampler.window_forwards
 
     if rank == 0:
-        attn_ms, attn_n = model.attn_timing()
+        attn_ms, attn_n = model.attn_timing() if model is not None else (0.0, 0)
         n2 = 8 * (res // 8) ** 2
         # total level-2 attention FLOPs of the timed region = 4*N^2*d*heads per (window-forward, block) x 12 blocks
         # x window-forwards; every one of those launches was event-timed, so achieved = FLOPs / summed duration.
@@ -492,10 +596,12 @@ def main():
         total_attn_flop = 4.0 * n2 * n2 * 64 * 9 * 12 * fwd
         achieved = total_attn_flop / (attn_ms * 1e-3) / 1e12 if attn_n else None
         traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r02_pmc_hbm_traffic_8f.json")
-        if os.path.exists(pmc) and res == 256 and not long_rollout:
+        pmc = next((f for f in (os.path.join(ROOT, "profiles", n) for n in ("r03_pmc_hbm_traffic_8f.json", "r02_pmc_hbm_traffic_8f.json")) if os.path.exists(f)), None)
+        if pmc and res == 256 and not long_rollout:
             ks = [v for n, v in json.load(open(pmc))["kernels"].items() if "attn64_kernel_v5" in n]
             traffic = ks[0]["hbm_bytes_per_launch_corrected"] if ks else None
+        akern = int(model.query("attn_kernel_l2")) if model is not None else None
+        kname = {14: "attn64_kernel_v5 (no running max: QK-norm bound < 64)", 5: "attn64_kernel_v3 (running max)"}.get(akern, "none (dry run)")
         line = {
             "metric": "denoised latent frames/sec, DFoT RE10K 8f & 200f rollout @1/2/4/8 GPU",
             "value": total_frames / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -503,22 +609,26 @@ def main():
             "dtype": "bf16", "data": "synthetic latents, seeded random-init weights",
             "config": {"workload": (f"DFoT_RE10K 200-frame rollout: 12 key frames (stabilized HG 4.0/0.02) + 2-stage interpolation "
                                     f"(HG 1.5, batches of 4 windows), {args.sampling_steps} DDIM steps, {res}x{res}, windows sharded "
-                                    f"over ranks") if long_rollout else
+                                    f"over ranks, key-frame HG branches split over rank pairs") if long_rollout else
                                    (f"DFoT_RE10K 8-frame sample: context 1, {args.sampling_steps} DDIM steps, vanilla history "
                                     f"guidance 4.0 (NFE 2), {res}x{res}, one video per GPU"),
                        "window_forwards_per_step": fwd // args.steps, "frames_per_step": frames_per_sample},
             "window_forward_ms": dt / fwd * 1e3,
             "model_tflops": WINDOW_FLOP * (res / 256.0) ** 2 * fwd / dt / 1e12 if res == 256 else None,
-            "roofline": {"bound": "mfma", "kernel": "attn64_kernel_v5 + attn64_merge_kernel (level-2 flash attention, N=%d, d=64; the event pair "
-                                                   "brackets both launches)" % n2,
+            "roofline": {"bound": "mfma", "kernel": "%s + attn64_merge_kernel (level-2 flash attention, N=%d, d=64; the event pair "
+                                                   "brackets both launches)" % (kname.split(" (")[0], n2),
                          "achieved": achieved, "peak": 2500.0, "unit": "TFLOP/s",
                          "frac": achieved / 2500.0 if achieved else None, "traffic": traffic,
                          "launches": attn_n, "avg_launch_ms": attn_ms / max(attn_n, 1),
                          "flop_per_launch": flop_per_launch},
+            # which level-2 attention kernel these weights got and why: the fast kernel needs the bound below 64
+            "attention_kernel": kname, "score_bound": model.query("score_bound_l2") if model is not None else None,
         }
-        if not args.no_cpu_baseline and world == 1:  # reported baseline: rank 0 at N=1 only
+        if not args.no_cpu_baseline and world == 1 and not args.dry_run:  # reported baseline: rank 0 at N=1 only
             line["cpu_baseline"] = cpu_baseline(res, 1, frames_per_sample, fwd // args.steps)
-        line["sampler_mode"] = "hipgraph" if args.graph else "eager"
+        line["sampler_mode"] = "dry-run (host plumbing only, nothing launched)" if args.dry_run else ("hipgraph" if sampler.use_graph else "eager")
+        if ranks_identical is not None:
+            line["ranks_bit_identical"] = ranks_identical
         if extras is not None:
             line["extra"] = extras
         print(json.dumps(line), flush=True)

@@ -91,6 +91,7 @@ class UViT3DPose(nn.Module):
         self._train_names = None     # parameter names in named_parameters() order (operator input order of the training form)
         self._trainer = None         # uvit_train.UViT3DPoseTrainer on this module's weights, built at the first training forward
         self._trainer_sig = None
+        self._train_stamp = 0        # counts training forwards: the autograd ctx of a forward remembers its number (ops._train_setup_context)
         self._dropout_generator: Optional[torch.Generator] = None  # set a CUDA generator to enable the MLP-branch nn.Dropout in train()
 
     # ------------------------------------------------------------------ module tree
@@ -155,6 +156,13 @@ class UViT3DPose(nn.Module):
 
     def set_option(self, key: str, value: int) -> None:
         capi.check(capi.lib.dfot_uvit_set_option(self._handle, key.encode(), int(value)))
+
+    def query(self, key: str) -> float:
+        """read-outs of the engine ("score_bound_l2", "attn_kernel_l2": include/dfot_hip.h); the weights are synced first"""
+        self.sync_weights()
+        val = C.c_double()
+        capi.check(capi.lib.dfot_uvit_query(self._handle, key.encode(), C.byref(val)))
+        return float(val.value)
 
     def attn_timing(self):
         """(total_ms, launches) of the level-2 attention launches recorded since set_option('time_attn', N)."""
@@ -252,13 +260,19 @@ class UViT3DPose(nn.Module):
         if drop is None and self.training and pdrop > 0:
             drop = torch.rand(x.shape[0], device=dev) < pdrop
         eng.dropout_generator = self._dropout_generator if self.training else None
+        self._train_stamp += 1  # this forward now owns the engine's saved activations (checked by the backward)
         with torch.no_grad():
             return eng.forward(x, noise_levels, external_cond, drop).to(x.dtype)
 
-    def _train_backward_impl(self, grad_out, params):
+    def _train_backward_impl(self, grad_out, params, stamp=None):
         eng = self._trainer
         if eng is None:
             raise RuntimeError("backward without a training forward")
+        if stamp is not None and stamp != self._train_stamp:
+            raise RuntimeError(
+                f"UViT3DPose: backward of training forward #{stamp}, but forward #{self._train_stamp} has run since and overwritten the "
+                "saved activations (one engine per module). Run backward after each forward (accumulate gradients as forward/backward "
+                "pairs); two forwards of one module inside one loss are not supported.")
         with torch.no_grad():
             grads = eng.backward(grad_out)
         return [grads[n].to(p.dtype).reshape(p.shape) if n in grads else torch.zeros_like(p) for n, p in zip(self._train_names, params)]

@@ -56,6 +56,7 @@ SIGNATURES = {
     "dfot_uvit_reserve": (_I, [_P, _I]),
     "dfot_uvit_workspace_bytes": (C.c_size_t, [_P]),
     "dfot_uvit_set_option": (_I, [_P, C.c_char_p, _I]),
+    "dfot_uvit_query": (_I, [_P, C.c_char_p, C.POINTER(C.c_double)]),
     "dfot_uvit_attn_timing": (_I, [_P, C.POINTER(C.c_double), C.POINTER(_L)]),
     "dfot_uvit_forward": (_I, [_P, _P, _P, _P, _P, _P, _I, _P]),
     "dfot_uvit_set_conditions": (_I, [_P, _P, _P, _I, _P]),

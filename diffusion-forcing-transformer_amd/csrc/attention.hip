@@ -221,8 +221,7 @@ __device__ __forceinline__ bf16x8 v2_bf16x8(v2_u32x2 lo, v2_u32x2 hi) {
 template <int D, int NST, int DQK = D, int DV = D, bool QRELOAD = false>
 __global__ __launch_bounds__(256, QRELOAD ? 4 : 1) void attn_kernel_v2(const bf16* __restrict__ Q, const bf16* __restrict__ K,
                                                       const bf16* __restrict__ V, bf16* __restrict__ O, long ldo, int N,
-                                                      int heads, int xcd, int ohs, int dvalid, float* __restrict__ lse, int full_tiles,
-                                                      int nsplit, float* __restrict__ part_o, float* __restrict__ part_ml) {
+                                                      int heads, int xcd, int ohs, int dvalid, float* __restrict__ lse) {
   static_assert(DQK % 16 == 0 && DV % 32 == 0 && DQK <= D && DV <= D, "head-dim sub-range");
   using C = AttnCfg<D>;
   constexpr float THR = 8.0f;
@@ -233,20 +232,9 @@ __global__ __launch_bounds__(256, QRELOAD ? 4 : 1) void attn_kernel_v2(const bf1
   const int lq = lane & 31, lh = lane >> 5;
   // 1-D grid, (batch*head)-major logical order handed out per XCD: the q-tiles of one head share K/V in one L2
   const int qtiles = N / 128;
-  // work item: a full query tile (whole key range) or one key segment of a left-over tile (balanced tail, as attention_v3.hip:
-  // the first `full_tiles` workgroups are whole rounds of the resident workgroups, the rest split the remaining tiles over the keys)
-  int lin, kt0 = 0, kt1 = N / C::KV, seg = -1;
-  if ((int)blockIdx.x < full_tiles) {
-    lin = xcd_remap(blockIdx.x, full_tiles, xcd & 1);
-  } else {
-    const int nseg = gridDim.x - full_tiles;
-    seg = xcd_remap(blockIdx.x - full_tiles, nseg, xcd & 1);
-    lin = full_tiles + seg / nsplit;
-    const int per = (N / C::KV) / nsplit;
-    kt0 = (seg % nsplit) * per;
-    kt1 = kt0 + per;
-    if (nsplit == 1) seg = -1;  // an unsplit left-over tile is a full tile
-  }
+  const int lin = xcd_remap(blockIdx.x, gridDim.x, xcd & 1);
+  constexpr int kt0 = 0;
+  const int kt1 = N / C::KV;
   const bool prio = (xcd & 2) != 0;  // A/B switch: raise the wave priority around the MFMA clusters
   const int bh = lin / qtiles;
   const long base = (long)bh * N * D;
@@ -441,21 +429,6 @@ __global__ __launch_bounds__(256, QRELOAD ? 4 : 1) void attn_kernel_v2(const bf1
   }
 
   const float l_tot = l_i + __shfl_xor(l_i, 32);
-  if (seg >= 0) {  // key segment: fp32 partial (O, m, l) for attn_merge_rows_kernel
-    const int rloc = wave * 32 + lq;
-    float* prow = part_o + ((long)seg * 128 + rloc) * D;
-#pragma unroll
-    for (int dvt = 0; dvt < DV / 32; ++dvt)
-#pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {
-        f32x4 o4;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) o4[j] = oacc[dvt][4 * g4 + j];
-        *reinterpret_cast<f32x4*>(prow + dvt * 32 + 8 * g4 + 4 * lh) = o4;
-      }
-    if (lh == 0) *reinterpret_cast<float2*>(part_ml + ((long)seg * 128 + rloc) * 2) = make_float2(m_run, l_tot);
-    return;
-  }
   const float inv = 1.0f / l_tot;
   const int b = bh / heads, hd = bh % heads;
   if (lse && lh == 0) lse[(long)bh * N + q0 + lq] = m_run + __log2f(l_tot);  // training: log2-domain log-sum-exp per query
@@ -472,62 +445,6 @@ __global__ __launch_bounds__(256, QRELOAD ? 4 : 1) void attn_kernel_v2(const bf1
     }
 }
 
-// combine the key segments of the left-over tiles of attn_kernel_v2: O = sum_s 2^(m_s - M) O_s / sum_s 2^(m_s - M) l_s (and the
-// log-sum-exp M + log2 l).  One thread per (query row, 4 columns), D / 4 threads per row; columns >= dvalid are not touched.
-template <int D>
-__global__ __launch_bounds__(256) void attn_merge_rows_kernel(const float* __restrict__ part_o, const float* __restrict__ part_ml,
-                                                              bf16* __restrict__ O, long ldo, int N, int heads, int ohs, int dvalid,
-                                                              int full_tiles, int nsplit, int rem_tiles, float* __restrict__ lse) {
-  constexpr int TPR = D / 4, QR = 128;
-  const long gid = (long)blockIdx.x * 256 + threadIdx.x;
-  const long row = gid / TPR;
-  const int c4 = (int)(gid % TPR) * 4;
-  if (row >= (long)rem_tiles * QR) return;
-  const int lt = (int)(row / QR), rloc = (int)(row % QR);
-  const int qtiles = N / QR;
-  float mmax = -INFINITY;
-  for (int s = 0; s < nsplit; ++s) mmax = fmaxf(mmax, part_ml[((long)(lt * nsplit + s) * QR + rloc) * 2]);
-  float acc[4] = {0.f, 0.f, 0.f, 0.f}, l = 0.f;
-  for (int s = 0; s < nsplit; ++s) {
-    const long pr = (long)(lt * nsplit + s) * QR + rloc;
-    const float w = exp2f(part_ml[pr * 2] - mmax);
-    l += w * part_ml[pr * 2 + 1];
-    if (c4 < dvalid) {
-      const f32x4 o = *reinterpret_cast<const f32x4*>(part_o + pr * D + c4);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[j] += w * o[j];
-    }
-  }
-  const float inv = 1.0f / l;
-  const int tile = full_tiles + lt;
-  const int bh = tile / qtiles, b = bh / heads, hd = bh % heads;
-  const int qrow = (tile % qtiles) * QR + rloc;
-  if (lse && c4 == 0) lse[(long)bh * N + qrow] = mmax + __log2f(l);
-  if (c4 >= dvalid) return;
-  bf16x4 o4;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) o4[j] = f2bf(acc[j] * inv);
-  *reinterpret_cast<bf16x4*>(O + ((long)b * N + qrow) * ldo + hd * ohs + c4) = o4;
-}
-
-// Balanced tail of the 128-row kernel (d = 128 rows only: 64 KiB of LDS and 180-220 VGPRs hold two workgroups per CU) -- an A/B
-// experiment, OFF by default (DFOT_ATTN_V2_SPLIT=1).  T tiles: T >= 2 * #CU: whole rounds of 2 * #CU workgroups, the left-over
-// tiles split over the keys (Kinetics-600 DiT3D: 1280 tiles = 2.5 rounds); #CU < T < 2 * #CU: one workgroup per CU takes a whole
-// tile and the T - #CU others are split to fill the second slot of every CU (RE10K level 3 at model batch 2: 288 tiles -> 256 +
-// 32 x 8 segments).  Measured (same box): level 3 at batch 2 62.4 -> 65.4 us, at batch 8 198.7 -> 190.1 us, Kinetics-600 65.4 ->
-// 64.1 latent frames/s, RE10K 8f 9.50 -> 9.47 frames/s: workgroups of this kernel do not finish in lock-step rounds, so the
-// dispatcher already evens most of the tail out and the partials + merge launch cost what is left of it.
-static AttnSplit plan_split_v2(int batch, int heads, int n) {
-  static const int enabled = tuning_flag("ATTN_V2_SPLIT", 0);
-  const int tiles = batch * heads * (n / 128);
-  const AttnSplit none{tiles, tiles, 0, 1};
-  if (!enabled) return none;
-  AttnSplit sp = attn_plan_split(batch, heads, n, 128, 2);          // rounds of two workgroups per CU
-  if (sp.full == 0) sp = attn_plan_split(batch, heads, n, 128, 1);  // less than one such round: one whole tile per CU + segments
-  if (sp.full == 0 || sp.nsplit == 1) return none;
-  return sp;
-}
-
 template <int D, int NST, int DQK = D, int DV = D, bool QRELOAD = false>
 static int launch_attn_v2(const bf16* q, const bf16* k, const bf16* v, bf16* o, long ldo, int batch, int heads, int n,
                           hipStream_t stream, int ohs = D, int dvalid = D, float* lse = nullptr) {
@@ -540,22 +457,8 @@ static int launch_attn_v2(const bf16* q, const bf16* k, const bf16* v, bf16* o, 
     attr_set = true;
   }
   const int tiles = (n / 128) * batch * heads;
-  AttnSplit sp{tiles, tiles, 0, 1};
-  float *po = nullptr, *pml = nullptr;
-  if constexpr (D == 128 && !QRELOAD) {
-    sp = plan_split_v2(batch, heads, n);
-    int rc = attn_partials(sp, 128, &po, &pml, D);
-    if (rc) return rc;
-  }
-  hipLaunchKernelGGL(kern, dim3(sp.full + sp.rem * sp.nsplit), dim3(256), lds, stream, q, k, v, o, ldo, n, heads, xcd_flag, ohs, dvalid, lse,
-                     sp.full + (sp.nsplit == 1 ? sp.rem : 0), sp.nsplit, po, pml);
+  hipLaunchKernelGGL(kern, dim3(tiles), dim3(256), lds, stream, q, k, v, o, ldo, n, heads, xcd_flag, ohs, dvalid, lse);
   DFOT_CHECK_HIP(hipGetLastError());
-  if (sp.nsplit > 1) {
-    const long threads = (long)sp.rem * 128 * (D / 4);
-    hipLaunchKernelGGL(attn_merge_rows_kernel<D>, dim3(cdiv(threads, 256)), dim3(256), 0, stream, po, pml, o, ldo, n, heads, ohs, dvalid, sp.full,
-                       sp.nsplit, sp.rem, lse);
-    DFOT_CHECK_HIP(hipGetLastError());
-  }
   return DFOT_OK;
 }
 
@@ -575,21 +478,16 @@ static int launch_attn_t(const bf16* q, const bf16* k, const bf16* v, bf16* o, l
 }
 
 int launch_attention(const bf16* q, const bf16* k, const bf16* v, bf16* o, long ldo, int batch, int heads, int n, int d,
-                     int variant, hipStream_t stream) {
+                     int variant, hipStream_t stream, AttnScratch* scratch) {
   DFOT_REQUIRE(q && k && v && o, DFOT_ERR_ARG, "attention: null pointer");
   DFOT_REQUIRE(d == 64 || d == 128, DFOT_ERR_SHAPE, "attention: head dim %d not in {64,128}", d);
   DFOT_REQUIRE(n > 0 && n % 128 == 0, DFOT_ERR_SHAPE, "attention: N=%d must be a multiple of 128", n);
   DFOT_REQUIRE(ldo % 4 == 0, DFOT_ERR_SHAPE, "attention: output row stride %ld must be a multiple of 4", ldo);
   if ((variant == 5 || variant == 6) && d == 64 && n % 256 == 0)  // 64 query rows per wave, balanced tail; 6: no running max
-    return launch_attention_v3(q, k, v, o, ldo, batch, heads, n, variant == 6, stream);
-  if (variant >= 7 && variant <= 12 && d == 64 && n % 512 == 0)  // 8-wave ping-pong, no running max; odd: priority raised in MFMA phases
-    return launch_attention_pp(q, k, v, o, ldo, batch, heads, n, (variant & 1) | (((variant - 7) >> 1) << 1), stream);
-  if (variant == 14 && d == 64 && n % 256 == 0) return launch_attention_v5(q, k, v, o, ldo, batch, heads, n, stream);  // pipelined, no running max
-  if ((variant >= 5 && variant <= 12) || variant == 14) variant = 2;
+    return launch_attention_v3(q, k, v, o, ldo, batch, heads, n, variant == 6, stream, scratch);
+  if (variant == 14 && d == 64 && n % 256 == 0) return launch_attention_v5(q, k, v, o, ldo, batch, heads, n, stream, scratch);  // pipelined, no running max
+  if (variant == 5 || variant == 6 || variant == 14) variant = 2;
   if (variant == 2) {  // tuned kernel; K/V ring depth chosen by measurement: 3 stages (48 KiB) at d = 64, 2 stages at d = 128
-    static const int rows64 = tuning_flag("ATTN_ROWS64_D128", 0);  // see launch_attention_padded
-    if (d == 128 && rows64 && n % 256 == 0 && (long)batch * heads * (n / 256) >= 256)
-      return launch_attention_rows64_d128(q, k, v, o, ldo, batch, heads, n, d, nullptr, stream);
     return d == 64 ? launch_attn_v2<64, 3>(q, k, v, o, ldo, batch, heads, n, stream)
                    : launch_attn_v2<128, 2>(q, k, v, o, ldo, batch, heads, n, stream);
   }
@@ -609,13 +507,6 @@ int launch_attention(const bf16* q, const bf16* k, const bf16* v, bf16* o, long 
                       : launch_attn_t<128, true>(q, k, v, o, ldo, batch, heads, n, stream);
 }
 
-// pre-size the partial-output scratch of the balanced tail for a launch shape (no reallocation inside a timed / captured region)
-int attention_v2_reserve(int batch, int heads, int n, int d) {
-  if (d <= 64 || n % 128 != 0) return DFOT_OK;
-  float *a, *b;
-  return attn_partials(plan_split_v2(batch, heads, n), 128, &a, &b, 128);
-}
-
 // Attention over q/k/v stored [B][heads][N][dstride] with a logical head dim d <= dstride (dstride = 64 or 128, pad
 // columns zero); the output is compact: O[row][head*d + c], c < d.  Used by the DiT blocks (d = 72).
 int attention_dstride(int d) { return d <= 64 ? 64 : 128; }
@@ -627,12 +518,6 @@ int launch_attention_padded(const bf16* q, const bf16* k, const bf16* v, bf16* o
   DFOT_REQUIRE(ldo % 4 == 0, DFOT_ERR_SHAPE, "attention: output row stride %ld must be a multiple of 4", ldo);
   if (d <= 32) return launch_attn_v2<64, 3, 32, 32>(q, k, v, o, ldo, batch, heads, n, stream, d, d, lse);
   if (d <= 64) return launch_attn_v2<64, 3>(q, k, v, o, ldo, batch, heads, n, stream, d, d, lse);
-  // A/B experiment, off by default (DFOT_ATTN_ROWS64_D128=1): 64 query rows per wave (attention_v3d.hip) where the launch has at least
-  // one full round of 256-row tiles.  Half the LDS bytes per FLOP, but its ~300-360 VGPRs leave ONE wave per SIMD and the loop is not
-  // software-pipelined: 225 vs 207 us at B*H = 72, N = 2048, d = 128; Kinetics-600 DiT3D 60.3 vs 63.1 latent frames/s (same box)
-  static const int rows64 = tuning_flag("ATTN_ROWS64_D128", 0);
-  if (rows64 && n % 256 == 0 && (long)batch * heads * (n / 256) >= 256)
-    return launch_attention_rows64_d128(q, k, v, o, ldo, batch, heads, n, d, lse, stream);
   if (d <= 80) return launch_attn_v2<128, 2, 80, 96>(q, k, v, o, ldo, batch, heads, n, stream, d, d, lse);
   if (d <= 96) return launch_attn_v2<128, 2, 96, 96>(q, k, v, o, ldo, batch, heads, n, stream, d, d, lse);
   return launch_attn_v2<128, 2>(q, k, v, o, ldo, batch, heads, n, stream, d, d, lse);

@@ -312,23 +312,6 @@ __global__ __launch_bounds__(256) void attn64_merge_kernel(const float* __restri
   *reinterpret_cast<bf16x4*>(O + ((long)b * N + (tile % qtiles) * qrows + rloc) * ldo + hd * ohs + c4) = o4;
 }
 
-// grow-only scratch for the segment partials (sized by the first call of a shape; attention_v3_reserve pre-sizes it)
-float* g_part = nullptr;
-size_t g_part_bytes = 0;
-
-int ensure_partials(size_t bytes) {
-  if (bytes <= g_part_bytes) return DFOT_OK;
-  if (g_part) {
-    DFOT_CHECK_HIP(hipDeviceSynchronize());
-    DFOT_CHECK_HIP(hipFree(g_part));
-    g_part = nullptr;
-    g_part_bytes = 0;
-  }
-  DFOT_CHECK_HIP(hipMalloc(&g_part, bytes));
-  g_part_bytes = bytes;
-  return DFOT_OK;
-}
-
 }  // namespace
 
 // wgs_per_cu workgroups of qrows query rows are resident per CU (registers: 2 waves per SIMD)
@@ -354,15 +337,40 @@ AttnSplit attn_plan_split(int batch, int heads, int n, int qrows, int wgs_per_cu
   return sp;
 }
 
-// dcols: floats per partial output row (64; 128 for the 128-element-row kernels of attention_v3d.hip)
-int attn_partials(const AttnSplit& sp, int qrows, float** po, float** pml, int dcols) {
+// Process-wide scratch of the op-level entry points (dfot_op_attention, tools): it only ever GROWS by allocating a new block; the
+// blocks it outgrows are kept until the process ends, so a kernel in flight or a captured graph that holds an old pointer stays
+// valid (nothing is freed or synchronised on a launch path).  Backbone handles do not use it: they own an AttnScratch sized in
+// their reserve() and pass it in, so two handles / streams never share partial rows and a reserve on one model cannot pull the
+// buffer from under another model's captured graph.
+AttnScratch* attention_default_scratch() {
+  static AttnScratch g;
+  return &g;
+}
+
+size_t attention_scratch_bytes(int batch, int heads, int n, int d) {
+  if (d != 64 || n % QROWS != 0) return 0;  // only the 64-rows-per-wave level-2 kernels (attention_v3 / v5) split their tail
+  const AttnSplit sp = attn_plan_split(batch, heads, n, QROWS, 2);
+  return sp.nsplit == 1 ? 0 : (size_t)sp.rem * sp.nsplit * QROWS * (D + 2) * sizeof(float);
+}
+
+int attn_partials(const AttnSplit& sp, int qrows, float** po, float** pml, AttnScratch* scratch) {
   *po = *pml = nullptr;
   if (sp.nsplit == 1) return DFOT_OK;
   const size_t rows = (size_t)sp.rem * sp.nsplit * qrows;
-  int rc = ensure_partials(rows * (dcols + 2) * sizeof(float));
-  if (rc) return rc;
-  *po = g_part;
-  *pml = g_part + rows * dcols;
+  const size_t bytes = rows * (D + 2) * sizeof(float);
+  if (!scratch) {
+    scratch = attention_default_scratch();
+    if (bytes > scratch->bytes) {  // grow: a NEW block; the old one is deliberately leaked (see above)
+      void* p = nullptr;
+      DFOT_CHECK_HIP(hipMalloc(&p, bytes));
+      scratch->p = reinterpret_cast<float*>(p);
+      scratch->bytes = bytes;
+    }
+  }
+  DFOT_REQUIRE(scratch->p && bytes <= scratch->bytes, DFOT_ERR_STATE,
+               "attention: key-split scratch of %zu bytes, launch needs %zu (reserve the handle for this batch first)", scratch->bytes, bytes);
+  *po = scratch->p;
+  *pml = scratch->p + rows * D;
   return DFOT_OK;
 }
 
@@ -376,24 +384,16 @@ int attn_launch_merge(const AttnSplit& sp, int qrows, const float* po, const flo
   return DFOT_OK;
 }
 
-int attention_v3_reserve(int batch, int heads, int n) {
-  float *a, *b;
-  int rc = DFOT_OK;
-  if (n % QROWS == 0) rc = attn_partials(attn_plan_split(batch, heads, n, QROWS, 2), QROWS, &a, &b);
-  if (!rc && n % 512 == 0) rc = attn_partials(attn_plan_split(batch, heads, n, 512, 1), 512, &a, &b);
-  return rc;
-}
-
 // q, k, v: [B][heads][N][64] bf16, q pre-scaled by log2(e)/sqrt(d); o: row r of batch b, head hd at o[(b*N + r)*ldo + hd*64].
 // nomax: the caller guarantees bounded scores (see the header of this file).
 int launch_attention_v3(const bf16* q, const bf16* k, const bf16* v, bf16* o, long ldo, int batch, int heads, int n, bool nomax,
-                        hipStream_t stream) {
+                        hipStream_t stream, AttnScratch* scratch) {
   DFOT_REQUIRE(q && k && v && o, DFOT_ERR_ARG, "attention: null pointer");
   DFOT_REQUIRE(n > 0 && n % QROWS == 0, DFOT_ERR_SHAPE, "attention v3: N=%d must be a multiple of %d", n, QROWS);
   DFOT_REQUIRE(ldo % 4 == 0, DFOT_ERR_SHAPE, "attention: output row stride %ld must be a multiple of 4", ldo);
   const AttnSplit sp = attn_plan_split(batch, heads, n, QROWS, 2);
   float *po = nullptr, *pml = nullptr;
-  int rc0 = attn_partials(sp, QROWS, &po, &pml);
+  int rc0 = attn_partials(sp, QROWS, &po, &pml, scratch);
   if (rc0) return rc0;
   const int lds = 2 * 3 * TILE;
   const int grid = sp.full + sp.rem * sp.nsplit;

@@ -327,13 +327,14 @@ __global__ __launch_bounds__(256, 2) void attn64_kernel_v5(const bf16* __restric
 
 }  // namespace
 
-int launch_attention_v5(const bf16* q, const bf16* k, const bf16* v, bf16* o, long ldo, int batch, int heads, int n, hipStream_t stream, int vpm) {
+int launch_attention_v5(const bf16* q, const bf16* k, const bf16* v, bf16* o, long ldo, int batch, int heads, int n, hipStream_t stream,
+                        AttnScratch* scratch) {
   DFOT_REQUIRE(q && k && v && o, DFOT_ERR_ARG, "attention: null pointer");
   DFOT_REQUIRE(n > 0 && n % QROWS == 0, DFOT_ERR_SHAPE, "attention v5: N=%d must be a multiple of %d", n, QROWS);
   DFOT_REQUIRE(ldo % 4 == 0, DFOT_ERR_SHAPE, "attention: output row stride %ld must be a multiple of 4", ldo);
   const AttnSplit sp = attn_plan_split(batch, heads, n, QROWS, 2);
   float *po = nullptr, *pml = nullptr;
-  int rc = attn_partials(sp, QROWS, &po, &pml);
+  int rc = attn_partials(sp, QROWS, &po, &pml, scratch);
   if (rc) return rc;
   const int lds = 2 * 3 * TILE;
   auto go = [&](auto kern) -> int {
@@ -346,8 +347,6 @@ int launch_attention_v5(const bf16* q, const bf16* k, const bf16* v, bf16* o, lo
     DFOT_CHECK_HIP(hipGetLastError());
     return DFOT_OK;
   };
-  // the requested interleave ratio made no measurable difference (2..5 vector instructions per MFMA: 276-279 us); 4 and 5 spill 3 VGPRs
-  (void)vpm;
   rc = go(attn64_kernel_v5<3>);
   if (rc) return rc;
   return attn_launch_merge(sp, QROWS, po, pml, o, ldo, n, heads, stream);

@@ -872,11 +872,6 @@ int dfot_dit_reserve(dfot_dit_t h, int max_batch) {
     if ((rc = dit_alloc(h, &h->Z, frames * c.embed_col_dim * 3 * c.hidden_size, true))) return rc;
     if ((rc = dit_alloc(h, &h->idx, frames, true))) return rc;
   }
-  // partial-output scratch of the attention kernel's balanced tail, for every batch up to max_batch (full model: one sequence of
-  // max_tokens * P tokens per video)
-  if (c.variant == 0)
-    for (int b = 1; b <= max_batch; ++b)
-      if ((rc = attention_v2_reserve(b, c.num_heads, c.max_tokens * h->P, h->d))) return rc;
   h->max_batch = max_batch;
   return DFOT_OK;
 }

@@ -12,6 +12,7 @@ struct GemmArgs {
   const bf16* A = nullptr;
   long lda = 0;
   const bf16* W = nullptr;  // [N][K] bf16 (torch Linear layout; conv: [Cout][tap][Cin])
+  long ldw = 0;             // dense A: row stride of W in elements (0 = K); > K when the GEMM contracts a K sub-range of a wider matrix
   int M = 0, N = 0, K = 0;
   int H = 0, Wd = 0, Cin = 0;
   const bf16* zeros = nullptr;  // >= 128 B of zeros (conv padding source)
@@ -27,7 +28,7 @@ struct GemmArgs {
   const int* gate_index = nullptr;
   long ldg = 0;
   int gate_rows = 0;
-  int act = 0;  // E_BF16: 0 = none, 1 = GELU(tanh approximation) applied before the bf16 store
+  int act = 0;  // E_BF16: 0 = none, 1 = GELU(tanh approximation), 2 = SiLU applied before the bf16 store
   bf16* pre_act = nullptr;  // E_BF16 with act: optional second output, the value BEFORE the activation (training keeps both)
   int bias_rows = 0;  // E_F32 / E_BF16: > 0 = two-dimensional bias[(row % bias_rows)][N] (MatrixAttention), else bias[N]
   // E_BF16: tr_rows = R > 0 stores the result transposed inside consecutive groups of R rows ("frames"):
@@ -76,10 +77,6 @@ enum GemmVariant {
   GEMM_DMA_128_KS2 = 8,  // 128x128 tile, 8 waves: two k-groups alternate k-tiles (intra-workgroup split-K)
   GEMM_DMA_256x192 = 9,  // 256x192 tile (12 waves), 2 stages, dense A only: N = multiples of 192 (1152, 3456) without padding
   GEMM_DMA_128x192 = 10,  // 128x192 tile (6 waves), 2 stages, dense A: long-K GEMMs with slightly more 128x128 tiles than CUs
-  // 256x256 tile, K-tiles of 32, 4-stage ring with counted vmcnt (three prefetches in flight), dense A.  A/B experiment:
-  // 6-15 % SLOWER than the two-stage BK = 64 loop on every model shape (twice the barriers per K), never auto-picked
-  GEMM_DMA4_256x256_BK32 = 11,
-  GEMM_DMA4_256x256_W128_BK32 = 12,  // as 11 with 8 waves of 128x64 (42.7 FLOP per LDS byte, 2 waves per SIMD): equal to variant 7, slower than 4
   // 256x144 tile (12 waves of 64x48), 2 stages, dense A, plain epilogues: N = multiples of 144 (576, 1152) give M/256 x N/144 tiles =
   // exactly one per CU for the level-2 out-projection (256) and, with two K slices, for the level-3 one (128 x 2)
   GEMM_DMA_256x144 = 13,

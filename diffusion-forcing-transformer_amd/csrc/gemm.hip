@@ -125,7 +125,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int tile_inde
     const int c = ppos ^ swz(r);
     int n = n0 + r;
     n = n < g.N ? n : g.N - 1;
-    w_src[i] = g.W + (long)n * g.K + c * 8 + kbeg;
+    w_src[i] = g.W + (long)n * (AMODE == A_DENSE && g.ldw ? g.ldw : (long)g.K) + c * 8 + kbeg;
   }
 
   // conv3x3: k-tile kt covers channels [cv_c0, cv_c0 + BKT) of tap (cv_dy, cv_dx).  issue() is called with consecutive k-tiles
@@ -427,12 +427,13 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int tile_inde
             }
         }
         if (live) {
+          const bool silu = g.act == 2;  // SiLU (the MLP half of fused_attn_mlp_proj when it runs as its own GEMM), applied at the conversion
 #pragma unroll
           for (int p = 0; p < 2; ++p) {
             const int r = p * 8 + (lane >> 3);
             bf16x8 o;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] = f2bf(vals[p][j]);
+            for (int j = 0; j < 8; ++j) o[j] = f2bf(silu ? silu_f(vals[p][j]) : vals[p][j]);
             *reinterpret_cast<bf16x8*>(g.out_bf16 + (mw + r) * g.ldo + col) = o;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {  // GroupNorm statistics of the values as stored (bf16-rounded)
@@ -674,15 +675,6 @@ static int launch_v(int variant, const GemmArgs& g, hipStream_t s) {
         if (g.gn_part) break;
         return launch_t<256, 144, 64, 2, AMODE, EPI, true>(g, s);
       }
-    case GEMM_DMA4_256x256_BK32:
-      if constexpr (AMODE != A_DENSE) break;
-      else return launch_t<256, 256, 64, 4, AMODE, EPI, true, 1, 32>(g, s);
-    case GEMM_DMA4_256x256_W128_BK32:
-      if constexpr (AMODE != A_DENSE) break;
-      else {
-        if (g.gn_part) break;
-        return launch_t<256, 256, 128, 4, AMODE, EPI, true, 1, 32>(g, s);
-      }
     case GEMM_DMA_128x192:
       if constexpr (AMODE != A_DENSE || EPI == E_QKV) break;
       else return launch_t<128, 192, 64, 2, AMODE, EPI, true>(g, s);
@@ -734,19 +726,20 @@ int launch_gemm(int amode, int epi, int variant, const GemmArgs& g, hipStream_t 
   if (variant == GEMM_DMA_128_KS2 && epi == E_QKV) variant = GEMM_DMA_128;  // the QKV epilogue has workgroup barriers
   if (variant == GEMM_DMA_128x192 && epi == E_QKV) variant = GEMM_DMA_128;
   if (variant == GEMM_DMA_256x192 && epi == E_QKV) variant = GEMM_DMA_256x256;  // its head pairing needs 128-aligned tiles
-  const int bm = variant == GEMM_DMA_512x128 ? 512 : (variant == GEMM_DMA3_256 || variant == GEMM_DMA_256x256 || variant == GEMM_DMA_256x128 || variant == GEMM_DMA_256x256_W128 || variant == GEMM_DMA_256x192 || variant == GEMM_DMA4_256x256_BK32 || variant == GEMM_DMA4_256x256_W128_BK32 || variant == GEMM_DMA_256x144) ? 256 : 128;
+  const int bm = variant == GEMM_DMA_512x128 ? 512 : (variant == GEMM_DMA3_256 || variant == GEMM_DMA_256x256 || variant == GEMM_DMA_256x128 || variant == GEMM_DMA_256x256_W128 || variant == GEMM_DMA_256x192 || variant == GEMM_DMA_256x144) ? 256 : 128;
   DFOT_REQUIRE(g.M > 0 && g.M % bm == 0, DFOT_ERR_SHAPE, "gemm: M=%d must be a positive multiple of %d", g.M, bm);
   DFOT_REQUIRE(g.K > 0 && g.K % BK == 0, DFOT_ERR_SHAPE, "gemm: K=%d must be a positive multiple of %d", g.K, BK);
   DFOT_REQUIRE(g.N > 0 && g.N % (epi == E_F32 ? 4 : 8) == 0, DFOT_ERR_SHAPE, "gemm: N=%d must be a multiple of %d", g.N, epi == E_F32 ? 4 : 8);
   DFOT_REQUIRE((epi == E_QKV || epi == E_QKV_DIT || g.ldo % (epi == E_F32 ? 4 : 8) == 0) && (epi != E_QKV || (g.ldo2 % 8 == 0 && g.split % 64 == 0)),
                DFOT_ERR_SHAPE, "gemm: output row strides must be multiples of %d", epi == E_F32 ? 4 : 8);
+  DFOT_REQUIRE(g.ldw == 0 || (amode == A_DENSE && g.ldw >= g.K && g.ldw % 8 == 0), DFOT_ERR_SHAPE, "gemm: ldw=%ld must be >= K and a multiple of 8 (dense A only)", g.ldw);
   if (amode == A_CONV3) {
     DFOT_REQUIRE(g.Cin % BK == 0 && g.K == 9 * g.Cin, DFOT_ERR_SHAPE, "conv3x3: Cin=%d must be a multiple of %d", g.Cin, BK);
     DFOT_REQUIRE(g.zeros != nullptr, DFOT_ERR_ARG, "conv3x3: zero page missing");
     DFOT_REQUIRE(g.H > 0 && g.Wd > 0 && g.M % (g.H * g.Wd) == 0, DFOT_ERR_SHAPE, "conv3x3: M=%d not a whole number of %dx%d images", g.M, g.H, g.Wd);
   }
   if (epi == E_QKV) {
-    DFOT_REQUIRE(g.q && g.k && g.v && g.qw && g.kw && g.rope_cs && g.out2, DFOT_ERR_ARG, "qkv epilogue: null pointer");
+    DFOT_REQUIRE(g.q && g.k && g.v && g.qw && g.kw && g.rope_cs && (g.out2 || g.N == g.split), DFOT_ERR_ARG, "qkv epilogue: null pointer");
     DFOT_REQUIRE((g.d == 64 || g.d == 128) && g.heads > 0 && g.split == 3 * g.heads * g.d && g.ntok > 0 && g.M % g.ntok == 0,
                  DFOT_ERR_SHAPE, "qkv epilogue: heads=%d d=%d split=%d ntok=%d M=%d", g.heads, g.d, g.split, g.ntok, g.M);
   }

@@ -92,29 +92,27 @@ int launch_gather_f32(const float* src, float* dst, const int* map, int n, hipSt
 int launch_nhwc_to_nchw(const float* src, float* dst, int bt, int p, int c, hipStream_t s);
 int launch_bf16_nhwc_to_nchw(const bf16* src, float* dst, int bt, int p, int c, hipStream_t s);
 
+// fp32 partial rows (O | m, l) of the key-split tail of the level-2 attention kernels.  A backbone handle owns one, sized by
+// attention_scratch_bytes() in its reserve(); nullptr = the process-wide op-level scratch (grow-only, never freed: attention_v3.hip)
+struct AttnScratch {
+  float* p = nullptr;
+  size_t bytes = 0;
+};
+size_t attention_scratch_bytes(int batch, int heads, int n, int d);
 int launch_attention(const bf16* q, const bf16* k, const bf16* v, bf16* o, long ldo, int batch, int heads, int n, int d,
-                     int variant, hipStream_t stream);
+                     int variant, hipStream_t stream, AttnScratch* scratch = nullptr);
 // attention_v3.hip: d = 64, 64 query rows per wave, balanced tail (key-split left-over tiles + merge); nomax = caller bounds |score|
 int launch_attention_v3(const bf16* q, const bf16* k, const bf16* v, bf16* o, long ldo, int batch, int heads, int n, bool nomax,
-                        hipStream_t stream);
-int attention_v3_reserve(int batch, int heads, int n);
+                        hipStream_t stream, AttnScratch* scratch = nullptr);
 // attention_v5.hip: attention_v3's NOMAX kernel with the key loop software-pipelined at half-tile granularity inside each wave
 int launch_attention_v5(const bf16* q, const bf16* k, const bf16* v, bf16* o, long ldo, int batch, int heads, int n, hipStream_t stream,
-                        int vpm = 3);
-// attention_pp.hip: the same products as an 8-wave ping-pong (SIMD partners alternate MFMA and softmax phases); no running max
-int launch_attention_pp(const bf16* q, const bf16* k, const bf16* v, bf16* o, long ldo, int batch, int heads, int n, int flags,
-                        hipStream_t stream);
+                        AttnScratch* scratch = nullptr);
 // shared by the two: balanced tail (left-over query tiles split over the key axis) + merge of the fp32 partials
 struct AttnSplit {
   int tiles, full, rem, nsplit;
 };
 AttnSplit attn_plan_split(int batch, int heads, int n, int qrows, int wgs_per_cu);
-int attn_partials(const AttnSplit& sp, int qrows, float** po, float** pml, int dcols = 64);
-// 64 query rows per wave for head dims 65..128 in 128-element rows (attention_v3d.hip)
-int launch_attention_rows64_d128(const bf16* q, const bf16* k, const bf16* v, bf16* o, long ldo, int batch, int heads, int n, int d, float* lse,
-                                 hipStream_t stream);
-int attention_rows64_d128_reserve(int batch, int heads, int n);
-int attention_v2_reserve(int batch, int heads, int n, int d);  // partial-output scratch of attn_kernel_v2<128>'s balanced tail
+int attn_partials(const AttnSplit& sp, int qrows, float** po, float** pml, AttnScratch* scratch);
 int attn_launch_merge(const AttnSplit& sp, int qrows, const float* po, const float* pml, bf16* o, long ldo, int n, int heads,
                       hipStream_t stream);
 int attention_dstride(int d);

@@ -109,6 +109,7 @@ struct dfot_uvit_s {
   int cond_batch = 0;            // batch the pose caches were built for (0 = none)
   bf16 *acond = nullptr, *emb[4] = {nullptr, nullptr, nullptr, nullptr}, *s1 = nullptr, *hbf = nullptr,
        *cat = nullptr, *q = nullptr, *k = nullptr, *v = nullptr;
+  AttnScratch attn_scratch;   // key-split partials of the level-2 attention, owned by this handle (sized in reserve)
   float* out_part = nullptr;  // two fp32 partial slices of an out-projection (K split, see run_tr_block)
   size_t out_part_elems = 0;  // its capacity in floats: the split path is taken only when 2 * M * N fits
   // the slices of the last out-projection not yet added to X[pend_lvl] (pend_bias != nullptr): the next block's norm kernel adds
@@ -119,6 +120,12 @@ struct dfot_uvit_s {
   int last_batch = 0;
   int gemm_variant = GEMM_AUTO;
   int attn_variant = 2;
+  bool attn_force_safe = false;  // level-2 attention: always the running-max kernel (what weights with a bound >= 64 get)
+  // the block's two independent branches on two streams (run_tr_block_2s): bit 0 = level 3, bit 1 = level 2
+  int two_stream = 0;
+  hipStream_t side = nullptr;
+  std::vector<hipEvent_t> ev_sync;  // fork / join events, used round-robin
+  size_t ev_sync_next = 0;
   // optional in-run timing of the level-2 attention launches (HIP events on the launch stream)
   bool time_attn = false;
   std::vector<hipEvent_t> ev_start, ev_stop;
@@ -418,9 +425,14 @@ static int flush_pending(dfot_uvit_s* h, hipStream_t s) {
   return DFOT_OK;
 }
 
+static int run_tr_block_2s(dfot_uvit_s* h, const TrW& w, int lvl, int batch, hipStream_t s);
+
 static int run_tr_block(dfot_uvit_s* h, const TrW& w, int lvl, int batch, hipStream_t s) {
   const int c = w.c, rr = h->r[lvl], n = h->T * rr * rr, d = c / h->heads;
   const int m = batch * n;
+  if (((h->two_stream >> (3 - lvl)) & 1) && h->side && h->gemm_variant == GEMM_AUTO && h->out_part && (size_t)3 * m * c <= h->out_part_elems &&
+      m % 256 == 0)
+    return run_tr_block_2s(h, w, lvl, batch, s);
   float* x = h->X[lvl];
   int rc = 0;
   if (h->pend_bias && (h->pend_lvl != lvl || h->pend_m != m || h->pend_c != c) && (rc = flush_pending(h, s))) return rc;
@@ -440,8 +452,8 @@ static int run_tr_block(dfot_uvit_s* h, const TrW& w, int lvl, int batch, hipStr
   // default (2): level 2 (d = 64) runs the 64-rows-per-wave kernel with the balanced tail; without a running max when the
   // QK-norm weights bound the scores far inside the fp32 / bf16 exponent range (2^64 * N keys << 2^127), else with it
   int av = h->attn_variant;
-  if (av == 2 && d == 64 && n % 256 == 0) av = w.score_bound < 64.0f ? 14 : 5;  // 14: attention_v5.hip (software-pipelined, no running max)
-  if ((rc = launch_attention(h->q, h->k, h->v, h->cat, 5 * c, batch, h->heads, n, d, av, s))) return rc;
+  if (av == 2 && d == 64 && n % 256 == 0) av = (w.score_bound < 64.0f && !h->attn_force_safe) ? 14 : 5;  // 14: attention_v5.hip (software-pipelined, no running max)
+  if ((rc = launch_attention(h->q, h->k, h->v, h->cat, 5 * c, batch, h->heads, n, d, av, s, &h->attn_scratch))) return rc;
   if (timed) DFOT_CHECK_HIP(hipEventRecord(h->ev_stop[h->ev_used++], s));
   GemmArgs o;
   o.A = h->cat; o.lda = 5 * c; o.W = w.w_out; o.M = m; o.N = c; o.K = 5 * c; o.bias = w.b_out; o.out_f32 = x; o.resid = x;
@@ -474,6 +486,68 @@ static int run_tr_block(dfot_uvit_s* h, const TrW& w, int lvl, int batch, hipStr
     return defer ? DFOT_OK : flush_pending(h, s);
   }
   return launch_gemm(A_DENSE, E_F32, h->gemm_variant, o, s);
+}
+
+// The reference block is PARALLEL attention + MLP (u_vit_blocks.py:253-277: x + attn_out(attn(q, k, v)) + mlp_out(silu(mlp_h))): after the
+// shared norm the two branches are independent until the residual sum.  Two streams, forked / joined with events (parallel branches
+// of the graph under stream capture):
+//   s    : [q|k|v] columns of fused_attn_mlp_proj (QK-norm + RoPE epilogue) -> attention -> attn_out (K = C)    -> slice 0
+//   side : mlp_h columns (SiLU epilogue)                                     -> mlp_out (K = 4C, 1-2 K slices) -> slices 1..
+// and the slice sum + bias rides in the next block's norm kernel as before (flush_pending for every other reader).  At level 3 /
+// model batch 2 every kernel of the serial chain has 240-512 workgroups for 256 CUs and the 288-workgroup attention launch (one
+// workgroup per CU, latency-bound) owned an otherwise idle chip; with the fork its tail and the GEMMs' tails fill each other.
+static hipEvent_t next_event(dfot_uvit_s* h) { return h->ev_sync[h->ev_sync_next++ % h->ev_sync.size()]; }
+
+static int run_tr_block_2s(dfot_uvit_s* h, const TrW& w, int lvl, int batch, hipStream_t s) {
+  const int c = w.c, rr = h->r[lvl], n = h->T * rr * rr, d = c / h->heads;
+  const int m = batch * n;
+  float* x = h->X[lvl];
+  hipStream_t s2 = h->side;
+  int rc = 0;
+  if (h->pend_bias && (h->pend_lvl != lvl || h->pend_m != m || h->pend_c != c) && (rc = flush_pending(h, s))) return rc;
+  RmsPending pend{x, h->pend_bias, h->out_part, h->out_part + (long)m * c, h->pend_slices == 3 ? h->out_part + 2L * m * c : nullptr};
+  if ((rc = launch_rms_film(x, w.nw, w.fcache, h->sv + w.sv_off, h->have_mask ? h->cond_mask : nullptr, h->s1, m, c,
+                            rr * rr, h->T, h->cfg.eps, s, h->pend_bias ? &pend : nullptr)))
+    return rc;
+  h->pend_bias = nullptr;
+  hipEvent_t fork = next_event(h), join = next_event(h);
+  DFOT_CHECK_HIP(hipEventRecord(fork, s));
+  DFOT_CHECK_HIP(hipStreamWaitEvent(s2, fork, 0));
+  // ---- side stream: MLP branch
+  static const int mlp_slices_l3 = tuning_flag("UVIT_2S_MLP_SLICES_L3", 2), mlp_slices_l2 = tuning_flag("UVIT_2S_MLP_SLICES_L2", 1);
+  const int mlp_slices = lvl == 3 ? mlp_slices_l3 : mlp_slices_l2;
+  {
+    GemmArgs pm;
+    pm.A = h->s1; pm.lda = c; pm.W = w.w_fused + 3L * c * c; pm.M = m; pm.N = 4 * c; pm.K = c; pm.bias = w.b_fused + 3 * c;
+    pm.out_bf16 = h->cat + c; pm.ldo = 5 * c; pm.act = 2;
+    if ((rc = launch_gemm(A_DENSE, E_BF16, h->gemm_variant, pm, s2))) return rc;
+    GemmArgs om;
+    om.A = h->cat + c; om.lda = 5 * c; om.W = w.w_out + c; om.ldw = 5 * c; om.M = m; om.N = c; om.K = 4 * c;
+    om.out_f32 = h->out_part + (long)m * c; om.ldo = c; om.ksplit = mlp_slices; om.slice_stride = (long)m * c;
+    const int ov = (mlp_slices > 1 && h->gemm_variant == GEMM_AUTO) ? GEMM_DMA_256x256 : h->gemm_variant;
+    if ((rc = launch_gemm(A_DENSE, E_F32, ov, om, s2))) return rc;
+  }
+  DFOT_CHECK_HIP(hipEventRecord(join, s2));
+  // ---- main stream: attention branch
+  GemmArgs p;
+  p.A = h->s1; p.lda = c; p.W = w.w_fused; p.M = m; p.N = 3 * c; p.K = c; p.bias = w.b_fused;
+  p.split = 3 * c;
+  p.q = h->q; p.k = h->k; p.v = h->v; p.qw = w.qw; p.kw = w.kw; p.rope_cs = h->rope_cs[lvl]; p.heads = h->heads; p.d = d;
+  p.ntok = n; p.qscale = 1.4426950408889634f / sqrtf((float)d); p.eps = h->cfg.eps;
+  if ((rc = launch_gemm(A_DENSE, E_QKV, h->gemm_variant, p, s))) return rc;
+  const bool timed = h->time_attn && lvl == 2 && h->ev_used < h->ev_start.size();
+  if (timed) DFOT_CHECK_HIP(hipEventRecord(h->ev_start[h->ev_used], s));
+  int av = h->attn_variant;
+  if (av == 2 && d == 64 && n % 256 == 0) av = (w.score_bound < 64.0f && !h->attn_force_safe) ? 14 : 5;
+  if ((rc = launch_attention(h->q, h->k, h->v, h->cat, 5 * c, batch, h->heads, n, d, av, s, &h->attn_scratch))) return rc;
+  if (timed) DFOT_CHECK_HIP(hipEventRecord(h->ev_stop[h->ev_used++], s));
+  GemmArgs oa;
+  oa.A = h->cat; oa.lda = 5 * c; oa.W = w.w_out; oa.ldw = 5 * c; oa.M = m; oa.N = c; oa.K = c; oa.out_f32 = h->out_part; oa.ldo = c;
+  if ((rc = launch_gemm(A_DENSE, E_F32, h->gemm_variant, oa, s))) return rc;
+  DFOT_CHECK_HIP(hipStreamWaitEvent(s, join, 0));
+  h->pend_bias = w.b_out;
+  h->pend_lvl = lvl; h->pend_m = m; h->pend_c = c; h->pend_slices = 1 + mlp_slices;
+  return DFOT_OK;
 }
 
 static int run_down(dfot_uvit_s* h, int l, int bt, hipStream_t s) {
@@ -532,6 +606,16 @@ int dfot_uvit_create(const dfot_uvit_config* cfg, dfot_uvit_t* out) {
   DFOT_REQUIRE((cfg->max_tokens * r3 * r3) % 128 == 0, DFOT_ERR_SHAPE, "tokens at the coarsest level (%d) must be a multiple of 128", cfg->max_tokens * r3 * r3);
   auto* h = new dfot_uvit_s();
   h->cfg = *cfg;
+  h->two_stream = tuning_flag("UVIT_TWO_STREAM", 1);  // A/B: 0 = the serial chain on one stream; bit 0 = level 3, bit 1 = level 2
+  if (h->two_stream) {
+    if (hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess) h->side = nullptr;
+    for (int i = 0; h->side && i < 8; ++i) {
+      hipEvent_t e;
+      if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) break;
+      h->ev_sync.push_back(e);
+    }
+    if (h->ev_sync.size() < 8) h->two_stream = 0;
+  }
   int rc = build(h);
   if (rc) {
     dfot_uvit_destroy(h);
@@ -547,6 +631,8 @@ int dfot_uvit_destroy(dfot_uvit_t h) {
   for (void* p : h->ws_owned) (void)hipFree(p);
   for (hipEvent_t e : h->ev_start) (void)hipEventDestroy(e);
   for (hipEvent_t e : h->ev_stop) (void)hipEventDestroy(e);
+  for (hipEvent_t e : h->ev_sync) (void)hipEventDestroy(e);
+  if (h->side) (void)hipStreamDestroy(h->side);
   delete h;
   return DFOT_OK;
 }
@@ -600,9 +686,13 @@ int dfot_uvit_finalize(dfot_uvit_t h, void* stream) {
       qk.resize(2 * d);
       DFOT_CHECK_HIP(hipMemcpy(qk.data(), w.qw, d * sizeof(float), hipMemcpyDeviceToHost));
       DFOT_CHECK_HIP(hipMemcpy(qk.data() + d, w.kw, d * sizeof(float), hipMemcpyDeviceToHost));
-      float mq = 0.f, mk = 0.f;
-      for (int i = 0; i < d; ++i) mq = fmaxf(mq, fabsf(qk[i])), mk = fmaxf(mk, fabsf(qk[d + i]));
-      w.score_bound = sqrtf((float)d) * mq * mk * 1.4426950408889634f;
+      // |q.k| after the per-head RMSNorm (|x^|^2 = d) and the rotation of the pairs (2j, 2j+1): sum_j |q_j||k_j| with
+      // |q_j| <= a_j |x^q_j|, a_j = max(|w_q,2j|, |w_q,2j+1|) (b_j likewise) <= max_j(a_j b_j) |x^q||x^k| = max_j(a_j b_j) d:
+      // the largest PRODUCT over a rotary pair, not the product of the two maxima taken over all channels
+      float mqk = 0.f;
+      for (int i = 0; i + 1 < d; i += 2)
+        mqk = fmaxf(mqk, fmaxf(fabsf(qk[i]), fabsf(qk[i + 1])) * fmaxf(fabsf(qk[d + i]), fabsf(qk[d + i + 1])));
+      w.score_bound = sqrtf((float)d) * mqk * 1.4426950408889634f;
       if (!(w.score_bound == w.score_bound)) w.score_bound = INFINITY;  // NaN weights: keep the general kernel
     }
     return DFOT_OK;
@@ -621,6 +711,7 @@ int dfot_uvit_reserve(dfot_uvit_t h, int max_batch) {
   h->max_batch = 0;
   h->out_part = nullptr;
   h->out_part_elems = 0;
+  h->attn_scratch = AttnScratch{};
   const size_t bt = (size_t)max_batch * h->T;
   size_t pix[4];
   for (int l = 0; l < 4; ++l) pix[l] = (size_t)h->r[l] * h->r[l];
@@ -685,11 +776,13 @@ int dfot_uvit_reserve(dfot_uvit_t h, int max_batch) {
     h->out_part_elems = 3 * (e2 > e3 ? e2 : e3);
     if ((rc = dev_alloc(h, &h->out_part, h->out_part_elems, true))) return rc;
   }
-  // key-split partial buffers of the level-2 attention's balanced tail, for every batch this workspace can serve (so that
-  // nothing is allocated inside forward / stream capture)
-  for (int b = 1; b <= max_batch; ++b) {
-    if ((rc = attention_v3_reserve(b, h->heads, h->T * h->r[2] * h->r[2]))) return rc;
-    if ((rc = attention_v2_reserve(b, h->heads, h->T * h->r[3] * h->r[3], h->ch[3] / h->heads))) return rc;
+  // key-split partial buffers of the level-2 attention's balanced tail, large enough for every batch this workspace can serve:
+  // owned by the handle (nothing is allocated, freed or shared with another handle inside forward / stream capture)
+  {
+    size_t need = 16;
+    for (int b = 1; b <= max_batch; ++b) need = std::max(need, attention_scratch_bytes(b, h->heads, h->T * h->r[2] * h->r[2], h->ch[2] / h->heads));
+    if ((rc = dev_alloc(h, &h->attn_scratch.p, need / sizeof(float), true))) return rc;
+    h->attn_scratch.bytes = need;
   }
   h->max_batch = max_batch;
   return DFOT_OK;
@@ -716,6 +809,8 @@ int dfot_uvit_set_option(dfot_uvit_t h, const char* key, int value) {
   DFOT_REQUIRE(h && key, DFOT_ERR_ARG, "set_option: null argument");
   if (!strcmp(key, "gemm_variant")) h->gemm_variant = value;
   else if (!strcmp(key, "attn_variant")) h->attn_variant = value;
+  else if (!strcmp(key, "attn_force_safe")) h->attn_force_safe = value != 0;
+  else if (!strcmp(key, "two_stream")) h->two_stream = (h->side && h->ev_sync.size() >= 8) ? value : 0;
   else if (!strcmp(key, "time_attn")) {
     // value = number of launches to record (0 disables); events are created here, never inside forward
     h->time_attn = value > 0;
@@ -730,6 +825,21 @@ int dfot_uvit_set_option(dfot_uvit_t h, const char* key, int value) {
   }
   else {
     set_error("set_option: unknown key '%s'", key);
+    return DFOT_ERR_ARG;
+  }
+  return DFOT_OK;
+}
+
+int dfot_uvit_query(dfot_uvit_t h, const char* key, double* value) {
+  DFOT_REQUIRE(h && key && value, DFOT_ERR_ARG, "query: null argument");
+  DFOT_REQUIRE(h->finalized, DFOT_ERR_STATE, "query: weights not finalized");
+  float bound = 0.f;
+  for (const TrW& w : h->down_tr) bound = fmaxf(bound, w.score_bound);
+  for (const TrW& w : h->up_tr) bound = fmaxf(bound, w.score_bound);
+  if (!strcmp(key, "score_bound_l2")) *value = bound;
+  else if (!strcmp(key, "attn_kernel_l2")) *value = (bound < 64.0f && !h->attn_force_safe) ? 14 : 5;
+  else {
+    set_error("query: unknown key '%s'", key);
     return DFOT_ERR_ARG;
   }
   return DFOT_OK;

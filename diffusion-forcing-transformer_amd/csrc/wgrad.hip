@@ -417,13 +417,7 @@ int launch_wgrad_conv_taps(const bf16* dy, const bf16* x, float* out, int co, in
   DFOT_REQUIRE(dy && x && out && co % 8 == 0 && ci % 8 == 0 && pix % 64 == 0 && pix < (1L << 31) && slices >= 1 && slices <= pix / 64 && img_h > 0 && img_w > 0 &&
                    pix % ((long)img_h * img_w) == 0,
                DFOT_ERR_SHAPE, "wgrad_conv_taps: %d -> %d channels, %ld pixels unsupported", ci, co, pix);
-  // A/B (off): 32-row K tiles, four resident workgroups per CU.  No gain (273.5 ms/step either way): the 128-channel convolution's
-  // weight gradient is bound by operand traffic, not occupancy -- 128 x 128 tiles read both operands once per tap, 4.7 GB per call
-  // through L2 at 6.7 TB/s (MFMA utilisation 0.18); sharing one dy tile between taps (128 x 256 tiles) is the remaining lever
-  static const int kt32 = tuning_flag("WGRAD_CONV_KT32", 0);
-  if (co <= 128 && ci <= 128)
-    return kt32 ? launch_big<2, 2, true, 32>(dy, co, x, ci, out, co, ci, pix, slices, s, img_h, img_w)
-                : launch_big<2, 2, true>(dy, co, x, ci, out, co, ci, pix, slices, s, img_h, img_w);
+  if (co <= 128 && ci <= 128) return launch_big<2, 2, true>(dy, co, x, ci, out, co, ci, pix, slices, s, img_h, img_w);
   return launch_big<4, 4, true>(dy, co, x, ci, out, co, ci, pix, slices, s, img_h, img_w);
 }
 // workgroups per tap and slice of launch_wgrad_conv_taps, and the workgroup count to aim for with K slices (two rounds of the

@@ -68,6 +68,7 @@ class DiT3D(nn.Module):
         self._ctor = dict(max_tokens=int(max_tokens), timesteps=int(timesteps))
         self._trainer = None
         self._trainer_sig = None
+        self._train_stamp = 0  # counts training forwards (see backbone.UViT3DPose._train_backward_impl)
         self._train_names = [n for n, _ in self.named_parameters()]
 
     def _configure(self, c: "capi.DiTConfig", cfg, max_tokens: int) -> None:
@@ -209,13 +210,18 @@ class DiT3D(nn.Module):
         if dev.type != "cuda":
             raise RuntimeError(f"the backbone's parameters are on {dev}; move the module to the GPU first (there is no CPU path)")
         capi.require_device(dev, x=x, noise_levels=noise_levels)
+        self._train_stamp += 1
         with torch.no_grad():
             return self._train_engine(params).forward(x, noise_levels).to(x.dtype)
 
-    def _train_backward_impl(self, grad_out, params):
+    def _train_backward_impl(self, grad_out, params, stamp=None):
         eng = self._trainer
         if eng is None:
             raise RuntimeError("backward without a training forward")
+        if stamp is not None and stamp != self._train_stamp:
+            raise RuntimeError(
+                f"DiT3D: backward of training forward #{stamp}, but forward #{self._train_stamp} has run since and overwritten the saved "
+                "activations (one engine per module). Run backward after each forward (accumulate gradients as forward/backward pairs).")
         with torch.no_grad():
             eng.backward(grad_out)
             return [eng.view(n, eng.grads).to(p.dtype).clone() if n in eng.layout else torch.zeros_like(p)

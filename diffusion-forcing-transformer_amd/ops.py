@@ -72,23 +72,28 @@ def _(x, noise_levels, external_cond, external_cond_mask, params, model):
     return torch.empty_like(x)
 
 
+# `stamp` = the module's training-forward counter at the time of the forward this backward belongs to: the saved activations live
+# in the module's ONE engine, so a second training forward before this backward has overwritten them -- the backward then raises
+# instead of returning the gradients of another input (forward, forward, backward, backward is refused; run backward after each
+# forward, e.g. gradient accumulation as forward/backward pairs).
 @custom_op("dfot::uvit3d_pose_backward", mutates_args=())
-def uvit3d_pose_backward(grad_out: Tensor, params: List[Tensor], model: int) -> List[Tensor]:
-    return _model(model)._train_backward_impl(grad_out, params)
+def uvit3d_pose_backward(grad_out: Tensor, params: List[Tensor], model: int, stamp: int) -> List[Tensor]:
+    return _model(model)._train_backward_impl(grad_out, params, stamp)
 
 
 @uvit3d_pose_backward.register_fake
-def _(grad_out, params, model):
+def _(grad_out, params, model, stamp):
     return [torch.empty_like(p) for p in params]
 
 
 def _train_setup_context(ctx, inputs, output):
     ctx.params = inputs[4]
     ctx.model = inputs[5]
+    ctx.stamp = _model(inputs[5])._train_stamp  # setup_context runs right after the forward it describes
 
 
 def _train_backward(ctx, grad_out):
-    grads = torch.ops.dfot.uvit3d_pose_backward(grad_out.contiguous(), ctx.params, ctx.model)
+    grads = torch.ops.dfot.uvit3d_pose_backward(grad_out.contiguous(), ctx.params, ctx.model, ctx.stamp)
     return None, None, None, None, grads, None
 
 
@@ -117,22 +122,23 @@ def _(x, noise_levels, params, model):
 
 
 @custom_op("dfot::dit3d_backward", mutates_args=())
-def dit3d_backward(grad_out: Tensor, params: List[Tensor], model: int) -> List[Tensor]:
-    return _model(model)._train_backward_impl(grad_out, params)
+def dit3d_backward(grad_out: Tensor, params: List[Tensor], model: int, stamp: int) -> List[Tensor]:
+    return _model(model)._train_backward_impl(grad_out, params, stamp)
 
 
 @dit3d_backward.register_fake
-def _(grad_out, params, model):
+def _(grad_out, params, model, stamp):
     return [torch.empty_like(p) for p in params]
 
 
 def _dit_train_setup_context(ctx, inputs, output):
     ctx.params = inputs[2]
     ctx.model = inputs[3]
+    ctx.stamp = _model(inputs[3])._train_stamp
 
 
 def _dit_train_backward(ctx, grad_out):
-    grads = torch.ops.dfot.dit3d_backward(grad_out.contiguous(), ctx.params, ctx.model)
+    grads = torch.ops.dfot.dit3d_backward(grad_out.contiguous(), ctx.params, ctx.model, ctx.stamp)
     return None, None, grads, None
 
 

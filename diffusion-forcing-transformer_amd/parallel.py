@@ -104,59 +104,129 @@ def allreduce_mean_(flat: torch.Tensor, group=None, bucket_numel: int = 1 << 26)
     return flat
 
 
-class OverlappedGradReducer:
-    """Gradient averaging OVERLAPPED with the backward pass: gradients are handed over as the backward produces
-    them (deepest levels last), packed into buckets of `bucket_numel` elements and all-reduced asynchronously while the backward of
-    the next blocks runs; `finish()` waits, scales by 1/world and scatters the means into the destination views (the trainer's flat
-    gradient buffer).  Few large buckets (xGMI is point-to-point: a ring all-reduce is bound per link).  Summation order per
-    element is that of one all-reduce, so the result equals `allreduce_mean_` on the whole flat buffer bit for bit."""
+def _avg_supported(group=None) -> bool:
+    """RCCL (backend "nccl") reduces with ReduceOp.AVG in the collective itself; gloo only sums"""
+    try:
+        return dist.get_backend(group) == "nccl"
+    except Exception:
+        return False
 
-    def __init__(self, bucket_numel: int = 1 << 25, group=None):
+
+class OverlappedGradReducer:
+    """Gradient averaging OVERLAPPED with the backward pass: gradients are handed over as the backward produces them (deepest
+    levels last).  Each is copied ONCE into its slot of the trainer's flat gradient buffer (the copy every path needs), the filled
+    slots are merged into contiguous ranges, and a range that reaches `bucket_numel` elements is all-reduced IN PLACE (a view of the
+    flat buffer, async) while the backward of the next blocks runs; `finish()` reduces the remaining ranges and waits.  No bucket
+    packing (`torch.cat`) and no copy-back: the only extra pass over the gradients is the 1/world scale, and over RCCL not even that
+    (ReduceOp.AVG).  Few large ranges (xGMI is point-to-point: a ring all-reduce is bound per link).  Per element the summation is
+    that of one all-reduce, so the result equals `allreduce_mean_` on the whole flat buffer bit for bit."""
+
+    def __init__(self, bucket_numel: int = 1 << 25, group=None, flat: Optional[torch.Tensor] = None):
         self.bucket_numel, self.group = int(bucket_numel), group
         self.world, _ = world_info(group)
-        self._pending: List[tuple] = []   # (dest view, source gradient) of the bucket being filled
-        self._pending_numel = 0
-        self._inflight: List[tuple] = []  # (work, bucket buffer, [(dest, numel)])
+        self.flat = flat                     # the flat buffer every `dest` is a view of (found from the first dest when None)
+        self._copies: List[tuple] = []       # (dest view, source gradient) not yet copied
+        self._ranges: List[List[int]] = []   # filled, not yet reduced element ranges [lo, hi) of `flat`, sorted and merged
+        self._inflight: List[tuple] = []     # (work, lo, hi)
+        self._avg = self.world > 1 and _avg_supported(group)
+        self.calls = 0                       # collectives issued (tests / reports)
+
+    def _offset(self, dest: torch.Tensor) -> int:
+        if self.flat is None:
+            st = dest.untyped_storage()
+            self.flat = torch.empty(0, dtype=dest.dtype, device=dest.device).set_(st, 0, (st.nbytes() // dest.element_size(),))
+        off = (dest.data_ptr() - self.flat.data_ptr()) // dest.element_size()
+        if off < 0 or off + dest.numel() > self.flat.numel() or not dest.is_contiguous():
+            raise ValueError("OverlappedGradReducer: dest must be a contiguous view of the flat gradient buffer")
+        return off
 
     def add(self, dest: torch.Tensor, grad: torch.Tensor) -> None:
         """dest: flat view that must finally hold the mean of `grad` over the ranks"""
+        self._copies.append((dest, grad.reshape(-1)))
         if self.world == 1:
-            dest.copy_(grad.reshape(-1))
             return
-        self._pending.append((dest, grad))
-        self._pending_numel += grad.numel()
-        if self._pending_numel >= self.bucket_numel:
-            self.flush()
+        lo = self._offset(dest)
+        self._insert(lo, lo + dest.numel())
+        if max(hi - lo_ for lo_, hi in self._ranges) >= self.bucket_numel:
+            self.flush(final=False)
 
-    def flush(self) -> None:
-        if not self._pending:
+    def _insert(self, lo: int, hi: int) -> None:
+        import bisect
+        r = self._ranges
+        i = bisect.bisect_left(r, [lo, hi])
+        r.insert(i, [lo, hi])
+        if i + 1 < len(r) and r[i + 1][0] <= r[i][1]:
+            r[i][1] = max(r[i][1], r[i + 1][1])
+            del r[i + 1]
+        if i > 0 and r[i][0] <= r[i - 1][1]:
+            r[i - 1][1] = max(r[i - 1][1], r[i][1])
+            del r[i]
+
+    def _copy_pending(self) -> None:
+        if self._copies:  # one multi-tensor copy for everything handed over since the last flush
+            torch._foreach_copy_([d for d, _ in self._copies], [g for _, g in self._copies])
+            self._copies = []
+
+    def flush(self, final: bool = True) -> None:
+        """all-reduce the filled ranges (all of them when `final`, else only those that reached the bucket size)"""
+        self._copy_pending()
+        if self.world == 1:
             return
-        buf = torch.cat([g.reshape(-1).to(torch.float32) for _, g in self._pending])
-        work = dist.all_reduce(buf, group=self.group, async_op=True)
-        self._inflight.append((work, buf, [(d, g.numel()) for d, g in self._pending]))
-        self._pending, self._pending_numel = [], 0
+        keep = []
+        for lo, hi in self._ranges:
+            if final or hi - lo >= self.bucket_numel:
+                op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
+                work = dist.all_reduce(self.flat[lo:hi], op=op, group=self.group, async_op=True)
+                self._inflight.append((work, lo, hi))
+                self.calls += 1
+            else:
+                keep.append([lo, hi])
+        self._ranges = keep
 
     def finish(self) -> None:
-        self.flush()
-        for work, buf, dests in self._inflight:
+        self.flush(final=True)
+        for work, lo, hi in self._inflight:
             work.wait()
-            buf.mul_(1.0 / self.world)
-            off = 0
-            for d, n in dests:
-                d.copy_(buf[off: off + n])
-                off += n
+            if not self._avg:
+                self.flat[lo:hi].mul_(1.0 / self.world)
         self._inflight = []
+
+
+_BRANCH_GROUPS = {}
+
+
+def branch_group(nfe: int, group=None):
+    """The `nfe`-rank sub-group this rank exchanges History-Guidance branches in: ranks [g*nfe, (g+1)*nfe) form group g, so that with
+    8 ranks and 2 branches four PAIRS each exchange 2 x v (instead of one all-gather over 8 ranks, of which 6 carried redundant
+    copies).  Ranks beyond the last full group get None (they evaluate every branch themselves).  Collective on first use: every rank
+    of the world must call it with the same nfe (dist.new_group is a world-wide call)."""
+    world, rank = world_info(group)
+    if group is not None:
+        raise ValueError("branch_group: nested groups are not supported")
+    key = (nfe, world)
+    if key not in _BRANCH_GROUPS:
+        groups = []
+        for g in range(world // nfe):
+            ranks = list(range(g * nfe, (g + 1) * nfe))
+            groups.append(dist.new_group(ranks) if world > nfe else None)  # world == nfe: the default group is the pair
+        _BRANCH_GROUPS[key] = groups
+    g = rank // nfe
+    groups = _BRANCH_GROUPS[key]
+    return (g < len(groups)), (groups[g] if g < len(groups) else None)
 
 
 def exchange_branches(v_local: torch.Tensor, nfe: int, group=None) -> torch.Tensor:
     """History-Guidance branch parallelism for the sequential key-frame windows (the branches of a step are
     independent forwards combined only by compose, history_guidance.py:545-568,978-982).  Rank r has evaluated branch r % nfe of
-    every sample: v_local [B, T, ...].  One all-gather returns v [B * nfe, T, ...] in the sampler's (sample, branch) row order."""
+    every sample: v_local [B, T, ...].  One all-gather inside the rank's `nfe`-rank sub-group (`branch_group`) returns
+    v [B * nfe, T, ...] in the sampler's (sample, branch) row order; every sub-group computes the same result."""
     world, rank = world_info(group)
     if world < nfe:
         raise ValueError(f"branch parallelism needs at least {nfe} ranks, have {world}")
-    out = v_local.new_empty((world * v_local.shape[0], *v_local.shape[1:]))
-    dist.all_gather_into_tensor(out, v_local.contiguous(), group=group)
+    member, sub = branch_group(nfe, group)
+    if not member:
+        raise ValueError(f"rank {rank} is outside the last full {nfe}-rank branch group; it must evaluate all branches itself")
+    out = v_local.new_empty((nfe * v_local.shape[0], *v_local.shape[1:]))
+    dist.all_gather_into_tensor(out, v_local.contiguous(), group=sub)
     b = v_local.shape[0]
-    per_rank = out.view(world, b, *v_local.shape[1:])[:nfe]          # ranks 0..nfe-1 hold branches 0..nfe-1
-    return per_rank.transpose(0, 1).reshape(b * nfe, *v_local.shape[1:]).contiguous()
+    return out.view(nfe, b, *v_local.shape[1:]).transpose(0, 1).reshape(b * nfe, *v_local.shape[1:]).contiguous()

@@ -405,7 +405,7 @@ class DFoTVideoPoseSampler:
             # discrete diffusion hands the backbone integer level indices (exact in the float32 table)
             lvl = tables[7] if cfg.diffusion.is_continuous else tables[7].to(torch.int32)
             world, rank = parallel.world_info()
-            if self._branch_split_active and nfe > 1 and world >= nfe:
+            if self._branch_split_active and nfe > 1 and (rank // nfe + 1) * nfe <= world:  # rank inside a full nfe-rank branch group
                 # this rank's branch only; the conditioning slices are cached per window so that the backbone's pose cache (keyed on
                 # tensor identity) still hits on every step
                 hb = rank % nfe
@@ -461,8 +461,11 @@ class DFoTVideoPoseSampler:
         if self.use_graph and uniform and not strict and len(plans) > 2 and all(p_["sigma"] is None for p_ in plans) and not self._branch_split_active:
             xs = self._run_steps_graph(plans, xs, draw_noise, step, flat_dev, gens_dev, horizon)
         else:
-            for p_ in plans:
+            hook = getattr(self, "step_hook", None)  # test instrumentation (drift per step); None on every product path
+            for i, p_ in enumerate(plans):
                 xs = step(p_, xs, draw_noise(p_), p_["tables_dev"], p_["gen_dev"])
+                if hook is not None:
+                    hook(i, xs)
         self.window_forwards += sum(p_["bm"] for p_ in plans)
         if padding > 0:
             xs = xs[:, :-padding]
@@ -665,6 +668,10 @@ class DFoTVideoPoseSampler:
         keys = torch.linspace(0, n - 1, round(density * n)).round().long()
         keys = torch.cat([torch.arange(n_context_tokens), keys]).unique()
         kc = None if conditions is None else conditions[:, keys]
+        if self.branch_parallel and parallel.world_info()[0] > 1 and not (hasattr(self.noise_fn, "set_windows") or getattr(self.noise_fn, "replicated", False)):
+            # the gathered v mixes branches evaluated on DIFFERENT ranks: they must all hold bit-identical xs and noise
+            raise ValueError("branch_parallel needs a rank-independent noise source: parallel.WindowKeyedNoise (set_windows) or a noise_fn "
+                             "whose attribute `replicated` is True (every rank draws the same tensors)")
         self._branch_split_active = bool(self.branch_parallel)  # key-frame windows are replicated on every rank: split their branches
         try:
             pred, _ = self._predict_sequence(out[:, :n_context_tokens], length=len(keys), conditions=kc, history_guidance=hg,

@@ -101,9 +101,11 @@ def training_step_forward(sampler, xs: torch.Tensor, masks: torch.Tensor, noise_
 def lr_at_step(step: int, base_lr: float, name: str = "constant_with_warmup", num_warmup_steps: int = 10000, num_training_steps: int = 0) -> float:
     """Learning rate of optimizer step `step` (0-based) under the reference's schedulers (`transformers.get_scheduler(name=cfg.lr_scheduler.name,
     num_warmup_steps=...)` stepped once per optimizer step: experiments/simple_video_generation.py:271, realestate10k_video_generation.yaml:19-22
-    `constant_with_warmup`, 10000 warm-up steps): linear warm-up from 0, then constant / linear decay / cosine decay."""
+    `constant_with_warmup`, 10000 warm-up steps): linear warm-up from 0, then constant / linear decay / cosine decay.  A LambdaLR is
+    at epoch s when optimizer step s runs (it is stepped AFTER each optimizer step), so step s runs at base * s / warmup: the first
+    step has learning rate 0 and step `num_warmup_steps` is the first at the base rate."""
     import math
-    warm = min(1.0, (step + 1) / max(1, num_warmup_steps)) if num_warmup_steps > 0 else 1.0
+    warm = min(1.0, step / max(1, num_warmup_steps)) if num_warmup_steps > 0 else 1.0
     if name in ("constant", "constant_with_warmup"):
         return base_lr * (warm if name == "constant_with_warmup" else 1.0)
     if step < num_warmup_steps:

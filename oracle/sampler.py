@@ -176,6 +176,8 @@ class Sampler:
                 x_out = self.diff.ddpm_step(x_in, f_in, cond, cmask, step_noise)
             xs = g.compose(x_out)
             xs = torch.where(_ext(context_mask, nd) == 0, xs, prev)
+            if getattr(self, "step_hook", None) is not None:  # test instrumentation: the window state after step m
+                self.step_hook(m, xs)
         return xs[:, :length] if padding > 0 else xs
 
     # ------------------------------------------------------------------ one window, refinement ladder

