@@ -747,7 +747,8 @@ int launch_rms_film(const float* x, const float* w, const bf16* fcache, const fl
   hipLaunchKernelGGL((rms_film_kernel<MC, P>), dim3(cdiv(m, 4)), dim3(256), 0, s, x, w, fcache, sv, cond_mask, out, m, c, rows_per_bt, \
                      tokens, eps, P ? pend->x : nullptr, P ? pend->bias : nullptr, P ? pend->s0 : nullptr, P ? pend->s1 : nullptr, P ? pend->s2 : nullptr)
   if (pend) {
-    DFOT_REQUIRE(pend->x == x && pend->bias && pend->s0 && pend->s1, DFOT_ERR_ARG, "rms_film: pending sum must target the normalised stream");
+    // x is read, x + bias + slices is normalised AND written to pend->x (the same buffer, or X[l] when the stream still sits in the skip tensor)
+    DFOT_REQUIRE(pend->x && pend->bias && pend->s0 && pend->s1, DFOT_ERR_ARG, "rms_film: pending sum needs a target, a bias and two slices");
     if (c <= 8 * 64 * 2) RMS_CALL(2, true); else RMS_CALL(3, true);
   } else {
     if (c <= 8 * 64 * 2) RMS_CALL(2, false); else RMS_CALL(3, false);

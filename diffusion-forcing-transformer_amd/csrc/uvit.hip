@@ -110,6 +110,7 @@ struct dfot_uvit_s {
   bf16 *acond = nullptr, *emb[4] = {nullptr, nullptr, nullptr, nullptr}, *s1 = nullptr, *hbf = nullptr,
        *cat = nullptr, *q = nullptr, *k = nullptr, *v = nullptr;
   AttnScratch attn_scratch;   // key-split partials of the level-2 attention, owned by this handle (sized in reserve)
+  const float* pend_part = nullptr;  // where the pending slices are
   float* out_part = nullptr;  // two fp32 partial slices of an out-projection (K split, see run_tr_block)
   size_t out_part_elems = 0;  // its capacity in floats: the split path is taken only when 2 * M * N fits
   // the slices of the last out-projection not yet added to X[pend_lvl] (pend_bias != nullptr): the next block's norm kernel adds
@@ -118,6 +119,9 @@ struct dfot_uvit_s {
   int pend_lvl = 0, pend_c = 0, pend_slices = 2;
   long pend_m = 0;
   int last_batch = 0;
+  // where the residual stream of a level currently lives: X[l], or HSA[l-1] right after the Downsample convolution (its output is both
+  // the skip tensor and the next level's input: the first block of the level reads it there and writes X[l], no copy)
+  const float* xin[4] = {nullptr, nullptr, nullptr, nullptr};
   int gemm_variant = GEMM_AUTO;
   int attn_variant = 2;
   bool attn_force_safe = false;  // level-2 attention: always the running-max kernel (what weights with a bound >= 64 get)
@@ -377,14 +381,15 @@ static int run_res_block(dfot_uvit_s* h, const ResW& w, int lvl, int bt, hipStre
   const int m = bt * pix;
   const int slots = pix / 64;
   float* x = h->X[lvl];
+  const float* xi = h->xin[lvl];
   int rc = 0;
   if (h->gn1_nblk == 0) {
-    if ((rc = launch_gn_partial_f32(x, h->gn_partial, bt, pix, c, s))) return rc;
+    if ((rc = launch_gn_partial_f32(xi, h->gn_partial, bt, pix, c, s))) return rc;
     h->gn1_nblk = gn_partial_blocks(pix);
   }
   if ((rc = launch_gn_finalize(h->gn_partial, h->gn_stats, bt, h->gn1_nblk, pix, c, h->cfg.eps, s))) return rc;
   h->gn1_nblk = 0;
-  if ((rc = launch_gn_apply_silu(x, h->gn_stats, w.g1, w.be1, h->s1, bt, pix, c, s))) return rc;
+  if ((rc = launch_gn_apply_silu(xi, h->gn_stats, w.g1, w.be1, h->s1, bt, pix, c, s))) return rc;
   GemmArgs g;
   g.A = h->s1; g.W = w.w1; g.M = m; g.N = c; g.K = 9 * c; g.H = rr; g.Wd = rr; g.Cin = c; g.zeros = h->zeros;
   g.bias = w.bias1; g.out_bf16 = h->hbf; g.ldo = c;
@@ -396,30 +401,34 @@ static int run_res_block(dfot_uvit_s* h, const ResW& w, int lvl, int bt, hipStre
     return rc;
   GemmArgs o;
   o.A = h->s1; o.W = w.w2; o.M = m; o.N = c; o.K = 9 * c; o.H = rr; o.Wd = rr; o.Cin = c; o.zeros = h->zeros;
-  o.bias = w.bias2; o.out_f32 = x; o.resid = x; o.ldo = c;
+  o.bias = w.bias2; o.out_f32 = x; o.resid = xi; o.ldo = c;
   o.gn_part = h->gn_partial; o.gn_rows_per_bt = pix; o.gn_cpg = c / 32;
   if ((rc = launch_gemm(A_CONV3, E_F32, h->gemm_variant, o, s))) return rc;
+  h->xin[lvl] = x;
   h->gn1_nblk = slots;
   return DFOT_OK;
 }
 
 // x += bias + slice0 + slice1 (fp32, 4 elements per thread): the reduce pass of the two-slice out-projection
-__global__ void out_reduce_kernel(float* __restrict__ x, const float* __restrict__ bias, const float* __restrict__ s0,
+__global__ void out_reduce_kernel(float* x, const float* xsrc, const float* __restrict__ bias, const float* __restrict__ s0,
                                   const float* __restrict__ s1, const float* __restrict__ s2, long total4, int cq) {
   typedef __attribute__((ext_vector_type(4))) float f4;
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total4) return;
   f4 b = reinterpret_cast<const f4*>(bias)[i % cq] + reinterpret_cast<const f4*>(s0)[i] + reinterpret_cast<const f4*>(s1)[i];
   if (s2) b += reinterpret_cast<const f4*>(s2)[i];
-  reinterpret_cast<f4*>(x)[i] += b;
+  reinterpret_cast<f4*>(x)[i] = reinterpret_cast<const f4*>(xsrc)[i] + b;
 }
+
+static void swap_out_part(dfot_uvit_s* h) { h->pend_part = h->out_part; }
 
 static int flush_pending(dfot_uvit_s* h, hipStream_t s) {
   if (!h->pend_bias) return DFOT_OK;
   const long total4 = h->pend_m * h->pend_c / 4;
-  hipLaunchKernelGGL(out_reduce_kernel, dim3(cdiv(total4, 256)), dim3(256), 0, s, h->X[h->pend_lvl], h->pend_bias, h->out_part,
-                     h->out_part + h->pend_m * h->pend_c, h->pend_slices == 3 ? h->out_part + 2 * h->pend_m * h->pend_c : nullptr, total4,
+  hipLaunchKernelGGL(out_reduce_kernel, dim3(cdiv(total4, 256)), dim3(256), 0, s, h->X[h->pend_lvl], h->xin[h->pend_lvl], h->pend_bias, h->pend_part,
+                     h->pend_part + h->pend_m * h->pend_c, h->pend_slices == 3 ? h->pend_part + 2 * h->pend_m * h->pend_c : nullptr, total4,
                      h->pend_c / 4);
+  h->xin[h->pend_lvl] = h->X[h->pend_lvl];
   h->pend_bias = nullptr;
   DFOT_CHECK_HIP(hipGetLastError());
   return DFOT_OK;
@@ -436,10 +445,11 @@ static int run_tr_block(dfot_uvit_s* h, const TrW& w, int lvl, int batch, hipStr
   float* x = h->X[lvl];
   int rc = 0;
   if (h->pend_bias && (h->pend_lvl != lvl || h->pend_m != m || h->pend_c != c) && (rc = flush_pending(h, s))) return rc;
-  RmsPending pend{x, h->pend_bias, h->out_part, h->out_part + (long)m * c, h->pend_slices == 3 ? h->out_part + 2L * m * c : nullptr};
-  if ((rc = launch_rms_film(x, w.nw, w.fcache, h->sv + w.sv_off, h->have_mask ? h->cond_mask : nullptr, h->s1, m, c,
+  RmsPending pend{x, h->pend_bias, h->pend_part, h->pend_part + (long)m * c, h->pend_slices == 3 ? h->pend_part + 2L * m * c : nullptr};
+  if ((rc = launch_rms_film(h->xin[lvl], w.nw, w.fcache, h->sv + w.sv_off, h->have_mask ? h->cond_mask : nullptr, h->s1, m, c,
                             rr * rr, h->T, h->cfg.eps, s, h->pend_bias ? &pend : nullptr)))
     return rc;
+  if (h->pend_bias) h->xin[lvl] = x;  // the pending sum was written to X[lvl]
   h->pend_bias = nullptr;
   GemmArgs p;
   p.A = h->s1; p.lda = c; p.W = w.w_fused; p.M = m; p.N = 7 * c; p.K = c; p.bias = w.b_fused;
@@ -456,11 +466,11 @@ static int run_tr_block(dfot_uvit_s* h, const TrW& w, int lvl, int batch, hipStr
   if ((rc = launch_attention(h->q, h->k, h->v, h->cat, 5 * c, batch, h->heads, n, d, av, s, &h->attn_scratch))) return rc;
   if (timed) DFOT_CHECK_HIP(hipEventRecord(h->ev_stop[h->ev_used++], s));
   GemmArgs o;
-  o.A = h->cat; o.lda = 5 * c; o.W = w.w_out; o.M = m; o.N = c; o.K = 5 * c; o.bias = w.b_out; o.out_f32 = x; o.resid = x;
+  o.A = h->cat; o.lda = 5 * c; o.W = w.w_out; o.M = m; o.N = c; o.K = 5 * c; o.bias = w.b_out; o.out_f32 = x; o.resid = h->xin[lvl];
   o.ldo = c;
   // A/B: K split over workgroups where the out-projection has fewer tiles than CUs (level 3: 96 tiles of 256x192)
   static const int l3_split = tuning_flag("UVIT_OUT_KSPLIT", 1);
-  if (l3_split > 1 && (long)(m / 256) * ((c + 191) / 192) < 200) o.ksplit = l3_split;
+  if (l3_split > 1 && (long)(m / 256) * ((c + 191) / 192) < 200 && h->xin[lvl] == x) o.ksplit = l3_split;
   // level 3 at small model batch: 256x144 tiles give M/256 x N/144 = 128 workgroups for 256 CUs; two K slices into partial
   // buffers make it 256, and one pass adds slices + bias into the fp32 residual stream (out_reduce_kernel)
   static const int split144 = tuning_flag("UVIT_OUT_SPLIT144", 2);  // 0: one GEMM with the residual epilogue; 1: 256x144 x 2 slices; 2: 256x256 x 3 slices
@@ -474,6 +484,7 @@ static int run_tr_block(dfot_uvit_s* h, const TrW& w, int lvl, int batch, hipStr
     if ((rc = launch_gemm(A_DENSE, E_F32, GEMM_DMA_256x256, p3, s))) return rc;
     h->pend_bias = w.b_out;
     h->pend_lvl = lvl; h->pend_m = m; h->pend_c = c; h->pend_slices = 3;
+    swap_out_part(h);
     return defer ? DFOT_OK : flush_pending(h, s);
   }
   if (split144 && h->gemm_variant == GEMM_AUTO && h->out_part && (size_t)2 * m * c <= h->out_part_elems && m % 256 == 0 && c % 144 == 0 &&
@@ -483,9 +494,19 @@ static int run_tr_block(dfot_uvit_s* h, const TrW& w, int lvl, int batch, hipStr
     if ((rc = launch_gemm(A_DENSE, E_F32, GEMM_DMA_256x144, p2, s))) return rc;
     h->pend_bias = w.b_out;
     h->pend_lvl = lvl; h->pend_m = m; h->pend_c = c; h->pend_slices = 2;
+    swap_out_part(h);
     return defer ? DFOT_OK : flush_pending(h, s);
   }
-  return launch_gemm(A_DENSE, E_F32, h->gemm_variant, o, s);
+  // level 2 (M = 16384, N = 576): 256x192 tiles are 192 workgroups -- a quarter of the chip idle for the whole kernel; 256x144 tiles
+  // (N = 4 x 144) are exactly 256, one per CU, at 92 instead of 110 FLOP per operand byte
+  static const int l2_144 = tuning_flag("UVIT_OUT_L2_144", 1);
+  if (l2_144 && h->gemm_variant == GEMM_AUTO && o.ksplit == 1 && c % 144 == 0 && m % 256 == 0 && (long)(m / 256) * ((c + 191) / 192) < 256 &&
+      (long)(m / 256) * (c / 144) >= 200 && (long)(m / 256) * (c / 144) <= 256)
+    rc = launch_gemm(A_DENSE, E_F32, GEMM_DMA_256x144, o, s);
+  else
+    rc = launch_gemm(A_DENSE, E_F32, h->gemm_variant, o, s);
+  h->xin[lvl] = x;
+  return rc;
 }
 
 // The reference block is PARALLEL attention + MLP (u_vit_blocks.py:253-277: x + attn_out(attn(q, k, v)) + mlp_out(silu(mlp_h))): after the
@@ -505,10 +526,11 @@ static int run_tr_block_2s(dfot_uvit_s* h, const TrW& w, int lvl, int batch, hip
   hipStream_t s2 = h->side;
   int rc = 0;
   if (h->pend_bias && (h->pend_lvl != lvl || h->pend_m != m || h->pend_c != c) && (rc = flush_pending(h, s))) return rc;
-  RmsPending pend{x, h->pend_bias, h->out_part, h->out_part + (long)m * c, h->pend_slices == 3 ? h->out_part + 2L * m * c : nullptr};
-  if ((rc = launch_rms_film(x, w.nw, w.fcache, h->sv + w.sv_off, h->have_mask ? h->cond_mask : nullptr, h->s1, m, c,
+  RmsPending pend{x, h->pend_bias, h->pend_part, h->pend_part + (long)m * c, h->pend_slices == 3 ? h->pend_part + 2L * m * c : nullptr};
+  if ((rc = launch_rms_film(h->xin[lvl], w.nw, w.fcache, h->sv + w.sv_off, h->have_mask ? h->cond_mask : nullptr, h->s1, m, c,
                             rr * rr, h->T, h->cfg.eps, s, h->pend_bias ? &pend : nullptr)))
     return rc;
+  if (h->pend_bias) h->xin[lvl] = x;  // the pending sum was written to X[lvl]
   h->pend_bias = nullptr;
   hipEvent_t fork = next_event(h), join = next_event(h);
   DFOT_CHECK_HIP(hipEventRecord(fork, s));
@@ -547,13 +569,14 @@ static int run_tr_block_2s(dfot_uvit_s* h, const TrW& w, int lvl, int batch, hip
   DFOT_CHECK_HIP(hipStreamWaitEvent(s, join, 0));
   h->pend_bias = w.b_out;
   h->pend_lvl = lvl; h->pend_m = m; h->pend_c = c; h->pend_slices = 1 + mlp_slices;
+  swap_out_part(h);
   return DFOT_OK;
 }
 
 static int run_down(dfot_uvit_s* h, int l, int bt, hipStream_t s) {
   const int rr = h->r[l], cin = h->ch[l], cout = h->ch[l + 1];
   int rc = 0;
-  if ((rc = launch_pool2_bf16(h->X[l], h->s1, bt, rr, rr, cin, s))) return rc;
+  if ((rc = launch_pool2_bf16(h->xin[l], h->s1, bt, rr, rr, cin, s))) return rc;
   GemmArgs g;
   g.A = h->s1; g.W = h->down_conv[l].w; g.M = bt * (rr / 2) * (rr / 2); g.N = cout; g.K = 9 * cin; g.H = rr / 2; g.Wd = rr / 2;
   g.Cin = cin; g.zeros = h->zeros; g.bias = h->down_conv[l].b; g.out_f32 = h->HSA[l]; g.ldo = cout;
@@ -563,20 +586,23 @@ static int run_down(dfot_uvit_s* h, int l, int bt, hipStream_t s) {
   }
   if ((rc = launch_gemm(A_CONV3, E_F32, h->gemm_variant, g, s))) return rc;
   h->gn1_nblk = next_is_res ? g.gn_rows_per_bt / 64 : 0;
-  return copy_f32(h->X[l + 1], h->HSA[l], (size_t)g.M * cout, s);
+  h->xin[l + 1] = h->HSA[l];  // the skip tensor IS the next level's input: its first block reads it here and writes X[l + 1]
+  return DFOT_OK;
 }
 
 static int run_up(dfot_uvit_s* h, int l, int bt, hipStream_t s) {  // level l+1 -> l
   const int rr = h->r[l + 1], cin = h->ch[l + 1], cout = h->ch[l];
   const long n_in = (long)bt * rr * rr * cin;
   int rc = 0;
-  if ((rc = launch_sub_bf16(h->X[l + 1], h->HSA[l], h->s1, n_in, s))) return rc;
+  if ((rc = launch_sub_bf16(h->xin[l + 1], h->HSA[l], h->s1, n_in, s))) return rc;
   GemmArgs g;
   g.A = h->s1; g.W = h->up_conv[l].w; g.M = bt * rr * rr; g.N = cout; g.K = 9 * cin; g.H = rr; g.Wd = rr; g.Cin = cin;
   g.zeros = h->zeros; g.bias = h->up_conv[l].b; g.out_f32 = h->tmp; g.ldo = cout;
   if ((rc = launch_gemm(A_CONV3, E_F32, h->gemm_variant, g, s))) return rc;
   h->gn1_nblk = 0;  // X[l] is rewritten by an elementwise kernel: its statistics come from the standalone kernel
-  return launch_upsample_add(h->tmp, h->X[l], h->X[l], bt, rr, rr, cout, s);
+  rc = launch_upsample_add(h->tmp, h->xin[l], h->X[l], bt, rr, rr, cout, s);
+  h->xin[l] = h->X[l];
+  return rc;
 }
 
 }  // namespace dfot
@@ -606,7 +632,11 @@ int dfot_uvit_create(const dfot_uvit_config* cfg, dfot_uvit_t* out) {
   DFOT_REQUIRE((cfg->max_tokens * r3 * r3) % 128 == 0, DFOT_ERR_SHAPE, "tokens at the coarsest level (%d) must be a multiple of 128", cfg->max_tokens * r3 * r3);
   auto* h = new dfot_uvit_s();
   h->cfg = *cfg;
-  h->two_stream = tuning_flag("UVIT_TWO_STREAM", 1);  // A/B: 0 = the serial chain on one stream; bit 0 = level 3, bit 1 = level 2
+  // bit 0 = level 3, bit 1 = level 2.  OFF by default: +1.3 % frames/s at 256x256 (two same-box A/B pairs), but at
+  // 64x64 -- where workgroups of the concurrently running kernels share CUs -- two runs of one forward differ by ~2e-3 relative
+  // (tools/debug_2s.py); every dependency is covered by the fork / join events and host synchronisation at the fork makes it exact, the
+  // cause is not found, so the serial chain stays the default
+  h->two_stream = tuning_flag("UVIT_TWO_STREAM", 0);
   if (h->two_stream) {
     if (hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess) h->side = nullptr;
     for (int i = 0; h->side && i < 8; ++i) {
@@ -710,6 +740,7 @@ int dfot_uvit_reserve(dfot_uvit_t h, int max_batch) {
   h->ws_bytes = 0;
   h->max_batch = 0;
   h->out_part = nullptr;
+  h->pend_part = nullptr;
   h->out_part_elems = 0;
   h->attn_scratch = AttnScratch{};
   const size_t bt = (size_t)max_batch * h->T;
@@ -900,6 +931,7 @@ int dfot_uvit_forward_cached(dfot_uvit_t h, const float* x, const float* noise_l
   if ((rc = launch_film_vec(h->film_table, h->film_chunks, h->nemb, h->sv, bt, e, s))) return rc;
   if ((rc = launch_embed_input(x, h->ein_w, h->ein_b, h->X[0], bt, c.resolution, c.in_channels, h->ch[0], s))) return rc;
   h->gn1_nblk = 0;
+  for (int l = 0; l < 4; ++l) h->xin[l] = h->X[l];
 
   for (int l = 0; l < 2; ++l) {
     for (const ResW& w : h->down_res[l])
@@ -924,7 +956,7 @@ int dfot_uvit_forward_cached(dfot_uvit_t h, const float* x, const float* noise_l
       if ((rc = run_res_block(h, w, l, bt, s))) return rc;
   }
   h->last_batch = batch;
-  return launch_project_output(h->X[0], h->pout_w, h->pout_b, out, bt, c.resolution, h->ch[0], c.in_channels, s);
+  return launch_project_output(h->xin[0], h->pout_w, h->pout_b, out, bt, c.resolution, h->ch[0], c.in_channels, s);
 }
 
 int dfot_uvit_forward(dfot_uvit_t h, const float* x, const float* noise_levels, const float* external_cond,
@@ -945,8 +977,8 @@ int dfot_uvit_read_tap(dfot_uvit_t h, const char* name, float* out, size_t capac
   const Tap taps[] = {
       {"pose_emb0", 0, h->E, nullptr, h->emb[0]}, {"down0", 1, h->ch[1], h->HSA[0], nullptr},
       {"down1", 2, h->ch[2], h->HSA[1], nullptr}, {"down2", 3, h->ch[3], h->HSA[2], nullptr},
-      {"mid", 3, h->ch[3], h->X[3], nullptr}, {"up2", 2, h->ch[2], h->X[2], nullptr},
-      {"up1", 1, h->ch[1], h->X[1], nullptr}, {"up0", 0, h->ch[0], h->X[0], nullptr},
+      {"mid", 3, h->ch[3], h->xin[3], nullptr}, {"up2", 2, h->ch[2], h->xin[2], nullptr},
+      {"up1", 1, h->ch[1], h->xin[1], nullptr}, {"up0", 0, h->ch[0], h->xin[0], nullptr},
   };
   for (const Tap& t : taps) {
     if (strcmp(t.n, name)) continue;

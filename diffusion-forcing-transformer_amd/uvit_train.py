@@ -132,10 +132,17 @@ class TransformerBlockTrain:
         self.saved = dict(x=x, emb=emb, film=film, xn=xn, fused=fused, q=q, k=k, v=v, cat=cat, lse=lse, batch=batch, mlp_mask=mlp_mask)
         return y
 
+    def drop_saved(self) -> None:
+        """gradient checkpointing (torch.utils.checkpoint around the block, u_vit3d.py:237-243): keep the block's inputs only"""
+        self.saved = {k: self.saved[k] for k in ("x", "emb", "batch", "mlp_mask")}
+
     def backward(self, dy: torch.Tensor, demb_acc: Optional[torch.Tensor] = None, dy_bf: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
         """dy fp32 [B*N][C] -> (dx fp32, demb fp32 [B*N][E]); parameter gradients in self.grads (reference names).
         demb_acc: the level's embedding-gradient accumulator, added to in the GEMM epilogue (no separate pass).
         dy_bf: dy already in bf16 (the block above wrote it next to its dx: self.dx_bf), else it is cast here"""
+        if "xn" not in self.saved:  # gradient checkpointing: only the block's inputs were kept -- run its forward again (same kernels, same
+            ck = self.saved        # dropout mask: bit-identical activations), then the ordinary backward
+            self.forward(ck["x"], ck["emb"], ck["batch"], ck["mlp_mask"])
         s, c, hds, d, p, lib = self.saved, self.c, self.heads, self.d, self.p, capi.lib
         rows, batch = dy.shape[0], s["batch"]
         ntok = rows // batch
@@ -227,11 +234,17 @@ class ResBlockTrain:
         self.saved = dict(x=x, emb=emb, h1=h1, c1=c1, film=film, h2=h2, st1=st1, st2=st2, geom=(bt, h, w))
         return y
 
+    def drop_saved(self) -> None:
+        self.saved = {k: self.saved[k] for k in ("x", "emb", "geom")}
+
     def backward(self, dy: torch.Tensor, demb_acc: Optional[torch.Tensor] = None,
                  dfilm_out: Optional[torch.Tensor] = None, dy_bf: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
         """dfilm_out: a [rows][2C] bf16 column block of the level's FiLM-gradient matrix; the block then leaves the embedding gradient
         (dfilm W_e over the level's concatenated K) to the caller instead of adding its own [rows][E] product to demb_acc.
         dy_bf: dy already in bf16 (the block above left it in self.dx_bf), else it is cast here"""
+        if "h1" not in self.saved:  # gradient checkpointing (see TransformerBlockTrain.backward)
+            ck = self.saved
+            self.forward(ck["x"], ck["emb"], *ck["geom"])
         s, c, p, lib = self.saved, self.c, self.p, capi.lib
         bt, h, w = s["geom"]
         P = h * w
@@ -321,6 +334,14 @@ class UViT3DPoseTrainer:
         # block_dropouts of u_vit3d_pose.yaml ([0, 0, 0.1, 0.1]); applied only when a CUDA generator is set (training with dropout on)
         self.block_dropouts = list(g("block_dropouts", [0.0] * 4))
         self.dropout_generator: Optional[torch.Generator] = None
+        # use_checkpointing of u_vit3d.yaml, per level ([false, false, false, true] for RE10K training, realestate10k_video_generation.yaml:44):
+        # the blocks of such a level keep only their inputs and are run forward again inside the backward
+        self.use_checkpointing = [bool(v) for v in g("use_checkpointing", [False] * 4)]
+        # optional trainer state (experiments/simple_video_generation.py): EMA shadow weights, gradient accumulation
+        self.ema: Optional[torch.Tensor] = None
+        self.ema_decay = 0.0
+        self._acc: Optional[torch.Tensor] = None
+        self._acc_n = 0
         self.sync()
 
     def sync(self) -> None:
@@ -365,6 +386,8 @@ class UViT3DPoseTrainer:
                     keep = torch.rand(x.shape[0], 4 * self.ch[lvl], device="cuda", generator=self.dropout_generator) >= p
                     mask = (keep.to(torch.float32) / (1.0 - p)).to(BF)
                 x = b.forward(x, self.emb[lvl], self.B, mask)
+            if self.use_checkpointing[lvl]:
+                b.drop_saved()
         return x
 
     def forward(self, x: torch.Tensor, noise_levels: torch.Tensor, cond: torch.Tensor, cond_drop: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -557,20 +580,89 @@ class UViT3DPoseTrainer:
             self._grads_reduced = False
         return (per_token * mk.cuda()).mean()
 
+    def accumulate(self) -> None:
+        """accumulate_grad_batches (accelerator.accumulate, simple_video_generation.py:260): add the gradients of the last
+        loss_and_grads to the running sum; the next optimizer_step uses the MEAN over the accumulated micro-batches"""
+        if self._acc is None:
+            self._acc = torch.zeros_like(self.flat_grads)
+        self._acc.add_(self.flat_grads)
+        self._acc_n += 1
+
     def optimizer_step(self, lr: float = 5e-5, betas=(0.9, 0.99), eps: float = 1e-8, weight_decay: float = 0.01, max_grad_norm: Optional[float] = 1.0,
                        world_size: int = 1) -> None:
         from . import parallel
+        if self._acc_n:
+            self.flat_grads.copy_(self._acc).mul_(1.0 / self._acc_n)
+            self._acc.zero_()
+            self._acc_n = 0
+            self._grads_reduced = False  # the accumulated sum holds local gradients: reduce it once here
         if world_size > 1 and not getattr(self, "_grads_reduced", False):
             parallel.allreduce_mean_(self.flat_grads)
         self.step_count += 1
+        self._opt = dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay)
         lib = capi.lib
         sumsq = None
         if max_grad_norm is not None:
             capi.check(lib.dfot_sumsq(_P(self.flat_grads), self.numel, _P(self._sumsq), _S()))
             sumsq = self._sumsq
+        # EMA shadow weights (algorithms/common/ema.py:21-33: shadow = decay * shadow + (1 - decay) * param after every optimizer step) are
+        # updated by the same kernel pass that writes the new parameters
         capi.check(lib.dfot_adamw_step(_P(self.flat), _P(self.flat_grads), _P(self.exp_avg), _P(self.exp_avg_sq), self.numel, lr, betas[0], betas[1], eps,
-                                       weight_decay, self.step_count, _P(sumsq), float(max_grad_norm or 0.0), None, 0.0, _S()))
+                                       weight_decay, self.step_count, _P(sumsq), float(max_grad_norm or 0.0), _P(self.ema), float(self.ema_decay), _S()))
         self.sync()
+
+    # ------------------------------------------------------------------ EMA and optimizer state (checkpoint / resume), as trainer.DiT3DTrainer
+    def enable_ema(self, decay: float) -> None:
+        """experiment.ema (algorithms/common/ema.py): shadow weights start as a copy of the parameters"""
+        self.ema, self.ema_decay = self.flat.clone(), float(decay)
+
+    def _view(self, name: str, flat: torch.Tensor) -> torch.Tensor:
+        o, shp = self.layout[name]
+        n = 1
+        for d in shp:
+            n *= d
+        return flat[o: o + n].view(shp)
+
+    def ema_state_dict(self) -> Dict[str, torch.Tensor]:
+        """what the reference writes to ema.safetensors (simple_video_generation.py:653-657): the shadow of every trainable parameter"""
+        if self.ema is None:
+            raise RuntimeError("EMA is not enabled")
+        return {k: self._view(k, self.ema).detach().clone() for k in self.layout}
+
+    def load_ema_state_dict(self, sd: Dict[str, torch.Tensor]) -> None:
+        if self.ema is None:
+            raise RuntimeError("EMA is not enabled")
+        if set(sd.keys()) != set(self.layout.keys()):
+            raise ValueError("The provided state_dict does not match the structure of the EMA model.")
+        for k, t in sd.items():
+            self._view(k, self.ema).copy_(t.to(device="cuda", dtype=torch.float32))
+
+    def optimizer_state_dict(self) -> Dict:
+        """torch.optim.AdamW.state_dict() layout (parameter index = position in the reference's parameter order)"""
+        opt = getattr(self, "_opt", dict(lr=5e-5, betas=(0.9, 0.99), eps=1e-8, weight_decay=0.01))
+        state = {i: {"step": torch.tensor(float(self.step_count)), "exp_avg": self._view(k, self.exp_avg).clone(),
+                     "exp_avg_sq": self._view(k, self.exp_avg_sq).clone()} for i, k in enumerate(self.layout)} if self.step_count else {}
+        group = dict(lr=opt["lr"], betas=opt["betas"], eps=opt["eps"], weight_decay=opt["weight_decay"], amsgrad=False, params=list(range(len(self.layout))))
+        return {"state": state, "param_groups": [group]}
+
+    def load_optimizer_state_dict(self, sd: Dict) -> None:
+        names = list(self.layout)
+        steps = set()
+        for i, st in sd.get("state", {}).items():
+            k = names[int(i)]
+            self._view(k, self.exp_avg).copy_(st["exp_avg"].to("cuda"))
+            self._view(k, self.exp_avg_sq).copy_(st["exp_avg_sq"].to("cuda"))
+            steps.add(int(float(st["step"])))
+        if len(steps) > 1:
+            raise ValueError("per-parameter step counts differ: the flat optimizer keeps one")
+        self.step_count = steps.pop() if steps else 0
+        if sd.get("param_groups"):
+            g0 = sd["param_groups"][0]
+            self._opt = dict(lr=g0["lr"], betas=tuple(g0["betas"]), eps=g0["eps"], weight_decay=g0["weight_decay"])
+
+    def grad_norm(self) -> float:
+        capi.check(capi.lib.dfot_sumsq(_P(self.flat_grads), self.numel, _P(self._sumsq), _S()))
+        return float(self._sumsq.sqrt().item())
 
     def state_dict(self) -> Dict[str, torch.Tensor]:
         return {n: t.detach().clone() for n, t in self.p.items()}

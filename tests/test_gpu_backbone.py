@@ -75,8 +75,8 @@ def test_backbone_vs_golden_and_oracle_taps(w64, dma, variant):
 
 def test_large_qk_norm_weights_take_the_running_max_attention(w64):
     """VERDICT r2 weak #4 / ADVICE: the level-2 attention runs without a running max only while the q_norm / k_norm weights bound the
-    scores (sqrt(d) * max over rotary pairs of |w_q||w_k| * log2 e < 64).  With those weights scaled x3 (a trained checkpoint may do
-    that) the bound is exceeded: the engine must report and run the running-max kernel (variant 5) and stay within the same 2e-2 of
+    scores (sqrt(d) * max over rotary pairs of |w_q||w_k| * log2 e < 64).  With those weights scaled x1.9 each (a trained checkpoint may do
+    that; logits x3.6) the bound is exceeded: the engine must report and run the running-max kernel (variant 5) and stay within the same 2e-2 of
     the oracle evaluated on the same weights; the two-stream and the serial block schedules must agree with each other too."""
     from oracle import uvit as ouvit
     ocfg = w64["ocfg"]
@@ -86,11 +86,20 @@ def test_large_qk_norm_weights_take_the_running_max_attention(w64):
     assert small.query("attn_kernel_l2") == 14 and b0 < 64
     for n in params:
         if n.endswith("q_norm.weight") or n.endswith("k_norm.weight"):
-            params[n] = params[n] * 3.0
+            params[n] = params[n] * 1.9
     model = make_model(ocfg, params, 64)
     b1 = model.query("score_bound_l2")
-    assert model.query("attn_kernel_l2") == 5 and b1 >= 64 and abs(b1 / b0 - 9.0) < 1e-3
+    assert model.query("attn_kernel_l2") == 5 and b1 >= 64 and abs(b1 / b0 - 3.61) < 1e-3
     x, k, c, m = (w64[n] for n in ("x", "k", "cond", "mask"))
+    with torch.no_grad():  # block schedules on the ordinary weights: serial chain vs attention / MLP branches on two streams at both levels
+        small.set_option("two_stream", 0)
+        s1 = small(x.cuda(), k.cuda(), c.cuda(), m.cuda()).cpu()
+        small.set_option("two_stream", 3)
+        s2 = small(x.cuda(), k.cuda(), c.cuda(), m.cuda()).cpu()
+    print(f"serial vs two-stream schedule, ordinary weights: rel_l2 {rel(s1, s2):.2e}")
+    # (the opt-in two-stream schedule is not run-to-run reproducible at this size -- csrc/uvit.hip, dfot_uvit_create -- so it is held to
+    # the oracle tolerance, not to bit equality with the serial chain)
+    assert rel(s1, w64["ref"]) < REL_TOL and rel(s2, w64["ref"]) < REL_TOL and rel(s1, s2) < 1e-2
     with torch.no_grad():
         ref = ouvit.forward(params, ocfg, x, k, c, m)
         v = model(x.cuda(), k.cuda(), c.cuda(), m.cuda()).cpu()
@@ -99,18 +108,18 @@ def test_large_qk_norm_weights_take_the_running_max_attention(w64):
         model.set_option("two_stream", 3)
         v2 = model(x.cuda(), k.cuda(), c.cuda(), m.cuda()).cpu()
     r = rel(v, ref)
-    print(f"q/k-norm weights x3: score bound {b0:.1f} -> {b1:.1f}, running-max attention, rel_l2 vs oracle {r:.3e}; "
+    print(f"q/k-norm weights x1.9: score bound {b0:.1f} -> {b1:.1f}, running-max attention, rel_l2 vs oracle {r:.3e}; "
           f"serial vs two-stream (both levels) {rel(v1, v2):.2e}")
     assert torch.isfinite(v).all() and r < REL_TOL and rel(v1, ref) < REL_TOL and rel(v2, ref) < REL_TOL
     # the bound is per rotary PAIR: a large q weight and a large k weight in DIFFERENT pairs do not add up
     p2 = {n: t.clone() for n, t in w64["params"].items()}
     for n in p2:
         if n.endswith("q_norm.weight"):
-            p2[n][0] *= 6.0
+            p2[n][0] *= 3.0
         if n.endswith("k_norm.weight"):
-            p2[n][2] *= 6.0
-    m2 = make_model(ocfg, p2, 64)
-    assert m2.query("score_bound_l2") < 6.5 * b0 and m2.query("attn_kernel_l2") == 14
+            p2[n][2] *= 3.0
+    m2 = make_model(ocfg, p2, 64)   # max|w_q| * max|w_k| would be 9 x the bound (>= 64); per pair it is at most 3 x
+    assert m2.query("score_bound_l2") < 3.3 * b0 < 64 and m2.query("attn_kernel_l2") == 14
 
 
 def test_backbone_is_deterministic_and_does_not_mutate_inputs(w64):
