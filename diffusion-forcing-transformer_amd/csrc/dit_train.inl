@@ -253,20 +253,68 @@ __global__ void qkv_grad_pack_kernel(const bf16* __restrict__ dq, const bf16* __
   *reinterpret_cast<bf16x8*>(out + row * (long)(3 * cdim) + col) = g;
 }
 
+// ---- deterministic two-stage sums --------------------------------------------------------------------------------------------
+// Kernels that used to end in float atomics (bias / norm-weight / embedding sums: run-to-run differences of up to 5e-3 on
+// cancellation-heavy sums) store ONE partial row per workgroup with plain stores; det_sum adds the rows in a fixed order (16 row
+// groups per column, then a fixed tree through LDS), so two runs of one step give bit-identical gradients.
+// det_scratch: grow-only device buffers of the training ops (process lifetime).  A buffer that is outgrown is KEPT (never freed or
+// synchronised on a launch path): kernels in flight that still read the old block stay valid.
+static int det_scratch(int slot, size_t floats, float** out) {
+  static float* buf[4] = {nullptr, nullptr, nullptr, nullptr};
+  static size_t cap[4] = {0, 0, 0, 0};
+  if (cap[slot] < floats) {
+    const size_t want = floats + floats / 4 + 1024;
+    void* p = nullptr;
+    DFOT_CHECK_HIP(hipMalloc(&p, want * sizeof(float)));
+    buf[slot] = reinterpret_cast<float*>(p);
+    cap[slot] = want;
+  }
+  *out = buf[slot];
+  return DFOT_OK;
+}
+// out[b * out_batch_stride + c] (+)= sum_{i < nparts} part[b * batch_stride + i * row_stride + c], c < len
+__global__ __launch_bounds__(1024) void det_sum_kernel(const float* __restrict__ part, long row_stride, long batch_stride, int nparts, int len,
+                                                       float* out, long out_batch_stride, int accumulate) {
+  __shared__ float red[16][64];
+  const int l = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + l;
+  const float* p = part + (long)blockIdx.y * batch_stride + c;
+  float acc = 0.f;
+  if (c < len)
+    for (int i = q; i < nparts; i += 16) acc += p[(long)i * row_stride];
+  red[q][l] = acc;
+  __syncthreads();
+  if (q == 0 && c < len) {
+    float t[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) t[j] = red[2 * j][l] + red[2 * j + 1][l];
+    const float total = ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
+    float* o = out + (long)blockIdx.y * out_batch_stride + c;
+    *o = accumulate ? *o + total : total;
+  }
+}
+static int det_sum(const float* part, long row_stride, int nparts, int len, float* out, bool accumulate, hipStream_t s, int batch = 1,
+                   long batch_stride = 0, long out_batch_stride = 0) {
+  hipLaunchKernelGGL(det_sum_kernel, dim3(cdiv(len, 64), batch), dim3(1024), 0, s, part, row_stride, batch_stride, nparts, len, out, out_batch_stride,
+                     accumulate ? 1 : 0);
+  DFOT_CHECK_HIP(hipGetLastError());
+  return DFOT_OK;
+}
+
 // out[c] += sum_rows src[row][c]   (bf16 source; 128 rows per workgroup)
-__global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16* __restrict__ src, float* __restrict__ out, long rows, int n, long ld) {
+__global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16* __restrict__ src, float* __restrict__ part, long rows, int n, long ld) {
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= n) return;
   const long r0 = (long)blockIdx.y * 128;
   float acc = 0.f;
   for (long r = r0; r < r0 + 128 && r < rows; ++r) acc += bf2f(src[r * ld + c]);
-  atomicAdd(out + c, acc);
+  part[(long)blockIdx.y * n + c] = acc;  // one partial row per row block: det_sum adds them in a fixed order
 }
 // the streaming form: a workgroup owns 128 rows x (LANES * 8) columns; LANES lanes cover one row with 16-byte loads, the 256 / LANES
 // row groups take alternate rows (8 independent loads in flight per thread), the groups are summed through LDS and the workgroup adds
 // its LANES * 8 column sums once.  n, ld multiples of 8, src 16-byte aligned (launcher)
 template <int LANES>
-__global__ __launch_bounds__(256) void colsum_bf16_kernel8(const bf16* __restrict__ src, float* __restrict__ out, long rows, int n, long ld,
+__global__ __launch_bounds__(256) void colsum_bf16_kernel8(const bf16* __restrict__ src, float* __restrict__ part, long rows, int n, long ld,
                                                            int iters) {
   constexpr int GROUPS = 256 / LANES;
   __shared__ float sm[GROUPS][LANES * 8 + 4];
@@ -305,25 +353,34 @@ __global__ __launch_bounds__(256) void colsum_bf16_kernel8(const bf16* __restric
       float t = 0.f;
 #pragma unroll
       for (int g = 0; g < GROUPS; ++g) t += sm[g][threadIdx.x];
-      atomicAdd(out + cc, t);
+      part[(long)blockIdx.y * n + cc] = t;
     }
   }
 }
-static void launch_colsum_bf16(const bf16* src, float* out, long rows, int n, long ld, hipStream_t s) {
+// out[c] += sum_rows src[row][c], deterministic (partial rows + det_sum)
+static int launch_colsum_bf16(const bf16* src, float* out, long rows, int n, long ld, hipStream_t s) {
+  float* part = nullptr;
+  int rc = 0;
   if (n % 8 == 0 && ld % 8 == 0 && ((uintptr_t)src & 15) == 0) {
-    // every workgroup ends in LANES * 8 atomics on the same addresses: with more than ~2048 row blocks per column block the atomics of
-    // one address (serialised in L2) outlast the streaming, so long inputs give a workgroup several 128-row blocks
+    // a workgroup takes several 128-row blocks on long inputs, so that at most ~2048 partial rows remain per column block
     const int xb = n <= 128 ? cdiv(n, 128) : cdiv(n, 256);
     const long yb = cdiv(rows, 128);
     int iters = 1;
     while (iters < 16 && yb / iters * xb > 2048) iters *= 2;
+    const int ny = (int)cdiv(yb, iters);
+    if ((rc = det_scratch(0, (size_t)ny * n, &part))) return rc;
     if (n <= 128)
-      hipLaunchKernelGGL(colsum_bf16_kernel8<16>, dim3(xb, cdiv(yb, iters)), dim3(256), 0, s, src, out, rows, n, ld, iters);
+      hipLaunchKernelGGL(colsum_bf16_kernel8<16>, dim3(xb, ny), dim3(256), 0, s, src, part, rows, n, ld, iters);
     else
-      hipLaunchKernelGGL(colsum_bf16_kernel8<32>, dim3(xb, cdiv(yb, iters)), dim3(256), 0, s, src, out, rows, n, ld, iters);
-  } else {
-    hipLaunchKernelGGL(colsum_bf16_kernel, dim3(cdiv(n, 256), cdiv(rows, 128)), dim3(256), 0, s, src, out, rows, n, ld);
+      hipLaunchKernelGGL(colsum_bf16_kernel8<32>, dim3(xb, ny), dim3(256), 0, s, src, part, rows, n, ld, iters);
+    DFOT_CHECK_HIP(hipGetLastError());
+    return det_sum(part, n, ny, n, out, true, s);
   }
+  const int ny = (int)cdiv(rows, 128);
+  if ((rc = det_scratch(0, (size_t)ny * n, &part))) return rc;
+  hipLaunchKernelGGL(colsum_bf16_kernel, dim3(cdiv(n, 256), ny), dim3(256), 0, s, src, part, rows, n, ld);
+  DFOT_CHECK_HIP(hipGetLastError());
+  return det_sum(part, n, ny, n, out, true, s);
 }
 
 // gradient of the unpatchified output [BT][C][H][W] gathered per token: dyp [rows][64] bf16 (columns >= oc stay zero) and its
@@ -348,8 +405,8 @@ __global__ void final_gather_kernel(const float* __restrict__ dout, bf16* __rest
 // products stay in registers over all chunks, so a workgroup issues hidden * (kdim + 1) atomics once (a 64-row workgroup per launch
 // put 25 M atomics on the 1536 addresses of the 128-wide RE10K embedding: 4.9 ms).  hidden < 256 dividing 256: the 256 / hidden
 // thread groups take alternate rows.
-__global__ __launch_bounds__(256) void pe_wgrad_kernel(const float* __restrict__ dx0, const float* __restrict__ x, float* __restrict__ dW,
-                                                       float* __restrict__ db, int c, int hh, int ww, int ps, int hidden, long rows, int chunks) {
+__global__ __launch_bounds__(256) void pe_wgrad_kernel(const float* __restrict__ dx0, const float* __restrict__ x, float* __restrict__ part,
+                                                       int c, int hh, int ww, int ps, int hidden, long rows, int chunks) {
   extern __shared__ float patch[];  // [64][kdim]
   const int gh = hh / ps, gw = ww / ps, kdim = c * ps * ps;
   const int nsub = (hidden < 256 && 256 % hidden == 0) ? 256 / hidden : 1;
@@ -357,6 +414,8 @@ __global__ __launch_bounds__(256) void pe_wgrad_kernel(const float* __restrict__
   const int o = nsub > 1 ? threadIdx.x % hidden : blockIdx.x * 256 + threadIdx.x;
   const bool live = o < hidden;
   const bool keep = kdim <= 16;  // accumulate over the chunks in registers
+  // the workgroup's partial row: dW [hidden][kdim] then db [hidden]; thread groups (nsub > 1) own one row each and are added by det_sum too
+  float* prow = part + ((long)blockIdx.y * nsub + sub) * ((long)hidden * (kdim + 1));
   float acc[16], bsum = 0.f;
 #pragma unroll
   for (int j = 0; j < 16; ++j) acc[j] = 0.f;
@@ -407,10 +466,10 @@ __global__ __launch_bounds__(256) void pe_wgrad_kernel(const float* __restrict__
             if (k0 + j < kdim) acc[j] += g * patch[r * kdim + k0 + j];
         }
       }
-      if (!keep) {
+      if (!keep) {  // (chunks == 1 for kdim > 16: see the launcher -- every element of the row is stored exactly once)
 #pragma unroll
         for (int j = 0; j < 16; ++j)
-          if (k0 + j < kdim) atomicAdd(dW + (long)o * kdim + k0 + j, acc[j]);
+          if (k0 + j < kdim) prow[(long)o * kdim + k0 + j] = acc[j];
       }
     }
   }
@@ -418,15 +477,26 @@ __global__ __launch_bounds__(256) void pe_wgrad_kernel(const float* __restrict__
   if (keep) {
 #pragma unroll
     for (int j = 0; j < 16; ++j)
-      if (j < kdim) atomicAdd(dW + (long)o * kdim + j, acc[j]);
+      if (j < kdim) prow[(long)o * kdim + j] = acc[j];
   }
-  atomicAdd(db + o, bsum);
+  prow[(long)hidden * kdim + o] = bsum;
 }
-static void launch_pe_wgrad(const float* dx0, const float* x, float* dW, float* db, int c, int hh, int ww, int ps, int hidden, long rows, hipStream_t s) {
+// dW [hidden][kdim] += , db [hidden] += , deterministic (one partial row per workgroup and thread group + det_sum)
+static int launch_pe_wgrad(const float* dx0, const float* x, float* dW, float* db, int c, int hh, int ww, int ps, int hidden, long rows, hipStream_t s) {
   const int kdim = c * ps * ps;
-  const int chunks = rows >= 64L * 16 * 512 ? 16 : (rows >= 64L * 4 * 512 ? 4 : 1);  // keep >= 512 workgroups
-  hipLaunchKernelGGL(pe_wgrad_kernel, dim3(cdiv(hidden, 256), cdiv(rows, 64L * chunks)), dim3(256), 64 * kdim * sizeof(float), s, dx0, x, dW, db, c, hh, ww,
-                     ps, hidden, rows, chunks);
+  // keep >= 512 workgroups; rows of a workgroup are accumulated in registers only for kdim <= 16, else one 64-row chunk per workgroup
+  const int chunks = kdim > 16 ? 1 : (rows >= 64L * 16 * 512 ? 16 : (rows >= 64L * 4 * 512 ? 4 : 1));
+  const int nsub = (hidden < 256 && 256 % hidden == 0) ? 256 / hidden : 1;
+  const int ny = (int)cdiv(rows, 64L * chunks);
+  const long rowlen = (long)hidden * (kdim + 1);
+  float* part = nullptr;
+  int rc = det_scratch(1, (size_t)ny * nsub * rowlen, &part);
+  if (rc) return rc;
+  if (nsub > 1 && hidden * nsub < 256) DFOT_CHECK_HIP(hipMemsetAsync(part, 0, (size_t)ny * nsub * rowlen * sizeof(float), s));
+  hipLaunchKernelGGL(pe_wgrad_kernel, dim3(cdiv(hidden, 256), ny), dim3(256), 64 * kdim * sizeof(float), s, dx0, x, part, c, hh, ww, ps, hidden, rows, chunks);
+  DFOT_CHECK_HIP(hipGetLastError());
+  if ((rc = det_sum(part, rowlen, ny * nsub, hidden * kdim, dW, true, s))) return rc;
+  return det_sum(part + (long)hidden * kdim, rowlen, ny * nsub, hidden, db, true, s);
 }
 
 // ---- MatrixDiTBlock (factorized matrix attention, variant 1) ------------------------------------------------------------

@@ -73,8 +73,7 @@ int conv3_backward(const bf16* x, const bf16* dy, const bf16* w_dgrad, float* dx
     if ((rc = launch_gemm(A_CONV3, E_F32, GEMM_AUTO, g, s))) return rc;
   }
   if (db) {
-    launch_colsum_bf16(dy, db, pix, co, (long)co, s);
-    DFOT_CHECK_HIP(hipGetLastError());
+    if ((rc = launch_colsum_bf16(dy, db, pix, co, (long)co, s))) return rc;
   }
   // weight gradient: one token-axis GEMM per tap, both operands read in place (wgrad.hip conv mode: x rows shifted by the tap, zero outside
   // the image); few output tiles, K = pixels: split over workgroups into partial buffers
@@ -163,14 +162,13 @@ __device__ __forceinline__ float silu_grad(float z) {
   return sg * (1.0f + z * (1.0f - sg));
 }
 
-// pass 1: sums[bt][grp] += (sum dxhat, sum dxhat xhat) over a chunk of pixels; dgamma / dbeta += per-channel sums.  One workgroup =
+// pass 1: per-workgroup partial sums of (sum dxhat, sum dxhat xhat) per group and of dgamma / dbeta per channel.  One workgroup =
 // one (image, pixel chunk); C / 4 lanes cover a pixel row with 16-byte loads and the 256 / (C / 4) lane groups take alternate
 // pixels; the groups are summed through LDS before the atomics.  C a multiple of 128 and at most 1024 (launcher)
 template <bool FILM>
 __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ stats,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                            const bf16* __restrict__ film, float* __restrict__ sums, float* __restrict__ dgamma,
-                                                            float* __restrict__ dbeta, int P, int C, int chunk) {
+                                                            const bf16* __restrict__ film, float* __restrict__ part, int P, int C, int chunk) {
   typedef __attribute__((ext_vector_type(4))) float f4;
   __shared__ f4 red[4][256];  // [quantity][thread]
   const int bt = blockIdx.x, p0 = blockIdx.y * chunk;
@@ -218,13 +216,20 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const float* __restr
     for (int g = 1; g < groups; ++g) {
       dgm += red[0][g * lanes + lane]; dbt += red[1][g * lanes + lane]; s1 += red[2][g * lanes + lane]; s2 += red[3][g * lanes + lane];
     }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      atomicAdd(dgamma + c + j, dgm[j]);
-      atomicAdd(dbeta + c + j, dbt[j]);
+    // the workgroup's partial row (no atomics: det_sum adds the rows in a fixed order): dgamma [C] | dbeta [C] | (sum dxhat, sum dxhat xhat) [32][2]
+    float* prow = part + ((long)bt * gridDim.y + blockIdx.y) * (2L * C + 64);
+    *reinterpret_cast<f4*>(prow + c) = dgm;
+    *reinterpret_cast<f4*>(prow + C + c) = dbt;
+    float a1 = (s1[0] + s1[1]) + (s1[2] + s1[3]), a2 = (s2[0] + s2[1]) + (s2[2] + s2[3]);
+    const int lpg = cpg / 4;  // lanes per group: 1, 2, 4 or 8 consecutive lanes (lanes == C / 4 <= 256, so they sit in this half of the if)
+    for (int o = 1; o < lpg; o <<= 1) {
+      a1 += __shfl_xor(a1, o);
+      a2 += __shfl_xor(a2, o);
     }
-    atomicAdd(sums + ((long)bt * 32 + grp) * 2, (s1[0] + s1[1]) + (s1[2] + s1[3]));
-    atomicAdd(sums + ((long)bt * 32 + grp) * 2 + 1, (s2[0] + s2[1]) + (s2[2] + s2[3]));
+    if (lane % lpg == 0) {
+      prow[2L * C + grp * 2] = a1;
+      prow[2L * C + grp * 2 + 1] = a2;
+    }
   }
 }
 
@@ -285,7 +290,7 @@ __global__ void gn_bwd_apply_kernel(const float* __restrict__ x, const float* __
   }
 }
 
-// sums [BT][32][2] scratch; dgamma / dbeta must be zeroed by the caller (they accumulate)
+// sums [BT][32][2] scratch; dgamma / dbeta are written (fixed-order sums of per-workgroup partial rows)
 int gn_silu_backward(const float* x, const float* dy, const float* stats, const float* gamma, const float* beta, const bf16* film, float* sums,
                      float* dx, bf16* dfilm, float* dgamma, float* dbeta, int bt, int P, int C, bool accumulate, hipStream_t s, long ldf = 0,
                      const float* dres = nullptr, bf16* dx_bf = nullptr) {
@@ -294,16 +299,27 @@ int gn_silu_backward(const float* x, const float* dy, const float* stats, const 
   DFOT_REQUIRE(!accumulate || dres || dx, DFOT_ERR_ARG, "gn_silu_backward: nothing to accumulate onto");
   DFOT_REQUIRE(C % 128 == 0 && C <= 1024 && 256 % (C / 4 < 256 ? C / 4 : 256) == 0 && (film == nullptr) == (dfilm == nullptr), DFOT_ERR_ARG,
                "gn_silu_backward: channels %d must be 128, 256, 512 or 1024", C);
-  DFOT_CHECK_HIP(hipMemsetAsync(sums, 0, (size_t)bt * 64 * sizeof(float), s));
-  const int chunk = P >= 4096 ? 512 : 64;  // pixels per workgroup: every thread ends with 4 atomics, so few, long chunks on the big maps
+  const int chunk = P >= 4096 ? 512 : 64;  // pixels per workgroup
   const dim3 grid(bt, cdiv(P, chunk));
   const long total = (long)bt * P * (C / 4);
+  // deterministic: one partial row per workgroup, then fixed-order sums (dit_train.inl, det_sum): per-image group sums and per-channel
+  // dgamma / dbeta (written, not accumulated)
+  const long rowlen = 2L * C + 64;
+  float* part = nullptr;
+  int rc = det_scratch(2, (size_t)grid.x * grid.y * rowlen, &part);
+  if (rc) return rc;
+  if (film)
+    hipLaunchKernelGGL(gn_bwd_reduce_kernel<true>, grid, dim3(256), 0, s, x, dy, stats, gamma, beta, film, part, P, C, chunk);
+  else
+    hipLaunchKernelGGL(gn_bwd_reduce_kernel<false>, grid, dim3(256), 0, s, x, dy, stats, gamma, beta, film, part, P, C, chunk);
+  DFOT_CHECK_HIP(hipGetLastError());
+  if ((rc = det_sum(part + 2L * C, rowlen, (int)grid.y, 64, sums, false, s, bt, (long)grid.y * rowlen, 64))) return rc;
+  if ((rc = det_sum(part, rowlen, (int)(grid.x * grid.y), C, dgamma, false, s))) return rc;
+  if ((rc = det_sum(part + C, rowlen, (int)(grid.x * grid.y), C, dbeta, false, s))) return rc;
   if (film) {
-    hipLaunchKernelGGL(gn_bwd_reduce_kernel<true>, grid, dim3(256), 0, s, x, dy, stats, gamma, beta, film, sums, dgamma, dbeta, P, C, chunk);
     hipLaunchKernelGGL(gn_bwd_apply_kernel<true>, dim3(cdiv(total, 256)), dim3(256), 0, s, x, dy, stats, gamma, beta, film, sums, dx, dfilm, total, P, C,
                        accumulate ? 1 : 0, ldf, dres, dx_bf);
   } else {
-    hipLaunchKernelGGL(gn_bwd_reduce_kernel<false>, grid, dim3(256), 0, s, x, dy, stats, gamma, beta, film, sums, dgamma, dbeta, P, C, chunk);
     hipLaunchKernelGGL(gn_bwd_apply_kernel<false>, dim3(cdiv(total, 256)), dim3(256), 0, s, x, dy, stats, gamma, beta, film, sums, dx, dfilm, total, P, C,
                        accumulate ? 1 : 0, ldf, dres, dx_bf);
   }
@@ -436,19 +452,21 @@ __global__ __launch_bounds__(256) void rms_film_bwd_kernel(const float* __restri
 #pragma unroll
     for (int j = 0; j < VEC; ++j) red[threadIdx.x >> 6][(i * 64 + lane) * VEC + j] = dwacc[i * VEC + j];
   __syncthreads();
-  for (int c = threadIdx.x; c < C; c += 256) atomicAdd(dw + c, (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]));
+  for (int c = threadIdx.x; c < C; c += 256) dw[(long)blockIdx.x * C + c] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);  // dw = partial rows
 }
 
-// dw must be zeroed by the caller
 int rms_film_backward(const float* x, const float* dxn, const float* w, const bf16* film, float* dx, bf16* dfilm, float* dw, long rows, int hidden,
                       float eps, bool accumulate, hipStream_t s, const float* dres = nullptr, bf16* dx_bf = nullptr) {
   const int grid = (int)(rows / 4 < 512 ? (rows + 3) / 4 : 512);
+  float* part = nullptr;  // one partial dw row per workgroup, added in a fixed order (deterministic; dw is written, not accumulated)
+  int rc = det_scratch(2, (size_t)grid * hidden, &part);
+  if (rc) return rc;
 #define CALL(V, C) \
-  hipLaunchKernelGGL((rms_film_bwd_kernel<V, C>), dim3(grid), dim3(256), 0, s, x, dxn, w, film, dx, dfilm, dw, rows, eps, accumulate ? 1 : 0, dres, dx_bf)
+  hipLaunchKernelGGL((rms_film_bwd_kernel<V, C>), dim3(grid), dim3(256), 0, s, x, dxn, w, film, dx, dfilm, part, rows, eps, accumulate ? 1 : 0, dres, dx_bf)
   DIT_LN_DISPATCH(CALL)
 #undef CALL
   DFOT_CHECK_HIP(hipGetLastError());
-  return DFOT_OK;
+  return det_sum(part, hidden, grid, hidden, dw, false, s);
 }
 
 // q / k of the fused projection: per head RMSNorm (weights qw / kw [d]) then RoPE (then q *= qscale, folded into the attention backward's
@@ -533,7 +551,7 @@ __global__ __launch_bounds__(256) void qknorm_rope_bwd_kernel(const bf16* __rest
   __syncthreads();
   for (int i = threadIdx.x; i < 2 * 64 * EPL; i += 256) {
     const int a = i / (64 * EPL), e = i % (64 * EPL);
-    atomicAdd((a == 0 ? dqw : dkw) + e, (red[0][a][e] + red[1][a][e]) + (red[2][a][e] + red[3][a][e]));
+    dqw[(long)blockIdx.x * (2 * 64 * EPL) + i] = (red[0][a][e] + red[1][a][e]) + (red[2][a][e] + red[3][a][e]);  // dqw = partial rows [2][D]
   }
 }
 
@@ -543,12 +561,16 @@ int qknorm_rope_backward(const bf16* fused, long ld, const bf16* dq, const bf16*
   DFOT_REQUIRE(d == 64 || d == 128, DFOT_ERR_SHAPE, "qknorm_rope_backward: head dim %d not in {64,128}", d);
   const long items = rows * heads;
   const int grid = (int)(items / 4 < 1024 ? (items + 3) / 4 : 1024);
+  float* part = nullptr;  // per-workgroup partial rows (dqw [d] | dkw [d]), added in a fixed order: deterministic, written not accumulated
+  int rc = det_scratch(2, (size_t)grid * 2 * d, &part);
+  if (rc) return rc;
   if (d == 64)
-    hipLaunchKernelGGL(qknorm_rope_bwd_kernel<1>, dim3(grid), dim3(256), 0, s, fused, ld, dq, dk, dv, qw, kw, rope_cs, dfused, ldo, dqw, dkw, rows, ntok, heads, eps);
+    hipLaunchKernelGGL(qknorm_rope_bwd_kernel<1>, dim3(grid), dim3(256), 0, s, fused, ld, dq, dk, dv, qw, kw, rope_cs, dfused, ldo, part, nullptr, rows, ntok, heads, eps);
   else
-    hipLaunchKernelGGL(qknorm_rope_bwd_kernel<2>, dim3(grid), dim3(256), 0, s, fused, ld, dq, dk, dv, qw, kw, rope_cs, dfused, ldo, dqw, dkw, rows, ntok, heads, eps);
+    hipLaunchKernelGGL(qknorm_rope_bwd_kernel<2>, dim3(grid), dim3(256), 0, s, fused, ld, dq, dk, dv, qw, kw, rope_cs, dfused, ldo, part, nullptr, rows, ntok, heads, eps);
   DFOT_CHECK_HIP(hipGetLastError());
-  return DFOT_OK;
+  if ((rc = det_sum(part, 2L * d, grid, d, dqw, false, s))) return rc;
+  return det_sum(part + d, 2L * d, grid, d, dkw, false, s);
 }
 
 }  // namespace
@@ -556,26 +578,22 @@ int qknorm_rope_backward(const bf16* fused, long ld, const bf16* dq, const bf16*
 
 extern "C" {
 using namespace dfot;
-// test entries (dw / dqw / dkw are zeroed here)
+// test entries (dw / dqw / dkw are written, not accumulated)
 int dfot_op_rms_film_bwd(const float* x, const float* dxn, const float* w, const void* film, float eps, float* dx, void* dfilm, float* dw,
                          int64_t rows, int channels, int accumulate_dx, void* stream) {
   DFOT_REQUIRE(x && dxn && w && film && dx && dfilm && dw, DFOT_ERR_ARG, "op_rms_film_bwd: null argument");
-  DFOT_CHECK_HIP(hipMemsetAsync(dw, 0, (size_t)channels * sizeof(float), (hipStream_t)stream));
   return rms_film_backward(x, dxn, w, (const bf16*)film, dx, (bf16*)dfilm, dw, (long)rows, channels, eps, accumulate_dx != 0, (hipStream_t)stream);
 }
 // the same with the residual-path gradient read from `dres` (not modified): dx = dres + the norm's input gradient, out of place
 int dfot_op_rms_film_bwd_res(const float* x, const float* dxn, const float* w, const void* film, float eps, const float* dres, float* dx, void* dx_bf,
                              void* dfilm, float* dw, int64_t rows, int channels, void* stream) {
   DFOT_REQUIRE(x && dxn && w && film && dres && dx && dfilm && dw && dres != dx, DFOT_ERR_ARG, "op_rms_film_bwd_res: null or aliased argument");
-  DFOT_CHECK_HIP(hipMemsetAsync(dw, 0, (size_t)channels * sizeof(float), (hipStream_t)stream));
   return rms_film_backward(x, dxn, w, (const bf16*)film, dx, (bf16*)dfilm, dw, (long)rows, channels, eps, true, (hipStream_t)stream, dres, (bf16*)dx_bf);
 }
 int dfot_op_qknorm_rope_bwd(const void* fused, int ld, const void* dq, const void* dk, const void* dv, const float* qw, const float* kw,
                             const float* rope_cs, float eps, void* dfused, int ldo, float* dqw, float* dkw, int64_t rows, int ntok, int heads, int d,
                             void* stream) {
   DFOT_REQUIRE(fused && dq && dk && dv && qw && kw && rope_cs && dfused && dqw && dkw, DFOT_ERR_ARG, "op_qknorm_rope_bwd: null argument");
-  DFOT_CHECK_HIP(hipMemsetAsync(dqw, 0, (size_t)d * sizeof(float), (hipStream_t)stream));
-  DFOT_CHECK_HIP(hipMemsetAsync(dkw, 0, (size_t)d * sizeof(float), (hipStream_t)stream));
   return qknorm_rope_backward((const bf16*)fused, ld, (const bf16*)dq, (const bf16*)dk, (const bf16*)dv, qw, kw, rope_cs, (bf16*)dfused, ldo, dqw, dkw,
                               (long)rows, ntok, heads, d, eps, (hipStream_t)stream);
 }
@@ -727,9 +745,7 @@ int dfot_op_colsum_bf16(const void* src, int ld, float* out, int64_t rows, int n
   DFOT_REQUIRE(src && out, DFOT_ERR_ARG, "op_colsum_bf16: null argument");
   hipStream_t s = (hipStream_t)stream;
   DFOT_CHECK_HIP(hipMemsetAsync(out, 0, (size_t)n * sizeof(float), s));
-  launch_colsum_bf16((const bf16*)src, out, (long)rows, n, (long)ld, s);
-  DFOT_CHECK_HIP(hipGetLastError());
-  return DFOT_OK;
+  return launch_colsum_bf16((const bf16*)src, out, (long)rows, n, (long)ld, s);
 }
 int dfot_op_rms_film_fwd(const float* x, const float* w, const void* film, float eps, void* out, int64_t rows, int channels, void* stream) {
   DFOT_REQUIRE(x && w && film && out, DFOT_ERR_ARG, "op_rms_film_fwd: null argument");
@@ -907,14 +923,14 @@ __global__ void masked_cast_kernel(const float* __restrict__ src, const uint8_t*
 }
 // fine[bt][2y+a][2x+b][e] += coarse[bt][y][x][e] / 4   (adjoint of one level of the embedding pyramid's average pool), fp32
 // == pool2_bwd_kernel; dnemb[bt][e] = sum_p demb0[bt][p][e] is frames-style column sum over P rows:
-__global__ void rows_sum_kernel(const float* __restrict__ src, float* __restrict__ out, int P, int E) {  // out must be zero (accumulates)
+__global__ void rows_sum_kernel(const float* __restrict__ src, float* __restrict__ part, int P, int E) {  // part [gridDim.z][BT][E] partial sums
   const int bt = blockIdx.y;
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= E) return;
   const int per = (P + gridDim.z - 1) / gridDim.z, p0 = blockIdx.z * per, p1 = p0 + per < P ? p0 + per : P;
   float acc = 0.f;
   for (int p = p0; p < p1; ++p) acc += src[((long)bt * P + p) * E + e];
-  atomicAdd(out + (long)bt * E + e, acc);
+  part[((long)blockIdx.z * gridDim.y + bt) * E + e] = acc;
 }
 // gradient of the ConvTranspose(k = s = p) output [BT][Co][R][R] gathered per input pixel: dpatch [pix][64] bf16, column (co, py, px)
 __global__ void outgrad_gather_kernel(const float* __restrict__ dout, bf16* __restrict__ dpatch, long pix, int R, int co, int ps) {
@@ -955,7 +971,7 @@ int dfot_op_gn_silu_fwd(const float* x, const float* gamma, const float* beta, c
   DFOT_CHECK_HIP(hipGetLastError());
   return DFOT_OK;
 }
-// backward with saved statistics; dx += when accumulate_dx; dgamma / dbeta are zeroed here
+// backward with saved statistics; dx += when accumulate_dx; dgamma / dbeta are written (deterministic two-stage sums)
 int dfot_op_gn_silu_bwd2(const float* x, const float* dy, const float* stats, const float* gamma, const float* beta, const void* film, float* dx,
                          void* dfilm, float* dgamma, float* dbeta, int bt, int pixels, int channels, int accumulate_dx, void* stream) {
   DFOT_REQUIRE(x && dy && stats && gamma && beta && dx && dgamma && dbeta, DFOT_ERR_ARG, "op_gn_silu_bwd2: null argument");
@@ -963,8 +979,6 @@ int dfot_op_gn_silu_bwd2(const float* x, const float* dy, const float* stats, co
   void* sums = nullptr;
   int rc = op_scratch(4, (size_t)bt * 64 * sizeof(float), &sums);
   if (rc) return rc;
-  DFOT_CHECK_HIP(hipMemsetAsync(dgamma, 0, (size_t)channels * sizeof(float), s));
-  DFOT_CHECK_HIP(hipMemsetAsync(dbeta, 0, (size_t)channels * sizeof(float), s));
   return gn_silu_backward(x, dy, stats, gamma, beta, (const bf16*)film, (float*)sums, dx, (bf16*)dfilm, dgamma, dbeta, bt, pixels, channels,
                           accumulate_dx != 0, s);
 }
@@ -976,8 +990,6 @@ int dfot_op_gn_silu_bwd3(const float* x, const float* dy, const float* stats, co
   void* sums = nullptr;
   int rc = op_scratch(4, (size_t)bt * 64 * sizeof(float), &sums);
   if (rc) return rc;
-  DFOT_CHECK_HIP(hipMemsetAsync(dgamma, 0, (size_t)channels * sizeof(float), s));
-  DFOT_CHECK_HIP(hipMemsetAsync(dbeta, 0, (size_t)channels * sizeof(float), s));
   return gn_silu_backward(x, dy, stats, gamma, beta, (const bf16*)film, (float*)sums, dx, (bf16*)dfilm, dgamma, dbeta, bt, pixels, channels,
                           accumulate_dx != 0, s, (long)dfilm_ld);
 }
@@ -993,8 +1005,6 @@ int dfot_op_gn_silu_bwd4(const float* x, const float* dy, const float* stats, co
   void* sums = nullptr;
   int rc = op_scratch(4, (size_t)bt * 64 * sizeof(float), &sums);
   if (rc) return rc;
-  DFOT_CHECK_HIP(hipMemsetAsync(dgamma, 0, (size_t)channels * sizeof(float), s));
-  DFOT_CHECK_HIP(hipMemsetAsync(dbeta, 0, (size_t)channels * sizeof(float), s));
   return gn_silu_backward(x, dy, stats, gamma, beta, (const bf16*)film, (float*)sums, dx, (bf16*)dfilm, dgamma, dbeta, bt, pixels, channels,
                           dres != nullptr, s, (long)dfilm_ld, dres, (bf16*)dx_bf);
 }
@@ -1073,10 +1083,14 @@ int dfot_op_emb_pyramid(const void* emb0, void* emb1, void* emb2, void* emb3, in
   return launch_emb_pyramid((const bf16*)emb0, (bf16*)emb1, (bf16*)emb2, (bf16*)emb3, bt, r0, e, (hipStream_t)stream);
 }
 int dfot_op_rows_sum(const float* src, float* out, int bt, int pixels, int e, void* stream) {
-  DFOT_CHECK_HIP(hipMemsetAsync(out, 0, (size_t)bt * e * sizeof(float), (hipStream_t)stream));
-  hipLaunchKernelGGL(rows_sum_kernel, dim3(cdiv(e, 256), bt, pixels >= 2048 ? 64 : 1), dim3(256), 0, (hipStream_t)stream, src, out, pixels, e);
+  hipStream_t s = (hipStream_t)stream;
+  const int nz = pixels >= 2048 ? 64 : 1;
+  float* part = nullptr;  // deterministic: partial sums per pixel chunk, then a fixed-order sum
+  int rc = det_scratch(2, (size_t)nz * bt * e, &part);
+  if (rc) return rc;
+  hipLaunchKernelGGL(rows_sum_kernel, dim3(cdiv(e, 256), bt, nz), dim3(256), 0, s, src, part, pixels, e);
   DFOT_CHECK_HIP(hipGetLastError());
-  return DFOT_OK;
+  return det_sum(part, (long)bt * e, nz, bt * e, out, false, s);
 }
 int dfot_op_cond_repack(const float* cond, void* a, int bt, int res, int cdim, int kpad, void* stream) {
   return launch_cond_repack(cond, (bf16*)a, bt, res, cdim, kpad, (hipStream_t)stream);
@@ -1091,9 +1105,7 @@ int dfot_op_embed_input_wgrad(const float* dx0, const float* x, float* dw, float
   const int kdim = cin * ps * ps;
   DFOT_CHECK_HIP(hipMemsetAsync(dw, 0, (size_t)c0 * kdim * sizeof(float), s));
   DFOT_CHECK_HIP(hipMemsetAsync(db, 0, (size_t)c0 * sizeof(float), s));
-  launch_pe_wgrad(dx0, x, dw, db, cin, res, res, ps, c0, rows, s);
-  DFOT_CHECK_HIP(hipGetLastError());
-  return DFOT_OK;
+  return launch_pe_wgrad(dx0, x, dw, db, cin, res, res, ps, c0, rows, s);
 }
 int dfot_op_project_output(const float* x0, const float* w, const float* b, float* out, int bt, int res, int c0, int cout, void* stream) {
   return launch_project_output(x0, w, b, out, bt, res, c0, cout, (hipStream_t)stream);

@@ -140,6 +140,7 @@ class TransformerBlockTrain:
         """dy fp32 [B*N][C] -> (dx fp32, demb fp32 [B*N][E]); parameter gradients in self.grads (reference names).
         demb_acc: the level's embedding-gradient accumulator, added to in the GEMM epilogue (no separate pass).
         dy_bf: dy already in bf16 (the block above wrote it next to its dx: self.dx_bf), else it is cast here"""
+        ck = None
         if "xn" not in self.saved:  # gradient checkpointing: only the block's inputs were kept -- run its forward again (same kernels, same
             ck = self.saved        # dropout mask: bit-identical activations), then the ordinary backward
             self.forward(ck["x"], ck["emb"], ck["batch"], ck["mlp_mask"])
@@ -176,6 +177,8 @@ class TransformerBlockTrain:
             "attn_out.weight": dw_out[:, :c].contiguous(), "attn_out.bias": db_out, "mlp_out.2.weight": dw_out[:, c:].contiguous(),
             "mlp_out.2.bias": db_out.clone(),
         }
+        if ck is not None:
+            self.saved = ck  # release the recomputed activations
         return dx, demb
 
 
@@ -242,6 +245,7 @@ class ResBlockTrain:
         """dfilm_out: a [rows][2C] bf16 column block of the level's FiLM-gradient matrix; the block then leaves the embedding gradient
         (dfilm W_e over the level's concatenated K) to the caller instead of adding its own [rows][E] product to demb_acc.
         dy_bf: dy already in bf16 (the block above left it in self.dx_bf), else it is cast here"""
+        ck = None
         if "h1" not in self.saved:  # gradient checkpointing (see TransformerBlockTrain.backward)
             ck = self.saved
             self.forward(ck["x"], ck["emb"], *ck["geom"])
@@ -267,6 +271,8 @@ class ResBlockTrain:
             "in_layers.0.weight": dg1, "in_layers.0.bias": dbe1, "in_layers.2.weight": dw1, "in_layers.2.bias": db1,
             "out_norm.weight": dg2, "out_norm.bias": dbe2, "out_rest.1.weight": dw2, "out_rest.1.bias": db2,
         }
+        if ck is not None:
+            self.saved = ck  # release the recomputed activations
         return dx, demb
 
 
