@@ -91,6 +91,7 @@ class UViT3DPose(nn.Module):
         self._train_names = None     # parameter names in named_parameters() order (operator input order of the training form)
         self._trainer = None         # uvit_train.UViT3DPoseTrainer on this module's weights, built at the first training forward
         self._trainer_sig = None
+        self.live_frames = None      # see _forward_impl: set by the sampler around its backbone calls, None otherwise
         self._train_stamp = 0        # counts training forwards: the autograd ctx of a forward remembers its number (ops._train_setup_context)
         self._dropout_generator: Optional[torch.Generator] = None  # set a CUDA generator to enable the MLP-branch nn.Dropout in train()
 
@@ -312,8 +313,16 @@ class UViT3DPose(nn.Module):
             self._cond_key = key
             self._cond_refs = (external_cond, external_cond_mask)  # keep the keyed tensors alive
         out = torch.empty_like(xf)
-        capi.check(capi.lib.dfot_uvit_forward_cached(self._handle, capi.ptr(xf, torch.float32, "x"),
-                                                     capi.ptr(kf, torch.float32, "noise_levels"), capi.ptr(out), b, capi.stream_ptr()))
+        live = self.live_frames
+        if live is not None:
+            # sampler-only hint (sampler.py): uint8 (B, T), 0 = the caller discards this frame's output -> it is not computed past the
+            # last transformer block and its rows of the result are zeros.  A plain forward(x, k, cond, mask) never sets it.
+            if tuple(live.shape) != (b, self.temporal_length) or live.dtype != torch.uint8 or not live.is_contiguous():
+                raise ValueError(f"live_frames must be a contiguous uint8 tensor of shape {(b, self.temporal_length)}")
+            capi.require_device(dev, live_frames=live)
+        capi.check(capi.lib.dfot_uvit_forward_cached_live(self._handle, capi.ptr(xf, torch.float32, "x"),
+                                                          capi.ptr(kf, torch.float32, "noise_levels"), capi.ptr(out), b,
+                                                          capi.ptr(live, torch.uint8, "live_frames"), capi.stream_ptr()))
         return out.to(x.dtype)
 
     def read_tap(self, name: str, channels: int, level: int, batch: int) -> torch.Tensor:

@@ -16,6 +16,9 @@ struct GemmArgs {
   int M = 0, N = 0, K = 0;
   int H = 0, Wd = 0, Cin = 0;
   const bf16* zeros = nullptr;  // >= 128 B of zeros (conv padding source)
+  // conv: optional per-image flags (device uint8 [M / (H * Wd)]); the tiles of an image whose flag is 0 exit at once (no loads, no stores,
+  // no GroupNorm partials): images whose output the caller discards.  A tile must lie inside one image (launcher)
+  const uint8_t* live = nullptr;
   // epilogue
   const float* bias = nullptr;
   float* out_f32 = nullptr;

@@ -83,6 +83,9 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int tile_inde
   const int bid = ksplit > 1 ? xcd_remap(tile_index / ksplit, tile_count / ksplit, g.xcd) : xcd_remap(tile_index, tile_count, g.xcd);
   const int tn = bid % tiles_n, tm = bid / tiles_n;
   const int m0 = tm * BM_T, n0 = tn * BN_T;
+  if constexpr (AMODE == A_CONV3) {
+    if (g.live && !g.live[(unsigned)m0 / (unsigned)(g.H * g.Wd)]) return;  // workgroup-uniform, before any barrier
+  }
   int nk = g.K / BKT;
   long kbeg = 0;  // first element of this workgroup's K range
   if (ksplit > 1) {
@@ -725,7 +728,7 @@ int launch_gemm(int amode, int epi, int variant, const GemmArgs& g, hipStream_t 
   if (variant == GEMM_AUTO) variant = gemm_pick_variant(amode, g.M, g.N, g.K);
   if (variant == GEMM_DMA_128_KS2 && epi == E_QKV) variant = GEMM_DMA_128;  // the QKV epilogue has workgroup barriers
   if (variant == GEMM_DMA_128x192 && epi == E_QKV) variant = GEMM_DMA_128;
-  if (variant == GEMM_DMA_256x192 && epi == E_QKV) variant = GEMM_DMA_256x256;  // its head pairing needs 128-aligned tiles
+  if (variant == GEMM_DMA_256x192 && epi == E_QKV && g.d != 64) variant = GEMM_DMA_256x256;  // the d = 128 head pairing needs 128-aligned tiles
   const int bm = variant == GEMM_DMA_512x128 ? 512 : (variant == GEMM_DMA3_256 || variant == GEMM_DMA_256x256 || variant == GEMM_DMA_256x128 || variant == GEMM_DMA_256x256_W128 || variant == GEMM_DMA_256x192 || variant == GEMM_DMA_256x144) ? 256 : 128;
   DFOT_REQUIRE(g.M > 0 && g.M % bm == 0, DFOT_ERR_SHAPE, "gemm: M=%d must be a positive multiple of %d", g.M, bm);
   DFOT_REQUIRE(g.K > 0 && g.K % BK == 0, DFOT_ERR_SHAPE, "gemm: K=%d must be a positive multiple of %d", g.K, BK);
@@ -737,6 +740,7 @@ int launch_gemm(int amode, int epi, int variant, const GemmArgs& g, hipStream_t 
     DFOT_REQUIRE(g.Cin % BK == 0 && g.K == 9 * g.Cin, DFOT_ERR_SHAPE, "conv3x3: Cin=%d must be a multiple of %d", g.Cin, BK);
     DFOT_REQUIRE(g.zeros != nullptr, DFOT_ERR_ARG, "conv3x3: zero page missing");
     DFOT_REQUIRE(g.H > 0 && g.Wd > 0 && g.M % (g.H * g.Wd) == 0, DFOT_ERR_SHAPE, "conv3x3: M=%d not a whole number of %dx%d images", g.M, g.H, g.Wd);
+    DFOT_REQUIRE(!g.live || (g.H * g.Wd) % bm == 0, DFOT_ERR_SHAPE, "conv3x3: live-image flags need whole %d-row tiles per %dx%d image", bm, g.H, g.Wd);
   }
   if (epi == E_QKV) {
     DFOT_REQUIRE(g.q && g.k && g.v && g.qw && g.kw && g.rope_cs && (g.out2 || g.N == g.split), DFOT_ERR_ARG, "qkv epilogue: null pointer");

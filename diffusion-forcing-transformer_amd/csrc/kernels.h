@@ -11,8 +11,10 @@ int launch_embed_input(const float* x, const float* w, const float* b, float* ou
                        hipStream_t s);
 int launch_cond_repack(const float* cond, bf16* a, int bt, int res, int cdim, int kpad, hipStream_t s);
 int launch_emb_pyramid(const bf16* emb0, bf16* emb1, bf16* emb2, bf16* emb3, int bt, int r0, int e, hipStream_t s);
+// live (optional, device uint8 [bt]): frames whose flag is 0 are SKIPPED by the kernels that take it -- nothing read, nothing written
+// (project_output writes zeros) -- for frames whose output the caller discards (the sampler's context tokens), uvit.hip
 int launch_project_output(const float* x0, const float* w, const float* b, float* out, int bt, int res, int c0, int cout,
-                          hipStream_t s);
+                          hipStream_t s, const uint8_t* live = nullptr);
 // ---- norms ----
 // GroupNorm(32): partial[bt][nblk][32][2] = (sum, sumsq) per block of pixels (standalone kernels below, or the fused
 // GEMM epilogue with nblk = pixels/64); launch_gn_finalize reduces them deterministically to stats[bt][32][2] = (mean, rstd)
@@ -21,7 +23,7 @@ int launch_gn_partial_bf16(const bf16* x, float* partial, int bt, int pixels, in
 int launch_gn_finalize(const float* partial, float* stats, int bt, int nblk, int pixels, int c, float eps, hipStream_t s);
 int gn_partial_blocks(int pixels);
 int launch_gn_apply_silu(const float* x, const float* stats, const float* gamma, const float* beta, bf16* out, int bt,
-                         int pixels, int c, hipStream_t s);
+                         int pixels, int c, hipStream_t s, const uint8_t* live = nullptr);
 // FiLM with the per-window pose cache (see kernels.hip). One FilmChunk per 64 rows of every FiLM projection:
 struct FilmChunk {
   const bf16* w;   // &W_film[row0][0], row stride = emb dim
@@ -32,7 +34,7 @@ struct FilmChunk {
 int launch_film_vec(const FilmChunk* table, int chunks, const float* nemb, float* sv, int bt, int e, hipStream_t s);
 int launch_gn_film_silu(const bf16* h, const float* stats, const float* gamma, const float* beta, const bf16* fcache,
                         const float* sv, const uint8_t* cond_mask, bf16* out, int bt, int pixels, int c, int tokens,
-                        hipStream_t s);
+                        hipStream_t s, const uint8_t* live = nullptr);
 // a residual stream whose last out-projection is still two or three K-slice partials: x += bias[c] + s0 + s1 (+ s2) (run_tr_block, uvit.hip)
 struct RmsPending {
   float* x;
@@ -46,8 +48,8 @@ int launch_rms_film(const float* x, const float* w, const bf16* fcache, const fl
 
 // ---- resampling / skips ----
 int launch_pool2_bf16(const float* x, bf16* out, int bt, int h, int w, int c, hipStream_t s);
-int launch_sub_bf16(const float* a, const float* b, bf16* out, long n, hipStream_t s);
-int launch_upsample_add(const float* t, const float* skip, float* out, int bt, int h, int w, int c, hipStream_t s);
+int launch_sub_bf16(const float* a, const float* b, bf16* out, long n, hipStream_t s, const uint8_t* live = nullptr, long frame_elems = 0);
+int launch_upsample_add(const float* t, const float* skip, float* out, int bt, int h, int w, int c, hipStream_t s, const uint8_t* live = nullptr);
 // ---- pose ----
 int launch_ray_encode(const float* poses, float* out, int b, int t, int res, int normalized, hipStream_t s);
 // ---- sampler ----

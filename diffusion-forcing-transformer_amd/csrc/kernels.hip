@@ -295,7 +295,7 @@ __device__ __forceinline__ void halve_exchange(float* acc, int lane) {
 template <int COUT>
 __global__ __launch_bounds__(256) void project_output_c128_kernel(const float* __restrict__ x0, const float* __restrict__ w,
                                                                   const float* __restrict__ b, float* __restrict__ out, unsigned npix,
-                                                                  int res) {
+                                                                  int res, const uint8_t* __restrict__ live_frames) {
   constexpr int NO = COUT * 4;
   const int lane = threadIdx.x & 63, sub = lane & 15;
   float wt[8][NO];
@@ -310,10 +310,12 @@ __global__ __launch_bounds__(256) void project_output_c128_kernel(const float* _
   for (unsigned it = 0; it < iters; ++it) {
     const unsigned pix = group + it * ngroups;
     const bool live = pix < npix;
+    // frames whose output the caller discards (context tokens of the sampler): zeros are written, nothing is read
+    const bool dead = live && live_frames && !live_frames[pix / (r0 * r0)];
     float acc[16];
 #pragma unroll
     for (int o = 0; o < 16; ++o) acc[o] = 0.f;
-    if (live) {
+    if (live && !dead) {
       const float* xp = x0 + (long)pix * 128 + sub * 8;
       const float4v a = *reinterpret_cast<const float4v*>(xp), c = *reinterpret_cast<const float4v*>(xp + 4);
 #pragma unroll
@@ -330,19 +332,19 @@ __global__ __launch_bounds__(256) void project_output_c128_kernel(const float* _
       const int px = (int)(pix % r0), py = (int)((pix / r0) % r0);
       const long bt = pix / (r0 * r0);
       const int co = sub >> 2, dy = (sub >> 1) & 1, dx = sub & 1;
-      out[((bt * COUT + co) * res + 2 * py + dy) * (long)res + 2 * px + dx] = acc[0] + bias;
+      out[((bt * COUT + co) * res + 2 * py + dy) * (long)res + 2 * px + dx] = dead ? 0.f : acc[0] + bias;
     }
   }
 }
 
 int launch_project_output(const float* x0, const float* w, const float* b, float* out, int bt, int res, int c0, int cout,
-                          hipStream_t s) {
+                          hipStream_t s, const uint8_t* live) {
   DFOT_REQUIRE(cout <= 3 && c0 % 4 == 0, DFOT_ERR_SHAPE, "project_output: cout=%d (<=3), c0=%d", cout, c0);
   const long npix = (long)bt * (res / 2) * (res / 2);
   DFOT_REQUIRE(npix < (1L << 31), DFOT_ERR_SHAPE, "project_output: %ld pixels exceed the 32-bit index range", npix);
   if (c0 == 128 && cout == 3) {
     const long wgs = cdiv(npix, 16);
-    hipLaunchKernelGGL(project_output_c128_kernel<3>, dim3((unsigned)(wgs < 4096 ? wgs : 4096)), dim3(256), 0, s, x0, w, b, out, (unsigned)npix, res);
+    hipLaunchKernelGGL(project_output_c128_kernel<3>, dim3((unsigned)(wgs < 4096 ? wgs : 4096)), dim3(256), 0, s, x0, w, b, out, (unsigned)npix, res, live);
     DFOT_CHECK_HIP(hipGetLastError());
     return DFOT_OK;
   }
@@ -453,13 +455,14 @@ int launch_gn_partial_bf16(const bf16* x, float* partial, int bt, int pixels, in
 // GroupNorm apply + SiLU, fp32 in -> bf16 out (feeds the 3x3 conv's A operand)
 __global__ void gn_apply_silu_kernel(const float* __restrict__ x, const float* __restrict__ stats,
                                      const float* __restrict__ gamma, const float* __restrict__ beta,
-                                     bf16* __restrict__ out, long total8, int pixels, int c) {
+                                     bf16* __restrict__ out, long total8, int pixels, int c, const uint8_t* __restrict__ live) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= total8) return;
   const unsigned iu = (unsigned)idx, cq = (unsigned)(c / 8);  // 32-bit index arithmetic (launcher: total < 2^31)
   const int c8 = (int)(iu % cq);
   const long pix = iu / cq;
   const int bt = (int)((unsigned)pix / (unsigned)pixels);
+  if (live && !live[bt]) return;  // a frame whose output is discarded: nothing read, nothing written
   const int cpg = c / 32;
   const float* src = x + pix * c + c8 * 8;
   const float4v a = *reinterpret_cast<const float4v*>(src);
@@ -478,11 +481,11 @@ __global__ void gn_apply_silu_kernel(const float* __restrict__ x, const float* _
 }
 
 int launch_gn_apply_silu(const float* x, const float* stats, const float* gamma, const float* beta, bf16* out, int bt,
-                         int pixels, int c, hipStream_t s) {
+                         int pixels, int c, hipStream_t s, const uint8_t* live) {
   const long total8 = (long)bt * pixels * (c / 8);
   DFOT_REQUIRE(total8 < (1L << 31), DFOT_ERR_SHAPE, "groupnorm apply: %ld work items exceed the 32-bit index range", total8);
   hipLaunchKernelGGL(gn_apply_silu_kernel, dim3(cdiv(total8, 256)), dim3(256), 0, s, x, stats, gamma, beta, out, total8,
-                     pixels, c);
+                     pixels, c, live);
   DFOT_CHECK_HIP(hipGetLastError());
   return DFOT_OK;
 }
@@ -613,13 +616,14 @@ __global__ void gn_film_silu_kernel(const bf16* __restrict__ h, const float* __r
                                     const float* __restrict__ gamma, const float* __restrict__ beta,
                                     const bf16* __restrict__ fcache, const float* __restrict__ sv,
                                     const uint8_t* __restrict__ cond_mask, bf16* __restrict__ out, long total8, int pixels,
-                                    int c, int tokens) {
+                                    int c, int tokens, const uint8_t* __restrict__ live) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= total8) return;
   const unsigned iu = (unsigned)idx, cq = (unsigned)(c / 8);  // 32-bit index arithmetic (launcher: total < 2^31)
   const int c8 = (int)(iu % cq);
   const long pix = iu / cq;
   const int bt = (int)((unsigned)pix / (unsigned)pixels);
+  if (live && !live[bt]) return;
   const int cpg = c / 32;
   const int c0 = c8 * 8;
   const int col = (c0 >> 5) * 64 + (c0 & 31);  // scale columns col..col+7, shift columns col+32..col+39
@@ -654,11 +658,11 @@ __global__ void gn_film_silu_kernel(const bf16* __restrict__ h, const float* __r
 }
 int launch_gn_film_silu(const bf16* h, const float* stats, const float* gamma, const float* beta, const bf16* fcache,
                         const float* sv, const uint8_t* cond_mask, bf16* out, int bt, int pixels, int c, int tokens,
-                        hipStream_t s) {
+                        hipStream_t s, const uint8_t* live) {
   const long total8 = (long)bt * pixels * (c / 8);
   DFOT_REQUIRE(total8 < (1L << 31), DFOT_ERR_SHAPE, "groupnorm apply: %ld work items exceed the 32-bit index range", total8);
   hipLaunchKernelGGL(gn_film_silu_kernel, dim3(cdiv(total8, 256)), dim3(256), 0, s, h, stats, gamma, beta, fcache, sv,
-                     cond_mask, out, total8, pixels, c, tokens);
+                     cond_mask, out, total8, pixels, c, tokens, live);
   DFOT_CHECK_HIP(hipGetLastError());
   return DFOT_OK;
 }
@@ -787,9 +791,11 @@ int launch_pool2_bf16(const float* x, bf16* out, int bt, int h, int w, int c, hi
   return DFOT_OK;
 }
 
-__global__ void sub_bf16_kernel(const float* __restrict__ a, const float* __restrict__ b, bf16* __restrict__ out, long n4) {
+__global__ void sub_bf16_kernel(const float* __restrict__ a, const float* __restrict__ b, bf16* __restrict__ out, long n4,
+                                const uint8_t* __restrict__ live, long frame4) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= n4) return;
+  if (live && !live[idx / frame4]) return;
   const float4v x = *reinterpret_cast<const float4v*>(a + idx * 4);
   const float4v y = *reinterpret_cast<const float4v*>(b + idx * 4);
   bf16x4 o;
@@ -797,16 +803,16 @@ __global__ void sub_bf16_kernel(const float* __restrict__ a, const float* __rest
   for (int j = 0; j < 4; ++j) o[j] = f2bf(x[j] - y[j]);
   *reinterpret_cast<bf16x4*>(out + idx * 4) = o;
 }
-int launch_sub_bf16(const float* a, const float* b, bf16* out, long n, hipStream_t s) {
-  DFOT_REQUIRE(n % 4 == 0, DFOT_ERR_SHAPE, "sub: length %ld must be a multiple of 4", n);
-  hipLaunchKernelGGL(sub_bf16_kernel, dim3(cdiv(n / 4, 256)), dim3(256), 0, s, a, b, out, n / 4);
+int launch_sub_bf16(const float* a, const float* b, bf16* out, long n, hipStream_t s, const uint8_t* live, long frame_elems) {
+  DFOT_REQUIRE(n % 4 == 0 && (!live || (frame_elems > 0 && frame_elems % 4 == 0)), DFOT_ERR_SHAPE, "sub: length %ld must be a multiple of 4", n);
+  hipLaunchKernelGGL(sub_bf16_kernel, dim3(cdiv(n / 4, 256)), dim3(256), 0, s, a, b, out, n / 4, live, live ? frame_elems / 4 : 1L);
   DFOT_CHECK_HIP(hipGetLastError());
   return DFOT_OK;
 }
 
 // out[bt][y][x][:] = t[bt][y/2][x/2][:] + skip[bt][y][x][:]   (h,w are the LOW-resolution sizes)
 __global__ void upsample_add_kernel(const float* __restrict__ t, const float* __restrict__ skip, float* __restrict__ out,
-                                    long total4, int h, int w, int c) {
+                                    long total4, int h, int w, int c, const uint8_t* __restrict__ live) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= total4) return;
   const unsigned iu = (unsigned)idx, cq = (unsigned)(c / 4), w2 = (unsigned)(2 * w), h2 = (unsigned)(2 * h);
@@ -814,14 +820,15 @@ __global__ void upsample_add_kernel(const float* __restrict__ t, const float* __
   const unsigned pix = iu / cq;
   const int x = (int)(pix % w2), y = (int)((pix / w2) % h2);
   const long bt = pix / (w2 * h2);
+  if (live && !live[bt]) return;
   const float4v a = *reinterpret_cast<const float4v*>(t + ((bt * h + y / 2) * w + x / 2) * (long)c + c4 * 4);
   const float4v b = *reinterpret_cast<const float4v*>(skip + pix * c + c4 * 4);
   *reinterpret_cast<float4v*>(out + pix * c + c4 * 4) = a + b;
 }
-int launch_upsample_add(const float* t, const float* skip, float* out, int bt, int h, int w, int c, hipStream_t s) {
+int launch_upsample_add(const float* t, const float* skip, float* out, int bt, int h, int w, int c, hipStream_t s, const uint8_t* live) {
   const long total4 = (long)bt * 4 * h * w * (c / 4);
   DFOT_REQUIRE(total4 < (1L << 31), DFOT_ERR_SHAPE, "upsample_add: %ld work items exceed the 32-bit index range", total4);
-  hipLaunchKernelGGL(upsample_add_kernel, dim3(cdiv(total4, 256)), dim3(256), 0, s, t, skip, out, total4, h, w, c);
+  hipLaunchKernelGGL(upsample_add_kernel, dim3(cdiv(total4, 256)), dim3(256), 0, s, t, skip, out, total4, h, w, c, live);
   DFOT_CHECK_HIP(hipGetLastError());
   return DFOT_OK;
 }

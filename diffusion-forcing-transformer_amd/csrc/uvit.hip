@@ -376,7 +376,7 @@ __global__ void add_vec_kernel(const float* a, const float* b, float* o, int n) 
 // sums (conv1 -> statistics of h; conv2 / Downsample conv -> statistics of the next block's input); only the first block
 // after embed_input / upsample_add needs the standalone partial kernel.  h->gn1_nblk > 0 means gn_partial already holds
 // the partials of X[lvl].
-static int run_res_block(dfot_uvit_s* h, const ResW& w, int lvl, int bt, hipStream_t s) {
+static int run_res_block(dfot_uvit_s* h, const ResW& w, int lvl, int bt, hipStream_t s, const uint8_t* live = nullptr) {
   const int c = w.c, rr = h->r[lvl], pix = rr * rr;
   const int m = bt * pix;
   const int slots = pix / 64;
@@ -389,19 +389,19 @@ static int run_res_block(dfot_uvit_s* h, const ResW& w, int lvl, int bt, hipStre
   }
   if ((rc = launch_gn_finalize(h->gn_partial, h->gn_stats, bt, h->gn1_nblk, pix, c, h->cfg.eps, s))) return rc;
   h->gn1_nblk = 0;
-  if ((rc = launch_gn_apply_silu(xi, h->gn_stats, w.g1, w.be1, h->s1, bt, pix, c, s))) return rc;
+  if ((rc = launch_gn_apply_silu(xi, h->gn_stats, w.g1, w.be1, h->s1, bt, pix, c, s, live))) return rc;
   GemmArgs g;
   g.A = h->s1; g.W = w.w1; g.M = m; g.N = c; g.K = 9 * c; g.H = rr; g.Wd = rr; g.Cin = c; g.zeros = h->zeros;
-  g.bias = w.bias1; g.out_bf16 = h->hbf; g.ldo = c;
+  g.bias = w.bias1; g.out_bf16 = h->hbf; g.ldo = c; g.live = live;
   g.gn_part = h->gn_partial2; g.gn_rows_per_bt = pix; g.gn_cpg = c / 32;
   if ((rc = launch_gemm(A_CONV3, E_BF16, h->gemm_variant, g, s))) return rc;
   if ((rc = launch_gn_finalize(h->gn_partial2, h->gn_stats, bt, slots, pix, c, h->cfg.eps, s))) return rc;
   if ((rc = launch_gn_film_silu(h->hbf, h->gn_stats, w.g2, w.be2, w.fcache, h->sv + w.sv_off,
-                                h->have_mask ? h->cond_mask : nullptr, h->s1, bt, pix, c, h->T, s)))
+                                h->have_mask ? h->cond_mask : nullptr, h->s1, bt, pix, c, h->T, s, live)))
     return rc;
   GemmArgs o;
   o.A = h->s1; o.W = w.w2; o.M = m; o.N = c; o.K = 9 * c; o.H = rr; o.Wd = rr; o.Cin = c; o.zeros = h->zeros;
-  o.bias = w.bias2; o.out_f32 = x; o.resid = xi; o.ldo = c;
+  o.bias = w.bias2; o.out_f32 = x; o.resid = xi; o.ldo = c; o.live = live;
   o.gn_part = h->gn_partial; o.gn_rows_per_bt = pix; o.gn_cpg = c / 32;
   if ((rc = launch_gemm(A_CONV3, E_F32, h->gemm_variant, o, s))) return rc;
   h->xin[lvl] = x;
@@ -456,7 +456,12 @@ static int run_tr_block(dfot_uvit_s* h, const TrW& w, int lvl, int batch, hipStr
   p.out2 = h->cat + c; p.ldo2 = 5 * c; p.split = 3 * c;
   p.q = h->q; p.k = h->k; p.v = h->v; p.qw = w.qw; p.kw = w.kw; p.rope_cs = h->rope_cs[lvl]; p.heads = h->heads; p.d = d;
   p.ntok = n; p.qscale = 1.4426950408889634f / sqrtf((float)d); p.eps = h->cfg.eps;
-  if ((rc = launch_gemm(A_DENSE, E_QKV, h->gemm_variant, p, s))) return rc;
+  // d = 64 (level 2: N = 7 x 576 = 21 x 192): 256x192 tiles in the persistent tile loop (the epilogue stores of a tile drain under the next
+  // tile's first loads) measured 109.5 vs 116.8 us for the 256x256 tiles on this shape (tools/bench_ops.py, plain epilogue)
+  static const int qkv192 = tuning_flag("UVIT_QKV_192", 0);  // ... but INSIDE the model the 256x256 form wins (9.79 vs 9.72 frames/s, two same-box rounds): off
+  int qv = h->gemm_variant;
+  if (qkv192 && qv == GEMM_AUTO && d == 64 && c % 192 == 0 && m % 256 == 0 && (long)(m / 256) * (7 * c / 192) >= 512) qv = GEMM_DMA_256x192;
+  if ((rc = launch_gemm(A_DENSE, E_QKV, qv, p, s))) return rc;
   const bool timed = h->time_attn && lvl == 2 && h->ev_used < h->ev_start.size();
   if (timed) DFOT_CHECK_HIP(hipEventRecord(h->ev_start[h->ev_used], s));
   // default (2): level 2 (d = 64) runs the 64-rows-per-wave kernel with the balanced tail; without a running max when the
@@ -499,7 +504,7 @@ static int run_tr_block(dfot_uvit_s* h, const TrW& w, int lvl, int batch, hipStr
   }
   // level 2 (M = 16384, N = 576): 256x192 tiles are 192 workgroups -- a quarter of the chip idle for the whole kernel; 256x144 tiles
   // (N = 4 x 144) are exactly 256, one per CU, at 92 instead of 110 FLOP per operand byte
-  static const int l2_144 = tuning_flag("UVIT_OUT_L2_144", 1);
+  static const int l2_144 = tuning_flag("UVIT_OUT_L2_144", 0);  // A/B: equal within noise (9.42 vs 9.42 frames/s, two rounds): off
   if (l2_144 && h->gemm_variant == GEMM_AUTO && o.ksplit == 1 && c % 144 == 0 && m % 256 == 0 && (long)(m / 256) * ((c + 191) / 192) < 256 &&
       (long)(m / 256) * (c / 144) >= 200 && (long)(m / 256) * (c / 144) <= 256)
     rc = launch_gemm(A_DENSE, E_F32, GEMM_DMA_256x144, o, s);
@@ -590,17 +595,19 @@ static int run_down(dfot_uvit_s* h, int l, int bt, hipStream_t s) {
   return DFOT_OK;
 }
 
-static int run_up(dfot_uvit_s* h, int l, int bt, hipStream_t s) {  // level l+1 -> l
+static int run_up(dfot_uvit_s* h, int l, int bt, hipStream_t s, const uint8_t* live = nullptr) {  // level l+1 -> l
   const int rr = h->r[l + 1], cin = h->ch[l + 1], cout = h->ch[l];
   const long n_in = (long)bt * rr * rr * cin;
   int rc = 0;
-  if ((rc = launch_sub_bf16(h->xin[l + 1], h->HSA[l], h->s1, n_in, s))) return rc;
+  if ((rc = launch_sub_bf16(h->xin[l + 1], h->HSA[l], h->s1, n_in, s, live, (long)rr * rr * cin))) return rc;
   GemmArgs g;
   g.A = h->s1; g.W = h->up_conv[l].w; g.M = bt * rr * rr; g.N = cout; g.K = 9 * cin; g.H = rr; g.Wd = rr; g.Cin = cin;
   g.zeros = h->zeros; g.bias = h->up_conv[l].b; g.out_f32 = h->tmp; g.ldo = cout;
+  // (a 16x16 / 32x32 coarse map is smaller than the larger tiles: the flags apply only where whole tiles lie inside one image)
+  if (live && (rr * rr) % 256 == 0 && h->gemm_variant == GEMM_AUTO) g.live = live;
   if ((rc = launch_gemm(A_CONV3, E_F32, h->gemm_variant, g, s))) return rc;
   h->gn1_nblk = 0;  // X[l] is rewritten by an elementwise kernel: its statistics come from the standalone kernel
-  rc = launch_upsample_add(h->tmp, h->xin[l], h->X[l], bt, rr, rr, cout, s);
+  rc = launch_upsample_add(h->tmp, h->xin[l], h->X[l], bt, rr, rr, cout, s, live);
   h->xin[l] = h->X[l];
   return rc;
 }
@@ -917,6 +924,11 @@ int dfot_uvit_set_conditions(dfot_uvit_t h, const float* external_cond, const ui
 }
 
 int dfot_uvit_forward_cached(dfot_uvit_t h, const float* x, const float* noise_levels, float* out, int batch, void* stream) {
+  return dfot_uvit_forward_cached_live(h, x, noise_levels, out, batch, nullptr, stream);
+}
+
+int dfot_uvit_forward_cached_live(dfot_uvit_t h, const float* x, const float* noise_levels, float* out, int batch, const uint8_t* live_frames,
+                                  void* stream) {
   DFOT_REQUIRE(h && x && noise_levels && out, DFOT_ERR_ARG, "forward: null argument");
   DFOT_REQUIRE(h->finalized, DFOT_ERR_STATE, "forward: weights not finalized");
   DFOT_REQUIRE(batch > 0 && batch == h->cond_batch, DFOT_ERR_STATE,
@@ -950,13 +962,16 @@ int dfot_uvit_forward_cached(dfot_uvit_t h, const float* x, const float* noise_l
   for (const TrW& w : h->up_tr)
     if ((rc = run_tr_block(h, w, 2, batch, s))) return rc;
   if ((rc = flush_pending(h, s))) return rc;
+  // past the last transformer block every kernel works on one frame at a time (3x3 convolutions, per-frame GroupNorm, per-pixel
+  // FiLM): frames whose output the caller discards (live_frames[b * T + t] == 0: the sampler's context tokens, whose v the composition
+  // step never reads) are skipped there -- their rows of the output are zeros
   for (int l = 1; l >= 0; --l) {
-    if ((rc = run_up(h, l, bt, s))) return rc;
+    if ((rc = run_up(h, l, bt, s, live_frames))) return rc;
     for (const ResW& w : h->up_res[l])
-      if ((rc = run_res_block(h, w, l, bt, s))) return rc;
+      if ((rc = run_res_block(h, w, l, bt, s, live_frames))) return rc;
   }
   h->last_batch = batch;
-  return launch_project_output(h->xin[0], h->pout_w, h->pout_b, out, bt, c.resolution, h->ch[0], c.in_channels, s);
+  return launch_project_output(h->xin[0], h->pout_w, h->pout_b, out, bt, c.resolution, h->ch[0], c.in_channels, s, live_frames);
 }
 
 int dfot_uvit_forward(dfot_uvit_t h, const float* x, const float* noise_levels, const float* external_cond,

@@ -78,6 +78,7 @@ class DFoTVideoPoseSampler:
         self.device = "cuda"        # where the rollout state lives; "cpu" only together with dry_run (planner inspection / host tests)
         self.dry_run = False        # True: plan every window (trace, noise draws in the reference's order) but launch nothing
         self.use_graph = False      # True: capture one DDIM step in a hipGraph and replay it (see _run_steps_graph)
+        self.skip_dead_frames = True  # the backbone does not compute the output of tokens the composition step ignores (context / padding)
         self.graph_replays = 0
         self.graph_captures = 0
         self._graphs: Dict[tuple, dict] = {}
@@ -348,6 +349,7 @@ class DFoTVideoPoseSampler:
         off = 0
         cmask_cache: Dict[bytes, torch.Tensor] = {}
         weight_cache: Dict[bytes, torch.Tensor] = {}
+        lives_by_nfe: Dict[int, torch.Tensor] = {}
         for i, p_ in enumerate(plans):
             n = p_["tables"].size
             p_["tables_dev"] = flat_dev[off:off + n].view(8, p_["bm"], horizon)
@@ -355,6 +357,9 @@ class DFoTVideoPoseSampler:
             p_["gen_dev"] = gens_dev[i]
             if p_.get("renoise"):
                 continue
+            if p_["nfe"] not in lives_by_nfe:  # one expansion per branch count of the window, not one per step
+                lives_by_nfe[p_["nfe"]] = gens_dev if p_["nfe"] == 1 else gens_dev.repeat_interleave(p_["nfe"], dim=1)
+            p_["live_dev"] = lives_by_nfe[p_["nfe"]][i]
             wsrc = p_["plan"].weights if p_["plan"].tok_weights is None else p_["plan"].tok_weights
             wkey = wsrc.tobytes()
             if wkey not in weight_cache:
@@ -391,7 +396,11 @@ class DFoTVideoPoseSampler:
         s = capi.stream_ptr
         branch_cache: Dict[tuple, tuple] = {}
 
-        def step(p_, xs, noise, tables, gen_dev, xs_next=None):
+        # frames whose model output the composition never reads (context / padding tokens: gen == 0): the U-ViT backbone skips them past
+        # its last transformer block (backbone.live_frames).  A backbone without the attribute (DiT3D) computes everything.
+        skip_dead = self.skip_dead_frames and hasattr(self.model, "live_frames")
+
+        def step(p_, xs, noise, tables, gen_dev, xs_next=None, live_dev=None):
             nonlocal cond_rep, cond_nfe
             nfe, bm = p_["nfe"], p_["bm"]
             x_in = torch.empty(bm, horizon, *x_shape, device="cuda", dtype=torch.float32)
@@ -417,9 +426,21 @@ class DFoTVideoPoseSampler:
                 c_h, m_h = branch_cache[key][:2]
                 x_h = x_in.view(batch_size, nfe, horizon, *x_shape)[:, hb].contiguous()
                 l_h = lvl.view(batch_size, nfe, horizon)[:, hb].contiguous()
-                v = parallel.exchange_branches(self.model(x_h, l_h, c_h, m_h), nfe)
+                if skip_dead:
+                    self.model.live_frames = gen_dev
+                try:
+                    v = parallel.exchange_branches(self.model(x_h, l_h, c_h, m_h), nfe)
+                finally:
+                    if skip_dead:
+                        self.model.live_frames = None
             else:
-                v = self.model(x_in, lvl, cond_rep, p_["cmask_dev"])
+                if skip_dead:  # rows of the model batch are (sample, branch): every branch of a sample shares the sample's flags
+                    self.model.live_frames = live_dev if live_dev is not None else p_["live_dev"]
+                try:
+                    v = self.model(x_in, lvl, cond_rep, p_["cmask_dev"])
+                finally:
+                    if skip_dead:
+                        self.model.live_frames = None
             step_noise = None
             if strict or p_["sigma"] is not None:  # the reference draws it every step; with sigma = 0 it is multiplied by 0
                 step_noise = self.noise_fn("ddim", (bm, horizon, *x_shape))
@@ -513,10 +534,12 @@ class DFoTVideoPoseSampler:
         if ent is None:
             ent = dict(tables=torch.empty(n_steps, 8, bm, horizon, device="cuda", dtype=torch.float32),
                        gens=torch.empty_like(gens_dev), weights=torch.empty_like(p0["weights_dev"]),
+                       lives=torch.empty(n_steps, bm, horizon, device="cuda", dtype=torch.uint8),
                        noise=torch.empty(n_steps, bm, *xs.shape[1:], device="cuda") if need_noise else None,
                        xs=torch.empty_like(xs), out=None, graph=None)
         ent["tables"].copy_(flat_dev.view(n_steps, 8, bm, horizon))
         ent["gens"].copy_(gens_dev)
+        ent["lives"].copy_(gens_dev if nfe == 1 else gens_dev.repeat_interleave(nfe, dim=1))
         ent["weights"].copy_(p0["weights_dev"])
         if need_noise:
             for i, p_ in enumerate(plans):
@@ -525,14 +548,14 @@ class DFoTVideoPoseSampler:
                 else:
                     ent["noise"][i].zero_()
         p_static = dict(p0, weights_dev=ent["weights"])
-        ent["xs"].copy_(step(p_static, xs, None if not need_noise else ent["noise"][0], ent["tables"][0], ent["gens"][0]))
+        ent["xs"].copy_(step(p_static, xs, None if not need_noise else ent["noise"][0], ent["tables"][0], ent["gens"][0], live_dev=ent["lives"][0]))
         if ent["graph"] is None:
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
                 x = ent["xs"]
                 for i in range(1, n_steps):
-                    x = step(p_static, x, ent["noise"][i] if need_noise else None, ent["tables"][i], ent["gens"][i])
+                    x = step(p_static, x, ent["noise"][i] if need_noise else None, ent["tables"][i], ent["gens"][i], live_dev=ent["lives"][i])
                 ent["out"] = x
             ent["graph"] = graph
             if len(self._graphs) >= 4:  # small LRU: each entry owns a private memory pool

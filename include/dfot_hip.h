@@ -109,6 +109,12 @@ int dfot_uvit_set_conditions(dfot_uvit_t h, const float* external_cond, const ui
                              void* stream);
 int dfot_uvit_forward_cached(dfot_uvit_t h, const float* x, const float* noise_levels, float* out, int batch,
                              void* stream);
+/* The same with a per-frame flag (device uint8 [batch * T], or NULL = every frame): the rows of `out` of frames whose flag is 0 are not
+ * computed (zeros are written).  The sampler's composition step (history_guidance.py:545-568, dfot_video.py:750-752) never reads the
+ * model output of context tokens; past the last transformer block the U-Net works frame by frame (ResBlocks, up-convolutions, output
+ * projection: u_vit3d.py:30-185), so those frames are skipped there.  Attention levels always run on every frame (context frames are keys). */
+int dfot_uvit_forward_cached_live(dfot_uvit_t h, const float* x, const float* noise_levels, float* out, int batch,
+                                  const uint8_t* live_frames, void* stream);
 /* debug/parity taps: copy an internal activation after the last forward (fp32). names: "pose_emb0","down0","down1",
  * "down2","mid","up2","up1","up0" in the oracle's NCHW layout. */
 int dfot_uvit_read_tap(dfot_uvit_t h, const char* name, float* out, size_t capacity_floats, void* stream);

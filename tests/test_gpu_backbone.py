@@ -122,6 +122,32 @@ def test_large_qk_norm_weights_take_the_running_max_attention(w64):
     assert m2.query("score_bound_l2") < 3.3 * b0 < 64 and m2.query("attn_kernel_l2") == 14
 
 
+def test_live_frame_flags_skip_dead_frames_exactly(w64):
+    """Sampler-only hint: frames whose model output the composition step discards (context tokens) are not computed past the last
+    transformer block (every kernel there works on one frame at a time).  The live frames must come out BIT-identical to the plain
+    forward, the dead ones as zeros; the attention levels still see every frame (context frames are keys)."""
+    model = make_model(w64["ocfg"], w64["params"], 64)
+    x, k, c, m = (w64[n].cuda() for n in ("x", "k", "cond", "mask"))
+    with torch.no_grad():
+        full = model(x, k, c, m)
+        live = torch.ones(2, 8, dtype=torch.uint8, device="cuda")
+        live[:, 0] = 0          # the context frame of both History-Guidance branches (BASELINE config 2)
+        live[1, 5] = 0
+        model.live_frames = live
+        part = model(x, k, c, m)
+        model.live_frames = None
+        again = model(x, k, c, m)
+    lv = live.bool()
+    assert torch.equal(part[lv], full[lv]) and torch.count_nonzero(part[~lv]) == 0
+    assert torch.equal(again, full)
+    with pytest.raises(ValueError), torch.no_grad():
+        model.live_frames = live[:1]
+        try:
+            model(x, k, c, m)
+        finally:
+            model.live_frames = None
+
+
 def test_backbone_is_deterministic_and_does_not_mutate_inputs(w64):
     model = make_model(w64["ocfg"], w64["params"], 64)
     x, k, c, m = (w64[n].cuda() for n in ("x", "k", "cond", "mask"))
