@@ -33,6 +33,10 @@ struct GemmArgs {
   int gate_rows = 0;
   int act = 0;  // E_BF16: 0 = none, 1 = GELU(tanh approximation), 2 = SiLU applied before the bf16 store
   bf16* pre_act = nullptr;  // E_BF16 with act: optional second output, the value BEFORE the activation (training keeps both)
+  // E_QKV: optional copy of the raw projection output (bias added, before QK-norm / RoPE / SiLU) as bf16 [M][ldraw]: the training forward
+  // keeps it for the backward of the norm and the activation (uvit_train.py) while q, k, v and SiLU(mlp_h) come out of the same epilogue
+  bf16* raw = nullptr;
+  long ldraw = 0;
   int bias_rows = 0;  // E_F32 / E_BF16: > 0 = two-dimensional bias[(row % bias_rows)][N] (MatrixAttention), else bias[N]
   // E_BF16: tr_rows = R > 0 stores the result transposed inside consecutive groups of R rows ("frames"):
   // out[(row / R)][col][row % R] -- the left factor of a matrix_mul contracts the ROW index of its operand

@@ -502,6 +502,16 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int tile_inde
           ssq[0] += xch[(wave ^ 1) * 16 + (lane >> 3)];
           ssq[1] += xch[(wave ^ 1) * 16 + 8 + (lane >> 3)];
         }
+        if (live && g.raw) {
+#pragma unroll
+          for (int p = 0; p < 2; ++p) {
+            const int r = p * 8 + (lane >> 3);
+            bf16x8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = f2bf(vals[p][j]);
+            *reinterpret_cast<bf16x8*>(g.raw + (mw + r) * g.ldraw + col) = o;
+          }
+        }
         if (live) {
           if (col >= g.split) {  // MLP half: SiLU
 #pragma unroll
@@ -744,6 +754,7 @@ int launch_gemm(int amode, int epi, int variant, const GemmArgs& g, hipStream_t 
   }
   if (epi == E_QKV) {
     DFOT_REQUIRE(g.q && g.k && g.v && g.qw && g.kw && g.rope_cs && (g.out2 || g.N == g.split), DFOT_ERR_ARG, "qkv epilogue: null pointer");
+    DFOT_REQUIRE(!g.raw || (g.ldraw >= g.N && g.ldraw % 8 == 0), DFOT_ERR_SHAPE, "qkv epilogue: raw copy needs ldraw >= N, a multiple of 8");
     DFOT_REQUIRE((g.d == 64 || g.d == 128) && g.heads > 0 && g.split == 3 * g.heads * g.d && g.ntok > 0 && g.M % g.ntok == 0,
                  DFOT_ERR_SHAPE, "qkv epilogue: heads=%d d=%d split=%d ntok=%d M=%d", g.heads, g.d, g.split, g.ntok, g.M);
   }

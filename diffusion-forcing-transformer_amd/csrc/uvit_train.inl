@@ -772,6 +772,24 @@ int dfot_op_qknorm_rope_fwd(const void* fused, int ld, const float* qw, const fl
   DFOT_CHECK_HIP(hipGetLastError());
   return DFOT_OK;
 }
+// Training forward of fused_attn_mlp_proj in ONE launch (u_vit_blocks.py:253-262): fused = a W^T + bias is kept raw (bf16 [rows][7C], what the
+// backward of the QK-norm and of SiLU needs) while the same epilogue writes q, k (per-head RMSNorm + RoPE, q scaled) and v as
+// [B][heads][ntok][d] and SiLU(mlp_h) into cat[:, ccol0 : ccol0 + 4C] -- instead of a plain GEMM followed by a norm / RoPE pass and a
+// SiLU pass that each re-read the 7C-wide projection.  a bf16 [rows][lda], w bf16 [7C][C]
+int dfot_op_fused_proj_train(const void* a, int lda, const void* w, const float* bias, const float* qw, const float* kw, const float* rope_cs, float eps,
+                             float qscale, void* fused, void* q, void* k, void* v, void* cat, int ldcat, int ccol0, int64_t rows, int ntok, int heads,
+                             int d, void* stream) {
+  DFOT_REQUIRE(a && w && bias && qw && kw && rope_cs && fused && q && k && v && cat && (d == 64 || d == 128) && ccol0 % 8 == 0 && rows % 128 == 0,
+               DFOT_ERR_ARG, "op_fused_proj_train: bad argument");
+  const int c = heads * d;
+  GemmArgs g;
+  g.A = (const bf16*)a; g.lda = lda; g.W = (const bf16*)w; g.M = (int)rows; g.N = 7 * c; g.K = c; g.bias = bias;
+  g.out2 = (bf16*)cat + ccol0; g.ldo2 = ldcat; g.split = 3 * c;
+  g.q = (bf16*)q; g.k = (bf16*)k; g.v = (bf16*)v; g.qw = qw; g.kw = kw; g.rope_cs = rope_cs; g.heads = heads; g.d = d; g.ntok = ntok;
+  g.qscale = qscale; g.eps = eps;
+  g.raw = (bf16*)fused; g.ldraw = 7L * c;
+  return launch_gemm(A_DENSE, E_QKV, GEMM_AUTO, g, (hipStream_t)stream);
+}
 // grad == NULL: dst[:, dcol0:+ncols] = SiLU(src[:, scol0:+ncols]); else dst = grad[:, gcol0:+ncols] * SiLU'(src[:, scol0:+ncols])
 int dfot_op_silu_cols(const void* src, int lds_, int scol0, const void* grad, int ldg, int gcol0, void* dst, int ldd, int dcol0, int64_t rows,
                       int ncols, void* stream) {

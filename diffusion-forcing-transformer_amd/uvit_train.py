@@ -9,6 +9,7 @@ A first, op-by-op driver: correct (parity-tested against torch autograd through 
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -18,6 +19,7 @@ from . import capi
 BF = torch.bfloat16
 _S = capi.stream_ptr
 _P = capi.ptr
+FUSED_PROJ = os.environ.get("DFOT_TRAIN_FUSED_PROJ", "1") != "0"  # A/B: 0 = plain GEMM + separate norm / RoPE and SiLU passes
 _PV = capi.ptr_rows  # matrices that may be column blocks of wider ones (the entry point takes the row stride)
 
 
@@ -118,14 +120,22 @@ class TransformerBlockTrain:
         film = gemm_bf16(emb, self.w_e, p["norm.emb_layer.bias"])
         xn = torch.empty(rows, c, dtype=BF, device="cuda")
         capi.check(lib.dfot_op_rms_film_fwd(_P(x), _P(p["norm.norm.weight"]), _P(film), self.eps, _P(xn), rows, c, _S()))
-        fused = gemm_bf16(xn, self.w_f, p["fused_attn_mlp_proj.bias"])
         q, k, v = (torch.empty(batch, hds, ntok, d, dtype=BF, device="cuda") for _ in range(3))
-        capi.check(lib.dfot_op_qknorm_rope_fwd(_P(fused), 7 * c, _P(p["q_norm.weight"]), _P(p["k_norm.weight"]), _P(self.rope), self.eps,
-                                               math.log2(math.e) / math.sqrt(d), _P(q), _P(k), _P(v), rows, ntok, hds, d, _S()))
         cat = torch.empty(rows, 5 * c, dtype=BF, device="cuda")  # [attention output | SiLU(mlp_h)]
+        if FUSED_PROJ and rows % 128 == 0:
+            # one launch: the raw projection is kept for the backward while the GEMM epilogue applies QK-norm + RoPE (q, k, v in the attention
+            # layout) and SiLU (MLP half, straight into cat) -- no norm / RoPE pass and no SiLU pass over the 7C-wide projection
+            fused = torch.empty(rows, 7 * c, dtype=BF, device="cuda")
+            capi.check(lib.dfot_op_fused_proj_train(_P(xn), c, _P(self.w_f), _P(p["fused_attn_mlp_proj.bias"]), _P(p["q_norm.weight"]),
+                                                    _P(p["k_norm.weight"]), _P(self.rope), self.eps, math.log2(math.e) / math.sqrt(d), _P(fused),
+                                                    _P(q), _P(k), _P(v), _P(cat), 5 * c, c, rows, ntok, hds, d, _S()))
+        else:
+            fused = gemm_bf16(xn, self.w_f, p["fused_attn_mlp_proj.bias"])
+            capi.check(lib.dfot_op_qknorm_rope_fwd(_P(fused), 7 * c, _P(p["q_norm.weight"]), _P(p["k_norm.weight"]), _P(self.rope), self.eps,
+                                                   math.log2(math.e) / math.sqrt(d), _P(q), _P(k), _P(v), rows, ntok, hds, d, _S()))
+            capi.check(lib.dfot_op_silu_cols(_P(fused), 7 * c, 3 * c, None, 0, 0, _P(cat), 5 * c, c, rows, 4 * c, _S()))
         lse = torch.empty(batch, hds, ntok, dtype=torch.float32, device="cuda")
         capi.check(lib.dfot_op_attention_fwd_lse(_P(q), _P(k), _P(v), _P(cat), 5 * c, _P(lse), batch, hds, ntok, d, _S()))
-        capi.check(lib.dfot_op_silu_cols(_P(fused), 7 * c, 3 * c, None, 0, 0, _P(cat), 5 * c, c, rows, 4 * c, _S()))
         if mlp_mask is not None:
             capi.check(lib.dfot_op_mul_cols(_P(cat), 5 * c, c, _P(mlp_mask), rows, 4 * c, _S()))
         y = gemm_f32(cat, self.w_out, self.b_out, resid=x)

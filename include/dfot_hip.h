@@ -325,6 +325,12 @@ int dfot_op_gemm_f32(const void* a, int lda, const void* w, const float* bias, c
 int dfot_op_transpose_bf16(const void* src, void* dst, int rows, int cols, void* stream);
 int dfot_op_colsum_bf16(const void* src, int ld, float* out, int64_t rows, int n, void* stream);
 int dfot_op_rms_film_fwd(const float* x, const float* w, const void* film, float eps, void* out, int64_t rows, int channels, void* stream);
+/* fused_attn_mlp_proj of a TransformerBlock in its training form, one launch (u_vit_blocks.py:253-262): the raw projection (bias added) is kept
+ * as bf16 `fused` [rows][7C] for the backward, and the same epilogue writes q, k (per-head RMSNorm + RoPE; q * qscale), v as
+ * [B][heads][ntok][d] and SiLU(mlp_h) into cat[:, ccol0 : ccol0 + 4C] (row stride ldcat) */
+int dfot_op_fused_proj_train(const void* a, int lda, const void* w, const float* bias, const float* qw, const float* kw, const float* rope_cs, float eps,
+                             float qscale, void* fused, void* q, void* k, void* v, void* cat, int ldcat, int ccol0, int64_t rows, int ntok, int heads,
+                             int d, void* stream);
 int dfot_op_qknorm_rope_fwd(const void* fused, int ld, const float* qw, const float* kw, const float* rope_cs, float eps, float qscale, void* q,
                             void* k, void* v, int64_t rows, int ntok, int heads, int d, void* stream);
 int dfot_op_silu_cols(const void* src, int lds_, int scol0, const void* grad, int ldg, int gcol0, void* dst, int ldd, int dcol0, int64_t rows,
