@@ -124,6 +124,7 @@ struct dfot_uvit_s {
   const float* xin[4] = {nullptr, nullptr, nullptr, nullptr};
   int gemm_variant = GEMM_AUTO;
   int attn_variant = 2;
+  bool debug_stop_after_mid = false;
   bool attn_force_safe = false;  // level-2 attention: always the running-max kernel (what weights with a bound >= 64 get)
   // the block's two independent branches on two streams (run_tr_block_2s): bit 0 = level 3, bit 1 = level 2
   int two_stream = 0;
@@ -639,12 +640,15 @@ int dfot_uvit_create(const dfot_uvit_config* cfg, dfot_uvit_t* out) {
   DFOT_REQUIRE((cfg->max_tokens * r3 * r3) % 128 == 0, DFOT_ERR_SHAPE, "tokens at the coarsest level (%d) must be a multiple of 128", cfg->max_tokens * r3 * r3);
   auto* h = new dfot_uvit_s();
   h->cfg = *cfg;
-  // bit 0 = level 3, bit 1 = level 2.  OFF by default: +1.3 % frames/s at 256x256 (two same-box A/B pairs), but at
-  // 64x64 -- where workgroups of the concurrently running kernels share CUs -- two runs of one forward differ by ~2e-3 relative
-  // (tools/debug_2s.py); every dependency is covered by the fork / join events and host synchronisation at the fork makes it exact, the
-  // cause is not found, so the serial chain stays the default
+  // bit 0 = level 3, bit 1 = level 2.  OFF by default: +1.3 % frames/s at 256x256 (two same-box A/B pairs), but NOT
+  // run-to-run reproducible: at 64x64, where the workgroups of concurrently running kernels share CUs, about one forward in eight comes
+  // out with a few (7-30) wrong elements of q in ONE two-stream block -- the output of the main stream's own fused-projection GEMM, while
+  // the MLP GEMM runs on the side stream (tools/debug_2s.py: the side branch's buffers are always identical; host synchronisation at the
+  // fork, or the MLP GEMM on the main stream, makes it exact; event flags, a third stream, an agent-scope release at the end of the side
+  // GEMM and double-buffered slices do not).  Every cross-stream dependency is covered by the fork / join events; the cause is not found
+  // (the register-staged GEMM form did not show it in 8 runs), so the serial chain stays the default.
   h->two_stream = tuning_flag("UVIT_TWO_STREAM", 0);
-  if (h->two_stream) {
+  {  // the side stream and its events exist whether or not the schedule is on, so that set_option("two_stream", ..) can switch it
     if (hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess) h->side = nullptr;
     for (int i = 0; h->side && i < 8; ++i) {
       hipEvent_t e;
@@ -848,6 +852,7 @@ int dfot_uvit_set_option(dfot_uvit_t h, const char* key, int value) {
   if (!strcmp(key, "gemm_variant")) h->gemm_variant = value;
   else if (!strcmp(key, "attn_variant")) h->attn_variant = value;
   else if (!strcmp(key, "attn_force_safe")) h->attn_force_safe = value != 0;
+  else if (!strcmp(key, "debug_stop_after_mid")) h->debug_stop_after_mid = value != 0;
   else if (!strcmp(key, "two_stream")) h->two_stream = (h->side && h->ev_sync.size() >= 8) ? value : 0;
   else if (!strcmp(key, "time_attn")) {
     // value = number of launches to record (0 disables); events are created here, never inside forward
@@ -958,6 +963,10 @@ int dfot_uvit_forward_cached_live(dfot_uvit_t h, const float* x, const float* no
   for (const TrW& w : h->mid_tr)
     if ((rc = run_tr_block(h, w, 3, batch, s))) return rc;
   if ((rc = flush_pending(h, s))) return rc;
+  if (h->debug_stop_after_mid) {  // diagnostics (tools/debug_2s.py): leave the level-3 workspace as the mid blocks left it
+    h->last_batch = batch;
+    return DFOT_OK;
+  }
   if ((rc = run_up(h, 2, bt, s))) return rc;
   for (const TrW& w : h->up_tr)
     if ((rc = run_tr_block(h, w, 2, batch, s))) return rc;
@@ -1001,6 +1010,20 @@ int dfot_uvit_read_tap(dfot_uvit_t h, const char* name, float* out, size_t capac
     DFOT_REQUIRE(capacity >= need, DFOT_ERR_SHAPE, "read_tap: need %zu floats, got %zu", need, capacity);
     return t.f ? launch_nhwc_to_nchw(t.f, out, bt, pixels(t.lvl), t.c, s)
                : launch_bf16_nhwc_to_nchw(t.b, out, bt, pixels(t.lvl), t.c, s);
+  }
+  // raw workspace buffers of the last transformer block (diagnostics, tools/debug_2s.py): element counts are the caller's business
+  {
+    struct Raw { const char* n; const void* p; size_t bytes; };
+    const size_t m3 = (size_t)h->last_batch * h->T * pixels(3), c3 = h->ch[3];
+    const Raw raws[] = {{"raw_cat", h->cat, m3 * 5 * c3 * sizeof(bf16)}, {"raw_s1", h->s1, m3 * c3 * sizeof(bf16)},
+                        {"raw_part", h->out_part, 3 * m3 * c3 * sizeof(float)}, {"raw_q", h->q, m3 * c3 * sizeof(bf16)},
+                        {"raw_x3", h->X[3], m3 * c3 * sizeof(float)}};
+    for (const Raw& r : raws) {
+      if (strcmp(r.n, name)) continue;
+      DFOT_REQUIRE(capacity * sizeof(float) >= r.bytes, DFOT_ERR_SHAPE, "read_tap: need %zu bytes", r.bytes);
+      DFOT_CHECK_HIP(hipMemcpyAsync(out, r.p, r.bytes, hipMemcpyDeviceToDevice, s));
+      return DFOT_OK;
+    }
   }
   set_error("read_tap: unknown tap '%s'", name);
   return DFOT_ERR_NAME;
