@@ -487,6 +487,7 @@ int launch_attention(const bf16* q, const bf16* k, const bf16* v, bf16* o, long 
     return launch_attention_v3(q, k, v, o, ldo, batch, heads, n, variant == 6, stream, scratch);
   if (variant == 14 && d == 64 && n % 256 == 0) return launch_attention_v5(q, k, v, o, ldo, batch, heads, n, stream, scratch);  // pipelined, no running max
   if (variant == 5 || variant == 6 || variant == 14) variant = 2;
+  if (variant == 2 && attention_ks_applies(batch, heads, n, d)) return launch_attention_ks(q, k, v, o, ldo, batch, heads, n, stream, scratch);
   if (variant == 2) {  // tuned kernel; K/V ring depth chosen by measurement: 3 stages (48 KiB) at d = 64, 2 stages at d = 128
     return d == 64 ? launch_attn_v2<64, 3>(q, k, v, o, ldo, batch, heads, n, stream)
                    : launch_attn_v2<128, 2>(q, k, v, o, ldo, batch, heads, n, stream);

@@ -348,16 +348,17 @@ AttnScratch* attention_default_scratch() {
 }
 
 size_t attention_scratch_bytes(int batch, int heads, int n, int d) {
-  if (d != 64 || n % QROWS != 0) return 0;  // only the 64-rows-per-wave level-2 kernels (attention_v3 / v5) split their tail
+  if (d == 128) return attention_ks_scratch_bytes(batch, heads, n, d);  // the 8-wave key-split kernel of attention_ks.hip
+  if (d != 64 || n % QROWS != 0) return 0;  // d = 64: the 64-rows-per-wave level-2 kernels (attention_v3 / v5) split their tail
   const AttnSplit sp = attn_plan_split(batch, heads, n, QROWS, 2);
   return sp.nsplit == 1 ? 0 : (size_t)sp.rem * sp.nsplit * QROWS * (D + 2) * sizeof(float);
 }
 
-int attn_partials(const AttnSplit& sp, int qrows, float** po, float** pml, AttnScratch* scratch) {
+int attn_partials(const AttnSplit& sp, int qrows, float** po, float** pml, AttnScratch* scratch, int dcols) {
   *po = *pml = nullptr;
   if (sp.nsplit == 1) return DFOT_OK;
   const size_t rows = (size_t)sp.rem * sp.nsplit * qrows;
-  const size_t bytes = rows * (D + 2) * sizeof(float);
+  const size_t bytes = rows * (dcols + 2) * sizeof(float);
   if (!scratch) {
     scratch = attention_default_scratch();
     if (bytes > scratch->bytes) {  // grow: a NEW block; the old one is deliberately leaked (see above)
@@ -370,7 +371,7 @@ int attn_partials(const AttnSplit& sp, int qrows, float** po, float** pml, AttnS
   DFOT_REQUIRE(scratch->p && bytes <= scratch->bytes, DFOT_ERR_STATE,
                "attention: key-split scratch of %zu bytes, launch needs %zu (reserve the handle for this batch first)", scratch->bytes, bytes);
   *po = scratch->p;
-  *pml = scratch->p + rows * D;
+  *pml = scratch->p + rows * dcols;
   return DFOT_OK;
 }
 

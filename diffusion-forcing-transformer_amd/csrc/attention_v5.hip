@@ -67,7 +67,7 @@ __device__ __forceinline__ void lds_wait4(u32x4& a, u32x4& b, u32x4& c, u32x4& d
   asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
 }
 
-template <int VPM>  // vector instructions requested per MFMA in the interleave
+template <int VPM, bool PIN>  // vector instructions requested per MFMA in the interleave; PIN: see iteration()
 __global__ __launch_bounds__(256, 2) void attn64_kernel_v5(const bf16* __restrict__ Q, const bf16* __restrict__ K,
                                                            const bf16* __restrict__ V, bf16* __restrict__ O, long ldo, int N,
                                                            int heads, int ohs, int full_tiles, int nsplit,
@@ -233,6 +233,9 @@ __global__ __launch_bounds__(256, 2) void attn64_kernel_v5(const bf16* __restric
     if constexpr (has_next) read_k(KT2N{}, kstage, kr);
     if constexpr (has_prev) read_v(KT2N{}, vstage, vr);  // half-tile h-1 has the same key parity as h+1
     softmax_part(cb_c, C0{});                            // vector work that needs no LDS data covers the read latency
+    // ... provided it stays in front of the wait: without a use there LLVM sinks it behind the wait and the wave idles through the
+    // latency of its twelve LDS reads at the top of every iteration (DFOT_ATTN5_PIN=0 restores that order for the A/B)
+    if constexpr (PIN) asm volatile("" : "+v"(pf[0][cb][0]), "+v"(pf[1][cb][0]), "+v"(l_i[0]), "+v"(l_i[1]));
     if constexpr (has_next && has_prev) lds_wait12(kr[0], kr[1], kr[2], kr[3], vr[0], vr[1], vr[2], vr[3], vr[4], vr[5], vr[6], vr[7]);
     else if constexpr (has_next) lds_wait4(kr[0], kr[1], kr[2], kr[3]);
     else if constexpr (has_prev) lds_wait(vr[0], vr[1], vr[2], vr[3], vr[4], vr[5], vr[6], vr[7]);
@@ -347,7 +350,8 @@ int launch_attention_v5(const bf16* q, const bf16* k, const bf16* v, bf16* o, lo
     DFOT_CHECK_HIP(hipGetLastError());
     return DFOT_OK;
   };
-  rc = go(attn64_kernel_v5<3>);
+  static const int pin = tuning_flag("ATTN5_PIN", 1);
+  rc = pin ? go(attn64_kernel_v5<3, true>) : go(attn64_kernel_v5<3, false>);
   if (rc) return rc;
   return attn_launch_merge(sp, QROWS, po, pml, o, ldo, n, heads, stream);
 }

@@ -114,7 +114,12 @@ struct AttnSplit {
   int tiles, full, rem, nsplit;
 };
 AttnSplit attn_plan_split(int batch, int heads, int n, int qrows, int wgs_per_cu);
-int attn_partials(const AttnSplit& sp, int qrows, float** po, float** pml, AttnScratch* scratch);
+int attn_partials(const AttnSplit& sp, int qrows, float** po, float** pml, AttnScratch* scratch, int dcols = 64);
+// attention_ks.hip: 128-element rows, 8 waves per workgroup with the key axis split inside the workgroup (launches of few query tiles)
+bool attention_ks_applies(int batch, int heads, int n, int d);
+size_t attention_ks_scratch_bytes(int batch, int heads, int n, int d);
+int launch_attention_ks(const bf16* q, const bf16* k, const bf16* v, bf16* o, long ldo, int batch, int heads, int n, hipStream_t stream,
+                        AttnScratch* scratch = nullptr);
 int attn_launch_merge(const AttnSplit& sp, int qrows, const float* po, const float* pml, bf16* o, long ldo, int n, int heads,
                       hipStream_t stream);
 int attention_dstride(int d);

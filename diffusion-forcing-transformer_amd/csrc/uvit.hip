@@ -822,7 +822,8 @@ int dfot_uvit_reserve(dfot_uvit_t h, int max_batch) {
   // owned by the handle (nothing is allocated, freed or shared with another handle inside forward / stream capture)
   {
     size_t need = 16;
-    for (int b = 1; b <= max_batch; ++b) need = std::max(need, attention_scratch_bytes(b, h->heads, h->T * h->r[2] * h->r[2], h->ch[2] / h->heads));
+    for (int b = 1; b <= max_batch; ++b)
+      for (int l = 2; l < 4; ++l) need = std::max(need, attention_scratch_bytes(b, h->heads, h->T * h->r[l] * h->r[l], h->ch[l] / h->heads));
     if ((rc = dev_alloc(h, &h->attn_scratch.p, need / sizeof(float), true))) return rc;
     h->attn_scratch.bytes = need;
   }

@@ -241,7 +241,9 @@ def test_sampler_contract_errors():
 
 
 def test_hipgraph_step_replay_matches_eager():
-    """One captured DDIM step replayed with a device-side step counter reproduces the eager loop bit for bit."""
+    """All remaining DDIM steps of a window captured as ONE hipGraph (step 0 runs eagerly, each captured step reads its own slice of the
+    static per-step tables; one replay per window) reproduce the eager loop bit for bit, also when a later window of the same shape
+    re-uses the captured graph."""
     import dfot_amd
     from dfot_amd import parallel
     _, _, model = build(blocks=(1, 1, 1), mid=2)
