@@ -557,6 +557,8 @@ def main():
     sampler.use_graph = use_graph and not args.dry_run
     for _ in range(args.warmup):
         sampler._predict_videos(xs, n_context_tokens=1, conditions=conds)
+    # HIP events around the level-2 attention launches need the eager loop: hipEventElapsedTime refuses events recorded as nodes of a
+    # captured graph ("invalid resource handle" on ROCm 7.2), so the hipGraph mode reports no in-run roofline
     timed_attn = not sampler.use_graph and not args.dry_run
     attn_per_sample = args.sampling_steps * 12 * (14 if long_rollout else 1) if timed_attn else 0
     if model is not None:
