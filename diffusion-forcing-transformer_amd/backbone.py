@@ -92,6 +92,8 @@ class UViT3DPose(nn.Module):
         self._trainer = None         # uvit_train.UViT3DPoseTrainer on this module's weights, built at the first training forward
         self._trainer_sig = None
         self.live_frames = None      # see _forward_impl: set by the sampler around its backbone calls, None otherwise
+        self.fresh_frames = None
+        self._fresh_key = None       # conditioning key of the previous forward (frozen frames are only honoured behind the same one)
         self._train_stamp = 0        # counts training forwards: the autograd ctx of a forward remembers its number (ops._train_setup_context)
         self._dropout_generator: Optional[torch.Generator] = None  # set a CUDA generator to enable the MLP-branch nn.Dropout in train()
 
@@ -320,9 +322,20 @@ class UViT3DPose(nn.Module):
             if tuple(live.shape) != (b, self.temporal_length) or live.dtype != torch.uint8 or not live.is_contiguous():
                 raise ValueError(f"live_frames must be a contiguous uint8 tensor of shape {(b, self.temporal_length)}")
             capi.require_device(dev, live_frames=live)
-        capi.check(capi.lib.dfot_uvit_forward_cached_live(self._handle, capi.ptr(xf, torch.float32, "x"),
-                                                          capi.ptr(kf, torch.float32, "noise_levels"), capi.ptr(out), b,
-                                                          capi.ptr(live, torch.uint8, "live_frames"), capi.stream_ptr()))
+        fresh = self.fresh_frames
+        if fresh is not None:
+            # sampler-only hint: uint8 (B, T), 0 = this frame's input / level / conditioning equal the previous forward's -> its down-path
+            # activations are still in the workspace (include/dfot_hip.h, dfot_uvit_forward_cached_masks)
+            if tuple(fresh.shape) != (b, self.temporal_length) or fresh.dtype != torch.uint8 or not fresh.is_contiguous():
+                raise ValueError(f"fresh_frames must be a contiguous uint8 tensor of shape {(b, self.temporal_length)}")
+            capi.require_device(dev, fresh_frames=fresh)
+            if key != self._fresh_key:  # the conditioning caches were rebuilt or another batch ran in between: nothing is frozen
+                fresh = None
+        capi.check(capi.lib.dfot_uvit_forward_cached_masks(self._handle, capi.ptr(xf, torch.float32, "x"),
+                                                           capi.ptr(kf, torch.float32, "noise_levels"), capi.ptr(out), b,
+                                                           capi.ptr(live, torch.uint8, "live_frames"),
+                                                           capi.ptr(fresh, torch.uint8, "fresh_frames"), capi.stream_ptr()))
+        self._fresh_key = key
         return out.to(x.dtype)
 
     def read_tap(self, name: str, channels: int, level: int, batch: int) -> torch.Tensor:

@@ -62,6 +62,7 @@ SIGNATURES = {
     "dfot_uvit_set_conditions": (_I, [_P, _P, _P, _I, _P]),
     "dfot_uvit_forward_cached": (_I, [_P, _P, _P, _P, _I, _P]),
     "dfot_uvit_forward_cached_live": (_I, [_P, _P, _P, _P, _I, _P, _P]),
+    "dfot_uvit_forward_cached_masks": (_I, [_P, _P, _P, _P, _I, _P, _P, _P]),
     "dfot_uvit_read_tap": (_I, [_P, C.c_char_p, _P, C.c_size_t, _P]),
     "dfot_dit_create": (_I, [C.POINTER(DiTConfig), C.POINTER(_P)]),
     "dfot_dit_destroy": (_I, [_P]),

@@ -579,13 +579,14 @@ static int run_tr_block_2s(dfot_uvit_s* h, const TrW& w, int lvl, int batch, hip
   return DFOT_OK;
 }
 
-static int run_down(dfot_uvit_s* h, int l, int bt, hipStream_t s) {
+static int run_down(dfot_uvit_s* h, int l, int bt, hipStream_t s, const uint8_t* live = nullptr) {
   const int rr = h->r[l], cin = h->ch[l], cout = h->ch[l + 1];
   int rc = 0;
   if ((rc = launch_pool2_bf16(h->xin[l], h->s1, bt, rr, rr, cin, s))) return rc;
   GemmArgs g;
   g.A = h->s1; g.W = h->down_conv[l].w; g.M = bt * (rr / 2) * (rr / 2); g.N = cout; g.K = 9 * cin; g.H = rr / 2; g.Wd = rr / 2;
   g.Cin = cin; g.zeros = h->zeros; g.bias = h->down_conv[l].b; g.out_f32 = h->HSA[l]; g.ldo = cout;
+  g.live = live;  // frozen frames (forward_cached_masks checked that whole tiles lie inside one image)
   const bool next_is_res = l + 1 < 2;
   if (next_is_res) {
     g.gn_part = h->gn_partial; g.gn_rows_per_bt = (rr / 2) * (rr / 2); g.gn_cpg = cout / 32;
@@ -935,7 +936,15 @@ int dfot_uvit_forward_cached(dfot_uvit_t h, const float* x, const float* noise_l
 
 int dfot_uvit_forward_cached_live(dfot_uvit_t h, const float* x, const float* noise_levels, float* out, int batch, const uint8_t* live_frames,
                                   void* stream) {
+  return dfot_uvit_forward_cached_masks(h, x, noise_levels, out, batch, live_frames, nullptr, stream);
+}
+
+int dfot_uvit_forward_cached_masks(dfot_uvit_t h, const float* x, const float* noise_levels, float* out, int batch, const uint8_t* live_frames,
+                                   const uint8_t* fresh_frames, void* stream) {
   DFOT_REQUIRE(h && x && noise_levels && out, DFOT_ERR_ARG, "forward: null argument");
+  DFOT_REQUIRE(!fresh_frames || h->last_batch == batch, DFOT_ERR_STATE,
+               "forward: frozen frames need the previous forward of this handle to have run the same batch (%d, now %d)", h->last_batch, batch);
+  DFOT_REQUIRE(!fresh_frames || live_frames, DFOT_ERR_ARG, "forward: frozen frames must also be dead frames (live_frames is null)");
   DFOT_REQUIRE(h->finalized, DFOT_ERR_STATE, "forward: weights not finalized");
   DFOT_REQUIRE(batch > 0 && batch == h->cond_batch, DFOT_ERR_STATE,
                "forward_cached: batch %d does not match the cached conditions (%d)", batch, h->cond_batch);
@@ -951,10 +960,18 @@ int dfot_uvit_forward_cached_live(dfot_uvit_t h, const float* x, const float* no
   h->gn1_nblk = 0;
   for (int l = 0; l < 4; ++l) h->xin[l] = h->X[l];
 
+  // frames that are NOT fresh (fresh_frames[b * T + t] == 0): the caller states that this frame's input, noise level and conditioning
+  // equal those of the previous forward of this handle (a clean context frame of the conditional branch across the DDIM steps of a
+  // window).  The ResBlock levels work frame by frame, so the frame's rows of the skip tensors and of the level-2 input still hold
+  // exactly what would be recomputed: its tiles and rows are skipped on the way down.  All or nothing: a frame skipped by one stage and
+  // recomputed by the next would be recomputed from stale rows, so the flags are dropped unless every convolution of the down path
+  // has whole tiles per image (the largest tile is 512 rows)
+  static const int frozen_skip = tuning_flag("UVIT_FROZEN_SKIP", 1);  // A/B switch (tools/ab_8f.sh)
+  if (fresh_frames && (!frozen_skip || h->gemm_variant != GEMM_AUTO || (h->r[2] * h->r[2]) % 512 != 0)) fresh_frames = nullptr;
   for (int l = 0; l < 2; ++l) {
     for (const ResW& w : h->down_res[l])
-      if ((rc = run_res_block(h, w, l, bt, s))) return rc;
-    if ((rc = run_down(h, l, bt, s))) return rc;
+      if ((rc = run_res_block(h, w, l, bt, s, fresh_frames))) return rc;
+    if ((rc = run_down(h, l, bt, s, fresh_frames))) return rc;
   }
   h->pend_bias = nullptr;
   for (const TrW& w : h->down_tr)

@@ -78,6 +78,7 @@ class DFoTVideoPoseSampler:
         self.device = "cuda"        # where the rollout state lives; "cpu" only together with dry_run (planner inspection / host tests)
         self.dry_run = False        # True: plan every window (trace, noise draws in the reference's order) but launch nothing
         self.use_graph = False      # True: capture one DDIM step in a hipGraph and replay it (see _run_steps_graph)
+        self.skip_frozen_frames = True  # ... nor the down path of frames whose input equals the previous step's (clean context)
         self.skip_dead_frames = True  # the backbone does not compute the output of tokens the composition step ignores (context / padding)
         self.graph_replays = 0
         self.graph_captures = 0
@@ -392,6 +393,11 @@ class DFoTVideoPoseSampler:
                     p_["cond"] = by_mask[key]
             finally:
                 self._interpolate_masked_poses = False
+        fresh_dev = torch.from_numpy(np.concatenate([a.ravel() for a in self._fresh_flags(plans, batch_size, horizon)])).cuda()
+        foff = 0
+        for p_ in plans:
+            p_["fresh_dev"] = fresh_dev[foff:foff + p_["bm"] * horizon].view(p_["bm"], horizon)
+            foff += p_["bm"] * horizon
         xs = xs.contiguous()
         s = capi.stream_ptr
         branch_cache: Dict[tuple, tuple] = {}
@@ -399,8 +405,11 @@ class DFoTVideoPoseSampler:
         # frames whose model output the composition never reads (context / padding tokens: gen == 0): the U-ViT backbone skips them past
         # its last transformer block (backbone.live_frames).  A backbone without the attribute (DiT3D) computes everything.
         skip_dead = self.skip_dead_frames and hasattr(self.model, "live_frames")
+        # ... and frames whose backbone input did not change since the previous step (clean context of the conditional branch): their
+        # frame-local down-path activations are still in the backbone's workspace (backbone.fresh_frames, _fresh_flags below)
+        skip_frozen = skip_dead and self.skip_frozen_frames and hasattr(self.model, "fresh_frames")
 
-        def step(p_, xs, noise, tables, gen_dev, xs_next=None, live_dev=None):
+        def step(p_, xs, noise, tables, gen_dev, xs_next=None, live_dev=None, fresh_dev=None):
             nonlocal cond_rep, cond_nfe
             nfe, bm = p_["nfe"], p_["bm"]
             x_in = torch.empty(bm, horizon, *x_shape, device="cuda", dtype=torch.float32)
@@ -436,11 +445,15 @@ class DFoTVideoPoseSampler:
             else:
                 if skip_dead:  # rows of the model batch are (sample, branch): every branch of a sample shares the sample's flags
                     self.model.live_frames = live_dev if live_dev is not None else p_["live_dev"]
+                if skip_frozen:
+                    self.model.fresh_frames = fresh_dev if fresh_dev is not None else p_["fresh_dev"]
                 try:
                     v = self.model(x_in, lvl, cond_rep, p_["cmask_dev"])
                 finally:
                     if skip_dead:
                         self.model.live_frames = None
+                    if skip_frozen:
+                        self.model.fresh_frames = None
             step_noise = None
             if strict or p_["sigma"] is not None:  # the reference draws it every step; with sigma = 0 it is multiplied by 0
                 step_noise = self.noise_fn("ddim", (bm, horizon, *x_shape))
@@ -511,6 +524,31 @@ class DFoTVideoPoseSampler:
         """which per-window sampler the rollout / interpolation drivers call (the base classes always use _sample_sequence)"""
         return self._sample_sequence
 
+    @staticmethod
+    def _fresh_flags(plans, batch_size: int, horizon: int):
+        """per step, uint8 (bm, horizon): 0 where the backbone input of (row, frame) is bit-for-bit the previous step's.  That holds when
+        in BOTH steps the token enters as x_in = 1 * xs + 0 * noise (tables rows 0, 1) at the same model level (row 7), the previous
+        composition left it alone (gen == 0: dfot_ddim_compose copies such tokens) and the steps share the branch batch and the
+        conditioning tensors -- the clean context frames of a conditional History-Guidance branch (history_guidance.py:474-533,
+        dfot_video.py:682-752).  Every frame of a window's first step, and of a step after a re-noising row, is fresh."""
+        out, prev = [], None
+        for p_ in plans:
+            fresh = np.ones((p_["bm"], horizon), np.uint8)
+            if p_.get("renoise"):
+                out.append(fresh)
+                prev = None
+                continue
+            if (prev is not None and prev["bm"] == p_["bm"] and prev["nfe"] == p_["nfe"] and prev.get("cond") is p_.get("cond")
+                    and ((prev["cmask"] is None and p_["cmask"] is None)
+                         or (prev["cmask"] is not None and p_["cmask"] is not None and np.array_equal(prev["cmask"], p_["cmask"])))):
+                a, b = prev["tables"], p_["tables"]
+                same_in = (a[0] == 1) & (a[1] == 0) & (b[0] == 1) & (b[1] == 0) & (a[7] == b[7])
+                untouched = np.repeat(prev["gen"].reshape(batch_size, horizon) == 0, p_["nfe"], axis=0)
+                fresh = np.where(same_in & untouched, 0, 1).astype(np.uint8)
+            out.append(fresh)
+            prev = p_
+        return out
+
     def _run_steps_graph(self, plans, xs, draw_noise, step, flat_dev, gens_dev, horizon):
         """hipGraph execution of the step loop: step 0 runs eagerly (lazy initialisation, pose caches), then ALL remaining steps
         [hg_prepare -> backbone -> ddim/compose/clamp] x (n_steps - 1) are captured as ONE graph and launched with one replay.
@@ -535,11 +573,13 @@ class DFoTVideoPoseSampler:
             ent = dict(tables=torch.empty(n_steps, 8, bm, horizon, device="cuda", dtype=torch.float32),
                        gens=torch.empty_like(gens_dev), weights=torch.empty_like(p0["weights_dev"]),
                        lives=torch.empty(n_steps, bm, horizon, device="cuda", dtype=torch.uint8),
+                       fresh=torch.empty(n_steps, bm, horizon, device="cuda", dtype=torch.uint8),
                        noise=torch.empty(n_steps, bm, *xs.shape[1:], device="cuda") if need_noise else None,
                        xs=torch.empty_like(xs), out=None, graph=None)
         ent["tables"].copy_(flat_dev.view(n_steps, 8, bm, horizon))
         ent["gens"].copy_(gens_dev)
         ent["lives"].copy_(gens_dev if nfe == 1 else gens_dev.repeat_interleave(nfe, dim=1))
+        ent["fresh"].copy_(torch.stack([p_["fresh_dev"] for p_ in plans]))
         ent["weights"].copy_(p0["weights_dev"])
         if need_noise:
             for i, p_ in enumerate(plans):
@@ -548,14 +588,16 @@ class DFoTVideoPoseSampler:
                 else:
                     ent["noise"][i].zero_()
         p_static = dict(p0, weights_dev=ent["weights"])
-        ent["xs"].copy_(step(p_static, xs, None if not need_noise else ent["noise"][0], ent["tables"][0], ent["gens"][0], live_dev=ent["lives"][0]))
+        ent["xs"].copy_(step(p_static, xs, None if not need_noise else ent["noise"][0], ent["tables"][0], ent["gens"][0], live_dev=ent["lives"][0],
+                            fresh_dev=ent["fresh"][0]))
         if ent["graph"] is None:
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
                 x = ent["xs"]
                 for i in range(1, n_steps):
-                    x = step(p_static, x, ent["noise"][i] if need_noise else None, ent["tables"][i], ent["gens"][i], live_dev=ent["lives"][i])
+                    x = step(p_static, x, ent["noise"][i] if need_noise else None, ent["tables"][i], ent["gens"][i], live_dev=ent["lives"][i],
+                             fresh_dev=ent["fresh"][i])
                 ent["out"] = x
             ent["graph"] = graph
             if len(self._graphs) >= 4:  # small LRU: each entry owns a private memory pool

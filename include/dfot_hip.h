@@ -115,6 +115,16 @@ int dfot_uvit_forward_cached(dfot_uvit_t h, const float* x, const float* noise_l
  * projection: u_vit3d.py:30-185), so those frames are skipped there.  Attention levels always run on every frame (context frames are keys). */
 int dfot_uvit_forward_cached_live(dfot_uvit_t h, const float* x, const float* noise_levels, float* out, int batch,
                                   const uint8_t* live_frames, void* stream);
+/* ... and with a second flag per frame (device uint8 [batch * T], or NULL = every frame is fresh): fresh_frames == 0 states that this frame's
+ * input, noise level and conditioning are those of the PREVIOUS forward of this handle (same batch) -- a clean context frame of the
+ * conditional History-Guidance branch keeps its value and its level over the DDIM steps of a window (dfot_video.py:682-752) -- so its
+ * activations in the frame-local down path (ResBlock levels, Downsample convolutions) are still in the workspace and are not recomputed.
+ * A frozen frame must be a dead frame (live_frames == 0) in this forward AND in the previous one -- the up path overwrites the level
+ * buffers of live frames in place -- so live_frames may not be NULL (DFOT_ERR_ARG).  DFOT_ERR_STATE when the previous forward ran another
+ * batch.  The flags are ignored (everything is recomputed) when an image of the third level has fewer rows than the largest GEMM tile
+ * (resolution < 256).  Results are bit-identical to the full forward. */
+int dfot_uvit_forward_cached_masks(dfot_uvit_t h, const float* x, const float* noise_levels, float* out, int batch,
+                                   const uint8_t* live_frames, const uint8_t* fresh_frames, void* stream);
 /* debug/parity taps: copy an internal activation after the last forward (fp32). names: "pose_emb0","down0","down1",
  * "down2","mid","up2","up1","up0" in the oracle's NCHW layout. */
 int dfot_uvit_read_tap(dfot_uvit_t h, const char* name, float* out, size_t capacity_floats, void* stream);

@@ -510,3 +510,43 @@ def test_config2_50_steps_full_size_vs_fp32_oracle():
     print("50 steps @256^2 full depth: PSNR %.1f dB (worst frame %.1f); rel-L2 of the window state at steps 1/10/25/40/50: %s"
           % (p, worst, " ".join("%.2e" % drift[i] for i in (0, 9, 24, 39, 49))))
     assert torch.isfinite(out).all() and p >= 35.0
+
+
+def test_frozen_context_frames_skip_the_down_path_bit_exactly():
+    """Clean context frames of the conditional History-Guidance branch enter the backbone with the same pixels, level and pose every DDIM
+    step of a window: from the second step on their ResBlock / Downsample work is skipped (their activations are still in the
+    workspace; include/dfot_hip.h dfot_uvit_forward_cached_masks).  At 256x256 (whole GEMM tiles per frame) the sample must be
+    BIT-identical with the skipping on, off, and with the dead-frame skipping off as well; eager and hipGraph."""
+    import dfot_amd
+    from oracle import uvit as ouvit
+    ocfg = ouvit.UViTConfig(resolution=256, num_updown_blocks=(1, 1, 1), num_mid_blocks=1)
+    params = ouvit.seeded_params(ocfg, 2)
+    cfg = dict(channels=list(ocfg.channels), emb_channels=ocfg.emb_channels, patch_size=2, block_types=list(ocfg.block_types),
+               num_updown_blocks=list(ocfg.num_updown_blocks), num_mid_blocks=ocfg.num_mid_blocks, num_heads=ocfg.num_heads,
+               pos_emb_type="rope", use_fourier_noise_embedding=True, conditioning=dict(dim=180))
+    model = dfot_amd.UViT3DPose(cfg, x_shape=(3, 256, 256), max_tokens=8).cuda()
+    model.load_state_dict(params, strict=True)
+    xs = torch.randn(1, 8, 3, 256, 256, generator=torch.Generator().manual_seed(5))
+    cnd = poses(1, 8, 5)
+    outs = {}
+    for name, dead, frozen, graph in (("all", False, False, False), ("dead", True, False, False), ("frozen", True, True, False),
+                                      ("frozen_graph", True, True, True)):
+        scfg = dfot_amd.SamplerConfig(x_shape=(3, 256, 256), diffusion=dfot_amd.DiffusionConfig(sampling_timesteps=6),
+                                      prediction_guidance=dict(name="vanilla", guidance_scale=4.0))
+        noise = Replay(17, "cuda")
+        noise.strict_order = False  # (the hipGraph path refuses a strict-order noise source)
+        samp = dfot_amd.DFoTVideoPoseSampler(scfg, model, noise)
+        samp.skip_dead_frames, samp.skip_frozen_frames, samp.use_graph = dead, frozen, graph
+        derive, seen = samp._fresh_flags, []
+        samp._fresh_flags = lambda plans, b, h: seen.append(derive(plans, b, h)) or seen[-1]
+        outs[name] = samp._predict_videos(xs, n_context_tokens=2, conditions=cnd).cpu()
+        assert samp.graph_replays == (5 if graph else 0)
+    assert torch.isfinite(outs["all"]).all()
+    for name in ("dead", "frozen", "frozen_graph"):
+        assert torch.equal(outs[name], outs["all"]), name
+    # the flags the sampler derived (rows = (sample, branch): unconditional, conditional -- guidance.py): the two context frames of the
+    # conditional branch are frozen from the second step on and nothing else ever is (the other branch re-noises its context every step)
+    fresh = np.stack(seen[0])
+    want = np.ones((6, 2, 8), np.uint8)
+    want[1:, 1, :2] = 0
+    assert np.array_equal(fresh, want)
