@@ -25,7 +25,10 @@ __device__ __forceinline__ int xcd_remap(int orig, int nwg, int enable = 1) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
 }
 
-__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+// x * sigmoid(x) with the hardware reciprocal (1 ulp) instead of an IEEE division: the division is ten instructions per element, and
+// the GEMM epilogues that apply SiLU to a 256x256 tile run with the matrix pipe idle (14 of the 118 us of the level-2 fused
+// projection were this division; profiles/r03 notes in DESIGN.md)
+__device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 
 __device__ __forceinline__ float bf2f(bf16 v) { return (float)v; }
 __device__ __forceinline__ bf16 f2bf(float v) { return (bf16)v; }

@@ -330,7 +330,14 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int tile_inde
   const bool live = col < g.N && cw < WTN;  // N is a multiple of the lane's column count, so a lane is entirely in or out
   f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = {0.f, 0.f, 0.f, 0.f};
   [[maybe_unused]] const bool bias2d = g.bias_rows > 0;  // bias[(row % bias_rows)][col] (MatrixAttention qkv_bias / proj_bias)
-  if (g.bias && live && !bias2d && kslice == 0) {  // split-K: slice 0 alone adds the bias
+  [[maybe_unused]] float bc[NI];  // E_QKV: the bias in the MFMA C layout (one column per lane and 16-column tile), added on the way into LDS
+  if constexpr (EPI == E_QKV) {
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      const int c = nw + ni * 16 + colq;
+      bc[ni] = (g.bias && c < g.N) ? g.bias[c] : 0.f;
+    }
+  } else if (g.bias && live && !bias2d && kslice == 0) {  // split-K: slice 0 alone adds the bias
     b0 = *reinterpret_cast<const f32x4*>(g.bias + col);
     if constexpr (EPI != E_F32) b1 = *reinterpret_cast<const f32x4*>(g.bias + col + 4);
   }
@@ -357,27 +364,108 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int tile_inde
       return;
     }
   }
+  // E_QKV: everything that does not depend on the row is worked out once per lane, and the rotary table rows of a pass are fetched one
+  // pass AHEAD, in front of the previous pass's stores: the vector-memory counter retires loads and stores in issue order, so a load
+  // issued behind a pass's stores cannot be waited for without waiting for those stores too (four exposed store round trips per pass
+  // in the first form of this epilogue: 20 of the 118 us of the level-2 fused projection)
+  [[maybe_unused]] f32x4 res_cur[4];
+  [[maybe_unused]] const bool pre_res = EPI == E_F32 && has_res && ksplit == 1 && live;
+  [[maybe_unused]] auto load_res = [&](int mi) {  // residual rows of pass mi (16 rows of the wave's tile)
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const long row = (long)m0 + wm * WTM + mi * 16 + p * 4 + (lane >> 4);
+      res_cur[p] = *reinterpret_cast<const f32x4*>(g.resid + row * g.ldo + col);
+    }
+  };
+  if constexpr (EPI == E_F32) {
+    if (pre_res) load_res(0);
+  }
+  [[maybe_unused]] int q_which = 0, q_head = 0, q_e0 = 0;
+  [[maybe_unused]] bool q_rot = false;            // this lane's columns are q or k columns (normalised and rotated)
+  [[maybe_unused]] float q_w[8], q_mul = 1.f;
+  [[maybe_unused]] bf16* q_dst = nullptr;
+  [[maybe_unused]] f32x4 cs_cur[2][2];
+  [[maybe_unused]] unsigned t_b = 0, t_k = 0;     // batch element and token of the tile's first row
+  [[maybe_unused]] auto row_token = [&](int ro, long& bidx, int& tok) {  // row m0 + ro -> (batch element, token), ro < BM_T
+    unsigned t = t_k + (unsigned)ro, b = t_b;
+    if (g.ntok >= BM_T) {  // uniform: a tile spans at most two batch elements
+      if (t >= (unsigned)g.ntok) {
+        t -= (unsigned)g.ntok;
+        ++b;
+      }
+    } else {
+      b += t / (unsigned)g.ntok;
+      t = t % (unsigned)g.ntok;
+    }
+    bidx = b;
+    tok = (int)t;
+  };
+  [[maybe_unused]] auto load_cs = [&](int mi, f32x4 (&dst)[2][2]) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      long bidx;
+      int tok;
+      row_token(wm * WTM + mi * 16 + p * 8 + (lane >> 3), bidx, tok);
+      const float* cs = g.rope_cs + ((long)tok * (g.d / 2) + q_e0 / 2) * 2;
+      dst[p][0] = *reinterpret_cast<const f32x4*>(cs);
+      dst[p][1] = *reinterpret_cast<const f32x4*>(cs + 4);
+    }
+  };
+  if constexpr (EPI == E_QKV) {
+    // the wave's 64 columns lie inside one region and one head: region, head and destination are wave-uniform (scalar registers)
+    t_b = (unsigned)m0 / (unsigned)g.ntok;
+    t_k = (unsigned)m0 - t_b * (unsigned)g.ntok;
+    const int colw = __builtin_amdgcn_readfirstlane(nw);
+    if (live && colw < g.split) {
+      const int cdim = g.split / 3;
+      q_which = colw / cdim;
+      const int ccw = colw - q_which * cdim;
+      q_head = ccw / g.d;
+      q_e0 = ccw % g.d + cw;
+      q_dst = q_which == 0 ? g.q : (q_which == 1 ? g.k : g.v);
+      q_rot = q_which < 2;
+      if (q_rot) {
+        const float* wgt = (q_which == 0 ? g.qw : g.kw) + q_e0;
+        const f32x4 w0 = *reinterpret_cast<const f32x4*>(wgt), w1 = *reinterpret_cast<const f32x4*>(wgt + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) q_w[j] = w0[j], q_w[4 + j] = w1[j];
+        q_mul = q_which == 0 ? g.qscale : 1.f;
+        load_cs(0, cs_cur);
+      }
+    }
+  }
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) ep[(rowq + j) * EP_LD + ni * 16 + colq] = acc[mi][ni][j];
+      for (int j = 0; j < 4; ++j) ep[(rowq + j) * EP_LD + ni * 16 + colq] = EPI == E_QKV ? acc[mi][ni][j] + bc[ni] : acc[mi][ni][j];
     const long mw = (long)m0 + wm * WTM + mi * 16;
     if constexpr (EPI == E_F32) {
       if (live) {
+        // the pass's four output rows are finished first, the NEXT pass's residual rows are fetched, and only then are this pass's
+        // rows stored: a residual load issued behind a store could not be waited for without that store (in-order memory counter)
+        f32x4 vout[4];
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
           const int r = p * 4 + (lane >> 4);
           f32x4 v = *reinterpret_cast<const f32x4*>(ep + r * EP_LD + cw) + b0;
           if (bias2d) v += *reinterpret_cast<const f32x4*>(g.bias + (long)((unsigned)(mw + r) % (unsigned)g.bias_rows) * g.N + col);
-          const long off = (mw + r) * g.ldo + col + (ksplit > 1 ? (long)kslice * g.slice_stride : 0L);
           if (has_gate) {
             long gr = (unsigned)(mw + r) / (unsigned)g.gate_rows;  // 32-bit division (a 64-bit one costs ~100 instructions)
             if (g.gate_index) gr = g.gate_index[gr];
             v *= *reinterpret_cast<const f32x4*>(g.gate + gr * g.ldg + col);
           }
-          if (has_res && ksplit == 1) v += *reinterpret_cast<const f32x4*>(g.resid + off);
+          if (pre_res) v += res_cur[p];
+          vout[p] = v;
+        }
+        if (pre_res && mi + 1 < MI) load_res(mi + 1);
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          const int r = p * 4 + (lane >> 4);
+          const f32x4 v = vout[p];
+          const long off = (mw + r) * g.ldo + col + (ksplit > 1 ? (long)kslice * g.slice_stride : 0L);
           if (ksplit > 1 && g.slice_stride == 0) {  // out already holds the residual (resid == out, checked by the launcher) or zeros
 #pragma unroll
             for (int j = 0; j < 4; ++j) atomicAdd(g.out_f32 + off + j, v[j]);
@@ -389,9 +477,9 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int tile_inde
         }
       }
     } else {
-      float vals[2][8];
+      [[maybe_unused]] float vals[2][8];
 #pragma unroll
-      for (int p = 0; p < 2; ++p) {
+      for (int p = 0; p < (EPI == E_QKV ? 0 : 2); ++p) {
         const int r = p * 8 + (lane >> 3);
         f32x4 v0 = *reinterpret_cast<const f32x4*>(ep + r * EP_LD + cw) + b0;
         f32x4 v1 = *reinterpret_cast<const f32x4*>(ep + r * EP_LD + cw + 4) + b1;
@@ -482,15 +570,31 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int tile_inde
         // The wave's 64 columns lie inside one region (q | k | v | MLP) and, for q/k, inside one head: the whole head
         // when d = 64, half of it when d = 128 -- then the other half belongs to wave^1 and the squared sums are
         // exchanged through LDS.  Everything up to the barrier is executed by every lane of the workgroup.
-        float ssq[2];
+        // The 16 transposed rows stay in the wave's LDS scratch for the whole pass and are read again where they are used (8 values
+        // at a time) instead of being held in registers across the row reduction: the 16-wave kernels sit at the 128-register cap.
+        auto read_row = [&](int p, float (&v)[8]) {
+          const int r = p * 8 + (lane >> 3);
+          const f32x4 v0 = *reinterpret_cast<const f32x4*>(ep + r * EP_LD + cw);
+          const f32x4 v1 = *reinterpret_cast<const f32x4*>(ep + r * EP_LD + cw + 4);
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
-          float t = 0.f;
+          for (int j = 0; j < 4; ++j) v[j] = v0[j], v[4 + j] = v1[j];
+        };
+        float ssq[2] = {0.f, 0.f};
+        if (q_rot || g.d == 128) {
 #pragma unroll
-          for (int j = 0; j < 8; ++j) t += vals[p][j] * vals[p][j];
+          for (int p = 0; p < 2; ++p) {
+            float v[8];
+            read_row(p, v);
+            float t = 0.f;
 #pragma unroll
-          for (int o = 1; o < 8; o <<= 1) t += __shfl_xor(t, o);  // 8 lanes = this wave's 64 columns of one row
-          ssq[p] = t;
+            for (int j = 0; j < 8; ++j) t += v[j] * v[j];
+            // 8 lanes = this wave's 64 columns of one row: butterfly over lane bits 0, 1 (quad permutes) and 2 (mirror of the
+            // 8-lane half row: after the first two steps the four lanes of a quad agree, so lane i <-> 7 - i pairs the quads)
+            t += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0xB1, 0xF, 0xF, false));
+            t += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0x4E, 0xF, 0xF, false));
+            t += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0x141, 0xF, 0xF, false));
+            ssq[p] = t;
+          }
         }
         if (g.d == 128) {  // workgroup-uniform
           float* xch = reinterpret_cast<float*>(smem) + NW * 16 * EP_LD + (mi & 1) * NW * 16;
@@ -506,9 +610,11 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int tile_inde
 #pragma unroll
           for (int p = 0; p < 2; ++p) {
             const int r = p * 8 + (lane >> 3);
+            float v[8];
+            read_row(p, v);
             bf16x8 o;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] = f2bf(vals[p][j]);
+            for (int j = 0; j < 8; ++j) o[j] = f2bf(v[j]);
             *reinterpret_cast<bf16x8*>(g.raw + (mw + r) * g.ldraw + col) = o;
           }
         }
@@ -517,41 +623,45 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int tile_inde
 #pragma unroll
             for (int p = 0; p < 2; ++p) {
               const int r = p * 8 + (lane >> 3);
+              float v[8];
+              read_row(p, v);
               bf16x8 o;
 #pragma unroll
-              for (int j = 0; j < 8; ++j) o[j] = f2bf(silu_f(vals[p][j]));
+              for (int j = 0; j < 8; ++j) o[j] = f2bf(silu_f(v[j]));
               *reinterpret_cast<bf16x8*>(g.out2 + (mw + r) * g.ldo2 + (col - g.split)) = o;
             }
           } else {
-            const int cdim = g.split / 3;
-            const int which = col / cdim;
-            const int cc = col - which * cdim;
-            const int head = cc / g.d, e0 = cc % g.d;
+            bf16x8 o2[2];
 #pragma unroll
             for (int p = 0; p < 2; ++p) {
-              const unsigned row = (unsigned)(mw + p * 8 + (lane >> 3));
-              const long bidx = row / (unsigned)g.ntok;
-              const int tok = (int)(row % (unsigned)g.ntok);
-              bf16x8 o;
-              if (which == 2) {
+              bf16x8& o = o2[p];
+              float v[8];
+              read_row(p, v);
+              if (!q_rot) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) o[j] = f2bf(vals[p][j]);
+                for (int j = 0; j < 8; ++j) o[j] = f2bf(v[j]);
               } else {
                 const float rs = rsqrtf(ssq[p] / (float)g.d + g.eps);
-                const float* wgt = (which == 0 ? g.qw : g.kw) + e0;
-                const float mul = which == 0 ? g.qscale : 1.f;
-                const float* cs = g.rope_cs + ((long)tok * (g.d / 2) + e0 / 2) * 2;
 #pragma unroll
                 for (int pr = 0; pr < 4; ++pr) {
-                  const float x0 = vals[p][2 * pr] * rs * wgt[2 * pr];
-                  const float x1 = vals[p][2 * pr + 1] * rs * wgt[2 * pr + 1];
-                  const float co = cs[2 * pr], si = cs[2 * pr + 1];
-                  o[2 * pr] = f2bf((x0 * co - x1 * si) * mul);
-                  o[2 * pr + 1] = f2bf((x1 * co + x0 * si) * mul);
+                  const float x0 = v[2 * pr] * rs * q_w[2 * pr];
+                  const float x1 = v[2 * pr + 1] * rs * q_w[2 * pr + 1];
+                  const float co = cs_cur[p][pr >> 1][2 * (pr & 1)], si = cs_cur[p][pr >> 1][2 * (pr & 1) + 1];
+                  o[2 * pr] = f2bf((x0 * co - x1 * si) * q_mul);
+                  o[2 * pr + 1] = f2bf((x1 * co + x0 * si) * q_mul);
                 }
               }
-              bf16* dst = which == 0 ? g.q : (which == 1 ? g.k : g.v);
-              *reinterpret_cast<bf16x8*>(dst + ((bidx * g.heads + head) * g.ntok + tok) * (long)g.d + e0) = o;
+            }
+            // the next pass's table rows go out behind the last use of this pass's and in FRONT of this pass's stores (the compiler
+            // may not move either across the barrier: float loads and bf16 stores do not alias for it otherwise)
+            if (q_rot && mi + 1 < MI) load_cs(mi + 1, cs_cur);
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+              long bidx;
+              int tok;
+              row_token(wm * WTM + mi * 16 + p * 8 + (lane >> 3), bidx, tok);
+              *reinterpret_cast<bf16x8*>(q_dst + ((bidx * g.heads + q_head) * g.ntok + tok) * (long)g.d + q_e0) = o2[p];
             }
           }
         }
