@@ -87,6 +87,7 @@ enum GemmVariant {
   // 256x144 tile (12 waves of 64x48), 2 stages, dense A, plain epilogues: N = multiples of 144 (576, 1152) give M/256 x N/144 tiles =
   // exactly one per CU for the level-2 out-projection (256) and, with two K slices, for the level-3 one (128 x 2)
   GEMM_DMA_256x144 = 13,
+  GEMM_DMA3_256x144 = 14,  // ... with a 3-stage ring (150 KB): the long-K out-projections wait on the one k-tile a 2-stage loop has in flight
   GEMM_AUTO = -1      // pick by shape (gemm_pick_variant)
 };
 int gemm_pick_variant(int amode, int m, int n, int k);

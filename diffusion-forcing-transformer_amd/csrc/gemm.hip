@@ -39,6 +39,22 @@ __device__ __forceinline__ void wait_all_but() {
   if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)\n\ts_barrier" ::: "memory");
 }
 
+// ... with a run-time (wave-uniform) count: tiles whose staging instructions do not divide evenly over the waves (256x144 over 12 waves:
+// 5, 4 or 3 LDS-DMA instructions per k-tile depending on the wave)
+__device__ __forceinline__ void wait_all_but_n(int n) {
+  switch (n) {
+    case 1: asm volatile("s_waitcnt vmcnt(1)\n\ts_barrier" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(3)\n\ts_barrier" ::: "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory"); break;
+    case 5: asm volatile("s_waitcnt vmcnt(5)\n\ts_barrier" ::: "memory"); break;
+    case 6: asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory"); break;
+    case 7: asm volatile("s_waitcnt vmcnt(7)\n\ts_barrier" ::: "memory"); break;
+    case 8: asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory"); break;
+  }
+}
+
 // KS = 2: intra-workgroup split-K for grids too small to fill the chip (level-3 GEMMs at model batch 2): two groups of
 // NW waves each own a private pair of LDS stages and alternate k-tiles (group g takes k-tiles g, g+2, ...), doubling the
 // waves per CU and halving the serial k-loop; group 1's accumulators are folded into group 0's through LDS at the end.
@@ -64,7 +80,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int tile_inde
   constexpr int ACH = (AINS + NW - 1) / NW;     // A chunks (16 B) per thread per k-tile
   constexpr int WCH = (WINS + NW - 1) / NW;     // W chunks per thread per k-tile
   constexpr bool A_EVEN = AINS % NW == 0, W_EVEN = WINS % NW == 0;
-  static_assert((A_EVEN && W_EVEN) || (DMA && NST == 2 && KS == 1), "uneven staging: two-stage LDS-DMA kernels only");
+  static_assert((A_EVEN && W_EVEN) || (DMA && KS == 1), "uneven staging: LDS-DMA kernels without intra-workgroup split-K only");
   constexpr int A_BYTES = BM_T * BKT * 2;
   constexpr int STAGE_BYTES = (BM_T + BN_T) * BKT * 2;
   constexpr int LOADS = ACH + WCH;              // LDS-DMA instructions per thread per k-tile
@@ -289,12 +305,19 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int tile_inde
   } else {
     // NST-stage ring (NST >= 3).  Invariant at the top of iteration kt: tile kt has landed and is visible to every wave
     // (its waves waited for it, then passed a barrier); tiles kt+1 .. kt+NST-2 may still be in flight.
-    static_assert(NST >= 3 && A_EVEN && W_EVEN, "ring: even staging only");
+    static_assert(NST >= 3, "ring");
+    // LDS-DMA instructions THIS wave issues per k-tile (wave-uniform; = LOADS when the staging divides evenly)
+    [[maybe_unused]] const int my_loads =
+        __builtin_amdgcn_readfirstlane((AINS - wave + NW - 1) / NW + (WINS - wave + NW - 1) / NW);
+    auto ring_wait = [&]() {
+      if constexpr (A_EVEN && W_EVEN) wait_all_but<(NST - 2) * LOADS>();
+      else wait_all_but_n((NST - 2) * my_loads);
+    };
 #pragma unroll
     for (int t = 0; t < NST - 1; ++t)
       if (t < nk) issue(t, t);
     if (nk >= NST - 1) {
-      wait_all_but<(NST - 2) * LOADS>();
+      ring_wait();
     } else {
       asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
     }
@@ -305,7 +328,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int tile_inde
       if (kt + NST - 1 < nk) issue(kt + NST - 1, nxt);
       compute(st);
       if (kt + NST - 1 < nk) {
-        wait_all_but<(NST - 2) * LOADS>();  // tile kt+1 has landed; the NST-2 newer ones may stay in flight
+        ring_wait();  // tile kt+1 has landed; the NST-2 newer ones may stay in flight
       } else {
         asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
       }
@@ -798,6 +821,12 @@ static int launch_v(int variant, const GemmArgs& g, hipStream_t s) {
         if (g.gn_part) break;
         return launch_t<256, 144, 64, 2, AMODE, EPI, true>(g, s);
       }
+    case GEMM_DMA3_256x144:
+      if constexpr (AMODE != A_DENSE || EPI != E_F32) break;
+      else {
+        if (g.gn_part) break;
+        return launch_t<256, 144, 64, 3, AMODE, EPI, true>(g, s);
+      }
     case GEMM_DMA_128x192:
       if constexpr (AMODE != A_DENSE || EPI == E_QKV) break;
       else return launch_t<128, 192, 64, 2, AMODE, EPI, true>(g, s);
@@ -849,7 +878,7 @@ int launch_gemm(int amode, int epi, int variant, const GemmArgs& g, hipStream_t 
   if (variant == GEMM_DMA_128_KS2 && epi == E_QKV) variant = GEMM_DMA_128;  // the QKV epilogue has workgroup barriers
   if (variant == GEMM_DMA_128x192 && epi == E_QKV) variant = GEMM_DMA_128;
   if (variant == GEMM_DMA_256x192 && epi == E_QKV && g.d != 64) variant = GEMM_DMA_256x256;  // the d = 128 head pairing needs 128-aligned tiles
-  const int bm = variant == GEMM_DMA_512x128 ? 512 : (variant == GEMM_DMA3_256 || variant == GEMM_DMA_256x256 || variant == GEMM_DMA_256x128 || variant == GEMM_DMA_256x256_W128 || variant == GEMM_DMA_256x192 || variant == GEMM_DMA_256x144) ? 256 : 128;
+  const int bm = variant == GEMM_DMA_512x128 ? 512 : (variant == GEMM_DMA3_256 || variant == GEMM_DMA_256x256 || variant == GEMM_DMA_256x128 || variant == GEMM_DMA_256x256_W128 || variant == GEMM_DMA_256x192 || variant == GEMM_DMA_256x144 || variant == GEMM_DMA3_256x144) ? 256 : 128;
   DFOT_REQUIRE(g.M > 0 && g.M % bm == 0, DFOT_ERR_SHAPE, "gemm: M=%d must be a positive multiple of %d", g.M, bm);
   DFOT_REQUIRE(g.K > 0 && g.K % BK == 0, DFOT_ERR_SHAPE, "gemm: K=%d must be a positive multiple of %d", g.K, BK);
   DFOT_REQUIRE(g.N > 0 && g.N % (epi == E_F32 ? 4 : 8) == 0, DFOT_ERR_SHAPE, "gemm: N=%d must be a multiple of %d", g.N, epi == E_F32 ? 4 : 8);

@@ -479,10 +479,12 @@ static int run_tr_block(dfot_uvit_s* h, const TrW& w, int lvl, int batch, hipStr
   if (l3_split > 1 && (long)(m / 256) * ((c + 191) / 192) < 200 && h->xin[lvl] == x) o.ksplit = l3_split;
   // level 3 at small model batch: 256x144 tiles give M/256 x N/144 = 128 workgroups for 256 CUs; two K slices into partial
   // buffers make it 256, and one pass adds slices + bias into the fp32 residual stream (out_reduce_kernel)
-  static const int split144 = tuning_flag("UVIT_OUT_SPLIT144", 2);  // 0: one GEMM with the residual epilogue; 1: 256x144 x 2 slices; 2: 256x256 x 3 slices
+  static const int split144 = tuning_flag("UVIT_OUT_SPLIT144", 1);  // 0: one GEMM with the residual epilogue; 1: 256x144 x 2 slices; 2: 256x256 x 3 slices
   static const int defer = tuning_flag("UVIT_OUT_DEFER", 1);  // A/B: 0 = reduce pass right away
-  // default (2): 256x256 tiles (the best main loop: half the L2 -> LDS operand bytes per FLOP of 256x144; N padded to the tile: 5 column
-  // tiles for 1152) x three K slices = 240 workgroups for 256 CUs; +1.0 / +1.6 % frames/s over mode 1 in two same-box A/B pairs
+  // mode 2: 256x256 tiles (half the L2 -> LDS operand bytes per FLOP of 256x144; N padded to the tile: 5 column tiles for 1152) x three K
+  // slices = 240 workgroups for 256 CUs; +1.0 / +1.6 % frames/s over mode 1 while mode 1 ran the two-stage 256x144 kernel.  With the
+  // THREE-stage 256x144 ring (150 KB of LDS: the long-K loop no longer waits on the single k-tile a two-stage loop has in flight) mode 1
+  // is ahead: 10.08 vs 9.99 frames/s (two same-box rounds), 256 workgroups, no padded columns, two slabs instead of three: default
   if (split144 == 2 && h->gemm_variant == GEMM_AUTO && h->out_part && (size_t)3 * m * c <= h->out_part_elems && m % 256 == 0 &&
       (long)(m / 256) * ((c + 255) / 256) * 3 <= 256 && (5 * c / 64) % 3 == 0 && (5 * c / 64) >= 12) {
     GemmArgs p3 = o;
@@ -497,7 +499,8 @@ static int run_tr_block(dfot_uvit_s* h, const TrW& w, int lvl, int batch, hipStr
       (long)(m / 256) * (c / 144) * 2 <= 256 && (5 * c / 64) >= 8) {
     GemmArgs p2 = o;
     p2.bias = nullptr; p2.resid = nullptr; p2.out_f32 = h->out_part; p2.ksplit = 2; p2.slice_stride = (long)m * c;
-    if ((rc = launch_gemm(A_DENSE, E_F32, GEMM_DMA_256x144, p2, s))) return rc;
+    static const int ring144 = tuning_flag("UVIT_OUT_RING144", 1);
+    if ((rc = launch_gemm(A_DENSE, E_F32, ring144 ? GEMM_DMA3_256x144 : GEMM_DMA_256x144, p2, s))) return rc;
     h->pend_bias = w.b_out;
     h->pend_lvl = lvl; h->pend_m = m; h->pend_c = c; h->pend_slices = 2;
     swap_out_part(h);
@@ -505,10 +508,11 @@ static int run_tr_block(dfot_uvit_s* h, const TrW& w, int lvl, int batch, hipStr
   }
   // level 2 (M = 16384, N = 576): 256x192 tiles are 192 workgroups -- a quarter of the chip idle for the whole kernel; 256x144 tiles
   // (N = 4 x 144) are exactly 256, one per CU, at 92 instead of 110 FLOP per operand byte
-  static const int l2_144 = tuning_flag("UVIT_OUT_L2_144", 0);  // A/B: equal within noise (9.42 vs 9.42 frames/s, two rounds): off
+  // (two-stage kernel, flag = 1: equal within noise, 9.42 vs 9.42 frames/s; three-stage ring, flag = 2: 10.10 vs 10.00, two rounds: default)
+  static const int l2_144 = tuning_flag("UVIT_OUT_L2_144", 2);
   if (l2_144 && h->gemm_variant == GEMM_AUTO && o.ksplit == 1 && c % 144 == 0 && m % 256 == 0 && (long)(m / 256) * ((c + 191) / 192) < 256 &&
       (long)(m / 256) * (c / 144) >= 200 && (long)(m / 256) * (c / 144) <= 256)
-    rc = launch_gemm(A_DENSE, E_F32, GEMM_DMA_256x144, o, s);
+    rc = launch_gemm(A_DENSE, E_F32, l2_144 == 2 ? GEMM_DMA3_256x144 : GEMM_DMA_256x144, o, s);
   else
     rc = launch_gemm(A_DENSE, E_F32, h->gemm_variant, o, s);
   h->xin[lvl] = x;
