@@ -42,7 +42,7 @@ with torch.no_grad():
     for ts in (0, int(os.environ.get("TS", "1"))):
         model.set_option("two_stream", ts)
         runs = []
-        for _ in range(4):
+        for _ in range(int(os.environ.get("RUNS", "4"))):
             o = model(x, k, cond, None).clone()
             r = grab() if not os.environ.get("NOGRAB") else {}
             r["out"] = o
