@@ -391,7 +391,14 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int tile_inde
   // pass AHEAD, in front of the previous pass's stores: the vector-memory counter retires loads and stores in issue order, so a load
   // issued behind a pass's stores cannot be waited for without waiting for those stores too (four exposed store round trips per pass
   // in the first form of this epilogue: 20 of the 118 us of the level-2 fused projection)
-  [[maybe_unused]] f32x4 res_cur[4];
+  [[maybe_unused]] f32x4 res_cur[4], gate_cur;
+  // adaLN gate: one gate vector per gate_rows output rows; when that is a multiple of 16 the 16 rows of a pass share it (4 registers)
+  [[maybe_unused]] const bool pre_gate = EPI == E_F32 && has_gate && live && g.gate_rows % 16 == 0;
+  [[maybe_unused]] auto load_gate = [&](int mi) {
+    long gr = (unsigned)(m0 + wm * WTM + mi * 16) / (unsigned)g.gate_rows;  // 32-bit division (a 64-bit one costs ~100 instructions)
+    if (g.gate_index) gr = g.gate_index[gr];
+    gate_cur = *reinterpret_cast<const f32x4*>(g.gate + gr * g.ldg + col);
+  };
   [[maybe_unused]] const bool pre_res = EPI == E_F32 && has_res && ksplit == 1 && live;
   [[maybe_unused]] auto load_res = [&](int mi) {  // residual rows of pass mi (16 rows of the wave's tile)
 #pragma unroll
@@ -402,6 +409,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int tile_inde
   };
   if constexpr (EPI == E_F32) {
     if (pre_res) load_res(0);
+    if (pre_gate) load_gate(0);
   }
   [[maybe_unused]] int q_which = 0, q_head = 0, q_e0 = 0;
   [[maybe_unused]] bool q_rot = false;            // this lane's columns are q or k columns (normalised and rotated)
@@ -456,6 +464,22 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int tile_inde
         load_cs(0, cs_cur);
       }
     }
+  } else if constexpr (EPI == E_QKV_DIT) {
+    // DiT blocks: q | k | v columns only, no RMS norm; the head dimension need not divide the wave's 64 columns (72 for DiT/XL), so
+    // region / head / offset are per lane (a lane's 8 columns stay inside one head: d % 8 == 0)
+    t_b = (unsigned)m0 / (unsigned)g.ntok;
+    t_k = (unsigned)m0 - t_b * (unsigned)g.ntok;
+    if (live) {
+      const int cdim = g.heads * g.d;
+      q_which = col / cdim;
+      const int cc = col - q_which * cdim;
+      q_head = cc / g.d;
+      q_e0 = cc % g.d;
+      q_dst = q_which == 0 ? g.q : (q_which == 1 ? g.k : g.v);
+      q_mul = q_which == 0 ? g.qscale : 1.f;
+      q_rot = q_which < 2 && g.rope_cs != nullptr;  // v, and q / k of the per-frame spatial blocks, are not rotated
+      if (q_rot) load_cs(0, cs_cur);
+    }
   }
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
@@ -475,14 +499,19 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int tile_inde
           f32x4 v = *reinterpret_cast<const f32x4*>(ep + r * EP_LD + cw) + b0;
           if (bias2d) v += *reinterpret_cast<const f32x4*>(g.bias + (long)((unsigned)(mw + r) % (unsigned)g.bias_rows) * g.N + col);
           if (has_gate) {
-            long gr = (unsigned)(mw + r) / (unsigned)g.gate_rows;  // 32-bit division (a 64-bit one costs ~100 instructions)
-            if (g.gate_index) gr = g.gate_index[gr];
-            v *= *reinterpret_cast<const f32x4*>(g.gate + gr * g.ldg + col);
+            if (pre_gate) {
+              v *= gate_cur;
+            } else {
+              long gr = (unsigned)(mw + r) / (unsigned)g.gate_rows;
+              if (g.gate_index) gr = g.gate_index[gr];
+              v *= *reinterpret_cast<const f32x4*>(g.gate + gr * g.ldg + col);
+            }
           }
           if (pre_res) v += res_cur[p];
           vout[p] = v;
         }
         if (pre_res && mi + 1 < MI) load_res(mi + 1);
+        if (pre_gate && mi + 1 < MI) load_gate(mi + 1);
         asm volatile("" ::: "memory");
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
@@ -561,32 +590,31 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int tile_inde
         }
       } else if constexpr (EPI == E_QKV_DIT) {
         if (live) {
-          const int cdim = g.heads * g.d;
-          const int which = col / cdim;
-          const int cc = col - which * cdim;
-          const int head = cc / g.d, e0 = cc % g.d;  // d % 8 == 0: the lane's 8 columns stay inside one head
-          bf16* dst = which == 0 ? g.q : (which == 1 ? g.k : g.v);
-          const float mul = which == 0 ? g.qscale : 1.f;
+          bf16x8 o2[2];
 #pragma unroll
           for (int p = 0; p < 2; ++p) {
-            const unsigned row = (unsigned)(mw + p * 8 + (lane >> 3));
-            const long bidx = row / (unsigned)g.ntok;
-            const int tok = (int)(row % (unsigned)g.ntok);
-            bf16x8 o;
-            if (which == 2 || g.rope_cs == nullptr) {  // v, or q/k without rotary embedding (per-frame spatial blocks)
+            bf16x8& o = o2[p];
+            if (!q_rot) {
 #pragma unroll
-              for (int j = 0; j < 8; ++j) o[j] = f2bf(vals[p][j] * mul);
+              for (int j = 0; j < 8; ++j) o[j] = f2bf(vals[p][j] * q_mul);
             } else {
-              const float* cs = g.rope_cs + ((long)tok * (g.d / 2) + e0 / 2) * 2;
 #pragma unroll
               for (int pr = 0; pr < 4; ++pr) {
                 const float x0 = vals[p][2 * pr], x1 = vals[p][2 * pr + 1];
-                const float co = cs[2 * pr], si = cs[2 * pr + 1];
-                o[2 * pr] = f2bf((x0 * co - x1 * si) * mul);
-                o[2 * pr + 1] = f2bf((x1 * co + x0 * si) * mul);
+                const float co = cs_cur[p][pr >> 1][2 * (pr & 1)], si = cs_cur[p][pr >> 1][2 * (pr & 1) + 1];
+                o[2 * pr] = f2bf((x0 * co - x1 * si) * q_mul);
+                o[2 * pr + 1] = f2bf((x1 * co + x0 * si) * q_mul);
               }
             }
-            *reinterpret_cast<bf16x8*>(dst + ((bidx * g.heads + head) * g.ntok + tok) * (long)g.dstride + e0) = o;
+          }
+          if (q_rot && mi + 1 < MI) load_cs(mi + 1, cs_cur);  // in front of this pass's stores (see the E_QKV epilogue)
+          asm volatile("" ::: "memory");
+#pragma unroll
+          for (int p = 0; p < 2; ++p) {
+            long bidx;
+            int tok;
+            row_token(wm * WTM + mi * 16 + p * 8 + (lane >> 3), bidx, tok);
+            *reinterpret_cast<bf16x8*>(q_dst + ((bidx * g.heads + q_head) * g.ntok + tok) * (long)g.dstride + q_e0) = o2[p];
           }
         }
       } else {  // E_QKV
