@@ -211,7 +211,7 @@ class UViT3DPose(nn.Module):
         assert external_cond is not None, "External condition (camera pose) is required for U-ViT3DPose model."
         if self._op_key is None:
             self._op_key = ops.register_model(self)
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
             if self._train_names is None:
                 self._train_names = [n for n, _ in self.named_parameters()]
             params = [p for _, p in self.named_parameters()]
@@ -267,7 +267,7 @@ class UViT3DPose(nn.Module):
         with torch.no_grad():
             return eng.forward(x, noise_levels, external_cond, drop).to(x.dtype)
 
-    def _train_backward_impl(self, grad_out, params, stamp=None):
+    def _train_backward_impl(self, grad_out, params, stamp=None, want_dx=False):
         eng = self._trainer
         if eng is None:
             raise RuntimeError("backward without a training forward")
@@ -277,8 +277,11 @@ class UViT3DPose(nn.Module):
                 "saved activations (one engine per module). Run backward after each forward (accumulate gradients as forward/backward "
                 "pairs); two forwards of one module inside one loss are not supported.")
         with torch.no_grad():
-            grads = eng.backward(grad_out)
-        return [grads[n].to(p.dtype).reshape(p.shape) if n in grads else torch.zeros_like(p) for n, p in zip(self._train_names, params)]
+            grads = eng.backward(grad_out, input_grad=want_dx)
+        out = [grads[n].to(p.dtype).reshape(p.shape) if n in grads else torch.zeros_like(p) for n, p in zip(self._train_names, params)]
+        if want_dx:  # the gradient w.r.t. x rides as the last element (ops.py hands it to autograd as x's gradient)
+            out.append(eng.dx_in.to(grad_out.dtype))
+        return out
 
     def _forward_impl(self, x: torch.Tensor, noise_levels: torch.Tensor, external_cond: Optional[torch.Tensor] = None,
                       external_cond_mask: Optional[torch.Tensor] = None) -> torch.Tensor:

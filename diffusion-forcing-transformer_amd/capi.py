@@ -143,6 +143,7 @@ SIGNATURES = {
     "dfot_op_cond_repack": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "dfot_op_embed_input": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "dfot_op_embed_input_wgrad": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "dfot_op_embed_input_dgrad": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "dfot_op_project_output": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "dfot_op_outgrad_gather": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "dfot_op_groupnorm_scratch_floats": (_L, [_I, _I]),

@@ -967,6 +967,39 @@ __global__ void outgrad_gather_kernel(const float* __restrict__ dout, bf16* __re
 }  // namespace
 }  // namespace dfot
 
+// one thread per 2x2 patch: dX[bt][ci][2py+dy][2px+dx] = sum_c dY[patch][c] * W[c][ci*4 + dy*2 + dx]; W staged in LDS (read as a broadcast)
+__global__ __launch_bounds__(256) void embed_input_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ w,
+                                                                float* __restrict__ dx, long patches, int res, int cin, int c0) {
+  extern __shared__ float wsh[];  // [c0][cin * 4]
+  const int taps = cin * 4;
+  for (int i = threadIdx.x; i < c0 * taps; i += 256) wsh[i] = w[i];
+  __syncthreads();
+  const long patch = (long)blockIdx.x * 256 + threadIdx.x;
+  if (patch >= patches) return;
+  float acc[16];
+#pragma unroll
+  for (int t = 0; t < 16; ++t) acc[t] = 0.f;
+  const float* row = dy + patch * c0;
+  for (int c = 0; c < c0; c += 4) {
+    const f32x4 d = *reinterpret_cast<const f32x4*>(row + c);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int t = 0; t < 16; ++t)
+        if (t < taps) acc[t] += d[j] * wsh[(c + j) * taps + t];
+  }
+  const unsigned r0 = (unsigned)res / 2;
+  const unsigned pu = (unsigned)(patch % ((long)r0 * r0));
+  const long b = patch / ((long)r0 * r0);
+  const int py = (int)(pu / r0), px = (int)(pu % r0);
+#pragma unroll
+  for (int t = 0; t < 16; ++t)
+    if (t < taps) {
+      const int ci = t >> 2, ddy = (t >> 1) & 1, ddx = t & 1;
+      dx[((b * cin + ci) * res + 2 * py + ddy) * (long)res + 2 * px + ddx] = acc[t];
+    }
+}
+
 extern "C" {
 using namespace dfot;
 
@@ -1124,6 +1157,18 @@ int dfot_op_embed_input_wgrad(const float* dx0, const float* x, float* dw, float
   DFOT_CHECK_HIP(hipMemsetAsync(dw, 0, (size_t)c0 * kdim * sizeof(float), s));
   DFOT_CHECK_HIP(hipMemsetAsync(db, 0, (size_t)c0 * sizeof(float), s));
   return launch_pe_wgrad(dx0, x, dw, db, cin, res, res, ps, c0, rows, s);
+}
+// dX [BT][Cin][R][R] = dx0 [pix][C0] . W [C0][Cin][p][p] of the k = s = p patch embedding: the gradient w.r.t. the backbone INPUT
+// (reconstruction guidance differentiates the prediction w.r.t. x_t: discrete_diffusion.py:485-513).  One thread per patch.
+int dfot_op_embed_input_dgrad(const float* dx0, const float* w, float* dx, int bt, int res, int cin, int c0, int ps, void* stream) {
+  DFOT_REQUIRE(dx0 && w && dx, DFOT_ERR_ARG, "embed_input_dgrad: null pointer");
+  DFOT_REQUIRE(ps == 2 && cin >= 1 && cin <= 4 && c0 % 4 == 0 && res % 2 == 0, DFOT_ERR_SHAPE,
+               "embed_input_dgrad: patch %d, %d input channels, %d embedding channels unsupported", ps, cin, c0);
+  const long patches = (long)bt * (res / 2) * (res / 2);
+  hipLaunchKernelGGL(embed_input_dgrad_kernel, dim3(cdiv(patches, 256)), dim3(256), (size_t)c0 * cin * 4 * sizeof(float), (hipStream_t)stream,
+                     dx0, w, dx, patches, res, cin, c0);
+  DFOT_CHECK_HIP(hipGetLastError());
+  return DFOT_OK;
 }
 int dfot_op_project_output(const float* x0, const float* w, const float* b, float* out, int bt, int res, int c0, int cout, void* stream) {
   return launch_project_output(x0, w, b, out, bt, res, c0, cout, (hipStream_t)stream);

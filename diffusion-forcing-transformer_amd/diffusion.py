@@ -34,6 +34,9 @@ class DiffusionConfig:
     clip_noise: float = 20.0
     precond_scale: float = 0.125
     objective: str = "pred_v"
+    # dfot_video.py:161,700-723 / discrete_diffusion.py:485-513: > 0 pulls the predicted clean context towards the given one through
+    # d prediction / d x_t (one backbone backward per step); 0.0 in every shipped configuration
+    reconstruction_guidance: float = 0.0
     # False: DiscreteDiffusion (the backbone receives the integer level index, discrete_diffusion.py:173-174);
     # True: ContinuousDiffusion (precond_scale * logsnr[k])
     is_continuous: bool = True

@@ -60,7 +60,8 @@ def _(x, noise_levels, external_cond, external_cond_mask, model):
 # their gradients back (torch.library.register_autograd).  Forward = the saved-activation forward of uvit_train.UViT3DPoseTrainer
 # on the module's current weights, backward = its hand-written backward: what `accelerator.backward(loss)` walks into when the
 # reference's training_step calls `self.model(x_t, precond_scale * logsnr, external_cond)` (continuous_diffusion.py:154,
-# experiments/simple_video_generation.py:260-270).  No input gradient: the reference never differentiates w.r.t. x_t here.
+# experiments/simple_video_generation.py:260-270).  The gradient w.r.t. x is produced only when x requires it: training never
+# differentiates w.r.t. x_t, reconstruction guidance does (discrete_diffusion.py:485-513: torch.autograd.grad(guidance_loss, x)).
 @custom_op("dfot::uvit3d_pose_forward_train", mutates_args=())
 def uvit3d_pose_forward_train(x: Tensor, noise_levels: Tensor, external_cond: Tensor, external_cond_mask: Optional[Tensor],
                               params: List[Tensor], model: int) -> Tensor:
@@ -77,13 +78,13 @@ def _(x, noise_levels, external_cond, external_cond_mask, params, model):
 # instead of returning the gradients of another input (forward, forward, backward, backward is refused; run backward after each
 # forward, e.g. gradient accumulation as forward/backward pairs).
 @custom_op("dfot::uvit3d_pose_backward", mutates_args=())
-def uvit3d_pose_backward(grad_out: Tensor, params: List[Tensor], model: int, stamp: int) -> List[Tensor]:
-    return _model(model)._train_backward_impl(grad_out, params, stamp)
+def uvit3d_pose_backward(grad_out: Tensor, params: List[Tensor], model: int, stamp: int, want_dx: bool = False) -> List[Tensor]:
+    return _model(model)._train_backward_impl(grad_out, params, stamp, want_dx)
 
 
 @uvit3d_pose_backward.register_fake
-def _(grad_out, params, model, stamp):
-    return [torch.empty_like(p) for p in params]
+def _(grad_out, params, model, stamp, want_dx=False):
+    return [torch.empty_like(p) for p in params] + ([torch.empty_like(grad_out)] if want_dx else [])
 
 
 def _train_setup_context(ctx, inputs, output):
@@ -93,8 +94,13 @@ def _train_setup_context(ctx, inputs, output):
 
 
 def _train_backward(ctx, grad_out):
-    grads = torch.ops.dfot.uvit3d_pose_backward(grad_out.contiguous(), ctx.params, ctx.model, ctx.stamp)
-    return None, None, None, None, grads, None
+    want_dx = bool(ctx.needs_input_grad[0])
+    grads = torch.ops.dfot.uvit3d_pose_backward(grad_out.contiguous(), ctx.params, ctx.model, ctx.stamp, want_dx)
+    dx = None
+    if want_dx:
+        dx = grads[-1].view_as(grad_out)
+        grads = grads[:-1]
+    return dx, None, None, None, grads, None
 
 
 uvit3d_pose_forward_train.register_autograd(_train_backward, setup_context=_train_setup_context)

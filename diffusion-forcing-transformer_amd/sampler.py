@@ -241,6 +241,10 @@ class DFoTVideoPoseSampler:
                 mask = np.concatenate([mask, -np.ones((batch_size, padding), np.int64)], 1)
             keep = torch.from_numpy(mask >= 1).to(dev).view(batch_size, horizon, 1, 1, 1)
             xs = torch.where(keep, ctx, xs)
+        rg = float(getattr(cfg.diffusion, "reconstruction_guidance", 0.0) or 0.0)
+        if rg > 0 and not sch.is_ddim_sampling:
+            raise ValueError("reconstruction guidance is a DDIM-step feature (discrete_diffusion.py:455-513); sampling_timesteps == timesteps selects DDPM")
+        rg_ctx = (ctx if context is not None else torch.zeros_like(xs)) if rg > 0 and not self.dry_run else None
         if history_guidance is None:
             history_guidance = HistoryGuidance.conditional(timesteps=self.timesteps)
 
@@ -442,6 +446,8 @@ class DFoTVideoPoseSampler:
                 finally:
                     if skip_dead:
                         self.model.live_frames = None
+            elif rg > 0:
+                v = self._reconstruction_guided_v(x_in, lvl, cond_rep, p_["cmask_dev"], tables, gen_dev, rg_ctx, rg, nfe)
             else:
                 if skip_dead:  # rows of the model batch are (sample, branch): every branch of a sample shares the sample's flags
                     self.model.live_frames = live_dev if live_dev is not None else p_["live_dev"]
@@ -492,7 +498,8 @@ class DFoTVideoPoseSampler:
         # composition weights AND conditioning tensor (temporal guidance re-interpolates the poses of pure-noise tokens per step)
         uniform = all(p_["bm"] == plans[0]["bm"] and p_["cmask_dev"] is plans[0]["cmask_dev"]
                       and p_["weights_dev"] is plans[0]["weights_dev"] and p_.get("cond") is plans[0].get("cond") for p_ in plans)
-        if self.use_graph and uniform and not strict and len(plans) > 2 and all(p_["sigma"] is None for p_ in plans) and not self._branch_split_active:
+        if (self.use_graph and uniform and not strict and len(plans) > 2 and all(p_["sigma"] is None for p_ in plans) and not self._branch_split_active
+                and rg == 0):
             xs = self._run_steps_graph(plans, xs, draw_noise, step, flat_dev, gens_dev, horizon)
         else:
             hook = getattr(self, "step_hook", None)  # test instrumentation (drift per step); None on every product path
@@ -523,6 +530,33 @@ class DFoTVideoPoseSampler:
     def _window_sampler(self):
         """which per-window sampler the rollout / interpolation drivers call (the base classes always use _sample_sequence)"""
         return self._sample_sequence
+
+    def _reconstruction_guided_v(self, x_in, lvl, cond, cmask, tables, gen_dev, ctx, rg: float, nfe: int):
+        """Reconstruction guidance (dfot_video.py:700-723, discrete_diffusion.py:485-513): the model prediction is differentiated w.r.t.
+        x_t -- the backbone runs in its saved-activation form and its hand-written backward returns d / d x (ops.py) -- and the
+        gradient of  rg/2 * sum( (pred_x0 - context)^2 * sqrt(alphas_cumprod) * [mask != 0] / #[mask != 0] )  shifts the predicted noise:
+        eps' = eps + sqrt(1 - ac) * grad,  x0' = (x - sqrt(1 - ac) eps') / sqrt(ac).  For the v-objective that is exactly the ordinary
+        step on  v' = v + sqrt(1 - ac) / sqrt(ac) * grad  (eps = sqrt(ac) v + sqrt(1 - ac) x), so v' goes into the fused composition
+        kernel; where alphas_cumprod = 0 the reference keeps the unguided x0 and this keeps the unguided v.  The few elementwise
+        steps around the backbone run as torch ops under autograd, as in the reference; one-branch guidance only (the reference
+        compares the (B * NFE, ...) prediction with the (B, ...) context)."""
+        if nfe != 1:
+            raise ValueError("reconstruction guidance needs one-branch history guidance (the reference's loss compares the "
+                             "(B * NFE, ...) prediction with the (B, ...) context)")
+        if self.cfg.diffusion.objective != "pred_v":
+            raise ValueError("reconstruction guidance is implemented for the v objective")
+        nd = x_in.ndim
+        ext = lambda a: a.reshape(*a.shape, *([1] * (nd - a.ndim)))
+        sa, s1 = ext(tables[2]), ext(tables[3])  # sqrt(alphas_cumprod), sqrt(1 - alphas_cumprod) of the step's (clamped) levels
+        with torch.enable_grad():
+            x = x_in.detach().requires_grad_(True)
+            v = self.model(x, lvl, cond, cmask)
+            pred_x0 = sa * x - s1 * v
+            cm = ext((gen_dev == 0).to(torch.float32))
+            loss = torch.sum((pred_x0 - ctx) ** 2 * sa * cm / cm.sum(dim=1, keepdim=True).clamp(min=1))
+            grad = torch.nan_to_num(-torch.autograd.grad(-rg * 0.5 * loss, x)[0], nan=0.0)
+        scale = torch.where(sa > 0, s1 / sa.clamp(min=1e-30), torch.zeros_like(sa))
+        return (v.detach() + scale * grad).contiguous()
 
     @staticmethod
     def _fresh_flags(plans, batch_size: int, horizon: int):

@@ -463,9 +463,10 @@ class UViT3DPoseTrainer:
                                               self.cin, _S()))
         return out.view(self.B, t, self.cin, self.res, self.res)
 
-    def backward(self, d_out: torch.Tensor, reducer=None) -> Dict[str, torch.Tensor]:
+    def backward(self, d_out: torch.Tensor, reducer=None, input_grad: bool = False) -> Dict[str, torch.Tensor]:
         """reducer (parallel.OverlappedGradReducer): gradients are handed over level by level as they are produced, so their
-        all-reduce overlaps the rest of the backward; without it they are only returned"""
+        all-reduce overlaps the rest of the backward; without it they are only returned.  input_grad: also leave d loss / d x in
+        ``self.dx_in`` (B, T, C, H, W; fp32) -- what reconstruction guidance differentiates (discrete_diffusion.py:485-513)"""
         lib, p, e, r, ch, bt = capi.lib, self.p, self.e, self.r, self.ch, self.bt
         G: Dict[str, torch.Tensor] = {}
         handed = set()
@@ -535,6 +536,11 @@ class UViT3DPoseTrainer:
         dw, db = torch.empty_like(p["embed_input.proj.weight"]), torch.empty(ch[0], device="cuda")
         capi.check(lib.dfot_op_embed_input_wgrad(_P(dh), _P(self.x_in), _P(dw), _P(db), bt, self.res, self.cin, ch[0], self.ps, _S()))
         G["embed_input.proj.weight"], G["embed_input.proj.bias"] = dw, db
+        self.dx_in = None
+        if input_grad:
+            dx = torch.empty_like(self.x_in)
+            capi.check(lib.dfot_op_embed_input_dgrad(_P(dh), _P(p["embed_input.proj.weight"]), _P(dx), bt, self.res, self.cin, ch[0], self.ps, _S()))
+            self.dx_in = dx.view(self.B, bt // self.B, self.cin, self.res, self.res)
         # embedding pyramid (successive 2x2 average pools), pose patch embedding, noise-level MLP
         for l in sorted(dfilm_cat, reverse=True):
             demb[l] = gemm_f32(dfilm_cat[l], self.res_wcat[l])

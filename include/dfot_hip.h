@@ -380,6 +380,9 @@ int dfot_op_rows_sum(const float* src, float* out, int bt, int pixels, int e, vo
 int dfot_op_cond_repack(const float* cond, void* a, int bt, int res, int cdim, int kpad, void* stream);
 int dfot_op_embed_input(const float* x, const float* w, const float* b, float* out, int bt, int res, int cin, int c0, void* stream);
 int dfot_op_embed_input_wgrad(const float* dx0, const float* x, float* dw, float* db, int bt, int res, int cin, int c0, int ps, void* stream);
+/* gradient w.r.t. the backbone input x [BT][Cin][R][R] of the patch embedding (dx0 fp32 [pix][C0], w [C0][Cin][2][2]): the last step of
+ * d prediction / d x_t, which reconstruction guidance needs (discrete_diffusion.py:485-513) */
+int dfot_op_embed_input_dgrad(const float* dx0, const float* w, float* dx, int bt, int res, int cin, int c0, int ps, void* stream);
 int dfot_op_project_output(const float* x0, const float* w, const float* b, float* out, int bt, int res, int c0, int cout, void* stream);
 int dfot_op_outgrad_gather(const float* dout, void* dpatch, int bt, int res, int cout, int ps, void* stream);
 /* fp32 <-> bf16 helpers for tests */

@@ -75,7 +75,7 @@ class Diffusion:
         a, s = _ext(t.sqrt_alphas_cumprod[k], x.ndim), _ext(t.sqrt_one_minus_alphas_cumprod[k], x.ndim)
         return v, a * x - s * v, a * v + s * x  # v, x0, eps
 
-    def ddim_step(self, x, curr, nxt, cond, cond_mask, noise=None):
+    def ddim_step(self, x, curr, nxt, cond, cond_mask, noise=None, guidance_fn=None):
         ac = self.tables.alphas_cumprod
         kc = curr.clamp(min=0)
         alpha = ac[kc]
@@ -83,7 +83,21 @@ class Diffusion:
         sigma = torch.where(nxt < 0, torch.zeros_like(alpha),
                             self.eta * ((1 - alpha / alpha_next) * (1 - alpha_next) / (1 - alpha)).sqrt())
         c = (1 - alpha_next - sigma ** 2).sqrt()
-        _, x0, eps = self.predictions(x, kc, cond, cond_mask)
+        if guidance_fn is not None:
+            # discrete_diffusion.py:485-513: the prediction is differentiated w.r.t. x_t; the negative gradient of the guidance
+            # "likelihood" shifts the predicted noise, and x0 is recomputed from it (kept where alphas_cumprod = 0)
+            with torch.enable_grad():
+                xg = x.detach().requires_grad_()
+                _, x0_raw, eps = self.predictions(xg, kc, cond, cond_mask)
+                like = guidance_fn(xk=xg, pred_x0=x0_raw, alpha_cumprod=_ext(alpha, x.ndim))
+                grad = torch.nan_to_num(-torch.autograd.grad(like, xg)[0], nan=0.0)
+            t = self.tables
+            eps = eps.detach() + _ext((1 - alpha).sqrt(), x.ndim) * grad
+            x0 = torch.where(_ext(alpha, x.ndim) > 0,
+                             (x - _ext(t.sqrt_one_minus_alphas_cumprod[kc], x.ndim) * eps) / _ext(t.sqrt_alphas_cumprod[kc], x.ndim),
+                             x0_raw.detach())
+        else:
+            _, x0, eps = self.predictions(x, kc, cond, cond_mask)
         out = x0 * _ext(alpha_next.sqrt(), x.ndim) + eps * _ext(c, x.ndim)
         if self.eta != 0.0:
             out = out + _ext(sigma, x.ndim) * noise
@@ -115,6 +129,7 @@ class SamplerConfig:
     keyframe_density: Optional[float] = None
     sliding_context_len: Optional[int] = None
     interpolation_max_batch_size: Optional[int] = None
+    reconstruction_guidance: float = 0.0  # dfot_video.py:700-723 (needs a differentiable model_fn)
 
 
 class Sampler:
@@ -170,8 +185,20 @@ class Sampler:
                 # dfot_video_pose.py:75-83: under temporal guidance the pose processing also sees the branch's noise levels
                 cond = self.cond_fn(rep, f_in) if getattr(self, "cond_uses_levels", False) else self.cond_fn(rep)
             step_noise = self.noise_fn("ddim", tuple(x_in.shape))
+            gfn = None
+            if cfg.reconstruction_guidance > 0:
+                # dfot_video.py:700-723: squared error of the predicted clean context against the given one, weighted by
+                # sqrt(alphas_cumprod), summed over everything that is not "to be generated" (mask != 0: the reference's
+                # `.bool()` also counts generated context and padding, whose `context` rows are zeros) and divided by that count
+                cm = _ext(context_mask.bool(), nd).to(context.dtype)
+                rg = float(cfg.reconstruction_guidance)
+
+                def gfn(xk, pred_x0, alpha_cumprod, context=context, cm=cm, rg=rg):
+                    loss = (pred_x0 - context) ** 2 * alpha_cumprod.sqrt()
+                    loss = torch.sum(loss * cm / cm.sum(dim=1, keepdim=True).clamp(min=1))
+                    return -rg * 0.5 * loss
             if self.diff.sampling_timesteps < self.diff.tables.timesteps:  # is_ddim_sampling (discrete_diffusion.py:108)
-                x_out = self.diff.ddim_step(x_in, f_in, t_in, cond, cmask, step_noise)
+                x_out = self.diff.ddim_step(x_in, f_in, t_in, cond, cmask, step_noise, guidance_fn=gfn)
             else:
                 x_out = self.diff.ddpm_step(x_in, f_in, cond, cmask, step_noise)
             xs = g.compose(x_out)

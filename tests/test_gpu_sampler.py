@@ -550,3 +550,48 @@ def test_frozen_context_frames_skip_the_down_path_bit_exactly():
     want = np.ones((6, 2, 8), np.uint8)
     want[1:, 1, :2] = 0
     assert np.array_equal(fresh, want)
+
+
+def test_reconstruction_guidance_matches_the_oracle():
+    """Reconstruction guidance (dfot_video.py:700-723, discrete_diffusion.py:485-513; 0.0 in every shipped config): the prediction is
+    differentiated w.r.t. x_t -- on the engine through the backbone's hand-written backward, which now returns d / d x -- and pulls the
+    predicted clean context towards the given one.  Engine vs oracle.sampler (torch autograd through oracle.uvit in fp32) on replayed
+    noise, conditional (one-branch) history guidance, 3 DDIM steps at 64x64; the guided sample must also differ from the unguided one
+    by far more than the engine's distance to the oracle."""
+    import dfot_amd
+    from oracle import pose as opose, sampler as osm, schedule as sch, uvit as ouvit
+    res, steps, rg = 64, 3, 400.0  # (large enough for the pull to dwarf the bf16 distance between engine and oracle)
+    ocfg, params, model = build()
+    g = torch.Generator().manual_seed(9)
+    xs = torch.randn(1, 8, 3, res, res, generator=g)
+    cnd = poses(1, 8, 9)
+    hgd = dict(name="conditional")
+    outs = {}
+    for w in (rg, 0.0):
+        r1 = Replay(7, "cpu")
+        diff = osm.Diffusion(sch.build_tables(), lambda x, k, c, m: ouvit.forward(params, ocfg, x, k, c, m), sampling_timesteps=steps)
+        osamp = osm.Sampler(osm.SamplerConfig(x_shape=(3, res, res), sampling_timesteps=steps, prediction_guidance=hgd,
+                                              reconstruction_guidance=w), diff, lambda c: opose.ray_encoding(c, res), r1)
+        ref = osamp.predict_videos(xs, 2, cnd).detach()
+        r2 = Replay(7, "cuda")
+        scfg = dfot_amd.SamplerConfig(x_shape=(3, res, res), prediction_guidance=hgd,
+                                      diffusion=dfot_amd.DiffusionConfig(sampling_timesteps=steps, reconstruction_guidance=w))
+        samp = dfot_amd.DFoTVideoPoseSampler(scfg, model, r2)
+        out = samp._predict_videos(xs, n_context_tokens=2, conditions=cnd).cpu()
+        assert r1.log == r2.log
+        outs[w] = (out, ref)
+    out, ref = outs[rg]
+    rel = ((out - ref).norm() / ref.norm()).item()
+    moved = ((ref - outs[0.0][1]).norm() / ref.norm()).item()
+    print(f"reconstruction guidance {rg}: engine vs oracle rel-L2 {rel:.3e}, PSNR {psnr(out, ref):.1f} dB; guided vs unguided (oracle) rel-L2 {moved:.3e}")
+    assert torch.isfinite(out).all() and torch.equal(out[:, :2], xs[:, :2].float())
+    # the shift the guidance causes, engine vs oracle: this is the gradient path alone (bf16 backward vs fp32 autograd)
+    d_e, d_o = out - outs[0.0][0], ref - outs[0.0][1]
+    drel = ((d_e - d_o).norm() / d_o.norm()).item()
+    print(f"guidance-induced shift, engine vs oracle: rel-L2 {drel:.3e}")
+    assert psnr(out, ref) >= 35.0 and rel < 3e-2 and moved > 5 * rel and drel < 0.1
+    # two-branch guidance: refused (the reference's loss compares the (B * NFE, ...) prediction with the (B, ...) context)
+    scfg = dfot_amd.SamplerConfig(x_shape=(3, res, res), prediction_guidance=dict(name="vanilla", guidance_scale=2.0),
+                                  diffusion=dfot_amd.DiffusionConfig(sampling_timesteps=steps, reconstruction_guidance=rg))
+    with pytest.raises(ValueError, match="one-branch"):
+        dfot_amd.DFoTVideoPoseSampler(scfg, model, Replay(7, "cuda"))._predict_videos(xs, n_context_tokens=2, conditions=cnd)

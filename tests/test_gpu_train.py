@@ -1038,3 +1038,35 @@ def test_uvit3d_pose_backward_at_re10k_widths(blocks, mid, bar):
     print(f"UViT3DPose backward at RE10K widths, depth {blocks}/{mid}: forward rel-L2 {r_out:.2e}; worst gradient rel-L2 {rs[worst]:.2e} at {worst}; "
           f"median {sorted(rs.values())[len(rs) // 2]:.2e}; above 3e-2: {over}")
     assert r_out < 2e-2 and rs[worst] < bar and sorted(rs.values())[len(rs) // 2] < 2e-2, (r_out, over)
+
+
+def test_uvit3d_pose_input_gradient_matches_fp32_autograd():
+    """d loss / d x of the autograd drop-in (ops.py: produced only when x requires it; reconstruction guidance differentiates the
+    prediction w.r.t. x_t) vs torch autograd through oracle.uvit in fp32: the last step is dfot_op_embed_input_dgrad"""
+    import dfot_amd
+    from oracle import pose as opose, uvit as ouvit
+    res = 64
+    ocfg = ouvit.UViTConfig(resolution=res, num_updown_blocks=(1, 1, 1), num_mid_blocks=1)
+    params = ouvit.seeded_params(ocfg, 4)
+    cfg = dict(channels=list(ocfg.channels), emb_channels=ocfg.emb_channels, patch_size=2, block_types=list(ocfg.block_types),
+               num_updown_blocks=list(ocfg.num_updown_blocks), num_mid_blocks=ocfg.num_mid_blocks, num_heads=ocfg.num_heads,
+               pos_emb_type="rope", use_fourier_noise_embedding=True, conditioning=dict(dim=180))
+    model = dfot_amd.UViT3DPose(cfg, x_shape=(3, res, res), max_tokens=8).cuda().eval()
+    model.load_state_dict(params, strict=True)
+    for p_ in model.parameters():
+        p_.requires_grad_(False)  # sampling-time use: only x requires a gradient
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(1, 8, 3, res, res, generator=g)
+    k = torch.randn(1, 8, generator=g)
+    pz = torch.eye(3, 4).reshape(1, 1, 12).repeat(1, 8, 1)
+    pz[..., 3] = torch.linspace(0, 0.5, 8)
+    cond = opose.ray_encoding(torch.cat([torch.tensor([0.5, 0.9, 0.5, 0.5]).repeat(1, 8, 1), pz], -1), res)
+    tgt = torch.randn(1, 8, 3, res, res, generator=g)
+    xr = x.clone().requires_grad_(True)
+    gp = {n: t.cuda() for n, t in params.items()}
+    ((ouvit.forward(gp, ocfg, xr.cuda(), k.cuda(), cond.cuda(), None).cpu() - tgt) ** 2).sum().backward()
+    xe = x.clone().cuda().requires_grad_(True)
+    ((model(xe, k.cuda(), cond.cuda(), None) - tgt.cuda()) ** 2).sum().backward()
+    rel = ((xe.grad.cpu() - xr.grad).norm() / xr.grad.norm()).item()
+    print(f"d loss / d x: rel-L2 {rel:.3e}")
+    assert torch.isfinite(xe.grad).all() and rel < 3e-2

@@ -238,3 +238,24 @@ def test_stochastic_sampling_steps_vs_reference_runs(tag):
     out = s.predict_videos(T(g[f"{tag}_xs"]), 1, T(g[f"{tag}_conds"]))
     assert not nfn.queue
     np.testing.assert_allclose(out.numpy(), g[f"{tag}_out"], rtol=1e-3, atol=2e-3)
+
+
+def test_reconstruction_guidance_vs_reference_run():
+    """cfg.diffusion.reconstruction_guidance > 0 (dfot_video.py:700-723, discrete_diffusion.py:485-513): the reference's own
+    `_predict_videos` run of the tiny pose model (conditional guidance, 2 context frames, 3 DDIM steps, weight 400) with every normal
+    draw recorded; the oracle (autograd through oracle.uvit) replays the draws and must reproduce it -- and the unguided run, which
+    the guided one must differ from by far more than the tolerance"""
+    g = load("sampler_recon.npz")
+    p, model = tiny_model()
+    assert digest(p) == str(g["digest"])
+    outs = {}
+    for tag, w in (("rg", float(g["weight"])), ("plain", 0.0)):
+        noise = [T(g[f"{tag}_noise{i}"]) for i in range(int(g[f"{tag}_n_noise"]))]
+        nfn = osm.replay_noise_fn(noise)
+        cfg = osm.SamplerConfig(x_shape=(3, 16, 16), sampling_timesteps=3, prediction_guidance=dict(name="conditional"),
+                                reconstruction_guidance=w)
+        s = osm.Sampler(cfg, osm.Diffusion(sch.build_tables(), model, sampling_timesteps=3), lambda c: opose.ray_encoding(c, 16), nfn)
+        outs[tag] = s.predict_videos(T(g["xs"]), 2, T(g["conds"])).detach()
+        assert not nfn.queue
+        np.testing.assert_allclose(outs[tag].numpy(), g[f"{tag}_out"], rtol=1e-3, atol=2e-3)
+    assert np.abs(g["rg_out"] - g["plain_out"]).max() > 0.05

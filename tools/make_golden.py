@@ -239,6 +239,30 @@ def stochastic_samplers(R):
     save("sampler_stochastic.npz", **out)
 
 
+def reconstruction_guidance_run(R):
+    """sampler_recon.npz: the reference's own `_predict_videos` with cfg.diffusion.reconstruction_guidance > 0 (dfot_video.py:700-723 builds
+    the guidance function, discrete_diffusion.py:485-513 differentiates the prediction w.r.t. x_t): tiny pose model, conditional history
+    guidance (one branch), 2 context frames, 3 DDIM steps, every normal draw recorded; plus the same run without guidance, so that a
+    test can see that the pull is far larger than its tolerance."""
+    A = R["AttrDict"]
+    out = {}
+    for tag, w in (("rg", 400.0), ("plain", 0.0)):
+        cfg = algo_cfg(A, 16, TINY, context=2, sampling_steps=3, pred_hg=dict(name="conditional"))
+        cfg.diffusion["reconstruction_guidance"] = w
+        algo, _, p = build_algo(R, cfg)
+        g = torch.Generator().manual_seed(67)
+        vid = torch.randn(1, 8, 3, 16, 16, generator=g)
+        cnd = synth_poses(1, 8, seed=10)
+        algo.generator = torch.Generator().manual_seed(0)
+        with RandnRecorder() as rec:
+            res = algo._predict_videos(vid.clone(), n_context_tokens=2, conditions=cnd.clone())
+        assert torch.isfinite(res).all()
+        out.update({f"{tag}_out": res.detach(), f"{tag}_n_noise": np.array(len(rec.draws))})
+        out.update({f"{tag}_noise{i}": d for i, d in enumerate(rec.draws)})
+        out.update(xs=vid, conds=cnd, weight=np.array(400.0), digest=np.array(weights_digest(p)))
+    save("sampler_recon.npz", **out)
+
+
 def vae_decode_golden():
     """The reference's own VideoVAE (default causal module choice, K600 latent geometry: 16 latent channels, 4x temporal / 8x spatial)
     with seeded random weights decodes seeded latents: `VideoVAE.decode(z, desired_length)` and the `_decode` convention `* 0.5 + 0.5`.
@@ -271,6 +295,8 @@ def main():
         return training_grads_uvit(R)
     if os.environ.get("ONLY") == "stochastic":
         return stochastic_samplers(R)
+    if os.environ.get("ONLY") == "recon":
+        return reconstruction_guidance_run(R)
 
     # ---------------------------------------------------------------- schedule + scheduling matrices
     print("schedule")
