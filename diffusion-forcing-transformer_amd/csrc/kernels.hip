@@ -357,7 +357,7 @@ int launch_project_output(const float* x0, const float* w, const float* b, float
 // --------------------------------------------------------------------------------------------
 // GroupNorm(32 groups) statistics over channels-last tensors, deterministic two-stage reduction
 // --------------------------------------------------------------------------------------------
-constexpr int GN_PIX_PER_BLOCK = 512;
+constexpr int GN_PIX_PER_BLOCK = 128;  // (512 left the 64x64 level with 8 x 16 = 128 workgroups for 67 MB: 65 us; 128-pixel blocks: 512 and 2048 workgroups)
 int gn_partial_blocks(int pixels) { return cdiv(pixels, GN_PIX_PER_BLOCK); }
 
 template <typename T>
