@@ -94,7 +94,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int tile_inde
   const int wm = wave / WN, wn = wave % WN;
   const int tiles_n = (g.N + BN_T - 1) / BN_T;
   // split-K over workgroups (EPI == E_F32 only): consecutive workgroups share a tile and take consecutive K slices
-  const int ksplit = (EPI == E_F32 && AMODE == A_DENSE && g.ksplit > 1) ? g.ksplit : 1;
+  const int ksplit = (EPI == E_F32 && (AMODE == A_DENSE || g.slice_stride > 0) && g.ksplit > 1) ? g.ksplit : 1;
   const int kslice = ksplit > 1 ? tile_index % ksplit : 0;
   const int bid = ksplit > 1 ? xcd_remap(tile_index / ksplit, tile_count / ksplit, g.xcd) : xcd_remap(tile_index, tile_count, g.xcd);
   const int tn = bid % tiles_n, tm = bid / tiles_n;
@@ -151,7 +151,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int tile_inde
   // (stride KS), so the tap position is carried along instead of being re-derived with three integer divisions per k-tile
   [[maybe_unused]] int cv_c0 = 0, cv_dy = -1, cv_dx = -1;
   if constexpr (AMODE == A_CONV3) {
-    const int kbase = kgroup * BKT;  // first k-tile of this k-group
+    const int kbase = kgroup * BKT + (int)kbeg;  // first k-tile of this k-group (of this workgroup's K slice: split-K into partial outputs)
     const int tap = kbase / g.Cin;
     cv_c0 = kbase - tap * g.Cin;
     cv_dy = tap / 3 - 1;
@@ -795,7 +795,7 @@ static int launch_t(const GemmArgs& g, hipStream_t stream) {
   constexpr int ep_lds = (nthreads / 64) * 16 * EP_LD * 4 + 2 * (nthreads / 64) * 16 * 4 +
                          (KS == 2 ? (nthreads / 128) * (WTM / 16) * 16 * 64 * 4 : 0);
   constexpr int lds = stage_lds > ep_lds ? stage_lds : ep_lds;
-  const int ksplit = (EPI == E_F32 && AMODE == A_DENSE && g.ksplit > 1) ? g.ksplit : 1;
+  const int ksplit = (EPI == E_F32 && (AMODE == A_DENSE || g.slice_stride > 0) && g.ksplit > 1) ? g.ksplit : 1;
   const int tiles = (g.M / BM_T) * ((g.N + BN_T - 1) / BN_T) * ksplit;
   static const int xcd_flag = tuning_flag("GEMM_XCD", 1);
   static const int persist_flag = tuning_flag("GEMM_PERSIST", 1);  // A/B: +0.6 % RE10K, +2.2 % bash/k600 model
@@ -849,8 +849,8 @@ static int launch_v(int variant, const GemmArgs& g, hipStream_t s) {
         if (g.gn_part) break;
         return launch_t<256, 144, 64, 2, AMODE, EPI, true>(g, s);
       }
-    case GEMM_DMA3_256x144:
-      if constexpr (AMODE != A_DENSE || EPI != E_F32) break;
+    case GEMM_DMA3_256x144:  // (also the long-K Downsample / Upsample convolutions: run_down / run_up)
+      if constexpr (EPI != E_F32) break;
       else {
         if (g.gn_part) break;
         return launch_t<256, 144, 64, 3, AMODE, EPI, true>(g, s);
@@ -938,8 +938,8 @@ int launch_gemm(int amode, int epi, int variant, const GemmArgs& g, hipStream_t 
   if (g.ksplit > 1 && g.slice_stride > 0)
     DFOT_REQUIRE(!g.bias && !g.resid, DFOT_ERR_ARG, "gemm: split-K into partial outputs takes no bias / residual");
   if (g.ksplit > 1)
-    DFOT_REQUIRE(epi == E_F32 && amode == A_DENSE && !g.bias_rows && (!g.resid || g.resid == g.out_f32) && !g.gate && !g.gn_part &&
-                     g.K / BK >= 2 * g.ksplit, DFOT_ERR_ARG,
+    DFOT_REQUIRE(epi == E_F32 && (amode == A_DENSE || g.slice_stride > 0) && !g.bias_rows && (!g.resid || g.resid == g.out_f32) && !g.gate &&
+                     !g.gn_part && g.K / BK >= 2 * g.ksplit, DFOT_ERR_ARG,
                  "gemm: split-K over workgroups needs the fp32 epilogue with an in-place residual (or none), no gate, and K >= %d", 2 * g.ksplit * BK);
   if (g.bias_rows) DFOT_REQUIRE((epi == E_F32 || epi == E_BF16) && g.bias && g.bias_rows > 0, DFOT_ERR_ARG, "gemm: 2-D bias needs a plain epilogue");
   if (g.tr_rows) {

@@ -583,6 +583,52 @@ static int run_tr_block_2s(dfot_uvit_s* h, const TrW& w, int lvl, int batch, hip
   return DFOT_OK;
 }
 
+// out[row][c] = bias[c] + sum_s slab[s][row][c] for the rows of live images (fp32, 4 elements per thread)
+__global__ void slab_reduce_kernel(float* __restrict__ out, const float* __restrict__ bias, const float* __restrict__ slabs, int nslab, long stride4,
+                                   long total4, int cq, const uint8_t* __restrict__ live, unsigned img4) {
+  typedef __attribute__((ext_vector_type(4))) float f4;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total4) return;
+  if (live && !live[(unsigned)i / img4]) return;
+  f4 v = reinterpret_cast<const f4*>(bias)[i % cq];
+  for (int sl = 0; sl < nslab; ++sl) v += reinterpret_cast<const f4*>(slabs)[sl * stride4 + i];
+  reinterpret_cast<f4*>(out)[i] = v;
+}
+
+// The Downsample / Upsample convolutions between the transformer levels are few-tile, long-K implicit GEMMs (M = 4096 or 16384 pixels,
+// K = 2304 ... 10368): on 128x128 tiles they ran at 400-690 TFLOP/s.  Where the shape allows it they take the three-stage 256x144 ring
+// (256x256 tiles for N = 256) with K split over workgroups into fp32 slabs -- enough slices for ~256 workgroups -- and one reduce pass
+// (bias + slabs; images skipped by the tile's flag are skipped there too, so their rows keep what they held).
+static int conv_between_levels(dfot_uvit_s* h, GemmArgs g, hipStream_t s) {
+  static const int on = tuning_flag("UVIT_CONV_SPLIT", 1);
+  const long px = (long)g.H * g.Wd;
+  if (on && h->gemm_variant == GEMM_AUTO && h->out_part && !g.gn_part && g.M % 256 == 0 && px % 256 == 0 && (g.N % 144 == 0 || g.N == 256) &&
+      (long)g.M * g.N < (1L << 31)) {
+    const int bn = g.N % 144 == 0 ? 144 : 256;
+    const int variant = bn == 144 ? GEMM_DMA3_256x144 : GEMM_DMA_256x256;
+    const int tiles = (g.M / 256) * (g.N / bn);
+    int ks = 1;
+    while (tiles * ks * 2 <= 256 && g.K / 64 / (ks * 2) >= 16) ks *= 2;
+    if (tiles * ks >= 192 && tiles * ks <= 256) {
+      if (ks == 1) return launch_gemm(A_CONV3, E_F32, variant, g, s);
+      if ((size_t)ks * g.M * g.N <= h->out_part_elems) {
+        GemmArgs p = g;
+        float* out = g.out_f32;
+        const float* bias = g.bias;
+        p.bias = nullptr; p.resid = nullptr; p.out_f32 = h->out_part; p.ksplit = ks; p.slice_stride = (long)g.M * g.N;
+        int rc = launch_gemm(A_CONV3, E_F32, variant, p, s);
+        if (rc) return rc;
+        const long total4 = (long)g.M * g.N / 4;
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3(cdiv(total4, 256)), dim3(256), 0, s, out, bias, h->out_part, ks, total4, total4, g.N / 4, g.live,
+                           (unsigned)(px * g.N / 4));
+        DFOT_CHECK_HIP(hipGetLastError());
+        return DFOT_OK;
+      }
+    }
+  }
+  return launch_gemm(A_CONV3, E_F32, h->gemm_variant, g, s);
+}
+
 static int run_down(dfot_uvit_s* h, int l, int bt, hipStream_t s, const uint8_t* live = nullptr) {
   const int rr = h->r[l], cin = h->ch[l], cout = h->ch[l + 1];
   int rc = 0;
@@ -595,7 +641,7 @@ static int run_down(dfot_uvit_s* h, int l, int bt, hipStream_t s, const uint8_t*
   if (next_is_res) {
     g.gn_part = h->gn_partial; g.gn_rows_per_bt = (rr / 2) * (rr / 2); g.gn_cpg = cout / 32;
   }
-  if ((rc = launch_gemm(A_CONV3, E_F32, h->gemm_variant, g, s))) return rc;
+  if ((rc = conv_between_levels(h, g, s))) return rc;
   h->gn1_nblk = next_is_res ? g.gn_rows_per_bt / 64 : 0;
   h->xin[l + 1] = h->HSA[l];  // the skip tensor IS the next level's input: its first block reads it here and writes X[l + 1]
   return DFOT_OK;
@@ -611,7 +657,7 @@ static int run_up(dfot_uvit_s* h, int l, int bt, hipStream_t s, const uint8_t* l
   g.zeros = h->zeros; g.bias = h->up_conv[l].b; g.out_f32 = h->tmp; g.ldo = cout;
   // (a 16x16 / 32x32 coarse map is smaller than the larger tiles: the flags apply only where whole tiles lie inside one image)
   if (live && (rr * rr) % 256 == 0 && h->gemm_variant == GEMM_AUTO) g.live = live;
-  if ((rc = launch_gemm(A_CONV3, E_F32, h->gemm_variant, g, s))) return rc;
+  if ((rc = conv_between_levels(h, g, s))) return rc;
   h->gn1_nblk = 0;  // X[l] is rewritten by an elementwise kernel: its statistics come from the standalone kernel
   rc = launch_upsample_add(h->tmp, h->xin[l], h->X[l], bt, rr, rr, cout, s, live);
   h->xin[l] = h->X[l];
