@@ -124,13 +124,7 @@ struct dfot_uvit_s {
   const float* xin[4] = {nullptr, nullptr, nullptr, nullptr};
   int gemm_variant = GEMM_AUTO;
   int attn_variant = 2;
-  bool debug_stop_after_mid = false;
   bool attn_force_safe = false;  // level-2 attention: always the running-max kernel (what weights with a bound >= 64 get)
-  // the block's two independent branches on two streams (run_tr_block_2s): bit 0 = level 3, bit 1 = level 2
-  int two_stream = 0;
-  hipStream_t side = nullptr;
-  std::vector<hipEvent_t> ev_sync;  // fork / join events, used round-robin
-  size_t ev_sync_next = 0;
   // optional in-run timing of the level-2 attention launches (HIP events on the launch stream)
   bool time_attn = false;
   std::vector<hipEvent_t> ev_start, ev_stop;
@@ -435,14 +429,9 @@ static int flush_pending(dfot_uvit_s* h, hipStream_t s) {
   return DFOT_OK;
 }
 
-static int run_tr_block_2s(dfot_uvit_s* h, const TrW& w, int lvl, int batch, hipStream_t s);
-
 static int run_tr_block(dfot_uvit_s* h, const TrW& w, int lvl, int batch, hipStream_t s) {
   const int c = w.c, rr = h->r[lvl], n = h->T * rr * rr, d = c / h->heads;
   const int m = batch * n;
-  if (((h->two_stream >> (3 - lvl)) & 1) && h->side && h->gemm_variant == GEMM_AUTO && h->out_part && (size_t)3 * m * c <= h->out_part_elems &&
-      m % 256 == 0)
-    return run_tr_block_2s(h, w, lvl, batch, s);
   float* x = h->X[lvl];
   int rc = 0;
   if (h->pend_bias && (h->pend_lvl != lvl || h->pend_m != m || h->pend_c != c) && (rc = flush_pending(h, s))) return rc;
@@ -519,69 +508,9 @@ static int run_tr_block(dfot_uvit_s* h, const TrW& w, int lvl, int batch, hipStr
   return rc;
 }
 
-// The reference block is PARALLEL attention + MLP (u_vit_blocks.py:253-277: x + attn_out(attn(q, k, v)) + mlp_out(silu(mlp_h))): after the
-// shared norm the two branches are independent until the residual sum.  Two streams, forked / joined with events (parallel branches
-// of the graph under stream capture):
-//   s    : [q|k|v] columns of fused_attn_mlp_proj (QK-norm + RoPE epilogue) -> attention -> attn_out (K = C)    -> slice 0
-//   side : mlp_h columns (SiLU epilogue)                                     -> mlp_out (K = 4C, 1-2 K slices) -> slices 1..
-// and the slice sum + bias rides in the next block's norm kernel as before (flush_pending for every other reader).  At level 3 /
-// model batch 2 every kernel of the serial chain has 240-512 workgroups for 256 CUs and the 288-workgroup attention launch (one
-// workgroup per CU, latency-bound) owned an otherwise idle chip; with the fork its tail and the GEMMs' tails fill each other.
-static hipEvent_t next_event(dfot_uvit_s* h) { return h->ev_sync[h->ev_sync_next++ % h->ev_sync.size()]; }
-
-static int run_tr_block_2s(dfot_uvit_s* h, const TrW& w, int lvl, int batch, hipStream_t s) {
-  const int c = w.c, rr = h->r[lvl], n = h->T * rr * rr, d = c / h->heads;
-  const int m = batch * n;
-  float* x = h->X[lvl];
-  hipStream_t s2 = h->side;
-  int rc = 0;
-  if (h->pend_bias && (h->pend_lvl != lvl || h->pend_m != m || h->pend_c != c) && (rc = flush_pending(h, s))) return rc;
-  RmsPending pend{x, h->pend_bias, h->pend_part, h->pend_part + (long)m * c, h->pend_slices == 3 ? h->pend_part + 2L * m * c : nullptr};
-  if ((rc = launch_rms_film(h->xin[lvl], w.nw, w.fcache, h->sv + w.sv_off, h->have_mask ? h->cond_mask : nullptr, h->s1, m, c,
-                            rr * rr, h->T, h->cfg.eps, s, h->pend_bias ? &pend : nullptr)))
-    return rc;
-  if (h->pend_bias) h->xin[lvl] = x;  // the pending sum was written to X[lvl]
-  h->pend_bias = nullptr;
-  hipEvent_t fork = next_event(h), join = next_event(h);
-  DFOT_CHECK_HIP(hipEventRecord(fork, s));
-  DFOT_CHECK_HIP(hipStreamWaitEvent(s2, fork, 0));
-  // ---- side stream: MLP branch
-  static const int mlp_slices_l3 = tuning_flag("UVIT_2S_MLP_SLICES_L3", 2), mlp_slices_l2 = tuning_flag("UVIT_2S_MLP_SLICES_L2", 1);
-  const int mlp_slices = lvl == 3 ? mlp_slices_l3 : mlp_slices_l2;
-  {
-    GemmArgs pm;
-    pm.A = h->s1; pm.lda = c; pm.W = w.w_fused + 3L * c * c; pm.M = m; pm.N = 4 * c; pm.K = c; pm.bias = w.b_fused + 3 * c;
-    pm.out_bf16 = h->cat + c; pm.ldo = 5 * c; pm.act = 2;
-    if ((rc = launch_gemm(A_DENSE, E_BF16, h->gemm_variant, pm, s2))) return rc;
-    GemmArgs om;
-    om.A = h->cat + c; om.lda = 5 * c; om.W = w.w_out + c; om.ldw = 5 * c; om.M = m; om.N = c; om.K = 4 * c;
-    om.out_f32 = h->out_part + (long)m * c; om.ldo = c; om.ksplit = mlp_slices; om.slice_stride = (long)m * c;
-    const int ov = (mlp_slices > 1 && h->gemm_variant == GEMM_AUTO) ? GEMM_DMA_256x256 : h->gemm_variant;
-    if ((rc = launch_gemm(A_DENSE, E_F32, ov, om, s2))) return rc;
-  }
-  DFOT_CHECK_HIP(hipEventRecord(join, s2));
-  // ---- main stream: attention branch
-  GemmArgs p;
-  p.A = h->s1; p.lda = c; p.W = w.w_fused; p.M = m; p.N = 3 * c; p.K = c; p.bias = w.b_fused;
-  p.split = 3 * c;
-  p.q = h->q; p.k = h->k; p.v = h->v; p.qw = w.qw; p.kw = w.kw; p.rope_cs = h->rope_cs[lvl]; p.heads = h->heads; p.d = d;
-  p.ntok = n; p.qscale = 1.4426950408889634f / sqrtf((float)d); p.eps = h->cfg.eps;
-  if ((rc = launch_gemm(A_DENSE, E_QKV, h->gemm_variant, p, s))) return rc;
-  const bool timed = h->time_attn && lvl == 2 && h->ev_used < h->ev_start.size();
-  if (timed) DFOT_CHECK_HIP(hipEventRecord(h->ev_start[h->ev_used], s));
-  int av = h->attn_variant;
-  if (av == 2 && d == 64 && n % 256 == 0) av = (w.score_bound < 64.0f && !h->attn_force_safe) ? 14 : 5;
-  if ((rc = launch_attention(h->q, h->k, h->v, h->cat, 5 * c, batch, h->heads, n, d, av, s, &h->attn_scratch))) return rc;
-  if (timed) DFOT_CHECK_HIP(hipEventRecord(h->ev_stop[h->ev_used++], s));
-  GemmArgs oa;
-  oa.A = h->cat; oa.lda = 5 * c; oa.W = w.w_out; oa.ldw = 5 * c; oa.M = m; oa.N = c; oa.K = c; oa.out_f32 = h->out_part; oa.ldo = c;
-  if ((rc = launch_gemm(A_DENSE, E_F32, h->gemm_variant, oa, s))) return rc;
-  DFOT_CHECK_HIP(hipStreamWaitEvent(s, join, 0));
-  h->pend_bias = w.b_out;
-  h->pend_lvl = lvl; h->pend_m = m; h->pend_c = c; h->pend_slices = 1 + mlp_slices;
-  swap_out_part(h);
-  return DFOT_OK;
-}
+// (The block's two independent branches -- attention and MLP, u_vit_blocks.py:253-277 -- were run on two streams for a while; with
+// this round's serial chain, cheaper epilogues and the two-slice ring out-projection, the fork measures SLOWER, 9.70 vs 9.78 frames/s,
+// and was removed)
 
 // out[row][c] = bias[c] + sum_s slab[s][row][c] for the rows of live images (fp32, 4 elements per thread)
 __global__ void slab_reduce_kernel(float* __restrict__ out, const float* __restrict__ bias, const float* __restrict__ slabs, int nslab, long stride4,
@@ -691,23 +620,6 @@ int dfot_uvit_create(const dfot_uvit_config* cfg, dfot_uvit_t* out) {
   DFOT_REQUIRE((cfg->max_tokens * r3 * r3) % 128 == 0, DFOT_ERR_SHAPE, "tokens at the coarsest level (%d) must be a multiple of 128", cfg->max_tokens * r3 * r3);
   auto* h = new dfot_uvit_s();
   h->cfg = *cfg;
-  // bit 0 = level 3, bit 1 = level 2.  OFF by default: +1.3 % frames/s at 256x256 (two same-box A/B pairs), but NOT
-  // run-to-run reproducible: at 64x64, where the workgroups of concurrently running kernels share CUs, about one forward in eight comes
-  // out with a few (7-30) wrong elements of q in ONE two-stream block -- the output of the main stream's own fused-projection GEMM, while
-  // the MLP GEMM runs on the side stream (tools/debug_2s.py: the side branch's buffers are always identical; host synchronisation at the
-  // fork, or the MLP GEMM on the main stream, makes it exact; event flags, a third stream, an agent-scope release at the end of the side
-  // GEMM and double-buffered slices do not).  Every cross-stream dependency is covered by the fork / join events; the cause is not found
-  // (the register-staged GEMM form did not show it in 8 runs), so the serial chain stays the default.
-  h->two_stream = tuning_flag("UVIT_TWO_STREAM", 0);
-  {  // the side stream and its events exist whether or not the schedule is on, so that set_option("two_stream", ..) can switch it
-    if (hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess) h->side = nullptr;
-    for (int i = 0; h->side && i < 8; ++i) {
-      hipEvent_t e;
-      if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) break;
-      h->ev_sync.push_back(e);
-    }
-    if (h->ev_sync.size() < 8) h->two_stream = 0;
-  }
   int rc = build(h);
   if (rc) {
     dfot_uvit_destroy(h);
@@ -723,8 +635,6 @@ int dfot_uvit_destroy(dfot_uvit_t h) {
   for (void* p : h->ws_owned) (void)hipFree(p);
   for (hipEvent_t e : h->ev_start) (void)hipEventDestroy(e);
   for (hipEvent_t e : h->ev_stop) (void)hipEventDestroy(e);
-  for (hipEvent_t e : h->ev_sync) (void)hipEventDestroy(e);
-  if (h->side) (void)hipStreamDestroy(h->side);
   delete h;
   return DFOT_OK;
 }
@@ -904,8 +814,6 @@ int dfot_uvit_set_option(dfot_uvit_t h, const char* key, int value) {
   if (!strcmp(key, "gemm_variant")) h->gemm_variant = value;
   else if (!strcmp(key, "attn_variant")) h->attn_variant = value;
   else if (!strcmp(key, "attn_force_safe")) h->attn_force_safe = value != 0;
-  else if (!strcmp(key, "debug_stop_after_mid")) h->debug_stop_after_mid = value != 0;
-  else if (!strcmp(key, "two_stream")) h->two_stream = (h->side && h->ev_sync.size() >= 8) ? value : 0;
   else if (!strcmp(key, "time_attn")) {
     // value = number of launches to record (0 disables); events are created here, never inside forward
     h->time_attn = value > 0;
@@ -1031,10 +939,6 @@ int dfot_uvit_forward_cached_masks(dfot_uvit_t h, const float* x, const float* n
   for (const TrW& w : h->mid_tr)
     if ((rc = run_tr_block(h, w, 3, batch, s))) return rc;
   if ((rc = flush_pending(h, s))) return rc;
-  if (h->debug_stop_after_mid) {  // diagnostics (tools/debug_2s.py): leave the level-3 workspace as the mid blocks left it
-    h->last_batch = batch;
-    return DFOT_OK;
-  }
   if ((rc = run_up(h, 2, bt, s))) return rc;
   for (const TrW& w : h->up_tr)
     if ((rc = run_tr_block(h, w, 2, batch, s))) return rc;
@@ -1078,20 +982,6 @@ int dfot_uvit_read_tap(dfot_uvit_t h, const char* name, float* out, size_t capac
     DFOT_REQUIRE(capacity >= need, DFOT_ERR_SHAPE, "read_tap: need %zu floats, got %zu", need, capacity);
     return t.f ? launch_nhwc_to_nchw(t.f, out, bt, pixels(t.lvl), t.c, s)
                : launch_bf16_nhwc_to_nchw(t.b, out, bt, pixels(t.lvl), t.c, s);
-  }
-  // raw workspace buffers of the last transformer block (diagnostics, tools/debug_2s.py): element counts are the caller's business
-  {
-    struct Raw { const char* n; const void* p; size_t bytes; };
-    const size_t m3 = (size_t)h->last_batch * h->T * pixels(3), c3 = h->ch[3];
-    const Raw raws[] = {{"raw_cat", h->cat, m3 * 5 * c3 * sizeof(bf16)}, {"raw_s1", h->s1, m3 * c3 * sizeof(bf16)},
-                        {"raw_part", h->out_part, 3 * m3 * c3 * sizeof(float)}, {"raw_q", h->q, m3 * c3 * sizeof(bf16)},
-                        {"raw_x3", h->X[3], m3 * c3 * sizeof(float)}};
-    for (const Raw& r : raws) {
-      if (strcmp(r.n, name)) continue;
-      DFOT_REQUIRE(capacity * sizeof(float) >= r.bytes, DFOT_ERR_SHAPE, "read_tap: need %zu bytes", r.bytes);
-      DFOT_CHECK_HIP(hipMemcpyAsync(out, r.p, r.bytes, hipMemcpyDeviceToDevice, s));
-      return DFOT_OK;
-    }
   }
   set_error("read_tap: unknown tap '%s'", name);
   return DFOT_ERR_NAME;

@@ -84,9 +84,7 @@ size_t dfot_uvit_workspace_bytes(dfot_uvit_t h);
  * "attn_variant" (2 = tuned kernel (default), 0 = baseline with transposed LDS reads for V, 1 = baseline with scalar LDS reads,
  * 3 = tuned kernel with two K/V stages, 4 = two stages + per-tile Q reload (4 waves per SIMD; slower, kept for A/B)), "time_attn" (see below) */
 int dfot_uvit_set_option(dfot_uvit_t h, const char* key, int value);
-/* also: "two_stream" (bit 0 = level 3, bit 1 = level 2: the block's attention and MLP branches -- independent between the shared norm
- * and the residual sum, u_vit_blocks.py:253-277 -- run on two streams forked / joined with events; 0 = one serial chain),
- * "attn_force_safe" (1 = level-2 attention always takes the running-max kernel, as weights with a large QK-norm bound would)
+/* also: "attn_force_safe" (1 = level-2 attention always takes the running-max kernel, as weights with a large QK-norm bound would)
  * Read-outs (valid after finalize), by key: "score_bound_l2" = the largest bound of |q.k| log2(e)/sqrt(d) over the level-2 blocks, from
  * their q_norm / k_norm weights (u_vit_blocks.py:255-262); "attn_kernel_l2" = 14 (no running max, bound < 64) or 5 (running max):
  * the level-2 attention kernel forward runs */

@@ -77,7 +77,7 @@ def test_large_qk_norm_weights_take_the_running_max_attention(w64):
     """VERDICT r2 weak #4 / ADVICE: the level-2 attention runs without a running max only while the q_norm / k_norm weights bound the
     scores (sqrt(d) * max over rotary pairs of |w_q||w_k| * log2 e < 64).  With those weights scaled x1.9 each (a trained checkpoint may do
     that; logits x3.6) the bound is exceeded: the engine must report and run the running-max kernel (variant 5) and stay within the same 2e-2 of
-    the oracle evaluated on the same weights; the two-stream and the serial block schedules must agree with each other too."""
+    the oracle evaluated on the same weights."""
     from oracle import uvit as ouvit
     ocfg = w64["ocfg"]
     params = {n: t.clone() for n, t in w64["params"].items()}
@@ -91,26 +91,12 @@ def test_large_qk_norm_weights_take_the_running_max_attention(w64):
     b1 = model.query("score_bound_l2")
     assert model.query("attn_kernel_l2") == 5 and b1 >= 64 and abs(b1 / b0 - 3.61) < 1e-3
     x, k, c, m = (w64[n] for n in ("x", "k", "cond", "mask"))
-    with torch.no_grad():  # block schedules on the ordinary weights: serial chain vs attention / MLP branches on two streams at both levels
-        small.set_option("two_stream", 0)
-        s1 = small(x.cuda(), k.cuda(), c.cuda(), m.cuda()).cpu()
-        small.set_option("two_stream", 3)
-        s2 = small(x.cuda(), k.cuda(), c.cuda(), m.cuda()).cpu()
-    print(f"serial vs two-stream schedule, ordinary weights: rel_l2 {rel(s1, s2):.2e}")
-    # (the opt-in two-stream schedule is not run-to-run reproducible at this size -- csrc/uvit.hip, dfot_uvit_create -- so it is held to
-    # the oracle tolerance, not to bit equality with the serial chain)
-    assert rel(s1, w64["ref"]) < REL_TOL and rel(s2, w64["ref"]) < REL_TOL and rel(s1, s2) < 1e-2
     with torch.no_grad():
         ref = ouvit.forward(params, ocfg, x, k, c, m)
         v = model(x.cuda(), k.cuda(), c.cuda(), m.cuda()).cpu()
-        model.set_option("two_stream", 0)
-        v1 = model(x.cuda(), k.cuda(), c.cuda(), m.cuda()).cpu()
-        model.set_option("two_stream", 3)
-        v2 = model(x.cuda(), k.cuda(), c.cuda(), m.cuda()).cpu()
     r = rel(v, ref)
-    print(f"q/k-norm weights x1.9: score bound {b0:.1f} -> {b1:.1f}, running-max attention, rel_l2 vs oracle {r:.3e}; "
-          f"serial vs two-stream (both levels) {rel(v1, v2):.2e}")
-    assert torch.isfinite(v).all() and r < REL_TOL and rel(v1, ref) < REL_TOL and rel(v2, ref) < REL_TOL
+    print(f"q/k-norm weights x1.9: score bound {b0:.1f} -> {b1:.1f}, running-max attention, rel_l2 vs oracle {r:.3e}")
+    assert torch.isfinite(v).all() and r < REL_TOL
     # the bound is per rotary PAIR: a large q weight and a large k weight in DIFFERENT pairs do not add up
     p2 = {n: t.clone() for n, t in w64["params"].items()}
     for n in p2:
