@@ -90,7 +90,7 @@ enum GemmVariant {
   GEMM_DMA3_256x144 = 14,  // ... with a 3-stage ring (150 KB): the long-K out-projections wait on the one k-tile a 2-stage loop has in flight
   GEMM_AUTO = -1      // pick by shape (gemm_pick_variant)
 };
-int gemm_pick_variant(int amode, int m, int n, int k);
+int gemm_pick_variant(int amode, int m, int n, int k, bool plain_f32 = false);  // plain_f32: the caller's epilogue is E_F32 without GroupNorm partials
 // returns DFOT_OK / error; validates the divisibility contract before launching
 int launch_gemm(int amode, int epi, int variant, const GemmArgs& g, hipStream_t stream);
 

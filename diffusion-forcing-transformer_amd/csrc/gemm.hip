@@ -869,7 +869,7 @@ static int launch_v(int variant, const GemmArgs& g, hipStream_t s) {
   return DFOT_ERR_ARG;
 }
 
-int gemm_pick_variant(int amode, int m, int n, int k) {
+int gemm_pick_variant(int amode, int m, int n, int k, bool plain_f32) {
   // Measured on MI355X at the model's shapes (tools/bench_ops.py, profiles/): these GEMMs are bound by L2->LDS operand
   // traffic, so the 256x256 tile (128 FLOP per operand byte instead of 64) wins whenever it still fills the chip:
   // N wide enough that the padded columns are cheap, and enough tiles for the 256 CUs.
@@ -881,6 +881,11 @@ int gemm_pick_variant(int amode, int m, int n, int k) {
       const long t = (long)(m / 256) * ((n + bn - 1) / bn);
       return (double)m * n / ((double)((t + 255) / 256) * 256 * 256 * bn);
     };
+    // long K and N a multiple of 144: the three-stage 256x144 ring where its tile count fills the rounds better than both
+    // (M = 16384, N = 1152 at model batch 8: 512 tiles = 2 full rounds against 384 tiles of 256x192 = 1.5; K = 5760: 231 vs 261 us,
+    // K = 8064: 319 vs 363 us; at equal utilisation the wider tiles win: M = 65536, N = 576, K = 2880: 262 vs 250 us)
+    if (plain_f32 && n % 144 == 0 && k >= 2304 && (long)(m / 256) * (n / 144) >= 256 && util(144) > 1.1 * util(192) && util(144) > 1.1 * util(256))
+      return GEMM_DMA3_256x144;
     if (util(192) > 1.05 * util(256) && (long)(m / 256) * ((n + 191) / 192) >= 160) return GEMM_DMA_256x192;
   }
   if (m % 256 == 0 && n >= 192 && tiles >= 160) return GEMM_DMA_256x256;
@@ -902,7 +907,7 @@ int gemm_pick_variant(int amode, int m, int n, int k) {
 
 int launch_gemm(int amode, int epi, int variant, const GemmArgs& g, hipStream_t stream) {
   DFOT_REQUIRE(g.A && g.W, DFOT_ERR_ARG, "gemm: null operand");
-  if (variant == GEMM_AUTO) variant = gemm_pick_variant(amode, g.M, g.N, g.K);
+  if (variant == GEMM_AUTO) variant = gemm_pick_variant(amode, g.M, g.N, g.K, epi == E_F32 && !g.gn_part);  // (the 256x144 ring: plain fp32 epilogue only)
   if (variant == GEMM_DMA_128_KS2 && epi == E_QKV) variant = GEMM_DMA_128;  // the QKV epilogue has workgroup barriers
   if (variant == GEMM_DMA_128x192 && epi == E_QKV) variant = GEMM_DMA_128;
   if (variant == GEMM_DMA_256x192 && epi == E_QKV && g.d != 64) variant = GEMM_DMA_256x256;  // the d = 128 head pairing needs 128-aligned tiles
