@@ -285,7 +285,7 @@ __global__ __launch_bounds__(256, 2) void attn64_kernel_v3(const bf16* __restric
 // (query row, 4 columns); 16 threads per row.
 __global__ __launch_bounds__(256) void attn64_merge_kernel(const float* __restrict__ part_o, const float* __restrict__ part_ml,
                                                            bf16* __restrict__ O, long ldo, int N, int heads, int ohs,
-                                                           int full_tiles, int nsplit, int rem_tiles, int qrows) {
+                                                           int full_tiles, int nsplit, int rem_tiles, int qrows, float* __restrict__ lse) {
   const long gid = (long)blockIdx.x * 256 + threadIdx.x;
   const long row = gid >> 4;
   const int c4 = (int)(gid & 15) * 4;
@@ -310,6 +310,7 @@ __global__ __launch_bounds__(256) void attn64_merge_kernel(const float* __restri
 #pragma unroll
   for (int j = 0; j < 4; ++j) o4[j] = f2bf(acc[j] * inv);
   *reinterpret_cast<bf16x4*>(O + ((long)b * N + (tile % qtiles) * qrows + rloc) * ldo + hd * ohs + c4) = o4;
+  if (lse && c4 == 0) lse[(long)bh * N + (tile % qtiles) * qrows + rloc] = mmax + __log2f(l);  // training: log2-domain log-sum-exp of the row
 }
 
 }  // namespace
@@ -376,11 +377,11 @@ int attn_partials(const AttnSplit& sp, int qrows, float** po, float** pml, AttnS
 }
 
 int attn_launch_merge(const AttnSplit& sp, int qrows, const float* po, const float* pml, bf16* o, long ldo, int n, int heads,
-                      hipStream_t stream) {
+                      hipStream_t stream, float* lse) {
   if (sp.nsplit == 1) return DFOT_OK;
   const long threads = (long)sp.rem * qrows * 16;
   hipLaunchKernelGGL(attn64_merge_kernel, dim3(cdiv(threads, 256)), dim3(256), 0, stream, po, pml, o, ldo, n, heads, D, sp.full,
-                     sp.nsplit, sp.rem, qrows);
+                     sp.nsplit, sp.rem, qrows, lse);
   DFOT_CHECK_HIP(hipGetLastError());
   return DFOT_OK;
 }

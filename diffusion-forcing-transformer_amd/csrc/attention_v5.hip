@@ -71,7 +71,7 @@ template <int VPM, bool PIN>  // vector instructions requested per MFMA in the i
 __global__ __launch_bounds__(256, 2) void attn64_kernel_v5(const bf16* __restrict__ Q, const bf16* __restrict__ K,
                                                            const bf16* __restrict__ V, bf16* __restrict__ O, long ldo, int N,
                                                            int heads, int ohs, int full_tiles, int nsplit,
-                                                           float* __restrict__ part_o, float* __restrict__ part_ml) {
+                                                           float* __restrict__ part_o, float* __restrict__ part_ml, float* __restrict__ lse) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lq = lane & 31, lh = lane >> 5;
@@ -299,6 +299,7 @@ __global__ __launch_bounds__(256, 2) void attn64_kernel_v5(const bf16* __restric
     const int rloc = wave * 64 + 32 * qb + lq;
     if (seg < 0) {
       const float inv = 1.0f / l_tot;
+      if (lse && lh == 0) lse[(long)bh * N + (tile % qtiles) * QROWS + rloc] = __log2f(l_tot);  // training: no running max, so lse = log2 l
       bf16* orow = O + ((long)b * N + (tile % qtiles) * QROWS + rloc) * ldo + hd * ohs;
 #pragma unroll
       for (int dvt = 0; dvt < 2; ++dvt)
@@ -331,7 +332,7 @@ __global__ __launch_bounds__(256, 2) void attn64_kernel_v5(const bf16* __restric
 }  // namespace
 
 int launch_attention_v5(const bf16* q, const bf16* k, const bf16* v, bf16* o, long ldo, int batch, int heads, int n, hipStream_t stream,
-                        AttnScratch* scratch) {
+                        AttnScratch* scratch, float* lse) {
   DFOT_REQUIRE(q && k && v && o, DFOT_ERR_ARG, "attention: null pointer");
   DFOT_REQUIRE(n > 0 && n % QROWS == 0, DFOT_ERR_SHAPE, "attention v5: N=%d must be a multiple of %d", n, QROWS);
   DFOT_REQUIRE(ldo % 4 == 0, DFOT_ERR_SHAPE, "attention: output row stride %ld must be a multiple of 4", ldo);
@@ -346,14 +347,14 @@ int launch_attention_v5(const bf16* q, const bf16* k, const bf16* v, bf16* o, lo
       DFOT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
       attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3(sp.full + sp.rem * sp.nsplit), dim3(256), lds, stream, q, k, v, o, ldo, n, heads, D, sp.full, sp.nsplit, po, pml);
+    hipLaunchKernelGGL(kern, dim3(sp.full + sp.rem * sp.nsplit), dim3(256), lds, stream, q, k, v, o, ldo, n, heads, D, sp.full, sp.nsplit, po, pml, lse);
     DFOT_CHECK_HIP(hipGetLastError());
     return DFOT_OK;
   };
   static const int pin = tuning_flag("ATTN5_PIN", 1);
   rc = pin ? go(attn64_kernel_v5<3, true>) : go(attn64_kernel_v5<3, false>);
   if (rc) return rc;
-  return attn_launch_merge(sp, QROWS, po, pml, o, ldo, n, heads, stream);
+  return attn_launch_merge(sp, QROWS, po, pml, o, ldo, n, heads, stream, lse);
 }
 
 }  // namespace dfot

@@ -108,7 +108,7 @@ int launch_attention_v3(const bf16* q, const bf16* k, const bf16* v, bf16* o, lo
                         hipStream_t stream, AttnScratch* scratch = nullptr);
 // attention_v5.hip: attention_v3's NOMAX kernel with the key loop software-pipelined at half-tile granularity inside each wave
 int launch_attention_v5(const bf16* q, const bf16* k, const bf16* v, bf16* o, long ldo, int batch, int heads, int n, hipStream_t stream,
-                        AttnScratch* scratch = nullptr);
+                        AttnScratch* scratch = nullptr, float* lse = nullptr);  // lse: [B][heads][N] log2-domain log-sum-exp (training)
 // shared by the two: balanced tail (left-over query tiles split over the key axis) + merge of the fp32 partials
 struct AttnSplit {
   int tiles, full, rem, nsplit;
@@ -121,7 +121,7 @@ size_t attention_ks_scratch_bytes(int batch, int heads, int n, int d);
 int launch_attention_ks(const bf16* q, const bf16* k, const bf16* v, bf16* o, long ldo, int batch, int heads, int n, hipStream_t stream,
                         AttnScratch* scratch = nullptr);
 int attn_launch_merge(const AttnSplit& sp, int qrows, const float* po, const float* pml, bf16* o, long ldo, int n, int heads,
-                      hipStream_t stream);
+                      hipStream_t stream, float* lse = nullptr);
 int attention_dstride(int d);
 // lse (optional, training): [B][heads][N] fp32, log2-domain log-sum-exp of every query row
 int launch_attention_padded(const bf16* q, const bf16* k, const bf16* v, bf16* o, long ldo, int batch, int heads, int n, int d,

@@ -100,6 +100,9 @@ class TransformerBlockTrain:
             raise ValueError(f"head dim {self.d} not in (64, 128)")
         self.p = {n: params[f"{prefix}.{n}"].detach().to(device="cuda", dtype=torch.float32).contiguous() for n in self.NAMES}
         self.grads: Dict[str, torch.Tensor] = {}
+        # bound of |q.k| log2(e) / sqrt(d) from the q_norm / k_norm weights (set by the trainer, see _refresh_score_bounds); inf = take
+        # the running-max attention kernel
+        self.score_bound = float("inf")
         self.sync()
 
     def sync(self) -> None:
@@ -135,7 +138,8 @@ class TransformerBlockTrain:
                                                    math.log2(math.e) / math.sqrt(d), _P(q), _P(k), _P(v), rows, ntok, hds, d, _S()))
             capi.check(lib.dfot_op_silu_cols(_P(fused), 7 * c, 3 * c, None, 0, 0, _P(cat), 5 * c, c, rows, 4 * c, _S()))
         lse = torch.empty(batch, hds, ntok, dtype=torch.float32, device="cuda")
-        capi.check(lib.dfot_op_attention_fwd_lse(_P(q), _P(k), _P(v), _P(cat), 5 * c, _P(lse), batch, hds, ntok, d, _S()))
+        capi.check(lib.dfot_op_attention_fwd_lse_bounded(_P(q), _P(k), _P(v), _P(cat), 5 * c, _P(lse), batch, hds, ntok, d,
+                                                         float(self.score_bound), _S()))
         if mlp_mask is not None:
             capi.check(lib.dfot_op_mul_cols(_P(cat), 5 * c, c, _P(mlp_mask), rows, 4 * c, _S()))
         y = gemm_f32(cat, self.w_out, self.b_out, resid=x)
@@ -376,6 +380,7 @@ class UViT3DPoseTrainer:
         self.wu = [pack_conv(p[f"up_blocks.{j}.0.conv.weight"]) for j in range(3)]
         for b in self._blocks():
             b.sync()
+        self._refresh_score_bounds()
         # ResBlock levels: the column offset of every block in its level's FiLM-gradient matrix, and the matching [E][blocks * 2C]
         # concatenation of the emb_layer weights (backward: one embedding-gradient GEMM per level)
         self.res_cols: Dict[int, int] = {}
@@ -390,6 +395,39 @@ class UViT3DPoseTrainer:
 
     def _blocks(self):
         return [b for lv in self.down for b in lv] + self.mid + [b for lv in self.up for b in lv]
+
+    def _refresh_score_bounds(self) -> None:
+        """The d = 64 blocks may run their forward attention without a running max while sqrt(d) * max over rotary pairs of
+        max|w_q| * max|w_k| * log2(e) < 64 (csrc/uvit.hip, u_vit_blocks.py:255-262).  The bounds of all blocks are computed on the
+        device in one go after every weight refresh and copied to pinned host memory WITHOUT a host synchronisation; a forward
+        uses the newest copy that has arrived (the first one is awaited), with a 10 % margin for the steps it may lag behind --
+        the weights move by ~1e-4 relative per optimizer step."""
+        blocks = [b for b in self._blocks() if isinstance(b, TransformerBlockTrain) and b.d == 64]
+        if not blocks:
+            return
+        d = blocks[0].d
+        wq = torch.stack([b.p["q_norm.weight"] for b in blocks]).abs().view(len(blocks), d // 2, 2).amax(-1)
+        wk = torch.stack([b.p["k_norm.weight"] for b in blocks]).abs().view(len(blocks), d // 2, 2).amax(-1)
+        bound = (wq * wk).amax(-1) * (math.sqrt(d) * math.log2(math.e))
+        bound = torch.nan_to_num(bound, nan=float("inf"))
+        first = not hasattr(self, "_bound_host")
+        if first:
+            self._bound_host = torch.empty(len(blocks), dtype=torch.float32).pin_memory()
+            self._bound_evt = torch.cuda.Event()
+            self._bound_blocks = blocks
+        elif not self._bound_evt.query():
+            return  # the previous copy has not landed yet: keep it in flight, the blocks keep their current (margined) bounds
+        else:
+            self._apply_score_bounds()
+        self._bound_host.copy_(bound, non_blocking=True)
+        self._bound_evt.record()
+        if first:
+            self._bound_evt.synchronize()
+            self._apply_score_bounds()
+
+    def _apply_score_bounds(self) -> None:
+        for b, v in zip(self._bound_blocks, self._bound_host.tolist()):
+            b.score_bound = 1.1 * float(v)
 
     def _run(self, blocks, x, lvl):
         p = self.block_dropouts[lvl] if self.dropout_generator is not None else 0.0
