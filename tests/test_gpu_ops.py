@@ -51,6 +51,21 @@ def test_gemm(capi, dma, m, n, k):
     assert rel < 1e-5 and err < 1e-3
 
 
+def test_gemm_auto_pick_at_a_ring_shape(capi):
+    """M = 16384, N = 1152, K = 5760 (level-3 out-projection at model batch 8, the training dgrad shapes): the shape picker takes the
+    three-stage 256x144 ring here (512 tiles = two full rounds; gemm_pick_variant) -- checked against an fp32 matmul on the GPU"""
+    m, n, k = 16384, 1152, 5760
+    g = torch.Generator().manual_seed(5)
+    a = torch.randn(m, k, generator=g).bfloat16().cuda()
+    w = (torch.randn(n, k, generator=g) / math.sqrt(k)).bfloat16().cuda()
+    bias = torch.randn(n, generator=g).cuda()
+    out = torch.full((m, n), float("nan"), device="cuda")
+    capi.check(capi.lib.dfot_op_gemm(P(a), k, P(w), P(bias), P(out), m, n, k, -1, S()))
+    ref = a.float() @ w.float().t() + bias
+    err, rel = report(f"gemm auto {m}x{n}x{k}", out, ref)
+    assert torch.isfinite(out).all() and rel < 1e-5 and err < 2e-3
+
+
 @pytest.mark.parametrize("m,n,k", [(512, 128, 192), (1024, 100, 640)])
 def test_gemm_512_row_tile(capi, m, n, k):
     g = torch.Generator().manual_seed(m + n + k)
