@@ -32,7 +32,23 @@ RE10K = dict(channels=[128, 256, 576, 1152], emb_channels=1024, patch_size=2,
              num_updown_blocks=[3, 3, 6], num_mid_blocks=20, num_heads=9, pos_emb_type="rope",
              use_fourier_noise_embedding=True, conditioning=dict(dim=180))
 WINDOW_FLOP = 6.63e12  # per 8-frame window-forward
-GRAPH_DEFAULT = False  # sampler mode of the headline line: hipGraph when it measures >= eager on the same box
+GRAPH_DEFAULT = True  # sampler mode of the headline line: the north_star's hipGraph-captured step loop (`--eager` for the A/B)
+# the reference's own source timed on its CPU path in the build container (tools/time_reference_cpu.py): it cannot
+# travel to the GPU box, so the figure is quoted next to the oracle ("port") timing taken on the box itself
+REFERENCE_SOURCE_CPU = {"seconds_per_window_forward": 20.9, "threads": 8, "host": "build container (8 vCPU Xeon 2.1 GHz), torch 2.10 CPU, fp32",
+                        "how": "tools/time_reference_cpu.py: UViT3DPose.forward of the reference's source, Bm=1, T=8, 256x256"}
+
+
+def executed_flop_fraction(res: int, frames: int, dead_rows: float, frozen_rows: float) -> float:
+    """Share of the reference's per-forward FLOPs (WINDOW_FLOP) the engine executes in a sampling step.  Removed,
+    all bit-exact: the pose patch-embed and every per-pixel FiLM projection (once per window instead of once per
+    forward), the frame-local up path of frames whose output the composition discards (`dead_rows` = mean fraction of frame rows),
+    the frame-local down path of frozen context frames (`frozen_rows`).  GFLOP per frame at 256x256, scaled by the pixel count."""
+    px = (res / 256.0) ** 2
+    total = 828.2 * px
+    film = (24.2 + 51.5 + 25.8 + 29.0 + 24.2) * px         # pose embed + emb_layer of L0 / L1 ResBlocks, L2 / L3 transformer blocks
+    frame_local = (3 * 9.66 + 2.42 + 3 * 9.66 + 2.72) * px  # three ResBlocks (convolutions only) + one between-level conv, levels 0 and 1
+    return (total - film - frame_local * (dead_rows + frozen_rows)) / total
 
 
 def synth_poses(b: int, t: int, seed: int) -> torch.Tensor:
@@ -63,6 +79,7 @@ def cpu_baseline(res: int, sample_forwards: int, frames: int, forwards_per_sampl
             ouvit.forward(params, ocfg, x, k, cond, None)
     dt = (time.perf_counter() - t0) / sample_forwards
     return {"value": frames / (forwards_per_sample * dt), "unit": "frames/s", "cores": cores, "kind": "port",
+            "reference_source": dict(REFERENCE_SOURCE_CPU, frames_per_s=frames / (forwards_per_sample * REFERENCE_SOURCE_CPU["seconds_per_window_forward"])),
             "sample": f"{sample_forwards} window-forward(s) of the oracle (Bm=1, T=8, {res}x{res}), {dt:.2f} s each; "
                       f"scaled to {forwards_per_sample} window-forwards per {frames}-frame sample"}
 
@@ -343,44 +360,115 @@ def bench_k600(args, rank, world, dist):
         dist.destroy_process_group()
 
 
-def run_extras(args):
-    """BASELINE configs 3, 4 and 5 as child processes of this run (each its own `bench.py --workload ...` line, reduced to the
-    fields that matter).  A child is a fresh process: nothing of this one is re-executed or replaced."""
-    import subprocess
-    jobs = {
+def _reduced(j: dict) -> dict:
+    """the fields of a child's line that matter under `extra`"""
+    keep = {k: j[k] for k in ("metric", "value", "unit", "n_gpus", "rccl_ranks", "steps", "ms_per_step", "dtype", "scaling") if k in j}
+    keep["workload"] = j.get("config", {}).get("workload")
+    for k in ("model_tflops", "executed_flop_fraction", "window_forward_ms", "video_forward_ms", "sampler_mode", "attention_kernel", "hbm_gbps",
+              "ranks_bit_identical", "keyframe_phase", "grad_reduce"):
+        if j.get(k) is not None:
+            keep[k] = j[k]
+    if "roofline" in j:
+        keep["roofline"] = {k: j["roofline"].get(k) for k in ("kernel", "achieved", "peak", "frac", "unit", "source")}
+    return keep
+
+
+def extra_jobs(args, world: int) -> dict:
+    """BASELINE configs 3, 4 and 5 (and the A/B modes of config 2) as short, labelled runs next to the headline.  One GPU: every
+    config.  N > 1 ranks: the two workloads whose multi-GPU form is NOT N independent replicas -- the 200-frame rollout (windows sharded
+    over the ranks, key-frame History-Guidance branches split over rank pairs, one all-gather per plan stage) and the RE10K training
+    step (gradient all-reduce overlapped with the backward) -- so that the driver's `--gpus N` run measures them on RCCL."""
+    if world > 1 or args.dry_run:
+        jobs = {"200f": ["--workload", "200f", "--steps", "1", "--warmup", "0"]}
+        if not args.dry_run:
+            jobs["train_re10k"] = ["--workload", "train_re10k", "--batch", "8", "--steps", "2", "--warmup", "1"]
+        return jobs
+    return {
         "200f": ["--workload", "200f", "--steps", "1", "--warmup", "0"],                       # config 3, full 50 DDIM steps
         "k600": ["--workload", "k600", "--steps", "2", "--warmup", "1"],                       # config 4, README @DiT/XL
         "k600diff": ["--workload", "k600diff", "--steps", "1", "--warmup", "1"],               # config 4, bash/k600 model
         "train_re10k": ["--workload", "train_re10k", "--batch", "8", "--steps", "2", "--warmup", "1"],  # config 5
         "train_k600": ["--workload", "train_k600", "--steps", "3", "--warmup", "1"],
-        "8f_eager" if args.graph_default else "8f_graph": ["--workload", "8f", "--no-extras", "--steps", "2", "--warmup", "1"] + (["--eager"] if args.graph_default else ["--graph"]),
+        ("8f_eager" if GRAPH_DEFAULT else "8f_graph"): ["--workload", "8f", "--steps", "2", "--warmup", "1"] + (["--eager"] if GRAPH_DEFAULT else ["--graph"]),
         # what a checkpoint whose q_norm / k_norm weights exceed the no-running-max bound would get: level-2 attention on attention_v3 (variant 5)
-        "8f_safe_attention": ["--workload", "8f", "--no-extras", "--steps", "2", "--warmup", "1", "--attn-safe"],
+        "8f_safe_attention": ["--workload", "8f", "--steps", "2", "--warmup", "1", "--attn-safe"],
         "vae_decode": ["--workload", "vae_decode", "--steps", "3", "--warmup", "1"],
     }
-    out = {}
-    for name, extra_args in jobs.items():
-        cmd = [sys.executable, os.path.abspath(__file__), "--no-cpu-baseline", "--sampling-steps", str(args.sampling_steps)] + extra_args
+
+
+def coordinate(args):
+    """The process the driver starts (one per rank under `torch.distributed.run`, or the single `python bench.py`).  It NEVER touches
+    the GPU: the headline and every extra run as fresh `--worker` children, one after the other, so each starts on a clean device and a
+    failing or hanging extra cannot cost the headline line.  With N > 1 ranks the N coordinators agree on one rendezvous port per job
+    over a CPU (gloo) group and keep in step with barriers; rank 0 assembles and prints the ONE JSON line."""
+    import datetime
+    import socket
+    import subprocess
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", str(rank)))
+    jobs = {} if args.no_extras else extra_jobs(args, world)
+    cdist = None
+    ports = [0] * (1 + len(jobs))
+    if world > 1:
+        import torch.distributed as cdist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        cdist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(minutes=40))
+        if rank == 0:
+            socks = [socket.socket() for _ in ports]
+            for sk in socks:
+                sk.bind(("127.0.0.1", 0))
+            ports = [sk.getsockname()[1] for sk in socks]
+            for sk in socks:
+                sk.close()
+        box = [ports]
+        cdist.broadcast_object_list(box, src=0)
+        ports = box[0]
+    base = [sys.executable, os.path.abspath(__file__), "--worker", "--sampling-steps", str(args.sampling_steps), "--res", str(args.res)] + \
+           (["--dry-run"] if args.dry_run else [])
+    # a child is a rank of ITS OWN job: same RANK / WORLD_SIZE, a fresh port, nothing of the launcher's agent-store settings
+    env0 = {k: v for k, v in os.environ.items() if not k.startswith("TORCHELASTIC_") and k not in ("GROUP_RANK", "ROLE_RANK", "ROLE_WORLD_SIZE")}
+
+    def run(job_index: int, job_args, timeout: float):
+        env = dict(env0, RANK=str(rank), LOCAL_RANK=str(local), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(ports[job_index]))
         t0 = time.perf_counter()
         try:
-            r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
-            rows = [l for l in r.stdout.splitlines() if l.startswith("{")]
-            if r.returncode != 0 or not rows:
-                out[name] = {"error": (r.stderr or r.stdout)[-300:], "returncode": r.returncode}
+            r = subprocess.run(base + job_args, capture_output=True, text=True, timeout=timeout, env=env)
+            rc, out, err = r.returncode, r.stdout, r.stderr
+        except subprocess.TimeoutExpired as e:
+            rc, out, err = -9, "", f"timeout after {timeout:.0f} s: {e}"
+        if cdist is not None:  # every rank's child has ended (or was killed) before the next job's rendezvous starts
+            ok = [None] * world
+            cdist.all_gather_object(ok, rc)
+            rc = next((c for c in ok if c), 0)
+        rows = [l for l in out.splitlines() if l.startswith("{")]
+        return rc, (json.loads(rows[-1]) if rows else None), err, time.perf_counter() - t0
+
+    head_args = ["--workload", "8f", "--steps", str(args.steps), "--warmup", str(args.warmup)] + (["--no-cpu-baseline"] if args.no_cpu_baseline else []) + \
+                (["--eager"] if args.eager else []) + (["--graph"] if args.graph else []) + (["--attn-safe"] if args.attn_safe else [])
+    rc, line, err, _ = run(0, head_args, 1500)
+    if rc != 0 or (rank == 0 and line is None):
+        sys.stderr.write(err[-4000:])
+        raise SystemExit(rc if rc > 0 else 1)
+    extra = {}
+    for i, (name, job_args) in enumerate(jobs.items()):
+        try:
+            rc, j, err, wall = run(1 + i, ["--no-cpu-baseline"] + job_args, 900)
+            if rc != 0 or (rank == 0 and j is None):
+                extra[name] = {"error": (err or "")[-300:], "returncode": rc}
                 continue
-            j = json.loads(rows[-1])
-            keep = {k: j[k] for k in ("metric", "value", "unit", "steps", "ms_per_step", "dtype") if k in j}
-            keep["workload"] = j.get("config", {}).get("workload")
-            for k in ("model_tflops", "window_forward_ms", "video_forward_ms", "sampler_mode", "attention_kernel", "hbm_gbps"):
-                if j.get(k) is not None:
-                    keep[k] = j[k]
-            if "roofline" in j:
-                keep["roofline"] = {k: j["roofline"].get(k) for k in ("kernel", "achieved", "peak", "frac", "unit")}
-            keep["wall_s"] = time.perf_counter() - t0
-            out[name] = keep
+            if rank == 0:
+                extra[name] = dict(_reduced(j), wall_s=wall)
         except Exception as e:  # an extra must never cost the headline line
-            out[name] = {"error": repr(e)[:300]}
-    return out
+            extra[name] = {"error": repr(e)[:300]}
+    if world > 1 and args.dry_run and not args.no_extras:
+        extra["train_re10k"] = {"skipped": "dry run: the training step has no host-only form"}
+    if rank == 0:
+        if jobs or extra:
+            line["extra"] = extra
+        print(json.dumps(line), flush=True)
+    if cdist is not None:
+        cdist.barrier()
+        cdist.destroy_process_group()
 
 
 def bench_vae_decode(args):
@@ -410,10 +498,10 @@ def bench_vae_decode(args):
 
 
 def spawn_ranks(args, argv):
-    """`python bench.py --gpus N` without a launcher: this parent (which never touches the GPU) starts N fresh child processes, one
-    per GPU, with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set -- what `accelerate launch --multi_gpu --num_processes N`
-    does for the reference (configurations/cluster/a2i2_multigpu.yaml:45-57) -- forwards rank 0's JSON line and exits non-zero if any
-    child does.  A child that dies takes the others down instead of leaving them in a collective."""
+    """`python bench.py --gpus N` without a launcher: this parent starts N fresh rank processes, one per GPU, with RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_ADDR / MASTER_PORT set -- what `accelerate launch --multi_gpu --num_processes N` does for the reference
+    (configurations/cluster/a2i2_multigpu.yaml:45-57) -- forwards rank 0's JSON line and exits non-zero if any rank does.  A rank that
+    dies takes the others down instead of leaving them in a collective.  The environment is inherited as it is."""
     import socket
     import subprocess
     with socket.socket() as sk:
@@ -422,17 +510,21 @@ def spawn_ranks(args, argv):
     procs = []
     for r in range(args.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+        # its own session: the rank and the workers it starts form one process group that can be ended together
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, start_new_session=True,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
     failed = None
     while failed is None and any(p.poll() is None for p in procs[1:]) and procs[0].poll() is None:
         time.sleep(0.2)
         failed = next((p for p in procs if p.poll() not in (None, 0)), None)
     if failed is not None:
+        import signal
         for p in procs:
             if p.poll() is None:
-                p.kill()
+                try:
+                    os.killpg(p.pid, signal.SIGKILL)
+                except ProcessLookupError:
+                    pass
     out0 = procs[0].stdout.read() if procs[0].stdout else ""
     rcs = [p.wait() for p in procs]
     for l in out0.splitlines():
@@ -452,7 +544,8 @@ def main():
     ap.add_argument("--sampling-steps", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="8f only: skip the short runs of the other BASELINE configs appended under 'extra'")
-    ap.add_argument("--graph", action="store_true", help="all remaining DDIM steps of a window as ONE hipGraph, one replay per window")
+    ap.add_argument("--worker", action="store_true", help="internal: this process IS a rank of one workload (started by the coordinator)")
+    ap.add_argument("--graph", action="store_true", help="hipGraph step loop (the default): all remaining DDIM steps of a window as ONE graph")
     ap.add_argument("--eager", action="store_true", help="force the eager step loop (A/B against the default)")
     ap.add_argument("--attn-safe", action="store_true", help="level-2 attention on the running-max kernel (what weights beyond the QK-norm bound get)")
     ap.add_argument("--dry-run", action="store_true", help="host plumbing only (CPU, gloo): plans, shards and gathers every window but launches nothing")
@@ -462,7 +555,6 @@ def main():
                          "200-frame rollout (keyframe density 0.0625, stabilized HG 4.0/0.02 + interpolation HG 1.5, batches of "
                          "4 windows), interpolation windows sharded over ranks")
     args = ap.parse_args()
-    args.graph_default = GRAPH_DEFAULT
     use_graph = (GRAPH_DEFAULT or args.graph) and not args.eager
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -470,24 +562,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    extras = None
-    if world == 1 and args.workload == "8f" and not args.no_extras and args.res == 256 and not args.dry_run:
-        # the other BASELINE configs, short and clearly labelled, inside the same driver-timed run (the headline stays config 2).
-        # This process never touches the GPU: the headline runs first, as a child of its own on the fresh device, then the extras;
-        # the one JSON line is assembled here.
-        import subprocess
-        cmd = [sys.executable, os.path.abspath(__file__), "--no-extras", "--steps", str(args.steps), "--warmup", str(args.warmup),
-               "--sampling-steps", str(args.sampling_steps)] + (["--no-cpu-baseline"] if args.no_cpu_baseline else []) + (["--eager"] if args.eager else []) + \
-              (["--graph"] if args.graph else []) + (["--attn-safe"] if args.attn_safe else [])
-        r = subprocess.run(cmd, capture_output=True, text=True)
-        rows = [l for l in r.stdout.splitlines() if l.startswith("{")]
-        if r.returncode != 0 or not rows:
-            sys.stderr.write(r.stderr)
-            raise SystemExit(r.returncode or 1)
-        line = json.loads(rows[-1])
-        line["extra"] = run_extras(args)
-        print(json.dumps(line), flush=True)
-        return
+    if not args.worker and args.workload == "8f" and not args.no_extras:
+        # the driver's command: headline (config 2) + the other BASELINE configs, each a fresh worker process of its own
+        return coordinate(args)
     dev = "cpu" if args.dry_run else "cuda"
     if not args.dry_run:
         torch.cuda.set_device(local)
@@ -557,11 +634,12 @@ def main():
     sampler.use_graph = use_graph and not args.dry_run
     for _ in range(args.warmup):
         sampler._predict_videos(xs, n_context_tokens=1, conditions=conds)
-    # HIP events around the level-2 attention launches need the eager loop: hipEventElapsedTime refuses events recorded as nodes of a
-    # captured graph ("invalid resource handle" on ROCm 7.2), so the hipGraph mode reports no in-run roofline
+    # HIP events around the level-2 attention launches need the eager loop (hipEventElapsedTime refuses events recorded as nodes of a
+    # captured graph, "invalid resource handle" on ROCm 7.2): in hipGraph mode the roofline comes from ONE labelled eager sample run
+    # right after the timed region, in this process; in eager mode every launch inside the timed region is event-timed
     timed_attn = not sampler.use_graph and not args.dry_run
-    attn_per_sample = args.sampling_steps * 12 * (14 if long_rollout else 1) if timed_attn else 0
-    if model is not None:
+    attn_per_sample = args.sampling_steps * 12 * (14 if long_rollout else 1)
+    if model is not None and timed_attn:
         model.set_option("time_attn", attn_per_sample * args.steps if rank == 0 else 0)
     sampler.window_forwards = 0
     barrier()
@@ -587,23 +665,39 @@ def main():
     # 8f: one video per rank (weak scaling); 200f: all ranks cooperate on one video (strong scaling)
     total_frames = frames_per_sample * args.steps * (1 if long_rollout else world)
     fwd = sampler.window_forwards
+    roofline_source = "HIP events around every level-2 attention launch inside the timed region (eager step loop)"
+    roofline_fwd = fwd
+    if model is not None and sampler.use_graph and rank == 0 and not long_rollout:
+        # the same kernels, launched eagerly once more so that they can be bracketed by events (not part of `value`)
+        sampler.use_graph = False
+        model.set_option("time_attn", attn_per_sample)
+        sampler.window_forwards = 0
+        sampler._predict_videos(xs, n_context_tokens=1, conditions=conds)
+        torch.cuda.synchronize()
+        roofline_fwd = sampler.window_forwards
+        sampler.use_graph = True
+        roofline_source = "eager pass of one sample right after the timed region, same process (events cannot be timed inside a captured graph)"
 
     if rank == 0:
         attn_ms, attn_n = model.attn_timing() if model is not None else (0.0, 0)
         n2 = 8 * (res // 8) ** 2
-        # total level-2 attention FLOPs of the timed region = 4*N^2*d*heads per (window-forward, block) x 12 blocks
-        # x window-forwards; every one of those launches was event-timed, so achieved = FLOPs / summed duration.
-        # flop_per_launch is quoted for the model-batch-2 launch of the 8f workload.
+        # total level-2 attention FLOPs of the event-timed launches = 4*N^2*d*heads per (window-forward, block) x 12 blocks
+        # x window-forwards; achieved = FLOPs / summed duration.  flop_per_launch is quoted for the model-batch-2 launch of 8f.
         flop_per_launch = 4.0 * n2 * n2 * 64 * 9 * 2
-        total_attn_flop = 4.0 * n2 * n2 * 64 * 9 * 12 * fwd
+        total_attn_flop = 4.0 * n2 * n2 * 64 * 9 * 12 * roofline_fwd
         achieved = total_attn_flop / (attn_ms * 1e-3) / 1e12 if attn_n else None
-        traffic = None
-        pmc = next((f for f in (os.path.join(ROOT, "profiles", n) for n in ("r03_pmc_hbm_traffic_8f.json", "r02_pmc_hbm_traffic_8f.json")) if os.path.exists(f)), None)
+        traffic = traffic_source = None
+        pmc = next((f for f in (os.path.join(ROOT, "profiles", n) for n in ("r04_pmc_hbm_traffic_8f.json", "r03_pmc_hbm_traffic_8f.json")) if os.path.exists(f)), None)
         if pmc and res == 256 and not long_rollout:
             ks = [v for n, v in json.load(open(pmc))["kernels"].items() if "attn64_kernel_v5" in n]
             traffic = ks[0]["hbm_bytes_per_launch_corrected"] if ks else None
+            traffic_source = "committed PMC pass of the same command (%s), not measured in this run" % os.path.relpath(pmc, ROOT)
         akern = int(model.query("attn_kernel_l2")) if model is not None else None
         kname = {14: "attn64_kernel_v5 (no running max: QK-norm bound < 64)", 5: "attn64_kernel_v3 (running max)"}.get(akern, "none (dry run)")
+        # rows of the model batch whose frame-local work is skipped: 8f has one context frame of eight -- dead in both branches (1/8 of
+        # the rows), frozen in the conditional branch from a window's second step on (1/16 of the rows)
+        exec_frac = None if long_rollout or res % 8 else executed_flop_fraction(res, 8, 1 / 8, (1 / 16) * (1 - 1 / args.sampling_steps) if (res // 8) ** 2 % 512 == 0 else 0.0)
+        nominal = WINDOW_FLOP * (res / 256.0) ** 2 * fwd / dt / 1e12
         line = {
             "metric": "denoised latent frames/sec, DFoT RE10K 8f & 200f rollout @1/2/4/8 GPU",
             "value": total_frames / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -615,24 +709,31 @@ def main():
                                    (f"DFoT_RE10K 8-frame sample: context 1, {args.sampling_steps} DDIM steps, vanilla history "
                                     f"guidance 4.0 (NFE 2), {res}x{res}, one video per GPU"),
                        "window_forwards_per_step": fwd // args.steps, "frames_per_step": frames_per_sample},
+            "rccl_ranks": dist.get_world_size() if world > 1 else 1, "collective_backend": dist.get_backend() if world > 1 else None,
             "window_forward_ms": dt / fwd * 1e3,
-            "model_tflops": WINDOW_FLOP * (res / 256.0) ** 2 * fwd / dt / 1e12 if res == 256 else None,
+            # NOMINAL rate: the reference's FLOPs per window-forward over the measured time.  The engine executes
+            # only `executed_flop_fraction` of them (per-window FiLM cache, dead / frozen frame skips: DESIGN.md 4a), so the hardware
+            # utilisation is model_tflops_executed / 2500, not model_tflops / 2500
+            "model_tflops": nominal, "executed_flop_fraction": exec_frac,
+            "model_tflops_executed": nominal * exec_frac if exec_frac else None,
             "roofline": {"bound": "mfma", "kernel": "%s + attn64_merge_kernel (level-2 flash attention, N=%d, d=64; the event pair "
                                                    "brackets both launches)" % (kname.split(" (")[0], n2),
                          "achieved": achieved, "peak": 2500.0, "unit": "TFLOP/s",
-                         "frac": achieved / 2500.0 if achieved else None, "traffic": traffic,
+                         "frac": achieved / 2500.0 if achieved else None, "traffic": traffic, "traffic_source": traffic_source,
                          "launches": attn_n, "avg_launch_ms": attn_ms / max(attn_n, 1),
-                         "flop_per_launch": flop_per_launch},
+                         "flop_per_launch": flop_per_launch, "source": roofline_source if attn_n else None},
             # which level-2 attention kernel these weights got and why: the fast kernel needs the bound below 64
             "attention_kernel": kname, "score_bound": model.query("score_bound_l2") if model is not None else None,
         }
+        if long_rollout and world > 1:
+            line["keyframe_phase"] = (f"{world // 2} rank pair(s) each evaluate the two History-Guidance branches of the sequential key-frame windows; "
+                                      "pairs beyond the first repeat the first pair's work (replicated state, no broadcast) -- that phase does not "
+                                      "scale past 2 ranks" + ("" if world % 2 == 0 else "; odd world: no branch split, every rank evaluates both branches"))
         if not args.no_cpu_baseline and world == 1 and not args.dry_run:  # reported baseline: rank 0 at N=1 only
             line["cpu_baseline"] = cpu_baseline(res, 1, frames_per_sample, fwd // args.steps)
         line["sampler_mode"] = "dry-run (host plumbing only, nothing launched)" if args.dry_run else ("hipgraph" if sampler.use_graph else "eager")
         if ranks_identical is not None:
             line["ranks_bit_identical"] = ranks_identical
-        if extras is not None:
-            line["extra"] = extras
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

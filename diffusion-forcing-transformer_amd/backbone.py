@@ -156,8 +156,11 @@ class UViT3DPose(nn.Module):
             capi.check(capi.lib.dfot_uvit_load_weight(self._handle, name.encode(), capi.ptr(src), shape, src.ndim, s))
         capi.check(capi.lib.dfot_uvit_finalize(self._handle, s))
         self._synced = sig
+        # captured sampler graphs bake the kernels chosen for the OLD weights (attention variant by score bound) and their pointers
+        self.reserve_generation = getattr(self, "reserve_generation", 0) + 1
 
     def set_option(self, key: str, value: int) -> None:
+        self.reserve_generation = getattr(self, "reserve_generation", 0) + 1  # options select kernels: captured graphs are stale
         capi.check(capi.lib.dfot_uvit_set_option(self._handle, key.encode(), int(value)))
 
     def query(self, key: str) -> float:

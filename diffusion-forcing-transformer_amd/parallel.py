@@ -119,7 +119,8 @@ class OverlappedGradReducer:
     flat buffer, async) while the backward of the next blocks runs; `finish()` reduces the remaining ranges and waits.  No bucket
     packing (`torch.cat`) and no copy-back: the only extra pass over the gradients is the 1/world scale, and over RCCL not even that
     (ReduceOp.AVG).  Few large ranges (xGMI is point-to-point: a ring all-reduce is bound per link).  Per element the summation is
-    that of one all-reduce, so the result equals `allreduce_mean_` on the whole flat buffer bit for bit."""
+    that of one all-reduce; against `allreduce_mean_` (SUM, then one multiply by 1/world) the mean can differ in the last bit when the
+    collective averages itself (ReduceOp.AVG) and the world is not a power of two -- every rank still holds the same bits."""
 
     def __init__(self, bucket_numel: int = 1 << 25, group=None, flat: Optional[torch.Tensor] = None):
         self.bucket_numel, self.group = int(bucket_numel), group
@@ -198,21 +199,23 @@ _BRANCH_GROUPS = {}
 def branch_group(nfe: int, group=None):
     """The `nfe`-rank sub-group this rank exchanges History-Guidance branches in: ranks [g*nfe, (g+1)*nfe) form group g, so that with
     8 ranks and 2 branches four PAIRS each exchange 2 x v (instead of one all-gather over 8 ranks, of which 6 carried redundant
-    copies).  Ranks beyond the last full group get None (they evaluate every branch themselves).  Collective on first use: every rank
-    of the world must call it with the same nfe (dist.new_group is a world-wide call)."""
+    copies).  The world must divide into such groups (the sampler runs a step unsplit on every rank otherwise: leftover ranks would
+    evaluate another model batch than the grouped ones, and kernel choices -- hence bits -- follow the batch).  Collective on first
+    use: EVERY rank of the world must call it with the same nfe (dist.new_group is a world-wide call); the sampler does so at the top
+    of each replicated window, before its step loop."""
     world, rank = world_info(group)
     if group is not None:
         raise ValueError("branch_group: nested groups are not supported")
+    if nfe < 1 or world % nfe != 0:
+        raise ValueError(f"branch_group: {world} ranks do not divide into groups of {nfe}")
     key = (nfe, world)
     if key not in _BRANCH_GROUPS:
         groups = []
         for g in range(world // nfe):
             ranks = list(range(g * nfe, (g + 1) * nfe))
-            groups.append(dist.new_group(ranks) if world > nfe else None)  # world == nfe: the default group is the pair
+            groups.append(dist.new_group(ranks) if world > nfe else None)  # world == nfe: the default group is the one group
         _BRANCH_GROUPS[key] = groups
-    g = rank // nfe
-    groups = _BRANCH_GROUPS[key]
-    return (g < len(groups)), (groups[g] if g < len(groups) else None)
+    return _BRANCH_GROUPS[key][rank // nfe]
 
 
 def exchange_branches(v_local: torch.Tensor, nfe: int, group=None) -> torch.Tensor:
@@ -223,9 +226,7 @@ def exchange_branches(v_local: torch.Tensor, nfe: int, group=None) -> torch.Tens
     world, rank = world_info(group)
     if world < nfe:
         raise ValueError(f"branch parallelism needs at least {nfe} ranks, have {world}")
-    member, sub = branch_group(nfe, group)
-    if not member:
-        raise ValueError(f"rank {rank} is outside the last full {nfe}-rank branch group; it must evaluate all branches itself")
+    sub = branch_group(nfe, group)
     out = v_local.new_empty((nfe * v_local.shape[0], *v_local.shape[1:]))
     dist.all_gather_into_tensor(out, v_local.contiguous(), group=sub)
     b = v_local.shape[0]

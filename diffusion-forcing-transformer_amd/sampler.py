@@ -14,7 +14,8 @@ window instead of once per step (it does not depend on the step), and all frame 
 step is two fused kernels around the backbone call.
 Randomness is drawn through ``noise_fn(tag, shape)`` (tags: "init", "q_sample", "ddim") so tests can
 replay the reference's draws; the default draws on the GPU with ``torch.randn``.
-With ``use_graph = True`` the steps of a window after the first are captured as ONE hipGraph (``torch.cuda.CUDAGraph``) and replayed.
+By default (``use_graph``) the steps of a window after the first are captured as ONE hipGraph (``torch.cuda.CUDAGraph``) and replayed;
+windows the capture cannot serve run eagerly.
 """
 from __future__ import annotations
 
@@ -77,7 +78,10 @@ class DFoTVideoPoseSampler:
         self._branch_split_active = False
         self.device = "cuda"        # where the rollout state lives; "cpu" only together with dry_run (planner inspection / host tests)
         self.dry_run = False        # True: plan every window (trace, noise draws in the reference's order) but launch nothing
-        self.use_graph = False      # True: capture one DDIM step in a hipGraph and replay it (see _run_steps_graph)
+        # hipGraph execution of the step loop (the default): the steps of a window after the first are ONE captured graph, one replay per
+        # window (_run_steps_graph).  Windows the capture cannot serve -- stochastic steps, strict-order noise replay, per-step
+        # conditioning, branch-parallel key frames, reconstruction guidance, a step_hook -- run the same kernels eagerly; False forces that.
+        self.use_graph = True
         self.skip_frozen_frames = True  # ... nor the down path of frames whose input equals the previous step's (clean context)
         self.skip_dead_frames = True  # the backbone does not compute the output of tokens the composition step ignores (context / padding)
         self.graph_replays = 0
@@ -335,10 +339,27 @@ class DFoTVideoPoseSampler:
                         noise = torch.where(em, fresh, noise if noise is not None else torch.zeros_like(fresh))
             return None if noise is None else noise.contiguous().view(bm, horizon, *x_shape)
 
+        # History-Guidance branch parallelism (replicated key-frame windows only): a step's `nfe` branches are split over nfe-rank
+        # sub-groups when the world divides into them; otherwise EVERY rank evaluates all branches of that step (same model batch on
+        # every rank, so the replicas stay bit-identical).  The sub-groups are created here, before the step loop, by every rank of
+        # the world (dist.new_group is a world-wide call): all ranks plan the same window, hence the same set of branch counts.
+        split_nfe = set()
+        if self._branch_split_active:
+            world_n = parallel.world_info()[0]
+            for n_ in sorted({p_["nfe"] for p_ in plans if not p_.get("renoise")}):
+                if n_ > 1 and world_n > 1 and world_n % n_ == 0:
+                    parallel.branch_group(n_)
+                    split_nfe.add(n_)
         if self.dry_run:
             # planner inspection: every host decision of the window has been taken (trace, per-step plans); consume the noise
             # draws in the order the device path would and hand back the context-filled window -- nothing is launched
             for p_ in plans:
+                if p_["nfe"] in split_nfe:  # host plumbing of the branch exchange: same groups, same collective, a marker payload
+                    hb = parallel.world_info()[1] % p_["nfe"]
+                    got = parallel.exchange_branches(torch.full((batch_size, 1), float(hb)), p_["nfe"])
+                    if not torch.equal(got.view(batch_size, p_["nfe"]), torch.arange(p_["nfe"], dtype=got.dtype).repeat(batch_size, 1)):
+                        raise RuntimeError("branch exchange returned the branches out of (sample, branch) order")
+                    self.branch_exchanges = getattr(self, "branch_exchanges", 0) + 1
                 if p_.get("renoise"):
                     self.noise_fn("renoise", (batch_size, horizon, *x_shape))
                     continue
@@ -427,7 +448,7 @@ class DFoTVideoPoseSampler:
             # discrete diffusion hands the backbone integer level indices (exact in the float32 table)
             lvl = tables[7] if cfg.diffusion.is_continuous else tables[7].to(torch.int32)
             world, rank = parallel.world_info()
-            if self._branch_split_active and nfe > 1 and (rank // nfe + 1) * nfe <= world:  # rank inside a full nfe-rank branch group
+            if nfe in split_nfe:  # this rank evaluates branch rank % nfe; its nfe-rank sub-group returns all of them
                 # this rank's branch only; the conditioning slices are cached per window so that the backbone's pose cache (keyed on
                 # tensor identity) still hits on every step
                 hb = rank % nfe
@@ -443,6 +464,7 @@ class DFoTVideoPoseSampler:
                     self.model.live_frames = gen_dev
                 try:
                     v = parallel.exchange_branches(self.model(x_h, l_h, c_h, m_h), nfe)
+                    self.branch_exchanges = getattr(self, "branch_exchanges", 0) + 1
                 finally:
                     if skip_dead:
                         self.model.live_frames = None
@@ -498,11 +520,11 @@ class DFoTVideoPoseSampler:
         # composition weights AND conditioning tensor (temporal guidance re-interpolates the poses of pure-noise tokens per step)
         uniform = all(p_["bm"] == plans[0]["bm"] and p_["cmask_dev"] is plans[0]["cmask_dev"]
                       and p_["weights_dev"] is plans[0]["weights_dev"] and p_.get("cond") is plans[0].get("cond") for p_ in plans)
+        hook = getattr(self, "step_hook", None)  # test instrumentation (drift per step); None on every product path
         if (self.use_graph and uniform and not strict and len(plans) > 2 and all(p_["sigma"] is None for p_ in plans) and not self._branch_split_active
-                and rg == 0):
+                and rg == 0 and hook is None):
             xs = self._run_steps_graph(plans, xs, draw_noise, step, flat_dev, gens_dev, horizon)
         else:
-            hook = getattr(self, "step_hook", None)  # test instrumentation (drift per step); None on every product path
             for i, p_ in enumerate(plans):
                 xs = step(p_, xs, draw_noise(p_), p_["tables_dev"], p_["gen_dev"])
                 if hook is not None:
@@ -596,6 +618,8 @@ class DFoTVideoPoseSampler:
         bm, n_steps, nfe = p0["bm"], len(plans), p0["nfe"]
         need_noise = any(p_["need_noise"] for p_ in plans)
         self.model.reserve(bm)  # before looking at the generation: a growing workspace invalidates every captured pointer
+        if hasattr(self.model, "sync_weights"):
+            self.model.sync_weights()  # ... and so do re-loaded weights (kernel choices follow them) or a changed engine option
         gen = getattr(self.model, "reserve_generation", 0)
         if gen != self._graphs_generation:
             self._graphs.clear()

@@ -196,13 +196,21 @@ def _branch_group_worker(rank, world, port, q):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from dfot_amd import parallel
-    member, _ = parallel.branch_group(2)
+    nfe = 2
+    divides = world % nfe == 0
     ok = True
-    if member:
+    if divides:
+        parallel.branch_group(nfe)  # every rank of the world enters dist.new_group
         # rank r evaluated branch r % 2 of 3 samples; the value also carries the pair id to show nothing crosses pairs
         v_local = torch.full((3, 8, 2), float(rank % 2) + 100.0 * (rank // 2)) + torch.arange(3).view(3, 1, 1) * 10
         v = parallel.exchange_branches(v_local, nfe=2)
         ok = v.shape == (6, 8, 2) and all(float(v[b * 2 + h, 0, 0]) == h + 10 * b + 100.0 * (rank // 2) for b in range(3) for h in range(2))
+    else:
+        try:  # three ranks do not divide into pairs: refused on every rank (the sampler then runs the step unsplit everywhere)
+            parallel.branch_group(nfe)
+            ok = False
+        except ValueError:
+            pass
     # in-place range reducer: out-of-order hand-over, ranges merge, result == the one-shot flat all-reduce
     g = torch.Generator().manual_seed(3)
     sizes = [40, 300, 8, 700, 129]
@@ -216,27 +224,69 @@ def _branch_group_worker(rank, world, port, q):
     whole = torch.cat(all_grads[rank]).clone()
     parallel.allreduce_mean_(whole, bucket_numel=1 << 20)
     # (three ranks: a ring's per-element summation order depends on how the buffer is cut, so close, not bit-equal; two ranks: bit-equal above)
-    q.put((rank, member, ok, bool(torch.allclose(flat, whole, atol=1e-6)), red.calls))
+    q.put((rank, divides, ok, bool(torch.allclose(flat, whole, atol=1e-6)), red.calls))
     dist.barrier()
     dist.destroy_process_group()
 
 
 @pytest.mark.timeout(300)
-def test_branch_groups_are_pairs_and_ranges_reduce_in_place_world3():
-    """three ranks, two History-Guidance branches: ranks 0 and 1 form the one full pair and exchange only with each other, rank 2 is
-    outside a full group (it evaluates both branches itself); the gradient reducer all-reduces merged ranges of the flat buffer in place"""
+@pytest.mark.parametrize("world", [3, 4])
+def test_branch_groups_are_pairs_and_ranges_reduce_in_place(world):
+    """two History-Guidance branches: four ranks form two pairs that exchange only inside the pair; three ranks do not divide into
+    pairs and the grouping is refused on every rank (no leftover rank with another model batch, dist.new_group entered by all
+    ranks or by none); the gradient reducer all-reduces merged ranges of the flat buffer in place"""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_branch_group_worker, args=(r, 3, port, q)) for r in range(3)]
+    procs = [ctx.Process(target=_branch_group_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted(q.get(timeout=120) for _ in procs)
     for p in procs:
         p.join(60)
-    assert [m for _, m, _, _, _ in res] == [True, True, False], res
+    assert [m for _, m, _, _, _ in res] == [world % 2 == 0] * world, res
     assert all(ok and same for _, _, ok, same, _ in res), res
     assert all(1 <= calls <= 3 for *_, calls in res), res
+
+
+def _sampler_branch_worker(rank, world, port, q):
+    """the SAMPLER's own branch-parallel path (dry run: host plumbing, gloo): replicated key-frame windows of a short rollout"""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import dfot_amd
+    from dfot_amd import parallel
+    cfg = dfot_amd.SamplerConfig(x_shape=(3, 16, 16), diffusion=dfot_amd.DiffusionConfig(sampling_timesteps=3),
+                                 prediction_guidance=dict(name="vanilla", guidance_scale=2.0), keyframe_density=0.25,
+                                 interpolation_guidance=dict(name="vanilla", guidance_scale=1.5), interpolation_max_batch_size=2)
+    samp = dfot_amd.DFoTVideoPoseSampler(cfg, backbone=None, noise_fn=parallel.WindowKeyedNoise(5, device="cpu"))
+    samp.device, samp.dry_run, samp.branch_parallel, samp.shard_windows = "cpu", True, True, True
+    out = samp._predict_videos(torch.zeros(1, 40, 3, 16, 16), n_context_tokens=1, conditions=None)
+    ref = out.clone()
+    dist.broadcast(ref, 0)
+    q.put((rank, getattr(samp, "branch_exchanges", 0), bool(torch.equal(ref, out)), samp.window_forwards))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("world", [2, 3])
+def test_sampler_branch_parallel_every_rank_same_path(world):
+    """through the sampler itself.  world 2 / nfe 2: every key-frame step exchanges branches inside the pair.
+    world 3 / nfe 2: NO rank splits (all three evaluate both branches, the same model batch everywhere) and nobody is left outside a
+    collective -- the run finishes, windows are still sharded and all-gathered, all ranks end with the same rollout."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sampler_branch_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=200) for _ in procs)
+    for p in procs:
+        p.join(60)
+    ex = [e for _, e, _, _ in res]
+    assert all(same for _, _, same, _ in res), res
+    assert len(set(ex)) == 1 and (ex[0] > 0) == (world % 2 == 0), res
 
 
 def test_branch_parallel_needs_rank_independent_noise(monkeypatch):
@@ -270,7 +320,34 @@ def test_bench_gpus_flag_starts_the_ranks():
     line = rows[0]
     assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["ranks_bit_identical"] is True
     assert line["config"]["frames_per_step"] == 199 and line["sampler_mode"].startswith("dry-run")
+    assert line["rccl_ranks"] == 2 and line["collective_backend"] == "gloo" and "keyframe_phase" in line
     # a rank that fails takes the job down with a non-zero exit code instead of hanging the others
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "k600", "--dry-run"], capture_output=True, text=True,
                        timeout=300, env=env)
     assert r.returncode != 0
+
+
+@pytest.mark.timeout(900)
+def test_bench_driver_command_measures_the_sharded_workloads():
+    """the driver's multi-GPU command is `bench.py --gpus N` with the DEFAULT workload.  Its line must carry, next
+    to the weak-scaling 8f headline, the workloads whose N-rank form is not N replicas: `extra.200f` (sharded windows, branch split,
+    ranks bit-identical) with n_gpus = N, and `extra.train_re10k` (here: marked skipped, the dry run has no device).  Rank processes
+    are coordinators that never touch the GPU; headline and extras are fresh worker processes with their own rendezvous."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--res", "64", "--sampling-steps", "2", "--dry-run",
+                        "--steps", "1", "--warmup", "0"], capture_output=True, text=True, timeout=800, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rows = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(rows) == 1
+    line = rows[0]
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["rccl_ranks"] == 2
+    assert line["config"]["frames_per_step"] == 7 and abs(line["value"] * line["ms_per_step"] / 1e3 - 14) < 1e-6  # two videos
+    ex = line["extra"]
+    assert set(ex) == {"200f", "train_re10k"}
+    assert ex["200f"]["n_gpus"] == 2 and ex["200f"]["rccl_ranks"] == 2 and ex["200f"]["ranks_bit_identical"] is True
+    assert ex["200f"]["scaling"] == "strong" and "keyframe_phase" in ex["200f"]
+    assert "skipped" in ex["train_re10k"]
