@@ -122,7 +122,8 @@ SIGNATURES = {
     "dfot_op_fused_proj_train": (_I, [_P, _I, _P, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P, _I, _I, _L, _I, _I, _I, _P]),
     "dfot_op_silu_cols": (_I, [_P, _I, _I, _P, _I, _I, _P, _I, _I, _L, _I, _P]),
     "dfot_op_attention_fwd_lse": (_I, [_P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _P]),
-    "dfot_op_attention_fwd_lse_bounded": (_I, [_P, _P, _P, _P, _I, _P, _I, _I, _I, _I, C.c_float, _P]),
+    "dfot_op_attention_fwd_lse_bounded": (_I, [_P, _P, _P, _P, _I, _P, _I, _I, _I, _I, C.c_float, _P, C.c_size_t, _P]),
+    "dfot_op_attention_scratch_bytes": (C.c_size_t, [_I, _I, _I, _I]),
     "dfot_op_attention_bwd_lse": (_I, [_P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "dfot_op_gn_silu_fwd": (_I, [_P, _P, _P, _P, _F, _P, _P, _I, _I, _I, _P]),
     "dfot_op_gn_silu_bwd2": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),

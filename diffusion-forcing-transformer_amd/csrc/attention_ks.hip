@@ -298,7 +298,7 @@ bool attention_ks_applies(int batch, int heads, int n, int d) {
   // against 82.5 us for this kernel without a balanced tail; B x H = 18: 67.5 -> 62.5 us; B x H = 9: 47.6 -> 38.2 us)
   if (!on || d != 128 || n % QR != 0 || (n / KV) % 2 != 0) return false;
   const AttnSplit sp = plan_ks(batch, heads, n);
-  return sp.full == 0 || (sp.full == 256 && sp.nsplit > 1);
+  return sp.full == 0 || (sp.full == sp.slots && sp.nsplit > 1);
 }
 
 size_t attention_ks_scratch_bytes(int batch, int heads, int n, int d) {

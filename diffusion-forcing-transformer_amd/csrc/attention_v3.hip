@@ -325,6 +325,7 @@ AttnSplit attn_plan_split(int batch, int heads, int n, int qrows, int wgs_per_cu
   }
   const int slots = wgs_per_cu * cus;
   AttnSplit sp;
+  sp.slots = slots;
   sp.tiles = batch * heads * (n / qrows);
   static const int mode = tuning_flag("ATTN3_SPLIT", 1);
   sp.rem = mode ? sp.tiles % slots : 0;

@@ -340,7 +340,23 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int tile_inde
   // 16 B per lane on whole 128/256-byte row segments (the MFMA C layout gives a lane one column and four rows).
   // All stage buffers are dead after the last barrier; same-wave LDS accesses complete in order.
   // (with split-K the scratch sits behind the reduction area, which other waves of group 0 may still be reading)
-  float* ep = reinterpret_cast<float*>(smem_all) + (KS == 2 ? NW * MI * 16 * 64 : 0) + wave * (16 * EP_LD);
+  //
+  // LDS invariants of the epilogue (argued once, here; DESIGN.md section 7 "the round-3 q mismatch"):
+  //  (1) ring -> scratch.  `ep` aliases stage 0 of the operand ring.  Every main-loop form ends with `s_waitcnt vmcnt(0)` (all of this
+  //      wave's LDS-DMA writes have landed) followed by a workgroup barrier that every wave reaches after its last fragment read
+  //      (the ds_reads feed MFMAs issued before the barrier), so no wave can still read operands, and no DMA can still write, where
+  //      another wave starts writing its scratch.
+  //  (2) scratch.  wave w touches only floats [w * 16 * EP_LD, (w + 1) * 16 * EP_LD): written in the MFMA C layout, read back as rows,
+  //      by the same wave.  ds_write / ds_read of one wave execute in issue order, so the read-back of pass mi sees the writes of pass
+  //      mi and is finished before the writes of pass mi + 1; no other wave and no DMA ever addresses the region: no barrier needed.
+  //  (3) d = 128 exchange (`xch`, behind all scratch regions, two buffers by pass parity).  wave w writes slots [w * 16, w * 16 + 16) of
+  //      buffer mi & 1, then the barrier, then reads the slots of wave w ^ 1.  The partner can overwrite buffer mi & 1 again only in
+  //      pass mi + 2, i.e. after the barrier of pass mi + 1, which this wave reaches after its reads of pass mi: write-after-read safe
+  //      with ONE barrier per pass.  The barrier is under a workgroup-uniform condition and no wave leaves the epilogue early.
+  //  (4) row reductions are DPP (register-to-register inside a row of 8 lanes): nothing of them goes through LDS.
+  // Nothing in (1)-(4) depends on which other workgroups (of this or another kernel) are resident on the CU: LDS allocations are
+  // disjoint and every address above is relative to this workgroup's own.
+  float* ep =reinterpret_cast<float*>(smem_all) + (KS == 2 ? NW * MI * 16 * 64 : 0) + wave * (16 * EP_LD);
   const int colq = lane & 15, rowq = (lane >> 4) * 4;
   const int nw = n0 + wn * WTN;
   [[maybe_unused]] const bool has_res = g.resid != nullptr;

@@ -112,6 +112,7 @@ int launch_attention_v5(const bf16* q, const bf16* k, const bf16* v, bf16* o, lo
 // shared by the two: balanced tail (left-over query tiles split over the key axis) + merge of the fp32 partials
 struct AttnSplit {
   int tiles, full, rem, nsplit;
+  int slots;  // resident workgroups of one round: wgs_per_cu x the device's CU count
 };
 AttnSplit attn_plan_split(int batch, int heads, int n, int qrows, int wgs_per_cu);
 int attn_partials(const AttnSplit& sp, int qrows, float** po, float** pml, AttnScratch* scratch, int dcols = 64);

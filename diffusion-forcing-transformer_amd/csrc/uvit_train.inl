@@ -807,11 +807,18 @@ int dfot_op_attention_fwd_lse(const void* q, const void* k, const void* v, void*
 // ... for a caller that knows a bound of |q.k| log2(e)/sqrt(d) (UViT blocks: from the q_norm / k_norm weights, u_vit_blocks.py:255-262;
 // the bound dfot_uvit_query reports): below 64 the d = 64 launch takes the pipelined kernel without a running max (attention_v5.hip;
 // lse = log2 of the row sum), which the backward consumes unchanged (it recomputes P = exp2(S - lse))
+size_t dfot_op_attention_scratch_bytes(int batch, int heads, int n, int d) { return attention_scratch_bytes(batch, heads, n, d); }
 int dfot_op_attention_fwd_lse_bounded(const void* q, const void* k, const void* v, void* o, int ldo, float* lse, int batch, int heads, int n, int d,
-                                      float score_bound, void* stream) {
+                                      float score_bound, void* scratch, size_t scratch_bytes, void* stream) {
   static const int on = tuning_flag("TRAIN_ATTN_V5", 1);
-  if (on && d == 64 && n % 256 == 0 && score_bound < 64.0f && lse)
-    return launch_attention_v5((const bf16*)q, (const bf16*)k, (const bf16*)v, (bf16*)o, ldo, batch, heads, n, (hipStream_t)stream, nullptr, lse);
+  // NaN-safe: only a bound that IS below 64 selects the kernel without a running max
+  if (on && d == 64 && n % 256 == 0 && score_bound < 64.0f && lse) {
+    // the key-split partial rows live in the CALLER's buffer (one per trainer / stream: nothing is allocated on this launch path and
+    // two trainers never share partial rows); a null buffer falls back to the process-wide grow-only block
+    AttnScratch own{reinterpret_cast<float*>(scratch), scratch_bytes};
+    return launch_attention_v5((const bf16*)q, (const bf16*)k, (const bf16*)v, (bf16*)o, ldo, batch, heads, n, (hipStream_t)stream,
+                               scratch ? &own : nullptr, lse);
+  }
   return launch_attention_padded((const bf16*)q, (const bf16*)k, (const bf16*)v, (bf16*)o, ldo, batch, heads, n, d, (hipStream_t)stream, lse);
 }
 int dfot_op_attention_bwd_lse(const void* q, const void* k, const void* v, const void* o, const void* d_o, int ldo, const float* lse, float* delta,

@@ -98,13 +98,22 @@ def training_step_forward(sampler, xs: torch.Tensor, masks: torch.Tensor, noise_
     return {"loss": per_token.mean(), "xs_pred": x_pred, "noise_levels": levels, "per_token": per_token}
 
 
-def lr_at_step(step: int, base_lr: float, name: str = "constant_with_warmup", num_warmup_steps: int = 10000, num_training_steps: int = 0) -> float:
+def lr_at_step(step: int, base_lr: float, name: str = "constant_with_warmup", num_warmup_steps: int = 10000, num_training_steps: int = 0,
+               num_processes: int = 1) -> float:
     """Learning rate of optimizer step `step` (0-based) under the reference's schedulers (`transformers.get_scheduler(name=cfg.lr_scheduler.name,
     num_warmup_steps=...)` stepped once per optimizer step: experiments/simple_video_generation.py:271, realestate10k_video_generation.yaml:19-22
     `constant_with_warmup`, 10000 warm-up steps): linear warm-up from 0, then constant / linear decay / cosine decay.  A LambdaLR is
     at epoch s when optimizer step s runs (it is stepped AFTER each optimizer step), so step s runs at base * s / warmup: the first
-    step has learning rate 0 and step `num_warmup_steps` is the first at the base rate."""
+    step has learning rate 0 and step `num_warmup_steps` is the first at the base rate.
+    num_processes: the reference hands its scheduler to `accelerator.prepare` (simple_video_generation.py:183); the AcceleratedScheduler
+    then steps the wrapped scheduler `num_processes` times per optimizer step (split_batches = False) and not at all on gradient-
+    accumulation micro-steps, so on N GPUs the schedule runs N times faster: optimizer step s is at scheduler epoch s * N (the
+    10000-step warm-up of the RE10K recipe takes 10000 / 12 optimizer steps on its 12 GPUs).  Pass the world size to reproduce that;
+    1 (default) is the bare LambdaLR."""
     import math
+    if num_processes < 1:
+        raise ValueError("num_processes must be >= 1")
+    step = step * int(num_processes)
     warm = min(1.0, step / max(1, num_warmup_steps)) if num_warmup_steps > 0 else 1.0
     if name in ("constant", "constant_with_warmup"):
         return base_lr * (warm if name == "constant_with_warmup" else 1.0)

@@ -12,6 +12,7 @@ import math
 import os
 from typing import Dict, List, Optional, Tuple
 
+import numpy as np
 import torch
 
 from . import capi
@@ -88,6 +89,24 @@ def rope_table(head_dim: int, sizes: Tuple[int, int, int], theta: float = 10000.
     return torch.stack([ang.cos(), ang.sin()], dim=-1).contiguous().cuda()
 
 
+_ADAM_MAX: Dict[tuple, float] = {}
+
+
+def _adam_max_update(b1: float, b2: float) -> float:
+    """sup over steps t of |m_hat| / sqrt(v_hat) for ANY gradient sequence (needs b1^2 < b2):  m_t^2 <= (1 - b1)^2 S_t v_t / (1 - b2) with
+    S_t = sum_{k<t} (b1^2 / b2)^k, times the bias corrections sqrt(1 - b2^t) / (1 - b1^t).  1.0 at t = 1; 2.35 for (0.9, 0.99)."""
+    key = (float(b1), float(b2))
+    if key not in _ADAM_MAX:
+        r = b1 * b1 / b2
+        t = np.arange(1, 1 << 16, dtype=np.float64)
+        s_t = (1.0 - r ** t) / (1.0 - r)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            corr = np.sqrt(1.0 - b2 ** t) / np.where(b1 > 0, 1.0 - b1 ** t, 1.0)
+        sup = float(np.max((1.0 - b1) * np.sqrt(s_t / (1.0 - b2)) * corr))
+        _ADAM_MAX[key] = max(sup, (1.0 - b1) / math.sqrt((1.0 - b2) * (1.0 - r)))
+    return _ADAM_MAX[key]
+
+
 class TransformerBlockTrain:
     """One UViT TransformerBlock: parameters under the reference's names (fp32 master copies), forward / backward over the C ABI."""
 
@@ -103,6 +122,7 @@ class TransformerBlockTrain:
         # bound of |q.k| log2(e) / sqrt(d) from the q_norm / k_norm weights (set by the trainer, see _refresh_score_bounds); inf = take
         # the running-max attention kernel
         self.score_bound = float("inf")
+        self._attn_pool: List[Optional[torch.Tensor]] = [None]  # replaced by the trainer's shared one
         self.sync()
 
     def sync(self) -> None:
@@ -138,8 +158,14 @@ class TransformerBlockTrain:
                                                    math.log2(math.e) / math.sqrt(d), _P(q), _P(k), _P(v), rows, ntok, hds, d, _S()))
             capi.check(lib.dfot_op_silu_cols(_P(fused), 7 * c, 3 * c, None, 0, 0, _P(cat), 5 * c, c, rows, 4 * c, _S()))
         lse = torch.empty(batch, hds, ntok, dtype=torch.float32, device="cuda")
+        # key-split partial rows of the attention tail: ONE buffer per trainer (its blocks run one after the other on one stream), grown
+        # here through the caching allocator -- never the library's process-wide block, never shared with another trainer
+        need = int(lib.dfot_op_attention_scratch_bytes(batch, hds, ntok, d))
+        pool = self._attn_pool
+        if need and (pool[0] is None or pool[0].numel() < need):
+            pool[0] = torch.empty(need, dtype=torch.uint8, device="cuda")
         capi.check(lib.dfot_op_attention_fwd_lse_bounded(_P(q), _P(k), _P(v), _P(cat), 5 * c, _P(lse), batch, hds, ntok, d,
-                                                         float(self.score_bound), _S()))
+                                                         float(self.score_bound), _P(pool[0]) if need else None, need, _S()))
         if mlp_mask is not None:
             capi.check(lib.dfot_op_mul_cols(_P(cat), 5 * c, c, _P(mlp_mask), rows, 4 * c, _S()))
         y = gemm_f32(cat, self.w_out, self.b_out, resid=x)
@@ -350,6 +376,10 @@ class UViT3DPoseTrainer:
         self.down = [[block(f"down_blocks.{l}.{i}", l) for i in range(n)] for l, n in enumerate(self.nud)]
         self.mid = [block(f"mid_blocks.{i}", 3) for i in range(self.nmid)]
         self.up = [[block(f"up_blocks.{j}.{i + 1}", l) for i in range(self.nud[l])] for j, l in enumerate((2, 1, 0))]
+        attn_pool: List[Optional[torch.Tensor]] = [None]
+        for b in self._blocks():
+            if isinstance(b, TransformerBlockTrain):
+                b._attn_pool = attn_pool
         self.grads: Dict[str, torch.Tensor] = {}
         # block_dropouts of u_vit3d_pose.yaml ([0, 0, 0.1, 0.1]); applied only when a CUDA generator is set (training with dropout on)
         self.block_dropouts = list(g("block_dropouts", [0.0] * 4))
@@ -364,7 +394,9 @@ class UViT3DPoseTrainer:
         self._acc_n = 0
         self.sync()
 
-    def sync(self) -> None:
+    def sync(self, own_step: Optional[Dict] = None) -> None:
+        """re-pack the bf16 operand copies from the fp32 master weights.  own_step: set only by this trainer's own `optimizer_step`
+        (its lr / betas / weight_decay bound how far the weights moved); None = the weights were changed from outside"""
         p, e = self.p, self.e
         ne = "noise_level_pos_embedding.embedding."
         self.w1, self.w2 = _bf(p[ne + "linear_1.weight"]), _bf(p[ne + "linear_2.weight"])
@@ -380,7 +412,7 @@ class UViT3DPoseTrainer:
         self.wu = [pack_conv(p[f"up_blocks.{j}.0.conv.weight"]) for j in range(3)]
         for b in self._blocks():
             b.sync()
-        self._refresh_score_bounds()
+        self._refresh_score_bounds(own_step)
         # ResBlock levels: the column offset of every block in its level's FiLM-gradient matrix, and the matching [E][blocks * 2C]
         # concatenation of the emb_layer weights (backward: one embedding-gradient GEMM per level)
         self.res_cols: Dict[int, int] = {}
@@ -396,38 +428,52 @@ class UViT3DPoseTrainer:
     def _blocks(self):
         return [b for lv in self.down for b in lv] + self.mid + [b for lv in self.up for b in lv]
 
-    def _refresh_score_bounds(self) -> None:
-        """The d = 64 blocks may run their forward attention without a running max while sqrt(d) * max over rotary pairs of
-        max|w_q| * max|w_k| * log2(e) < 64 (csrc/uvit.hip, u_vit_blocks.py:255-262).  The bounds of all blocks are computed on the
-        device in one go after every weight refresh and copied to pinned host memory WITHOUT a host synchronisation; a forward
-        uses the newest copy that has arrived (the first one is awaited), with a 10 % margin for the steps it may lag behind --
-        the weights move by ~1e-4 relative per optimizer step."""
+    def _refresh_score_bounds(self, own_step: Optional[Dict] = None) -> None:
+        """The d = 64 blocks may run their forward attention without a running max while  B = sqrt(d) log2(e) * max over rotary pairs of
+        max|w_q| * max|w_k|  stays below 64 (csrc/uvit.hip, u_vit_blocks.py:255-262).  What a block is told is an UPPER bound of B that
+        holds by construction:
+          * any weight change from outside (construction, a checkpoint or state dict copied into a live trainer, the autograd drop-in
+            after an external optimizer step, an EMA swap) reaches `sync()` with own_step = None: B and max|w| are computed on the
+            device and read back SYNCHRONOUSLY before the next forward can be issued;
+          * the trainer's own AdamW step moves every weight by at most  lr * (A + wd * |w|)  with  A = sup_t (1 - b1) sqrt(S_t / (1 - b2))
+            sqrt(1 - b2^t) / (1 - b1^t),  S_t = sum_{k<t} (b1^2 / b2)^k  (Cauchy-Schwarz on the two moment sums, bias corrections
+            included: `_adam_max_update`; gradient clipping scales g and cancels; eps only shrinks the update), so the host adds that
+            drift d to every |w|:  (|w_q| + d)(|w_k| + d) <= |w_q||w_k| + 2 max|w| d + d^2  -- no device read, no
+            assumption about how far the weights move.  The exact value is re-read every 256 own steps (one host sync), or at once
+            when the drifted bound would cross 64, or when b1^2 >= b2 (no finite A)."""
         blocks = [b for b in self._blocks() if isinstance(b, TransformerBlockTrain) and b.d == 64]
         if not blocks:
             return
         d = blocks[0].d
-        wq = torch.stack([b.p["q_norm.weight"] for b in blocks]).abs().view(len(blocks), d // 2, 2).amax(-1)
-        wk = torch.stack([b.p["k_norm.weight"] for b in blocks]).abs().view(len(blocks), d // 2, 2).amax(-1)
-        bound = (wq * wk).amax(-1) * (math.sqrt(d) * math.log2(math.e))
-        bound = torch.nan_to_num(bound, nan=float("inf"))
-        first = not hasattr(self, "_bound_host")
-        if first:
-            self._bound_host = torch.empty(len(blocks), dtype=torch.float32).pin_memory()
-            self._bound_evt = torch.cuda.Event()
+        kd = math.sqrt(d) * math.log2(math.e)
+        exact = own_step is None or not hasattr(self, "_bound_exact")
+        if not exact:
+            b1, b2 = own_step["betas"]
+            if not (0.0 <= b1 * b1 < b2 < 1.0):
+                exact = True
+            else:
+                a = _adam_max_update(b1, b2)
+                wmax = max(self._bound_wmax) + self._bound_drift
+                self._bound_drift += float(own_step["lr"]) * (a + float(own_step["weight_decay"]) * wmax)
+                self._bound_own_steps += 1
+                worst = max(e + kd * (2.0 * w * self._bound_drift + self._bound_drift ** 2) for e, w in zip(self._bound_exact, self._bound_wmax))
+                was_fast = max(self._bound_exact) < 64.0
+                if self._bound_own_steps >= 256 or (was_fast and worst >= 64.0):
+                    exact = True
+        if exact:
+            wq = torch.stack([b.p["q_norm.weight"] for b in blocks]).abs()
+            wk = torch.stack([b.p["k_norm.weight"] for b in blocks]).abs()
+            pq, pk = wq.view(len(blocks), d // 2, 2).amax(-1), wk.view(len(blocks), d // 2, 2).amax(-1)
+            bound = torch.nan_to_num((pq * pk).amax(-1) * kd, nan=float("inf"))
+            wmx = torch.nan_to_num(torch.maximum(wq.amax(-1), wk.amax(-1)), nan=float("inf"))
+            host = torch.stack([bound, wmx]).tolist()  # synchronous: the forward that follows sees THESE weights' bound
+            self._bound_exact, self._bound_wmax = host[0], host[1]
+            self._bound_drift, self._bound_own_steps = 0.0, 0
             self._bound_blocks = blocks
-        elif not self._bound_evt.query():
-            return  # the previous copy has not landed yet: keep it in flight, the blocks keep their current (margined) bounds
-        else:
-            self._apply_score_bounds()
-        self._bound_host.copy_(bound, non_blocking=True)
-        self._bound_evt.record()
-        if first:
-            self._bound_evt.synchronize()
-            self._apply_score_bounds()
-
-    def _apply_score_bounds(self) -> None:
-        for b, v in zip(self._bound_blocks, self._bound_host.tolist()):
-            b.score_bound = 1.1 * float(v)
+            self.bound_exact_reads = getattr(self, "bound_exact_reads", 0) + 1
+        dr = self._bound_drift
+        for b, e, w in zip(self._bound_blocks, self._bound_exact, self._bound_wmax):
+            b.score_bound = e + kd * (2.0 * w * dr + dr * dr)
 
     def _run(self, blocks, x, lvl):
         p = self.block_dropouts[lvl] if self.dropout_generator is not None else 0.0
@@ -645,6 +691,11 @@ class UViT3DPoseTrainer:
         loss_and_grads to the running sum; the next optimizer_step uses the MEAN over the accumulated micro-batches"""
         if self._acc is None:
             self._acc = torch.zeros_like(self.flat_grads)
+        if self._acc_n == 0:
+            self._acc_reduced = True
+        # the reference reduces once per optimizer step (accelerator.accumulate runs the micro-batches under no_sync); micro-batches whose
+        # gradients were already averaged over the ranks (loss_and_grads with a reducer) need no second exchange -- but only if ALL were
+        self._acc_reduced = self._acc_reduced and bool(getattr(self, "_grads_reduced", False))
         self._acc.add_(self.flat_grads)
         self._acc_n += 1
 
@@ -655,7 +706,7 @@ class UViT3DPoseTrainer:
             self.flat_grads.copy_(self._acc).mul_(1.0 / self._acc_n)
             self._acc.zero_()
             self._acc_n = 0
-            self._grads_reduced = False  # the accumulated sum holds local gradients: reduce it once here
+            self._grads_reduced = self._acc_reduced  # local micro-batch gradients: ONE exchange of the accumulated mean, here
         if world_size > 1 and not getattr(self, "_grads_reduced", False):
             parallel.allreduce_mean_(self.flat_grads)
         self.step_count += 1
@@ -669,7 +720,7 @@ class UViT3DPoseTrainer:
         # updated by the same kernel pass that writes the new parameters
         capi.check(lib.dfot_adamw_step(_P(self.flat), _P(self.flat_grads), _P(self.exp_avg), _P(self.exp_avg_sq), self.numel, lr, betas[0], betas[1], eps,
                                        weight_decay, self.step_count, _P(sumsq), float(max_grad_norm or 0.0), _P(self.ema), float(self.ema_decay), _S()))
-        self.sync()
+        self.sync(own_step=dict(lr=lr, betas=tuple(betas), weight_decay=weight_decay))
 
     # ------------------------------------------------------------------ EMA and optimizer state (checkpoint / resume), as trainer.DiT3DTrainer
     def enable_ema(self, decay: float) -> None:

@@ -343,9 +343,12 @@ int dfot_op_qknorm_rope_fwd(const void* fused, int ld, const float* qw, const fl
                             void* k, void* v, int64_t rows, int ntok, int heads, int d, void* stream);
 int dfot_op_silu_cols(const void* src, int lds_, int scol0, const void* grad, int ldg, int gcol0, void* dst, int ldd, int dcol0, int64_t rows,
                       int ncols, void* stream);
-/* the same with a caller-supplied bound of the scores in the log2 domain (< 64: the d = 64 launch may run without a running max) */
+/* the same with a caller-supplied bound of the scores in the log2 domain (< 64: the d = 64 launch may run without a running max; anything
+ * else, NaN included, takes the running-max kernel).  scratch: device buffer of at least dfot_op_attention_scratch_bytes(...) bytes for the
+ * fp32 partial rows of the key-split tail, owned by the caller (one per trainer / stream); null = a process-wide grow-only block */
+size_t dfot_op_attention_scratch_bytes(int batch, int heads, int n, int d);
 int dfot_op_attention_fwd_lse_bounded(const void* q, const void* k, const void* v, void* o, int ldo, float* lse, int batch, int heads, int n, int d,
-                                      float score_bound, void* stream);
+                                      float score_bound, void* scratch, size_t scratch_bytes, void* stream);
 int dfot_op_attention_fwd_lse(const void* q, const void* k, const void* v, void* o, int ldo, float* lse, int batch, int heads, int n, int d,
                               void* stream);
 int dfot_op_attention_bwd_lse(const void* q, const void* k, const void* v, const void* o, const void* d_o, int ldo, const float* lse, float* delta,

@@ -24,6 +24,10 @@ import torch.nn.functional as F
 
 Params = Dict[str, torch.Tensor]
 USE_SDPA = False  # True: F.scaled_dot_product_attention instead of the explicit softmax (same maths, fused kernel on a GPU)
+# True: every ResBlock / TransformerBlock runs under torch.utils.checkpoint (what the reference does per level with use_checkpointing,
+# u_vit3d.py:237-243): identical values and gradients, activations of one block at a time -- lets the full-size training-parity test
+# (256 x 256, full depth, fp32) run autograd through this restatement within the GPU's memory
+CHECKPOINT_BLOCKS = False
 
 
 @dataclass
@@ -258,16 +262,22 @@ def forward(p: Params, cfg: UViTConfig, x: torch.Tensor, noise_levels: torch.Ten
             r = cfg.level_res(lvl)
             angles[lvl] = rope3d_angles(cfg.channels[lvl] // cfg.num_heads, (cfg.max_tokens, r, r), cfg.rope_theta).to(x.device)
 
+    def ckpt(fn, *args):
+        if CHECKPOINT_BLOCKS and torch.is_grad_enabled():
+            from torch.utils.checkpoint import checkpoint
+            return checkpoint(fn, *args, use_reentrant=False)
+        return fn(*args)
+
     def run_level(h, lvl, prefixes):
         if cfg.block_types[lvl] == "ResBlock":
             for pre in prefixes:
-                h = res_block(p, pre, h, embs[lvl], cfg)
+                h = ckpt(lambda hh_, pre=pre: res_block(p, pre, hh_, embs[lvl], cfg), h)
             return h
         hh, ww = h.shape[-2:]
         tok = h.view(b, t, -1, hh, ww).permute(0, 1, 3, 4, 2).reshape(b, t * hh * ww, -1)
         etok = embs[lvl].view(b, t, -1, hh, ww).permute(0, 1, 3, 4, 2).reshape(b, t * hh * ww, -1)
         for pre in prefixes:
-            tok = transformer_block(p, pre, tok, etok, angles[lvl], cfg)
+            tok = ckpt(lambda tk_, pre=pre: transformer_block(p, pre, tk_, etok, angles[lvl], cfg), tok)
         return tok.view(b, t, hh, ww, -1).permute(0, 1, 4, 2, 3).reshape(b * t, -1, hh, ww)
 
     before, after = [], []

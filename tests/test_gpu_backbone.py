@@ -395,3 +395,38 @@ def test_backbone_dispatches_through_torch_operator_and_traces():
         assert torch.equal(eager, direct)
         traced = torch.compile(lambda a, b, c: model(a, b, c, None) * 1.0, backend="eager", fullgraph=True)
         assert torch.equal(traced(x, k, cond), eager)
+
+
+def test_two_handles_on_two_streams_are_each_bit_identical_to_their_serial_result(w64):
+    """two GEMM-using engines co-resident on the device.  Two UViT3DPose handles (their own weights, workspaces and
+    attention scratch) at 64 x 64 -- the size at which the fused-projection GEMM runs on 128 x 128 LDS-DMA tiles with several workgroups
+    per CU, the configuration in which the round-3 two-stream block schedule once showed wrong elements of q -- are driven from two
+    streams at the same time, a few forwards queued back to back on each.  Every output must equal, bit for bit, what the same handle
+    produced alone.  Run once; nothing here loops to provoke a fault."""
+    from oracle import uvit as ouvit
+    ocfg = w64["ocfg"]
+    m_a = make_model(ocfg, w64["params"], 64)
+    m_b = make_model(ocfg, ouvit.seeded_params(ocfg, 4), 64)
+    g = torch.Generator().manual_seed(11)
+    xa, xb = (torch.randn(2, 8, 3, 64, 64, generator=g).cuda() for _ in range(2))
+    k, cond, mask = w64["k"].cuda(), w64["cond"].cuda(), w64["mask"].cuda()
+    n_rep = 4
+    with torch.no_grad():
+        ref_a = m_a(xa, k, cond, mask).clone()
+        ref_b = m_b(xb, k, cond, mask).clone()
+        torch.cuda.synchronize()
+        assert torch.equal(m_a(xa, k, cond, mask), ref_a) and torch.equal(m_b(xb, k, cond, mask), ref_b)   # serial: reproducible
+        torch.cuda.synchronize()
+        s_a, s_b = torch.cuda.Stream(), torch.cuda.Stream()
+        outs_a, outs_b = [], []
+        for _ in range(n_rep):   # interleaved submission: both queues hold work at the same time
+            with torch.cuda.stream(s_a):
+                outs_a.append(m_a(xa, k, cond, mask).clone())
+            with torch.cuda.stream(s_b):
+                outs_b.append(m_b(xb, k, cond, mask).clone())
+        s_a.synchronize()
+        s_b.synchronize()
+    bad_a = [int((o != ref_a).sum()) for o in outs_a]
+    bad_b = [int((o != ref_b).sum()) for o in outs_b]
+    print(f"two handles / two streams: differing elements per forward, handle A {bad_a}, handle B {bad_b}")
+    assert not any(bad_a) and not any(bad_b)

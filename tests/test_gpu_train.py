@@ -1070,3 +1070,271 @@ def test_uvit3d_pose_input_gradient_matches_fp32_autograd():
     rel = ((xe.grad.cpu() - xr.grad).norm() / xr.grad.norm()).item()
     print(f"d loss / d x: rel-L2 {rel:.3e}")
     assert torch.isfinite(xe.grad).all() and rel < 3e-2
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------
+# round 4: the trainer's choice of the no-running-max attention kernel is safe by construction
+
+def _attn_fwd_lse_bounded(q, k, v, bound, own_scratch=True):
+    """q pre-scaled [B][H][N][64] bf16 -> (o [B][N][H*64] bf16, lse [B][H][N] fp32 log2-domain) through dfot_op_attention_fwd_lse_bounded"""
+    from dfot_amd import capi
+    b, h, n, d = q.shape
+    o = torch.empty(b, n, h * d, dtype=torch.bfloat16, device="cuda")
+    lse = torch.empty(b, h, n, dtype=torch.float32, device="cuda")
+    need = int(capi.lib.dfot_op_attention_scratch_bytes(b, h, n, d)) if own_scratch else 0
+    scratch = torch.empty(max(need, 1), dtype=torch.uint8, device="cuda") if need else None
+    capi.check(capi.lib.dfot_op_attention_fwd_lse_bounded(capi.ptr(q), capi.ptr(k), capi.ptr(v), capi.ptr(o), h * d, capi.ptr(lse), b, h, n, d,
+                                                          float(bound), capi.ptr(scratch), need, capi.stream_ptr()))
+    torch.cuda.synchronize()
+    return o, lse
+
+
+@pytest.mark.parametrize("bound", [80.0, float("inf"), float("nan")])
+def test_bounded_attention_forward_beyond_the_bound_is_exact_and_feeds_the_backward(bound):
+    """scores far beyond the no-running-max range (|s| up to ~100 in the log2 domain: exp2 without a maximum overflows fp32 row sums):
+    a caller that says so (bound >= 64, inf, or NaN) gets the running-max kernel -- output and log-sum-exp equal the fp64 softmax, and
+    dfot_op_attention_bwd_lse on that lse gives autograd's dq / dk / dv."""
+    from dfot_amd import capi
+    b, h, n, d = 2, 3, 512, 64
+    g = torch.Generator().manual_seed(7)
+    scale = math.log2(math.e) / math.sqrt(d)
+    q = (4.0 * torch.randn(b, h, n, d, generator=g))
+    k = (4.0 * torch.randn(b, h, n, d, generator=g))
+    v = torch.randn(b, h, n, d, generator=g)
+    do = torch.randn(b, n, h * d, generator=g)
+    bf = lambda t: t.to(torch.bfloat16)
+    qs, kb, vb = bf(q * scale).cuda(), bf(k).cuda(), bf(v).cuda()
+    s2 = qs.double() @ kb.double().transpose(-1, -2)           # log2-domain scores
+    assert float(s2.abs().max()) > 70.0                         # beyond what exp2 without a running max can sum
+    o, lse = _attn_fwd_lse_bounded(qs, kb, vb, bound)
+    ref_lse = torch.logsumexp(s2 * math.log(2.0), -1) / math.log(2.0)
+    ref_o = (torch.softmax(s2 * math.log(2.0), -1) @ vb.double()).transpose(1, 2).reshape(b, n, h * d)
+    assert torch.isfinite(o.float()).all() and torch.isfinite(lse).all()
+    assert rel(o.float(), ref_o) < 1.5e-2 and float((lse.double() - ref_lse).abs().max()) < 2e-2
+    # backward from that lse
+    dod = bf(do).cuda().contiguous()
+    delta = torch.empty(b, h, n, dtype=torch.float32, device="cuda")
+    dq, dk, dv = (torch.full((b, h, n, d), float("nan"), dtype=torch.bfloat16, device="cuda") for _ in range(3))
+    capi.check(capi.lib.dfot_op_attention_bwd_lse(capi.ptr(qs), capi.ptr(kb), capi.ptr(vb), capi.ptr(o), capi.ptr(dod), h * d, capi.ptr(lse),
+                                                  capi.ptr(delta), capi.ptr(dq), capi.ptr(dk), capi.ptr(dv), b, h, n, d, capi.stream_ptr()))
+    torch.cuda.synchronize()
+    qr = (qs.float() / scale).requires_grad_()
+    kr, vr = kb.float().requires_grad_(), vb.float().requires_grad_()
+    ref = (torch.softmax(qr @ kr.transpose(-1, -2) / math.sqrt(d), -1) @ vr).transpose(1, 2).reshape(b, n, h * d)
+    ref.backward(dod.float())
+    for name, got, want in (("dq", dq, qr.grad), ("dk", dk, kr.grad), ("dv", dv, vr.grad)):
+        r = rel(got.float(), want)
+        print(f"bounded attention (bound {bound}) {name}: rel {r:.2e}")
+        assert torch.isfinite(got.float()).all() and r < 2.5e-2, (name, r)
+
+
+def test_bounded_attention_below_the_bound_takes_the_fast_kernel_with_caller_scratch():
+    """ordinary QK-normed scores (|s| < 64): the pipelined no-running-max kernel, its key-split partial rows in the CALLER's buffer
+    (nothing allocated on the launch path, nothing shared between trainers); same result with the library's own block"""
+    b, h, n, d = 2, 9, 1024, 64   # 72 query tiles of 256 rows on 512 slots: the tail is split over the keys -> partial rows are used
+    g = torch.Generator().manual_seed(9)
+    scale = math.log2(math.e) / math.sqrt(d)
+    nrm = lambda t: t / t.pow(2).mean(-1, keepdim=True).sqrt()
+    q, k = nrm(torch.randn(b, h, n, d, generator=g)), nrm(torch.randn(b, h, n, d, generator=g))
+    v = torch.randn(b, h, n, d, generator=g)
+    qs, kb, vb = (q * scale).to(torch.bfloat16).cuda(), k.to(torch.bfloat16).cuda(), v.to(torch.bfloat16).cuda()
+    s2 = qs.double() @ kb.double().transpose(-1, -2)
+    o, lse = _attn_fwd_lse_bounded(qs, kb, vb, 13.0, own_scratch=True)
+    o2, lse2 = _attn_fwd_lse_bounded(qs, kb, vb, 13.0, own_scratch=False)
+    ref_o = (torch.softmax(s2 * math.log(2.0), -1) @ vb.double()).transpose(1, 2).reshape(b, n, h * d)
+    ref_lse = torch.logsumexp(s2 * math.log(2.0), -1) / math.log(2.0)
+    assert rel(o.float(), ref_o) < 1.5e-2 and float((lse.double() - ref_lse).abs().max()) < 2e-2
+    assert torch.equal(o, o2) and torch.equal(lse, lse2)
+
+
+def _re10k_width_trainer(seed=21):
+    from dfot_amd import uvit_train as ut
+    from oracle import pose as opose, uvit as ouvit
+    cfg = ouvit.UViTConfig(num_updown_blocks=(1, 1, 1), num_mid_blocks=1, resolution=64)   # RE10K widths: level 2 has d = 64
+    params = ouvit.seeded_params(cfg, seed=seed)
+    g = torch.Generator().manual_seed(seed + 1)
+    x = torch.randn(1, 8, 3, 64, 64, generator=g)
+    k = torch.randn(1, 8, generator=g)
+    pz = torch.eye(3, 4).reshape(1, 1, 12).repeat(1, 8, 1)
+    pz[..., 3] = torch.linspace(0, 0.4, 8)
+    cond = opose.ray_encoding(torch.cat([torch.tensor([0.5, 0.9, 0.5, 0.5]).repeat(1, 8, 1), pz], -1), 64)
+    tcfg = dict(channels=cfg.channels, emb_channels=cfg.emb_channels, patch_size=2, block_types=cfg.block_types, num_updown_blocks=cfg.num_updown_blocks,
+                num_mid_blocks=cfg.num_mid_blocks, num_heads=cfg.num_heads, resolution=64, max_tokens=8)
+    return ut, ouvit, cfg, params, tcfg, x, k, cond
+
+
+def _true_bound(blk):
+    d = blk.d
+    wq, wk = (blk.p[n].abs().view(d // 2, 2).amax(-1) for n in ("q_norm.weight", "k_norm.weight"))
+    return float((wq * wk).max()) * math.sqrt(d) * math.log2(math.e)
+
+
+def test_trainer_score_bound_follows_an_external_weight_change_at_once():
+    """q_norm / k_norm weights replaced x4 in a LIVE trainer (what a checkpoint load or the autograd drop-in
+    after load_state_dict does: copy into trainer.p, then sync()).  The bound the blocks hold must be the NEW weights' bound before the
+    next forward is issued (>= 64 here: running-max kernel), and that forward must match the oracle on the new weights."""
+    ut, ouvit, cfg, params, tcfg, x, k, cond = _re10k_width_trainer()
+    tr = ut.UViT3DPoseTrainer(params, tcfg)
+    d64 = [b for b in tr._blocks() if isinstance(b, ut.TransformerBlockTrain) and b.d == 64]
+    assert d64 and all(b.score_bound < 64 and b.score_bound >= _true_bound(b) for b in d64)
+    out0 = tr.forward(x, k, cond).cpu()
+    assert rel(out0, ouvit.forward(params, cfg, x, k, cond)) < 2e-2
+    new = {n: (t * 4.0 if n.endswith(("q_norm.weight", "k_norm.weight")) else t.clone()) for n, t in params.items()}
+    with torch.no_grad():
+        for n, t in new.items():
+            tr.p[n].copy_(t)
+    tr.sync()                                   # external change: exact bound, read back synchronously
+    assert all(b.score_bound >= 64 and b.score_bound >= _true_bound(b) for b in d64), [b.score_bound for b in d64]
+    out1 = tr.forward(x, k, cond).cpu()
+    ref1 = ouvit.forward(new, cfg, x, k, cond)
+    r = rel(out1, ref1)
+    print(f"trainer forward right after a x4 q/k-norm change: rel-L2 {r:.2e} (bound {d64[0].score_bound:.1f})")
+    assert torch.isfinite(out1).all() and r < 2e-2
+    # ... and the backward that follows consumes the running-max kernel's lse
+    grads = tr.backward(torch.randn(1, 8, 3, 64, 64, generator=torch.Generator().manual_seed(3)))
+    assert all(torch.isfinite(gr).all() for gr in grads.values())
+
+
+def test_trainer_score_bound_is_an_upper_bound_through_its_own_optimizer_steps():
+    """the trainer's own AdamW steps never read the device: the host adds the largest move an Adam step can make to every |w|.  After a few
+    deliberately LARGE steps (lr 2e-2) the bound each block holds is still >= the true bound of its current weights, with no exact read
+    in between; the periodic exact read resets the drift."""
+    ut, ouvit, cfg, params, tcfg, x, k, cond = _re10k_width_trainer(seed=31)
+    tr = ut.UViT3DPoseTrainer(params, tcfg)
+    d64 = [b for b in tr._blocks() if isinstance(b, ut.TransformerBlockTrain) and b.d == 64]
+    reads0 = tr.bound_exact_reads
+    g = torch.Generator().manual_seed(5)
+    for step in range(4):
+        tr.forward(x, k, cond)
+        tr.backward(torch.randn(1, 8, 3, 64, 64, generator=g))
+        tr.optimizer_step(lr=2e-2, betas=(0.9, 0.99), weight_decay=0.01, max_grad_norm=1.0)
+        for b in d64:
+            true = _true_bound(b)
+            assert b.score_bound >= true, (step, b.score_bound, true)
+    assert tr.bound_exact_reads == reads0 and tr._bound_drift > 0     # no device read on the trainer's own steps
+    tr.sync()                                                           # an external sync re-reads exactly
+    assert tr.bound_exact_reads == reads0 + 1 and tr._bound_drift == 0.0
+    assert all(abs(b.score_bound - _true_bound(b)) < 1e-3 * b.score_bound for b in d64)
+
+
+def test_drop_in_forward_after_load_state_dict_uses_the_new_weights_bound():
+    """one training forward on the initial weights, then load_state_dict with q/k-norm weights x4 (bound >= 64), then
+    the next training forward: it must run the running-max kernel (finite, oracle-matching), not the stale fast choice."""
+    import dfot_amd
+    ut, ouvit, cfg, params, tcfg, x, k, cond = _re10k_width_trainer(seed=41)
+    bcfg = dict(channels=list(cfg.channels), emb_channels=cfg.emb_channels, patch_size=2, block_types=list(cfg.block_types),
+                num_updown_blocks=list(cfg.num_updown_blocks), num_mid_blocks=cfg.num_mid_blocks, num_heads=cfg.num_heads, pos_emb_type="rope",
+                use_fourier_noise_embedding=True, conditioning=dict(dim=180))
+    model = dfot_amd.UViT3DPose(bcfg, x_shape=(3, 64, 64), max_tokens=8).cuda()
+    model.load_state_dict(params, strict=True)
+    model.train()
+    xd, kd, cd = x.cuda(), k.cuda(), cond.cuda()
+    v0 = model(xd, kd, cd)
+    v0.sum().backward()
+    new = {n: (t * 4.0 if n.endswith(("q_norm.weight", "k_norm.weight")) else t.clone()) for n, t in params.items()}
+    model.load_state_dict(new, strict=True)
+    v1 = model(xd, kd, cd)
+    d64 = [b for b in model._trainer._blocks() if isinstance(b, ut.TransformerBlockTrain) and b.d == 64]
+    assert all(b.score_bound >= 64 for b in d64)
+    r = rel(v1.detach().cpu(), ouvit.forward(new, cfg, x, k, cond))
+    print(f"drop-in forward after load_state_dict (q/k-norm x4): rel-L2 {r:.2e}")
+    assert torch.isfinite(v1).all() and r < 2e-2
+    v1.sum().backward()
+    assert all(torch.isfinite(p.grad).all() for p in model.parameters())
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------
+# round 4: BASELINE config 5 pinned at (nearly) its real size (VERDICT r3 weak #1, next #4)
+
+@pytest.mark.timeout(900)
+def test_attention_backward_at_the_level2_launch_shape_of_config5():
+    """dfot_op_attention_fwd_lse_bounded + dfot_op_attention_bwd_lse at (B * H, N, d) = (72, 8192, 64): the launch shape of the level-2
+    blocks in the 8 videos x 8 frames x 256 x 256 training step (attn_bwd_dkv_kernel<64,64,64> / attn_bwd_dq_kernel over 128-key tiles x 72
+    head-batches, the forward's key-split tail).  Reference: fp32 softmax attention under autograd on the GPU, one (video, head) at a
+    time (a 8192 x 8192 fp32 score matrix each) on the same bf16-rounded operands."""
+    from dfot_amd import capi
+    b, h, n, d = 8, 9, 8192, 64
+    g = torch.Generator(device="cuda").manual_seed(17)
+    scale = math.log2(math.e) / math.sqrt(d)
+    nrm = lambda t: t / t.pow(2).mean(-1, keepdim=True).sqrt()
+    q = nrm(torch.randn(b, h, n, d, device="cuda", generator=g)) * (1 + 0.1 * torch.randn(d, device="cuda", generator=g))
+    k = nrm(torch.randn(b, h, n, d, device="cuda", generator=g)) * (1 + 0.1 * torch.randn(d, device="cuda", generator=g))
+    v = torch.randn(b, h, n, d, device="cuda", generator=g)
+    do = torch.randn(b, n, h * d, device="cuda", generator=g).to(torch.bfloat16)
+    qs, kb, vb = (q * scale).to(torch.bfloat16), k.to(torch.bfloat16), v.to(torch.bfloat16)
+    o, lse = _attn_fwd_lse_bounded(qs, kb, vb, 20.0)
+    delta = torch.empty(b, h, n, dtype=torch.float32, device="cuda")
+    dq, dk, dv = (torch.full((b, h, n, d), float("nan"), dtype=torch.bfloat16, device="cuda") for _ in range(3))
+    capi.check(capi.lib.dfot_op_attention_bwd_lse(capi.ptr(qs), capi.ptr(kb), capi.ptr(vb), capi.ptr(o), capi.ptr(do), h * d, capi.ptr(lse),
+                                                  capi.ptr(delta), capi.ptr(dq), capi.ptr(dk), capi.ptr(dv), b, h, n, d, capi.stream_ptr()))
+    torch.cuda.synchronize()
+    num = {x: 0.0 for x in ("o", "dq", "dk", "dv", "lse")}
+    den = dict(num)
+    dov = do.float().view(b, n, h, d)
+    for bi in range(b):
+        for hi in range(h):
+            qr = (qs[bi, hi].float() / scale).requires_grad_()
+            kr, vr = kb[bi, hi].float().requires_grad_(), vb[bi, hi].float().requires_grad_()
+            s = qr @ kr.t() / math.sqrt(d)
+            ref = torch.softmax(s, -1) @ vr
+            ref.backward(dov[bi, :, hi])
+            ref_lse = torch.logsumexp(s.detach().double(), -1) / math.log(2.0)
+            for name, got, want in (("o", o.view(b, n, h, d)[bi, :, hi], ref.detach()), ("dq", dq[bi, hi], qr.grad), ("dk", dk[bi, hi], kr.grad),
+                                    ("dv", dv[bi, hi], vr.grad), ("lse", lse[bi, hi], ref_lse)):
+                num[name] += float((got.double() - want.double()).pow(2).sum())
+                den[name] += float(want.double().pow(2).sum())
+            del s, ref, qr, kr, vr
+    rs = {x: math.sqrt(num[x] / den[x]) for x in num}
+    print("attention fwd/bwd at (72, 8192, 64): rel-L2 " + ", ".join(f"{x} {r:.2e}" for x, r in rs.items()))
+    assert all(torch.isfinite(t.float()).all() for t in (o, dq, dk, dv))
+    assert rs["o"] < 1.5e-2 and rs["lse"] < 1e-3 and max(rs["dq"], rs["dk"], rs["dv"]) < 2e-2, rs
+
+
+@pytest.mark.timeout(1800)
+def test_uvit3d_pose_training_step_at_config5_frame_size_full_depth():
+    """BASELINE config 5 nearer its real size (continuous_diffusion.py:140-167, realestate10k_video_generation.yaml:44,49-51): the RE10K
+    model at FULL depth (3+3+6 / 20 blocks), 256 x 256 frames, 8 frames, batch 2 -- every kernel of the training step at its production
+    launch geometry per video (level-0 GroupNorm over 16384-pixel images, 113-slice convolution weight gradients, N = 8192 attention
+    backward) -- with level-3 checkpointing as in the recipe.  Engine loss and every parameter gradient vs torch autograd through
+    oracle.uvit in fp32 ON THE GPU (fused SDPA, every block under torch.utils.checkpoint so that it fits).  Bars: loss 1e-2 relative;
+    gradients worst <= 6e-2, median <= 2e-2 relative L2 (bf16 activations through 38 residual blocks; printed)."""
+    from dfot_amd import uvit_train as ut
+    from oracle import pose as opose, sampler as osm, uvit as ouvit
+    res, batch = 256, 2
+    cfg = ouvit.UViTConfig(resolution=res)   # defaults = the RE10K model
+    assert tuple(cfg.channels) == (128, 256, 576, 1152) and tuple(cfg.num_updown_blocks) == (3, 3, 6) and cfg.num_mid_blocks == 20
+    params = ouvit.seeded_params(cfg, seed=14)
+    g = torch.Generator().manual_seed(15)
+    xs = torch.randn(batch, 8, 3, res, res, generator=g)
+    noise = torch.randn(batch, 8, 3, res, res, generator=g)
+    t = torch.rand(batch, 8, generator=g)
+    pz = torch.eye(3, 4).reshape(1, 1, 12).repeat(batch, 8, 1)
+    pz[..., 3] = torch.linspace(0, 0.4, 8)
+    pz[1, :, 7] = 0.1
+    cond = opose.ray_encoding(torch.cat([torch.tensor([0.5, 0.9, 0.5, 0.5]).repeat(batch, 8, 1), pz], -1), res)
+    tr = ut.UViT3DPoseTrainer(params, dict(channels=cfg.channels, emb_channels=cfg.emb_channels, patch_size=2, block_types=cfg.block_types,
+                                           num_updown_blocks=cfg.num_updown_blocks, num_mid_blocks=cfg.num_mid_blocks, num_heads=cfg.num_heads,
+                                           resolution=res, max_tokens=8, use_checkpointing=[False, False, False, True]))
+    loss = float(tr.loss_and_grads(xs, cond.cuda(), t, noise).item())
+    grads = {n: tr._view(n, tr.flat_grads).detach().clone() for n in tr.layout}
+    torch.cuda.synchronize()
+    # fp32 autograd through the oracle on the GPU
+    old = (ouvit.USE_SDPA, ouvit.CHECKPOINT_BLOCKS, torch.backends.cuda.matmul.allow_tf32)
+    ouvit.USE_SDPA, ouvit.CHECKPOINT_BLOCKS, torch.backends.cuda.matmul.allow_tf32 = True, True, False
+    try:
+        ps = {n: v.cuda().requires_grad_(not n.endswith(("freqs", "phases"))) for n, v in params.items()}
+        _, per_el = osm.training_loss(lambda x, lv, c, m: ouvit.forward(ps, cfg, x, lv, c), xs.cuda(), cond.cuda(), t.cuda(), noise.cuda())
+        ref_loss = per_el.mean()
+        ref_loss.backward()
+    finally:
+        ouvit.USE_SDPA, ouvit.CHECKPOINT_BLOCKS, torch.backends.cuda.matmul.allow_tf32 = old
+    names = [n for n in ps if ps[n].requires_grad]
+    assert sorted(grads) == sorted(names)
+    rs = {n: rel(grads[n].reshape(ps[n].shape), ps[n].grad) for n in names}
+    worst = max(rs, key=rs.get)
+    med = sorted(rs.values())[len(rs) // 2]
+    over = {n: round(v, 4) for n, v in rs.items() if v >= 3e-2}
+    print(f"config 5 at {res}x{res}, batch {batch}, full depth: loss {loss:.6f} vs oracle {float(ref_loss):.6f}; gradient rel-L2 worst {rs[worst]:.2e} at "
+          f"{worst}, median {med:.2e}; above 3e-2: {over}")
+    assert abs(loss - float(ref_loss)) < 1e-2 * abs(float(ref_loss))
+    assert rs[worst] < 6e-2 and med < 2e-2, (worst, rs[worst], med)

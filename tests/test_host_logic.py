@@ -406,3 +406,22 @@ def test_training_schedule_comes_from_the_config_and_lr_warmup():
             sched.step()
     assert lr_at_step(55, 1.0, "linear", 10, 100) == pytest.approx(0.5)
     assert lr_at_step(55, 1.0, "cosine", 10, 100) == pytest.approx(0.5)
+    # the reference's scheduler goes through accelerator.prepare (simple_video_generation.py:183) -> AcceleratedScheduler steps the
+    # wrapped scheduler num_processes times per optimizer step.  accelerate's own class, with the process count it would read on 3 GPUs
+    import types
+    from accelerate import scheduler as asched
+    opt = torch.optim.SGD([torch.nn.Parameter(torch.zeros(1))], lr=5e-5)
+    opt.step_was_skipped = False  # what AcceleratedOptimizer exposes
+    inner = transformers.get_scheduler(name="constant_with_warmup", optimizer=opt, num_warmup_steps=10)
+    wrapped = asched.AcceleratedScheduler.__new__(asched.AcceleratedScheduler)
+    wrapped.scheduler, wrapped.optimizers, wrapped.split_batches, wrapped.step_with_optimizer = inner, [opt], False, True
+    wrapped.gradient_state = types.SimpleNamespace(sync_gradients=True, adjust_scheduler=True)
+    real_state, asched.AcceleratorState = asched.AcceleratorState, (lambda: types.SimpleNamespace(num_processes=3))
+    try:
+        for s in range(8):
+            assert opt.param_groups[0]["lr"] == pytest.approx(lr_at_step(s, 5e-5, "constant_with_warmup", 10, num_processes=3), rel=1e-6, abs=1e-12), s
+            opt.step()
+            wrapped.step()
+    finally:
+        asched.AcceleratorState = real_state
+    assert lr_at_step(4, 5e-5, "constant_with_warmup", 10, num_processes=3) == pytest.approx(5e-5)  # warm-up over after ceil(10 / 3) steps
