@@ -473,7 +473,7 @@ class UViT3DPoseTrainer:
             self.bound_exact_reads = getattr(self, "bound_exact_reads", 0) + 1
         dr = self._bound_drift
         for b, e, w in zip(self._bound_blocks, self._bound_exact, self._bound_wmax):
-            b.score_bound = e + kd * (2.0 * w * dr + dr * dr)
+            b.score_bound = (e + kd * (2.0 * w * dr + dr * dr)) * (1.0 + 1e-5)  # the product above was rounded in fp32 on the device
 
     def _run(self, blocks, x, lvl):
         p = self.block_dropouts[lvl] if self.dropout_generator is not None else 0.0

@@ -1170,7 +1170,7 @@ def _true_bound(blk):
 
 
 def test_trainer_score_bound_follows_an_external_weight_change_at_once():
-    """q_norm / k_norm weights replaced x4 in a LIVE trainer (what a checkpoint load or the autograd drop-in
+    """q_norm / k_norm weights scaled up in a LIVE trainer (what a checkpoint load or the autograd drop-in
     after load_state_dict does: copy into trainer.p, then sync()).  The bound the blocks hold must be the NEW weights' bound before the
     next forward is issued (>= 64 here: running-max kernel), and that forward must match the oracle on the new weights."""
     ut, ouvit, cfg, params, tcfg, x, k, cond = _re10k_width_trainer()
@@ -1179,7 +1179,9 @@ def test_trainer_score_bound_follows_an_external_weight_change_at_once():
     assert d64 and all(b.score_bound < 64 and b.score_bound >= _true_bound(b) for b in d64)
     out0 = tr.forward(x, k, cond).cpu()
     assert rel(out0, ouvit.forward(params, cfg, x, k, cond)) < 2e-2
-    new = {n: (t * 4.0 if n.endswith(("q_norm.weight", "k_norm.weight")) else t.clone()) for n, t in params.items()}
+    # x2.4 on both norms = x5.76 on the scores: bound ~ 75 >= 64.  (x4 each = x16 makes the softmax so peaked that bf16 q / k rounding
+    # alone costs 2.6e-2 against the fp32 oracle -- finite and on the running-max kernel, but no longer a 2e-2 comparison)
+    new = {n: (t * 2.4 if n.endswith(("q_norm.weight", "k_norm.weight")) else t.clone()) for n, t in params.items()}
     with torch.no_grad():
         for n, t in new.items():
             tr.p[n].copy_(t)
@@ -1188,7 +1190,7 @@ def test_trainer_score_bound_follows_an_external_weight_change_at_once():
     out1 = tr.forward(x, k, cond).cpu()
     ref1 = ouvit.forward(new, cfg, x, k, cond)
     r = rel(out1, ref1)
-    print(f"trainer forward right after a x4 q/k-norm change: rel-L2 {r:.2e} (bound {d64[0].score_bound:.1f})")
+    print(f"trainer forward right after a x2.4 q/k-norm change: rel-L2 {r:.2e} (bound {d64[0].score_bound:.1f})")
     assert torch.isfinite(out1).all() and r < 2e-2
     # ... and the backward that follows consumes the running-max kernel's lse
     grads = tr.backward(torch.randn(1, 8, 3, 64, 64, generator=torch.Generator().manual_seed(3)))
@@ -1214,11 +1216,11 @@ def test_trainer_score_bound_is_an_upper_bound_through_its_own_optimizer_steps()
     assert tr.bound_exact_reads == reads0 and tr._bound_drift > 0     # no device read on the trainer's own steps
     tr.sync()                                                           # an external sync re-reads exactly
     assert tr.bound_exact_reads == reads0 + 1 and tr._bound_drift == 0.0
-    assert all(abs(b.score_bound - _true_bound(b)) < 1e-3 * b.score_bound for b in d64)
+    assert all(0 <= b.score_bound - _true_bound(b) < 1e-3 * b.score_bound for b in d64)
 
 
 def test_drop_in_forward_after_load_state_dict_uses_the_new_weights_bound():
-    """one training forward on the initial weights, then load_state_dict with q/k-norm weights x4 (bound >= 64), then
+    """one training forward on the initial weights, then load_state_dict with q/k-norm weights x2.4 (bound >= 64), then
     the next training forward: it must run the running-max kernel (finite, oracle-matching), not the stale fast choice."""
     import dfot_amd
     ut, ouvit, cfg, params, tcfg, x, k, cond = _re10k_width_trainer(seed=41)
@@ -1231,13 +1233,13 @@ def test_drop_in_forward_after_load_state_dict_uses_the_new_weights_bound():
     xd, kd, cd = x.cuda(), k.cuda(), cond.cuda()
     v0 = model(xd, kd, cd)
     v0.sum().backward()
-    new = {n: (t * 4.0 if n.endswith(("q_norm.weight", "k_norm.weight")) else t.clone()) for n, t in params.items()}
+    new = {n: (t * 2.4 if n.endswith(("q_norm.weight", "k_norm.weight")) else t.clone()) for n, t in params.items()}
     model.load_state_dict(new, strict=True)
     v1 = model(xd, kd, cd)
     d64 = [b for b in model._trainer._blocks() if isinstance(b, ut.TransformerBlockTrain) and b.d == 64]
     assert all(b.score_bound >= 64 for b in d64)
     r = rel(v1.detach().cpu(), ouvit.forward(new, cfg, x, k, cond))
-    print(f"drop-in forward after load_state_dict (q/k-norm x4): rel-L2 {r:.2e}")
+    print(f"drop-in forward after load_state_dict (q/k-norm x2.4): rel-L2 {r:.2e}")
     assert torch.isfinite(v1).all() and r < 2e-2
     v1.sum().backward()
     assert all(torch.isfinite(p.grad).all() for p in model.parameters())
@@ -1297,7 +1299,7 @@ def test_uvit3d_pose_training_step_at_config5_frame_size_full_depth():
     launch geometry per video (level-0 GroupNorm over 16384-pixel images, 113-slice convolution weight gradients, N = 8192 attention
     backward) -- with level-3 checkpointing as in the recipe.  Engine loss and every parameter gradient vs torch autograd through
     oracle.uvit in fp32 ON THE GPU (fused SDPA, every block under torch.utils.checkpoint so that it fits).  Bars: loss 1e-2 relative;
-    gradients worst <= 6e-2, median <= 2e-2 relative L2 (bf16 activations through 38 residual blocks; printed)."""
+    gradients worst <= 3e-2, median <= 1.5e-2 relative L2 (bf16 activations through 38 residual blocks; measured 1.7e-2 / 7.9e-3, printed)."""
     from dfot_amd import uvit_train as ut
     from oracle import pose as opose, sampler as osm, uvit as ouvit
     res, batch = 256, 2
@@ -1326,6 +1328,7 @@ def test_uvit3d_pose_training_step_at_config5_frame_size_full_depth():
         _, per_el = osm.training_loss(lambda x, lv, c, m: ouvit.forward(ps, cfg, x, lv, c), xs.cuda(), cond.cuda(), t.cuda(), noise.cuda())
         ref_loss = per_el.mean()
         ref_loss.backward()
+        ref_loss = ref_loss.detach()
     finally:
         ouvit.USE_SDPA, ouvit.CHECKPOINT_BLOCKS, torch.backends.cuda.matmul.allow_tf32 = old
     names = [n for n in ps if ps[n].requires_grad]
@@ -1337,4 +1340,4 @@ def test_uvit3d_pose_training_step_at_config5_frame_size_full_depth():
     print(f"config 5 at {res}x{res}, batch {batch}, full depth: loss {loss:.6f} vs oracle {float(ref_loss):.6f}; gradient rel-L2 worst {rs[worst]:.2e} at "
           f"{worst}, median {med:.2e}; above 3e-2: {over}")
     assert abs(loss - float(ref_loss)) < 1e-2 * abs(float(ref_loss))
-    assert rs[worst] < 6e-2 and med < 2e-2, (worst, rs[worst], med)
+    assert rs[worst] < 3e-2 and med < 1.5e-2, (worst, rs[worst], med)
