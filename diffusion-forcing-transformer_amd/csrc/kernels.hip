@@ -480,8 +480,74 @@ __global__ void gn_apply_silu_kernel(const float* __restrict__ x, const float* _
   *reinterpret_cast<bf16x8*>(out + pix * c + c8 * 8) = o;
 }
 
+// The same, laid out for streaming: a thread keeps ITS 8 channels for the whole workgroup -- GroupNorm statistics, gamma, beta (and the
+// per-frame FiLM vector for gn_film_silu_rows_kernel below) are fetched ONCE with 16-byte loads into registers -- and walks down
+// GN_ROWS_IT pixels, so that per pixel it issues only the 16-byte loads of the streams themselves (the one-pixel-per-thread form issued
+// ~40 four-byte loads of cached constants next to its 3 stream loads and sat at 2.9 TB/s).  Workgroup = 256 / (C / 8) pixels per
+// iteration x GN_ROWS_IT iterations of ONE frame; arithmetic and its order are those of the kernels above (bit-identical results).
+constexpr int GN_ROWS_IT = 8;
+template <int C>
+struct GnRowConsts {
+  float mean[8], rsg[8], gam[8], bet[8];
+  __device__ __forceinline__ void load(const float* __restrict__ stats, const float* __restrict__ gamma, const float* __restrict__ beta, int bt,
+                                       int c0) {
+    constexpr int CPG = C / 32;  // channels per group: 4 (C = 128) or 8 (C = 256): this thread's 8 channels lie in 2 or 1 groups
+    const float4v g0 = *reinterpret_cast<const float4v*>(gamma + c0), g1 = *reinterpret_cast<const float4v*>(gamma + c0 + 4);
+    const float4v b0 = *reinterpret_cast<const float4v*>(beta + c0), b1 = *reinterpret_cast<const float4v*>(beta + c0 + 4);
+    const float* st = stats + ((long)bt * 32 + c0 / CPG) * 2;
+    float m0, r0, m1, r1;
+    if constexpr (CPG == 4) {
+      const float4v t = *reinterpret_cast<const float4v*>(st);
+      m0 = t[0], r0 = t[1], m1 = t[2], r1 = t[3];
+    } else {
+      m0 = m1 = st[0];
+      r0 = r1 = st[1];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      mean[j] = j < 4 ? m0 : m1;
+      rsg[j] = j < 4 ? r0 : r1;
+      gam[j] = j < 4 ? g0[j] : g1[j - 4];
+      bet[j] = j < 4 ? b0[j] : b1[j - 4];
+    }
+  }
+  __device__ __forceinline__ float norm(float v, int j) const { return (v - mean[j]) * rsg[j] * gam[j] + bet[j]; }
+};
+
+template <int C>
+__global__ __launch_bounds__(256) void gn_apply_silu_rows_kernel(const float* __restrict__ x, const float* __restrict__ stats,
+                                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                 bf16* __restrict__ out, int pixels, const uint8_t* __restrict__ live) {
+  constexpr int TPP = C / 8, PPI = 256 / TPP;
+  const int wg_per_bt = pixels / (PPI * GN_ROWS_IT);
+  const int bt = blockIdx.x / wg_per_bt;
+  if (live && !live[bt]) return;  // a frame whose output is discarded: nothing read, nothing written
+  const int c0 = (threadIdx.x % TPP) * 8;
+  GnRowConsts<C> k;
+  k.load(stats, gamma, beta, bt, c0);
+  long pix = (long)bt * pixels + (long)(blockIdx.x % wg_per_bt) * (PPI * GN_ROWS_IT) + threadIdx.x / TPP;
+#pragma unroll 4
+  for (int it = 0; it < GN_ROWS_IT; ++it, pix += PPI) {
+    const float* src = x + pix * C + c0;
+    const float4v a = *reinterpret_cast<const float4v*>(src);
+    const float4v b = *reinterpret_cast<const float4v*>(src + 4);
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = f2bf(silu_f(k.norm(j < 4 ? a[j] : b[j - 4], j)));
+    *reinterpret_cast<bf16x8*>(out + pix * C + c0) = o;
+  }
+}
+
 int launch_gn_apply_silu(const float* x, const float* stats, const float* gamma, const float* beta, bf16* out, int bt,
                          int pixels, int c, hipStream_t s, const uint8_t* live) {
+  static const int rows_form = tuning_flag("GN_ROWS", 1);
+  if (rows_form && (c == 128 || c == 256) && pixels % ((256 / (c / 8)) * GN_ROWS_IT) == 0) {
+    const int grid = bt * (pixels / ((256 / (c / 8)) * GN_ROWS_IT));
+    if (c == 128) hipLaunchKernelGGL(gn_apply_silu_rows_kernel<128>, dim3(grid), dim3(256), 0, s, x, stats, gamma, beta, out, pixels, live);
+    else hipLaunchKernelGGL(gn_apply_silu_rows_kernel<256>, dim3(grid), dim3(256), 0, s, x, stats, gamma, beta, out, pixels, live);
+    DFOT_CHECK_HIP(hipGetLastError());
+    return DFOT_OK;
+  }
   const long total8 = (long)bt * pixels * (c / 8);
   DFOT_REQUIRE(total8 < (1L << 31), DFOT_ERR_SHAPE, "groupnorm apply: %ld work items exceed the 32-bit index range", total8);
   hipLaunchKernelGGL(gn_apply_silu_kernel, dim3(cdiv(total8, 256)), dim3(256), 0, s, x, stats, gamma, beta, out, total8,
@@ -656,9 +722,73 @@ __global__ void gn_film_silu_kernel(const bf16* __restrict__ h, const float* __r
   }
   *reinterpret_cast<bf16x8*>(out + pix * c + c0) = o;
 }
+// streaming form (see gn_apply_silu_rows_kernel): constants of the thread's 8 channels in registers, GN_ROWS_IT pixels per thread
+template <int C>
+__global__ __launch_bounds__(256) void gn_film_silu_rows_kernel(const bf16* __restrict__ h, const float* __restrict__ stats,
+                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                const bf16* __restrict__ fcache, const float* __restrict__ sv,
+                                                                const uint8_t* __restrict__ cond_mask, bf16* __restrict__ out, int pixels,
+                                                                int tokens, const uint8_t* __restrict__ live) {
+  constexpr int TPP = C / 8, PPI = 256 / TPP;
+  const int wg_per_bt = pixels / (PPI * GN_ROWS_IT);
+  const int bt = blockIdx.x / wg_per_bt;
+  if (live && !live[bt]) return;
+  const int c0 = (threadIdx.x % TPP) * 8;
+  const int col = (c0 >> 5) * 64 + (c0 & 31);  // scale columns col..col+7, shift columns col+32..col+39
+  GnRowConsts<C> k;
+  k.load(stats, gamma, beta, bt, c0);
+  const float* svp = sv + (long)bt * 2 * C + col;
+  float svs[8], svh[8];
+  {
+    const float4v s0 = *reinterpret_cast<const float4v*>(svp), s1 = *reinterpret_cast<const float4v*>(svp + 4);
+    const float4v h0 = *reinterpret_cast<const float4v*>(svp + 32), h1 = *reinterpret_cast<const float4v*>(svp + 36);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      svs[j] = j < 4 ? s0[j] : s1[j - 4];
+      svh[j] = j < 4 ? h0[j] : h1[j - 4];
+    }
+  }
+  const bool use_pose = !(cond_mask && cond_mask[(unsigned)bt / (unsigned)tokens]);  // workgroup-uniform
+  long pix = (long)bt * pixels + (long)(blockIdx.x % wg_per_bt) * (PPI * GN_ROWS_IT) + threadIdx.x / TPP;
+  if (use_pose) {
+#pragma unroll 4
+    for (int it = 0; it < GN_ROWS_IT; ++it, pix += PPI) {
+      const bf16x8 hv = *reinterpret_cast<const bf16x8*>(h + pix * C + c0);
+      const bf16x8 fs = *reinterpret_cast<const bf16x8*>(fcache + pix * 2 * C + col);
+      const bf16x8 fh = *reinterpret_cast<const bf16x8*>(fcache + pix * 2 * C + col + 32);
+      bf16x8 o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float sc = svs[j] + bf2f(fs[j]), sh = svh[j] + bf2f(fh[j]);
+        o[j] = f2bf(silu_f(k.norm(bf2f(hv[j]), j) * (1.f + sc) + sh));
+      }
+      *reinterpret_cast<bf16x8*>(out + pix * C + c0) = o;
+    }
+  } else {
+#pragma unroll 4
+    for (int it = 0; it < GN_ROWS_IT; ++it, pix += PPI) {
+      const bf16x8 hv = *reinterpret_cast<const bf16x8*>(h + pix * C + c0);
+      bf16x8 o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = f2bf(silu_f(k.norm(bf2f(hv[j]), j) * (1.f + svs[j]) + svh[j]));
+      *reinterpret_cast<bf16x8*>(out + pix * C + c0) = o;
+    }
+  }
+}
+
 int launch_gn_film_silu(const bf16* h, const float* stats, const float* gamma, const float* beta, const bf16* fcache,
                         const float* sv, const uint8_t* cond_mask, bf16* out, int bt, int pixels, int c, int tokens,
                         hipStream_t s, const uint8_t* live) {
+  static const int rows_form = tuning_flag("GN_ROWS", 1);
+  if (rows_form && (c == 128 || c == 256) && pixels % ((256 / (c / 8)) * GN_ROWS_IT) == 0) {
+    const int grid = bt * (pixels / ((256 / (c / 8)) * GN_ROWS_IT));
+    if (c == 128)
+      hipLaunchKernelGGL(gn_film_silu_rows_kernel<128>, dim3(grid), dim3(256), 0, s, h, stats, gamma, beta, fcache, sv, cond_mask, out, pixels, tokens, live);
+    else
+      hipLaunchKernelGGL(gn_film_silu_rows_kernel<256>, dim3(grid), dim3(256), 0, s, h, stats, gamma, beta, fcache, sv, cond_mask, out, pixels, tokens, live);
+    DFOT_CHECK_HIP(hipGetLastError());
+    return DFOT_OK;
+  }
   const long total8 = (long)bt * pixels * (c / 8);
   DFOT_REQUIRE(total8 < (1L << 31), DFOT_ERR_SHAPE, "groupnorm apply: %ld work items exceed the 32-bit index range", total8);
   hipLaunchKernelGGL(gn_film_silu_kernel, dim3(cdiv(total8, 256)), dim3(256), 0, s, h, stats, gamma, beta, fcache, sv,

@@ -104,7 +104,7 @@ def test_conv3x3(capi, dma, bt, h, w, cin, cout):
 
 
 @pytest.mark.parametrize("variant", [1, 0, 2, 3, 4, 5, 6, 14])
-@pytest.mark.parametrize("b,heads,n,d", [(1, 2, 128, 64), (2, 9, 512, 64), (1, 3, 256, 128), (2, 9, 128, 128), (3, 5, 1024, 64)])
+@pytest.mark.parametrize("b,heads,n,d", [(1, 2, 128, 64), (2, 9, 512, 64), (1, 3, 256, 128), (2, 9, 128, 128), (3, 5, 1024, 64), (2, 5, 512, 128)])
 def test_attention(capi, variant, b, heads, n, d):
     g = torch.Generator().manual_seed(n + d + heads)
     q = torch.randn(b, heads, n, d, generator=g)
@@ -127,7 +127,7 @@ def test_attention(capi, variant, b, heads, n, d):
 
 
 @pytest.mark.parametrize("variant", [2, 5, 6, 14])
-@pytest.mark.parametrize("b,heads,n,d", [(2, 9, 8192, 64), (2, 9, 2048, 128), (8, 9, 8192, 64), (1, 9, 8192, 64)])
+@pytest.mark.parametrize("b,heads,n,d", [(2, 9, 8192, 64), (2, 9, 2048, 128), (8, 9, 8192, 64), (1, 9, 8192, 64), (1, 9, 2048, 128), (4, 9, 2048, 128)])
 def test_attention_production_shapes_vs_fp32_softmax(capi, variant, b, heads, n, d):
     """The launches bench.py times: level 2 = 18 (batch, head) units x N 8192 x d 64 (1152 workgroups through
     the XCD remap, 128 K/V tiles through the LDS ring), level 3 = N 2048 x d 128, and the model-batch-8 launch of the 200-frame
