@@ -449,7 +449,7 @@ template <int D, int NST, int DQK = D, int DV = D, bool QRELOAD = false>
 static int launch_attn_v2(const bf16* q, const bf16* k, const bf16* v, bf16* o, long ldo, int batch, int heads, int n,
                           hipStream_t stream, int ohs = D, int dvalid = D, float* lse = nullptr) {
   auto kern = attn_kernel_v2<D, NST, DQK, DV, QRELOAD>;
-  static const int xcd_flag = tuning_flag("ATTN_XCD", 1) | (tuning_flag("ATTN_PRIO", 1) << 1);
+  constexpr int xcd_flag = 1 | 2;  // bit 0: XCD-aware tile order, bit 1: s_setprio around the MFMA clusters (+1-2 %): both always on
   const int lds = 2 * NST * AttnCfg<D>::TILE;
   static bool attr_set = false;
   if (!attr_set) {

@@ -292,11 +292,10 @@ __global__ __launch_bounds__(256) void attn128_merge_kernel(const float* __restr
 static AttnSplit plan_ks(int batch, int heads, int n) { return attn_plan_split(batch, heads, n, QR, 1); }  // one 8-wave workgroup per CU
 
 bool attention_ks_applies(int batch, int heads, int n, int d) {
-  static const int on = tuning_flag("ATTN_KS2", 1);  // A/B: 0 = attn_kernel_v2<128> for every launch
   // few query tiles: at most one round of one workgroup per CU, or a second round small enough to be split over the keys.  Beyond that
   // the 4-wave kernel's two resident workgroups per CU already give every SIMD two waves (measured, B x H = 27, N = 2048: 73.6 us
   // against 82.5 us for this kernel without a balanced tail; B x H = 18: 67.5 -> 62.5 us; B x H = 9: 47.6 -> 38.2 us)
-  if (!on || d != 128 || n % QR != 0 || (n / KV) % 2 != 0) return false;
+  if (d != 128 || n % QR != 0 || (n / KV) % 2 != 0) return false;
   const AttnSplit sp = plan_ks(batch, heads, n);
   return sp.full == 0 || (sp.full == sp.slots && sp.nsplit > 1);
 }

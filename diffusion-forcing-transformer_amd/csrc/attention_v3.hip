@@ -327,8 +327,7 @@ AttnSplit attn_plan_split(int batch, int heads, int n, int qrows, int wgs_per_cu
   AttnSplit sp;
   sp.slots = slots;
   sp.tiles = batch * heads * (n / qrows);
-  static const int mode = tuning_flag("ATTN3_SPLIT", 1);
-  sp.rem = mode ? sp.tiles % slots : 0;
+  sp.rem = sp.tiles % slots;
   sp.full = sp.tiles - sp.rem;
   sp.nsplit = 1;
   if (sp.rem) {

@@ -234,7 +234,8 @@ __global__ __launch_bounds__(256, 2) void attn64_kernel_v5(const bf16* __restric
     if constexpr (has_prev) read_v(KT2N{}, vstage, vr);  // half-tile h-1 has the same key parity as h+1
     softmax_part(cb_c, C0{});                            // vector work that needs no LDS data covers the read latency
     // ... provided it stays in front of the wait: without a use there LLVM sinks it behind the wait and the wave idles through the
-    // latency of its twelve LDS reads at the top of every iteration (DFOT_ATTN5_PIN=0 restores that order for the A/B)
+    // latency of its twelve LDS reads at the top of every iteration (PIN = false restores that order: 335 vs 329 us, no loss once the
+    // partner wave covers the latency, but 256 instead of 217 VGPRs)
     if constexpr (PIN) asm volatile("" : "+v"(pf[0][cb][0]), "+v"(pf[1][cb][0]), "+v"(l_i[0]), "+v"(l_i[1]));
     if constexpr (has_next && has_prev) lds_wait12(kr[0], kr[1], kr[2], kr[3], vr[0], vr[1], vr[2], vr[3], vr[4], vr[5], vr[6], vr[7]);
     else if constexpr (has_next) lds_wait4(kr[0], kr[1], kr[2], kr[3]);
@@ -351,8 +352,7 @@ int launch_attention_v5(const bf16* q, const bf16* k, const bf16* v, bf16* o, lo
     DFOT_CHECK_HIP(hipGetLastError());
     return DFOT_OK;
   };
-  static const int pin = tuning_flag("ATTN5_PIN", 1);
-  rc = pin ? go(attn64_kernel_v5<3, true>) : go(attn64_kernel_v5<3, false>);
+  rc = go(attn64_kernel_v5<3, true>);
   if (rc) return rc;
   return attn_launch_merge(sp, QROWS, po, pml, o, ldo, n, heads, stream, lse);
 }

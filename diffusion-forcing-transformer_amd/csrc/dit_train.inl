@@ -768,16 +768,12 @@ int tr_gemm_f32(const bf16* A, long lda, const bf16* W, int M, int N, int K, flo
   return launch_gemm(A_DENSE, E_F32, variant, g, s);
 }
 // Weight gradient out[M][N] = A[M][K] W[N][K]^T with M, N = feature counts (multiples of 128 only) and K = tokens (long).
-// A/B (same box, DiT/XL, 8 videos): splitting K over workgroups with atomic accumulation (DFOT_TRAIN_WGRAD_WGS = target number of
-// workgroups) fills the chip for the 81-tile out-projection gradient but the 8 M fp32 atomics per GEMM cost more than that gains:
-// 42.3 ms/step at 512 workgroups, 46.0 at 768, 48.8 at 1024 vs 40.9 unsplit -- off by default.
+// (Splitting K over workgroups with atomic accumulation was measured and dropped: 42.3 ms/step at 512 workgroups, 46.0 at 768,
+// 48.8 at 1024 vs 40.9 unsplit on DiT/XL -- the 8 M fp32 atomics per GEMM cost more than the idle CUs they recruit.)
 // What does pay for the long-K shapes whose 256x192 tiling leaves CUs idle (MLP weights: 4608 x 1152 -> 108 tiles): K split in
 // two with each slice storing its partial tile to a workspace (plain stores) and one pass summing the slices (`ws`, `ws_floats`).
 int tr_wgrad(const bf16* A, const bf16* W, int M, int N, int K, float* out, hipStream_t s, float* ws = nullptr, size_t ws_floats = 0) {
-  static const int variant = tuning_flag("TRAIN_WGRAD_VARIANT", GEMM_AUTO);
-  static const int target = tuning_flag("TRAIN_WGRAD_WGS", 0);
-  static const int big = tuning_flag("TRAIN_WGRAD_BIGTILE", 1);
-  if (big && ws && target == 0 && variant == GEMM_AUTO) {
+  if (ws) {
     const long t192 = (long)(M / 256) * (N / 192);
     if (M % 256 == 0 && N % 192 == 0 && t192 >= 64 && t192 < 160 && K >= 4096) {
       const int split = t192 <= 85 ? 3 : 2;
@@ -797,8 +793,7 @@ int tr_wgrad(const bf16* A, const bf16* W, int M, int N, int K, float* out, hipS
     // few 128x128 tiles and a long K (out-projection weights: 81 tiles; matrix factors U, U': 2 tiles over K = frames x hidden)
     const long t128 = (long)(M / 128) * ((N + 127) / 128);
     if (t128 <= 128 && K >= 2048) {
-      static const int wide = tuning_flag("TRAIN_WGRAD_128X192", 1);  // A/B: 128x192 tiles where N allows (PMC: 0.21 vs 0.15 MFMA utilisation)
-      const bool use192 = wide && N % 192 == 0;
+      const bool use192 = N % 192 == 0;  // 128x192 tiles where N allows (PMC: 0.21 vs 0.15 MFMA utilisation)
       const long tiles = use192 ? (long)(M / 128) * (N / 192) : t128;
       int split = (int)(256 / tiles);
       split = split > 64 ? 64 : split;
@@ -814,19 +809,12 @@ int tr_wgrad(const bf16* A, const bf16* W, int M, int N, int K, float* out, hipS
       }
     }
   }
-  int split = 1;
-  if (target > 0) {
-    const long tiles = (long)(M / 128) * ((N + 127) / 128);
-    split = (int)((target + tiles / 2) / tiles);
-    split = split < 1 ? 1 : (split > 16 ? 16 : split);
-  }
-  return tr_gemm_f32(A, K, W, M, N, K, out, N, nullptr, s, split > 1 && variant == GEMM_AUTO ? (int)GEMM_DMA_128 : variant, split);
+  return tr_gemm_f32(A, K, W, M, N, K, out, N, nullptr, s, GEMM_AUTO, 1);
 }
 // dW[M][N] = dY^T X over `rows` tokens with both operands in their own layout (wgrad.hip): no transposed copies.  Returns
 // DFOT_ERR_STATE (and does nothing) when the shape is not covered, so the caller falls back to transposes + tr_wgrad.
 int tr_wgrad_nt(const bf16* dy, long ldy, const bf16* x, long ldx, int M, int N, long rows, float* out, hipStream_t s, float* ws, size_t ws_floats) {
-  static const int enabled = tuning_flag("TRAIN_WGRAD_NT", 1);
-  if (!enabled || M % 8 != 0 || N % 8 != 0 || rows % 64 != 0) return DFOT_ERR_STATE;
+  if (M % 8 != 0 || N % 8 != 0 || rows % 64 != 0) return DFOT_ERR_STATE;
   const WgradPlan plan = wgrad_plan(M, N, rows, ws ? (long)(ws_floats / ((size_t)M * N)) : 1);
   if (plan.slices == 1) return launch_wgrad_nt_plan(dy, ldy, x, ldx, out, M, N, rows, plan, s);
   int rc = launch_wgrad_nt_plan(dy, ldy, x, ldx, ws, M, N, rows, plan, s);

@@ -75,19 +75,17 @@ struct GemmArgs {
 enum GemmVariant {
   GEMM_REGS_128 = 0,  // 128x128 tile, register staging, 2 LDS stages (A/B reference)
   GEMM_DMA_128 = 1,   // 128x128 tile, LDS-DMA, 2 stages
-  GEMM_DMA3_128 = 2,  // 128x128 tile, LDS-DMA, 3-stage ring with counted vmcnt
-  GEMM_DMA3_256 = 3,  // 256x128 tile (8 waves), LDS-DMA, 3-stage ring
+  // (numbers 2, 3, 5, 7, 13 were tile forms measured slower on every model shape and removed in round 4: 128x128 / 256x128 three-stage
+  // rings, 256x128 two-stage, 256x256 with 128x64 wave tiles, the two-stage 256x144 -- DESIGN.md section 7)
   GEMM_DMA_256x256 = 4,  // 256x256 tile (16 waves), LDS-DMA, 2 stages: half the L2->LDS operand traffic per FLOP
-  GEMM_DMA_256x128 = 5,  // 256x128 tile (8 waves), 2 stages
   GEMM_DMA_512x128 = 6,  // 512x128 tile (16 waves), 2 stages (N = 128 convolutions)
-  GEMM_DMA_256x256_W128 = 7,  // 256x256 tile, 8 waves of 128x64 (fewer LDS fragment reads per MFMA)
   GEMM_DMA_128_KS2 = 8,  // 128x128 tile, 8 waves: two k-groups alternate k-tiles (intra-workgroup split-K)
   GEMM_DMA_256x192 = 9,  // 256x192 tile (12 waves), 2 stages, dense A only: N = multiples of 192 (1152, 3456) without padding
   GEMM_DMA_128x192 = 10,  // 128x192 tile (6 waves), 2 stages, dense A: long-K GEMMs with slightly more 128x128 tiles than CUs
-  // 256x144 tile (12 waves of 64x48), 2 stages, dense A, plain epilogues: N = multiples of 144 (576, 1152) give M/256 x N/144 tiles =
-  // exactly one per CU for the level-2 out-projection (256) and, with two K slices, for the level-3 one (128 x 2)
-  GEMM_DMA_256x144 = 13,
-  GEMM_DMA3_256x144 = 14,  // ... with a 3-stage ring (150 KB): the long-K out-projections wait on the one k-tile a 2-stage loop has in flight
+  // 256x144 tile (12 waves of 64x48), 3-stage ring (150 KB), plain fp32 epilogue: N = multiples of 144 (576, 1152) give M/256 x N/144
+  // tiles = exactly one per CU for the level-2 out-projection (256) and, with two K slices, for the level-3 one (128 x 2); the long-K
+  // loop no longer waits on the one k-tile a 2-stage loop has in flight
+  GEMM_DMA3_256x144 = 14,
   GEMM_AUTO = -1      // pick by shape (gemm_pick_variant)
 };
 int gemm_pick_variant(int amode, int m, int n, int k, bool plain_f32 = false);  // plain_f32: the caller's epilogue is E_F32 without GroupNorm partials

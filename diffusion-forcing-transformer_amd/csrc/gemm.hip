@@ -813,11 +813,11 @@ static int launch_t(const GemmArgs& g, hipStream_t stream) {
   constexpr int lds = stage_lds > ep_lds ? stage_lds : ep_lds;
   const int ksplit = (EPI == E_F32 && (AMODE == A_DENSE || g.slice_stride > 0) && g.ksplit > 1) ? g.ksplit : 1;
   const int tiles = (g.M / BM_T) * ((g.N + BN_T - 1) / BN_T) * ksplit;
-  static const int xcd_flag = tuning_flag("GEMM_XCD", 1);
-  static const int persist_flag = tuning_flag("GEMM_PERSIST", 1);  // A/B: +0.6 % RE10K, +2.2 % bash/k600 model
+  // XCD-aware tile order and the persistent tile loop of the <= 12-wave kernels are always on (measured: persistent +0.6 % RE10K,
+  // +2.2 % bash/k600 model)
   GemmArgs ga = g;
-  ga.xcd = xcd_flag;
-  if (persist_flag) ga.persist = 1;
+  ga.xcd = 1;
+  ga.persist = 1;
   constexpr bool kPersistOK = KS == 1 && nthreads <= 768;
   if constexpr (kPersistOK) {
     if (ga.persist > 0 && ksplit == 1) {
@@ -851,20 +851,11 @@ static int launch_v(int variant, const GemmArgs& g, hipStream_t s) {
   switch (variant) {
     case GEMM_REGS_128: return launch_t<128, 128, 64, 2, AMODE, EPI, false>(g, s);
     case GEMM_DMA_128: return launch_t<128, 128, 64, 2, AMODE, EPI, true>(g, s);
-    case GEMM_DMA3_128: return launch_t<128, 128, 64, 3, AMODE, EPI, true>(g, s);
-    case GEMM_DMA3_256: return launch_t<256, 128, 64, 3, AMODE, EPI, true>(g, s);
     case GEMM_DMA_256x256: return launch_t<256, 256, 64, 2, AMODE, EPI, true>(g, s);
-    case GEMM_DMA_256x128: return launch_t<256, 128, 64, 2, AMODE, EPI, true>(g, s);
     case GEMM_DMA_512x128: return launch_t<512, 128, 64, 2, AMODE, EPI, true>(g, s);
     case GEMM_DMA_256x192:
       if constexpr (AMODE != A_DENSE) break;
       else return launch_t<256, 192, 64, 2, AMODE, EPI, true>(g, s);
-    case GEMM_DMA_256x144:
-      if constexpr (AMODE != A_DENSE || (EPI != E_F32 && EPI != E_BF16)) break;
-      else {
-        if (g.gn_part) break;
-        return launch_t<256, 144, 64, 2, AMODE, EPI, true>(g, s);
-      }
     case GEMM_DMA3_256x144:  // (also the long-K Downsample / Upsample convolutions: run_down / run_up)
       if constexpr (EPI != E_F32) break;
       else {
@@ -877,9 +868,6 @@ static int launch_v(int variant, const GemmArgs& g, hipStream_t s) {
     case GEMM_DMA_128_KS2:
       if constexpr (EPI == E_QKV) break;
       else return launch_t<128, 128, 64, 2, AMODE, EPI, true, 2>(g, s);
-    case GEMM_DMA_256x256_W128:
-      if (g.gn_part) break;  // fused GroupNorm partials assume 64-row wave tiles
-      return launch_t<256, 256, 128, 2, AMODE, EPI, true>(g, s);
   }
   set_error("gemm: unknown variant %d", variant);
   return DFOT_ERR_ARG;
@@ -908,14 +896,8 @@ int gemm_pick_variant(int amode, int m, int n, int k, bool plain_f32) {
   // N = 128 (level-0 convolutions): one column of tiles, so grow the tile along M instead (16 waves, 102 FLOP/B)
   if (m % 512 == 0 && n <= 128 && m / 512 >= 256) return GEMM_DMA_512x128;
   const long tiles128 = (long)(m / 128) * ((n + 127) / 128);
-  // a few more 128x128 tiles than CUs and a long K (level-3 attn_out+mlp_out: 288 tiles, K = 5760): 128x192 tiles give one
-  // round of <= 256 larger tiles instead of a short second round
-  // measured INSIDE the model (bench.py A/B, same box, twice): 8.24 frames/s with this pick vs 8.33 without -- the isolated
-  // GEMM gains 7 % (tools/bench_ops.py) but the level-3 out-projection with its residual stream does not; off by default
-  static const int use_128x192 = tuning_flag("GEMM_128X192", 0);
-  if (use_128x192 && amode == A_DENSE && tiles128 > 256 && n % 192 == 0 && (long)(m / 128) * (n / 192) <= 256 && (long)(m / 128) * (n / 192) >= 160 &&
-      k >= 1024)
-    return GEMM_DMA_128x192;
+  // (128x192 tiles for "a few more 128x128 tiles than CUs and a long K" gain 7 % in isolation and lose inside the model, 8.24 vs 8.33
+  // frames/s: not picked here; the training weight gradients ask for that variant explicitly)
   // at most one 128x128 tile per CU and a long K (Upsample convolutions at 16x16 / 32x32): split K inside the workgroup
   if (tiles128 <= 256 && k >= 2048) return GEMM_DMA_128_KS2;
   return GEMM_DMA_128;
@@ -927,7 +909,7 @@ int launch_gemm(int amode, int epi, int variant, const GemmArgs& g, hipStream_t 
   if (variant == GEMM_DMA_128_KS2 && epi == E_QKV) variant = GEMM_DMA_128;  // the QKV epilogue has workgroup barriers
   if (variant == GEMM_DMA_128x192 && epi == E_QKV) variant = GEMM_DMA_128;
   if (variant == GEMM_DMA_256x192 && epi == E_QKV && g.d != 64) variant = GEMM_DMA_256x256;  // the d = 128 head pairing needs 128-aligned tiles
-  const int bm = variant == GEMM_DMA_512x128 ? 512 : (variant == GEMM_DMA3_256 || variant == GEMM_DMA_256x256 || variant == GEMM_DMA_256x128 || variant == GEMM_DMA_256x256_W128 || variant == GEMM_DMA_256x192 || variant == GEMM_DMA_256x144 || variant == GEMM_DMA3_256x144) ? 256 : 128;
+  const int bm = variant == GEMM_DMA_512x128 ? 512 : (variant == GEMM_DMA_256x256 || variant == GEMM_DMA_256x192 || variant == GEMM_DMA3_256x144) ? 256 : 128;
   DFOT_REQUIRE(g.M > 0 && g.M % bm == 0, DFOT_ERR_SHAPE, "gemm: M=%d must be a positive multiple of %d", g.M, bm);
   DFOT_REQUIRE(g.K > 0 && g.K % BK == 0, DFOT_ERR_SHAPE, "gemm: K=%d must be a positive multiple of %d", g.K, BK);
   DFOT_REQUIRE(g.N > 0 && g.N % (epi == E_F32 ? 4 : 8) == 0, DFOT_ERR_SHAPE, "gemm: N=%d must be a multiple of %d", g.N, epi == E_F32 ? 4 : 8);

@@ -540,8 +540,7 @@ __global__ __launch_bounds__(256) void gn_apply_silu_rows_kernel(const float* __
 
 int launch_gn_apply_silu(const float* x, const float* stats, const float* gamma, const float* beta, bf16* out, int bt,
                          int pixels, int c, hipStream_t s, const uint8_t* live) {
-  static const int rows_form = tuning_flag("GN_ROWS", 1);
-  if (rows_form && (c == 128 || c == 256) && pixels % ((256 / (c / 8)) * GN_ROWS_IT) == 0) {
+  if ((c == 128 || c == 256) && pixels % ((256 / (c / 8)) * GN_ROWS_IT) == 0) {
     const int grid = bt * (pixels / ((256 / (c / 8)) * GN_ROWS_IT));
     if (c == 128) hipLaunchKernelGGL(gn_apply_silu_rows_kernel<128>, dim3(grid), dim3(256), 0, s, x, stats, gamma, beta, out, pixels, live);
     else hipLaunchKernelGGL(gn_apply_silu_rows_kernel<256>, dim3(grid), dim3(256), 0, s, x, stats, gamma, beta, out, pixels, live);
@@ -779,8 +778,7 @@ __global__ __launch_bounds__(256) void gn_film_silu_rows_kernel(const bf16* __re
 int launch_gn_film_silu(const bf16* h, const float* stats, const float* gamma, const float* beta, const bf16* fcache,
                         const float* sv, const uint8_t* cond_mask, bf16* out, int bt, int pixels, int c, int tokens,
                         hipStream_t s, const uint8_t* live) {
-  static const int rows_form = tuning_flag("GN_ROWS", 1);
-  if (rows_form && (c == 128 || c == 256) && pixels % ((256 / (c / 8)) * GN_ROWS_IT) == 0) {
+  if ((c == 128 || c == 256) && pixels % ((256 / (c / 8)) * GN_ROWS_IT) == 0) {
     const int grid = bt * (pixels / ((256 / (c / 8)) * GN_ROWS_IT));
     if (c == 128)
       hipLaunchKernelGGL(gn_film_silu_rows_kernel<128>, dim3(grid), dim3(256), 0, s, h, stats, gamma, beta, fcache, sv, cond_mask, out, pixels, tokens, live);

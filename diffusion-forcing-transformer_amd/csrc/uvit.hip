@@ -446,12 +446,9 @@ static int run_tr_block(dfot_uvit_s* h, const TrW& w, int lvl, int batch, hipStr
   p.out2 = h->cat + c; p.ldo2 = 5 * c; p.split = 3 * c;
   p.q = h->q; p.k = h->k; p.v = h->v; p.qw = w.qw; p.kw = w.kw; p.rope_cs = h->rope_cs[lvl]; p.heads = h->heads; p.d = d;
   p.ntok = n; p.qscale = 1.4426950408889634f / sqrtf((float)d); p.eps = h->cfg.eps;
-  // d = 64 (level 2: N = 7 x 576 = 21 x 192): 256x192 tiles in the persistent tile loop (the epilogue stores of a tile drain under the next
-  // tile's first loads) measured 109.5 vs 116.8 us for the 256x256 tiles on this shape (tools/bench_ops.py, plain epilogue)
-  static const int qkv192 = tuning_flag("UVIT_QKV_192", 0);  // ... but INSIDE the model the 256x256 form wins (9.79 vs 9.72 frames/s, two same-box rounds): off
-  int qv = h->gemm_variant;
-  if (qkv192 && qv == GEMM_AUTO && d == 64 && c % 192 == 0 && m % 256 == 0 && (long)(m / 256) * (7 * c / 192) >= 512) qv = GEMM_DMA_256x192;
-  if ((rc = launch_gemm(A_DENSE, E_QKV, qv, p, s))) return rc;
+  // (d = 64, N = 21 x 192: persistent 256x192 tiles win in isolation, 109.5 vs 116.8 us with a plain epilogue, and lose inside the model,
+  // 9.72 vs 9.79 frames/s: the picker's 256x256 tiles stay)
+  if ((rc = launch_gemm(A_DENSE, E_QKV, h->gemm_variant, p, s))) return rc;
   const bool timed = h->time_attn && lvl == 2 && h->ev_used < h->ev_start.size();
   if (timed) DFOT_CHECK_HIP(hipEventRecord(h->ev_start[h->ev_used], s));
   // default (2): level 2 (d = 64) runs the 64-rows-per-wave kernel with the balanced tail; without a running max when the
@@ -463,45 +460,27 @@ static int run_tr_block(dfot_uvit_s* h, const TrW& w, int lvl, int batch, hipStr
   GemmArgs o;
   o.A = h->cat; o.lda = 5 * c; o.W = w.w_out; o.M = m; o.N = c; o.K = 5 * c; o.bias = w.b_out; o.out_f32 = x; o.resid = h->xin[lvl];
   o.ldo = c;
-  // A/B: K split over workgroups where the out-projection has fewer tiles than CUs (level 3: 96 tiles of 256x192)
-  static const int l3_split = tuning_flag("UVIT_OUT_KSPLIT", 1);
-  if (l3_split > 1 && (long)(m / 256) * ((c + 191) / 192) < 200 && h->xin[lvl] == x) o.ksplit = l3_split;
-  // level 3 at small model batch: 256x144 tiles give M/256 x N/144 = 128 workgroups for 256 CUs; two K slices into partial
-  // buffers make it 256, and one pass adds slices + bias into the fp32 residual stream (out_reduce_kernel)
-  static const int split144 = tuning_flag("UVIT_OUT_SPLIT144", 1);  // 0: one GEMM with the residual epilogue; 1: 256x144 x 2 slices; 2: 256x256 x 3 slices
-  static const int defer = tuning_flag("UVIT_OUT_DEFER", 1);  // A/B: 0 = reduce pass right away
-  // mode 2: 256x256 tiles (half the L2 -> LDS operand bytes per FLOP of 256x144; N padded to the tile: 5 column tiles for 1152) x three K
-  // slices = 240 workgroups for 256 CUs; +1.0 / +1.6 % frames/s over mode 1 while mode 1 ran the two-stage 256x144 kernel.  With the
-  // THREE-stage 256x144 ring (150 KB of LDS: the long-K loop no longer waits on the single k-tile a two-stage loop has in flight) mode 1
-  // is ahead: 10.08 vs 9.99 frames/s (two same-box rounds), 256 workgroups, no padded columns, two slabs instead of three: default
-  if (split144 == 2 && h->gemm_variant == GEMM_AUTO && h->out_part && (size_t)3 * m * c <= h->out_part_elems && m % 256 == 0 &&
-      (long)(m / 256) * ((c + 255) / 256) * 3 <= 256 && (5 * c / 64) % 3 == 0 && (5 * c / 64) >= 12) {
-    GemmArgs p3 = o;
-    p3.bias = nullptr; p3.resid = nullptr; p3.out_f32 = h->out_part; p3.ksplit = 3; p3.slice_stride = (long)m * c;
-    if ((rc = launch_gemm(A_DENSE, E_F32, GEMM_DMA_256x256, p3, s))) return rc;
-    h->pend_bias = w.b_out;
-    h->pend_lvl = lvl; h->pend_m = m; h->pend_c = c; h->pend_slices = 3;
-    swap_out_part(h);
-    return defer ? DFOT_OK : flush_pending(h, s);
-  }
-  if (split144 && h->gemm_variant == GEMM_AUTO && h->out_part && (size_t)2 * m * c <= h->out_part_elems && m % 256 == 0 && c % 144 == 0 &&
+  // level 3 at small model batch: 256x144 tiles give M/256 x N/144 = 128 workgroups for 256 CUs; two K slices into partial buffers
+  // make it 256 on the THREE-stage 256x144 ring (150 KB of LDS: the long-K loop no longer waits on the single k-tile a two-stage loop
+  // has in flight), and the slices + bias are added into the fp32 residual stream by the NEXT block's norm kernel (deferred: pend_*).
+  // Measured alternatives, dropped: one GEMM with the residual epilogue; fp32-atomic split-K (8.30 -> 6.61 frames/s); 256x256 tiles x
+  // three K slices (240 workgroups: 9.99 vs 10.08 frames/s); the two-stage 256x144 kernel; the reduce pass right away.
+  if (h->gemm_variant == GEMM_AUTO && h->out_part && (size_t)2 * m * c <= h->out_part_elems && m % 256 == 0 && c % 144 == 0 &&
       (long)(m / 256) * (c / 144) * 2 <= 256 && (5 * c / 64) >= 8) {
     GemmArgs p2 = o;
     p2.bias = nullptr; p2.resid = nullptr; p2.out_f32 = h->out_part; p2.ksplit = 2; p2.slice_stride = (long)m * c;
-    static const int ring144 = tuning_flag("UVIT_OUT_RING144", 1);
-    if ((rc = launch_gemm(A_DENSE, E_F32, ring144 ? GEMM_DMA3_256x144 : GEMM_DMA_256x144, p2, s))) return rc;
+    if ((rc = launch_gemm(A_DENSE, E_F32, GEMM_DMA3_256x144, p2, s))) return rc;
     h->pend_bias = w.b_out;
     h->pend_lvl = lvl; h->pend_m = m; h->pend_c = c; h->pend_slices = 2;
     swap_out_part(h);
-    return defer ? DFOT_OK : flush_pending(h, s);
+    return DFOT_OK;
   }
   // level 2 (M = 16384, N = 576): 256x192 tiles are 192 workgroups -- a quarter of the chip idle for the whole kernel; 256x144 tiles
-  // (N = 4 x 144) are exactly 256, one per CU, at 92 instead of 110 FLOP per operand byte
-  // (two-stage kernel, flag = 1: equal within noise, 9.42 vs 9.42 frames/s; three-stage ring, flag = 2: 10.10 vs 10.00, two rounds: default)
-  static const int l2_144 = tuning_flag("UVIT_OUT_L2_144", 2);
-  if (l2_144 && h->gemm_variant == GEMM_AUTO && o.ksplit == 1 && c % 144 == 0 && m % 256 == 0 && (long)(m / 256) * ((c + 191) / 192) < 256 &&
+  // (N = 4 x 144) are exactly 256, one per CU, at 92 instead of 110 FLOP per operand byte, on the three-stage ring (10.10 vs 10.00
+  // frames/s, two rounds; the two-stage form was equal to the 256x192 tiles)
+  if (h->gemm_variant == GEMM_AUTO && c % 144 == 0 && m % 256 == 0 && (long)(m / 256) * ((c + 191) / 192) < 256 &&
       (long)(m / 256) * (c / 144) >= 200 && (long)(m / 256) * (c / 144) <= 256)
-    rc = launch_gemm(A_DENSE, E_F32, l2_144 == 2 ? GEMM_DMA3_256x144 : GEMM_DMA_256x144, o, s);
+    rc = launch_gemm(A_DENSE, E_F32, GEMM_DMA3_256x144, o, s);
   else
     rc = launch_gemm(A_DENSE, E_F32, h->gemm_variant, o, s);
   h->xin[lvl] = x;
@@ -529,9 +508,8 @@ __global__ void slab_reduce_kernel(float* __restrict__ out, const float* __restr
 // (256x256 tiles for N = 256) with K split over workgroups into fp32 slabs -- enough slices for ~256 workgroups -- and one reduce pass
 // (bias + slabs; images skipped by the tile's flag are skipped there too, so their rows keep what they held).
 static int conv_between_levels(dfot_uvit_s* h, GemmArgs g, hipStream_t s) {
-  static const int on = tuning_flag("UVIT_CONV_SPLIT", 1);
   const long px = (long)g.H * g.Wd;
-  if (on && h->gemm_variant == GEMM_AUTO && h->out_part && !g.gn_part && g.M % 256 == 0 && px % 256 == 0 && (g.N % 144 == 0 || g.N == 256) &&
+  if (h->gemm_variant == GEMM_AUTO && h->out_part && !g.gn_part && g.M % 256 == 0 && px % 256 == 0 && (g.N % 144 == 0 || g.N == 256) &&
       (long)g.M * g.N < (1L << 31)) {
     const int bn = g.N % 144 == 0 ? 144 : 256;
     const int variant = bn == 144 ? GEMM_DMA3_256x144 : GEMM_DMA_256x256;
@@ -924,8 +902,7 @@ int dfot_uvit_forward_cached_masks(dfot_uvit_t h, const float* x, const float* n
   // exactly what would be recomputed: its tiles and rows are skipped on the way down.  All or nothing: a frame skipped by one stage and
   // recomputed by the next would be recomputed from stale rows, so the flags are dropped unless every convolution of the down path
   // has whole tiles per image (the largest tile is 512 rows)
-  static const int frozen_skip = tuning_flag("UVIT_FROZEN_SKIP", 1);  // A/B switch (tools/ab_8f.sh)
-  if (fresh_frames && (!frozen_skip || h->gemm_variant != GEMM_AUTO || (h->r[2] * h->r[2]) % 512 != 0)) fresh_frames = nullptr;
+  if (fresh_frames && (h->gemm_variant != GEMM_AUTO || (h->r[2] * h->r[2]) % 512 != 0)) fresh_frames = nullptr;
   for (int l = 0; l < 2; ++l) {
     for (const ResW& w : h->down_res[l])
       if ((rc = run_res_block(h, w, l, bt, s, fresh_frames))) return rc;

@@ -810,9 +810,8 @@ int dfot_op_attention_fwd_lse(const void* q, const void* k, const void* v, void*
 size_t dfot_op_attention_scratch_bytes(int batch, int heads, int n, int d) { return attention_scratch_bytes(batch, heads, n, d); }
 int dfot_op_attention_fwd_lse_bounded(const void* q, const void* k, const void* v, void* o, int ldo, float* lse, int batch, int heads, int n, int d,
                                       float score_bound, void* scratch, size_t scratch_bytes, void* stream) {
-  static const int on = tuning_flag("TRAIN_ATTN_V5", 1);
   // NaN-safe: only a bound that IS below 64 selects the kernel without a running max
-  if (on && d == 64 && n % 256 == 0 && score_bound < 64.0f && lse) {
+  if (d == 64 && n % 256 == 0 && score_bound < 64.0f && lse) {
     // the key-split partial rows live in the CALLER's buffer (one per trainer / stream: nothing is allocated on this launch path and
     // two trainers never share partial rows); a null buffer falls back to the process-wide grow-only block
     AttnScratch own{reinterpret_cast<float*>(scratch), scratch_bytes};

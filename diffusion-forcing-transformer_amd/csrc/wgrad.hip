@@ -410,10 +410,8 @@ WgradPlan wgrad_plan(int m, int n, long rows, long max_slices) {
 }
 
 // all nine taps of a 3x3 convolution's weight gradient in one launch (a = dy [pixels][co], b = x [pixels][ci], out [slices][9][co][ci]):
-// LDS-DMA form with a 128 x 128 (co, ci <= 128), 256 x 256 or the 128 x 128 register-staged tile (DFOT_WGRAD_CONV_DMA=0)
+// LDS-DMA form with a 128 x 128 (co, ci <= 128) or a 256 x 256 tile
 int launch_wgrad_conv_taps(const bf16* dy, const bf16* x, float* out, int co, int ci, long pix, int slices, int img_h, int img_w, hipStream_t s) {
-  static const int dma = tuning_flag("WGRAD_CONV_DMA", 1);
-  if (!dma) return launch_wgrad_nt(dy, co, x, ci, out, co, ci, pix, slices, s, img_h, img_w, 0, 0, 1);
   DFOT_REQUIRE(dy && x && out && co % 8 == 0 && ci % 8 == 0 && pix % 64 == 0 && pix < (1L << 31) && slices >= 1 && slices <= pix / 64 && img_h > 0 && img_w > 0 &&
                    pix % ((long)img_h * img_w) == 0,
                DFOT_ERR_SHAPE, "wgrad_conv_taps: %d -> %d channels, %ld pixels unsupported", ci, co, pix);
@@ -423,8 +421,7 @@ int launch_wgrad_conv_taps(const bf16* dy, const bf16* x, float* out, int co, in
 // workgroups per tap and slice of launch_wgrad_conv_taps, and the workgroup count to aim for with K slices (two rounds of the
 // 128 x 128 forms, two resident per CU; one round of the 256 x 256 form, whose partial outputs are four times as large)
 int wgrad_conv_tiles(int co, int ci, int* target) {
-  static const int dma = tuning_flag("WGRAD_CONV_DMA", 1);
-  const int f = (!dma || (co <= 128 && ci <= 128)) ? 128 : 256;
+  const int f = (co <= 128 && ci <= 128) ? 128 : 256;
   if (target) *target = f == 128 ? 1024 : 256;
   return ((co + f - 1) / f) * ((ci + f - 1) / f);
 }

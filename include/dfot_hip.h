@@ -80,7 +80,7 @@ int dfot_uvit_finalize(dfot_uvit_t h, void* stream);
 /* allocate activations for a model batch of up to `max_batch` videos (B*NFE) */
 int dfot_uvit_reserve(dfot_uvit_t h, int max_batch);
 size_t dfot_uvit_workspace_bytes(dfot_uvit_t h);
-/* tuning/debug switches: "gemm_variant" (-1 auto, 0..3 as in dfot_op_gemm),
+/* tuning/debug switches: "gemm_variant" (-1 auto, else a tile form as in dfot_op_gemm),
  * "attn_variant" (2 = tuned kernel (default), 0 = baseline with transposed LDS reads for V, 1 = baseline with scalar LDS reads,
  * 3 = tuned kernel with two K/V stages, 4 = two stages + per-tile Q reload (4 waves per SIMD; slower, kept for A/B)), "time_attn" (see below) */
 int dfot_uvit_set_option(dfot_uvit_t h, const char* key, int value);
@@ -275,9 +275,9 @@ int dfot_vspace_loss(const float* x, const float* noise, const float* v, const f
 
 /* ---- unit-testable primitives ------------------------------------------------------------------ */
 /* C[M,N] (fp32) = A[M,K] (bf16, row stride lda) * W[N,K]^T (bf16) + bias[N] (fp32 or NULL)
- * variant: -1 auto, 0 = 128-tile register staging, 1 = 128-tile LDS-DMA 2 stages, 2 = 128-tile LDS-DMA 3-stage ring,
- * 3 = 256x128-tile LDS-DMA 3-stage ring, 4 = 256x256 tile (16 waves), 5 = 256x128 two stages, 6 = 512x128 (16 waves);
- * variants 3-6 need M % 256 (512 for 6) == 0 */
+ * variant: -1 auto (pick by shape), 0 = 128x128 tile, register staging (independent reference), 1 = 128x128 LDS-DMA, 4 = 256x256
+ * (16 waves), 6 = 512x128 (16 waves), 8 = 128x128 with K split inside the workgroup, 9 = 256x192, 10 = 128x192, 14 = 256x144 three-stage
+ * ring; the 256-row forms need M % 256 == 0 (512 for 6).  Other numbers: DFOT_ERR_ARG */
 int dfot_op_gemm(const void* a_bf16, int lda, const void* w_bf16, const float* bias, float* c, int m, int n, int k,
                  int variant, void* stream);
 /* y[BT,H,W,Cout] (fp32) = conv3x3(pad 1)(a[BT,H,W,Cin] bf16, w[Cout][9*Cin] bf16 tap-major) + bias */

@@ -50,7 +50,7 @@ def test_state_dict_keys_match_reference_inventory(w64):
         assert tuple(sd[k].shape) == tuple(v.shape), k
 
 
-@pytest.mark.parametrize("dma,variant", [(-1, 2), (0, 1), (3, 0)])
+@pytest.mark.parametrize("dma,variant", [(-1, 2), (0, 1), (1, 0)])
 def test_backbone_vs_golden_and_oracle_taps(w64, dma, variant):
     model = make_model(w64["ocfg"], w64["params"], 64)
     model.set_option("gemm_variant", dma)

@@ -35,7 +35,7 @@ def report(name, got, ref):
     return err, rel
 
 
-@pytest.mark.parametrize("dma", [0, 1, 2, 3, 4, 5, 7, 8, 9, 10, 13, 14])
+@pytest.mark.parametrize("dma", [0, 1, 4, 8, 9, 10, 14])
 @pytest.mark.parametrize("m,n,k", [(256, 128, 64), (256, 192, 128), (1024, 576, 576), (256, 4032, 576), (768, 100, 2880),
                                    (512, 256, 192), (512, 1152, 1152)])
 def test_gemm(capi, dma, m, n, k):
