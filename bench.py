@@ -283,10 +283,12 @@ def bench_k600(args, rank, world, dist):
             dist.barrier()
         torch.cuda.synchronize()
 
+    use_graph = (GRAPH_DEFAULT or args.graph) and not args.eager
+    sampler.use_graph = use_graph
     for _ in range(args.warmup):
         run()
-    sampler.use_graph = args.graph
-    model.set_option("time_attn", 0 if args.graph or rank else args.sampling_steps * 28 * args.steps)
+    if not use_graph and rank == 0:
+        model.set_option("time_attn", args.sampling_steps * 28 * args.steps)
     sampler.window_forwards = 0
     barrier()
     t0 = time.perf_counter()
@@ -300,6 +302,14 @@ def bench_k600(args, rank, world, dist):
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     fwd = sampler.window_forwards
+    roofline_source = "HIP events around every attention launch inside the timed region (eager step loop)"
+    if use_graph and rank == 0:  # the same kernels launched eagerly once more, bracketed by events (not part of `value`)
+        sampler.use_graph = False
+        model.set_option("time_attn", args.sampling_steps * 28)
+        run()
+        torch.cuda.synchronize()
+        sampler.use_graph = True
+        roofline_source = "eager pass of one sample right after the timed region, same process (events cannot be timed inside a captured graph)"
     tokens_per_step = 3 * b  # generated latent frames per sample call (5 tokens - 2 context) x videos
     if rank == 0:
         attn_ms, attn_n = model.attn_timing()
@@ -332,7 +342,8 @@ def bench_k600(args, rank, world, dist):
                                                       "attn_kernel_v2<128,2,80,96> (DiT attention, N=1280, head dim 72 in 128-wide rows)"),
                          "achieved": achieved, "peak": 2500.0, "unit": "TFLOP/s", "frac": achieved / 2500.0 if achieved else None,
                          "traffic": k600_traffic(diff, b), "launches": attn_n, "avg_launch_ms": attn_ms / max(attn_n, 1),
-                         "flop_per_launch": flop_per_launch},
+                         "flop_per_launch": flop_per_launch, "source": roofline_source if attn_n else None},
+            "sampler_mode": "hipgraph" if use_graph else "eager",
         }
         if not args.no_cpu_baseline and world == 1:
             from oracle import dit as odit
