@@ -85,7 +85,7 @@ def test_gemm_rejects_bad_shapes(capi):
         capi.check(capi.lib.dfot_op_gemm(P(a), 64, P(a), None, P(out), 100, 64, 64, 1, S()))
 
 
-@pytest.mark.parametrize("dma", [0, 1, 2, 3, 4, 8])
+@pytest.mark.parametrize("dma", [0, 1, 4, 8])
 @pytest.mark.parametrize("bt,h,w,cin,cout", [(4, 8, 8, 128, 128), (1, 16, 16, 128, 256), (2, 8, 16, 576, 256), (4, 16, 8, 64, 100)])
 def test_conv3x3(capi, dma, bt, h, w, cin, cout):
     g = torch.Generator().manual_seed(bt * 1000 + cin + cout)

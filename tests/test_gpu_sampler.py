@@ -273,6 +273,42 @@ def test_hipgraph_step_replay_matches_eager():
     assert torch.equal(outs[0], outs[1])
 
 
+def test_hipgraph_is_the_default_and_follows_a_weight_reload():
+    """round 4: the hipGraph step loop is the sampler's DEFAULT mode.  A captured graph bakes weight-dependent kernel choices (the
+    level-2 attention variant follows the QK-norm bound) and device pointers, so re-loaded weights or a changed engine option must drop
+    it: sample, load other weights whose bound crosses 64, sample again -- the second result equals the eager result on the NEW
+    weights bit for bit and a new capture was taken."""
+    import dfot_amd
+    from dfot_amd import parallel
+    from oracle import uvit as ouvit
+    ocfg, params, model = build(blocks=(1, 1, 1), mid=2)
+    res = 64
+    xs = torch.randn(1, 8, 3, res, res, generator=torch.Generator().manual_seed(3))
+    cnd = poses(1, 8, 4)
+    cfg = dfot_amd.SamplerConfig(x_shape=(3, res, res), diffusion=dfot_amd.DiffusionConfig(sampling_timesteps=5),
+                                 prediction_guidance=dict(name="vanilla", guidance_scale=4.0))
+    samp = dfot_amd.DFoTVideoPoseSampler(cfg, model, parallel.WindowKeyedNoise(7))
+    assert samp.use_graph is True
+    out_a = samp._predict_videos(xs, n_context_tokens=1, conditions=cnd).cpu()
+    assert samp.graph_captures == 1 and samp.graph_replays == 4
+    assert model.query("attn_kernel_l2") == 14
+    new = {n: (t * 2.4 if n.endswith(("q_norm.weight", "k_norm.weight")) else t.clone()) for n, t in params.items()}
+    model.load_state_dict(new, strict=True)
+    samp.noise_fn = parallel.WindowKeyedNoise(7)
+    out_b = samp._predict_videos(xs, n_context_tokens=1, conditions=cnd).cpu()
+    assert samp.graph_captures == 2 and model.query("attn_kernel_l2") == 5   # recaptured on the running-max kernel
+    samp.use_graph = False
+    samp.noise_fn = parallel.WindowKeyedNoise(7)
+    ref_b = samp._predict_videos(xs, n_context_tokens=1, conditions=cnd).cpu()
+    assert torch.equal(out_b, ref_b) and not torch.equal(out_a, out_b)
+    # an engine option that selects kernels invalidates the capture as well
+    samp.use_graph = True
+    model.set_option("attn_force_safe", 1)
+    samp.noise_fn = parallel.WindowKeyedNoise(7)
+    samp._predict_videos(xs, n_context_tokens=1, conditions=cnd)
+    assert samp.graph_captures == 3
+
+
 def _sample_pair(scheme, length, mask_row, steps=2, batch=2, seed=21):
     """one _sample_sequence window on both paths with identical noise; returns (engine, oracle)"""
     import dfot_amd
