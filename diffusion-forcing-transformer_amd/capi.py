@@ -89,6 +89,7 @@ SIGNATURES = {
     "dfot_dit_train_reserve": (_I, [_P, _I]),
     "dfot_dit_train_sync_weights": (_I, [_P, _P]),
     "dfot_dit_train_forward": (_I, [_P, _P, _P, _P, _I, _I, _P]),
+    "dfot_dit_train_input_grad": (_I, [_P, _P, _P]),
     "dfot_dit_train_backward": (_I, [_P, _P, _P]),
     "dfot_vloss_grad": (_I, [_P] * 7 + [_I, _I, _L, _I, _P]),
     "dfot_sumsq": (_I, [_P, _L, _P, _P]),

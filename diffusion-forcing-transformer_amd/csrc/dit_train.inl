@@ -481,6 +481,23 @@ __global__ __launch_bounds__(256) void pe_wgrad_kernel(const float* __restrict__
   }
   prow[(long)hidden * kdim + o] = bsum;
 }
+// data gradient of the patch embedding (a Conv2d with stride = kernel = patch): dx[bt][ci][gy*ps+py][gx*ps+px] = sum_o dy[row][o] w[o][kk]
+// with kk = (ci, py, px); one thread per (token row, kk), the row's dy broadcast over its kk threads, the weights coalesced over kk
+__global__ __launch_bounds__(256) void pe_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ w, float* __restrict__ dx, int c, int hh,
+                                                       int ww, int ps, int hidden, long rows) {
+  const int kdim = c * ps * ps, gh = hh / ps, gw = ww / ps;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= rows * kdim) return;
+  const long row = i / kdim;
+  const int kk = (int)(i % kdim);
+  const float* d = dy + row * hidden;
+  float acc = 0.f;
+  for (int o = 0; o < hidden; ++o) acc += d[o] * w[(long)o * kdim + kk];
+  const long bt = row / (gh * gw);
+  const int g = (int)(row % (gh * gw)), gy = g / gw, gx = g % gw;
+  const int ci = kk / (ps * ps), py = (kk / ps) % ps, px = kk % ps;
+  dx[((bt * c + ci) * hh + gy * ps + py) * ww + gx * ps + px] = acc;
+}
 // dW [hidden][kdim] += , db [hidden] += , deterministic (one partial row per workgroup and thread group + det_sum)
 static int launch_pe_wgrad(const float* dx0, const float* x, float* dW, float* db, int c, int hh, int ww, int ps, int hidden, long rows, hipStream_t s) {
   const int kdim = c * ps * ps;
@@ -711,6 +728,7 @@ struct dfot_dit_train_s {
   int max_batch = 0, fp = 0, batch = 0, tokens = 0;
   int* idx = nullptr;
   const float* x_saved = nullptr;  // the forward's input (caller keeps it alive until backward)
+  const float* d_embed = nullptr;  // after a backward: gradient w.r.t. the patch-embedding output [rows][hidden] (for input_grad)
   float *feat = nullptr, *h1 = nullptr, *a1 = nullptr, *cemb = nullptr, *mod_table = nullptr, *X = nullptr, *x_fin = nullptr;
   dfot::bf16* semb = nullptr;
   float *dX = nullptr, *dX2 = nullptr, *stats = nullptr, *delta = nullptr, *dmod = nullptr, *dsemb = nullptr, *dwf = nullptr;
@@ -1147,6 +1165,7 @@ int dfot_dit_train_forward(dfot_dit_train_t h, const float* x, const int32_t* no
   const float* p = h->params_f32;
   int rc = 0;
   h->batch = batch; h->tokens = tokens; h->x_saved = x;
+  h->d_embed = nullptr;
   // ---- conditioning: c = Linear2(SiLU(Linear1(features(level)))) [+ diff embedding] per frame; table = Linear_mod(SiLU(c)) ----
   hipLaunchKernelGGL(iota_kernel, dim3(cdiv(frames, 256)), dim3(256), 0, s, h->idx, frames);
   hipLaunchKernelGGL(tr_features_kernel, dim3(cdiv((long)frames * nd, 256)), dim3(256), 0, s, h->freqs, noise_levels, h->feat, frames, nd, c.timesteps - 1);
@@ -1352,6 +1371,7 @@ int dfot_dit_train_backward(dfot_dit_train_t h, const float* d_out, void* stream
   // ---- patch embedding ----
   launch_pe_wgrad(dY, h->x_saved, G + h->o_pe_w, G + h->o_pe_b, c.in_channels, c.height, c.width, c.patch_size, hd, rows, s);
   DFOT_CHECK_HIP(hipGetLastError());
+  h->d_embed = dY;  // gradient w.r.t. the patch-embedding output: dfot_dit_train_input_grad turns it into d / d x
 
   // ---- modulation Linears: table = SiLU(c) W_mod^T + b_mod over the frames ----
   hipLaunchKernelGGL(frames_colsum_kernel, dim3(cdiv(h->ldt, 256)), dim3(256), 0, s, h->dmod, h->dbmod, frames, h->ldt);
@@ -1384,6 +1404,21 @@ int dfot_dit_train_backward(dfot_dit_train_t h, const float* d_out, void* stream
   hipLaunchKernelGGL(small_dgrad_kernel, dim3(cdiv(fh, 256)), dim3(256), 0, s, h->dc, p + h->o_t_w2, h->da1, frames, hd, hd);
   hipLaunchKernelGGL(silu_bwd_kernel, dim3(cdiv(fh, 256)), dim3(256), 0, s, h->da1, h->h1, h->dh1, fh);
   hipLaunchKernelGGL(small_wgrad_kernel, dim3(cdiv((long)hd * nd, 256)), dim3(256), 0, s, h->dh1, h->feat, G + h->o_t_w1, G + h->o_t_b1, frames, hd, nd);
+  DFOT_CHECK_HIP(hipGetLastError());
+  return DFOT_OK;
+}
+
+// d(sum(out * d_out)) / d x for the last forward / backward pair: the data gradient of the patch embedding.  What reconstruction
+// guidance differentiates (discrete_diffusion.py:485-513: the prediction w.r.t. x_t); the positional embedding and the noise-level
+// path do not depend on x.
+int dfot_dit_train_input_grad(dfot_dit_train_t h, float* dx, void* stream) {
+  DFOT_REQUIRE(h && dx, DFOT_ERR_ARG, "train_input_grad: null argument");
+  DFOT_REQUIRE(h->batch > 0 && h->d_embed, DFOT_ERR_STATE, "train_input_grad: run dfot_dit_train_backward first");
+  const dfot_dit_config& c = h->cfg;
+  const long rows = (long)h->batch * h->tokens * h->P;
+  const int kdim = c.in_channels * c.patch_size * c.patch_size;
+  hipLaunchKernelGGL(pe_dgrad_kernel, dim3(cdiv(rows * kdim, 256)), dim3(256), 0, (hipStream_t)stream, h->d_embed, h->params_f32 + h->o_pe_w, dx,
+                     c.in_channels, c.height, c.width, c.patch_size, c.hidden_size, rows);
   DFOT_CHECK_HIP(hipGetLastError());
   return DFOT_OK;
 }

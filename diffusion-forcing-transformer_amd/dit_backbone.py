@@ -177,7 +177,7 @@ class DiT3D(nn.Module):
         if self._op_key is None:
             self._op_key = ops.register_model(self)
         params = [p for _, p in self.named_parameters()]
-        if torch.is_grad_enabled() and any(p.requires_grad for p in params):
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params)):
             # the reference's training_step differentiates through `self.model(...)` (discrete_diffusion.py model_predictions ->
             # accelerator.backward): saved-activation forward + the hand-written backward, registered with autograd (ops.py)
             return torch.ops.dfot.dit3d_forward_train(x, noise_levels, params, self._op_key)
@@ -217,7 +217,7 @@ class DiT3D(nn.Module):
         with torch.no_grad():
             return self._train_engine(params).forward(x, noise_levels).to(x.dtype)
 
-    def _train_backward_impl(self, grad_out, params, stamp=None):
+    def _train_backward_impl(self, grad_out, params, stamp=None, want_dx=False):
         eng = self._trainer
         if eng is None:
             raise RuntimeError("backward without a training forward")
@@ -227,8 +227,11 @@ class DiT3D(nn.Module):
                 "activations (one engine per module). Run backward after each forward (accumulate gradients as forward/backward pairs).")
         with torch.no_grad():
             eng.backward(grad_out)
-            return [eng.view(n, eng.grads).to(p.dtype).clone() if n in eng.layout else torch.zeros_like(p)
-                    for n, p in zip(self._train_names, params)]
+            grads = [eng.view(n, eng.grads).to(p.dtype).clone() if n in eng.layout else torch.zeros_like(p)
+                     for n, p in zip(self._train_names, params)]
+            if want_dx:  # reconstruction guidance differentiates the prediction w.r.t. x_t (discrete_diffusion.py:485-513)
+                grads.append(eng.input_grad().to(grad_out.dtype))
+            return grads
 
     def _forward_impl(self, x: torch.Tensor, noise_levels: torch.Tensor) -> torch.Tensor:
         if x.ndim != 5 or tuple(x.shape[2:]) != self.x_shape:

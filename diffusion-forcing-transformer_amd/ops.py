@@ -128,13 +128,13 @@ def _(x, noise_levels, params, model):
 
 
 @custom_op("dfot::dit3d_backward", mutates_args=())
-def dit3d_backward(grad_out: Tensor, params: List[Tensor], model: int, stamp: int) -> List[Tensor]:
-    return _model(model)._train_backward_impl(grad_out, params, stamp)
+def dit3d_backward(grad_out: Tensor, params: List[Tensor], model: int, stamp: int, want_dx: bool = False) -> List[Tensor]:
+    return _model(model)._train_backward_impl(grad_out, params, stamp, want_dx)
 
 
 @dit3d_backward.register_fake
-def _(grad_out, params, model, stamp):
-    return [torch.empty_like(p) for p in params]
+def _(grad_out, params, model, stamp, want_dx=False):
+    return [torch.empty_like(p) for p in params] + ([torch.empty_like(grad_out)] if want_dx else [])
 
 
 def _dit_train_setup_context(ctx, inputs, output):
@@ -144,8 +144,12 @@ def _dit_train_setup_context(ctx, inputs, output):
 
 
 def _dit_train_backward(ctx, grad_out):
-    grads = torch.ops.dfot.dit3d_backward(grad_out.contiguous(), ctx.params, ctx.model, ctx.stamp)
-    return None, None, grads, None
+    want_dx = bool(ctx.needs_input_grad[0])
+    grads = torch.ops.dfot.dit3d_backward(grad_out.contiguous(), ctx.params, ctx.model, ctx.stamp, want_dx)
+    dx = None
+    if want_dx:
+        dx, grads = grads[-1], grads[:-1]
+    return dx, None, grads, None
 
 
 dit3d_forward_train.register_autograd(_dit_train_backward, setup_context=_dit_train_setup_context)

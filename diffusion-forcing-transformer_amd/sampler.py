@@ -559,7 +559,7 @@ class DFoTVideoPoseSampler:
         gradient of  rg/2 * sum( (pred_x0 - context)^2 * sqrt(alphas_cumprod) * [mask != 0] / #[mask != 0] )  shifts the predicted noise:
         eps' = eps + sqrt(1 - ac) * grad,  x0' = (x - sqrt(1 - ac) eps') / sqrt(ac).  For the v-objective that is exactly the ordinary
         step on  v' = v + sqrt(1 - ac) / sqrt(ac) * grad  (eps = sqrt(ac) v + sqrt(1 - ac) x), so v' goes into the fused composition
-        kernel; where alphas_cumprod = 0 the reference keeps the unguided x0 and this keeps the unguided v.  The few elementwise
+        kernel (the alphas_cumprod = 0 level is handled through the step's output, see the end of this function).  The few elementwise
         steps around the backbone run as torch ops under autograd, as in the reference; one-branch guidance only (the reference
         compares the (B * NFE, ...) prediction with the (B, ...) context)."""
         if nfe != 1:
@@ -577,7 +577,13 @@ class DFoTVideoPoseSampler:
             cm = ext((gen_dev == 0).to(torch.float32))
             loss = torch.sum((pred_x0 - ctx) ** 2 * sa * cm / cm.sum(dim=1, keepdim=True).clamp(min=1))
             grad = torch.nan_to_num(-torch.autograd.grad(-rg * 0.5 * loss, x)[0], nan=0.0)
-        scale = torch.where(sa > 0, s1 / sa.clamp(min=1e-30), torch.zeros_like(sa))
+        # sa > 0: v' = v + (s1 / sa) grad reproduces the reference's guided eps AND the x0 recomputed from it.  sa = 0 (zero terminal SNR,
+        # the first step of the K600 cosine schedule): the reference keeps the unguided x0 but still uses the guided eps' = eps + s1 grad,
+        # which no v can express (eps = sa v + s1 x does not depend on v there).  The step's OUTPUT an x0 + cn eps' is linear in v,
+        # d out / d v = cn sa - an s1 = -an s1, so v' = v - (cn / an) grad yields exactly the reference's x_pred (an = sqrt of the next
+        # level's alphas_cumprod > 0); x0 / eps are not used anywhere else in a one-branch step.
+        an, cn = ext(tables[4]), ext(tables[5])
+        scale = torch.where(sa > 0, s1 / sa.clamp(min=1e-30), torch.where(an > 0, -cn / an.clamp(min=1e-30), torch.zeros_like(sa)))
         return (v.detach() + scale * grad).contiguous()
 
     @staticmethod

@@ -142,6 +142,12 @@ class DiT3DTrainer:
         g = d_out.to(device="cuda", dtype=torch.float32).contiguous()
         capi.check(capi.lib.dfot_dit_train_backward(self._handle, capi.ptr(g), capi.stream_ptr()))
 
+    def input_grad(self) -> torch.Tensor:
+        """d(sum(out * d_out)) / d x of the last forward / backward pair, in x's layout (reconstruction guidance, discrete_diffusion.py:485-513)"""
+        dx = torch.empty_like(self._keep[0])
+        capi.check(capi.lib.dfot_dit_train_input_grad(self._handle, capi.ptr(dx), capi.stream_ptr()))
+        return dx
+
     # ------------------------------------------------------------------ one training step
     def loss_and_grads(self, xs: torch.Tensor, k: torch.Tensor, noise: torch.Tensor, masks: Optional[torch.Tensor] = None):
         """DiscreteDiffusion.forward (pred_v) + _reweight_loss + backward: noise every token to its level, one forward, the

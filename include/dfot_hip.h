@@ -209,6 +209,9 @@ int dfot_dit_train_sync_weights(dfot_dit_train_t h, void* stream);
 int dfot_dit_train_forward(dfot_dit_train_t h, const float* x, const int32_t* noise_levels, float* out, int batch, int tokens, void* stream);
 /* grads <- d(sum(out * d_out))/d(params) for the last forward (overwrites the attached gradient buffer) */
 int dfot_dit_train_backward(dfot_dit_train_t h, const float* d_out, void* stream);
+/* dx[B,T,C,H,W] <- d(sum(out * d_out))/d(x) of the same forward / backward pair (call after dfot_dit_train_backward): what autograd gives
+ * `x.grad` when x requires it -- reconstruction guidance differentiates the prediction w.r.t. x_t (discrete_diffusion.py:485-513) */
+int dfot_dit_train_input_grad(dfot_dit_train_t h, float* dx, void* stream);
 /* dv[B,T,F] = coef[b,t] * d/dv of the loss term of dfot_vspace_loss (vspace = 1) / dfot_vpred_loss (vspace = 0) */
 int dfot_vloss_grad(const float* x, const float* noise, const float* v, const float* a, const float* sigma, const float* coef, float* dv,
                     int batch, int tokens, int64_t frame_elems, int vspace, void* stream);

@@ -517,3 +517,83 @@ def test_sampler_k600_depth28_50_steps_vs_fp32_oracle():
     print("K600 DiT/XL depth 28, 50 steps: PSNR %.1f dB; rel-L2 of the window state at steps 1/10/25/40/last: %s"
           % (p, " ".join("%.2e" % drift[i] for i in (0, 9, 24, 39, len(drift) - 1))))
     assert torch.isfinite(out).all() and p >= 35.0
+
+
+# ---- round 4: d loss / d x of the DiT family (VERDICT r3 missing #4: reconstruction guidance beyond UViT3DPose) ---------------------
+@pytest.mark.parametrize("family", ["dit", "diffdit"])
+def test_dit_input_gradient_matches_fp32_autograd(family):
+    """x.grad of the autograd drop-in for DiT3D and DifferenceDiT3D (`dfot_dit_train_input_grad`: the patch embedding's data gradient
+    behind the hand-written backward) vs torch autograd through the oracle in fp32; parameter gradients still land next to it."""
+    from oracle import dit as odit
+    if family == "dit":
+        ocfg = tiny_cfgs()[0]
+        params, model = build(ocfg, 6)
+        fwd = lambda ps, x, k: odit.forward(ps, ocfg, x, k)
+        tokens = ocfg.max_tokens
+    else:
+        ocfg = odit.DiffDiTConfig(hidden_size=128, depth=2, num_heads=4, in_channels=4, resolution=(16, 8), embed_col_dim=64, num_row_heads=4)
+        params, model = build_diff(ocfg, 6)
+        fwd = lambda ps, x, k: odit.diff_forward(ps, ocfg, x, k)
+        tokens = 2 * ocfg.max_tokens
+    model.train()
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(2, tokens, ocfg.in_channels, *ocfg.resolution, generator=g)
+    k = torch.randint(0, 1000, (2, tokens), generator=g)
+    w = torch.randn(x.shape, generator=g)
+    xd = x.cuda().requires_grad_()
+    v = model(xd, k.cuda())
+    (v * w.cuda()).sum().backward()
+    ps = {n: t.clone().requires_grad_() for n, t in params.items()}
+    xr = x.clone().requires_grad_()
+    (fwd(ps, xr, k) * w).sum().backward()
+    r = ((xd.grad.cpu() - xr.grad).norm() / xr.grad.norm()).item()
+    print(f"{family}: d loss / d x rel-L2 vs fp32 autograd {r:.2e}")
+    assert xd.grad is not None and torch.isfinite(xd.grad).all() and r < 3e-2
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.parameters())
+
+
+def test_reconstruction_guidance_k600_matches_the_oracle():
+    """Reconstruction guidance (dfot_video.py:700-723, discrete_diffusion.py:485-513) on the Kinetics-600 path: DiT3D, cosine discrete
+    schedule, conditional (one-branch) history guidance, 3 DDIM steps; engine vs oracle.sampler (autograd through oracle.dit in fp32) on
+    replayed noise; the guided sample differs from the unguided one by far more than the engine's distance to the oracle."""
+    import dfot_amd
+    from oracle import dit as odit, sampler as osm, schedule as sch
+    ocfg = odit.DiTConfig(hidden_size=256, depth=3, num_heads=4, in_channels=4, resolution=(16, 8), max_tokens=5)
+    params, model = build(ocfg, 8)
+    gen = torch.Generator().manual_seed(12)
+    xs = torch.randn(2, 5, 4, 16, 8, generator=gen)
+    steps, rg = 3, 3.0e4  # (this small random model's prediction barely depends on x_t: a weight large enough for a visible pull)
+    hgd = dict(name="conditional")
+    outs = {}
+    for wgt in (rg, 0.0):
+        draws = []
+
+        class Rec:
+            strict_order = True
+
+            def __init__(self):
+                self.g = torch.Generator().manual_seed(31)
+
+            def __call__(self, tag, shape):
+                t = torch.randn(shape, generator=self.g)
+                draws.append(t)
+                return t if tag == "excluded" else t.clamp(-20, 20)
+        diff = osm.Diffusion(sch.build_tables(beta_schedule="cosine"), lambda x, k, c, m: odit.forward(params, ocfg, x, k),
+                             sampling_timesteps=steps, is_continuous=False)
+        ref = osm.Sampler(osm.SamplerConfig(x_shape=(4, 16, 8), max_tokens=5, sampling_timesteps=steps, prediction_guidance=hgd,
+                                            reconstruction_guidance=wgt), diff, None, Rec()).predict_videos(xs, 2, None).detach()
+        cfg = dfot_amd.SamplerConfig(x_shape=(4, 16, 8), max_tokens=5, prediction_guidance=hgd,
+                                     diffusion=dfot_amd.DiffusionConfig(sampling_timesteps=steps, beta_schedule="cosine", is_continuous=False,
+                                                                        reconstruction_guidance=wgt))
+        nfn = ReplayList(draws)
+        out = dfot_amd.DFoTVideoSampler(cfg, model, nfn)._predict_videos(xs.cuda(), n_context_tokens=2, conditions=None).cpu()
+        assert not nfn.queue
+        outs[wgt] = (out, ref)
+    out, ref = outs[rg]
+    rel = ((out - ref).norm() / ref.norm()).item()
+    moved = ((ref - outs[0.0][1]).norm() / ref.norm()).item()
+    d_e, d_o = out - outs[0.0][0], ref - outs[0.0][1]
+    drel = ((d_e - d_o).norm() / d_o.norm()).item()
+    print(f"K600 reconstruction guidance {rg}: engine vs oracle rel-L2 {rel:.3e}, PSNR {psnr(out, ref):.1f} dB; guided vs unguided {moved:.3e}; "
+          f"guidance-induced shift engine vs oracle {drel:.3e}")
+    assert torch.isfinite(out).all() and psnr(out, ref) >= 35.0 and rel < 3e-2 and moved > 5 * rel and drel < 0.1

@@ -258,3 +258,27 @@ def test_training_gradients_vs_reference_fixture():
         for key in stored:
             n = key.split("/", 1)[1]
             torch.testing.assert_close(ps[n].grad, T(g[key]), rtol=2e-3, atol=1e-6 + 2e-4 * float(T(g[key]).abs().max()))
+
+
+def test_reconstruction_guidance_discrete_vs_reference_run():
+    """cfg.diffusion.reconstruction_guidance > 0 on the DISCRETE cosine schedule (dfot_video.py:700-723, discrete_diffusion.py:485-513):
+    the reference's own `DFoTVideo._predict_videos`, recorded with its draws (sampler_recon_k600.npz).  The first DDIM step is at the
+    zero-terminal-SNR level, where the reference keeps the unguided x0 and still shifts the predicted noise -- the branch the
+    continuous fixture never reaches.  Pins the oracle there; the guided run differs from the unguided one far beyond the tolerance."""
+    g = load("sampler_recon_k600.npz")
+    p = odit.seeded_params(SMALL, 2)
+    assert digest(p) == str(g["digest"])
+    tb = sch.build_tables(beta_schedule="cosine")
+    outs = {}
+    for tag, w in (("rg", float(g["weight"])), ("plain", 0.0)):
+        noise = [T(g[f"{tag}_noise{i}"]) for i in range(int(g[f"{tag}_n_noise"]))]
+        nfn = osm.replay_noise_fn(noise)
+        cfg = osm.SamplerConfig(x_shape=(4, 16, 8), max_tokens=5, sampling_timesteps=3, prediction_guidance=dict(name="conditional"),
+                                reconstruction_guidance=w)
+        diff = osm.Diffusion(tb, lambda x, k, c, m: odit.forward(p, SMALL, x, k), sampling_timesteps=3, is_continuous=False)
+        out = osm.Sampler(cfg, diff, None, nfn).predict_videos(T(g["xs"]), 2, None).detach()
+        assert not nfn.queue
+        np.testing.assert_allclose(out.numpy(), g[f"{tag}_out"], rtol=1e-3, atol=2e-3)
+        outs[tag] = out
+    moved = float((outs["rg"] - outs["plain"]).norm() / outs["plain"].norm())
+    assert moved > 5e-3, moved

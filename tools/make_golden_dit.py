@@ -310,10 +310,43 @@ def diff_sampler_fixture(R):
          digest=np.array(weights_digest(ps)), **arrays)
 
 
-@torch.no_grad()
+def recon_k600_fixture(R):
+    """sampler_recon_k600.npz: the reference's own `DFoTVideo._predict_videos` on the DISCRETE cosine schedule with
+    cfg.diffusion.reconstruction_guidance > 0 (dfot_video.py:700-723, discrete_diffusion.py:485-513).  The first DDIM step sits at
+    the zero-terminal-SNR level (alphas_cumprod = 0), where the reference keeps the unguided x0 but still shifts the predicted noise:
+    the branch the continuous fixture (sampler_recon.npz) never reaches.  Tiny DiT3D, conditional (one-branch) guidance, 2 context
+    tokens, 3 DDIM steps, every normal draw recorded; plus the same run without guidance."""
+    print("reconstruction guidance, discrete cosine schedule")
+    A = R["AttrDict"]
+    small = odit.DiTConfig(hidden_size=128, depth=2, num_heads=4, patch_size=1, in_channels=4, resolution=(16, 8), max_tokens=5)
+    ps = odit.seeded_params(small, 2)
+    g = torch.Generator().manual_seed(19)
+    vid = torch.randn(2, 5, 4, 16, 8, generator=g)
+    out = dict(xs=vid, weight=np.array(3.0e4), digest=np.array(weights_digest(ps)))
+    for tag, w in (("rg", 3.0e4), ("plain", 0.0)):
+        cfg = video_cfg(A, small, sampling_steps=3, hg=dict(name="conditional"))
+        cfg.diffusion["reconstruction_guidance"] = w
+        algo = R["DFoTVideo"](cfg).eval()
+        algo.diffusion_model.model.load_state_dict(ps, strict=True)
+        algo.generator = torch.Generator().manual_seed(0)
+        with RandnRecorder() as rec:
+            res = algo._predict_videos(vid.clone(), n_context_tokens=2, conditions=None)
+        assert torch.isfinite(res).all()
+        out.update({f"{tag}_out": res.detach(), f"{tag}_n_noise": np.array(len(rec.draws))})
+        out.update({f"{tag}_noise{i}": d for i, d in enumerate(rec.draws)})
+    save("sampler_recon_k600.npz", **out)
+
+
 def main():
     R = ref_loader.install()
     A = R["AttrDict"]
+    if os.environ.get("ONLY") == "recon_k600":
+        return recon_k600_fixture(R)  # (differentiates the prediction w.r.t. x_t: not under no_grad)
+    with torch.no_grad():
+        return _main_no_grad(R, A)
+
+
+def _main_no_grad(R, A):
     if os.environ.get("ONLY") == "refine":
         return refine_fixture(R)
     if os.environ.get("ONLY") == "training_grads":
