@@ -743,6 +743,8 @@ def main():
         if not args.no_cpu_baseline and world == 1 and not args.dry_run:  # reported baseline: rank 0 at N=1 only
             line["cpu_baseline"] = cpu_baseline(res, 1, frames_per_sample, fwd // args.steps)
         line["sampler_mode"] = "dry-run (host plumbing only, nothing launched)" if args.dry_run else ("hipgraph" if sampler.use_graph else "eager")
+        if sampler.use_graph and not args.dry_run:  # captures paid (once per window shape) and steps replayed, warm-up included
+            line["graph_captures"], line["graph_step_replays"] = sampler.graph_captures, sampler.graph_replays
         if ranks_identical is not None:
             line["ranks_bit_identical"] = ranks_identical
         print(json.dumps(line), flush=True)
