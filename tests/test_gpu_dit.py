@@ -63,7 +63,7 @@ def tiny_cfgs():
 
 
 @pytest.mark.parametrize("d,heads,n,batch", [(72, 16, 1280, 2), (32, 4, 640, 3), (64, 2, 256, 1), (96, 2, 384, 1), (120, 1, 128, 2), (72, 16, 1280, 8),
-                                             (128, 9, 2048, 2)])
+                                             (128, 9, 2048, 2), (96, 12, 256, 5), (128, 3, 256, 2), (72, 4, 256, 3), (100, 2, 256, 1)])
 def test_attention_padded(d, heads, n, batch):
     from dfot_amd import capi
     g = torch.Generator().manual_seed(d)
@@ -89,7 +89,7 @@ def test_attention_padded(d, heads, n, batch):
 
 
 @pytest.mark.parametrize("d,heads,n,batch,big", [(72, 16, 1280, 8, False), (128, 9, 2048, 8, False), (96, 16, 256, 16, False), (80, 8, 512, 20, True),
-                                                 (128, 5, 768, 21, False)])
+                                                 (128, 5, 768, 21, False), (96, 12, 256, 30, True)])
 def test_attention_d128_rows_large_launches(d, heads, n, batch, big):
     """attention over 128-element rows (`attn_kernel_v2<128>` and its DiT head-dim instances) at launch sizes of several workgroup
     rounds, output AND log-sum-exp (training entry), including scores far outside the deferred-rescale threshold (`big`: |s| up to ~60
