@@ -166,7 +166,7 @@ def bench_train_k600(args, rank, world, dist):
         line = {
             "metric": "training samples/sec, DFoT K600 %s (AdamW, data parallel)" % ("DifferenceDiT3D FacMat XL-64-1 (bash/k600)" if diff else "DiT/XL (per-token independent noise levels)"),
             "value": b * args.steps * world / dt, "unit": "videos/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "rccl_ranks": (dist.get_world_size() if dist is not None else 1),
             "data": "synthetic latents, seeded random-init weights",
             "config": {"workload": (f"DFoT K600 bash/k600 difference_dit3d factorized_matrix_attention XL-64-1 training step: {b} videos per GPU, latents "
                                     "16x16x16, 5 frames -> 10 merged (difference, frame) tokens, random_uniform levels + variable context, " if diff else
@@ -235,7 +235,7 @@ def bench_train_re10k(args, rank, world, dist):
         line = {
             "metric": "training samples/sec, DFoT RE10K UViT3DPose (per-token independent noise levels, AdamW, data parallel)",
             "value": b * args.steps * world / dt, "unit": "videos/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "rccl_ranks": (dist.get_world_size() if dist is not None else 1),
             "data": "synthetic frames and camera poses, seeded random-init weights",
             "config": {"workload": f"DFoT RE10K training step (BASELINE config 5): {b} videos x 8 frames x {args.res}x{args.res} per GPU, UViT3DPose "
                                    "(channels 128/256/576/1152, 3+3+6 / 20 blocks), random_independent continuous levels, sigmoid-weighted v-loss, AdamW lr 5e-5 "
@@ -331,7 +331,7 @@ def bench_k600(args, rank, world, dist):
         line = {
             "metric": "denoised latent frames/sec, DFoT K600 (%s) 17-frame prediction" % ("DifferenceDiT3D FacMat XL-64-1" if diff else "DiT/XL"), "value": tokens_per_step * args.steps * world / dt,
             "unit": "latent frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "rccl_ranks": (dist.get_world_size() if dist is not None else 1),
             "data": "synthetic latents, seeded random-init weights",
             "config": {"workload": f"DFoT K600 {'bash/k600 difference_dit3d factorized_matrix_attention XL-64-1 (1358 M params)' if diff else '@DiT/XL'}: {b} videos per GPU, latents 16x16x16, 5 tokens (17 frames), context 2 tokens, "
                                    f"{args.sampling_steps} DDIM steps, conditional history guidance (NFE 1)",
