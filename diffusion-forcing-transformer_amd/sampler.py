@@ -657,7 +657,9 @@ class DFoTVideoPoseSampler:
         if ent["graph"] is None:
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            # thread-local capture mode: with a process group alive (sharded rollouts) the RCCL watchdog thread polls events while this
+            # thread captures; in the default "global" mode such calls from other threads invalidate the capture
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                 x = ent["xs"]
                 for i in range(1, n_steps):
                     x = step(p_static, x, ent["noise"][i] if need_noise else None, ent["tables"][i], ent["gens"][i], live_dev=ent["lives"][i],
