@@ -216,7 +216,7 @@ __global__ __launch_bounds__(256, (DC <= 96 ? 2 : 1)) void attn_bwd_dkv_kernel(c
       const bf16 z = f2bf(0.f);
       ro[i] = col < d ? *reinterpret_cast<const bf16x8*>(Ob + (long)(t * C::TR + row) * ldo + col) : bf16x8{z, z, z, z, z, z, z, z};
     }
-    if (tid < 2 * C::TR) rs = tid < C::TR ? Lb[t * C::TR + tid] : Db[t * C::TR + tid - C::TR];
+    if (tid < 2 * C::TR) rs = -(tid < C::TR ? Lb[t * C::TR + tid] : Db[t * C::TR + tid - C::TR]);  // negated: read straight into the accumulators
   };
   auto store = [&](int stage) {
     char* b = smem + stage * STAGE;
@@ -237,15 +237,19 @@ __global__ __launch_bounds__(256, (DC <= 96 ? 2 : 1)) void attn_bwd_dkv_kernel(c
     bf16x8 pf[2][2], dsf[2][2];
 #pragma unroll
     for (int kt2 = 0; kt2 < 2; ++kt2) {
-      f32x16 sacc, pacc;
-      // accumulators start at -L2[q] / -delta[q] of their row: q = kt2*32 + 8g + 4h + j
+      // accumulators start at -L2[q] / -delta[q] of their row (q = kt2*32 + 8g + 4h + j; the LDS copies are negated): the four 16-byte
+      // reads ARE the accumulator tuple -- no move, no negation on the vector pipe
+      f32x4 l4[4], d4[4];
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const f32x4 l4 = *reinterpret_cast<const f32x4*>(sl + kt2 * 32 + 8 * g + 4 * lh);
-        const f32x4 d4 = *reinterpret_cast<const f32x4*>(sd + kt2 * 32 + 8 * g + 4 * lh);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { sacc[4 * g + j] = -l4[j]; pacc[4 * g + j] = -d4[j]; }
+        l4[g] = *reinterpret_cast<const f32x4*>(sl + kt2 * 32 + 8 * g + 4 * lh);
+        d4[g] = *reinterpret_cast<const f32x4*>(sd + kt2 * 32 + 8 * g + 4 * lh);
       }
+      typedef __attribute__((ext_vector_type(8))) float f32x8;
+      f32x16 sacc = __builtin_shufflevector(__builtin_shufflevector(l4[0], l4[1], 0, 1, 2, 3, 4, 5, 6, 7), __builtin_shufflevector(l4[2], l4[3], 0, 1, 2, 3, 4, 5, 6, 7),
+                                            0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+      f32x16 pacc = __builtin_shufflevector(__builtin_shufflevector(d4[0], d4[1], 0, 1, 2, 3, 4, 5, 6, 7), __builtin_shufflevector(d4[2], d4[3], 0, 1, 2, 3, 4, 5, 6, 7),
+                                            0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
       const int row = kt2 * 32 + lq;
 #pragma unroll
       for (int ks = 0; ks < DC / 16; ++ks) {
@@ -527,7 +531,7 @@ __global__ __launch_bounds__(256, (DC <= 96 ? 2 : 1)) void attn_bwd_dkv_dma_kern
   auto issue = [&](int t, int stage) {
     char* sq = smem + stage * STAGE;
     char* so = sq + C::TILE;
-    if (tid < 2 * C::TR) rs = tid < C::TR ? Lb[t * C::TR + tid] : Db[t * C::TR + tid - C::TR];  // before the DMAs: its wait leaves them in flight
+    if (tid < 2 * C::TR) rs = -(tid < C::TR ? Lb[t * C::TR + tid] : Db[t * C::TR + tid - C::TR]);  // negated; before the DMAs: its wait leaves them in flight
     const bf16* qt = Qb + (long)t * C::TR * D;
     const bf16* ot = Ob + (long)t * C::TR * ldo;
 #pragma unroll
@@ -576,13 +580,13 @@ __global__ __launch_bounds__(256, (DC <= 96 ? 2 : 1)) void attn_bwd_dkv_dma_kern
 #pragma unroll
     for (int kt2 = 0; kt2 < 2; ++kt2) {
       f32x16 sacc, pacc;
-      // accumulators start at -L2[q] / -delta[q] of their row: q = kt2*32 + 8g + 4h + j
+      // accumulators start at -L2[q] / -delta[q] of their row: q = kt2*32 + 8g + 4h + j (the LDS copies are negated)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const f32x4 l4 = *reinterpret_cast<const f32x4*>(sl + kt2 * 32 + 8 * g + 4 * lhv);
         const f32x4 d4 = *reinterpret_cast<const f32x4*>(sd + kt2 * 32 + 8 * g + 4 * lhv);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { sacc[4 * g + j] = -l4[j]; pacc[4 * g + j] = -d4[j]; }
+        for (int j = 0; j < 4; ++j) { sacc[4 * g + j] = l4[j]; pacc[4 * g + j] = d4[j]; }
       }
       const int row = kt2 * 32 + lqv;
 #pragma unroll
