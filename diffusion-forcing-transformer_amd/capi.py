@@ -109,6 +109,7 @@ SIGNATURES = {
     "dfot_op_attention_padded": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "dfot_op_attention_bwd": (_I, [_P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _P]),
     "dfot_op_conv3x3_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "dfot_op_conv3x3_bwd2": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "dfot_op_gn_silu_bwd": (_I, [_P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _I, _I, _I, _P]),
     "dfot_op_rms_film_bwd": (_I, [_P, _P, _P, _P, _F, _P, _P, _P, _L, _I, _I, _P]),
     "dfot_op_rms_film_bwd_res": (_I, [_P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _L, _I, _P]),
@@ -130,6 +131,7 @@ SIGNATURES = {
     "dfot_op_gn_silu_bwd2": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "dfot_op_gn_silu_bwd3": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _L, _P]),
     "dfot_op_gn_silu_bwd4": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _P, _I, _I, _I, _P]),
+    "dfot_op_gn_silu_bwd5": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _P, _I, _I, _I, _P]),
     "dfot_op_pack_conv3": (_I, [_P, _P, _I, _I, _I, _P]),
     "dfot_op_conv3x3_f32": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "dfot_op_pool2_bf16": (_I, [_P, _P, _I, _I, _I, _I, _P]),

@@ -62,15 +62,16 @@ struct ConvBwdScratch {  // sized by the caller for the largest convolution it d
 
 // dx (fp32 [pix][Ci], optional), dW (fp32 [Co][Ci][3][3]), db (fp32 [Co], optional; must be zeroed by the caller)
 int conv3_backward(const bf16* x, const bf16* dy, const bf16* w_dgrad, float* dx, float* dw, float* db, int bt, int H, int W, int ci, int co,
-                   const ConvBwdScratch& sc, hipStream_t s) {
+                   const ConvBwdScratch& sc, hipStream_t s, bf16* dx_bf = nullptr) {
   const long pix = (long)bt * H * W;
   DFOT_REQUIRE(ci % 64 == 0 && co % 64 == 0 && pix % 64 == 0, DFOT_ERR_SHAPE, "conv3_backward: channels %d -> %d and %ld pixels must be multiples of 64", ci, co, pix);
   int rc = 0;
-  if (dx) {
+  if (dx || dx_bf) {  // dx_bf: the gradient only feeds a GroupNorm backward -- bf16 halves its bytes there and here
     GemmArgs g;
     g.zeros = sc.zeros;
-    g.A = dy; g.W = w_dgrad; g.M = (int)pix; g.N = ci; g.K = 9 * co; g.H = H; g.Wd = W; g.Cin = co; g.out_f32 = dx; g.ldo = ci;
-    if ((rc = launch_gemm(A_CONV3, E_F32, GEMM_AUTO, g, s))) return rc;
+    g.A = dy; g.W = w_dgrad; g.M = (int)pix; g.N = ci; g.K = 9 * co; g.H = H; g.Wd = W; g.Cin = co; g.ldo = ci;
+    if (dx_bf) g.out_bf16 = dx_bf; else g.out_f32 = dx;
+    if ((rc = launch_gemm(A_CONV3, dx_bf ? E_BF16 : E_F32, GEMM_AUTO, g, s))) return rc;
   }
   if (db) {
     if ((rc = launch_colsum_bf16(dy, db, pix, co, (long)co, s))) return rc;
@@ -127,9 +128,9 @@ extern "C" {
 using namespace dfot;
 
 // test entry: x, dy bf16 channels-last; w fp32 [Co][Ci][3][3]; dx fp32 [pix][Ci]; dw fp32 [Co][Ci][3][3]; db fp32 [Co]
-int dfot_op_conv3x3_bwd(const void* x, const void* dy, const float* w, float* dx, float* dw, float* db, int bt, int hh, int ww, int cin, int cout,
-                        void* stream) {
-  DFOT_REQUIRE(x && dy && w && dx && dw && db, DFOT_ERR_ARG, "op_conv3x3_bwd: null argument");
+int dfot_op_conv3x3_bwd2(const void* x, const void* dy, const float* w, float* dx, void* dx_bf, float* dw, float* db, int bt, int hh, int ww, int cin,
+                         int cout, void* stream) {
+  DFOT_REQUIRE(x && dy && w && (dx != nullptr) != (dx_bf != nullptr) && dw && db, DFOT_ERR_ARG, "op_conv3x3_bwd2: null argument, or both / neither of dx and dx_bf");
   hipStream_t s = (hipStream_t)stream;
   ConvBwdScratch sc;
   void *taps = nullptr, *ws = nullptr, *wd = nullptr, *zeros = nullptr;
@@ -144,7 +145,12 @@ int dfot_op_conv3x3_bwd(const void* x, const void* dy, const float* w, float* dx
   DFOT_CHECK_HIP(hipMemsetAsync(db, 0, (size_t)cout * sizeof(float), s));
   hipLaunchKernelGGL(pack_conv3_dgrad_kernel, dim3(cdiv((long)cout * cin * 9, 256)), dim3(256), 0, s, w, (bf16*)wd, cout, cin);
   DFOT_CHECK_HIP(hipGetLastError());
-  return conv3_backward((const bf16*)x, (const bf16*)dy, (const bf16*)wd, dx, dw, db, bt, hh, ww, cin, cout, sc, s);
+  return conv3_backward((const bf16*)x, (const bf16*)dy, (const bf16*)wd, dx_bf ? nullptr : dx, dw, db, bt, hh, ww, cin, cout, sc, s, (bf16*)dx_bf);
+}
+int dfot_op_conv3x3_bwd(const void* x, const void* dy, const float* w, float* dx, float* dw, float* db, int bt, int hh, int ww, int cin, int cout,
+                        void* stream) {
+  DFOT_REQUIRE(dx, DFOT_ERR_ARG, "op_conv3x3_bwd: null argument");
+  return dfot_op_conv3x3_bwd2(x, dy, w, dx, nullptr, dw, db, bt, hh, ww, cin, cout, stream);
 }
 
 }  // extern "C"
@@ -165,8 +171,20 @@ __device__ __forceinline__ float silu_grad(float z) {
 // pass 1: per-workgroup partial sums of (sum dxhat, sum dxhat xhat) per group and of dgamma / dbeta per channel.  One workgroup =
 // one (image, pixel chunk); C / 4 lanes cover a pixel row with 16-byte loads and the 256 / (C / 4) lane groups take alternate
 // pixels; the groups are summed through LDS before the atomics.  C a multiple of 128 and at most 1024 (launcher)
-template <bool FILM>
-__global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ stats,
+// dy as fp32 or bf16 (the data gradient of a convolution that feeds nothing else)
+template <typename TDY>
+__device__ __forceinline__ __attribute__((ext_vector_type(4))) float gn_load_dy4(const TDY* p) {
+  typedef __attribute__((ext_vector_type(4))) float f4;
+  if constexpr (sizeof(TDY) == 4) {
+    return *reinterpret_cast<const f4*>(p);
+  } else {
+    const bf16x4 v = *reinterpret_cast<const bf16x4*>(p);
+    return f4{bf2f(v[0]), bf2f(v[1]), bf2f(v[2]), bf2f(v[3])};
+  }
+}
+
+template <bool FILM, typename TDY>
+__global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const float* __restrict__ x, const TDY* __restrict__ dy, const float* __restrict__ stats,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
                                                             const bf16* __restrict__ film, float* __restrict__ part, int P, int C, int chunk) {
   typedef __attribute__((ext_vector_type(4))) float f4;
@@ -186,7 +204,7 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const float* __restr
 #pragma unroll 4
     for (int p = p0 + rg; p < p1; p += groups) {
       const long e = ((long)bt * P + p) * C + c;
-      const f4 xv = *reinterpret_cast<const f4*>(x + e), dv = *reinterpret_cast<const f4*>(dy + e);
+      const f4 xv = *reinterpret_cast<const f4*>(x + e), dv = gn_load_dy4(dy + e);
       bf16x4 fs, fh;
       if (FILM) {
         const long f = ((long)bt * P + p) * 2 * C + c;
@@ -234,8 +252,8 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const float* __restr
 }
 
 // pass 2: dx (+= when accumulate) and the FiLM gradients
-template <bool FILM>
-__global__ void gn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ stats,
+template <bool FILM, typename TDY>
+__global__ void gn_bwd_apply_kernel(const float* __restrict__ x, const TDY* __restrict__ dy, const float* __restrict__ stats,
                                     const float* __restrict__ gamma, const float* __restrict__ beta, const bf16* __restrict__ film,
                                     const float* __restrict__ sums, float* dx, bf16* __restrict__ dfilm, long total4, int P, int C,
                                     int accumulate, long ldf, const float* dres, bf16* __restrict__ dx_bf) {
@@ -251,7 +269,7 @@ __global__ void gn_bwd_apply_kernel(const float* __restrict__ x, const float* __
   const float inv_n = 1.0f / ((float)P * (float)cpg);
   const float s1 = sums[((long)bt * 32 + grp) * 2] * inv_n, s2 = sums[((long)bt * 32 + grp) * 2 + 1] * inv_n;
   const long e = row * C + c;
-  const f4 xv = *reinterpret_cast<const f4*>(x + e), dv = *reinterpret_cast<const f4*>(dy + e);
+  const f4 xv = *reinterpret_cast<const f4*>(x + e), dv = gn_load_dy4(dy + e);
   const f4 ga = *reinterpret_cast<const f4*>(gamma + c), be = *reinterpret_cast<const f4*>(beta + c);
   bf16x4 fs, fh, ds, dh;
   if (FILM) {
@@ -291,7 +309,8 @@ __global__ void gn_bwd_apply_kernel(const float* __restrict__ x, const float* __
 }
 
 // sums [BT][32][2] scratch; dgamma / dbeta are written (fixed-order sums of per-workgroup partial rows)
-int gn_silu_backward(const float* x, const float* dy, const float* stats, const float* gamma, const float* beta, const bf16* film, float* sums,
+template <typename TDY>
+int gn_silu_backward(const float* x, const TDY* dy, const float* stats, const float* gamma, const float* beta, const bf16* film, float* sums,
                      float* dx, bf16* dfilm, float* dgamma, float* dbeta, int bt, int P, int C, bool accumulate, hipStream_t s, long ldf = 0,
                      const float* dres = nullptr, bf16* dx_bf = nullptr) {
   if (ldf == 0) ldf = 2L * C;
@@ -309,18 +328,18 @@ int gn_silu_backward(const float* x, const float* dy, const float* stats, const 
   int rc = det_scratch(2, (size_t)grid.x * grid.y * rowlen, &part);
   if (rc) return rc;
   if (film)
-    hipLaunchKernelGGL(gn_bwd_reduce_kernel<true>, grid, dim3(256), 0, s, x, dy, stats, gamma, beta, film, part, P, C, chunk);
+    hipLaunchKernelGGL((gn_bwd_reduce_kernel<true, TDY>), grid, dim3(256), 0, s, x, dy, stats, gamma, beta, film, part, P, C, chunk);
   else
-    hipLaunchKernelGGL(gn_bwd_reduce_kernel<false>, grid, dim3(256), 0, s, x, dy, stats, gamma, beta, film, part, P, C, chunk);
+    hipLaunchKernelGGL((gn_bwd_reduce_kernel<false, TDY>), grid, dim3(256), 0, s, x, dy, stats, gamma, beta, film, part, P, C, chunk);
   DFOT_CHECK_HIP(hipGetLastError());
   if ((rc = det_sum(part + 2L * C, rowlen, (int)grid.y, 64, sums, false, s, bt, (long)grid.y * rowlen, 64))) return rc;
   if ((rc = det_sum(part, rowlen, (int)(grid.x * grid.y), C, dgamma, false, s))) return rc;
   if ((rc = det_sum(part + C, rowlen, (int)(grid.x * grid.y), C, dbeta, false, s))) return rc;
   if (film) {
-    hipLaunchKernelGGL(gn_bwd_apply_kernel<true>, dim3(cdiv(total, 256)), dim3(256), 0, s, x, dy, stats, gamma, beta, film, sums, dx, dfilm, total, P, C,
+    hipLaunchKernelGGL((gn_bwd_apply_kernel<true, TDY>), dim3(cdiv(total, 256)), dim3(256), 0, s, x, dy, stats, gamma, beta, film, sums, dx, dfilm, total, P, C,
                        accumulate ? 1 : 0, ldf, dres, dx_bf);
   } else {
-    hipLaunchKernelGGL(gn_bwd_apply_kernel<false>, dim3(cdiv(total, 256)), dim3(256), 0, s, x, dy, stats, gamma, beta, film, sums, dx, dfilm, total, P, C,
+    hipLaunchKernelGGL((gn_bwd_apply_kernel<false, TDY>), dim3(cdiv(total, 256)), dim3(256), 0, s, x, dy, stats, gamma, beta, film, sums, dx, dfilm, total, P, C,
                        accumulate ? 1 : 0, ldf, dres, dx_bf);
   }
   DFOT_CHECK_HIP(hipGetLastError());
@@ -1074,6 +1093,20 @@ int dfot_op_gn_silu_bwd4(const float* x, const float* dy, const float* stats, co
   if (rc) return rc;
   return gn_silu_backward(x, dy, stats, gamma, beta, (const bf16*)film, (float*)sums, dx, (bf16*)dfilm, dgamma, dbeta, bt, pixels, channels,
                           dres != nullptr, s, (long)dfilm_ld, dres, (bf16*)dx_bf);
+}
+// dfot_op_gn_silu_bwd4 with the upstream gradient in bf16 (what dfot_op_conv3x3_bwd2 leaves in dx_bf)
+int dfot_op_gn_silu_bwd5(const float* x, const void* dy_bf, const float* stats, const float* gamma, const float* beta, const void* film, const float* dres,
+                         float* dx, void* dx_bf, void* dfilm, int64_t dfilm_ld, float* dgamma, float* dbeta, int bt, int pixels, int channels,
+                         void* stream) {
+  DFOT_REQUIRE(x && dy_bf && stats && gamma && beta && (dx || dx_bf) && dgamma && dbeta && (!dres || dres != dx), DFOT_ERR_ARG,
+               "op_gn_silu_bwd5: null or aliased argument");
+  DFOT_REQUIRE(!dfilm || (dfilm_ld >= 2 * channels && dfilm_ld % 4 == 0), DFOT_ERR_ARG, "op_gn_silu_bwd5: bad dfilm row stride");
+  hipStream_t s = (hipStream_t)stream;
+  void* sums = nullptr;
+  int rc = op_scratch(4, (size_t)bt * 64 * sizeof(float), &sums);
+  if (rc) return rc;
+  return gn_silu_backward(x, (const bf16*)dy_bf, stats, gamma, beta, (const bf16*)film, (float*)sums, dx, (bf16*)dfilm, dgamma, dbeta, bt, pixels,
+                          channels, dres != nullptr, s, (long)dfilm_ld, dres, (bf16*)dx_bf);
 }
 // w fp32 [Co][Ci][3][3] -> the forward kernel's layout [Co][tap][Ci] bf16 (dgrad = 0) or the data-gradient weights [Ci][tap'][Co] (dgrad = 1)
 int dfot_op_pack_conv3(const float* w, void* out, int co, int ci, int dgrad, void* stream) {

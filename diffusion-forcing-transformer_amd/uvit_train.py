@@ -230,11 +230,13 @@ def conv3x3(a: torch.Tensor, w_packed: torch.Tensor, bias: torch.Tensor, bt: int
     return out
 
 
-def conv3x3_backward(x: torch.Tensor, dy: torch.Tensor, w: torch.Tensor, bt: int, h: int, wd: int, cin: int, cout: int):
-    """x bf16 [pix][Cin], dy bf16 [pix][Cout], w fp32 [Cout][Cin][3][3] -> (dx fp32 [pix][Cin], dW fp32, db fp32)"""
-    dx = torch.empty(bt * h * wd, cin, dtype=torch.float32, device="cuda")
+def conv3x3_backward(x: torch.Tensor, dy: torch.Tensor, w: torch.Tensor, bt: int, h: int, wd: int, cin: int, cout: int, dx_bf16: bool = False):
+    """x bf16 [pix][Cin], dy bf16 [pix][Cout], w fp32 [Cout][Cin][3][3] -> (dx [pix][Cin] fp32, or bf16 when it only feeds a GroupNorm
+    backward, dW fp32, db fp32)"""
+    dx = torch.empty(bt * h * wd, cin, dtype=BF if dx_bf16 else torch.float32, device="cuda")
     dw, db = torch.empty_like(w), torch.empty(cout, dtype=torch.float32, device="cuda")
-    capi.check(capi.lib.dfot_op_conv3x3_bwd(_P(x), _P(dy), _P(w), _P(dx), _P(dw), _P(db), bt, h, wd, cin, cout, _S()))
+    capi.check(capi.lib.dfot_op_conv3x3_bwd2(_P(x), _P(dy), _P(w), None if dx_bf16 else _P(dx), _P(dx) if dx_bf16 else None, _P(dw), _P(db), bt, h, wd,
+                                             cin, cout, _S()))
     return dx, dw, db
 
 
@@ -292,19 +294,20 @@ class ResBlockTrain:
         s, c, p, lib = self.saved, self.c, self.p, capi.lib
         bt, h, w = s["geom"]
         P = h * w
-        dh2, dw2, db2 = conv3x3_backward(s["h2"], dy_bf if dy_bf is not None else _bf(dy), p["out_rest.1.weight"], bt, h, w, c, c)
+        # both convolutions' data gradients feed one GroupNorm backward each and nothing else: bf16 (what autocast leaves there in the reference)
+        dh2, dw2, db2 = conv3x3_backward(s["h2"], dy_bf if dy_bf is not None else _bf(dy), p["out_rest.1.weight"], bt, h, w, c, c, dx_bf16=True)
         dfilm = dfilm_out if dfilm_out is not None else torch.empty(bt * P, 2 * c, dtype=BF, device="cuda")
         dg2, dbe2, dg1, dbe1 = (torch.empty(c, dtype=torch.float32, device="cuda") for _ in range(4))
         # the gradient of the first convolution's output only feeds that convolution's data / weight gradients: bf16 alone
         dc1 = torch.empty(bt * P, c, dtype=BF, device="cuda")
-        capi.check(lib.dfot_op_gn_silu_bwd4(_P(s["c1"]), _P(dh2), _P(s["st2"]), _P(p["out_norm.weight"]), _P(p["out_norm.bias"]), _P(s["film"]), None,
+        capi.check(lib.dfot_op_gn_silu_bwd5(_P(s["c1"]), _P(dh2), _P(s["st2"]), _P(p["out_norm.weight"]), _P(p["out_norm.bias"]), _P(s["film"]), None,
                                             None, _P(dc1), _PV(dfilm), dfilm.stride(0), _P(dg2), _P(dbe2), bt, P, c, _S()))
         demb = None if dfilm_out is not None else gemm_f32(dfilm, self.w_eT, resid=demb_acc, out=demb_acc)
-        dh1, dw1, db1 = conv3x3_backward(s["h1"], dc1, p["in_layers.2.weight"], bt, h, w, c, c)
+        dh1, dw1, db1 = conv3x3_backward(s["h1"], dc1, p["in_layers.2.weight"], bt, h, w, c, c, dx_bf16=True)
         # dx = dy (residual path) + the first norm's input gradient, in fp32 for the stream and in bf16 for the block below
         dx = torch.empty_like(dy)
         self.dx_bf = torch.empty(bt * P, c, dtype=BF, device="cuda")
-        capi.check(lib.dfot_op_gn_silu_bwd4(_P(s["x"]), _P(dh1), _P(s["st1"]), _P(p["in_layers.0.weight"]), _P(p["in_layers.0.bias"]), None, _P(dy),
+        capi.check(lib.dfot_op_gn_silu_bwd5(_P(s["x"]), _P(dh1), _P(s["st1"]), _P(p["in_layers.0.weight"]), _P(p["in_layers.0.bias"]), None, _P(dy),
                                             _P(dx), _P(self.dx_bf), None, 0, _P(dg1), _P(dbe1), bt, P, c, _S()))
         self.grads = {
             "emb_layer.weight": wgrad(dfilm, s["emb"]).view_as(p["emb_layer.weight"]), "emb_layer.bias": colsum(dfilm),

@@ -305,6 +305,11 @@ int dfot_op_attention_bwd(const void* q, const void* k, const void* v, const voi
  * db fp32 [Cout].  Channel counts multiples of 64.  Replaces autograd through F.conv2d (u_vit_blocks.py:16-93). */
 int dfot_op_conv3x3_bwd(const void* x, const void* dy, const float* w, float* dx, float* dw, float* db, int bt, int h, int w_, int cin, int cout,
                         void* stream);
+/* the same with the data gradient in fp32 (dx) OR in bf16 (dx_bf; exactly one of the two): a gradient that only feeds the backward of the
+ * GroupNorm in front of the convolution is written once, at half the bytes -- what torch.autocast(bf16) leaves there in the reference
+ * (F.conv2d runs in bf16 under the trainer's precision setting, configurations/experiment/base_pytorch_exp.yaml:12 `precision: bf16`). */
+int dfot_op_conv3x3_bwd2(const void* x, const void* dy, const float* w, float* dx, void* dx_bf, float* dw, float* db, int bt, int h, int w_, int cin,
+                         int cout, void* stream);
 /* test entry: backward of y = SiLU(FiLM(GroupNorm32(x))) (ResBlock in_layers: film NULL; out_norm: film [BT*P][2C] bf16 = scale | shift,
  * u_vit_blocks.py:57-93): x, dy, dx fp32 [BT][P][C]; dfilm bf16 like film; dgamma / dbeta fp32 [C] */
 int dfot_op_gn_silu_bwd(const float* x, const float* dy, const float* gamma, const float* beta, const void* film, float eps, float* dx, void* dfilm,
@@ -368,6 +373,10 @@ int dfot_op_gn_silu_bwd3(const float* x, const float* dy, const float* stats, co
                          void* dfilm, float* dgamma, float* dbeta, int bt, int pixels, int channels, int accumulate_dx, int64_t dfilm_ld, void* stream);
 /* general form: dx = (dres ? dres : 0) + input gradient, as fp32 (dx) and / or bf16 (dx_bf); dfilm optional with its row stride */
 int dfot_op_gn_silu_bwd4(const float* x, const float* dy, const float* stats, const float* gamma, const float* beta, const void* film, const float* dres,
+                         float* dx, void* dx_bf, void* dfilm, int64_t dfilm_ld, float* dgamma, float* dbeta, int bt, int pixels, int channels,
+                         void* stream);
+/* dfot_op_gn_silu_bwd4 with the upstream gradient dy in bf16 [BT][P][C] (dx_bf of dfot_op_conv3x3_bwd2) */
+int dfot_op_gn_silu_bwd5(const float* x, const void* dy_bf, const float* stats, const float* gamma, const float* beta, const void* film, const float* dres,
                          float* dx, void* dx_bf, void* dfilm, int64_t dfilm_ld, float* dgamma, float* dbeta, int bt, int pixels, int channels,
                          void* stream);
 int dfot_op_pack_conv3(const float* w, void* out, int co, int ci, int dgrad, void* stream);

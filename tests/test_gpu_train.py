@@ -455,6 +455,54 @@ def test_groupnorm_silu_backward(film, bt, pix, c):
     assert max(rs[:3]) < 1e-4 and (not film or rs[3] < 5e-3)
 
 
+@pytest.mark.parametrize("bt,h,w,c", [(2, 16, 16, 128), (8, 32, 32, 128), (2, 16, 16, 256)])
+def test_conv3x3_backward_bf16_data_gradient_feeds_the_groupnorm_backward(bt, h, w, c):
+    """the ResBlock's chain conv backward -> GroupNorm backward with the data gradient kept in bf16 (dfot_op_conv3x3_bwd2 dx_bf ->
+    dfot_op_gn_silu_bwd5): dx_bf is the bf16 rounding of the fp32 entry's dx (same kernel, other epilogue), and the chain equals torch
+    autograd through conv2d(SiLU(GroupNorm(x))) on the bf16-rounded operands.  Tolerances: bf16 data gradient (2^-9) into sums over
+    >= 256 pixels; dgamma / dbeta / dx 5e-3 (measured ~1e-3)."""
+    from dfot_amd import capi
+    F = torch.nn.functional
+    g = torch.Generator().manual_seed(7 * c + h)
+    pix = h * w
+    x = torch.randn(bt, pix, c, generator=g) * 1.5 + 0.3
+    gamma, beta = torch.randn(c, generator=g) * 0.5 + 1, torch.randn(c, generator=g) * 0.2
+    wt = torch.randn(c, c, 3, 3, generator=g) / math.sqrt(9 * c)
+    dy = torch.randn(bt, h, w, c, generator=g).to(torch.bfloat16)
+    xd, gd, bd, wd, dyd = x.cuda(), gamma.cuda(), beta.cuda(), wt.cuda().contiguous(), dy.cuda().contiguous()
+    # forward pieces on the device: hact = SiLU(GN(x)) in bf16 + saved statistics
+    hact = torch.empty(bt * pix, c, dtype=torch.bfloat16, device="cuda")
+    stats = torch.empty(bt, 32, 2, device="cuda")
+    capi.check(capi.lib.dfot_op_gn_silu_fwd(capi.ptr(xd), capi.ptr(gd), capi.ptr(bd), None, 1e-6, capi.ptr(hact), capi.ptr(stats), bt, pix, c, capi.stream_ptr()))
+    dh_bf = torch.full((bt * pix, c), float("nan"), dtype=torch.bfloat16, device="cuda")
+    dh32 = torch.full((bt * pix, c), float("nan"), device="cuda")
+    dw, db = torch.empty(c, c, 3, 3, device="cuda"), torch.empty(c, device="cuda")
+    dw2, db2 = torch.empty_like(dw), torch.empty_like(db)
+    capi.check(capi.lib.dfot_op_conv3x3_bwd2(capi.ptr(hact), capi.ptr(dyd), capi.ptr(wd), None, capi.ptr(dh_bf), capi.ptr(dw), capi.ptr(db), bt, h, w, c, c,
+                                             capi.stream_ptr()))
+    capi.check(capi.lib.dfot_op_conv3x3_bwd2(capi.ptr(hact), capi.ptr(dyd), capi.ptr(wd), capi.ptr(dh32), None, capi.ptr(dw2), capi.ptr(db2), bt, h, w, c, c,
+                                             capi.stream_ptr()))
+    torch.cuda.synchronize()
+    assert torch.equal(dh_bf, dh32.to(torch.bfloat16)) and torch.equal(dw, dw2) and torch.equal(db, db2)
+    # exactly one of dx / dx_bf
+    assert capi.lib.dfot_op_conv3x3_bwd2(capi.ptr(hact), capi.ptr(dyd), capi.ptr(wd), capi.ptr(dh32), capi.ptr(dh_bf), capi.ptr(dw), capi.ptr(db), bt, h, w,
+                                         c, c, capi.stream_ptr()) != 0
+    dres = torch.randn(bt, pix, c, generator=g).cuda()
+    dx, dx_bf = torch.full((bt, pix, c), float("nan"), device="cuda"), torch.empty(bt * pix, c, dtype=torch.bfloat16, device="cuda")
+    dga, dbe = torch.empty(c, device="cuda"), torch.empty(c, device="cuda")
+    capi.check(capi.lib.dfot_op_gn_silu_bwd5(capi.ptr(xd), capi.ptr(dh_bf), capi.ptr(stats), capi.ptr(gd), capi.ptr(bd), None, capi.ptr(dres), capi.ptr(dx),
+                                             capi.ptr(dx_bf), None, 0, capi.ptr(dga), capi.ptr(dbe), bt, pix, c, capi.stream_ptr()))
+    torch.cuda.synchronize()
+    xr, gr, br = x.clone().requires_grad_(), gamma.clone().requires_grad_(), beta.clone().requires_grad_()
+    hr = F.silu(F.group_norm(xr.permute(0, 2, 1), 32, gr, br, 1e-6))            # [bt][c][pix]
+    y = F.conv2d(hr.view(bt, c, h, w), wt.to(torch.bfloat16).float(), None, padding=1)
+    y.backward(dy.float().permute(0, 3, 1, 2))
+    rs = [rel(dx.cpu() - dres.cpu(), xr.grad), rel(dga.cpu(), gr.grad), rel(dbe.cpu(), br.grad)]
+    print(f"conv -> GN backward with a bf16 data gradient, C={c} {h}x{w}: " + " ".join(f"{r:.1e}" for r in rs))
+    assert max(rs) < 5e-3, rs
+    assert torch.equal(dx_bf.view(bt, pix, c), dx.to(torch.bfloat16))
+
+
 @pytest.mark.parametrize("rows,c", [(512, 576), (300, 1152), (64, 128)])
 def test_rms_film_backward(rows, c):
     """backward of RMSNorm(x; w) * (1 + scale) + shift (NormalizeWithCond of the UViT TransformerBlock) vs torch autograd"""
