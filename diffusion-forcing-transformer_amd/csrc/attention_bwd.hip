@@ -513,8 +513,10 @@ __global__ __launch_bounds__(256, (DC <= 96 ? 2 : 1)) void attn_bwd_dkv_dma_kern
   const float* Lb = L2 + (long)bh * N;
   const float* Db = delta + (long)bh * N;
 
-  // LDS: [stage][Q tile | dO tile | L2[64] | delta[64]]
+  // LDS: [stage][Q tile | dO tile | L2[64] | delta[64]]; the two statistics rows are kept NEGATED (they are read straight into the S / dP
+  // accumulators: no sign flips on the vector pipe) except in the <128, 96, 96> instance, which that costs 7 spilled registers
   constexpr int STAGE = 2 * C::TILE + 2 * C::TR * 4;
+  constexpr bool NEGL = !(D == 128 && DC == 96);
   // per-lane DMA sources: Q rows have pitch D; dO rows pitch ldo, chunks at or beyond d (next head / padding) come from the zero buffer
   int qoff[C::IPW];
   long ooff[C::IPW];
@@ -531,7 +533,10 @@ __global__ __launch_bounds__(256, (DC <= 96 ? 2 : 1)) void attn_bwd_dkv_dma_kern
   auto issue = [&](int t, int stage) {
     char* sq = smem + stage * STAGE;
     char* so = sq + C::TILE;
-    if (tid < 2 * C::TR) rs = -(tid < C::TR ? Lb[t * C::TR + tid] : Db[t * C::TR + tid - C::TR]);  // negated; before the DMAs: its wait leaves them in flight
+    if (tid < 2 * C::TR) {  // before the DMAs: its wait leaves them in flight
+      rs = tid < C::TR ? Lb[t * C::TR + tid] : Db[t * C::TR + tid - C::TR];
+      if constexpr (NEGL) rs = -rs;
+    }
     const bf16* qt = Qb + (long)t * C::TR * D;
     const bf16* ot = Ob + (long)t * C::TR * ldo;
 #pragma unroll
@@ -586,7 +591,7 @@ __global__ __launch_bounds__(256, (DC <= 96 ? 2 : 1)) void attn_bwd_dkv_dma_kern
         const f32x4 l4 = *reinterpret_cast<const f32x4*>(sl + kt2 * 32 + 8 * g + 4 * lhv);
         const f32x4 d4 = *reinterpret_cast<const f32x4*>(sd + kt2 * 32 + 8 * g + 4 * lhv);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { sacc[4 * g + j] = l4[j]; pacc[4 * g + j] = d4[j]; }
+        for (int j = 0; j < 4; ++j) { sacc[4 * g + j] = NEGL ? l4[j] : -l4[j]; pacc[4 * g + j] = NEGL ? d4[j] : -d4[j]; }
       }
       const int row = kt2 * 32 + lqv;
 #pragma unroll
