@@ -673,11 +673,41 @@ __global__ __launch_bounds__(256) void attn_bwd_delta_kernel(const bf16* __restr
   delta[((row / N) * heads + hd) * N + row % N] = acc;
 }
 
+// the coalesced form for head dims of 64 or 128 (8 or 16 lanes per head, 16 bytes each): consecutive lanes read consecutive chunks of a row,
+// the head's lanes are summed by xor shuffles (ldo % 8 == 0: launcher).
+template <int SEG>
+__global__ __launch_bounds__(256) void attn_bwd_delta_rows_kernel(const bf16* __restrict__ O, const bf16* __restrict__ dO, long ldo,
+                                                                  float* __restrict__ delta, long rows, int N, int heads) {
+  const int cpr = heads * SEG;  // 16-byte chunks of a row that hold attention output
+  const long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long row = g / cpr;
+  const int chunk = (int)(g % cpr);
+  float acc = 0.f;
+  if (row < rows) {
+    const bf16x8 ov = *reinterpret_cast<const bf16x8*>(O + row * ldo + chunk * 8);
+    const bf16x8 gv = *reinterpret_cast<const bf16x8*>(dO + row * ldo + chunk * 8);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc += bf2f(ov[j]) * bf2f(gv[j]);
+  }
+#pragma unroll
+  for (int o = 1; o < SEG; o <<= 1) acc += __shfl_xor(acc, o);
+  if (row < rows && chunk % SEG == 0) delta[((row / N) * heads + chunk / SEG) * N + row % N] = acc;
+}
+
 }  // namespace
 
 int launch_attention_bwd_delta(const bf16* o, const bf16* d_o, long ldo, float* delta, int batch, int heads, int n, int d, hipStream_t s) {
   DFOT_REQUIRE(d % 8 == 0 && ldo % 8 == 0, DFOT_ERR_SHAPE, "attention_bwd: head dim %d and row stride %ld must be multiples of 8", d, ldo);
   const long rows = (long)batch * n;
+  if ((d == 64 || d == 128) && ((uintptr_t)o & 15) == 0 && ((uintptr_t)d_o & 15) == 0) {
+    // a head's 8 / 16 lanes start at a multiple of 8 / 16 of the global thread index (the chunks per row are a multiple of it), so they
+    // never straddle two waves
+    const long threads = rows * (heads * d / 8);
+    if (d == 64) hipLaunchKernelGGL(attn_bwd_delta_rows_kernel<8>, dim3(cdiv(threads, 256)), dim3(256), 0, s, o, d_o, ldo, delta, rows, n, heads);
+    else hipLaunchKernelGGL(attn_bwd_delta_rows_kernel<16>, dim3(cdiv(threads, 256)), dim3(256), 0, s, o, d_o, ldo, delta, rows, n, heads);
+    DFOT_CHECK_HIP(hipGetLastError());
+    return DFOT_OK;
+  }
   hipLaunchKernelGGL(attn_bwd_delta_kernel, dim3(cdiv(rows * heads, 256)), dim3(256), 0, s, o, d_o, ldo, delta, rows, n, heads, d);
   DFOT_CHECK_HIP(hipGetLastError());
   return DFOT_OK;
