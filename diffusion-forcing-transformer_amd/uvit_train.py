@@ -632,15 +632,16 @@ class UViT3DPoseTrainer:
         for l in sorted(dfilm_cat, reverse=True):
             demb[l] = gemm_f32(dfilm_cat[l], self.res_wcat[l])
         dfilm_cat.clear()
-        for l in (2, 1, 0):
+        for l in (2, 1):
             capi.check(lib.dfot_op_pool2_bwd(_P(demb[l + 1]), _P(demb[l]), bt, r[l], r[l], e, _S()))
-        dpose = torch.empty(bt * P0, e, dtype=BF, device="cuda")  # the pose embedding of dropped videos was replaced by zero: no gradient
-        capi.check(lib.dfot_op_masked_cast(_P(demb[0]), _P(self.drop), _P(dpose), dpose.numel(), self.T * P0 * e, _S()))
+        # level 0 (4.3 GB in fp32 at 64 frames x 128 x 128 x 1024) in one pass: + the pooled level-1 gradient, the bf16 copy for the pose
+        # PatchEmbed's weight gradient (the pose embedding of dropped videos was replaced by zero: no gradient) and the per-frame sums
+        dpose = torch.empty(bt * P0, e, dtype=BF, device="cuda")
+        dn = torch.zeros(self.feats.shape[0], e, device="cuda")  # rows beyond bt pad the noise-level MLP's GEMMs: they stay zero
+        capi.check(lib.dfot_op_emb_grad_finish(_P(demb[0]), _P(demb[1]), _P(self.drop), _P(dpose), _P(dn), bt, r[0], r[0], e, self.T, _S()))
         pe = "external_cond_embedding.patch_embedder.proj."
         G[pe + "weight"] = wgrad(dpose, self.patches)[:, : self.cdim * 4].reshape(e, self.cdim, self.ps, self.ps).contiguous()
         G[pe + "bias"] = colsum(dpose)
-        dn = torch.zeros(self.feats.shape[0], e, device="cuda")
-        capi.check(lib.dfot_op_rows_sum(_P(demb[0]), _P(dn), bt, P0, e, _S()))
         dnb = _bf(dn)
         ne = "noise_level_pos_embedding.embedding."
         G[ne + "linear_2.weight"], G[ne + "linear_2.bias"] = wgrad(dnb, self.a1), colsum(dnb)

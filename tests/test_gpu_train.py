@@ -503,6 +503,36 @@ def test_conv3x3_backward_bf16_data_gradient_feeds_the_groupnorm_backward(bt, h,
     assert torch.equal(dx_bf.view(bt, pix, c), dx.to(torch.bfloat16))
 
 
+@pytest.mark.parametrize("bt,h,e,tokens", [(4, 16, 64, 2), (6, 64, 1024, 3)])
+def test_embedding_gradient_finish_equals_the_three_passes(bt, h, e, tokens):
+    """dfot_op_emb_grad_finish (one pass over the level-0 embedding gradient) gives the bits of dfot_op_pool2_bwd + dfot_op_masked_cast +
+    dfot_op_rows_sum, with and without dropped videos, and leaves its fp32 input untouched"""
+    from dfot_amd import capi
+    g = torch.Generator().manual_seed(bt * h + e)
+    P = h * h
+    fine = torch.randn(bt, P, e, generator=g).cuda()
+    coarse = torch.randn(bt, P // 4, e, generator=g).cuda()
+    for mask in (None, torch.tensor([1] + [0] * (bt // tokens - 1), dtype=torch.uint8).cuda()):
+        ref = fine.clone()
+        capi.check(capi.lib.dfot_op_pool2_bwd(capi.ptr(coarse), capi.ptr(ref), bt, h, h, e, capi.stream_ptr()))
+        want_pose = torch.empty(bt * P, e, dtype=torch.bfloat16, device="cuda")
+        capi.check(capi.lib.dfot_op_masked_cast(capi.ptr(ref), capi.ptr(mask), capi.ptr(want_pose), want_pose.numel(), tokens * P * e, capi.stream_ptr()))
+        want_dn = torch.empty(bt, e, device="cuda")
+        capi.check(capi.lib.dfot_op_rows_sum(capi.ptr(ref), capi.ptr(want_dn), bt, P, e, capi.stream_ptr()))
+        keep = fine.clone()
+        got_pose = torch.full((bt * P, e), float("nan"), dtype=torch.bfloat16, device="cuda")
+        got_dn = torch.full((bt, e), float("nan"), device="cuda")
+        capi.check(capi.lib.dfot_op_emb_grad_finish(capi.ptr(fine), capi.ptr(coarse), capi.ptr(mask), capi.ptr(got_pose), capi.ptr(got_dn), bt, h, h, e,
+                                                    tokens, capi.stream_ptr()))
+        torch.cuda.synchronize()
+        assert torch.equal(got_pose, want_pose) and torch.equal(got_dn, want_dn) and torch.equal(fine, keep)
+        if mask is not None:
+            assert float(got_pose[: tokens * P].float().abs().max()) == 0.0 and float(got_pose[tokens * P:].float().abs().max()) > 0.0
+        # the reference formula on the host
+        up = coarse.view(bt, h // 2, h // 2, e).repeat_interleave(2, 1).repeat_interleave(2, 2).reshape(bt, P, e)
+        assert rel(got_dn.cpu(), (fine + 0.25 * up).sum(1).cpu()) < 1e-5
+
+
 @pytest.mark.parametrize("rows,c", [(512, 576), (300, 1152), (64, 128)])
 def test_rms_film_backward(rows, c):
     """backward of RMSNorm(x; w) * (1 + scale) + shift (NormalizeWithCond of the UViT TransformerBlock) vs torch autograd"""
