@@ -132,6 +132,10 @@ SIGNATURES = {
     "dfot_op_gn_silu_bwd3": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _L, _P]),
     "dfot_op_gn_silu_bwd4": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _P, _I, _I, _I, _P]),
     "dfot_op_gn_silu_bwd5": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _P, _I, _I, _I, _P]),
+    "dfot_op_gn_silu_fwd2": (_I, [_P, _P, _P, _P, _P, _F, _P, _P, _I, _I, _I, _P]),
+    "dfot_op_gn_silu_bwd6": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _P, _I, _I, _I, _P]),
+    "dfot_op_frame_sums_bf16": (_I, [_P, _L, _P, _I, _I, _I, _P]),
+    "dfot_op_sgemm": (_I, [_P, _L, _L, _P, _L, _L, _P, _L, _I, _I, _I, _I, _P]),
     "dfot_op_pack_conv3": (_I, [_P, _P, _I, _I, _I, _P]),
     "dfot_op_conv3x3_f32": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "dfot_op_pool2_bf16": (_I, [_P, _P, _I, _I, _I, _I, _P]),

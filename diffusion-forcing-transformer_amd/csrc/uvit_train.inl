@@ -186,7 +186,8 @@ __device__ __forceinline__ __attribute__((ext_vector_type(4))) float gn_load_dy4
 template <bool FILM, typename TDY>
 __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const float* __restrict__ x, const TDY* __restrict__ dy, const float* __restrict__ stats,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                            const bf16* __restrict__ film, float* __restrict__ part, int P, int C, int chunk) {
+                                                            const bf16* __restrict__ film, float* __restrict__ part, int P, int C, int chunk,
+                                                            const float* __restrict__ fvec) {
   typedef __attribute__((ext_vector_type(4))) float f4;
   __shared__ f4 red[4][256];  // [quantity][thread]
   const int bt = blockIdx.x, p0 = blockIdx.y * chunk;
@@ -199,6 +200,11 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const float* __restr
   const float mean = stats[((long)bt * 32 + grp) * 2], rstd = stats[((long)bt * 32 + grp) * 2 + 1];
   const f4 ga = *reinterpret_cast<const f4*>(gamma + c), be = *reinterpret_cast<const f4*>(beta + c);
   f4 dgm = {0.f, 0.f, 0.f, 0.f}, dbt = dgm, s1 = dgm, s2 = dgm;
+  f4 vs = dgm, vh = dgm;  // the frame's part of the FiLM rows (see gn_silu_fwd_kernel)
+  if (FILM && fvec) {
+    vs = *reinterpret_cast<const f4*>(fvec + (long)bt * 2 * C + c);
+    vh = *reinterpret_cast<const f4*>(fvec + (long)bt * 2 * C + C + c);
+  }
   const int p1 = p0 + chunk < P ? p0 + chunk : P;
   if (rg < groups) {
 #pragma unroll 4
@@ -217,8 +223,8 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const float* __restr
         const float gv = xh * ga[j] + be[j];
         float z = gv, mul = 1.f;
         if (FILM) {
-          mul = 1.0f + bf2f(fs[j]);
-          z = gv * mul + bf2f(fh[j]);
+          mul = 1.0f + (bf2f(fs[j]) + vs[j]);
+          z = gv * mul + (bf2f(fh[j]) + vh[j]);
         }
         const float dg = dv[j] * silu_grad(z) * mul;
         dgm[j] += dg * xh;
@@ -256,7 +262,7 @@ template <bool FILM, typename TDY>
 __global__ void gn_bwd_apply_kernel(const float* __restrict__ x, const TDY* __restrict__ dy, const float* __restrict__ stats,
                                     const float* __restrict__ gamma, const float* __restrict__ beta, const bf16* __restrict__ film,
                                     const float* __restrict__ sums, float* dx, bf16* __restrict__ dfilm, long total4, int P, int C,
-                                    int accumulate, long ldf, const float* dres, bf16* __restrict__ dx_bf) {
+                                    int accumulate, long ldf, const float* dres, bf16* __restrict__ dx_bf, const float* __restrict__ fvec) {
   typedef __attribute__((ext_vector_type(4))) float f4;
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;  // 4 channels of one pixel (they share a group: C / 32 >= 4)
   if (i >= total4) return;
@@ -272,9 +278,14 @@ __global__ void gn_bwd_apply_kernel(const float* __restrict__ x, const TDY* __re
   const f4 xv = *reinterpret_cast<const f4*>(x + e), dv = gn_load_dy4(dy + e);
   const f4 ga = *reinterpret_cast<const f4*>(gamma + c), be = *reinterpret_cast<const f4*>(beta + c);
   bf16x4 fs, fh, ds, dh;
+  f4 vs = {0.f, 0.f, 0.f, 0.f}, vh = vs;
   if (FILM) {
     fs = *reinterpret_cast<const bf16x4*>(film + row * 2 * C + c);
     fh = *reinterpret_cast<const bf16x4*>(film + row * 2 * C + C + c);
+    if (fvec) {
+      vs = *reinterpret_cast<const f4*>(fvec + (long)bt * 2 * C + c);
+      vh = *reinterpret_cast<const f4*>(fvec + (long)bt * 2 * C + C + c);
+    }
   }
   f4 v;
 #pragma unroll
@@ -283,8 +294,8 @@ __global__ void gn_bwd_apply_kernel(const float* __restrict__ x, const TDY* __re
     const float gv = xh * ga[j] + be[j];
     float z = gv, mul = 1.f;
     if (FILM) {
-      mul = 1.0f + bf2f(fs[j]);
-      z = gv * mul + bf2f(fh[j]);
+      mul = 1.0f + (bf2f(fs[j]) + vs[j]);
+      z = gv * mul + (bf2f(fh[j]) + vh[j]);
     }
     const float dz = dv[j] * silu_grad(z);
     if (FILM) {
@@ -312,7 +323,7 @@ __global__ void gn_bwd_apply_kernel(const float* __restrict__ x, const TDY* __re
 template <typename TDY>
 int gn_silu_backward(const float* x, const TDY* dy, const float* stats, const float* gamma, const float* beta, const bf16* film, float* sums,
                      float* dx, bf16* dfilm, float* dgamma, float* dbeta, int bt, int P, int C, bool accumulate, hipStream_t s, long ldf = 0,
-                     const float* dres = nullptr, bf16* dx_bf = nullptr) {
+                     const float* dres = nullptr, bf16* dx_bf = nullptr, const float* fvec = nullptr) {
   if (ldf == 0) ldf = 2L * C;
   DFOT_REQUIRE(dx || dx_bf, DFOT_ERR_ARG, "gn_silu_backward: no output");
   DFOT_REQUIRE(!accumulate || dres || dx, DFOT_ERR_ARG, "gn_silu_backward: nothing to accumulate onto");
@@ -328,19 +339,19 @@ int gn_silu_backward(const float* x, const TDY* dy, const float* stats, const fl
   int rc = det_scratch(2, (size_t)grid.x * grid.y * rowlen, &part);
   if (rc) return rc;
   if (film)
-    hipLaunchKernelGGL((gn_bwd_reduce_kernel<true, TDY>), grid, dim3(256), 0, s, x, dy, stats, gamma, beta, film, part, P, C, chunk);
+    hipLaunchKernelGGL((gn_bwd_reduce_kernel<true, TDY>), grid, dim3(256), 0, s, x, dy, stats, gamma, beta, film, part, P, C, chunk, fvec);
   else
-    hipLaunchKernelGGL((gn_bwd_reduce_kernel<false, TDY>), grid, dim3(256), 0, s, x, dy, stats, gamma, beta, film, part, P, C, chunk);
+    hipLaunchKernelGGL((gn_bwd_reduce_kernel<false, TDY>), grid, dim3(256), 0, s, x, dy, stats, gamma, beta, film, part, P, C, chunk, fvec);
   DFOT_CHECK_HIP(hipGetLastError());
   if ((rc = det_sum(part + 2L * C, rowlen, (int)grid.y, 64, sums, false, s, bt, (long)grid.y * rowlen, 64))) return rc;
   if ((rc = det_sum(part, rowlen, (int)(grid.x * grid.y), C, dgamma, false, s))) return rc;
   if ((rc = det_sum(part + C, rowlen, (int)(grid.x * grid.y), C, dbeta, false, s))) return rc;
   if (film) {
     hipLaunchKernelGGL((gn_bwd_apply_kernel<true, TDY>), dim3(cdiv(total, 256)), dim3(256), 0, s, x, dy, stats, gamma, beta, film, sums, dx, dfilm, total, P, C,
-                       accumulate ? 1 : 0, ldf, dres, dx_bf);
+                       accumulate ? 1 : 0, ldf, dres, dx_bf, fvec);
   } else {
     hipLaunchKernelGGL((gn_bwd_apply_kernel<false, TDY>), dim3(cdiv(total, 256)), dim3(256), 0, s, x, dy, stats, gamma, beta, film, sums, dx, dfilm, total, P, C,
-                       accumulate ? 1 : 0, ldf, dres, dx_bf);
+                       accumulate ? 1 : 0, ldf, dres, dx_bf, fvec);
   }
   DFOT_CHECK_HIP(hipGetLastError());
   return DFOT_OK;
@@ -855,8 +866,11 @@ namespace dfot {
 namespace {
 
 // out bf16 = SiLU(GN(x) [* (1 + scale) + shift])   (x fp32 [BT][P][C], stats [BT][32][2], film bf16 [BT*P][2C] or null)
+// fvec (optional, with film): fp32 [BT][2C] added to every film row of its frame -- the per-frame part of a FiLM projection whose
+// per-pixel part was folded into the pose patches (uvit_train.py: film = M patches + fvec)
 __global__ void gn_silu_fwd_kernel(const float* __restrict__ x, const float* __restrict__ stats, const float* __restrict__ gamma,
-                                   const float* __restrict__ beta, const bf16* __restrict__ film, bf16* __restrict__ out, long total4, int P, int C) {
+                                   const float* __restrict__ beta, const bf16* __restrict__ film, bf16* __restrict__ out, long total4, int P, int C,
+                                   const float* __restrict__ fvec) {
   typedef __attribute__((ext_vector_type(4))) float f4;
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;  // 4 channels of one pixel (one group: C / 32 >= 4)
   if (i >= total4) return;
@@ -872,10 +886,15 @@ __global__ void gn_silu_fwd_kernel(const float* __restrict__ x, const float* __r
     fs = *reinterpret_cast<const bf16x4*>(film + row * 2 * C + c);
     fh = *reinterpret_cast<const bf16x4*>(film + row * 2 * C + C + c);
   }
+  f4 vs = {0.f, 0.f, 0.f, 0.f}, vh = vs;
+  if (film && fvec) {
+    vs = *reinterpret_cast<const f4*>(fvec + (long)bt * 2 * C + c);
+    vh = *reinterpret_cast<const f4*>(fvec + (long)bt * 2 * C + C + c);
+  }
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     float z = (xv[j] - mean) * rstd * ga[j] + be[j];
-    if (film) z = z * (1.0f + bf2f(fs[j])) + bf2f(fh[j]);
+    if (film) z = z * (1.0f + (bf2f(fs[j]) + vs[j])) + (bf2f(fh[j]) + vh[j]);
     o[j] = f2bf(silu_f(z));
   }
   *reinterpret_cast<bf16x4*>(out + row * C + c) = o;
@@ -1015,6 +1034,62 @@ __global__ __launch_bounds__(256) void emb_grad_finish_kernel(const float* __res
   }
   *reinterpret_cast<f4*>(part + ((long)blockIdx.z * gridDim.y + bt) * E + e) = acc;
 }
+// part[z][bt][c] = sum over the pixel chunk z of src[bt * P + p][c] (bf16 rows of pitch ld); 8 columns per thread
+__global__ __launch_bounds__(256) void frame_sums_bf16_kernel(const bf16* __restrict__ src, long ld, float* __restrict__ part, int P, int n) {
+  const int bt = blockIdx.y;
+  const int c = (blockIdx.x * blockDim.x + threadIdx.x) * 8;
+  if (c >= n) return;
+  const int per = (P + gridDim.z - 1) / gridDim.z, p0 = blockIdx.z * per, p1 = p0 + per < P ? p0 + per : P;
+  const bf16* b = src + (long)bt * P * ld + c;
+  float acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+#pragma unroll 4
+  for (int p = p0; p < p1; ++p) {
+    const bf16x8 v = *reinterpret_cast<const bf16x8*>(b + (long)p * ld);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] += bf2f(v[j]);
+  }
+  float* o = part + ((long)blockIdx.z * gridDim.y + bt) * n + c;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = acc[j];
+}
+// 64 x 64 output tile per workgroup, 16-deep K steps through LDS, 4 x 4 outputs per thread; strides in elements
+__global__ __launch_bounds__(256) void sgemm_strided_kernel(const float* __restrict__ A, long sa_i, long sa_k, const float* __restrict__ B, long sb_k,
+                                                            long sb_j, float* __restrict__ C, long ldc, int M, int N, int K, int accumulate) {
+  __shared__ float As[16][64 + 4], Bs[16][64 + 4];
+  const int i0 = blockIdx.y * 64, j0 = blockIdx.x * 64;
+  const int ti = (threadIdx.x / 16) * 4, tj = (threadIdx.x % 16) * 4;
+  float acc[4][4] = {};
+  for (int k0 = 0; k0 < K; k0 += 16) {
+    for (int t = threadIdx.x; t < 16 * 64; t += 256) {
+      // the fast index follows the operand's unit stride, so either orientation loads coalesced
+      const int kk_a = sa_k == 1 ? t % 16 : t / 64, ii = sa_k == 1 ? t / 16 : t % 64;
+      As[kk_a][ii] = (i0 + ii < M && k0 + kk_a < K) ? A[(long)(i0 + ii) * sa_i + (long)(k0 + kk_a) * sa_k] : 0.f;
+      const int kk_b = sb_k == 1 ? t % 16 : t / 64, jj = sb_k == 1 ? t / 16 : t % 64;
+      Bs[kk_b][jj] = (j0 + jj < N && k0 + kk_b < K) ? B[(long)(k0 + kk_b) * sb_k + (long)(j0 + jj) * sb_j] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+      float av[4], bv[4];
+#pragma unroll
+      for (int x = 0; x < 4; ++x) av[x] = As[kk][ti + x], bv[x] = Bs[kk][tj + x];
+#pragma unroll
+      for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int y = 0; y < 4; ++y) acc[x][y] += av[x] * bv[y];
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int x = 0; x < 4; ++x)
+#pragma unroll
+    for (int y = 0; y < 4; ++y) {
+      const int i = i0 + ti + x, j = j0 + tj + y;
+      if (i < M && j < N) C[(long)i * ldc + j] = (accumulate ? C[(long)i * ldc + j] : 0.f) + acc[x][y];
+    }
+}
 // gradient of the ConvTranspose(k = s = p) output [BT][Co][R][R] gathered per input pixel: dpatch [pix][64] bf16, column (co, py, px)
 __global__ void outgrad_gather_kernel(const float* __restrict__ dout, bf16* __restrict__ dpatch, long pix, int R, int co, int ps) {
   const int n = co * ps * ps;
@@ -1070,7 +1145,11 @@ using namespace dfot;
 
 int dfot_op_gn_silu_fwd(const float* x, const float* gamma, const float* beta, const void* film, float eps, void* out, float* stats, int bt,
                         int pixels, int channels, void* stream) {
-  DFOT_REQUIRE(x && gamma && beta && out && stats && channels % 32 == 0, DFOT_ERR_ARG, "op_gn_silu_fwd: bad argument");
+  return dfot_op_gn_silu_fwd2(x, gamma, beta, film, nullptr, eps, out, stats, bt, pixels, channels, stream);
+}
+int dfot_op_gn_silu_fwd2(const float* x, const float* gamma, const float* beta, const void* film, const float* film_vec, float eps, void* out,
+                         float* stats, int bt, int pixels, int channels, void* stream) {
+  DFOT_REQUIRE(x && gamma && beta && out && stats && channels % 32 == 0 && (film || !film_vec), DFOT_ERR_ARG, "op_gn_silu_fwd: bad argument");
   hipStream_t s = (hipStream_t)stream;
   DFOT_REQUIRE(channels % 128 == 0, DFOT_ERR_SHAPE, "op_gn_silu_fwd: channels %d must be a multiple of 128", channels);
   // statistics: streaming partial sums over 64-pixel blocks of all channels + a deterministic finalize (the inference kernels); one
@@ -1083,7 +1162,7 @@ int dfot_op_gn_silu_fwd(const float* x, const float* gamma, const float* beta, c
   if ((rc = launch_gn_finalize((const float*)part, stats, bt, nblk, pixels, channels, eps, s))) return rc;
   const long total = (long)bt * pixels * (channels / 4);
   hipLaunchKernelGGL(gn_silu_fwd_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, x, stats, gamma, beta, (const bf16*)film, (bf16*)out, total, pixels,
-                     channels);
+                     channels, film_vec);
   DFOT_CHECK_HIP(hipGetLastError());
   return DFOT_OK;
 }
@@ -1137,6 +1216,45 @@ int dfot_op_gn_silu_bwd5(const float* x, const void* dy_bf, const float* stats, 
   if (rc) return rc;
   return gn_silu_backward(x, (const bf16*)dy_bf, stats, gamma, beta, (const bf16*)film, (float*)sums, dx, (bf16*)dfilm, dgamma, dbeta, bt, pixels,
                           channels, dres != nullptr, s, (long)dfilm_ld, dres, (bf16*)dx_bf);
+}
+// dfot_op_gn_silu_bwd5 for a FiLM projection split into per-pixel rows (film) and a per-frame vector (film_vec fp32 [BT][2C], see
+// dfot_op_gn_silu_fwd2); dfilm is the gradient of the SUM (of either part)
+int dfot_op_gn_silu_bwd6(const float* x, const void* dy_bf, const float* stats, const float* gamma, const float* beta, const void* film,
+                         const float* film_vec, const float* dres, float* dx, void* dx_bf, void* dfilm, int64_t dfilm_ld, float* dgamma, float* dbeta,
+                         int bt, int pixels, int channels, void* stream) {
+  DFOT_REQUIRE(x && dy_bf && stats && gamma && beta && (dx || dx_bf) && dgamma && dbeta && (!dres || dres != dx) && (film || !film_vec), DFOT_ERR_ARG,
+               "op_gn_silu_bwd6: null or aliased argument");
+  DFOT_REQUIRE(!dfilm || (dfilm_ld >= 2 * channels && dfilm_ld % 4 == 0), DFOT_ERR_ARG, "op_gn_silu_bwd6: bad dfilm row stride");
+  hipStream_t s = (hipStream_t)stream;
+  void* sums = nullptr;
+  int rc = op_scratch(4, (size_t)bt * 64 * sizeof(float), &sums);
+  if (rc) return rc;
+  return gn_silu_backward(x, (const bf16*)dy_bf, stats, gamma, beta, (const bf16*)film, (float*)sums, dx, (bf16*)dfilm, dgamma, dbeta, bt, pixels,
+                          channels, dres != nullptr, s, (long)dfilm_ld, dres, (bf16*)dx_bf, film_vec);
+}
+// out [bt][n] fp32 = sum over the frame's `pixels` rows of src bf16 [bt * pixels][ld] (columns 0..n): per-frame column sums,
+// deterministic (partial rows per pixel chunk + fixed-order sum); n % 8 == 0, ld % 8 == 0
+int dfot_op_frame_sums_bf16(const void* src, int64_t ld, float* out, int bt, int pixels, int n, void* stream) {
+  DFOT_REQUIRE(src && out && bt > 0 && pixels > 0, DFOT_ERR_ARG, "op_frame_sums_bf16: null argument");
+  DFOT_REQUIRE(n % 8 == 0 && ld % 8 == 0 && ld >= n, DFOT_ERR_SHAPE, "op_frame_sums_bf16: n = %d and ld = %ld must be multiples of 8", n, (long)ld);
+  hipStream_t s = (hipStream_t)stream;
+  const int nz = pixels >= 2048 ? 32 : 1;
+  float* part = nullptr;
+  int rc = det_scratch(2, (size_t)nz * bt * n, &part);
+  if (rc) return rc;
+  hipLaunchKernelGGL(frame_sums_bf16_kernel, dim3(cdiv(n / 8, 256), bt, nz), dim3(256), 0, s, (const bf16*)src, (long)ld, part, pixels, n);
+  DFOT_CHECK_HIP(hipGetLastError());
+  return det_sum(part, (long)bt * n, nz, bt * n, out, false, s);
+}
+// C[i][j] (+)= sum_k A[i * sa_i + k * sa_k] * B[k * sb_k + j * sb_j], fp32, any strides (elements): the small dense products between
+// weight-sized matrices (folded FiLM weights and their gradients) that must not round through bf16.  Not a throughput kernel.
+int dfot_op_sgemm(const float* a, int64_t sa_i, int64_t sa_k, const float* b, int64_t sb_k, int64_t sb_j, float* c, int64_t ldc, int m, int n, int k,
+                  int accumulate, void* stream) {
+  DFOT_REQUIRE(a && b && c && m > 0 && n > 0 && k > 0 && ldc >= n, DFOT_ERR_ARG, "op_sgemm: bad argument");
+  hipLaunchKernelGGL(sgemm_strided_kernel, dim3(cdiv(n, 64), cdiv(m, 64)), dim3(256), 0, (hipStream_t)stream, a, (long)sa_i, (long)sa_k, b, (long)sb_k,
+                     (long)sb_j, c, (long)ldc, m, n, k, accumulate);
+  DFOT_CHECK_HIP(hipGetLastError());
+  return DFOT_OK;
 }
 // w fp32 [Co][Ci][3][3] -> the forward kernel's layout [Co][tap][Ci] bf16 (dgrad = 0) or the data-gradient weights [Ci][tap'][Co] (dgrad = 1)
 int dfot_op_pack_conv3(const float* w, void* out, int co, int ci, int dgrad, void* stream) {

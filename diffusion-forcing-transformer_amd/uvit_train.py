@@ -72,6 +72,18 @@ def wgrad(dy: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def sgemm(a: torch.Tensor, b: torch.Tensor, ta: bool = False, tb: bool = False, out: Optional[torch.Tensor] = None, accumulate: bool = False) -> torch.Tensor:
+    """fp32 op(a) @ op(b) for weight-sized matrices (op = transpose when ta / tb), no bf16 rounding; `out` (+)= when accumulate"""
+    m, k = (a.shape[1], a.shape[0]) if ta else a.shape
+    n = b.shape[0] if tb else b.shape[1]
+    if out is None:
+        out = torch.empty(m, n, dtype=torch.float32, device="cuda")
+    sa = (1, a.stride(0)) if ta else (a.stride(0), 1)     # (stride over i, stride over k)
+    sb = (1, b.stride(0)) if tb else (b.stride(0), 1)     # (stride over k, stride over j)
+    capi.check(capi.lib.dfot_op_sgemm(_P(a), sa[0], sa[1], _P(b), sb[0], sb[1], _P(out), out.stride(0), m, n, k, 1 if accumulate else 0, _S()))
+    return out
+
+
 def rope_table(head_dim: int, sizes: Tuple[int, int, int], theta: float = 10000.0) -> torch.Tensor:
     """(cos, sin) [T*H*W][head_dim/2][2] of RotaryEmbedding3D (embeddings.py:251-277): per-axis share of the head dim"""
     half = head_dim // 2
@@ -254,7 +266,7 @@ class ResBlockTrain:
              "out_norm.weight", "out_norm.bias", "out_rest.1.weight", "out_rest.1.bias")
 
     def __init__(self, params: Dict[str, torch.Tensor], prefix: str, channels: int, eps: float = 1e-6):
-        self.c, self.eps = channels, eps
+        self.c, self.eps, self.prefix = channels, eps, prefix
         self.p = {n: params[f"{prefix}.{n}"].detach().to(device="cuda", dtype=torch.float32).contiguous() for n in self.NAMES}
         self.grads: Dict[str, torch.Tensor] = {}
         self.sync()
@@ -265,22 +277,29 @@ class ResBlockTrain:
         self.w_eT = transpose(self.w_e)
         self.w1, self.w2 = pack_conv(p["in_layers.2.weight"]), pack_conv(p["out_rest.1.weight"])
 
-    def forward(self, x: torch.Tensor, emb: torch.Tensor, bt: int, h: int, w: int) -> torch.Tensor:
-        """x fp32 [BT*H*W][C], emb bf16 [BT*H*W][E]"""
+    def forward(self, x: torch.Tensor, emb: Optional[torch.Tensor], bt: int, h: int, w: int, film: Optional[torch.Tensor] = None,
+                film_vec: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """x fp32 [BT*H*W][C]; either emb bf16 [BT*H*W][E] (the block projects it: film = emb_layer(emb)), or the projection itself in two
+        parts -- film bf16 [BT*H*W][2C] (per pixel) + film_vec fp32 [BT][2C] (per frame) -- when the trainer folded emb_layer into the pose
+        patch embedding (UViT3DPoseTrainer.forward); the emb_layer gradients are then the trainer's to compute from the block's dfilm"""
         c, p, lib, P = self.c, self.p, capi.lib, h * w
         st1, st2 = (torch.empty(bt, 32, 2, dtype=torch.float32, device="cuda") for _ in range(2))
         h1 = torch.empty(bt * P, c, dtype=BF, device="cuda")
         capi.check(lib.dfot_op_gn_silu_fwd(_P(x), _P(p["in_layers.0.weight"]), _P(p["in_layers.0.bias"]), None, self.eps, _P(h1), _P(st1), bt, P, c, _S()))
         c1 = conv3x3(h1, self.w1, p["in_layers.2.bias"], bt, h, w, c, c)
-        film = gemm_bf16(emb, self.w_e, p["emb_layer.bias"])
+        folded = film is not None
+        if not folded:
+            film = gemm_bf16(emb, self.w_e, p["emb_layer.bias"])
         h2 = torch.empty(bt * P, c, dtype=BF, device="cuda")
-        capi.check(lib.dfot_op_gn_silu_fwd(_P(c1), _P(p["out_norm.weight"]), _P(p["out_norm.bias"]), _P(film), self.eps, _P(h2), _P(st2), bt, P, c, _S()))
+        capi.check(lib.dfot_op_gn_silu_fwd2(_P(c1), _P(p["out_norm.weight"]), _P(p["out_norm.bias"]), _P(film), _P(film_vec), self.eps, _P(h2), _P(st2), bt,
+                                            P, c, _S()))
         y = conv3x3(h2, self.w2, p["out_rest.1.bias"], bt, h, w, c, c, resid=x)
-        self.saved = dict(x=x, emb=emb, h1=h1, c1=c1, film=film, h2=h2, st1=st1, st2=st2, geom=(bt, h, w))
+        self.saved = dict(x=x, emb=emb, h1=h1, c1=c1, film=film, film_vec=film_vec, folded=folded, h2=h2, st1=st1, st2=st2, geom=(bt, h, w))
         return y
 
     def drop_saved(self) -> None:
-        self.saved = {k: self.saved[k] for k in ("x", "emb", "geom")}
+        keep = ("x", "emb", "geom", "folded") + (("film", "film_vec") if self.saved["folded"] else ())
+        self.saved = {k: self.saved[k] for k in keep}
 
     def backward(self, dy: torch.Tensor, demb_acc: Optional[torch.Tensor] = None,
                  dfilm_out: Optional[torch.Tensor] = None, dy_bf: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
@@ -290,7 +309,7 @@ class ResBlockTrain:
         ck = None
         if "h1" not in self.saved:  # gradient checkpointing (see TransformerBlockTrain.backward)
             ck = self.saved
-            self.forward(ck["x"], ck["emb"], *ck["geom"])
+            self.forward(ck["x"], ck["emb"], *ck["geom"], film=ck.get("film"), film_vec=ck.get("film_vec"))
         s, c, p, lib = self.saved, self.c, self.p, capi.lib
         bt, h, w = s["geom"]
         P = h * w
@@ -300,20 +319,20 @@ class ResBlockTrain:
         dg2, dbe2, dg1, dbe1 = (torch.empty(c, dtype=torch.float32, device="cuda") for _ in range(4))
         # the gradient of the first convolution's output only feeds that convolution's data / weight gradients: bf16 alone
         dc1 = torch.empty(bt * P, c, dtype=BF, device="cuda")
-        capi.check(lib.dfot_op_gn_silu_bwd5(_P(s["c1"]), _P(dh2), _P(s["st2"]), _P(p["out_norm.weight"]), _P(p["out_norm.bias"]), _P(s["film"]), None,
-                                            None, _P(dc1), _PV(dfilm), dfilm.stride(0), _P(dg2), _P(dbe2), bt, P, c, _S()))
-        demb = None if dfilm_out is not None else gemm_f32(dfilm, self.w_eT, resid=demb_acc, out=demb_acc)
+        capi.check(lib.dfot_op_gn_silu_bwd6(_P(s["c1"]), _P(dh2), _P(s["st2"]), _P(p["out_norm.weight"]), _P(p["out_norm.bias"]), _P(s["film"]),
+                                            _P(s["film_vec"]), None, None, _P(dc1), _PV(dfilm), dfilm.stride(0), _P(dg2), _P(dbe2), bt, P, c, _S()))
+        demb = None if (dfilm_out is not None or s["folded"]) else gemm_f32(dfilm, self.w_eT, resid=demb_acc, out=demb_acc)
         dh1, dw1, db1 = conv3x3_backward(s["h1"], dc1, p["in_layers.2.weight"], bt, h, w, c, c, dx_bf16=True)
         # dx = dy (residual path) + the first norm's input gradient, in fp32 for the stream and in bf16 for the block below
         dx = torch.empty_like(dy)
         self.dx_bf = torch.empty(bt * P, c, dtype=BF, device="cuda")
         capi.check(lib.dfot_op_gn_silu_bwd5(_P(s["x"]), _P(dh1), _P(s["st1"]), _P(p["in_layers.0.weight"]), _P(p["in_layers.0.bias"]), None, _P(dy),
                                             _P(dx), _P(self.dx_bf), None, 0, _P(dg1), _P(dbe1), bt, P, c, _S()))
-        self.grads = {
-            "emb_layer.weight": wgrad(dfilm, s["emb"]).view_as(p["emb_layer.weight"]), "emb_layer.bias": colsum(dfilm),
+        self.grads = {} if s["folded"] else {"emb_layer.weight": wgrad(dfilm, s["emb"]).view_as(p["emb_layer.weight"]), "emb_layer.bias": colsum(dfilm)}
+        self.grads.update({
             "in_layers.0.weight": dg1, "in_layers.0.bias": dbe1, "in_layers.2.weight": dw1, "in_layers.2.bias": db1,
             "out_norm.weight": dg2, "out_norm.bias": dbe2, "out_rest.1.weight": dw2, "out_rest.1.bias": db2,
-        }
+        })
         if ck is not None:
             self.saved = ck  # release the recomputed activations
         return dx, demb
@@ -407,7 +426,7 @@ class UViT3DPoseTrainer:
         self.kpad = -(-self.cdim * 4 // 64) * 64
         wp = torch.zeros(e, self.kpad, device="cuda")
         wp[:, : self.cdim * 4] = p["external_cond_embedding.patch_embedder.proj.weight"].flatten(1)
-        self.wp = _bf(wp)
+        self.wp, self.wp32 = _bf(wp), wp
         wo = torch.zeros(self.ch[0], 64, device="cuda")
         wo[:, : self.cin * 4] = p["project_output.proj.weight"].flatten(1)
         self.wo = _bf(wo)                    # [C0][64]: data gradient of the ConvTranspose as a GEMM with K = 64
@@ -416,17 +435,26 @@ class UViT3DPoseTrainer:
         for b in self._blocks():
             b.sync()
         self._refresh_score_bounds(own_step)
-        # ResBlock levels: the column offset of every block in its level's FiLM-gradient matrix, and the matching [E][blocks * 2C]
-        # concatenation of the emb_layer weights (backward: one embedding-gradient GEMM per level)
+        # ResBlock levels: FiLM folded into the pose patch embedding.  emb = PatchEmbed(patches) keep + noise embedding is linear in the
+        # patches and emb_layer is linear in emb, so a block's film = (W_e W_p) patches + W_e (b_p keep + nemb[frame]) + b_e: the per-pixel
+        # GEMM runs over the 768-wide patches instead of the 1024-wide embedding, and the backward never forms the per-pixel embedding
+        # gradient (4.3 GB in fp32 at level 0 of config 5).  Per level: the blocks' rows in the concatenated matrices (res_cols; also their
+        # column offsets in the level's FiLM-gradient matrix), W_e concatenated [R][E] (fp32), its bias [R], and M = W_e W_p [R][kpad] (bf16)
         self.res_cols: Dict[int, int] = {}
-        self.res_wcat: Dict[int, torch.Tensor] = {}
+        self.res_blocks: Dict[int, List[ResBlockTrain]] = {}
+        self.res_w32: Dict[int, torch.Tensor] = {}
+        self.res_b32: Dict[int, torch.Tensor] = {}
+        self.res_m: Dict[int, torch.Tensor] = {}
         for l in range(4):
             blocks = [b for b in (self.mid if l == 3 else self.down[l] + self.up[2 - l]) if isinstance(b, ResBlockTrain)]
             if not blocks:
                 continue
             for i, b in enumerate(blocks):
                 self.res_cols[id(b)] = i * 2 * self.ch[l]
-            self.res_wcat[l] = torch.cat([b.w_eT for b in blocks], dim=1).contiguous()
+            self.res_blocks[l] = blocks
+            self.res_w32[l] = torch.cat([b.p["emb_layer.weight"].flatten(1) for b in blocks], dim=0).contiguous()
+            self.res_b32[l] = torch.cat([b.p["emb_layer.bias"] for b in blocks], dim=0).contiguous()
+            self.res_m[l] = _bf(sgemm(self.res_w32[l], self.wp32))
 
     def _blocks(self):
         return [b for lv in self.down for b in lv] + self.mid + [b for lv in self.up for b in lv]
@@ -482,7 +510,9 @@ class UViT3DPoseTrainer:
         p = self.block_dropouts[lvl] if self.dropout_generator is not None else 0.0
         for b in blocks:
             if isinstance(b, ResBlockTrain):
-                x = b.forward(x, self.emb[lvl], self.bt, self.r[lvl], self.r[lvl])
+                c0, c2 = self.res_cols[id(b)], 2 * self.ch[lvl]
+                x = b.forward(x, None, self.bt, self.r[lvl], self.r[lvl], film=gemm_bf16(self.xl[lvl], self.res_m[lvl][c0: c0 + c2]),
+                              film_vec=self.film_vec[lvl][:, c0: c0 + c2].contiguous())
             else:
                 mask = None
                 if p > 0:  # nn.Dropout(p) of the MLP branch: keep with probability 1 - p, scale by 1 / (1 - p)
@@ -519,10 +549,25 @@ class UViT3DPoseTrainer:
         self.patches = torch.zeros(bt * P0, self.kpad, dtype=BF, device="cuda")
         cd = cond.to(device="cuda", dtype=torch.float32).reshape(bt, self.cdim, self.res, self.res).contiguous()
         capi.check(lib.dfot_op_cond_repack(_P(cd), _P(self.patches), bt, self.res, self.cdim, self.kpad, _S()))
-        pose = gemm_bf16(self.patches, self.wp, p["external_cond_embedding.patch_embedder.proj.bias"])
-        self.emb = [torch.empty(bt * r[l] * r[l], e, dtype=BF, device="cuda") for l in range(4)]
-        capi.check(lib.dfot_op_emb_combine(_P(pose), _P(nemb), _P(self.drop), _P(self.emb[0]), bt, P0, e, t, _S()))
-        capi.check(lib.dfot_op_emb_pyramid(_P(self.emb[0]), _P(self.emb[1]), _P(self.emb[2]), _P(self.emb[3]), bt, r[0], e, _S()))
+        bp = p["external_cond_embedding.patch_embedder.proj.bias"]
+        keep = torch.ones(bt, device="cuda") if self.drop is None else (1.0 - self.drop.to(torch.float32)).repeat_interleave(t)
+        if self.drop is not None:  # a dropped video's pose embedding is zero: no patches, no patch-embedding bias
+            self.patches.view(self.B, -1)[self.drop.bool()] = 0
+        self.keep = keep
+        # the pyramid is taken over the pose PATCHES (average pools commute with the linear patch embedding): xl[l] [BT * r_l^2][kpad]
+        self.xl = [self.patches] + [torch.empty(bt * r[l] * r[l], self.kpad, dtype=BF, device="cuda") for l in (1, 2, 3)]
+        capi.check(lib.dfot_op_emb_pyramid(_P(self.xl[0]), _P(self.xl[1]), _P(self.xl[2]), _P(self.xl[3]), bt, r[0], self.kpad, _S()))
+        # per-frame part of the embedding: c = b_p keep + nemb
+        self.cvec = (nemb + keep[:, None] * bp[None, :]).contiguous()
+        self.emb = [None] * 4
+        self.film_vec: Dict[int, torch.Tensor] = {}
+        for l in range(4):
+            if l in self.res_blocks:   # ResBlock level: the blocks' per-frame FiLM vectors W_e c + b_e, all blocks of the level at once
+                self.film_vec[l] = sgemm(self.cvec, self.res_w32[l], tb=True) + self.res_b32[l][None, :]
+            else:                       # transformer level: the per-token embedding itself, from the pooled patches
+                pose = gemm_bf16(self.xl[l], self.wp, bp)
+                self.emb[l] = torch.empty(bt * r[l] * r[l], e, dtype=BF, device="cuda")
+                capi.check(lib.dfot_op_emb_combine(_P(pose), _P(nemb), _P(self.drop), _P(self.emb[l]), bt, r[l] * r[l], e, t, _S()))
         # input embedding and the U
         h = torch.empty(bt * P0, ch[0], dtype=torch.float32, device="cuda")
         capi.check(lib.dfot_op_embed_input(_P(xd), _P(p["embed_input.proj.weight"]), _P(p["embed_input.proj.bias"]), _P(h), bt, self.res, self.cin, ch[0], _S()))
@@ -566,13 +611,12 @@ class UViT3DPoseTrainer:
                     handed.add(n)
                     o, shp = self.layout[n]
                     reducer.add(self.flat_grads[o: o + gv.numel()], gv)
-        # embedding gradients.  Levels 2, 3 (transformer blocks): every block adds dfilm W_e into the level's fp32 accumulator in its GEMM
-        # epilogue.  Levels 0, 1 (ResBlocks, 1 M / 262 K pixel rows x 1024): a read-modify-write of that accumulator per block is 8 GB of
-        # traffic at level 0, so the blocks of a level write their FiLM gradients side by side into one [rows][blocks * 2C] matrix and ONE
-        # GEMM over the concatenated K produces the level's embedding gradient (res_cols / res_wcat: _sync_derived)
-        demb: List[Optional[torch.Tensor]] = [None if l in self.res_wcat else torch.zeros(bt * r[l] * r[l], e, dtype=torch.float32, device="cuda")
+        # embedding gradients.  Transformer levels: every block adds dfilm W_e into the level's fp32 accumulator [rows][E] in its GEMM
+        # epilogue.  ResBlock levels (1 M / 262 K pixel rows): the blocks write their FiLM gradients side by side into one
+        # [rows][blocks * 2C] bf16 matrix; the folded FiLM (sync) turns it into weight-sized gradients at the end of this function
+        demb: List[Optional[torch.Tensor]] = [None if l in self.res_blocks else torch.zeros(bt * r[l] * r[l], e, dtype=torch.float32, device="cuda")
                                               for l in range(4)]
-        dfilm_cat = {l: torch.empty(bt * r[l] * r[l], w.shape[1], dtype=BF, device="cuda") for l, w in self.res_wcat.items()}
+        dfilm_cat = {l: torch.empty(bt * r[l] * r[l], w.shape[0], dtype=BF, device="cuda") for l, w in self.res_w32.items()}
 
         def run_back(blocks, prefix_fn, dh, lvl):
             dh_bf = None
@@ -628,20 +672,42 @@ class UViT3DPoseTrainer:
             dx = torch.empty_like(self.x_in)
             capi.check(lib.dfot_op_embed_input_dgrad(_P(dh), _P(p["embed_input.proj.weight"]), _P(dx), bt, self.res, self.cin, ch[0], self.ps, _S()))
             self.dx_in = dx.view(self.B, bt // self.B, self.cin, self.res, self.res)
-        # embedding pyramid (successive 2x2 average pools), pose patch embedding, noise-level MLP
-        for l in sorted(dfilm_cat, reverse=True):
-            demb[l] = gemm_f32(dfilm_cat[l], self.res_wcat[l])
+        # conditioning embedding: gradients of the emb_layer weights, the pose patch embedding (dP, d b_p) and the per-frame vector c
+        # (dc = the noise embedding's gradient), without the per-pixel embedding gradient.
+        #   ResBlock level: dM = dfilm^T patches_l [R][kpad], dv = per-frame sums of dfilm [BT][R];
+        #     dW_e = dM W_p^T + dv^T c,  db_e = sum_frames dv,  dP += W_e^T dM,  dc += dv W_e
+        #   transformer level: demb_l [rows][E] (accumulated by the blocks): dP += (demb_l keep)^T patches_l,  dc += per-frame sums of demb_l
+        dP = torch.zeros(e, self.kpad, device="cuda")
+        dc = torch.zeros(bt, e, device="cuda")
+        for l in range(4):
+            if l in dfilm_cat:
+                R = self.res_w32[l].shape[0]
+                dM = wgrad(dfilm_cat[l], self.xl[l])
+                dv = torch.empty(bt, R, device="cuda")
+                capi.check(lib.dfot_op_frame_sums_bf16(_P(dfilm_cat[l]), dfilm_cat[l].stride(0), _P(dv), bt, r[l] * r[l], R, _S()))
+                dW = sgemm(dM, self.wp32, tb=True)
+                sgemm(dv, self.cvec, ta=True, out=dW, accumulate=True)
+                db = sgemm(torch.ones(1, bt, device="cuda"), dv).view(-1)
+                sgemm(self.res_w32[l], dM, ta=True, out=dP, accumulate=True)
+                sgemm(dv, self.res_w32[l], out=dc, accumulate=True)
+                for blk in self.res_blocks[l]:
+                    c0, c2 = self.res_cols[id(blk)], 2 * ch[l]
+                    G[f"{blk.prefix}.emb_layer.weight"] = dW[c0: c0 + c2].reshape(c2, e, 1, 1).clone()  # own storage (the autograd op's outputs must not alias)
+                    G[f"{blk.prefix}.emb_layer.bias"] = db[c0: c0 + c2].clone()
+            else:
+                rows = bt * r[l] * r[l]
+                dpose = torch.empty(rows, e, dtype=BF, device="cuda")  # the pose embedding of dropped videos was replaced by zero: no gradient
+                capi.check(lib.dfot_op_masked_cast(_P(demb[l]), _P(self.drop), _P(dpose), dpose.numel(), self.T * r[l] * r[l] * e, _S()))
+                dP += wgrad(dpose, self.xl[l])
+                dsum = torch.empty(bt, e, device="cuda")
+                capi.check(lib.dfot_op_rows_sum(_P(demb[l]), _P(dsum), bt, r[l] * r[l], e, _S()))
+                dc += dsum
         dfilm_cat.clear()
-        for l in (2, 1):
-            capi.check(lib.dfot_op_pool2_bwd(_P(demb[l + 1]), _P(demb[l]), bt, r[l], r[l], e, _S()))
-        # level 0 (4.3 GB in fp32 at 64 frames x 128 x 128 x 1024) in one pass: + the pooled level-1 gradient, the bf16 copy for the pose
-        # PatchEmbed's weight gradient (the pose embedding of dropped videos was replaced by zero: no gradient) and the per-frame sums
-        dpose = torch.empty(bt * P0, e, dtype=BF, device="cuda")
-        dn = torch.zeros(self.feats.shape[0], e, device="cuda")  # rows beyond bt pad the noise-level MLP's GEMMs: they stay zero
-        capi.check(lib.dfot_op_emb_grad_finish(_P(demb[0]), _P(demb[1]), _P(self.drop), _P(dpose), _P(dn), bt, r[0], r[0], e, self.T, _S()))
         pe = "external_cond_embedding.patch_embedder.proj."
-        G[pe + "weight"] = wgrad(dpose, self.patches)[:, : self.cdim * 4].reshape(e, self.cdim, self.ps, self.ps).contiguous()
-        G[pe + "bias"] = colsum(dpose)
+        G[pe + "weight"] = dP[:, : self.cdim * 4].reshape(e, self.cdim, self.ps, self.ps).contiguous()
+        G[pe + "bias"] = sgemm(self.keep.view(1, bt), dc).view(-1)
+        dn = torch.zeros(self.feats.shape[0], e, device="cuda")  # rows beyond bt pad the noise-level MLP's GEMMs: they stay zero
+        dn[:bt] = dc
         dnb = _bf(dn)
         ne = "noise_level_pos_embedding.embedding."
         G[ne + "linear_2.weight"], G[ne + "linear_2.bias"] = wgrad(dnb, self.a1), colsum(dnb)

@@ -379,6 +379,22 @@ int dfot_op_gn_silu_bwd4(const float* x, const float* dy, const float* stats, co
 int dfot_op_gn_silu_bwd5(const float* x, const void* dy_bf, const float* stats, const float* gamma, const float* beta, const void* film, const float* dres,
                          float* dx, void* dx_bf, void* dfilm, int64_t dfilm_ld, float* dgamma, float* dbeta, int bt, int pixels, int channels,
                          void* stream);
+/* Folded FiLM of the ResBlock levels (training).  The reference computes emb = PatchEmbed(pose rays) + noise embedding per pixel
+ * (u_vit3d_pose.py:63-131, embeddings.py:390-428) and every ResBlock projects it: film = emb_layer(emb) (u_vit_blocks.py:57-93).  Both
+ * maps are linear, so film = (W_emb_layer W_patch) patches + W_emb_layer (b_patch keep + noise_emb[frame]) + b: the per-pixel part is a
+ * GEMM over the 768-wide pose patches instead of the 1024-wide embedding, the per-frame part a [BT][2C] vector (film_vec, fp32), and the
+ * backward never forms the per-pixel embedding gradient.  These entries take the two parts. */
+int dfot_op_gn_silu_fwd2(const float* x, const float* gamma, const float* beta, const void* film, const float* film_vec, float eps, void* out,
+                         float* stats, int bt, int pixels, int channels, void* stream);
+int dfot_op_gn_silu_bwd6(const float* x, const void* dy_bf, const float* stats, const float* gamma, const float* beta, const void* film,
+                         const float* film_vec, const float* dres, float* dx, void* dx_bf, void* dfilm, int64_t dfilm_ld, float* dgamma, float* dbeta,
+                         int bt, int pixels, int channels, void* stream);
+/* out [bt][n] fp32 = per-frame column sums of src bf16 [bt * pixels][ld] (the gradient of film_vec from the FiLM gradients) */
+int dfot_op_frame_sums_bf16(const void* src, int64_t ld, float* out, int bt, int pixels, int n, void* stream);
+/* C[i][j] (+)= sum_k A[i * sa_i + k * sa_k] * B[k * sb_k + j * sb_j] in fp32 with element strides: the weight-sized products of the
+ * folded FiLM (W_emb_layer W_patch and the gradients back to the two factors) */
+int dfot_op_sgemm(const float* a, int64_t sa_i, int64_t sa_k, const float* b, int64_t sb_k, int64_t sb_j, float* c, int64_t ldc, int m, int n, int k,
+                  int accumulate, void* stream);
 int dfot_op_pack_conv3(const float* w, void* out, int co, int ci, int dgrad, void* stream);
 int dfot_op_conv3x3_f32(const void* a, const void* w, const float* bias, const float* resid, float* y, int bt, int h, int w_, int cin, int cout,
                         void* stream);
