@@ -415,7 +415,8 @@ template <int VEC, int CNT>
 __global__ __launch_bounds__(256) void rms_film_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dxn, const float* __restrict__ w,
                                                            const bf16* __restrict__ film, float* dx, bf16* __restrict__ dfilm,
                                                            float* __restrict__ dw, long rows, float eps, int accumulate, const float* dres,
-                                                           bf16* __restrict__ dx_bf) {
+                                                           bf16* __restrict__ dx_bf, const float* __restrict__ fvec, int tpf) {
+  // fvec (optional): fp32 [frames][2C] added to the film rows of its frame (tpf tokens each) -- the per-frame part of a folded FiLM
   typedef typename VecT<VEC>::type V;
   constexpr int C = 64 * VEC * CNT;
   const int lane = threadIdx.x & 63;
@@ -427,6 +428,7 @@ __global__ __launch_bounds__(256) void rms_film_bwd_kernel(const float* __restri
     const float* xr = x + row * C;
     const float* gr = dxn + row * C;
     const bf16* fr = film + row * 2 * C;
+    const float* fv = fvec ? fvec + (long)((unsigned)row / (unsigned)tpf) * 2 * C : nullptr;  // rows < 2^32 (launcher)
     V xv[CNT], gv[CNT];
     float ss = 0.f;
 #pragma unroll
@@ -446,7 +448,7 @@ __global__ __launch_bounds__(256) void rms_film_bwd_kernel(const float* __restri
       for (int j = 0; j < VEC; ++j) {
         float dj, wj, xj;
         if constexpr (VEC == 1) { dj = d; wj = wv; xj = xv[i]; } else { dj = d[j]; wj = wv[j]; xj = xv[i][j]; }
-        const float sc = bf2f(fr[c0 + j]);
+        const float sc = bf2f(fr[c0 + j]) + (fv ? fv[c0 + j] : 0.f);
         const float y = xj * r * wj;
         dfr[c0 + j] = f2bf(dj * y);       // dscale
         dfr[C + c0 + j] = f2bf(dj);       // dshift
@@ -486,13 +488,15 @@ __global__ __launch_bounds__(256) void rms_film_bwd_kernel(const float* __restri
 }
 
 int rms_film_backward(const float* x, const float* dxn, const float* w, const bf16* film, float* dx, bf16* dfilm, float* dw, long rows, int hidden,
-                      float eps, bool accumulate, hipStream_t s, const float* dres = nullptr, bf16* dx_bf = nullptr) {
+                      float eps, bool accumulate, hipStream_t s, const float* dres = nullptr, bf16* dx_bf = nullptr, const float* fvec = nullptr,
+                      int tpf = 1) {
   const int grid = (int)(rows / 4 < 512 ? (rows + 3) / 4 : 512);
   float* part = nullptr;  // one partial dw row per workgroup, added in a fixed order (deterministic; dw is written, not accumulated)
   int rc = det_scratch(2, (size_t)grid * hidden, &part);
   if (rc) return rc;
 #define CALL(V, C) \
-  hipLaunchKernelGGL((rms_film_bwd_kernel<V, C>), dim3(grid), dim3(256), 0, s, x, dxn, w, film, dx, dfilm, part, rows, eps, accumulate ? 1 : 0, dres, dx_bf)
+  hipLaunchKernelGGL((rms_film_bwd_kernel<V, C>), dim3(grid), dim3(256), 0, s, x, dxn, w, film, dx, dfilm, part, rows, eps, accumulate ? 1 : 0, dres, dx_bf, \
+                     fvec, tpf)
   DIT_LN_DISPATCH(CALL)
 #undef CALL
   DFOT_CHECK_HIP(hipGetLastError());
@@ -620,6 +624,14 @@ int dfot_op_rms_film_bwd_res(const float* x, const float* dxn, const float* w, c
   DFOT_REQUIRE(x && dxn && w && film && dres && dx && dfilm && dw && dres != dx, DFOT_ERR_ARG, "op_rms_film_bwd_res: null or aliased argument");
   return rms_film_backward(x, dxn, w, (const bf16*)film, dx, (bf16*)dfilm, dw, (long)rows, channels, eps, true, (hipStream_t)stream, dres, (bf16*)dx_bf);
 }
+// dfot_op_rms_film_bwd_res for a FiLM projection in two parts: film rows (per token) + film_vec fp32 [rows / tokens_per_frame][2C] (per frame)
+int dfot_op_rms_film_bwd_res2(const float* x, const float* dxn, const float* w, const void* film, const float* film_vec, int tokens_per_frame, float eps,
+                              const float* dres, float* dx, void* dx_bf, void* dfilm, float* dw, int64_t rows, int channels, void* stream) {
+  DFOT_REQUIRE(x && dxn && w && film && dres && dx && dfilm && dw && dres != dx && (!film_vec || (tokens_per_frame > 0 && rows % tokens_per_frame == 0)),
+               DFOT_ERR_ARG, "op_rms_film_bwd_res2: null, aliased or misshaped argument");
+  return rms_film_backward(x, dxn, w, (const bf16*)film, dx, (bf16*)dfilm, dw, (long)rows, channels, eps, true, (hipStream_t)stream, dres, (bf16*)dx_bf,
+                           film_vec, film_vec ? tokens_per_frame : 1);
+}
 int dfot_op_qknorm_rope_bwd(const void* fused, int ld, const void* dq, const void* dk, const void* dv, const float* qw, const float* kw,
                             const float* rope_cs, float eps, void* dfused, int ldo, float* dqw, float* dkw, int64_t rows, int ntok, int heads, int d,
                             void* stream) {
@@ -656,7 +668,7 @@ namespace {
 
 template <int VEC, int CNT>
 __global__ __launch_bounds__(256) void rms_film_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const bf16* __restrict__ film,
-                                                           bf16* __restrict__ out, long rows, float eps) {
+                                                           bf16* __restrict__ out, long rows, float eps, const float* __restrict__ fvec, int tpf) {
   typedef typename VecT<VEC>::type V;
   constexpr int C = 64 * VEC * CNT;
   const int lane = threadIdx.x & 63;
@@ -664,6 +676,7 @@ __global__ __launch_bounds__(256) void rms_film_fwd_kernel(const float* __restri
   if (row >= rows) return;
   const float* xr = x + row * C;
   const bf16* fr = film + row * 2 * C;
+  const float* fv = fvec ? fvec + (long)((unsigned)row / (unsigned)tpf) * 2 * C : nullptr;  // the frame's part of a folded FiLM projection
   V xv[CNT];
   float ss = 0.f;
 #pragma unroll
@@ -679,7 +692,12 @@ __global__ __launch_bounds__(256) void rms_film_fwd_kernel(const float* __restri
     for (int j = 0; j < VEC; ++j) {
       float xj;
       if constexpr (VEC == 1) xj = xv[i]; else xj = xv[i][j];
-      out[row * C + c0 + j] = f2bf(xj * r * w[c0 + j] * (1.0f + bf2f(fr[c0 + j])) + bf2f(fr[C + c0 + j]));
+      float sc = bf2f(fr[c0 + j]), sh = bf2f(fr[C + c0 + j]);
+      if (fv) {
+        sc += fv[c0 + j];
+        sh += fv[C + c0 + j];
+      }
+      out[row * C + c0 + j] = f2bf(xj * r * w[c0 + j] * (1.0f + sc) + sh);
     }
   }
 }
@@ -778,11 +796,17 @@ int dfot_op_colsum_bf16(const void* src, int ld, float* out, int64_t rows, int n
   return launch_colsum_bf16((const bf16*)src, out, (long)rows, n, (long)ld, s);
 }
 int dfot_op_rms_film_fwd(const float* x, const float* w, const void* film, float eps, void* out, int64_t rows, int channels, void* stream) {
-  DFOT_REQUIRE(x && w && film && out, DFOT_ERR_ARG, "op_rms_film_fwd: null argument");
+  return dfot_op_rms_film_fwd2(x, w, film, nullptr, 1, eps, out, rows, channels, stream);
+}
+int dfot_op_rms_film_fwd2(const float* x, const float* w, const void* film, const float* film_vec, int tokens_per_frame, float eps, void* out,
+                          int64_t rows, int channels, void* stream) {
+  DFOT_REQUIRE(x && w && film && out && (!film_vec || (tokens_per_frame > 0 && rows % tokens_per_frame == 0)), DFOT_ERR_ARG,
+               "op_rms_film_fwd: null or misshaped argument");
   hipStream_t s = (hipStream_t)stream;
   const int hidden = channels;
+  const int tpf = film_vec ? tokens_per_frame : 1;
 #define CALL(V, C) \
-  hipLaunchKernelGGL((rms_film_fwd_kernel<V, C>), dim3(cdiv(rows, 4)), dim3(256), 0, s, x, w, (const bf16*)film, (bf16*)out, (long)rows, eps)
+  hipLaunchKernelGGL((rms_film_fwd_kernel<V, C>), dim3(cdiv(rows, 4)), dim3(256), 0, s, x, w, (const bf16*)film, (bf16*)out, (long)rows, eps, film_vec, tpf)
   DIT_LN_DISPATCH(CALL)
 #undef CALL
   DFOT_CHECK_HIP(hipGetLastError());
@@ -1034,6 +1058,22 @@ __global__ __launch_bounds__(256) void emb_grad_finish_kernel(const float* __res
   }
   *reinterpret_cast<f4*>(part + ((long)blockIdx.z * gridDim.y + bt) * E + e) = acc;
 }
+// hi = bf16(x), lo = bf16(x - hi): 8 elements per thread
+__global__ void split_bf16_kernel(const float* __restrict__ x, bf16* __restrict__ hi, bf16* __restrict__ lo, long n8) {
+  typedef __attribute__((ext_vector_type(4))) float f4;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n8) return;
+  const f4 a = reinterpret_cast<const f4*>(x)[2 * i], b = reinterpret_cast<const f4*>(x)[2 * i + 1];
+  bf16x8 h, l;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float v = j < 4 ? a[j] : b[j - 4];
+    h[j] = f2bf(v);
+    l[j] = f2bf(v - bf2f(h[j]));
+  }
+  reinterpret_cast<bf16x8*>(hi)[i] = h;
+  reinterpret_cast<bf16x8*>(lo)[i] = l;
+}
 // part[z][bt][c] = sum over the pixel chunk z of src[bt * P + p][c] (bf16 rows of pitch ld); 8 columns per thread
 __global__ __launch_bounds__(256) void frame_sums_bf16_kernel(const bf16* __restrict__ src, long ld, float* __restrict__ part, int P, int n) {
   const int bt = blockIdx.y;
@@ -1238,13 +1278,24 @@ int dfot_op_frame_sums_bf16(const void* src, int64_t ld, float* out, int bt, int
   DFOT_REQUIRE(src && out && bt > 0 && pixels > 0, DFOT_ERR_ARG, "op_frame_sums_bf16: null argument");
   DFOT_REQUIRE(n % 8 == 0 && ld % 8 == 0 && ld >= n, DFOT_ERR_SHAPE, "op_frame_sums_bf16: n = %d and ld = %ld must be multiples of 8", n, (long)ld);
   hipStream_t s = (hipStream_t)stream;
-  const int nz = pixels >= 2048 ? 32 : 1;
+  // pixel chunks per frame: ~2048 workgroups in all, at least 16 rows each
+  const int xb = cdiv(n / 8, 256);
+  int nz = 2048 / (xb * bt);
+  if (nz > pixels / 16) nz = pixels / 16;
+  if (nz < 1) nz = 1;
   float* part = nullptr;
   int rc = det_scratch(2, (size_t)nz * bt * n, &part);
   if (rc) return rc;
   hipLaunchKernelGGL(frame_sums_bf16_kernel, dim3(cdiv(n / 8, 256), bt, nz), dim3(256), 0, s, (const bf16*)src, (long)ld, part, pixels, n);
   DFOT_CHECK_HIP(hipGetLastError());
   return det_sum(part, (long)bt * n, nz, bt * n, out, false, s);
+}
+// x fp32 [n] = hi + lo with both parts in bf16 (n % 8 == 0): the operands of a three-product fp32-accurate GEMM on the bf16 matrix cores
+int dfot_op_split_bf16(const float* x, void* hi, void* lo, int64_t n, void* stream) {
+  DFOT_REQUIRE(x && hi && lo && n % 8 == 0, DFOT_ERR_ARG, "op_split_bf16: null argument or n not a multiple of 8");
+  hipLaunchKernelGGL(split_bf16_kernel, dim3(cdiv((long)n / 8, 256)), dim3(256), 0, (hipStream_t)stream, x, (bf16*)hi, (bf16*)lo, (long)n / 8);
+  DFOT_CHECK_HIP(hipGetLastError());
+  return DFOT_OK;
 }
 // C[i][j] (+)= sum_k A[i * sa_i + k * sa_k] * B[k * sb_k + j * sb_j], fp32, any strides (elements): the small dense products between
 // weight-sized matrices (folded FiLM weights and their gradients) that must not round through bf16.  Not a throughput kernel.

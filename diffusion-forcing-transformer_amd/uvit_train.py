@@ -63,11 +63,12 @@ def colsum(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def wgrad(dy: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
-    """dW [M][N] fp32 = dy^T x over the token axis; dy [rows][M], x [rows][N] bf16"""
+def wgrad(dy: torch.Tensor, x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """dW [M][N] fp32 = dy^T x over the token axis; dy [rows][M], x [rows][N] bf16; out: a contiguous [M][N] fp32 destination"""
     rows, m = dy.shape
     n = x.shape[1]
-    out = torch.empty(m, n, dtype=torch.float32, device="cuda")
+    if out is None:
+        out = torch.empty(m, n, dtype=torch.float32, device="cuda")
     capi.check(capi.lib.dfot_op_wgrad_nt(_PV(dy), dy.stride(0), _PV(x), x.stride(0), _P(out), m, n, rows, 0, _S()))  # 0: tile form / K slices by shape
     return out
 
@@ -81,6 +82,48 @@ def sgemm(a: torch.Tensor, b: torch.Tensor, ta: bool = False, tb: bool = False, 
     sa = (1, a.stride(0)) if ta else (a.stride(0), 1)     # (stride over i, stride over k)
     sb = (1, b.stride(0)) if tb else (b.stride(0), 1)     # (stride over k, stride over j)
     capi.check(capi.lib.dfot_op_sgemm(_P(a), sa[0], sa[1], _P(b), sb[0], sb[1], _P(out), out.stride(0), m, n, k, 1 if accumulate else 0, _S()))
+    return out
+
+
+def split_bf16(x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """fp32 x = hi + lo with both parts in bf16 (lo carries the next 8 mantissa bits): the operands of `wprod`"""
+    x = x.contiguous()
+    hi, lo = torch.empty(x.shape, dtype=BF, device="cuda"), torch.empty(x.shape, dtype=BF, device="cuda")
+    capi.check(capi.lib.dfot_op_split_bf16(_P(x), _P(hi), _P(lo), x.numel(), _S()))
+    return hi, lo
+
+
+def wprod(a: Tuple[torch.Tensor, torch.Tensor], b: Tuple[torch.Tensor, torch.Tensor], out: Optional[torch.Tensor] = None,
+          accumulate: bool = False) -> torch.Tensor:
+    """fp32 [M][N] (+)= A B^T for weight-sized operands given as split_bf16 pairs ([M][K], [N][K]; M a multiple of 128, K of 64):
+    Ah Bh + Ah Bl + Al Bh on the bf16 MFMA GEMM with fp32 accumulation -- relative error ~2^-16, against 2^-9 for a plain bf16 product"""
+    (ah, al), (bh, bl) = a, b
+    out = gemm_f32(ah, bh, resid=out if accumulate else None, out=out)
+    gemm_f32(ah, bl, resid=out, out=out)
+    return gemm_f32(al, bh, resid=out, out=out)
+
+
+def wprod_t(a: Tuple[torch.Tensor, torch.Tensor], b: Tuple[torch.Tensor, torch.Tensor]) -> torch.Tensor:
+    """fp32 [M][N] = A^T B for split_bf16 pairs A [rows][M], B [rows][N] that share their LONG axis (rows >> M, N; rows a multiple of
+    64): the token-axis weight-gradient kernel with K slices instead of a GEMM with a handful of output tiles"""
+    (ah, al), (bh, bl) = a, b
+    return wgrad(ah, bh) + wgrad(ah, bl) + wgrad(al, bh)
+
+
+def _pad_rows(x: torch.Tensor, mult: int = 128) -> torch.Tensor:
+    r = -(-x.shape[0] // mult) * mult
+    if r == x.shape[0]:
+        return x.contiguous()
+    o = torch.zeros(r, x.shape[1], dtype=x.dtype, device=x.device)
+    o[: x.shape[0]] = x
+    return o
+
+
+def frame_sums(src: torch.Tensor, bt: int, pixels: int) -> torch.Tensor:
+    """fp32 [bt][n]: per-frame column sums of bf16 src [bt * pixels][n]"""
+    n = src.shape[1]
+    out = torch.empty(bt, n, dtype=torch.float32, device="cuda")
+    capi.check(capi.lib.dfot_op_frame_sums_bf16(_PV(src), src.stride(0), _P(out), bt, pixels, n, _S()))
     return out
 
 
@@ -126,7 +169,7 @@ class TransformerBlockTrain:
              "q_norm.weight", "k_norm.weight", "attn_out.weight", "attn_out.bias", "mlp_out.2.weight", "mlp_out.2.bias")
 
     def __init__(self, params: Dict[str, torch.Tensor], prefix: str, channels: int, heads: int, rope: torch.Tensor, eps: float = 1e-6):
-        self.c, self.heads, self.d, self.eps, self.rope = channels, heads, channels // heads, eps, rope
+        self.c, self.heads, self.d, self.eps, self.rope, self.prefix = channels, heads, channels // heads, eps, rope, prefix
         if self.d not in (64, 128):
             raise ValueError(f"head dim {self.d} not in (64, 128)")
         self.p = {n: params[f"{prefix}.{n}"].detach().to(device="cuda", dtype=torch.float32).contiguous() for n in self.NAMES}
@@ -135,6 +178,7 @@ class TransformerBlockTrain:
         # the running-max attention kernel
         self.score_bound = float("inf")
         self._attn_pool: List[Optional[torch.Tensor]] = [None]  # replaced by the trainer's shared one
+        self.dM_out: Optional[torch.Tensor] = None               # folded FiLM: where the trainer wants this block's dM (a slice of the level's)
         self.sync()
 
     def sync(self) -> None:
@@ -145,16 +189,21 @@ class TransformerBlockTrain:
         self.b_out = (p["attn_out.bias"] + p["mlp_out.2.bias"]).contiguous()
         self.w_eT, self.w_fT, self.w_outT = transpose(self.w_e), transpose(self.w_f), transpose(self.w_out)
 
-    def forward(self, x: torch.Tensor, emb: torch.Tensor, batch: int, mlp_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, emb: Optional[torch.Tensor], batch: int, mlp_mask: Optional[torch.Tensor] = None,
+                fold: Optional[Tuple[torch.Tensor, torch.Tensor, torch.Tensor, int]] = None) -> torch.Tensor:
         """x fp32 [B*N][C] (residual stream), emb bf16 [B*N][E] (per-token conditioning embedding); returns y fp32.
-        mlp_mask: bf16 [B*N][4C] holding 0 or 1 / (1 - p): the nn.Dropout(p) after the MLP branch's SiLU (u_vit_blocks.py:230-234, training)"""
+        mlp_mask: bf16 [B*N][4C] holding 0 or 1 / (1 - p): the nn.Dropout(p) after the MLP branch's SiLU (u_vit_blocks.py:230-234, training).
+        fold = (patches bf16 [B*N][K], M bf16 [2C][K], film_vec fp32 [frames][2C], tokens per frame) instead of emb: the trainer folded
+        norm.emb_layer into the pose patch embedding (film = patches M^T + film_vec[frame], UViT3DPoseTrainer.sync); the block then leaves
+        dM = dfilm^T patches and dv = per-frame sums of dfilm (self.dM, self.dv) instead of the emb_layer / embedding gradients"""
         c, hds, d, p = self.c, self.heads, self.d, self.p
         rows = x.shape[0]
         ntok = rows // batch
         lib = capi.lib
-        film = gemm_bf16(emb, self.w_e, p["norm.emb_layer.bias"])
+        film = gemm_bf16(emb, self.w_e, p["norm.emb_layer.bias"]) if fold is None else gemm_bf16(fold[0], fold[1])
         xn = torch.empty(rows, c, dtype=BF, device="cuda")
-        capi.check(lib.dfot_op_rms_film_fwd(_P(x), _P(p["norm.norm.weight"]), _P(film), self.eps, _P(xn), rows, c, _S()))
+        capi.check(lib.dfot_op_rms_film_fwd2(_P(x), _P(p["norm.norm.weight"]), _P(film), _P(fold[2]) if fold else None, fold[3] if fold else 1, self.eps,
+                                             _P(xn), rows, c, _S()))
         q, k, v = (torch.empty(batch, hds, ntok, d, dtype=BF, device="cuda") for _ in range(3))
         cat = torch.empty(rows, 5 * c, dtype=BF, device="cuda")  # [attention output | SiLU(mlp_h)]
         if FUSED_PROJ and rows % 128 == 0:
@@ -181,12 +230,12 @@ class TransformerBlockTrain:
         if mlp_mask is not None:
             capi.check(lib.dfot_op_mul_cols(_P(cat), 5 * c, c, _P(mlp_mask), rows, 4 * c, _S()))
         y = gemm_f32(cat, self.w_out, self.b_out, resid=x)
-        self.saved = dict(x=x, emb=emb, film=film, xn=xn, fused=fused, q=q, k=k, v=v, cat=cat, lse=lse, batch=batch, mlp_mask=mlp_mask)
+        self.saved = dict(x=x, emb=emb, fold=fold, film=film, xn=xn, fused=fused, q=q, k=k, v=v, cat=cat, lse=lse, batch=batch, mlp_mask=mlp_mask)
         return y
 
     def drop_saved(self) -> None:
         """gradient checkpointing (torch.utils.checkpoint around the block, u_vit3d.py:237-243): keep the block's inputs only"""
-        self.saved = {k: self.saved[k] for k in ("x", "emb", "batch", "mlp_mask")}
+        self.saved = {k: self.saved[k] for k in ("x", "emb", "fold", "batch", "mlp_mask")}
 
     def backward(self, dy: torch.Tensor, demb_acc: Optional[torch.Tensor] = None, dy_bf: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
         """dy fp32 [B*N][C] -> (dx fp32, demb fp32 [B*N][E]); parameter gradients in self.grads (reference names).
@@ -195,7 +244,7 @@ class TransformerBlockTrain:
         ck = None
         if "xn" not in self.saved:  # gradient checkpointing: only the block's inputs were kept -- run its forward again (same kernels, same
             ck = self.saved        # dropout mask: bit-identical activations), then the ordinary backward
-            self.forward(ck["x"], ck["emb"], ck["batch"], ck["mlp_mask"])
+            self.forward(ck["x"], ck["emb"], ck["batch"], ck["mlp_mask"], ck["fold"])
         s, c, hds, d, p, lib = self.saved, self.c, self.heads, self.d, self.p, capi.lib
         rows, batch = dy.shape[0], s["batch"]
         ntok = rows // batch
@@ -220,15 +269,22 @@ class TransformerBlockTrain:
         dfilm = torch.empty(rows, 2 * c, dtype=BF, device="cuda")
         dnw = torch.empty(c, device="cuda")
         self.dx_bf = torch.empty(rows, c, dtype=BF, device="cuda")
-        capi.check(lib.dfot_op_rms_film_bwd_res(_P(s["x"]), _P(dxn), _P(p["norm.norm.weight"]), _P(s["film"]), self.eps, _P(dy), _P(dx), _P(self.dx_bf),
-                                                _P(dfilm), _P(dnw), rows, c, _S()))
-        demb = gemm_f32(dfilm, self.w_eT, resid=demb_acc, out=demb_acc)      # [rows][E]
-        self.grads = {
-            "norm.emb_layer.weight": wgrad(dfilm, s["emb"]), "norm.emb_layer.bias": colsum(dfilm), "norm.norm.weight": dnw,
+        fold = s["fold"]
+        capi.check(lib.dfot_op_rms_film_bwd_res2(_P(s["x"]), _P(dxn), _P(p["norm.norm.weight"]), _P(s["film"]), _P(fold[2]) if fold else None,
+                                                 fold[3] if fold else 1, self.eps, _P(dy), _P(dx), _P(self.dx_bf), _P(dfilm), _P(dnw), rows, c, _S()))
+        if fold is None:
+            demb = gemm_f32(dfilm, self.w_eT, resid=demb_acc, out=demb_acc)      # [rows][E]
+            self.grads = {"norm.emb_layer.weight": wgrad(dfilm, s["emb"]), "norm.emb_layer.bias": colsum(dfilm)}
+        else:
+            demb = None
+            self.dM, self.dv = wgrad(dfilm, fold[0], out=self.dM_out), frame_sums(dfilm, rows // fold[3], fold[3])
+            self.grads = {}
+        self.grads.update({
+            "norm.norm.weight": dnw,
             "fused_attn_mlp_proj.weight": dw_f, "fused_attn_mlp_proj.bias": db_f, "q_norm.weight": dqw, "k_norm.weight": dkw,
             "attn_out.weight": dw_out[:, :c].contiguous(), "attn_out.bias": db_out, "mlp_out.2.weight": dw_out[:, c:].contiguous(),
             "mlp_out.2.bias": db_out.clone(),
-        }
+        })
         if ck is not None:
             self.saved = ck  # release the recomputed activations
         return dx, demb
@@ -435,26 +491,32 @@ class UViT3DPoseTrainer:
         for b in self._blocks():
             b.sync()
         self._refresh_score_bounds(own_step)
-        # ResBlock levels: FiLM folded into the pose patch embedding.  emb = PatchEmbed(patches) keep + noise embedding is linear in the
-        # patches and emb_layer is linear in emb, so a block's film = (W_e W_p) patches + W_e (b_p keep + nemb[frame]) + b_e: the per-pixel
-        # GEMM runs over the 768-wide patches instead of the 1024-wide embedding, and the backward never forms the per-pixel embedding
-        # gradient (4.3 GB in fp32 at level 0 of config 5).  Per level: the blocks' rows in the concatenated matrices (res_cols; also their
-        # column offsets in the level's FiLM-gradient matrix), W_e concatenated [R][E] (fp32), its bias [R], and M = W_e W_p [R][kpad] (bf16)
+        # FiLM folded into the pose patch embedding, every level.  emb = PatchEmbed(patches) keep + noise embedding is linear in the
+        # patches (and average pools commute with it), and each block's emb_layer is linear in emb, so
+        #     film = (W_e W_p) patches_l + W_e (b_p keep + nemb[frame]) + b_e :
+        # the per-row GEMM runs over the 768-wide pose patches instead of the 1024-wide embedding, the per-frame part is a [BT][2C] vector,
+        # and the backward never forms a per-row embedding gradient (4.3 GB in fp32 at level 0 of config 5; one [rows][E] GEMM per
+        # transformer block).  Per level: the blocks in order, their row offsets in the concatenated matrices (= column offsets in a
+        # ResBlock level's FiLM-gradient matrix), W_e concatenated [R][E] as a split-bf16 pair, b_e [R], M = W_e W_p bf16
         self.res_cols: Dict[int, int] = {}
-        self.res_blocks: Dict[int, List[ResBlockTrain]] = {}
-        self.res_w32: Dict[int, torch.Tensor] = {}
-        self.res_b32: Dict[int, torch.Tensor] = {}
-        self.res_m: Dict[int, torch.Tensor] = {}
+        self.fold_blocks: Dict[int, list] = {}
+        self.fold_w: Dict[int, Tuple[torch.Tensor, torch.Tensor]] = {}
+        self.fold_b32: Dict[int, torch.Tensor] = {}
+        self.fold_m: Dict[int, torch.Tensor] = {}
+        self.p_split = split_bf16(self.wp32)                                       # W_p [E][kpad]
+        self.pT_split = tuple(t.t().contiguous() for t in self.p_split)            # W_p^T [kpad][E]
         for l in range(4):
-            blocks = [b for b in (self.mid if l == 3 else self.down[l] + self.up[2 - l]) if isinstance(b, ResBlockTrain)]
+            blocks = self.mid if l == 3 else self.down[l] + self.up[2 - l]
             if not blocks:
                 continue
+            key = lambda b: "emb_layer" if isinstance(b, ResBlockTrain) else "norm.emb_layer"
             for i, b in enumerate(blocks):
                 self.res_cols[id(b)] = i * 2 * self.ch[l]
-            self.res_blocks[l] = blocks
-            self.res_w32[l] = torch.cat([b.p["emb_layer.weight"].flatten(1) for b in blocks], dim=0).contiguous()
-            self.res_b32[l] = torch.cat([b.p["emb_layer.bias"] for b in blocks], dim=0).contiguous()
-            self.res_m[l] = _bf(sgemm(self.res_w32[l], self.wp32))
+            self.fold_blocks[l] = blocks
+            w32 = torch.cat([b.p[key(b) + ".weight"].flatten(1) for b in blocks], dim=0).contiguous()
+            self.fold_b32[l] = torch.cat([b.p[key(b) + ".bias"] for b in blocks], dim=0).contiguous()
+            self.fold_w[l] = split_bf16(w32)
+            self.fold_m[l] = _bf(wprod(self.fold_w[l], self.pT_split))
 
     def _blocks(self):
         return [b for lv in self.down for b in lv] + self.mid + [b for lv in self.up for b in lv]
@@ -509,16 +571,16 @@ class UViT3DPoseTrainer:
     def _run(self, blocks, x, lvl):
         p = self.block_dropouts[lvl] if self.dropout_generator is not None else 0.0
         for b in blocks:
+            c0, c2 = self.res_cols[id(b)], 2 * self.ch[lvl]
+            m_i, v_i = self.fold_m[lvl][c0: c0 + c2], self.film_vec[lvl][:, c0: c0 + c2].contiguous()
             if isinstance(b, ResBlockTrain):
-                c0, c2 = self.res_cols[id(b)], 2 * self.ch[lvl]
-                x = b.forward(x, None, self.bt, self.r[lvl], self.r[lvl], film=gemm_bf16(self.xl[lvl], self.res_m[lvl][c0: c0 + c2]),
-                              film_vec=self.film_vec[lvl][:, c0: c0 + c2].contiguous())
+                x = b.forward(x, None, self.bt, self.r[lvl], self.r[lvl], film=gemm_bf16(self.xl[lvl], m_i), film_vec=v_i)
             else:
                 mask = None
                 if p > 0:  # nn.Dropout(p) of the MLP branch: keep with probability 1 - p, scale by 1 / (1 - p)
                     keep = torch.rand(x.shape[0], 4 * self.ch[lvl], device="cuda", generator=self.dropout_generator) >= p
                     mask = (keep.to(torch.float32) / (1.0 - p)).to(BF)
-                x = b.forward(x, self.emb[lvl], self.B, mask)
+                x = b.forward(x, None, self.B, mask, fold=(self.xl[lvl], m_i, v_i, self.r[lvl] * self.r[lvl]))
             if self.use_checkpointing[lvl]:
                 b.drop_saved()
         return x
@@ -557,17 +619,10 @@ class UViT3DPoseTrainer:
         # the pyramid is taken over the pose PATCHES (average pools commute with the linear patch embedding): xl[l] [BT * r_l^2][kpad]
         self.xl = [self.patches] + [torch.empty(bt * r[l] * r[l], self.kpad, dtype=BF, device="cuda") for l in (1, 2, 3)]
         capi.check(lib.dfot_op_emb_pyramid(_P(self.xl[0]), _P(self.xl[1]), _P(self.xl[2]), _P(self.xl[3]), bt, r[0], self.kpad, _S()))
-        # per-frame part of the embedding: c = b_p keep + nemb
+        # per-frame part of the embedding, c = b_p keep + nemb, and every block's per-frame FiLM vector W_e c + b_e (a level at a time)
         self.cvec = (nemb + keep[:, None] * bp[None, :]).contiguous()
-        self.emb = [None] * 4
-        self.film_vec: Dict[int, torch.Tensor] = {}
-        for l in range(4):
-            if l in self.res_blocks:   # ResBlock level: the blocks' per-frame FiLM vectors W_e c + b_e, all blocks of the level at once
-                self.film_vec[l] = sgemm(self.cvec, self.res_w32[l], tb=True) + self.res_b32[l][None, :]
-            else:                       # transformer level: the per-token embedding itself, from the pooled patches
-                pose = gemm_bf16(self.xl[l], self.wp, bp)
-                self.emb[l] = torch.empty(bt * r[l] * r[l], e, dtype=BF, device="cuda")
-                capi.check(lib.dfot_op_emb_combine(_P(pose), _P(nemb), _P(self.drop), _P(self.emb[l]), bt, r[l] * r[l], e, t, _S()))
+        c_split = split_bf16(_pad_rows(self.cvec))  # the long axis (R) goes to the GEMM's rows: W_e c^T, transposed back
+        self.film_vec = {l: wprod(self.fold_w[l], c_split)[:, :bt].t().contiguous() + self.fold_b32[l][None, :] for l in self.fold_blocks}
         # input embedding and the U
         h = torch.empty(bt * P0, ch[0], dtype=torch.float32, device="cuda")
         capi.check(lib.dfot_op_embed_input(_P(xd), _P(p["embed_input.proj.weight"]), _P(p["embed_input.proj.bias"]), _P(h), bt, self.res, self.cin, ch[0], _S()))
@@ -611,12 +666,52 @@ class UViT3DPoseTrainer:
                     handed.add(n)
                     o, shp = self.layout[n]
                     reducer.add(self.flat_grads[o: o + gv.numel()], gv)
-        # embedding gradients.  Transformer levels: every block adds dfilm W_e into the level's fp32 accumulator [rows][E] in its GEMM
-        # epilogue.  ResBlock levels (1 M / 262 K pixel rows): the blocks write their FiLM gradients side by side into one
-        # [rows][blocks * 2C] bf16 matrix; the folded FiLM (sync) turns it into weight-sized gradients at the end of this function
-        demb: List[Optional[torch.Tensor]] = [None if l in self.res_blocks else torch.zeros(bt * r[l] * r[l], e, dtype=torch.float32, device="cuda")
-                                              for l in range(4)]
-        dfilm_cat = {l: torch.empty(bt * r[l] * r[l], w.shape[0], dtype=BF, device="cuda") for l, w in self.res_w32.items()}
+        # FiLM gradients (folded FiLM, see sync): the ResBlocks of a level write theirs side by side into one [rows][blocks * 2C] bf16 matrix,
+        # a transformer block leaves dM = dfilm^T patches and the per-frame sums of dfilm; finish_level turns either into weight-sized
+        # gradients as soon as the level's last block is done
+        dfilm_cat = {l: torch.empty(bt * r[l] * r[l], self.fold_b32[l].numel(), dtype=BF, device="cuda") for l, blocks in self.fold_blocks.items()
+                     if isinstance(blocks[0], ResBlockTrain)}
+        dP = torch.zeros(e, self.kpad, device="cuda")
+        dc = torch.zeros(bt, e, device="cuda")
+        kb = 64 * -(-bt // 64)
+        # a transformer level's dM [R][kpad]: every block's weight-gradient kernel writes its rows in place
+        dM_level = {l: torch.empty(self.fold_b32[l].numel(), self.kpad, device="cuda") for l, blocks in self.fold_blocks.items()
+                    if not isinstance(blocks[0], ResBlockTrain)}
+        for l, buf in dM_level.items():
+            for blk in self.fold_blocks[l]:
+                c0 = self.res_cols[id(blk)]
+                blk.dM_out = buf[c0: c0 + 2 * ch[l]]
+        cT = torch.zeros(e, kb, device="cuda")
+        cT[:, :bt] = self.cvec.t()
+        cT_split = split_bf16(cT)
+
+        def finish_level(l):
+            """the level's emb_layer gradients and its share of dP / dc from dM = dfilm^T patches_l [R][kpad] and dv = per-frame sums of
+            dfilm [BT][R]:  dW_e = dM W_p^T + dv^T c,  db_e = sum_frames dv,  dP += W_e^T dM,  dc += dv W_e"""
+            blocks = self.fold_blocks[l]
+            if l in dfilm_cat:
+                dM, dv = wgrad(dfilm_cat[l], self.xl[l]), frame_sums(dfilm_cat[l], bt, r[l] * r[l])
+                del dfilm_cat[l]
+            else:
+                dM, dv = dM_level[l], torch.cat([b.dv for b in blocks], dim=1)
+                for b in blocks:
+                    b.dM = b.dv = b.dM_out = None
+            R = dM.shape[0]
+            dM_split = split_bf16(dM)
+            dW = wprod(dM_split, self.p_split)
+            dvT = torch.zeros(R, kb, device="cuda")
+            dvT[:, :bt] = dv.t()
+            dvT_split = split_bf16(dvT)
+            wprod(dvT_split, cT_split, out=dW, accumulate=True)
+            db = sgemm(torch.ones(1, bt, device="cuda"), dv).view(-1)
+            dP.add_(wprod_t(self.fold_w[l], dM_split))                      # W_e^T dM: the long axis R is shared -> token-axis kernel
+            dc.add_(wprod_t(dvT_split, self.fold_w[l])[:bt])                # dv W_e
+            for blk in blocks:
+                c0, c2 = self.res_cols[id(blk)], 2 * ch[l]
+                res = isinstance(blk, ResBlockTrain)
+                name = f"{blk.prefix}.emb_layer" if res else f"{blk.prefix}.norm.emb_layer"
+                G[name + ".weight"] = dW[c0: c0 + c2].reshape((c2, e, 1, 1) if res else (c2, e)).clone()  # own storage (outputs of the autograd op must not alias)
+                G[name + ".bias"] = db[c0: c0 + c2].clone()
 
         def run_back(blocks, prefix_fn, dh, lvl):
             dh_bf = None
@@ -625,10 +720,8 @@ class UViT3DPoseTrainer:
                 if lvl in dfilm_cat:
                     c0 = self.res_cols[id(blocks[i])]
                     dh, _ = blocks[i].backward(dh, None, dfilm_cat[lvl][:, c0: c0 + 2 * ch[lvl]], dh_bf)
-                elif isinstance(blocks[i], ResBlockTrain):
-                    dh, _ = blocks[i].backward(dh, demb[lvl], None, dh_bf)
                 else:
-                    dh, _ = blocks[i].backward(dh, demb[lvl], dh_bf)  # adds its embedding gradient into the level's accumulator
+                    dh, _ = blocks[i].backward(dh, None, dh_bf)      # leaves dM / dv for finish_level
                 dh_bf = blocks[i].dx_bf
                 blocks[i].dx_bf = None
                 for n, gv in blocks[i].grads.items():
@@ -654,6 +747,8 @@ class UViT3DPoseTrainer:
             dsub[l] = dh                                              # d(h - after[l]): -> h, and minus -> after[l]
             hand_over()
         dh = run_back(self.mid, lambda i: f"mid_blocks.{i}", dh, 3)
+        if 3 in self.fold_blocks:
+            finish_level(3)
         hand_over()
         for l in (2, 1, 0):
             n = self.nud[l]
@@ -663,6 +758,8 @@ class UViT3DPoseTrainer:
             dh = dbefore[l].clone()
             capi.check(lib.dfot_op_pool2_bwd(_P(dpool), _P(dh), bt, r[l], r[l], ch[l], _S()))
             dh = run_back(self.down[l], lambda i, l=l: f"down_blocks.{l}.{i}", dh, l)
+            if l in self.fold_blocks:
+                finish_level(l)
             hand_over()
         dw, db = torch.empty_like(p["embed_input.proj.weight"]), torch.empty(ch[0], device="cuda")
         capi.check(lib.dfot_op_embed_input_wgrad(_P(dh), _P(self.x_in), _P(dw), _P(db), bt, self.res, self.cin, ch[0], self.ps, _S()))
@@ -672,37 +769,7 @@ class UViT3DPoseTrainer:
             dx = torch.empty_like(self.x_in)
             capi.check(lib.dfot_op_embed_input_dgrad(_P(dh), _P(p["embed_input.proj.weight"]), _P(dx), bt, self.res, self.cin, ch[0], self.ps, _S()))
             self.dx_in = dx.view(self.B, bt // self.B, self.cin, self.res, self.res)
-        # conditioning embedding: gradients of the emb_layer weights, the pose patch embedding (dP, d b_p) and the per-frame vector c
-        # (dc = the noise embedding's gradient), without the per-pixel embedding gradient.
-        #   ResBlock level: dM = dfilm^T patches_l [R][kpad], dv = per-frame sums of dfilm [BT][R];
-        #     dW_e = dM W_p^T + dv^T c,  db_e = sum_frames dv,  dP += W_e^T dM,  dc += dv W_e
-        #   transformer level: demb_l [rows][E] (accumulated by the blocks): dP += (demb_l keep)^T patches_l,  dc += per-frame sums of demb_l
-        dP = torch.zeros(e, self.kpad, device="cuda")
-        dc = torch.zeros(bt, e, device="cuda")
-        for l in range(4):
-            if l in dfilm_cat:
-                R = self.res_w32[l].shape[0]
-                dM = wgrad(dfilm_cat[l], self.xl[l])
-                dv = torch.empty(bt, R, device="cuda")
-                capi.check(lib.dfot_op_frame_sums_bf16(_P(dfilm_cat[l]), dfilm_cat[l].stride(0), _P(dv), bt, r[l] * r[l], R, _S()))
-                dW = sgemm(dM, self.wp32, tb=True)
-                sgemm(dv, self.cvec, ta=True, out=dW, accumulate=True)
-                db = sgemm(torch.ones(1, bt, device="cuda"), dv).view(-1)
-                sgemm(self.res_w32[l], dM, ta=True, out=dP, accumulate=True)
-                sgemm(dv, self.res_w32[l], out=dc, accumulate=True)
-                for blk in self.res_blocks[l]:
-                    c0, c2 = self.res_cols[id(blk)], 2 * ch[l]
-                    G[f"{blk.prefix}.emb_layer.weight"] = dW[c0: c0 + c2].reshape(c2, e, 1, 1).clone()  # own storage (the autograd op's outputs must not alias)
-                    G[f"{blk.prefix}.emb_layer.bias"] = db[c0: c0 + c2].clone()
-            else:
-                rows = bt * r[l] * r[l]
-                dpose = torch.empty(rows, e, dtype=BF, device="cuda")  # the pose embedding of dropped videos was replaced by zero: no gradient
-                capi.check(lib.dfot_op_masked_cast(_P(demb[l]), _P(self.drop), _P(dpose), dpose.numel(), self.T * r[l] * r[l] * e, _S()))
-                dP += wgrad(dpose, self.xl[l])
-                dsum = torch.empty(bt, e, device="cuda")
-                capi.check(lib.dfot_op_rows_sum(_P(demb[l]), _P(dsum), bt, r[l] * r[l], e, _S()))
-                dc += dsum
-        dfilm_cat.clear()
+        # pose patch embedding and the per-frame vector c = b_p keep + nemb (dc = the noise embedding's gradient): finish_level left dP, dc
         pe = "external_cond_embedding.patch_embedder.proj."
         G[pe + "weight"] = dP[:, : self.cdim * 4].reshape(e, self.cdim, self.ps, self.ps).contiguous()
         G[pe + "bias"] = sgemm(self.keep.view(1, bt), dc).view(-1)

@@ -389,8 +389,17 @@ int dfot_op_gn_silu_fwd2(const float* x, const float* gamma, const float* beta, 
 int dfot_op_gn_silu_bwd6(const float* x, const void* dy_bf, const float* stats, const float* gamma, const float* beta, const void* film,
                          const float* film_vec, const float* dres, float* dx, void* dx_bf, void* dfilm, int64_t dfilm_ld, float* dgamma, float* dbeta,
                          int bt, int pixels, int channels, void* stream);
+/* the same two-part FiLM for the TransformerBlock's NormalizeWithCond (u_vit_blocks.py:96-116): film rows per token + film_vec fp32
+ * [rows / tokens_per_frame][2C] per frame */
+int dfot_op_rms_film_fwd2(const float* x, const float* w, const void* film, const float* film_vec, int tokens_per_frame, float eps, void* out,
+                          int64_t rows, int channels, void* stream);
+int dfot_op_rms_film_bwd_res2(const float* x, const float* dxn, const float* w, const void* film, const float* film_vec, int tokens_per_frame, float eps,
+                              const float* dres, float* dx, void* dx_bf, void* dfilm, float* dw, int64_t rows, int channels, void* stream);
 /* out [bt][n] fp32 = per-frame column sums of src bf16 [bt * pixels][ld] (the gradient of film_vec from the FiLM gradients) */
 int dfot_op_frame_sums_bf16(const void* src, int64_t ld, float* out, int bt, int pixels, int n, void* stream);
+/* x fp32 = hi + lo, both bf16 (lo carries the next 8 mantissa bits): three bf16 products Ah Bh + Ah Bl + Al Bh with fp32 accumulation
+ * reproduce an fp32 product to ~2^-16 -- how the weight-sized products of the folded FiLM run on the matrix cores */
+int dfot_op_split_bf16(const float* x, void* hi, void* lo, int64_t n, void* stream);
 /* C[i][j] (+)= sum_k A[i * sa_i + k * sa_k] * B[k * sb_k + j * sb_j] in fp32 with element strides: the weight-sized products of the
  * folded FiLM (W_emb_layer W_patch and the gradients back to the two factors) */
 int dfot_op_sgemm(const float* a, int64_t sa_i, int64_t sa_k, const float* b, int64_t sb_k, int64_t sb_j, float* c, int64_t ldc, int m, int n, int k,
