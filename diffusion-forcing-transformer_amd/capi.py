@@ -152,7 +152,6 @@ SIGNATURES = {
     "dfot_op_masked_cast": (_I, [_P, _P, _P, _L, _L, _P]),
     "dfot_op_emb_pyramid": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
     "dfot_op_rows_sum": (_I, [_P, _P, _I, _I, _I, _P]),
-    "dfot_op_emb_grad_finish": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "dfot_op_cond_repack": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "dfot_op_embed_input": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "dfot_op_embed_input_wgrad": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),

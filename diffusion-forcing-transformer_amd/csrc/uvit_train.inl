@@ -1028,36 +1028,6 @@ __global__ void rows_sum_kernel(const float* __restrict__ src, float* __restrict
   for (int p = p0; p < p1; ++p) acc += src[((long)bt * P + p) * E + e];
   part[((long)blockIdx.z * gridDim.y + bt) * E + e] = acc;
 }
-// the last step of the embedding-gradient pyramid in ONE pass over the level-0 gradient (4.3 GB in fp32 at 64 frames x 128 x 128 x 1024):
-//   g = fine[bt][y][x][:] + coarse[bt][y/2][x/2][:] / 4      (pool2_bwd_kernel's sum, not written back: nothing reads it afterwards)
-//   dpose[bt][p][:] = bf16(dropped video ? 0 : g)           (masked_cast_kernel)
-//   part[z][bt][:]  = sum over the workgroup's pixel chunk of g   (rows_sum_kernel; same chunks, same order: the same bits)
-// 4 channels per thread; grid (ceil(E / 4 / 256), BT, chunks)
-__global__ __launch_bounds__(256) void emb_grad_finish_kernel(const float* __restrict__ fine, const float* __restrict__ coarse,
-                                                              const uint8_t* __restrict__ mask, bf16* __restrict__ dpose, float* __restrict__ part,
-                                                              int H, int W, int E, int tokens) {
-  typedef __attribute__((ext_vector_type(4))) float f4;
-  const int bt = blockIdx.y, P = H * W;
-  const int e = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
-  if (e >= E) return;
-  const int per = (P + gridDim.z - 1) / gridDim.z, p0 = blockIdx.z * per, p1 = p0 + per < P ? p0 + per : P;
-  const bool drop = mask && mask[bt / tokens];
-  const float* fb = fine + (long)bt * P * E + e;
-  const float* cb = coarse + (long)bt * (P / 4) * E + e;
-  bf16* ob = dpose + (long)bt * P * E + e;
-  f4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-  for (int p = p0; p < p1; ++p) {
-    const int x = p % W, y = p / W;
-    const f4 g = *reinterpret_cast<const f4*>(fb + (long)p * E) + *reinterpret_cast<const f4*>(cb + (long)((y / 2) * (W / 2) + x / 2) * E) * 0.25f;
-    acc += g;
-    bf16x4 o;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) o[j] = f2bf(drop ? 0.f : g[j]);
-    *reinterpret_cast<bf16x4*>(ob + (long)p * E) = o;
-  }
-  *reinterpret_cast<f4*>(part + ((long)blockIdx.z * gridDim.y + bt) * E + e) = acc;
-}
 // hi = bf16(x), lo = bf16(x - hi): 8 elements per thread
 __global__ void split_bf16_kernel(const float* __restrict__ x, bf16* __restrict__ hi, bf16* __restrict__ lo, long n8) {
   typedef __attribute__((ext_vector_type(4))) float f4;
@@ -1390,19 +1360,6 @@ int dfot_op_rows_sum(const float* src, float* out, int bt, int pixels, int e, vo
   hipLaunchKernelGGL(rows_sum_kernel, dim3(cdiv(e, 256), bt, nz), dim3(256), 0, s, src, part, pixels, e);
   DFOT_CHECK_HIP(hipGetLastError());
   return det_sum(part, (long)bt * e, nz, bt * e, out, false, s);
-}
-int dfot_op_emb_grad_finish(const float* fine, const float* coarse, const uint8_t* mask, void* dpose, float* dn, int bt, int h, int w, int e, int tokens,
-                            void* stream) {
-  DFOT_REQUIRE(fine && coarse && dpose && dn && bt > 0 && tokens > 0, DFOT_ERR_ARG, "op_emb_grad_finish: null argument");
-  DFOT_REQUIRE(h % 2 == 0 && w % 2 == 0 && e % 4 == 0, DFOT_ERR_SHAPE, "op_emb_grad_finish: %d x %d pixels must be even, %d channels a multiple of 4", h, w, e);
-  hipStream_t s = (hipStream_t)stream;
-  const int pixels = h * w, nz = pixels >= 2048 ? 64 : 1;  // the chunks of dfot_op_rows_sum
-  float* part = nullptr;
-  int rc = det_scratch(2, (size_t)nz * bt * e, &part);
-  if (rc) return rc;
-  hipLaunchKernelGGL(emb_grad_finish_kernel, dim3(cdiv(e / 4, 256), bt, nz), dim3(256), 0, s, fine, coarse, mask, (bf16*)dpose, part, h, w, e, tokens);
-  DFOT_CHECK_HIP(hipGetLastError());
-  return det_sum(part, (long)bt * e, nz, bt * e, dn, false, s);
 }
 int dfot_op_cond_repack(const float* cond, void* a, int bt, int res, int cdim, int kpad, void* stream) {
   return launch_cond_repack(cond, (bf16*)a, bt, res, cdim, kpad, (hipStream_t)stream);

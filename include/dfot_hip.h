@@ -418,13 +418,6 @@ int dfot_op_mul_cols(void* dst, int ldd, int dcol0, const void* mask, int64_t ro
 int dfot_op_masked_cast(const float* src, const uint8_t* mask, void* out, int64_t total, int64_t per_video, void* stream);
 int dfot_op_emb_pyramid(const void* emb0, void* emb1, void* emb2, void* emb3, int bt, int r0, int e, void* stream);
 int dfot_op_rows_sum(const float* src, float* out, int bt, int pixels, int e, void* stream);
-/* the end of the embedding-gradient pyramid in one pass (autograd through the conditioning embedding of UViT3DPose.forward,
- * u_vit3d_pose.py:63-131: 2x2 average pools of the per-pixel embedding, the pose PatchEmbed, the noise-level embedding broadcast over the
- * pixels): g = fine [BT][h][w][e] + coarse [BT][h/2][w/2][e] / 4 (fp32); dpose [BT*h*w][e] bf16 = g with the rows of dropped videos
- * (mask[bt / tokens]) zeroed; dn [BT][e] fp32 = sum of g over the pixels.  Same bits as dfot_op_pool2_bwd + dfot_op_masked_cast +
- * dfot_op_rows_sum; `fine` is not modified. */
-int dfot_op_emb_grad_finish(const float* fine, const float* coarse, const uint8_t* mask, void* dpose, float* dn, int bt, int h, int w, int e, int tokens,
-                            void* stream);
 int dfot_op_cond_repack(const float* cond, void* a, int bt, int res, int cdim, int kpad, void* stream);
 int dfot_op_embed_input(const float* x, const float* w, const float* b, float* out, int bt, int res, int cin, int c0, void* stream);
 int dfot_op_embed_input_wgrad(const float* dx0, const float* x, float* dw, float* db, int bt, int res, int cin, int c0, int ps, void* stream);

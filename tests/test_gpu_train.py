@@ -503,34 +503,92 @@ def test_conv3x3_backward_bf16_data_gradient_feeds_the_groupnorm_backward(bt, h,
     assert torch.equal(dx_bf.view(bt, pix, c), dx.to(torch.bfloat16))
 
 
-@pytest.mark.parametrize("bt,h,e,tokens", [(4, 16, 64, 2), (6, 64, 1024, 3)])
-def test_embedding_gradient_finish_equals_the_three_passes(bt, h, e, tokens):
-    """dfot_op_emb_grad_finish (one pass over the level-0 embedding gradient) gives the bits of dfot_op_pool2_bwd + dfot_op_masked_cast +
-    dfot_op_rows_sum, with and without dropped videos, and leaves its fp32 input untouched"""
+def test_folded_film_helpers_frame_sums_split_products():
+    """the small pieces of the folded FiLM (uvit_train.UViT3DPoseTrainer.sync): per-frame column sums of a bf16 matrix, the strided fp32
+    product in its four orientations, and the split-bf16 products (three MFMA GEMMs / token-axis kernels) against fp64"""
+    from dfot_amd import capi, uvit_train as ut
+    g = torch.Generator().manual_seed(5)
+    bt, pix, n = 6, 320, 264
+    src = torch.randn(bt * pix, n + 8, generator=g).to(torch.bfloat16).cuda()
+    got = ut.frame_sums(src[:, :n], bt, pix)
+    assert rel(got.cpu(), src[:, :n].float().view(bt, pix, n).sum(1).cpu()) < 1e-6
+    a, b = torch.randn(70, 45, generator=g).cuda(), torch.randn(45, 33, generator=g).cuda()
+    want = (a.double() @ b.double()).float()
+    assert rel(ut.sgemm(a, b).cpu(), want.cpu()) < 1e-6
+    assert rel(ut.sgemm(a.t().contiguous(), b, ta=True).cpu(), want.cpu()) < 1e-6
+    assert rel(ut.sgemm(a, b.t().contiguous(), tb=True).cpu(), want.cpu()) < 1e-6
+    acc = torch.ones(70, 33, device="cuda")
+    ut.sgemm(a.t().contiguous(), b.t().contiguous(), ta=True, tb=True, out=acc, accumulate=True)
+    assert rel(acc.cpu(), (want + 1).cpu()) < 1e-6
+    # split-bf16 products: fp32 accuracy from bf16 matrix cores
+    x = torch.randn(256, 192, generator=g).cuda() * 3
+    hi, lo = ut.split_bf16(x)
+    assert float((hi.float() + lo.float() - x).abs().max() / x.abs().max()) < 2.0 ** -15
+    w = torch.randn(384, 192, generator=g).cuda()
+    ref = (x.double() @ w.double().t())
+    got = ut.wprod(ut.split_bf16(x), ut.split_bf16(w))
+    plain = ut.gemm_f32(ut._bf(x), ut._bf(w))
+    e3, e1 = rel(got.cpu(), ref.float().cpu()), rel(plain.cpu(), ref.float().cpu())
+    print(f"split-bf16 product: rel error {e3:.1e} (one bf16 product: {e1:.1e})")
+    assert e3 < 3e-5 and e1 > 20 * e3
+    rows = 4096                                      # the long axis shared: A^T B on the token-axis kernel
+    A, B = torch.randn(rows, 128, generator=g).cuda(), torch.randn(rows, 64, generator=g).cuda()
+    got_t = ut.wprod_t(ut.split_bf16(A), ut.split_bf16(B))
+    assert rel(got_t.cpu(), (A.double().t() @ B.double()).float().cpu()) < 3e-5
+
+
+@pytest.mark.parametrize("c", [128, 256])
+def test_groupnorm_and_rms_film_with_a_per_frame_film_vector(c):
+    """the two-part FiLM entries (rows per pixel / token + an fp32 vector per frame: dfot_op_gn_silu_fwd2 / _bwd6, dfot_op_rms_film_fwd2 /
+    _bwd_res2) against torch autograd with the vector added to the rows"""
     from dfot_amd import capi
-    g = torch.Generator().manual_seed(bt * h + e)
-    P = h * h
-    fine = torch.randn(bt, P, e, generator=g).cuda()
-    coarse = torch.randn(bt, P // 4, e, generator=g).cuda()
-    for mask in (None, torch.tensor([1] + [0] * (bt // tokens - 1), dtype=torch.uint8).cuda()):
-        ref = fine.clone()
-        capi.check(capi.lib.dfot_op_pool2_bwd(capi.ptr(coarse), capi.ptr(ref), bt, h, h, e, capi.stream_ptr()))
-        want_pose = torch.empty(bt * P, e, dtype=torch.bfloat16, device="cuda")
-        capi.check(capi.lib.dfot_op_masked_cast(capi.ptr(ref), capi.ptr(mask), capi.ptr(want_pose), want_pose.numel(), tokens * P * e, capi.stream_ptr()))
-        want_dn = torch.empty(bt, e, device="cuda")
-        capi.check(capi.lib.dfot_op_rows_sum(capi.ptr(ref), capi.ptr(want_dn), bt, P, e, capi.stream_ptr()))
-        keep = fine.clone()
-        got_pose = torch.full((bt * P, e), float("nan"), dtype=torch.bfloat16, device="cuda")
-        got_dn = torch.full((bt, e), float("nan"), device="cuda")
-        capi.check(capi.lib.dfot_op_emb_grad_finish(capi.ptr(fine), capi.ptr(coarse), capi.ptr(mask), capi.ptr(got_pose), capi.ptr(got_dn), bt, h, h, e,
-                                                    tokens, capi.stream_ptr()))
-        torch.cuda.synchronize()
-        assert torch.equal(got_pose, want_pose) and torch.equal(got_dn, want_dn) and torch.equal(fine, keep)
-        if mask is not None:
-            assert float(got_pose[: tokens * P].float().abs().max()) == 0.0 and float(got_pose[tokens * P:].float().abs().max()) > 0.0
-        # the reference formula on the host
-        up = coarse.view(bt, h // 2, h // 2, e).repeat_interleave(2, 1).repeat_interleave(2, 2).reshape(bt, P, e)
-        assert rel(got_dn.cpu(), (fine + 0.25 * up).sum(1).cpu()) < 1e-5
+    F = torch.nn.functional
+    g = torch.Generator().manual_seed(c)
+    bt, pix = 3, 256
+    x = torch.randn(bt, pix, c, generator=g) * 1.5 + 0.3
+    gamma, beta = torch.randn(c, generator=g) * 0.5 + 1, torch.randn(c, generator=g) * 0.2
+    film = (torch.randn(bt * pix, 2 * c, generator=g) * 0.4).to(torch.bfloat16)
+    vec = torch.randn(bt, 2 * c, generator=g) * 0.4
+    dy = torch.randn(bt, pix, c, generator=g).to(torch.bfloat16)
+    xd, gd, bd, fd, vd, dyd = x.cuda(), gamma.cuda(), beta.cuda(), film.cuda(), vec.cuda(), dy.cuda()
+    P, S = capi.ptr, capi.stream_ptr
+    out = torch.empty(bt * pix, c, dtype=torch.bfloat16, device="cuda")
+    stats = torch.empty(bt, 32, 2, device="cuda")
+    capi.check(capi.lib.dfot_op_gn_silu_fwd2(P(xd), P(gd), P(bd), P(fd), P(vd), 1e-6, P(out), P(stats), bt, pix, c, S()))
+    dx, dfl = torch.full((bt, pix, c), float("nan"), device="cuda"), torch.empty(bt * pix, 2 * c, dtype=torch.bfloat16, device="cuda")
+    dga, dbe = torch.empty(c, device="cuda"), torch.empty(c, device="cuda")
+    capi.check(capi.lib.dfot_op_gn_silu_bwd6(P(xd), P(dyd), P(stats), P(gd), P(bd), P(fd), P(vd), None, P(dx), None, P(dfl), 2 * c, P(dga), P(dbe), bt, pix, c,
+                                             S()))
+    torch.cuda.synchronize()
+    xr, gr, br = x.clone().requires_grad_(), gamma.clone().requires_grad_(), beta.clone().requires_grad_()
+    fr = (film.float().view(bt, pix, 2 * c) + vec[:, None, :]).requires_grad_()
+    h = F.group_norm(xr.permute(0, 2, 1), 32, gr, br, 1e-6).permute(0, 2, 1)
+    y = F.silu(h * (1 + fr[..., :c]) + fr[..., c:])
+    y.backward(dy.float())
+    rs = [rel(out.float().cpu().view(bt, pix, c), y.detach()), rel(dx.cpu(), xr.grad), rel(dga.cpu(), gr.grad), rel(dbe.cpu(), br.grad),
+          rel(dfl.float().cpu().view(bt, pix, 2 * c), fr.grad)]
+    print(f"GroupNorm with a per-frame FiLM vector, C={c}: " + " ".join(f"{r:.1e}" for r in rs))
+    assert rs[0] < 5e-3 and max(rs[1:4]) < 1e-4 and rs[4] < 5e-3
+    # RMS-FiLM (NormalizeWithCond) with tokens_per_frame = pix
+    rows = bt * pix
+    w = (torch.randn(c, generator=g) * 0.3 + 1)
+    dxn, dres = torch.randn(rows, c, generator=g), torch.randn(rows, c, generator=g)
+    x2 = x.view(rows, c).contiguous()
+    x2d, wd, dxnd, dresd = x2.cuda(), w.cuda(), dxn.cuda(), dres.cuda()
+    xn = torch.empty(rows, c, dtype=torch.bfloat16, device="cuda")
+    capi.check(capi.lib.dfot_op_rms_film_fwd2(P(x2d), P(wd), P(fd), P(vd), pix, 1e-6, P(xn), rows, c, S()))
+    dx2, dxb = torch.full((rows, c), float("nan"), device="cuda"), torch.empty(rows, c, dtype=torch.bfloat16, device="cuda")
+    dfl2, dw = torch.empty(rows, 2 * c, dtype=torch.bfloat16, device="cuda"), torch.empty(c, device="cuda")
+    capi.check(capi.lib.dfot_op_rms_film_bwd_res2(P(x2d), P(dxnd), P(wd), P(fd), P(vd), pix, 1e-6, P(dresd), P(dx2), P(dxb), P(dfl2), P(dw), rows, c, S()))
+    torch.cuda.synchronize()
+    xr, wr = x2.clone().requires_grad_(), w.clone().requires_grad_()
+    fr = (film.float() + vec.repeat_interleave(pix, 0)).requires_grad_()
+    yn = xr * torch.rsqrt(xr.pow(2).mean(-1, keepdim=True) + 1e-6) * wr
+    o = yn * (1 + fr[:, :c]) + fr[:, c:]
+    o.backward(dxn)
+    rs = [rel(xn.float().cpu(), o.detach()), rel(dx2.cpu() - dres, xr.grad), rel(dw.cpu(), wr.grad), rel(dfl2.float().cpu(), fr.grad)]
+    print(f"RMS-FiLM with a per-frame FiLM vector, C={c}: " + " ".join(f"{r:.1e}" for r in rs))
+    assert rs[0] < 5e-3 and max(rs[1:3]) < 1e-4 and rs[3] < 5e-3
 
 
 @pytest.mark.parametrize("rows,c", [(512, 576), (300, 1152), (64, 128)])
