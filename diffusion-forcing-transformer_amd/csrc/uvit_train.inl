@@ -187,7 +187,7 @@ template <bool FILM, typename TDY>
 __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const float* __restrict__ x, const TDY* __restrict__ dy, const float* __restrict__ stats,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
                                                             const bf16* __restrict__ film, float* __restrict__ part, int P, int C, int chunk,
-                                                            const float* __restrict__ fvec) {
+                                                            const float* __restrict__ fvec, long ldfilm) {
   typedef __attribute__((ext_vector_type(4))) float f4;
   __shared__ f4 red[4][256];  // [quantity][thread]
   const int bt = blockIdx.x, p0 = blockIdx.y * chunk;
@@ -213,7 +213,7 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const float* __restr
       const f4 xv = *reinterpret_cast<const f4*>(x + e), dv = gn_load_dy4(dy + e);
       bf16x4 fs, fh;
       if (FILM) {
-        const long f = ((long)bt * P + p) * 2 * C + c;
+        const long f = ((long)bt * P + p) * ldfilm + c;
         fs = *reinterpret_cast<const bf16x4*>(film + f);
         fh = *reinterpret_cast<const bf16x4*>(film + f + C);
       }
@@ -262,7 +262,8 @@ template <bool FILM, typename TDY>
 __global__ void gn_bwd_apply_kernel(const float* __restrict__ x, const TDY* __restrict__ dy, const float* __restrict__ stats,
                                     const float* __restrict__ gamma, const float* __restrict__ beta, const bf16* __restrict__ film,
                                     const float* __restrict__ sums, float* dx, bf16* __restrict__ dfilm, long total4, int P, int C,
-                                    int accumulate, long ldf, const float* dres, bf16* __restrict__ dx_bf, const float* __restrict__ fvec) {
+                                    int accumulate, long ldf, const float* dres, bf16* __restrict__ dx_bf, const float* __restrict__ fvec,
+                                    long ldfilm) {
   typedef __attribute__((ext_vector_type(4))) float f4;
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;  // 4 channels of one pixel (they share a group: C / 32 >= 4)
   if (i >= total4) return;
@@ -280,8 +281,8 @@ __global__ void gn_bwd_apply_kernel(const float* __restrict__ x, const TDY* __re
   bf16x4 fs, fh, ds, dh;
   f4 vs = {0.f, 0.f, 0.f, 0.f}, vh = vs;
   if (FILM) {
-    fs = *reinterpret_cast<const bf16x4*>(film + row * 2 * C + c);
-    fh = *reinterpret_cast<const bf16x4*>(film + row * 2 * C + C + c);
+    fs = *reinterpret_cast<const bf16x4*>(film + row * ldfilm + c);
+    fh = *reinterpret_cast<const bf16x4*>(film + row * ldfilm + C + c);
     if (fvec) {
       vs = *reinterpret_cast<const f4*>(fvec + (long)bt * 2 * C + c);
       vh = *reinterpret_cast<const f4*>(fvec + (long)bt * 2 * C + C + c);
@@ -323,8 +324,9 @@ __global__ void gn_bwd_apply_kernel(const float* __restrict__ x, const TDY* __re
 template <typename TDY>
 int gn_silu_backward(const float* x, const TDY* dy, const float* stats, const float* gamma, const float* beta, const bf16* film, float* sums,
                      float* dx, bf16* dfilm, float* dgamma, float* dbeta, int bt, int P, int C, bool accumulate, hipStream_t s, long ldf = 0,
-                     const float* dres = nullptr, bf16* dx_bf = nullptr, const float* fvec = nullptr) {
+                     const float* dres = nullptr, bf16* dx_bf = nullptr, const float* fvec = nullptr, long ldfilm = 0) {
   if (ldf == 0) ldf = 2L * C;
+  if (ldfilm == 0) ldfilm = 2L * C;
   DFOT_REQUIRE(dx || dx_bf, DFOT_ERR_ARG, "gn_silu_backward: no output");
   DFOT_REQUIRE(!accumulate || dres || dx, DFOT_ERR_ARG, "gn_silu_backward: nothing to accumulate onto");
   DFOT_REQUIRE(C % 128 == 0 && C <= 1024 && 256 % (C / 4 < 256 ? C / 4 : 256) == 0 && (film == nullptr) == (dfilm == nullptr), DFOT_ERR_ARG,
@@ -339,19 +341,19 @@ int gn_silu_backward(const float* x, const TDY* dy, const float* stats, const fl
   int rc = det_scratch(2, (size_t)grid.x * grid.y * rowlen, &part);
   if (rc) return rc;
   if (film)
-    hipLaunchKernelGGL((gn_bwd_reduce_kernel<true, TDY>), grid, dim3(256), 0, s, x, dy, stats, gamma, beta, film, part, P, C, chunk, fvec);
+    hipLaunchKernelGGL((gn_bwd_reduce_kernel<true, TDY>), grid, dim3(256), 0, s, x, dy, stats, gamma, beta, film, part, P, C, chunk, fvec, ldfilm);
   else
-    hipLaunchKernelGGL((gn_bwd_reduce_kernel<false, TDY>), grid, dim3(256), 0, s, x, dy, stats, gamma, beta, film, part, P, C, chunk, fvec);
+    hipLaunchKernelGGL((gn_bwd_reduce_kernel<false, TDY>), grid, dim3(256), 0, s, x, dy, stats, gamma, beta, film, part, P, C, chunk, fvec, ldfilm);
   DFOT_CHECK_HIP(hipGetLastError());
   if ((rc = det_sum(part + 2L * C, rowlen, (int)grid.y, 64, sums, false, s, bt, (long)grid.y * rowlen, 64))) return rc;
   if ((rc = det_sum(part, rowlen, (int)(grid.x * grid.y), C, dgamma, false, s))) return rc;
   if ((rc = det_sum(part + C, rowlen, (int)(grid.x * grid.y), C, dbeta, false, s))) return rc;
   if (film) {
     hipLaunchKernelGGL((gn_bwd_apply_kernel<true, TDY>), dim3(cdiv(total, 256)), dim3(256), 0, s, x, dy, stats, gamma, beta, film, sums, dx, dfilm, total, P, C,
-                       accumulate ? 1 : 0, ldf, dres, dx_bf, fvec);
+                       accumulate ? 1 : 0, ldf, dres, dx_bf, fvec, ldfilm);
   } else {
     hipLaunchKernelGGL((gn_bwd_apply_kernel<false, TDY>), dim3(cdiv(total, 256)), dim3(256), 0, s, x, dy, stats, gamma, beta, film, sums, dx, dfilm, total, P, C,
-                       accumulate ? 1 : 0, ldf, dres, dx_bf, fvec);
+                       accumulate ? 1 : 0, ldf, dres, dx_bf, fvec, ldfilm);
   }
   DFOT_CHECK_HIP(hipGetLastError());
   return DFOT_OK;
@@ -998,7 +1000,7 @@ namespace {
 // per-pixel part was folded into the pose patches (uvit_train.py: film = M patches + fvec)
 __global__ void gn_silu_fwd_kernel(const float* __restrict__ x, const float* __restrict__ stats, const float* __restrict__ gamma,
                                    const float* __restrict__ beta, const bf16* __restrict__ film, bf16* __restrict__ out, long total4, int P, int C,
-                                   const float* __restrict__ fvec) {
+                                   const float* __restrict__ fvec, long ldfilm) {
   typedef __attribute__((ext_vector_type(4))) float f4;
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;  // 4 channels of one pixel (one group: C / 32 >= 4)
   if (i >= total4) return;
@@ -1010,9 +1012,9 @@ __global__ void gn_silu_fwd_kernel(const float* __restrict__ x, const float* __r
   const f4 xv = *reinterpret_cast<const f4*>(x + row * C + c);
   const f4 ga = *reinterpret_cast<const f4*>(gamma + c), be = *reinterpret_cast<const f4*>(beta + c);
   bf16x4 fs, fh, o;
-  if (film) {
-    fs = *reinterpret_cast<const bf16x4*>(film + row * 2 * C + c);
-    fh = *reinterpret_cast<const bf16x4*>(film + row * 2 * C + C + c);
+  if (film) {  // ldfilm: the block's (scale | shift) columns may be a column block of the level's FiLM matrix
+    fs = *reinterpret_cast<const bf16x4*>(film + row * ldfilm + c);
+    fh = *reinterpret_cast<const bf16x4*>(film + row * ldfilm + C + c);
   }
   f4 vs = {0.f, 0.f, 0.f, 0.f}, vh = vs;
   if (film && fvec) {
@@ -1259,11 +1261,12 @@ using namespace dfot;
 
 int dfot_op_gn_silu_fwd(const float* x, const float* gamma, const float* beta, const void* film, float eps, void* out, float* stats, int bt,
                         int pixels, int channels, void* stream) {
-  return dfot_op_gn_silu_fwd2(x, gamma, beta, film, nullptr, eps, out, stats, bt, pixels, channels, stream);
+  return dfot_op_gn_silu_fwd2(x, gamma, beta, film, 2 * channels, nullptr, eps, out, stats, bt, pixels, channels, stream);
 }
-int dfot_op_gn_silu_fwd2(const float* x, const float* gamma, const float* beta, const void* film, const float* film_vec, float eps, void* out,
-                         float* stats, int bt, int pixels, int channels, void* stream) {
-  DFOT_REQUIRE(x && gamma && beta && out && stats && channels % 32 == 0 && (film || !film_vec), DFOT_ERR_ARG, "op_gn_silu_fwd: bad argument");
+int dfot_op_gn_silu_fwd2(const float* x, const float* gamma, const float* beta, const void* film, int64_t film_ld, const float* film_vec, float eps,
+                         void* out, float* stats, int bt, int pixels, int channels, void* stream) {
+  DFOT_REQUIRE(x && gamma && beta && out && stats && channels % 32 == 0 && (film || !film_vec) && (!film || (film_ld >= 2 * channels && film_ld % 4 == 0)),
+               DFOT_ERR_ARG, "op_gn_silu_fwd: bad argument");
   hipStream_t s = (hipStream_t)stream;
   DFOT_REQUIRE(channels % 128 == 0, DFOT_ERR_SHAPE, "op_gn_silu_fwd: channels %d must be a multiple of 128", channels);
   // statistics: streaming partial sums over 64-pixel blocks of all channels + a deterministic finalize (the inference kernels); one
@@ -1276,7 +1279,7 @@ int dfot_op_gn_silu_fwd2(const float* x, const float* gamma, const float* beta, 
   if ((rc = launch_gn_finalize((const float*)part, stats, bt, nblk, pixels, channels, eps, s))) return rc;
   const long total = (long)bt * pixels * (channels / 4);
   hipLaunchKernelGGL(gn_silu_fwd_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, x, stats, gamma, beta, (const bf16*)film, (bf16*)out, total, pixels,
-                     channels, film_vec);
+                     channels, film_vec, (long)film_ld);
   DFOT_CHECK_HIP(hipGetLastError());
   return DFOT_OK;
 }
@@ -1334,17 +1337,18 @@ int dfot_op_gn_silu_bwd5(const float* x, const void* dy_bf, const float* stats, 
 // dfot_op_gn_silu_bwd5 for a FiLM projection split into per-pixel rows (film) and a per-frame vector (film_vec fp32 [BT][2C], see
 // dfot_op_gn_silu_fwd2); dfilm is the gradient of the SUM (of either part)
 int dfot_op_gn_silu_bwd6(const float* x, const void* dy_bf, const float* stats, const float* gamma, const float* beta, const void* film,
-                         const float* film_vec, const float* dres, float* dx, void* dx_bf, void* dfilm, int64_t dfilm_ld, float* dgamma, float* dbeta,
-                         int bt, int pixels, int channels, void* stream) {
-  DFOT_REQUIRE(x && dy_bf && stats && gamma && beta && (dx || dx_bf) && dgamma && dbeta && (!dres || dres != dx) && (film || !film_vec), DFOT_ERR_ARG,
-               "op_gn_silu_bwd6: null or aliased argument");
+                         int64_t film_ld, const float* film_vec, const float* dres, float* dx, void* dx_bf, void* dfilm, int64_t dfilm_ld,
+                         float* dgamma, float* dbeta, int bt, int pixels, int channels, void* stream) {
+  DFOT_REQUIRE(x && dy_bf && stats && gamma && beta && (dx || dx_bf) && dgamma && dbeta && (!dres || dres != dx) && (film || !film_vec) &&
+                   (!film || (film_ld >= 2 * channels && film_ld % 4 == 0)),
+               DFOT_ERR_ARG, "op_gn_silu_bwd6: null, aliased or misshaped argument");
   DFOT_REQUIRE(!dfilm || (dfilm_ld >= 2 * channels && dfilm_ld % 4 == 0), DFOT_ERR_ARG, "op_gn_silu_bwd6: bad dfilm row stride");
   hipStream_t s = (hipStream_t)stream;
   void* sums = nullptr;
   int rc = op_scratch(4, (size_t)bt * 64 * sizeof(float), &sums);
   if (rc) return rc;
   return gn_silu_backward(x, (const bf16*)dy_bf, stats, gamma, beta, (const bf16*)film, (float*)sums, dx, (bf16*)dfilm, dgamma, dbeta, bt, pixels,
-                          channels, dres != nullptr, s, (long)dfilm_ld, dres, (bf16*)dx_bf, film_vec);
+                          channels, dres != nullptr, s, (long)dfilm_ld, dres, (bf16*)dx_bf, film_vec, (long)film_ld);
 }
 // out [bt][n] fp32 = sum over the frame's `pixels` rows of src bf16 [bt * pixels][ld] (columns 0..n): per-frame column sums,
 // deterministic (partial rows per pixel chunk + fixed-order sum); n % 8 == 0, ld % 8 == 0

@@ -347,8 +347,8 @@ class ResBlockTrain:
         if not folded:
             film = gemm_bf16(emb, self.w_e, p["emb_layer.bias"])
         h2 = torch.empty(bt * P, c, dtype=BF, device="cuda")
-        capi.check(lib.dfot_op_gn_silu_fwd2(_P(c1), _P(p["out_norm.weight"]), _P(p["out_norm.bias"]), _P(film), _P(film_vec), self.eps, _P(h2), _P(st2), bt,
-                                            P, c, _S()))
+        capi.check(lib.dfot_op_gn_silu_fwd2(_P(c1), _P(p["out_norm.weight"]), _P(p["out_norm.bias"]), _PV(film), film.stride(0), _P(film_vec), self.eps,
+                                            _P(h2), _P(st2), bt, P, c, _S()))
         y = conv3x3(h2, self.w2, p["out_rest.1.bias"], bt, h, w, c, c, resid=x)
         self.saved = dict(x=x, emb=emb, h1=h1, c1=c1, film=film, film_vec=film_vec, folded=folded, h2=h2, st1=st1, st2=st2, geom=(bt, h, w))
         return y
@@ -375,8 +375,9 @@ class ResBlockTrain:
         dg2, dbe2, dg1, dbe1 = (torch.empty(c, dtype=torch.float32, device="cuda") for _ in range(4))
         # the gradient of the first convolution's output only feeds that convolution's data / weight gradients: bf16 alone
         dc1 = torch.empty(bt * P, c, dtype=BF, device="cuda")
-        capi.check(lib.dfot_op_gn_silu_bwd6(_P(s["c1"]), _P(dh2), _P(s["st2"]), _P(p["out_norm.weight"]), _P(p["out_norm.bias"]), _P(s["film"]),
-                                            _P(s["film_vec"]), None, None, _P(dc1), _PV(dfilm), dfilm.stride(0), _P(dg2), _P(dbe2), bt, P, c, _S()))
+        capi.check(lib.dfot_op_gn_silu_bwd6(_P(s["c1"]), _P(dh2), _P(s["st2"]), _P(p["out_norm.weight"]), _P(p["out_norm.bias"]), _PV(s["film"]),
+                                            s["film"].stride(0), _P(s["film_vec"]), None, None, _P(dc1), _PV(dfilm), dfilm.stride(0), _P(dg2), _P(dbe2),
+                                            bt, P, c, _S()))
         demb = None if (dfilm_out is not None or s["folded"]) else gemm_f32(dfilm, self.w_eT, resid=demb_acc, out=demb_acc)
         dh1, dw1, db1 = conv3x3_backward(s["h1"], dc1, p["in_layers.2.weight"], bt, h, w, c, c, dx_bf16=True)
         # dx = dy (residual path) + the first norm's input gradient, in fp32 for the stream and in bf16 for the block below
@@ -574,7 +575,11 @@ class UViT3DPoseTrainer:
             c0, c2 = self.res_cols[id(b)], 2 * self.ch[lvl]
             m_i, v_i = self.fold_m[lvl][c0: c0 + c2], self.film_vec[lvl][:, c0: c0 + c2].contiguous()
             if isinstance(b, ResBlockTrain):
-                x = b.forward(x, None, self.bt, self.r[lvl], self.r[lvl], film=gemm_bf16(self.xl[lvl], m_i), film_vec=v_i)
+                # the level's ResBlocks share ONE projection GEMM (N = blocks * 2C): the patches are read once, not once per block
+                # (level 0 of config 5: 1.6 GB of patches against 0.5 GB of output per block -- the per-block GEMM was HBM-bound)
+                if lvl not in self.film_cat:
+                    self.film_cat[lvl] = gemm_bf16(self.xl[lvl], self.fold_m[lvl])
+                x = b.forward(x, None, self.bt, self.r[lvl], self.r[lvl], film=self.film_cat[lvl][:, c0: c0 + c2], film_vec=v_i)
             else:
                 mask = None
                 if p > 0:  # nn.Dropout(p) of the MLP branch: keep with probability 1 - p, scale by 1 / (1 - p)
@@ -621,6 +626,7 @@ class UViT3DPoseTrainer:
         capi.check(lib.dfot_op_emb_pyramid(_P(self.xl[0]), _P(self.xl[1]), _P(self.xl[2]), _P(self.xl[3]), bt, r[0], self.kpad, _S()))
         # per-frame part of the embedding, c = b_p keep + nemb, and every block's per-frame FiLM vector W_e c + b_e (a level at a time)
         self.cvec = (nemb + keep[:, None] * bp[None, :]).contiguous()
+        self.film_cat: Dict[int, torch.Tensor] = {}
         c_split = split_bf16(_pad_rows(self.cvec))  # the long axis (R) goes to the GEMM's rows: W_e c^T, transposed back
         self.film_vec = {l: wprod(self.fold_w[l], c_split)[:, :bt].t().contiguous() + self.fold_b32[l][None, :] for l in self.fold_blocks}
         # input embedding and the U

@@ -384,11 +384,12 @@ int dfot_op_gn_silu_bwd5(const float* x, const void* dy_bf, const float* stats, 
  * maps are linear, so film = (W_emb_layer W_patch) patches + W_emb_layer (b_patch keep + noise_emb[frame]) + b: the per-pixel part is a
  * GEMM over the 768-wide pose patches instead of the 1024-wide embedding, the per-frame part a [BT][2C] vector (film_vec, fp32), and the
  * backward never forms the per-pixel embedding gradient.  These entries take the two parts. */
-int dfot_op_gn_silu_fwd2(const float* x, const float* gamma, const float* beta, const void* film, const float* film_vec, float eps, void* out,
-                         float* stats, int bt, int pixels, int channels, void* stream);
+/* film_ld: row pitch of `film` in elements (>= 2C): the block's (scale | shift) columns may be a column block of a level-wide matrix */
+int dfot_op_gn_silu_fwd2(const float* x, const float* gamma, const float* beta, const void* film, int64_t film_ld, const float* film_vec, float eps,
+                         void* out, float* stats, int bt, int pixels, int channels, void* stream);
 int dfot_op_gn_silu_bwd6(const float* x, const void* dy_bf, const float* stats, const float* gamma, const float* beta, const void* film,
-                         const float* film_vec, const float* dres, float* dx, void* dx_bf, void* dfilm, int64_t dfilm_ld, float* dgamma, float* dbeta,
-                         int bt, int pixels, int channels, void* stream);
+                         int64_t film_ld, const float* film_vec, const float* dres, float* dx, void* dx_bf, void* dfilm, int64_t dfilm_ld,
+                         float* dgamma, float* dbeta, int bt, int pixels, int channels, void* stream);
 /* the same two-part FiLM for the TransformerBlock's NormalizeWithCond (u_vit_blocks.py:96-116): film rows per token + film_vec fp32
  * [rows / tokens_per_frame][2C] per frame */
 int dfot_op_rms_film_fwd2(const float* x, const float* w, const void* film, const float* film_vec, int tokens_per_frame, float eps, void* out,

@@ -552,13 +552,17 @@ def test_groupnorm_and_rms_film_with_a_per_frame_film_vector(c):
     dy = torch.randn(bt, pix, c, generator=g).to(torch.bfloat16)
     xd, gd, bd, fd, vd, dyd = x.cuda(), gamma.cuda(), beta.cuda(), film.cuda(), vec.cuda(), dy.cuda()
     P, S = capi.ptr, capi.stream_ptr
+    # the block's film columns as a column block of a wider (level-wide) matrix: row pitch 6C, columns [2C, 4C)
+    wide = torch.full((bt * pix, 6 * c), float("nan"), dtype=torch.bfloat16, device="cuda")
+    wide[:, 2 * c: 4 * c] = fd
+    fview = wide[:, 2 * c: 4 * c]
     out = torch.empty(bt * pix, c, dtype=torch.bfloat16, device="cuda")
     stats = torch.empty(bt, 32, 2, device="cuda")
-    capi.check(capi.lib.dfot_op_gn_silu_fwd2(P(xd), P(gd), P(bd), P(fd), P(vd), 1e-6, P(out), P(stats), bt, pix, c, S()))
+    capi.check(capi.lib.dfot_op_gn_silu_fwd2(P(xd), P(gd), P(bd), capi.ptr_rows(fview), 6 * c, P(vd), 1e-6, P(out), P(stats), bt, pix, c, S()))
     dx, dfl = torch.full((bt, pix, c), float("nan"), device="cuda"), torch.empty(bt * pix, 2 * c, dtype=torch.bfloat16, device="cuda")
     dga, dbe = torch.empty(c, device="cuda"), torch.empty(c, device="cuda")
-    capi.check(capi.lib.dfot_op_gn_silu_bwd6(P(xd), P(dyd), P(stats), P(gd), P(bd), P(fd), P(vd), None, P(dx), None, P(dfl), 2 * c, P(dga), P(dbe), bt, pix, c,
-                                             S()))
+    capi.check(capi.lib.dfot_op_gn_silu_bwd6(P(xd), P(dyd), P(stats), P(gd), P(bd), capi.ptr_rows(fview), 6 * c, P(vd), None, P(dx), None, P(dfl), 2 * c,
+                                             P(dga), P(dbe), bt, pix, c, S()))
     torch.cuda.synchronize()
     xr, gr, br = x.clone().requires_grad_(), gamma.clone().requires_grad_(), beta.clone().requires_grad_()
     fr = (film.float().view(bt, pix, 2 * c) + vec[:, None, :]).requires_grad_()
