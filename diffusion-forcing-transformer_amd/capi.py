@@ -132,10 +132,9 @@ SIGNATURES = {
     "dfot_op_gn_silu_bwd3": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _L, _P]),
     "dfot_op_gn_silu_bwd4": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _P, _I, _I, _I, _P]),
     "dfot_op_gn_silu_bwd5": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _P, _I, _I, _I, _P]),
-    "dfot_op_gn_silu_fwd2": (_I, [_P, _P, _P, _P, _L, _P, _F, _P, _P, _I, _I, _I, _P]),
-    "dfot_op_gn_silu_bwd6": (_I, [_P, _P, _P, _P, _P, _P, _L, _P, _P, _P, _P, _P, _L, _P, _P, _I, _I, _I, _P]),
-    "dfot_op_rms_film_fwd2": (_I, [_P, _P, _P, _P, _I, _F, _P, _L, _I, _P]),
-    "dfot_op_rms_film_bwd_res2": (_I, [_P, _P, _P, _P, _P, _I, _F, _P, _P, _P, _P, _P, _L, _I, _P]),
+    "dfot_op_gn_silu_fwd2": (_I, [_P, _P, _P, _P, _L, _F, _P, _P, _I, _I, _I, _P]),
+    "dfot_op_gn_silu_bwd6": (_I, [_P, _P, _P, _P, _P, _P, _L, _P, _P, _P, _P, _L, _P, _P, _I, _I, _I, _P]),
+    "dfot_op_gemm_bf16_frame_bias": (_I, [_P, _I, _P, _P, _I, _P, _I, _I, _I, _I, _P]),
     "dfot_op_split_bf16": (_I, [_P, _P, _P, _L, _P]),
     "dfot_op_frame_sums_bf16": (_I, [_P, _L, _P, _I, _I, _I, _P]),
     "dfot_op_sgemm": (_I, [_P, _L, _L, _P, _L, _L, _P, _L, _I, _I, _I, _I, _P]),

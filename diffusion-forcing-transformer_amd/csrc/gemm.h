@@ -37,7 +37,7 @@ struct GemmArgs {
   // keeps it for the backward of the norm and the activation (uvit_train.py) while q, k, v and SiLU(mlp_h) come out of the same epilogue
   bf16* raw = nullptr;
   long ldraw = 0;
-  int bias_rows = 0;  // E_F32 / E_BF16: > 0 = two-dimensional bias[(row % bias_rows)][N] (MatrixAttention), else bias[N]
+  int bias_rows = 0;  // E_F32 / E_BF16: > 0 = two-dimensional bias[(row % bias_rows)][N] (MatrixAttention), < 0 = bias[row / -bias_rows][N], else bias[N]
   // E_BF16: tr_rows = R > 0 stores the result transposed inside consecutive groups of R rows ("frames"):
   // out[(row / R)][col][row % R] -- the left factor of a matrix_mul contracts the ROW index of its operand
   int tr_rows = 0;

@@ -368,7 +368,11 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int tile_inde
   const int col = nw + cw;
   const bool live = col < g.N && cw < WTN;  // N is a multiple of the lane's column count, so a lane is entirely in or out
   f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = {0.f, 0.f, 0.f, 0.f};
-  [[maybe_unused]] const bool bias2d = g.bias_rows > 0;  // bias[(row % bias_rows)][col] (MatrixAttention qkv_bias / proj_bias)
+  // two-dimensional bias: bias_rows > 0: bias[row % bias_rows][col] (MatrixAttention qkv_bias / proj_bias); bias_rows < 0:
+  // bias[row / -bias_rows][col] (one bias row per frame of -bias_rows consecutive rows: the per-frame part of the trainer's folded FiLM)
+  [[maybe_unused]] const bool bias2d = g.bias_rows != 0;
+  [[maybe_unused]] const unsigned bias_den = (unsigned)(g.bias_rows > 0 ? g.bias_rows : -g.bias_rows);
+  [[maybe_unused]] const bool bias_mod = g.bias_rows > 0;
   [[maybe_unused]] float bc[NI];  // E_QKV: the bias in the MFMA C layout (one column per lane and 16-column tile), added on the way into LDS
   if constexpr (EPI == E_QKV) {
 #pragma unroll
@@ -513,7 +517,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int tile_inde
         for (int p = 0; p < 4; ++p) {
           const int r = p * 4 + (lane >> 4);
           f32x4 v = *reinterpret_cast<const f32x4*>(ep + r * EP_LD + cw) + b0;
-          if (bias2d) v += *reinterpret_cast<const f32x4*>(g.bias + (long)((unsigned)(mw + r) % (unsigned)g.bias_rows) * g.N + col);
+          if (bias2d) v += *reinterpret_cast<const f32x4*>(g.bias + (long)(bias_mod ? (unsigned)(mw + r) % bias_den : (unsigned)(mw + r) / bias_den) * g.N + col);
           if (has_gate) {
             if (pre_gate) {
               v *= gate_cur;
@@ -553,7 +557,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int tile_inde
         f32x4 v1 = *reinterpret_cast<const f32x4*>(ep + r * EP_LD + cw + 4) + b1;
         if constexpr (EPI == E_BF16) {
           if (bias2d && live) {
-            const float* bp = g.bias + (long)((unsigned)(mw + r) % (unsigned)g.bias_rows) * g.N + col;
+            const float* bp = g.bias + (long)(bias_mod ? (unsigned)(mw + r) % bias_den : (unsigned)(mw + r) / bias_den) * g.N + col;
             v0 += *reinterpret_cast<const f32x4*>(bp);
             v1 += *reinterpret_cast<const f32x4*>(bp + 4);
           }
@@ -944,7 +948,7 @@ int launch_gemm(int amode, int epi, int variant, const GemmArgs& g, hipStream_t 
     DFOT_REQUIRE(epi == E_F32 && (amode == A_DENSE || g.slice_stride > 0) && !g.bias_rows && (!g.resid || g.resid == g.out_f32) && !g.gate &&
                      !g.gn_part && g.K / BK >= 2 * g.ksplit, DFOT_ERR_ARG,
                  "gemm: split-K over workgroups needs the fp32 epilogue with an in-place residual (or none), no gate, and K >= %d", 2 * g.ksplit * BK);
-  if (g.bias_rows) DFOT_REQUIRE((epi == E_F32 || epi == E_BF16) && g.bias && g.bias_rows > 0, DFOT_ERR_ARG, "gemm: 2-D bias needs a plain epilogue");
+  if (g.bias_rows) DFOT_REQUIRE((epi == E_F32 || epi == E_BF16) && g.bias, DFOT_ERR_ARG, "gemm: 2-D bias needs a plain epilogue");
   if (g.tr_rows) {
     DFOT_REQUIRE(epi == E_BF16 && !g.bias && !g.act && !g.gn_part && g.tr_rows % 4 == 0 && g.M % g.tr_rows == 0 && amode == A_DENSE,
                  DFOT_ERR_ARG, "gemm: transposed store needs the plain bf16 epilogue and tr_rows %% 4 == 0 dividing M");

@@ -187,7 +187,7 @@ template <bool FILM, typename TDY>
 __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const float* __restrict__ x, const TDY* __restrict__ dy, const float* __restrict__ stats,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
                                                             const bf16* __restrict__ film, float* __restrict__ part, int P, int C, int chunk,
-                                                            const float* __restrict__ fvec, long ldfilm) {
+                                                            long ldfilm) {
   typedef __attribute__((ext_vector_type(4))) float f4;
   __shared__ f4 red[4][256];  // [quantity][thread]
   const int bt = blockIdx.x, p0 = blockIdx.y * chunk;
@@ -200,11 +200,6 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const float* __restr
   const float mean = stats[((long)bt * 32 + grp) * 2], rstd = stats[((long)bt * 32 + grp) * 2 + 1];
   const f4 ga = *reinterpret_cast<const f4*>(gamma + c), be = *reinterpret_cast<const f4*>(beta + c);
   f4 dgm = {0.f, 0.f, 0.f, 0.f}, dbt = dgm, s1 = dgm, s2 = dgm;
-  f4 vs = dgm, vh = dgm;  // the frame's part of the FiLM rows (see gn_silu_fwd_kernel)
-  if (FILM && fvec) {
-    vs = *reinterpret_cast<const f4*>(fvec + (long)bt * 2 * C + c);
-    vh = *reinterpret_cast<const f4*>(fvec + (long)bt * 2 * C + C + c);
-  }
   const int p1 = p0 + chunk < P ? p0 + chunk : P;
   if (rg < groups) {
 #pragma unroll 4
@@ -223,8 +218,8 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const float* __restr
         const float gv = xh * ga[j] + be[j];
         float z = gv, mul = 1.f;
         if (FILM) {
-          mul = 1.0f + (bf2f(fs[j]) + vs[j]);
-          z = gv * mul + (bf2f(fh[j]) + vh[j]);
+          mul = 1.0f + bf2f(fs[j]);
+          z = gv * mul + bf2f(fh[j]);
         }
         const float dg = dv[j] * silu_grad(z) * mul;
         dgm[j] += dg * xh;
@@ -262,8 +257,7 @@ template <bool FILM, typename TDY>
 __global__ void gn_bwd_apply_kernel(const float* __restrict__ x, const TDY* __restrict__ dy, const float* __restrict__ stats,
                                     const float* __restrict__ gamma, const float* __restrict__ beta, const bf16* __restrict__ film,
                                     const float* __restrict__ sums, float* dx, bf16* __restrict__ dfilm, long total4, int P, int C,
-                                    int accumulate, long ldf, const float* dres, bf16* __restrict__ dx_bf, const float* __restrict__ fvec,
-                                    long ldfilm) {
+                                    int accumulate, long ldf, const float* dres, bf16* __restrict__ dx_bf, long ldfilm) {
   typedef __attribute__((ext_vector_type(4))) float f4;
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;  // 4 channels of one pixel (they share a group: C / 32 >= 4)
   if (i >= total4) return;
@@ -279,14 +273,9 @@ __global__ void gn_bwd_apply_kernel(const float* __restrict__ x, const TDY* __re
   const f4 xv = *reinterpret_cast<const f4*>(x + e), dv = gn_load_dy4(dy + e);
   const f4 ga = *reinterpret_cast<const f4*>(gamma + c), be = *reinterpret_cast<const f4*>(beta + c);
   bf16x4 fs, fh, ds, dh;
-  f4 vs = {0.f, 0.f, 0.f, 0.f}, vh = vs;
   if (FILM) {
     fs = *reinterpret_cast<const bf16x4*>(film + row * ldfilm + c);
     fh = *reinterpret_cast<const bf16x4*>(film + row * ldfilm + C + c);
-    if (fvec) {
-      vs = *reinterpret_cast<const f4*>(fvec + (long)bt * 2 * C + c);
-      vh = *reinterpret_cast<const f4*>(fvec + (long)bt * 2 * C + C + c);
-    }
   }
   f4 v;
 #pragma unroll
@@ -295,8 +284,8 @@ __global__ void gn_bwd_apply_kernel(const float* __restrict__ x, const TDY* __re
     const float gv = xh * ga[j] + be[j];
     float z = gv, mul = 1.f;
     if (FILM) {
-      mul = 1.0f + (bf2f(fs[j]) + vs[j]);
-      z = gv * mul + (bf2f(fh[j]) + vh[j]);
+      mul = 1.0f + bf2f(fs[j]);
+      z = gv * mul + bf2f(fh[j]);
     }
     const float dz = dv[j] * silu_grad(z);
     if (FILM) {
@@ -324,7 +313,7 @@ __global__ void gn_bwd_apply_kernel(const float* __restrict__ x, const TDY* __re
 template <typename TDY>
 int gn_silu_backward(const float* x, const TDY* dy, const float* stats, const float* gamma, const float* beta, const bf16* film, float* sums,
                      float* dx, bf16* dfilm, float* dgamma, float* dbeta, int bt, int P, int C, bool accumulate, hipStream_t s, long ldf = 0,
-                     const float* dres = nullptr, bf16* dx_bf = nullptr, const float* fvec = nullptr, long ldfilm = 0) {
+                     const float* dres = nullptr, bf16* dx_bf = nullptr, long ldfilm = 0) {
   if (ldf == 0) ldf = 2L * C;
   if (ldfilm == 0) ldfilm = 2L * C;
   DFOT_REQUIRE(dx || dx_bf, DFOT_ERR_ARG, "gn_silu_backward: no output");
@@ -341,19 +330,19 @@ int gn_silu_backward(const float* x, const TDY* dy, const float* stats, const fl
   int rc = det_scratch(2, (size_t)grid.x * grid.y * rowlen, &part);
   if (rc) return rc;
   if (film)
-    hipLaunchKernelGGL((gn_bwd_reduce_kernel<true, TDY>), grid, dim3(256), 0, s, x, dy, stats, gamma, beta, film, part, P, C, chunk, fvec, ldfilm);
+    hipLaunchKernelGGL((gn_bwd_reduce_kernel<true, TDY>), grid, dim3(256), 0, s, x, dy, stats, gamma, beta, film, part, P, C, chunk, ldfilm);
   else
-    hipLaunchKernelGGL((gn_bwd_reduce_kernel<false, TDY>), grid, dim3(256), 0, s, x, dy, stats, gamma, beta, film, part, P, C, chunk, fvec, ldfilm);
+    hipLaunchKernelGGL((gn_bwd_reduce_kernel<false, TDY>), grid, dim3(256), 0, s, x, dy, stats, gamma, beta, film, part, P, C, chunk, ldfilm);
   DFOT_CHECK_HIP(hipGetLastError());
   if ((rc = det_sum(part + 2L * C, rowlen, (int)grid.y, 64, sums, false, s, bt, (long)grid.y * rowlen, 64))) return rc;
   if ((rc = det_sum(part, rowlen, (int)(grid.x * grid.y), C, dgamma, false, s))) return rc;
   if ((rc = det_sum(part + C, rowlen, (int)(grid.x * grid.y), C, dbeta, false, s))) return rc;
   if (film) {
     hipLaunchKernelGGL((gn_bwd_apply_kernel<true, TDY>), dim3(cdiv(total, 256)), dim3(256), 0, s, x, dy, stats, gamma, beta, film, sums, dx, dfilm, total, P, C,
-                       accumulate ? 1 : 0, ldf, dres, dx_bf, fvec, ldfilm);
+                       accumulate ? 1 : 0, ldf, dres, dx_bf, ldfilm);
   } else {
     hipLaunchKernelGGL((gn_bwd_apply_kernel<false, TDY>), dim3(cdiv(total, 256)), dim3(256), 0, s, x, dy, stats, gamma, beta, film, sums, dx, dfilm, total, P, C,
-                       accumulate ? 1 : 0, ldf, dres, dx_bf, fvec, ldfilm);
+                       accumulate ? 1 : 0, ldf, dres, dx_bf, ldfilm);
   }
   DFOT_CHECK_HIP(hipGetLastError());
   return DFOT_OK;
@@ -417,8 +406,7 @@ template <int VEC, int CNT>
 __global__ __launch_bounds__(256) void rms_film_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dxn, const float* __restrict__ w,
                                                            const bf16* __restrict__ film, float* dx, bf16* __restrict__ dfilm,
                                                            float* __restrict__ dw, long rows, float eps, int accumulate, const float* dres,
-                                                           bf16* __restrict__ dx_bf, const float* __restrict__ fvec, int tpf) {
-  // fvec (optional): fp32 [frames][2C] added to the film rows of its frame (tpf tokens each) -- the per-frame part of a folded FiLM
+                                                           bf16* __restrict__ dx_bf) {
   typedef typename VecT<VEC>::type V;
   constexpr int C = 64 * VEC * CNT;
   const int lane = threadIdx.x & 63;
@@ -430,7 +418,6 @@ __global__ __launch_bounds__(256) void rms_film_bwd_kernel(const float* __restri
     const float* xr = x + row * C;
     const float* gr = dxn + row * C;
     const bf16* fr = film + row * 2 * C;
-    const float* fv = fvec ? fvec + (long)((unsigned)row / (unsigned)tpf) * 2 * C : nullptr;  // rows < 2^32 (launcher)
     V xv[CNT], gv[CNT];
     float ss = 0.f;
 #pragma unroll
@@ -450,7 +437,7 @@ __global__ __launch_bounds__(256) void rms_film_bwd_kernel(const float* __restri
       for (int j = 0; j < VEC; ++j) {
         float dj, wj, xj;
         if constexpr (VEC == 1) { dj = d; wj = wv; xj = xv[i]; } else { dj = d[j]; wj = wv[j]; xj = xv[i][j]; }
-        const float sc = bf2f(fr[c0 + j]) + (fv ? fv[c0 + j] : 0.f);
+        const float sc = bf2f(fr[c0 + j]);
         const float y = xj * r * wj;
         dfr[c0 + j] = f2bf(dj * y);       // dscale
         dfr[C + c0 + j] = f2bf(dj);       // dshift
@@ -490,15 +477,13 @@ __global__ __launch_bounds__(256) void rms_film_bwd_kernel(const float* __restri
 }
 
 int rms_film_backward(const float* x, const float* dxn, const float* w, const bf16* film, float* dx, bf16* dfilm, float* dw, long rows, int hidden,
-                      float eps, bool accumulate, hipStream_t s, const float* dres = nullptr, bf16* dx_bf = nullptr, const float* fvec = nullptr,
-                      int tpf = 1) {
+                      float eps, bool accumulate, hipStream_t s, const float* dres = nullptr, bf16* dx_bf = nullptr) {
   const int grid = (int)(rows / 4 < 512 ? (rows + 3) / 4 : 512);
   float* part = nullptr;  // one partial dw row per workgroup, added in a fixed order (deterministic; dw is written, not accumulated)
   int rc = det_scratch(2, (size_t)grid * hidden, &part);
   if (rc) return rc;
 #define CALL(V, C) \
-  hipLaunchKernelGGL((rms_film_bwd_kernel<V, C>), dim3(grid), dim3(256), 0, s, x, dxn, w, film, dx, dfilm, part, rows, eps, accumulate ? 1 : 0, dres, dx_bf, \
-                     fvec, tpf)
+  hipLaunchKernelGGL((rms_film_bwd_kernel<V, C>), dim3(grid), dim3(256), 0, s, x, dxn, w, film, dx, dfilm, part, rows, eps, accumulate ? 1 : 0, dres, dx_bf)
   DIT_LN_DISPATCH(CALL)
 #undef CALL
   DFOT_CHECK_HIP(hipGetLastError());
@@ -730,14 +715,6 @@ int dfot_op_rms_film_bwd_res(const float* x, const float* dxn, const float* w, c
   DFOT_REQUIRE(x && dxn && w && film && dres && dx && dfilm && dw && dres != dx, DFOT_ERR_ARG, "op_rms_film_bwd_res: null or aliased argument");
   return rms_film_backward(x, dxn, w, (const bf16*)film, dx, (bf16*)dfilm, dw, (long)rows, channels, eps, true, (hipStream_t)stream, dres, (bf16*)dx_bf);
 }
-// dfot_op_rms_film_bwd_res for a FiLM projection in two parts: film rows (per token) + film_vec fp32 [rows / tokens_per_frame][2C] (per frame)
-int dfot_op_rms_film_bwd_res2(const float* x, const float* dxn, const float* w, const void* film, const float* film_vec, int tokens_per_frame, float eps,
-                              const float* dres, float* dx, void* dx_bf, void* dfilm, float* dw, int64_t rows, int channels, void* stream) {
-  DFOT_REQUIRE(x && dxn && w && film && dres && dx && dfilm && dw && dres != dx && (!film_vec || (tokens_per_frame > 0 && rows % tokens_per_frame == 0)),
-               DFOT_ERR_ARG, "op_rms_film_bwd_res2: null, aliased or misshaped argument");
-  return rms_film_backward(x, dxn, w, (const bf16*)film, dx, (bf16*)dfilm, dw, (long)rows, channels, eps, true, (hipStream_t)stream, dres, (bf16*)dx_bf,
-                           film_vec, film_vec ? tokens_per_frame : 1);
-}
 int dfot_op_qknorm_rope_bwd(const void* fused, int ld, const void* dq, const void* dk, const void* dv, const float* qw, const float* kw,
                             const float* rope_cs, float eps, void* dfused, int ldo, float* dqw, float* dkw, int64_t rows, int ntok, int heads, int d,
                             void* stream) {
@@ -774,7 +751,7 @@ namespace {
 
 template <int VEC, int CNT>
 __global__ __launch_bounds__(256) void rms_film_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const bf16* __restrict__ film,
-                                                           bf16* __restrict__ out, long rows, float eps, const float* __restrict__ fvec, int tpf) {
+                                                           bf16* __restrict__ out, long rows, float eps) {
   typedef typename VecT<VEC>::type V;
   constexpr int C = 64 * VEC * CNT;
   const int lane = threadIdx.x & 63;
@@ -782,7 +759,6 @@ __global__ __launch_bounds__(256) void rms_film_fwd_kernel(const float* __restri
   if (row >= rows) return;
   const float* xr = x + row * C;
   const bf16* fr = film + row * 2 * C;
-  const float* fv = fvec ? fvec + (long)((unsigned)row / (unsigned)tpf) * 2 * C : nullptr;  // the frame's part of a folded FiLM projection
   V xv[CNT];
   float ss = 0.f;
 #pragma unroll
@@ -798,12 +774,7 @@ __global__ __launch_bounds__(256) void rms_film_fwd_kernel(const float* __restri
     for (int j = 0; j < VEC; ++j) {
       float xj;
       if constexpr (VEC == 1) xj = xv[i]; else xj = xv[i][j];
-      float sc = bf2f(fr[c0 + j]), sh = bf2f(fr[C + c0 + j]);
-      if (fv) {
-        sc += fv[c0 + j];
-        sh += fv[C + c0 + j];
-      }
-      out[row * C + c0 + j] = f2bf(xj * r * w[c0 + j] * (1.0f + sc) + sh);
+      out[row * C + c0 + j] = f2bf(xj * r * w[c0 + j] * (1.0f + bf2f(fr[c0 + j])) + bf2f(fr[C + c0 + j]));
     }
   }
 }
@@ -884,6 +855,14 @@ int dfot_op_gemm_bf16(const void* a, int lda, const void* w, const float* bias, 
   DFOT_REQUIRE(a && w && out, DFOT_ERR_ARG, "op_gemm_bf16: null argument");
   return tr_gemm_bf16((const bf16*)a, lda, (const bf16*)w, m, n, k, bias, (bf16*)out, ldo, (hipStream_t)stream);
 }
+// out bf16 [M][N] = a w^T + frame_bias[row / rows_per_frame][:]   (frame_bias fp32 [M / rows_per_frame][N]): the folded FiLM projection, whose
+// per-frame part rides in the GEMM epilogue
+int dfot_op_gemm_bf16_frame_bias(const void* a, int lda, const void* w, const float* frame_bias, int rows_per_frame, void* out, int ldo, int m, int n, int k,
+                                 void* stream) {
+  DFOT_REQUIRE(a && w && out && frame_bias && rows_per_frame > 0 && m % rows_per_frame == 0 && n % 8 == 0, DFOT_ERR_ARG,
+               "op_gemm_bf16_frame_bias: null argument, or rows_per_frame = %d does not divide M = %d", rows_per_frame, m);
+  return tr_gemm_bf16((const bf16*)a, lda, (const bf16*)w, m, n, k, frame_bias, (bf16*)out, ldo, (hipStream_t)stream, -rows_per_frame);
+}
 int dfot_op_gemm_f32(const void* a, int lda, const void* w, const float* bias, const float* resid, float* out, int ldo, int m, int n, int k,
                      void* stream) {
   DFOT_REQUIRE(a && w && out, DFOT_ERR_ARG, "op_gemm_f32: null argument");
@@ -902,17 +881,11 @@ int dfot_op_colsum_bf16(const void* src, int ld, float* out, int64_t rows, int n
   return launch_colsum_bf16((const bf16*)src, out, (long)rows, n, (long)ld, s);
 }
 int dfot_op_rms_film_fwd(const float* x, const float* w, const void* film, float eps, void* out, int64_t rows, int channels, void* stream) {
-  return dfot_op_rms_film_fwd2(x, w, film, nullptr, 1, eps, out, rows, channels, stream);
-}
-int dfot_op_rms_film_fwd2(const float* x, const float* w, const void* film, const float* film_vec, int tokens_per_frame, float eps, void* out,
-                          int64_t rows, int channels, void* stream) {
-  DFOT_REQUIRE(x && w && film && out && (!film_vec || (tokens_per_frame > 0 && rows % tokens_per_frame == 0)), DFOT_ERR_ARG,
-               "op_rms_film_fwd: null or misshaped argument");
+  DFOT_REQUIRE(x && w && film && out, DFOT_ERR_ARG, "op_rms_film_fwd: null argument");
   hipStream_t s = (hipStream_t)stream;
   const int hidden = channels;
-  const int tpf = film_vec ? tokens_per_frame : 1;
 #define CALL(V, C) \
-  hipLaunchKernelGGL((rms_film_fwd_kernel<V, C>), dim3(cdiv(rows, 4)), dim3(256), 0, s, x, w, (const bf16*)film, (bf16*)out, (long)rows, eps, film_vec, tpf)
+  hipLaunchKernelGGL((rms_film_fwd_kernel<V, C>), dim3(cdiv(rows, 4)), dim3(256), 0, s, x, w, (const bf16*)film, (bf16*)out, (long)rows, eps)
   DIT_LN_DISPATCH(CALL)
 #undef CALL
   DFOT_CHECK_HIP(hipGetLastError());
@@ -996,11 +969,9 @@ namespace dfot {
 namespace {
 
 // out bf16 = SiLU(GN(x) [* (1 + scale) + shift])   (x fp32 [BT][P][C], stats [BT][32][2], film bf16 [BT*P][2C] or null)
-// fvec (optional, with film): fp32 [BT][2C] added to every film row of its frame -- the per-frame part of a FiLM projection whose
-// per-pixel part was folded into the pose patches (uvit_train.py: film = M patches + fvec)
 __global__ void gn_silu_fwd_kernel(const float* __restrict__ x, const float* __restrict__ stats, const float* __restrict__ gamma,
                                    const float* __restrict__ beta, const bf16* __restrict__ film, bf16* __restrict__ out, long total4, int P, int C,
-                                   const float* __restrict__ fvec, long ldfilm) {
+                                   long ldfilm) {
   typedef __attribute__((ext_vector_type(4))) float f4;
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;  // 4 channels of one pixel (one group: C / 32 >= 4)
   if (i >= total4) return;
@@ -1016,15 +987,10 @@ __global__ void gn_silu_fwd_kernel(const float* __restrict__ x, const float* __r
     fs = *reinterpret_cast<const bf16x4*>(film + row * ldfilm + c);
     fh = *reinterpret_cast<const bf16x4*>(film + row * ldfilm + C + c);
   }
-  f4 vs = {0.f, 0.f, 0.f, 0.f}, vh = vs;
-  if (film && fvec) {
-    vs = *reinterpret_cast<const f4*>(fvec + (long)bt * 2 * C + c);
-    vh = *reinterpret_cast<const f4*>(fvec + (long)bt * 2 * C + C + c);
-  }
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     float z = (xv[j] - mean) * rstd * ga[j] + be[j];
-    if (film) z = z * (1.0f + (bf2f(fs[j]) + vs[j])) + (bf2f(fh[j]) + vh[j]);
+    if (film) z = z * (1.0f + bf2f(fs[j])) + bf2f(fh[j]);
     o[j] = f2bf(silu_f(z));
   }
   *reinterpret_cast<bf16x4*>(out + row * C + c) = o;
@@ -1261,12 +1227,12 @@ using namespace dfot;
 
 int dfot_op_gn_silu_fwd(const float* x, const float* gamma, const float* beta, const void* film, float eps, void* out, float* stats, int bt,
                         int pixels, int channels, void* stream) {
-  return dfot_op_gn_silu_fwd2(x, gamma, beta, film, 2 * channels, nullptr, eps, out, stats, bt, pixels, channels, stream);
+  return dfot_op_gn_silu_fwd2(x, gamma, beta, film, 2 * channels, eps, out, stats, bt, pixels, channels, stream);
 }
-int dfot_op_gn_silu_fwd2(const float* x, const float* gamma, const float* beta, const void* film, int64_t film_ld, const float* film_vec, float eps,
-                         void* out, float* stats, int bt, int pixels, int channels, void* stream) {
-  DFOT_REQUIRE(x && gamma && beta && out && stats && channels % 32 == 0 && (film || !film_vec) && (!film || (film_ld >= 2 * channels && film_ld % 4 == 0)),
-               DFOT_ERR_ARG, "op_gn_silu_fwd: bad argument");
+int dfot_op_gn_silu_fwd2(const float* x, const float* gamma, const float* beta, const void* film, int64_t film_ld, float eps, void* out, float* stats,
+                         int bt, int pixels, int channels, void* stream) {
+  DFOT_REQUIRE(x && gamma && beta && out && stats && channels % 32 == 0 && (!film || (film_ld >= 2 * channels && film_ld % 4 == 0)), DFOT_ERR_ARG,
+               "op_gn_silu_fwd: bad argument");
   hipStream_t s = (hipStream_t)stream;
   DFOT_REQUIRE(channels % 128 == 0, DFOT_ERR_SHAPE, "op_gn_silu_fwd: channels %d must be a multiple of 128", channels);
   // statistics: streaming partial sums over 64-pixel blocks of all channels + a deterministic finalize (the inference kernels); one
@@ -1279,7 +1245,7 @@ int dfot_op_gn_silu_fwd2(const float* x, const float* gamma, const float* beta, 
   if ((rc = launch_gn_finalize((const float*)part, stats, bt, nblk, pixels, channels, eps, s))) return rc;
   const long total = (long)bt * pixels * (channels / 4);
   hipLaunchKernelGGL(gn_silu_fwd_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, x, stats, gamma, beta, (const bf16*)film, (bf16*)out, total, pixels,
-                     channels, film_vec, (long)film_ld);
+                     channels, (long)film_ld);
   DFOT_CHECK_HIP(hipGetLastError());
   return DFOT_OK;
 }
@@ -1334,12 +1300,11 @@ int dfot_op_gn_silu_bwd5(const float* x, const void* dy_bf, const float* stats, 
   return gn_silu_backward(x, (const bf16*)dy_bf, stats, gamma, beta, (const bf16*)film, (float*)sums, dx, (bf16*)dfilm, dgamma, dbeta, bt, pixels,
                           channels, dres != nullptr, s, (long)dfilm_ld, dres, (bf16*)dx_bf);
 }
-// dfot_op_gn_silu_bwd5 for a FiLM projection split into per-pixel rows (film) and a per-frame vector (film_vec fp32 [BT][2C], see
-// dfot_op_gn_silu_fwd2); dfilm is the gradient of the SUM (of either part)
+// dfot_op_gn_silu_bwd5 with the block's film columns given as a column block of a wider matrix (row pitch film_ld)
 int dfot_op_gn_silu_bwd6(const float* x, const void* dy_bf, const float* stats, const float* gamma, const float* beta, const void* film,
-                         int64_t film_ld, const float* film_vec, const float* dres, float* dx, void* dx_bf, void* dfilm, int64_t dfilm_ld,
-                         float* dgamma, float* dbeta, int bt, int pixels, int channels, void* stream) {
-  DFOT_REQUIRE(x && dy_bf && stats && gamma && beta && (dx || dx_bf) && dgamma && dbeta && (!dres || dres != dx) && (film || !film_vec) &&
+                         int64_t film_ld, const float* dres, float* dx, void* dx_bf, void* dfilm, int64_t dfilm_ld, float* dgamma, float* dbeta, int bt,
+                         int pixels, int channels, void* stream) {
+  DFOT_REQUIRE(x && dy_bf && stats && gamma && beta && (dx || dx_bf) && dgamma && dbeta && (!dres || dres != dx) &&
                    (!film || (film_ld >= 2 * channels && film_ld % 4 == 0)),
                DFOT_ERR_ARG, "op_gn_silu_bwd6: null, aliased or misshaped argument");
   DFOT_REQUIRE(!dfilm || (dfilm_ld >= 2 * channels && dfilm_ld % 4 == 0), DFOT_ERR_ARG, "op_gn_silu_bwd6: bad dfilm row stride");
@@ -1348,7 +1313,7 @@ int dfot_op_gn_silu_bwd6(const float* x, const void* dy_bf, const float* stats, 
   int rc = op_scratch(4, (size_t)bt * 64 * sizeof(float), &sums);
   if (rc) return rc;
   return gn_silu_backward(x, (const bf16*)dy_bf, stats, gamma, beta, (const bf16*)film, (float*)sums, dx, (bf16*)dfilm, dgamma, dbeta, bt, pixels,
-                          channels, dres != nullptr, s, (long)dfilm_ld, dres, (bf16*)dx_bf, film_vec, (long)film_ld);
+                          channels, dres != nullptr, s, (long)dfilm_ld, dres, (bf16*)dx_bf, (long)film_ld);
 }
 // out [bt][n] fp32 = sum over the frame's `pixels` rows of src bf16 [bt * pixels][ld] (columns 0..n): per-frame column sums,
 // deterministic (partial rows per pixel chunk + fixed-order sum); n % 8 == 0, ld % 8 == 0

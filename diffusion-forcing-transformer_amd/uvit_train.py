@@ -47,6 +47,15 @@ def gemm_bf16(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = N
     return out
 
 
+def gemm_bf16_frames(a: torch.Tensor, w: torch.Tensor, frame_bias: torch.Tensor, rows_per_frame: int) -> torch.Tensor:
+    """a [M][K] @ w [N][K]^T + frame_bias[row // rows_per_frame] -> bf16 [M][N]   (frame_bias fp32 [M / rows_per_frame][N], contiguous)"""
+    m, k = a.shape
+    out = torch.empty(m, w.shape[0], dtype=BF, device="cuda")
+    capi.check(capi.lib.dfot_op_gemm_bf16_frame_bias(_PV(a), a.stride(0), _P(w), _P(frame_bias), rows_per_frame, _P(out), out.stride(0), m, w.shape[0], k,
+                                                     _S()))
+    return out
+
+
 def gemm_f32(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, resid: Optional[torch.Tensor] = None,
              out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """fp32 [M][N] = a w^T (+ bias) (+ resid); out may be resid itself (accumulate in place)"""
@@ -193,17 +202,16 @@ class TransformerBlockTrain:
                 fold: Optional[Tuple[torch.Tensor, torch.Tensor, torch.Tensor, int]] = None) -> torch.Tensor:
         """x fp32 [B*N][C] (residual stream), emb bf16 [B*N][E] (per-token conditioning embedding); returns y fp32.
         mlp_mask: bf16 [B*N][4C] holding 0 or 1 / (1 - p): the nn.Dropout(p) after the MLP branch's SiLU (u_vit_blocks.py:230-234, training).
-        fold = (patches bf16 [B*N][K], M bf16 [2C][K], film_vec fp32 [frames][2C], tokens per frame) instead of emb: the trainer folded
-        norm.emb_layer into the pose patch embedding (film = patches M^T + film_vec[frame], UViT3DPoseTrainer.sync); the block then leaves
+        fold = (patches bf16 [B*N][K], M bf16 [2C][K], frame table fp32 [frames][2C], tokens per frame) instead of emb: the trainer folded
+        norm.emb_layer into the pose patch embedding (film = patches M^T + table[frame], one GEMM; UViT3DPoseTrainer.sync); the block then leaves
         dM = dfilm^T patches and dv = per-frame sums of dfilm (self.dM, self.dv) instead of the emb_layer / embedding gradients"""
         c, hds, d, p = self.c, self.heads, self.d, self.p
         rows = x.shape[0]
         ntok = rows // batch
         lib = capi.lib
-        film = gemm_bf16(emb, self.w_e, p["norm.emb_layer.bias"]) if fold is None else gemm_bf16(fold[0], fold[1])
+        film = gemm_bf16(emb, self.w_e, p["norm.emb_layer.bias"]) if fold is None else gemm_bf16_frames(fold[0], fold[1], fold[2], fold[3])
         xn = torch.empty(rows, c, dtype=BF, device="cuda")
-        capi.check(lib.dfot_op_rms_film_fwd2(_P(x), _P(p["norm.norm.weight"]), _P(film), _P(fold[2]) if fold else None, fold[3] if fold else 1, self.eps,
-                                             _P(xn), rows, c, _S()))
+        capi.check(lib.dfot_op_rms_film_fwd(_P(x), _P(p["norm.norm.weight"]), _P(film), self.eps, _P(xn), rows, c, _S()))
         q, k, v = (torch.empty(batch, hds, ntok, d, dtype=BF, device="cuda") for _ in range(3))
         cat = torch.empty(rows, 5 * c, dtype=BF, device="cuda")  # [attention output | SiLU(mlp_h)]
         if FUSED_PROJ and rows % 128 == 0:
@@ -270,8 +278,8 @@ class TransformerBlockTrain:
         dnw = torch.empty(c, device="cuda")
         self.dx_bf = torch.empty(rows, c, dtype=BF, device="cuda")
         fold = s["fold"]
-        capi.check(lib.dfot_op_rms_film_bwd_res2(_P(s["x"]), _P(dxn), _P(p["norm.norm.weight"]), _P(s["film"]), _P(fold[2]) if fold else None,
-                                                 fold[3] if fold else 1, self.eps, _P(dy), _P(dx), _P(self.dx_bf), _P(dfilm), _P(dnw), rows, c, _S()))
+        capi.check(lib.dfot_op_rms_film_bwd_res(_P(s["x"]), _P(dxn), _P(p["norm.norm.weight"]), _P(s["film"]), self.eps, _P(dy), _P(dx), _P(self.dx_bf),
+                                                _P(dfilm), _P(dnw), rows, c, _S()))
         if fold is None:
             demb = gemm_f32(dfilm, self.w_eT, resid=demb_acc, out=demb_acc)      # [rows][E]
             self.grads = {"norm.emb_layer.weight": wgrad(dfilm, s["emb"]), "norm.emb_layer.bias": colsum(dfilm)}
@@ -333,11 +341,10 @@ class ResBlockTrain:
         self.w_eT = transpose(self.w_e)
         self.w1, self.w2 = pack_conv(p["in_layers.2.weight"]), pack_conv(p["out_rest.1.weight"])
 
-    def forward(self, x: torch.Tensor, emb: Optional[torch.Tensor], bt: int, h: int, w: int, film: Optional[torch.Tensor] = None,
-                film_vec: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """x fp32 [BT*H*W][C]; either emb bf16 [BT*H*W][E] (the block projects it: film = emb_layer(emb)), or the projection itself in two
-        parts -- film bf16 [BT*H*W][2C] (per pixel) + film_vec fp32 [BT][2C] (per frame) -- when the trainer folded emb_layer into the pose
-        patch embedding (UViT3DPoseTrainer.forward); the emb_layer gradients are then the trainer's to compute from the block's dfilm"""
+    def forward(self, x: torch.Tensor, emb: Optional[torch.Tensor], bt: int, h: int, w: int, film: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """x fp32 [BT*H*W][C]; either emb bf16 [BT*H*W][E] (the block projects it: film = emb_layer(emb)), or the projection itself -- film
+        bf16 [BT*H*W][2C], possibly a column block of a level-wide matrix -- when the trainer folded emb_layer into the pose patch embedding
+        (UViT3DPoseTrainer.forward); the emb_layer gradients are then the trainer's to compute from the block's dfilm"""
         c, p, lib, P = self.c, self.p, capi.lib, h * w
         st1, st2 = (torch.empty(bt, 32, 2, dtype=torch.float32, device="cuda") for _ in range(2))
         h1 = torch.empty(bt * P, c, dtype=BF, device="cuda")
@@ -347,14 +354,14 @@ class ResBlockTrain:
         if not folded:
             film = gemm_bf16(emb, self.w_e, p["emb_layer.bias"])
         h2 = torch.empty(bt * P, c, dtype=BF, device="cuda")
-        capi.check(lib.dfot_op_gn_silu_fwd2(_P(c1), _P(p["out_norm.weight"]), _P(p["out_norm.bias"]), _PV(film), film.stride(0), _P(film_vec), self.eps,
-                                            _P(h2), _P(st2), bt, P, c, _S()))
+        capi.check(lib.dfot_op_gn_silu_fwd2(_P(c1), _P(p["out_norm.weight"]), _P(p["out_norm.bias"]), _PV(film), film.stride(0), self.eps, _P(h2), _P(st2),
+                                            bt, P, c, _S()))
         y = conv3x3(h2, self.w2, p["out_rest.1.bias"], bt, h, w, c, c, resid=x)
-        self.saved = dict(x=x, emb=emb, h1=h1, c1=c1, film=film, film_vec=film_vec, folded=folded, h2=h2, st1=st1, st2=st2, geom=(bt, h, w))
+        self.saved = dict(x=x, emb=emb, h1=h1, c1=c1, film=film, folded=folded, h2=h2, st1=st1, st2=st2, geom=(bt, h, w))
         return y
 
     def drop_saved(self) -> None:
-        keep = ("x", "emb", "geom", "folded") + (("film", "film_vec") if self.saved["folded"] else ())
+        keep = ("x", "emb", "geom", "folded") + (("film",) if self.saved["folded"] else ())
         self.saved = {k: self.saved[k] for k in keep}
 
     def backward(self, dy: torch.Tensor, demb_acc: Optional[torch.Tensor] = None,
@@ -365,7 +372,7 @@ class ResBlockTrain:
         ck = None
         if "h1" not in self.saved:  # gradient checkpointing (see TransformerBlockTrain.backward)
             ck = self.saved
-            self.forward(ck["x"], ck["emb"], *ck["geom"], film=ck.get("film"), film_vec=ck.get("film_vec"))
+            self.forward(ck["x"], ck["emb"], *ck["geom"], film=ck.get("film"))
         s, c, p, lib = self.saved, self.c, self.p, capi.lib
         bt, h, w = s["geom"]
         P = h * w
@@ -376,8 +383,7 @@ class ResBlockTrain:
         # the gradient of the first convolution's output only feeds that convolution's data / weight gradients: bf16 alone
         dc1 = torch.empty(bt * P, c, dtype=BF, device="cuda")
         capi.check(lib.dfot_op_gn_silu_bwd6(_P(s["c1"]), _P(dh2), _P(s["st2"]), _P(p["out_norm.weight"]), _P(p["out_norm.bias"]), _PV(s["film"]),
-                                            s["film"].stride(0), _P(s["film_vec"]), None, None, _P(dc1), _PV(dfilm), dfilm.stride(0), _P(dg2), _P(dbe2),
-                                            bt, P, c, _S()))
+                                            s["film"].stride(0), None, None, _P(dc1), _PV(dfilm), dfilm.stride(0), _P(dg2), _P(dbe2), bt, P, c, _S()))
         demb = None if (dfilm_out is not None or s["folded"]) else gemm_f32(dfilm, self.w_eT, resid=demb_acc, out=demb_acc)
         dh1, dw1, db1 = conv3x3_backward(s["h1"], dc1, p["in_layers.2.weight"], bt, h, w, c, c, dx_bf16=True)
         # dx = dy (residual path) + the first norm's input gradient, in fp32 for the stream and in bf16 for the block below
@@ -573,19 +579,19 @@ class UViT3DPoseTrainer:
         p = self.block_dropouts[lvl] if self.dropout_generator is not None else 0.0
         for b in blocks:
             c0, c2 = self.res_cols[id(b)], 2 * self.ch[lvl]
-            m_i, v_i = self.fold_m[lvl][c0: c0 + c2], self.film_vec[lvl][:, c0: c0 + c2].contiguous()
             if isinstance(b, ResBlockTrain):
                 # the level's ResBlocks share ONE projection GEMM (N = blocks * 2C): the patches are read once, not once per block
                 # (level 0 of config 5: 1.6 GB of patches against 0.5 GB of output per block -- the per-block GEMM was HBM-bound)
                 if lvl not in self.film_cat:
-                    self.film_cat[lvl] = gemm_bf16(self.xl[lvl], self.fold_m[lvl])
-                x = b.forward(x, None, self.bt, self.r[lvl], self.r[lvl], film=self.film_cat[lvl][:, c0: c0 + c2], film_vec=v_i)
+                    self.film_cat[lvl] = gemm_bf16_frames(self.xl[lvl], self.fold_m[lvl], self.film_vec[lvl], self.r[lvl] * self.r[lvl])
+                x = b.forward(x, None, self.bt, self.r[lvl], self.r[lvl], film=self.film_cat[lvl][:, c0: c0 + c2])
             else:
                 mask = None
                 if p > 0:  # nn.Dropout(p) of the MLP branch: keep with probability 1 - p, scale by 1 / (1 - p)
                     keep = torch.rand(x.shape[0], 4 * self.ch[lvl], device="cuda", generator=self.dropout_generator) >= p
                     mask = (keep.to(torch.float32) / (1.0 - p)).to(BF)
-                x = b.forward(x, None, self.B, mask, fold=(self.xl[lvl], m_i, v_i, self.r[lvl] * self.r[lvl]))
+                x = b.forward(x, None, self.B, mask, fold=(self.xl[lvl], self.fold_m[lvl][c0: c0 + c2], self.film_vec[lvl][:, c0: c0 + c2].contiguous(),
+                                                          self.r[lvl] * self.r[lvl]))
             if self.use_checkpointing[lvl]:
                 b.drop_saved()
         return x

@@ -379,24 +379,21 @@ int dfot_op_gn_silu_bwd4(const float* x, const float* dy, const float* stats, co
 int dfot_op_gn_silu_bwd5(const float* x, const void* dy_bf, const float* stats, const float* gamma, const float* beta, const void* film, const float* dres,
                          float* dx, void* dx_bf, void* dfilm, int64_t dfilm_ld, float* dgamma, float* dbeta, int bt, int pixels, int channels,
                          void* stream);
-/* Folded FiLM of the ResBlock levels (training).  The reference computes emb = PatchEmbed(pose rays) + noise embedding per pixel
- * (u_vit3d_pose.py:63-131, embeddings.py:390-428) and every ResBlock projects it: film = emb_layer(emb) (u_vit_blocks.py:57-93).  Both
- * maps are linear, so film = (W_emb_layer W_patch) patches + W_emb_layer (b_patch keep + noise_emb[frame]) + b: the per-pixel part is a
- * GEMM over the 768-wide pose patches instead of the 1024-wide embedding, the per-frame part a [BT][2C] vector (film_vec, fp32), and the
- * backward never forms the per-pixel embedding gradient.  These entries take the two parts. */
-/* film_ld: row pitch of `film` in elements (>= 2C): the block's (scale | shift) columns may be a column block of a level-wide matrix */
-int dfot_op_gn_silu_fwd2(const float* x, const float* gamma, const float* beta, const void* film, int64_t film_ld, const float* film_vec, float eps,
-                         void* out, float* stats, int bt, int pixels, int channels, void* stream);
+/* Folded FiLM (training).  The reference computes emb = PatchEmbed(pose rays) keep + noise embedding per pixel (u_vit3d_pose.py:63-131,
+ * embeddings.py:390-428), pools it down the levels and every block projects it: film = emb_layer(emb) (u_vit_blocks.py:57-116).  All of
+ * these maps are linear, so film = (W_emb_layer W_patch) patches + [W_emb_layer (b_patch keep + noise_emb[frame]) + b]: the per-row part is a
+ * GEMM over the 768-wide pose patches instead of the 1024-wide embedding, the per-frame part a [frames][2C] fp32 table added in that GEMM's
+ * epilogue, and the backward never forms a per-row embedding gradient (uvit_train.py, UViT3DPoseTrainer.sync).
+ * out bf16 [M][N] = a w^T + frame_bias[row / rows_per_frame][:] */
+int dfot_op_gemm_bf16_frame_bias(const void* a, int lda, const void* w, const float* frame_bias, int rows_per_frame, void* out, int ldo, int m, int n, int k,
+                                 void* stream);
+/* GroupNorm + FiLM + SiLU with the block's (scale | shift) columns given as a column block of a level-wide matrix (row pitch film_ld >= 2C) */
+int dfot_op_gn_silu_fwd2(const float* x, const float* gamma, const float* beta, const void* film, int64_t film_ld, float eps, void* out, float* stats,
+                         int bt, int pixels, int channels, void* stream);
 int dfot_op_gn_silu_bwd6(const float* x, const void* dy_bf, const float* stats, const float* gamma, const float* beta, const void* film,
-                         int64_t film_ld, const float* film_vec, const float* dres, float* dx, void* dx_bf, void* dfilm, int64_t dfilm_ld,
-                         float* dgamma, float* dbeta, int bt, int pixels, int channels, void* stream);
-/* the same two-part FiLM for the TransformerBlock's NormalizeWithCond (u_vit_blocks.py:96-116): film rows per token + film_vec fp32
- * [rows / tokens_per_frame][2C] per frame */
-int dfot_op_rms_film_fwd2(const float* x, const float* w, const void* film, const float* film_vec, int tokens_per_frame, float eps, void* out,
-                          int64_t rows, int channels, void* stream);
-int dfot_op_rms_film_bwd_res2(const float* x, const float* dxn, const float* w, const void* film, const float* film_vec, int tokens_per_frame, float eps,
-                              const float* dres, float* dx, void* dx_bf, void* dfilm, float* dw, int64_t rows, int channels, void* stream);
-/* out [bt][n] fp32 = per-frame column sums of src bf16 [bt * pixels][ld] (the gradient of film_vec from the FiLM gradients) */
+                         int64_t film_ld, const float* dres, float* dx, void* dx_bf, void* dfilm, int64_t dfilm_ld, float* dgamma, float* dbeta, int bt,
+                         int pixels, int channels, void* stream);
+/* out [bt][n] fp32 = per-frame column sums of src bf16 [bt * pixels][ld] (the gradient of the per-frame FiLM table from the FiLM gradients) */
 int dfot_op_frame_sums_bf16(const void* src, int64_t ld, float* out, int bt, int pixels, int n, void* stream);
 /* x fp32 = hi + lo, both bf16 (lo carries the next 8 mantissa bits): three bf16 products Ah Bh + Ah Bl + Al Bh with fp32 accumulation
  * reproduce an fp32 product to ~2^-16 -- how the weight-sized products of the folded FiLM run on the matrix cores */

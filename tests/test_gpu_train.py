@@ -538,61 +538,46 @@ def test_folded_film_helpers_frame_sums_split_products():
 
 
 @pytest.mark.parametrize("c", [128, 256])
-def test_groupnorm_and_rms_film_with_a_per_frame_film_vector(c):
-    """the two-part FiLM entries (rows per pixel / token + an fp32 vector per frame: dfot_op_gn_silu_fwd2 / _bwd6, dfot_op_rms_film_fwd2 /
-    _bwd_res2) against torch autograd with the vector added to the rows"""
-    from dfot_amd import capi
+def test_frame_bias_gemm_and_groupnorm_on_a_column_block(c):
+    """the folded-FiLM projection: dfot_op_gemm_bf16_frame_bias (a w^T + table[row // rows_per_frame], the per-frame part in the GEMM
+    epilogue) vs fp32 torch, and the GroupNorm + FiLM + SiLU entries reading a block's (scale | shift) columns out of a level-wide matrix
+    (film_ld: dfot_op_gn_silu_fwd2 / _bwd6) vs torch autograd"""
+    from dfot_amd import capi, uvit_train as ut
     F = torch.nn.functional
     g = torch.Generator().manual_seed(c)
-    bt, pix = 3, 256
+    bt, pix, k, nblk = 3, 256, 192, 3
+    a = torch.randn(bt * pix, k, generator=g).to(torch.bfloat16).cuda()
+    w = (torch.randn(nblk * 2 * c, k, generator=g) / math.sqrt(k)).to(torch.bfloat16).cuda()
+    table = (torch.randn(bt, nblk * 2 * c, generator=g) * 0.4).cuda()
+    film_all = ut.gemm_bf16_frames(a, w, table, pix)
+    want = a.float() @ w.float().t() + table.repeat_interleave(pix, 0)
+    assert rel(film_all.float().cpu(), want.cpu()) < 4e-3
+    # rows_per_frame must divide M
+    assert capi.lib.dfot_op_gemm_bf16_frame_bias(capi.ptr(a), k, capi.ptr(w), capi.ptr(table), pix - 1, capi.ptr(film_all), nblk * 2 * c, bt * pix,
+                                                 nblk * 2 * c, k, capi.stream_ptr()) != 0
     x = torch.randn(bt, pix, c, generator=g) * 1.5 + 0.3
     gamma, beta = torch.randn(c, generator=g) * 0.5 + 1, torch.randn(c, generator=g) * 0.2
-    film = (torch.randn(bt * pix, 2 * c, generator=g) * 0.4).to(torch.bfloat16)
-    vec = torch.randn(bt, 2 * c, generator=g) * 0.4
     dy = torch.randn(bt, pix, c, generator=g).to(torch.bfloat16)
-    xd, gd, bd, fd, vd, dyd = x.cuda(), gamma.cuda(), beta.cuda(), film.cuda(), vec.cuda(), dy.cuda()
+    xd, gd, bd, dyd = x.cuda(), gamma.cuda(), beta.cuda(), dy.cuda()
     P, S = capi.ptr, capi.stream_ptr
-    # the block's film columns as a column block of a wider (level-wide) matrix: row pitch 6C, columns [2C, 4C)
-    wide = torch.full((bt * pix, 6 * c), float("nan"), dtype=torch.bfloat16, device="cuda")
-    wide[:, 2 * c: 4 * c] = fd
-    fview = wide[:, 2 * c: 4 * c]
+    fview = film_all[:, 2 * c: 4 * c]                            # block 1 of 3: row pitch 6C
     out = torch.empty(bt * pix, c, dtype=torch.bfloat16, device="cuda")
     stats = torch.empty(bt, 32, 2, device="cuda")
-    capi.check(capi.lib.dfot_op_gn_silu_fwd2(P(xd), P(gd), P(bd), capi.ptr_rows(fview), 6 * c, P(vd), 1e-6, P(out), P(stats), bt, pix, c, S()))
+    capi.check(capi.lib.dfot_op_gn_silu_fwd2(P(xd), P(gd), P(bd), capi.ptr_rows(fview), 6 * c, 1e-6, P(out), P(stats), bt, pix, c, S()))
     dx, dfl = torch.full((bt, pix, c), float("nan"), device="cuda"), torch.empty(bt * pix, 2 * c, dtype=torch.bfloat16, device="cuda")
     dga, dbe = torch.empty(c, device="cuda"), torch.empty(c, device="cuda")
-    capi.check(capi.lib.dfot_op_gn_silu_bwd6(P(xd), P(dyd), P(stats), P(gd), P(bd), capi.ptr_rows(fview), 6 * c, P(vd), None, P(dx), None, P(dfl), 2 * c,
-                                             P(dga), P(dbe), bt, pix, c, S()))
+    capi.check(capi.lib.dfot_op_gn_silu_bwd6(P(xd), P(dyd), P(stats), P(gd), P(bd), capi.ptr_rows(fview), 6 * c, None, P(dx), None, P(dfl), 2 * c, P(dga),
+                                             P(dbe), bt, pix, c, S()))
     torch.cuda.synchronize()
     xr, gr, br = x.clone().requires_grad_(), gamma.clone().requires_grad_(), beta.clone().requires_grad_()
-    fr = (film.float().view(bt, pix, 2 * c) + vec[:, None, :]).requires_grad_()
+    fr = fview.float().cpu().view(bt, pix, 2 * c).requires_grad_()
     h = F.group_norm(xr.permute(0, 2, 1), 32, gr, br, 1e-6).permute(0, 2, 1)
     y = F.silu(h * (1 + fr[..., :c]) + fr[..., c:])
     y.backward(dy.float())
     rs = [rel(out.float().cpu().view(bt, pix, c), y.detach()), rel(dx.cpu(), xr.grad), rel(dga.cpu(), gr.grad), rel(dbe.cpu(), br.grad),
           rel(dfl.float().cpu().view(bt, pix, 2 * c), fr.grad)]
-    print(f"GroupNorm with a per-frame FiLM vector, C={c}: " + " ".join(f"{r:.1e}" for r in rs))
+    print(f"GroupNorm + FiLM on a column block, C={c}: " + " ".join(f"{r:.1e}" for r in rs))
     assert rs[0] < 5e-3 and max(rs[1:4]) < 1e-4 and rs[4] < 5e-3
-    # RMS-FiLM (NormalizeWithCond) with tokens_per_frame = pix
-    rows = bt * pix
-    w = (torch.randn(c, generator=g) * 0.3 + 1)
-    dxn, dres = torch.randn(rows, c, generator=g), torch.randn(rows, c, generator=g)
-    x2 = x.view(rows, c).contiguous()
-    x2d, wd, dxnd, dresd = x2.cuda(), w.cuda(), dxn.cuda(), dres.cuda()
-    xn = torch.empty(rows, c, dtype=torch.bfloat16, device="cuda")
-    capi.check(capi.lib.dfot_op_rms_film_fwd2(P(x2d), P(wd), P(fd), P(vd), pix, 1e-6, P(xn), rows, c, S()))
-    dx2, dxb = torch.full((rows, c), float("nan"), device="cuda"), torch.empty(rows, c, dtype=torch.bfloat16, device="cuda")
-    dfl2, dw = torch.empty(rows, 2 * c, dtype=torch.bfloat16, device="cuda"), torch.empty(c, device="cuda")
-    capi.check(capi.lib.dfot_op_rms_film_bwd_res2(P(x2d), P(dxnd), P(wd), P(fd), P(vd), pix, 1e-6, P(dresd), P(dx2), P(dxb), P(dfl2), P(dw), rows, c, S()))
-    torch.cuda.synchronize()
-    xr, wr = x2.clone().requires_grad_(), w.clone().requires_grad_()
-    fr = (film.float() + vec.repeat_interleave(pix, 0)).requires_grad_()
-    yn = xr * torch.rsqrt(xr.pow(2).mean(-1, keepdim=True) + 1e-6) * wr
-    o = yn * (1 + fr[:, :c]) + fr[:, c:]
-    o.backward(dxn)
-    rs = [rel(xn.float().cpu(), o.detach()), rel(dx2.cpu() - dres, xr.grad), rel(dw.cpu(), wr.grad), rel(dfl2.float().cpu(), fr.grad)]
-    print(f"RMS-FiLM with a per-frame FiLM vector, C={c}: " + " ".join(f"{r:.1e}" for r in rs))
-    assert rs[0] < 5e-3 and max(rs[1:3]) < 1e-4 and rs[3] < 5e-3
 
 
 @pytest.mark.parametrize("rows,c", [(512, 576), (300, 1152), (64, 128)])
