@@ -25,6 +25,7 @@ struct GemmArgs {
   bf16* out_bf16 = nullptr;
   long ldo = 0;
   const float* resid = nullptr;  // E_F32: optional fp32 residual, same ld as out
+  const bf16* resid_bf = nullptr;  // E_BF16: optional bf16 residual, same ld as out (may be out itself: each element is read before it is written)
   // E_F32: optional per-(frame, column) gate (DiT AdaLN-Zero): out = resid + gate[row / gate_rows][col] * (acc + bias)
   //   (gate_index: optional indirection, gate row = gate_index[row / gate_rows] -- the per-level modulation table)
   const float* gate = nullptr;

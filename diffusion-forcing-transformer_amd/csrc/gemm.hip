@@ -561,6 +561,14 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int tile_inde
             v0 += *reinterpret_cast<const f32x4*>(bp);
             v1 += *reinterpret_cast<const f32x4*>(bp + 4);
           }
+          if (g.resid_bf && live) {  // bf16 residual stream (ResBlock levels of the inference engine): same rows / pitch as the output
+            const bf16x8 rb = *reinterpret_cast<const bf16x8*>(g.resid_bf + (mw + r) * g.ldo + col);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { v0[j] += bf2f(rb[j]); v1[j] += bf2f(rb[4 + j]); }
+          } else if (g.resid && live) {  // ... entered from an fp32 tensor (the level's input: a Downsample output)
+            v0 += *reinterpret_cast<const f32x4*>(g.resid + (mw + r) * g.ldo + col);
+            v1 += *reinterpret_cast<const f32x4*>(g.resid + (mw + r) * g.ldo + col + 4);
+          }
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {

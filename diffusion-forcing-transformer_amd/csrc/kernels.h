@@ -48,6 +48,15 @@ int launch_rms_film(const float* x, const float* w, const bf16* fcache, const fl
 
 // ---- resampling / skips ----
 int launch_pool2_bf16(const float* x, bf16* out, int bt, int h, int w, int c, hipStream_t s);
+// the same kernels on a bf16 residual stream (the inference engine's ResBlock levels)
+int launch_pool2_bf16_bf16in(const bf16* x, bf16* out, int bt, int h, int w, int c, hipStream_t s);
+int launch_sub_bf16_bf16in(const bf16* a, const float* b, bf16* out, long n, hipStream_t s, const uint8_t* live = nullptr, long frame_elems = 0);
+int launch_upsample_add_bf16(const float* t, const bf16* skip, bf16* out, int bt, int h, int w, int c, hipStream_t s, const uint8_t* live = nullptr);
+int launch_gn_apply_silu_bf16in(const bf16* x, const float* stats, const float* gamma, const float* beta, bf16* out, int bt, int pixels, int c,
+                                hipStream_t s, const uint8_t* live = nullptr);
+int launch_embed_input_bf16(const float* x, const float* w, const float* b, bf16* out, int bt, int res, int cin, int c0, hipStream_t s);
+int launch_project_output_bf16(const bf16* x0, const float* w, const float* b, float* out, int bt, int res, int c0, int cout, hipStream_t s,
+                               const uint8_t* live = nullptr);
 int launch_sub_bf16(const float* a, const float* b, bf16* out, long n, hipStream_t s, const uint8_t* live = nullptr, long frame_elems = 0);
 int launch_upsample_add(const float* t, const float* skip, float* out, int bt, int h, int w, int c, hipStream_t s, const uint8_t* live = nullptr);
 // ---- pose ----

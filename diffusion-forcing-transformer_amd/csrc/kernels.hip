@@ -52,6 +52,38 @@ int launch_noise_emb(const float* k, const float* freqs, const float* phases, co
   return DFOT_OK;
 }
 
+// The residual stream of the ResBlock levels is fp32 (training ops, tests of single ops) or bf16 (the inference engine: what
+// torch.autocast(bf16) keeps there in the reference): stream accessors for either element type
+template <typename T>
+__device__ __forceinline__ void stream_ld8(const T* p, float (&v)[8]) {
+  if constexpr (sizeof(T) == 4) {
+    const float4v a = *reinterpret_cast<const float4v*>(p), b = *reinterpret_cast<const float4v*>(p + 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { v[j] = a[j]; v[4 + j] = b[j]; }
+  } else {
+    const bf16x8 a = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = bf2f(a[j]);
+  }
+}
+template <typename T>
+__device__ __forceinline__ float4v stream_ld4(const T* p) {
+  if constexpr (sizeof(T) == 4) {
+    return *reinterpret_cast<const float4v*>(p);
+  } else {
+    const bf16x4 a = *reinterpret_cast<const bf16x4*>(p);
+    return float4v{bf2f(a[0]), bf2f(a[1]), bf2f(a[2]), bf2f(a[3])};
+  }
+}
+template <typename T>
+__device__ __forceinline__ void stream_st4(T* p, float4v v) {
+  if constexpr (sizeof(T) == 4) {
+    *reinterpret_cast<float4v*>(p) = v;
+  } else {
+    *reinterpret_cast<bf16x4*>(p) = bf16x4{f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+  }
+}
+
 // --------------------------------------------------------------------------------------------
 // EmbedInput: conv k2 s2, Cin(3) -> C0, NCHW fp32 in, channels-last fp32 out (u_vit_blocks.py:16-30)
 // --------------------------------------------------------------------------------------------
@@ -87,9 +119,9 @@ __global__ __launch_bounds__(256) void embed_input_kernel(const float* __restric
 // the same with the 4 x (CIN * 4) weights of the thread's channel quad in registers: the thread count is a multiple of c0 / 4, so a
 // thread keeps its channels over the grid-stride loop and no workgroup stages the weights through LDS (32768 workgroups each
 // re-reading 6 KiB of weights and synchronising was most of the 94 us this took for 134 MB of output)
-template <int CIN>
+template <int CIN, typename TOUT>
 __global__ __launch_bounds__(256) void embed_input_reg_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                              const float* __restrict__ b, float* __restrict__ out, unsigned total4,
+                                                              const float* __restrict__ b, TOUT* __restrict__ out, unsigned total4,
                                                               int res, int c0) {
   constexpr int TAPS = CIN * 4;
   const unsigned q = c0 / 4, r0 = res / 2;
@@ -114,7 +146,7 @@ __global__ __launch_bounds__(256) void embed_input_reg_kernel(const float* __res
       const float2v bot = *reinterpret_cast<const float2v*>(xp + res);
       acc += wt[ci * 4] * top[0] + wt[ci * 4 + 1] * top[1] + wt[ci * 4 + 2] * bot[0] + wt[ci * 4 + 3] * bot[1];
     }
-    *reinterpret_cast<float4v*>(out + (long)pix * c0 + c4) = acc;
+    stream_st4(out + (long)pix * c0 + c4, acc);
   }
 }
 
@@ -125,12 +157,23 @@ int launch_embed_input(const float* x, const float* w, const float* b, float* ou
   DFOT_REQUIRE(total4 < (1L << 31), DFOT_ERR_SHAPE, "embed_input: %ld work items exceed the 32-bit index range", total4);
   if (cin == 3 && 256 % (c0 / 4) == 0) {
     const long wgs = cdiv(total4, 256);
-    hipLaunchKernelGGL(embed_input_reg_kernel<3>, dim3((unsigned)(wgs < 4096 ? wgs : 4096)), dim3(256), 0, s, x, w, b, out, (unsigned)total4, res, c0);
+    hipLaunchKernelGGL((embed_input_reg_kernel<3, float>), dim3((unsigned)(wgs < 4096 ? wgs : 4096)), dim3(256), 0, s, x, w, b, out, (unsigned)total4, res, c0);
     DFOT_CHECK_HIP(hipGetLastError());
     return DFOT_OK;
   }
   hipLaunchKernelGGL(embed_input_kernel, dim3(cdiv(total4, 256)), dim3(256), (size_t)cin * 4 * c0 * sizeof(float), s, x, w, b,
                      out, total4, res, cin, c0);
+  DFOT_CHECK_HIP(hipGetLastError());
+  return DFOT_OK;
+}
+// output in the bf16 residual stream (the inference engine; three input channels, the register-weight form)
+int launch_embed_input_bf16(const float* x, const float* w, const float* b, bf16* out, int bt, int res, int cin, int c0, hipStream_t s) {
+  DFOT_REQUIRE(c0 % 4 == 0 && res % 2 == 0 && cin == 3 && 256 % (c0 / 4) == 0, DFOT_ERR_SHAPE,
+               "embed_input (bf16 stream): %d input channels / %d channels / resolution %d unsupported", cin, c0, res);
+  const long total4 = (long)bt * (res / 2) * (res / 2) * (c0 / 4);
+  DFOT_REQUIRE(total4 < (1L << 31), DFOT_ERR_SHAPE, "embed_input: %ld work items exceed the 32-bit index range", total4);
+  const long wgs = cdiv(total4, 256);
+  hipLaunchKernelGGL((embed_input_reg_kernel<3, bf16>), dim3((unsigned)(wgs < 4096 ? wgs : 4096)), dim3(256), 0, s, x, w, b, out, (unsigned)total4, res, c0);
   DFOT_CHECK_HIP(hipGetLastError());
   return DFOT_OK;
 }
@@ -292,8 +335,8 @@ __device__ __forceinline__ void halve_exchange(float* acc, int lane) {
 // C0 = 128: sixteen lanes share a pixel, each with 8 of its channels (one coalesced 512-byte row per pixel instead of 64 lanes
 // striding 512 bytes apart) and the 8 x (COUT * 4) weights of those channels in registers; the COUT * 4 <= 16 partial sums are
 // reduced over the 16 lanes with a halving exchange (15 shuffles), which leaves output o = lane % 16 in its lane
-template <int COUT>
-__global__ __launch_bounds__(256) void project_output_c128_kernel(const float* __restrict__ x0, const float* __restrict__ w,
+template <int COUT, typename TIN>
+__global__ __launch_bounds__(256) void project_output_c128_kernel(const TIN* __restrict__ x0, const float* __restrict__ w,
                                                                   const float* __restrict__ b, float* __restrict__ out, unsigned npix,
                                                                   int res, const uint8_t* __restrict__ live_frames) {
   constexpr int NO = COUT * 4;
@@ -316,12 +359,12 @@ __global__ __launch_bounds__(256) void project_output_c128_kernel(const float* _
 #pragma unroll
     for (int o = 0; o < 16; ++o) acc[o] = 0.f;
     if (live && !dead) {
-      const float* xp = x0 + (long)pix * 128 + sub * 8;
-      const float4v a = *reinterpret_cast<const float4v*>(xp), c = *reinterpret_cast<const float4v*>(xp + 4);
+      float xv[8];
+      stream_ld8(x0 + (long)pix * 128 + sub * 8, xv);
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int o = 0; o < NO; ++o) acc[o] += a[j] * wt[j][o] + c[j] * wt[4 + j][o];
+        for (int o = 0; o < NO; ++o) acc[o] += xv[j] * wt[j][o] + xv[4 + j] * wt[4 + j][o];
     }
     // halve the value count while exchanging across lane bits 3, 2, 1, 0
     halve_exchange<8, 8>(acc, lane);
@@ -344,12 +387,23 @@ int launch_project_output(const float* x0, const float* w, const float* b, float
   DFOT_REQUIRE(npix < (1L << 31), DFOT_ERR_SHAPE, "project_output: %ld pixels exceed the 32-bit index range", npix);
   if (c0 == 128 && cout == 3) {
     const long wgs = cdiv(npix, 16);
-    hipLaunchKernelGGL(project_output_c128_kernel<3>, dim3((unsigned)(wgs < 4096 ? wgs : 4096)), dim3(256), 0, s, x0, w, b, out, (unsigned)npix, res, live);
+    hipLaunchKernelGGL((project_output_c128_kernel<3, float>), dim3((unsigned)(wgs < 4096 ? wgs : 4096)), dim3(256), 0, s, x0, w, b, out, (unsigned)npix, res, live);
     DFOT_CHECK_HIP(hipGetLastError());
     return DFOT_OK;
   }
   hipLaunchKernelGGL(project_output_kernel, dim3(cdiv(npix, 256)), dim3(256), c0 * cout * 4 * sizeof(float), s, x0, w, b,
                      out, npix, res, c0, cout);
+  DFOT_CHECK_HIP(hipGetLastError());
+  return DFOT_OK;
+}
+// input from the bf16 residual stream (the inference engine: 128 level-0 channels, 3 output channels)
+int launch_project_output_bf16(const bf16* x0, const float* w, const float* b, float* out, int bt, int res, int c0, int cout, hipStream_t s,
+                               const uint8_t* live) {
+  DFOT_REQUIRE(c0 == 128 && cout == 3, DFOT_ERR_SHAPE, "project_output (bf16 stream): c0=%d cout=%d unsupported", c0, cout);
+  const long npix = (long)bt * (res / 2) * (res / 2);
+  DFOT_REQUIRE(npix < (1L << 31), DFOT_ERR_SHAPE, "project_output: %ld pixels exceed the 32-bit index range", npix);
+  const long wgs = cdiv(npix, 16);
+  hipLaunchKernelGGL((project_output_c128_kernel<3, bf16>), dim3((unsigned)(wgs < 4096 ? wgs : 4096)), dim3(256), 0, s, x0, w, b, out, (unsigned)npix, res, live);
   DFOT_CHECK_HIP(hipGetLastError());
   return DFOT_OK;
 }
@@ -514,8 +568,8 @@ struct GnRowConsts {
   __device__ __forceinline__ float norm(float v, int j) const { return (v - mean[j]) * rsg[j] * gam[j] + bet[j]; }
 };
 
-template <int C>
-__global__ __launch_bounds__(256) void gn_apply_silu_rows_kernel(const float* __restrict__ x, const float* __restrict__ stats,
+template <int C, typename TIN>
+__global__ __launch_bounds__(256) void gn_apply_silu_rows_kernel(const TIN* __restrict__ x, const float* __restrict__ stats,
                                                                  const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                  bf16* __restrict__ out, int pixels, const uint8_t* __restrict__ live) {
   constexpr int TPP = C / 8, PPI = 256 / TPP;
@@ -528,22 +582,33 @@ __global__ __launch_bounds__(256) void gn_apply_silu_rows_kernel(const float* __
   long pix = (long)bt * pixels + (long)(blockIdx.x % wg_per_bt) * (PPI * GN_ROWS_IT) + threadIdx.x / TPP;
 #pragma unroll 4
   for (int it = 0; it < GN_ROWS_IT; ++it, pix += PPI) {
-    const float* src = x + pix * C + c0;
-    const float4v a = *reinterpret_cast<const float4v*>(src);
-    const float4v b = *reinterpret_cast<const float4v*>(src + 4);
+    float v[8];
+    stream_ld8(x + pix * C + c0, v);
     bf16x8 o;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = f2bf(silu_f(k.norm(j < 4 ? a[j] : b[j - 4], j)));
+    for (int j = 0; j < 8; ++j) o[j] = f2bf(silu_f(k.norm(v[j], j)));
     *reinterpret_cast<bf16x8*>(out + pix * C + c0) = o;
   }
+}
+
+// bf16 input stream (the inference engine's ResBlock levels): the row-streaming form only (its shape conditions are the engine's)
+int launch_gn_apply_silu_bf16in(const bf16* x, const float* stats, const float* gamma, const float* beta, bf16* out, int bt, int pixels, int c,
+                                hipStream_t s, const uint8_t* live) {
+  DFOT_REQUIRE((c == 128 || c == 256) && pixels % ((256 / (c / 8)) * GN_ROWS_IT) == 0, DFOT_ERR_SHAPE,
+               "groupnorm apply (bf16 stream): %d channels / %d pixels per frame unsupported", c, pixels);
+  const int grid = bt * (pixels / ((256 / (c / 8)) * GN_ROWS_IT));
+  if (c == 128) hipLaunchKernelGGL((gn_apply_silu_rows_kernel<128, bf16>), dim3(grid), dim3(256), 0, s, x, stats, gamma, beta, out, pixels, live);
+  else hipLaunchKernelGGL((gn_apply_silu_rows_kernel<256, bf16>), dim3(grid), dim3(256), 0, s, x, stats, gamma, beta, out, pixels, live);
+  DFOT_CHECK_HIP(hipGetLastError());
+  return DFOT_OK;
 }
 
 int launch_gn_apply_silu(const float* x, const float* stats, const float* gamma, const float* beta, bf16* out, int bt,
                          int pixels, int c, hipStream_t s, const uint8_t* live) {
   if ((c == 128 || c == 256) && pixels % ((256 / (c / 8)) * GN_ROWS_IT) == 0) {
     const int grid = bt * (pixels / ((256 / (c / 8)) * GN_ROWS_IT));
-    if (c == 128) hipLaunchKernelGGL(gn_apply_silu_rows_kernel<128>, dim3(grid), dim3(256), 0, s, x, stats, gamma, beta, out, pixels, live);
-    else hipLaunchKernelGGL(gn_apply_silu_rows_kernel<256>, dim3(grid), dim3(256), 0, s, x, stats, gamma, beta, out, pixels, live);
+    if (c == 128) hipLaunchKernelGGL((gn_apply_silu_rows_kernel<128, float>), dim3(grid), dim3(256), 0, s, x, stats, gamma, beta, out, pixels, live);
+    else hipLaunchKernelGGL((gn_apply_silu_rows_kernel<256, float>), dim3(grid), dim3(256), 0, s, x, stats, gamma, beta, out, pixels, live);
     DFOT_CHECK_HIP(hipGetLastError());
     return DFOT_OK;
   }
@@ -893,7 +958,8 @@ int launch_rms_film(const float* x, const float* w, const bf16* fcache, const fl
 // --------------------------------------------------------------------------------------------
 // resampling and skip arithmetic (u_vit_blocks.py:284-314, u_vit3d_pose.py:124-127)
 // --------------------------------------------------------------------------------------------
-__global__ void pool2_bf16_kernel(const float* __restrict__ x, bf16* __restrict__ out, long total4, int h, int w, int c) {
+template <typename TIN>
+__global__ void pool2_bf16_kernel(const TIN* __restrict__ x, bf16* __restrict__ out, long total4, int h, int w, int c) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= total4) return;
   const unsigned iu = (unsigned)idx, cq = (unsigned)(c / 4), w2 = (unsigned)(w / 2), h2 = (unsigned)(h / 2);
@@ -901,11 +967,11 @@ __global__ void pool2_bf16_kernel(const float* __restrict__ x, bf16* __restrict_
   const unsigned pix = iu / cq;
   const int ox = (int)(pix % w2), oy = (int)((pix / w2) % h2);
   const long bt = pix / (w2 * h2);
-  const float* base = x + ((bt * h + 2 * oy) * w + 2 * ox) * (long)c + c4 * 4;
-  const float4v a = *reinterpret_cast<const float4v*>(base);
-  const float4v b = *reinterpret_cast<const float4v*>(base + c);
-  const float4v cc = *reinterpret_cast<const float4v*>(base + (long)w * c);
-  const float4v dd = *reinterpret_cast<const float4v*>(base + (long)w * c + c);
+  const TIN* base = x + ((bt * h + 2 * oy) * w + 2 * ox) * (long)c + c4 * 4;
+  const float4v a = stream_ld4(base);
+  const float4v b = stream_ld4(base + c);
+  const float4v cc = stream_ld4(base + (long)w * c);
+  const float4v dd = stream_ld4(base + (long)w * c + c);
   bf16x4 o;
 #pragma unroll
   for (int j = 0; j < 4; ++j) o[j] = f2bf((a[j] + b[j] + cc[j] + dd[j]) * 0.25f);
@@ -914,18 +980,26 @@ __global__ void pool2_bf16_kernel(const float* __restrict__ x, bf16* __restrict_
 int launch_pool2_bf16(const float* x, bf16* out, int bt, int h, int w, int c, hipStream_t s) {
   const long total4 = (long)bt * (h / 2) * (w / 2) * (c / 4);
   DFOT_REQUIRE(total4 < (1L << 31), DFOT_ERR_SHAPE, "pool2: %ld work items exceed the 32-bit index range", total4);
-  hipLaunchKernelGGL(pool2_bf16_kernel, dim3(cdiv(total4, 256)), dim3(256), 0, s, x, out, total4, h, w, c);
+  hipLaunchKernelGGL(pool2_bf16_kernel<float>, dim3(cdiv(total4, 256)), dim3(256), 0, s, x, out, total4, h, w, c);
+  DFOT_CHECK_HIP(hipGetLastError());
+  return DFOT_OK;
+}
+int launch_pool2_bf16_bf16in(const bf16* x, bf16* out, int bt, int h, int w, int c, hipStream_t s) {
+  const long total4 = (long)bt * (h / 2) * (w / 2) * (c / 4);
+  DFOT_REQUIRE(total4 < (1L << 31), DFOT_ERR_SHAPE, "pool2: %ld work items exceed the 32-bit index range", total4);
+  hipLaunchKernelGGL(pool2_bf16_kernel<bf16>, dim3(cdiv(total4, 256)), dim3(256), 0, s, x, out, total4, h, w, c);
   DFOT_CHECK_HIP(hipGetLastError());
   return DFOT_OK;
 }
 
-__global__ void sub_bf16_kernel(const float* __restrict__ a, const float* __restrict__ b, bf16* __restrict__ out, long n4,
+template <typename TIN, typename TB = TIN>
+__global__ void sub_bf16_kernel(const TIN* __restrict__ a, const TB* __restrict__ b, bf16* __restrict__ out, long n4,
                                 const uint8_t* __restrict__ live, long frame4) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= n4) return;
   if (live && !live[idx / frame4]) return;
-  const float4v x = *reinterpret_cast<const float4v*>(a + idx * 4);
-  const float4v y = *reinterpret_cast<const float4v*>(b + idx * 4);
+  const float4v x = stream_ld4(a + idx * 4);
+  const float4v y = stream_ld4(b + idx * 4);
   bf16x4 o;
 #pragma unroll
   for (int j = 0; j < 4; ++j) o[j] = f2bf(x[j] - y[j]);
@@ -933,13 +1007,21 @@ __global__ void sub_bf16_kernel(const float* __restrict__ a, const float* __rest
 }
 int launch_sub_bf16(const float* a, const float* b, bf16* out, long n, hipStream_t s, const uint8_t* live, long frame_elems) {
   DFOT_REQUIRE(n % 4 == 0 && (!live || (frame_elems > 0 && frame_elems % 4 == 0)), DFOT_ERR_SHAPE, "sub: length %ld must be a multiple of 4", n);
-  hipLaunchKernelGGL(sub_bf16_kernel, dim3(cdiv(n / 4, 256)), dim3(256), 0, s, a, b, out, n / 4, live, live ? frame_elems / 4 : 1L);
+  hipLaunchKernelGGL((sub_bf16_kernel<float, float>), dim3(cdiv(n / 4, 256)), dim3(256), 0, s, a, b, out, n / 4, live, live ? frame_elems / 4 : 1L);
+  DFOT_CHECK_HIP(hipGetLastError());
+  return DFOT_OK;
+}
+// a from the bf16 stream, b an fp32 skip tensor
+int launch_sub_bf16_bf16in(const bf16* a, const float* b, bf16* out, long n, hipStream_t s, const uint8_t* live, long frame_elems) {
+  DFOT_REQUIRE(n % 4 == 0 && (!live || (frame_elems > 0 && frame_elems % 4 == 0)), DFOT_ERR_SHAPE, "sub: length %ld must be a multiple of 4", n);
+  hipLaunchKernelGGL((sub_bf16_kernel<bf16, float>), dim3(cdiv(n / 4, 256)), dim3(256), 0, s, a, b, out, n / 4, live, live ? frame_elems / 4 : 1L);
   DFOT_CHECK_HIP(hipGetLastError());
   return DFOT_OK;
 }
 
 // out[bt][y][x][:] = t[bt][y/2][x/2][:] + skip[bt][y][x][:]   (h,w are the LOW-resolution sizes)
-__global__ void upsample_add_kernel(const float* __restrict__ t, const float* __restrict__ skip, float* __restrict__ out,
+template <typename TS>
+__global__ void upsample_add_kernel(const float* __restrict__ t, const TS* __restrict__ skip, TS* __restrict__ out,
                                     long total4, int h, int w, int c, const uint8_t* __restrict__ live) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= total4) return;
@@ -950,13 +1032,21 @@ __global__ void upsample_add_kernel(const float* __restrict__ t, const float* __
   const long bt = pix / (w2 * h2);
   if (live && !live[bt]) return;
   const float4v a = *reinterpret_cast<const float4v*>(t + ((bt * h + y / 2) * w + x / 2) * (long)c + c4 * 4);
-  const float4v b = *reinterpret_cast<const float4v*>(skip + pix * c + c4 * 4);
-  *reinterpret_cast<float4v*>(out + pix * c + c4 * 4) = a + b;
+  const float4v b = stream_ld4(skip + pix * c + c4 * 4);
+  stream_st4(out + pix * c + c4 * 4, a + b);
 }
 int launch_upsample_add(const float* t, const float* skip, float* out, int bt, int h, int w, int c, hipStream_t s, const uint8_t* live) {
   const long total4 = (long)bt * 4 * h * w * (c / 4);
   DFOT_REQUIRE(total4 < (1L << 31), DFOT_ERR_SHAPE, "upsample_add: %ld work items exceed the 32-bit index range", total4);
-  hipLaunchKernelGGL(upsample_add_kernel, dim3(cdiv(total4, 256)), dim3(256), 0, s, t, skip, out, total4, h, w, c, live);
+  hipLaunchKernelGGL(upsample_add_kernel<float>, dim3(cdiv(total4, 256)), dim3(256), 0, s, t, skip, out, total4, h, w, c, live);
+  DFOT_CHECK_HIP(hipGetLastError());
+  return DFOT_OK;
+}
+// skip and out in the bf16 stream (t stays the fp32 output of the Upsample convolution)
+int launch_upsample_add_bf16(const float* t, const bf16* skip, bf16* out, int bt, int h, int w, int c, hipStream_t s, const uint8_t* live) {
+  const long total4 = (long)bt * 4 * h * w * (c / 4);
+  DFOT_REQUIRE(total4 < (1L << 31), DFOT_ERR_SHAPE, "upsample_add: %ld work items exceed the 32-bit index range", total4);
+  hipLaunchKernelGGL(upsample_add_kernel<bf16>, dim3(cdiv(total4, 256)), dim3(256), 0, s, t, skip, out, total4, h, w, c, live);
   DFOT_CHECK_HIP(hipGetLastError());
   return DFOT_OK;
 }

@@ -122,6 +122,12 @@ struct dfot_uvit_s {
   // where the residual stream of a level currently lives: X[l], or HSA[l-1] right after the Downsample convolution (its output is both
   // the skip tensor and the next level's input: the first block of the level reads it there and writes X[l], no copy)
   const float* xin[4] = {nullptr, nullptr, nullptr, nullptr};
+  // ResBlock levels (0, 1): the stream between blocks is bf16 (XB[l]) -- what torch.autocast(bf16) keeps there in the reference: every
+  // block's second convolution adds the residual in its bf16 epilogue.  A level is ENTERED from an fp32 tensor (level 1: the Downsample
+  // output HSA[0], which stays fp32 as skip tensor) or from XB[l] itself (level 0: the patch embedding writes bf16; up path: upsample_add).
+  // xin_bf[l]: the level's stream currently lives in XB[l] (xin[l] is then unused).
+  bf16* XB[2] = {nullptr, nullptr};
+  bool xin_bf[2] = {false, false};
   int gemm_variant = GEMM_AUTO;
   int attn_variant = 2;
   bool attn_force_safe = false;  // level-2 attention: always the running-max kernel (what weights with a bound >= 64 get)
@@ -375,16 +381,19 @@ static int run_res_block(dfot_uvit_s* h, const ResW& w, int lvl, int bt, hipStre
   const int c = w.c, rr = h->r[lvl], pix = rr * rr;
   const int m = bt * pix;
   const int slots = pix / 64;
-  float* x = h->X[lvl];
+  bf16* xb = h->XB[lvl];
+  const bool in_bf = h->xin_bf[lvl];
   const float* xi = h->xin[lvl];
   int rc = 0;
   if (h->gn1_nblk == 0) {
-    if ((rc = launch_gn_partial_f32(xi, h->gn_partial, bt, pix, c, s))) return rc;
+    if ((rc = in_bf ? launch_gn_partial_bf16(xb, h->gn_partial, bt, pix, c, s) : launch_gn_partial_f32(xi, h->gn_partial, bt, pix, c, s))) return rc;
     h->gn1_nblk = gn_partial_blocks(pix);
   }
   if ((rc = launch_gn_finalize(h->gn_partial, h->gn_stats, bt, h->gn1_nblk, pix, c, h->cfg.eps, s))) return rc;
   h->gn1_nblk = 0;
-  if ((rc = launch_gn_apply_silu(xi, h->gn_stats, w.g1, w.be1, h->s1, bt, pix, c, s, live))) return rc;
+  if ((rc = in_bf ? launch_gn_apply_silu_bf16in(xb, h->gn_stats, w.g1, w.be1, h->s1, bt, pix, c, s, live)
+                  : launch_gn_apply_silu(xi, h->gn_stats, w.g1, w.be1, h->s1, bt, pix, c, s, live)))
+    return rc;
   GemmArgs g;
   g.A = h->s1; g.W = w.w1; g.M = m; g.N = c; g.K = 9 * c; g.H = rr; g.Wd = rr; g.Cin = c; g.zeros = h->zeros;
   g.bias = w.bias1; g.out_bf16 = h->hbf; g.ldo = c; g.live = live;
@@ -396,10 +405,11 @@ static int run_res_block(dfot_uvit_s* h, const ResW& w, int lvl, int bt, hipStre
     return rc;
   GemmArgs o;
   o.A = h->s1; o.W = w.w2; o.M = m; o.N = c; o.K = 9 * c; o.H = rr; o.Wd = rr; o.Cin = c; o.zeros = h->zeros;
-  o.bias = w.bias2; o.out_f32 = x; o.resid = xi; o.ldo = c; o.live = live;
+  o.bias = w.bias2; o.out_bf16 = xb; o.ldo = c; o.live = live;
+  if (in_bf) o.resid_bf = xb; else o.resid = xi;  // in place on the bf16 stream: a thread reads its elements before it writes them
   o.gn_part = h->gn_partial; o.gn_rows_per_bt = pix; o.gn_cpg = c / 32;
-  if ((rc = launch_gemm(A_CONV3, E_F32, h->gemm_variant, o, s))) return rc;
-  h->xin[lvl] = x;
+  if ((rc = launch_gemm(A_CONV3, E_BF16, h->gemm_variant, o, s))) return rc;
+  h->xin_bf[lvl] = true;
   h->gn1_nblk = slots;
   return DFOT_OK;
 }
@@ -539,7 +549,8 @@ static int conv_between_levels(dfot_uvit_s* h, GemmArgs g, hipStream_t s) {
 static int run_down(dfot_uvit_s* h, int l, int bt, hipStream_t s, const uint8_t* live = nullptr) {
   const int rr = h->r[l], cin = h->ch[l], cout = h->ch[l + 1];
   int rc = 0;
-  if ((rc = launch_pool2_bf16(h->xin[l], h->s1, bt, rr, rr, cin, s))) return rc;
+  if ((rc = (l < 2 && h->xin_bf[l]) ? launch_pool2_bf16_bf16in(h->XB[l], h->s1, bt, rr, rr, cin, s) : launch_pool2_bf16(h->xin[l], h->s1, bt, rr, rr, cin, s)))
+    return rc;
   GemmArgs g;
   g.A = h->s1; g.W = h->down_conv[l].w; g.M = bt * (rr / 2) * (rr / 2); g.N = cout; g.K = 9 * cin; g.H = rr / 2; g.Wd = rr / 2;
   g.Cin = cin; g.zeros = h->zeros; g.bias = h->down_conv[l].b; g.out_f32 = h->HSA[l]; g.ldo = cout;
@@ -551,6 +562,7 @@ static int run_down(dfot_uvit_s* h, int l, int bt, hipStream_t s, const uint8_t*
   if ((rc = conv_between_levels(h, g, s))) return rc;
   h->gn1_nblk = next_is_res ? g.gn_rows_per_bt / 64 : 0;
   h->xin[l + 1] = h->HSA[l];  // the skip tensor IS the next level's input: its first block reads it here and writes X[l + 1]
+  if (l + 1 < 2) h->xin_bf[l + 1] = false;
   return DFOT_OK;
 }
 
@@ -558,7 +570,9 @@ static int run_up(dfot_uvit_s* h, int l, int bt, hipStream_t s, const uint8_t* l
   const int rr = h->r[l + 1], cin = h->ch[l + 1], cout = h->ch[l];
   const long n_in = (long)bt * rr * rr * cin;
   int rc = 0;
-  if ((rc = launch_sub_bf16(h->xin[l + 1], h->HSA[l], h->s1, n_in, s, live, (long)rr * rr * cin))) return rc;
+  if ((rc = (l + 1 < 2 && h->xin_bf[l + 1]) ? launch_sub_bf16_bf16in(h->XB[l + 1], h->HSA[l], h->s1, n_in, s, live, (long)rr * rr * cin)
+                                             : launch_sub_bf16(h->xin[l + 1], h->HSA[l], h->s1, n_in, s, live, (long)rr * rr * cin)))
+    return rc;
   GemmArgs g;
   g.A = h->s1; g.W = h->up_conv[l].w; g.M = bt * rr * rr; g.N = cout; g.K = 9 * cin; g.H = rr; g.Wd = rr; g.Cin = cin;
   g.zeros = h->zeros; g.bias = h->up_conv[l].b; g.out_f32 = h->tmp; g.ldo = cout;
@@ -566,6 +580,13 @@ static int run_up(dfot_uvit_s* h, int l, int bt, hipStream_t s, const uint8_t* l
   if (live && (rr * rr) % 256 == 0 && h->gemm_variant == GEMM_AUTO) g.live = live;
   if ((rc = conv_between_levels(h, g, s))) return rc;
   h->gn1_nblk = 0;  // X[l] is rewritten by an elementwise kernel: its statistics come from the standalone kernel
+  if (l < 2) {  // ResBlock level: the down path left its output in the bf16 stream; the sum goes back into it (elementwise, in place)
+    if (!h->xin_bf[l]) {
+      set_error("run_up: level %d stream is not in its bf16 buffer", l);
+      return DFOT_ERR_STATE;
+    }
+    return launch_upsample_add_bf16(h->tmp, h->XB[l], h->XB[l], bt, rr, rr, cout, s, live);
+  }
   rc = launch_upsample_add(h->tmp, h->xin[l], h->X[l], bt, rr, rr, cout, s, live);
   h->xin[l] = h->X[l];
   return rc;
@@ -700,7 +721,11 @@ int dfot_uvit_reserve(dfot_uvit_t h, int max_batch) {
   if ((rc = dev_alloc(h, &h->nemb, bt * h->E, true))) return rc;
   if ((rc = dev_alloc(h, &h->nhid, bt * h->E, true))) return rc;
   for (int l = 0; l < 4; ++l) {
-    if ((rc = dev_alloc(h, &h->X[l], bt * pix[l] * h->ch[l], true))) return rc;
+    if (l < 2) {
+      if ((rc = dev_alloc(h, &h->XB[l], bt * pix[l] * h->ch[l], true))) return rc;
+    } else if ((rc = dev_alloc(h, &h->X[l], bt * pix[l] * h->ch[l], true))) {
+      return rc;
+    }
     if ((rc = dev_alloc(h, &h->emb[l], bt * pix[l] * h->E, true))) return rc;
   }
   for (int l = 0; l < 3; ++l)
@@ -892,9 +917,11 @@ int dfot_uvit_forward_cached_masks(dfot_uvit_t h, const float* x, const float* n
                              h->nemb, bt, c.noise_dim, e, s)))
     return rc;
   if ((rc = launch_film_vec(h->film_table, h->film_chunks, h->nemb, h->sv, bt, e, s))) return rc;
-  if ((rc = launch_embed_input(x, h->ein_w, h->ein_b, h->X[0], bt, c.resolution, c.in_channels, h->ch[0], s))) return rc;
+  if ((rc = launch_embed_input_bf16(x, h->ein_w, h->ein_b, h->XB[0], bt, c.resolution, c.in_channels, h->ch[0], s))) return rc;
   h->gn1_nblk = 0;
   for (int l = 0; l < 4; ++l) h->xin[l] = h->X[l];
+  h->xin_bf[0] = true;
+  h->xin_bf[1] = false;
 
   // frames that are NOT fresh (fresh_frames[b * T + t] == 0): the caller states that this frame's input, noise level and conditioning
   // equal those of the previous forward of this handle (a clean context frame of the conditional branch across the DDIM steps of a
@@ -929,7 +956,7 @@ int dfot_uvit_forward_cached_masks(dfot_uvit_t h, const float* x, const float* n
       if ((rc = run_res_block(h, w, l, bt, s, live_frames))) return rc;
   }
   h->last_batch = batch;
-  return launch_project_output(h->xin[0], h->pout_w, h->pout_b, out, bt, c.resolution, h->ch[0], c.in_channels, s, live_frames);
+  return launch_project_output_bf16(h->XB[0], h->pout_w, h->pout_b, out, bt, c.resolution, h->ch[0], c.in_channels, s, live_frames);
 }
 
 int dfot_uvit_forward(dfot_uvit_t h, const float* x, const float* noise_levels, const float* external_cond,
@@ -951,7 +978,7 @@ int dfot_uvit_read_tap(dfot_uvit_t h, const char* name, float* out, size_t capac
       {"pose_emb0", 0, h->E, nullptr, h->emb[0]}, {"down0", 1, h->ch[1], h->HSA[0], nullptr},
       {"down1", 2, h->ch[2], h->HSA[1], nullptr}, {"down2", 3, h->ch[3], h->HSA[2], nullptr},
       {"mid", 3, h->ch[3], h->xin[3], nullptr}, {"up2", 2, h->ch[2], h->xin[2], nullptr},
-      {"up1", 1, h->ch[1], h->xin[1], nullptr}, {"up0", 0, h->ch[0], h->xin[0], nullptr},
+      {"up1", 1, h->ch[1], nullptr, h->XB[1]}, {"up0", 0, h->ch[0], nullptr, h->XB[0]},
   };
   for (const Tap& t : taps) {
     if (strcmp(t.n, name)) continue;
