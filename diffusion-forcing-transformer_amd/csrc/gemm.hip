@@ -561,14 +561,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int tile_inde
             v0 += *reinterpret_cast<const f32x4*>(bp);
             v1 += *reinterpret_cast<const f32x4*>(bp + 4);
           }
-          if (g.resid_bf && live) {  // bf16 residual stream (ResBlock levels of the inference engine): same rows / pitch as the output
-            const bf16x8 rb = *reinterpret_cast<const bf16x8*>(g.resid_bf + (mw + r) * g.ldo + col);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { v0[j] += bf2f(rb[j]); v1[j] += bf2f(rb[4 + j]); }
-          } else if (g.resid && live) {  // ... entered from an fp32 tensor (the level's input: a Downsample output)
-            v0 += *reinterpret_cast<const f32x4*>(g.resid + (mw + r) * g.ldo + col);
-            v1 += *reinterpret_cast<const f32x4*>(g.resid + (mw + r) * g.ldo + col + 4);
-          }
+
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -603,8 +596,15 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int tile_inde
           for (int p = 0; p < 2; ++p) {
             const int r = p * 8 + (lane >> 3);
             bf16x8 o;
+            if (AMODE == A_CONV3 && g.resid_bf) {  // (convolutions only: the dense 12-wave tiles have no register to spare) bf16 residual stream (ResBlock levels of the inference engine): same rows / pitch as the output, added
+              // last (after an activation, if any), loaded here so that it is live for one row only (the 128-register budget of the 16-wave tiles)
+              const bf16x8 rb = *reinterpret_cast<const bf16x8*>(g.resid_bf + (mw + r) * g.ldo + col);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] = f2bf(silu ? silu_f(vals[p][j]) : vals[p][j]);
+              for (int j = 0; j < 8; ++j) o[j] = f2bf((silu ? silu_f(vals[p][j]) : vals[p][j]) + bf2f(rb[j]));
+            } else {
+#pragma unroll
+              for (int j = 0; j < 8; ++j) o[j] = f2bf(silu ? silu_f(vals[p][j]) : vals[p][j]);
+            }
             *reinterpret_cast<bf16x8*>(g.out_bf16 + (mw + r) * g.ldo + col) = o;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {  // GroupNorm statistics of the values as stored (bf16-rounded)
@@ -957,6 +957,7 @@ int launch_gemm(int amode, int epi, int variant, const GemmArgs& g, hipStream_t 
                      !g.gn_part && g.K / BK >= 2 * g.ksplit, DFOT_ERR_ARG,
                  "gemm: split-K over workgroups needs the fp32 epilogue with an in-place residual (or none), no gate, and K >= %d", 2 * g.ksplit * BK);
   if (g.bias_rows) DFOT_REQUIRE((epi == E_F32 || epi == E_BF16) && g.bias, DFOT_ERR_ARG, "gemm: 2-D bias needs a plain epilogue");
+  if (g.resid_bf) DFOT_REQUIRE(epi == E_BF16 && amode == A_CONV3 && !g.resid, DFOT_ERR_ARG, "gemm: a bf16 residual needs a convolution with the bf16 epilogue");
   if (g.tr_rows) {
     DFOT_REQUIRE(epi == E_BF16 && !g.bias && !g.act && !g.gn_part && g.tr_rows % 4 == 0 && g.M % g.tr_rows == 0 && amode == A_DENSE,
                  DFOT_ERR_ARG, "gemm: transposed store needs the plain bf16 epilogue and tr_rows %% 4 == 0 dividing M");

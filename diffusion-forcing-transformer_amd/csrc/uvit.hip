@@ -382,18 +382,22 @@ static int run_res_block(dfot_uvit_s* h, const ResW& w, int lvl, int bt, hipStre
   const int m = bt * pix;
   const int slots = pix / 64;
   bf16* xb = h->XB[lvl];
-  const bool in_bf = h->xin_bf[lvl];
-  const float* xi = h->xin[lvl];
   int rc = 0;
+  if (!h->xin_bf[lvl]) {
+    // the level is entered from an fp32 tensor (level 1: the Downsample output, which stays fp32 as the skip tensor): one cast into the
+    // bf16 stream (67 MB read at level 1 of config 2, once per forward).  The GroupNorm statistics the convolution's epilogue left
+    // (gn1_nblk > 0) are those of the fp32 values: the same numbers up to the bf16 rounding of the elements.  Frozen frames are cast too
+    // (their rows of this level's stream are never read again: frozen frames are dead frames, and the Downsample skips their tiles)
+    if ((rc = launch_f32_to_bf16(h->xin[lvl], xb, (long)m * c, s))) return rc;
+    h->xin_bf[lvl] = true;
+  }
   if (h->gn1_nblk == 0) {
-    if ((rc = in_bf ? launch_gn_partial_bf16(xb, h->gn_partial, bt, pix, c, s) : launch_gn_partial_f32(xi, h->gn_partial, bt, pix, c, s))) return rc;
+    if ((rc = launch_gn_partial_bf16(xb, h->gn_partial, bt, pix, c, s))) return rc;
     h->gn1_nblk = gn_partial_blocks(pix);
   }
   if ((rc = launch_gn_finalize(h->gn_partial, h->gn_stats, bt, h->gn1_nblk, pix, c, h->cfg.eps, s))) return rc;
   h->gn1_nblk = 0;
-  if ((rc = in_bf ? launch_gn_apply_silu_bf16in(xb, h->gn_stats, w.g1, w.be1, h->s1, bt, pix, c, s, live)
-                  : launch_gn_apply_silu(xi, h->gn_stats, w.g1, w.be1, h->s1, bt, pix, c, s, live)))
-    return rc;
+  if ((rc = launch_gn_apply_silu_bf16in(xb, h->gn_stats, w.g1, w.be1, h->s1, bt, pix, c, s, live))) return rc;
   GemmArgs g;
   g.A = h->s1; g.W = w.w1; g.M = m; g.N = c; g.K = 9 * c; g.H = rr; g.Wd = rr; g.Cin = c; g.zeros = h->zeros;
   g.bias = w.bias1; g.out_bf16 = h->hbf; g.ldo = c; g.live = live;
@@ -406,7 +410,7 @@ static int run_res_block(dfot_uvit_s* h, const ResW& w, int lvl, int bt, hipStre
   GemmArgs o;
   o.A = h->s1; o.W = w.w2; o.M = m; o.N = c; o.K = 9 * c; o.H = rr; o.Wd = rr; o.Cin = c; o.zeros = h->zeros;
   o.bias = w.bias2; o.out_bf16 = xb; o.ldo = c; o.live = live;
-  if (in_bf) o.resid_bf = xb; else o.resid = xi;  // in place on the bf16 stream: a thread reads its elements before it writes them
+  o.resid_bf = xb;  // in place on the bf16 stream: a thread reads its elements before it writes them
   o.gn_part = h->gn_partial; o.gn_rows_per_bt = pix; o.gn_cpg = c / 32;
   if ((rc = launch_gemm(A_CONV3, E_BF16, h->gemm_variant, o, s))) return rc;
   h->xin_bf[lvl] = true;
