@@ -128,9 +128,6 @@ SIGNATURES = {
     "dfot_op_attention_scratch_bytes": (C.c_size_t, [_I, _I, _I, _I]),
     "dfot_op_attention_bwd_lse": (_I, [_P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "dfot_op_gn_silu_fwd": (_I, [_P, _P, _P, _P, _F, _P, _P, _I, _I, _I, _P]),
-    "dfot_op_gn_silu_bwd2": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
-    "dfot_op_gn_silu_bwd3": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _L, _P]),
-    "dfot_op_gn_silu_bwd4": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _P, _I, _I, _I, _P]),
     "dfot_op_gn_silu_bwd5": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _P, _I, _I, _I, _P]),
     "dfot_op_gn_silu_fwd2": (_I, [_P, _P, _P, _P, _L, _F, _P, _P, _I, _I, _I, _P]),
     "dfot_op_gn_silu_bwd6": (_I, [_P, _P, _P, _P, _P, _P, _L, _P, _P, _P, _P, _L, _P, _P, _I, _I, _I, _P]),
@@ -146,11 +143,8 @@ SIGNATURES = {
     "dfot_op_upsample_add": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "dfot_op_upsample_bwd": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "dfot_op_axpy": (_I, [_P, _P, _F, _L, _P]),
-    "dfot_op_emb_combine": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "dfot_op_mul_cols": (_I, [_P, _I, _I, _P, _L, _I, _P]),
-    "dfot_op_masked_cast": (_I, [_P, _P, _P, _L, _L, _P]),
     "dfot_op_emb_pyramid": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
-    "dfot_op_rows_sum": (_I, [_P, _P, _I, _I, _I, _P]),
     "dfot_op_cond_repack": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "dfot_op_embed_input": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "dfot_op_embed_input_wgrad": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),

@@ -1035,30 +1035,6 @@ __global__ void axpy_kernel4(float* __restrict__ a, const float* __restrict__ b,
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n4) reinterpret_cast<f4*>(a)[i] += reinterpret_cast<const f4*>(b)[i] * alpha;
 }
-// emb0[row][e] = bf16((masked ? 0 : pose[row][e]) + nemb[row / P][e])
-// 8 embedding channels per thread (E % 8 == 0: launcher); total = elements / 8
-__global__ void emb_combine_kernel(const bf16* __restrict__ pose, const float* __restrict__ nemb, const uint8_t* __restrict__ mask, bf16* __restrict__ out,
-                                   long total, int P, int E, int tokens) {
-  typedef __attribute__((ext_vector_type(4))) float f4;
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= total) return;
-  const int eq = E / 8;
-  const long row = i / eq;
-  const int e = (int)(i % eq) * 8;
-  const long bt = row / P;
-  const bool drop = mask && mask[bt / tokens];
-  const f4 n0 = *reinterpret_cast<const f4*>(nemb + bt * E + e), n1 = *reinterpret_cast<const f4*>(nemb + bt * E + e + 4);
-  bf16x8 o;
-  if (drop) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) o[j] = f2bf(n0[j]), o[4 + j] = f2bf(n1[j]);
-  } else {
-    const bf16x8 pv = *reinterpret_cast<const bf16x8*>(pose + row * E + e);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) o[j] = f2bf(bf2f(pv[j]) + n0[j]), o[4 + j] = f2bf(bf2f(pv[4 + j]) + n1[j]);
-  }
-  *reinterpret_cast<bf16x8*>(out + row * E + e) = o;
-}
 // dst[r][dcol0 + c] *= mask[r][c]   (dropout: mask holds 0 or 1 / (1 - p)); 8 columns per thread
 __global__ void mul_cols_kernel(bf16* __restrict__ dst, long ldd, int dcol0, const bf16* __restrict__ mask, long rows, int ncols) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1071,34 +1047,6 @@ __global__ void mul_cols_kernel(bf16* __restrict__ dst, long ldd, int dcol0, con
 #pragma unroll
   for (int j = 0; j < 8; ++j) v[j] = f2bf(bf2f(v[j]) * bf2f(m[j]));
   *reinterpret_cast<bf16x8*>(dst + r * ldd + dcol0 + c) = v;
-}
-// out bf16 = src fp32 with the rows of masked videos zeroed (gradient of the dropped pose embedding)
-// 8 elements per thread (total, per_video multiples of 8: launcher); total8 = elements / 8
-__global__ void masked_cast_kernel(const float* __restrict__ src, const uint8_t* __restrict__ mask, bf16* __restrict__ out, long total8, long per_video) {
-  typedef __attribute__((ext_vector_type(4))) float f4;
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= total8) return;
-  bf16x8 o;
-  if (mask && mask[(i * 8) / per_video]) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = f2bf(0.f);
-  } else {
-    const f4 a = reinterpret_cast<const f4*>(src)[2 * i], b = reinterpret_cast<const f4*>(src)[2 * i + 1];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) o[j] = f2bf(a[j]), o[4 + j] = f2bf(b[j]);
-  }
-  reinterpret_cast<bf16x8*>(out)[i] = o;
-}
-// fine[bt][2y+a][2x+b][e] += coarse[bt][y][x][e] / 4   (adjoint of one level of the embedding pyramid's average pool), fp32
-// == pool2_bwd_kernel; dnemb[bt][e] = sum_p demb0[bt][p][e] is frames-style column sum over P rows:
-__global__ void rows_sum_kernel(const float* __restrict__ src, float* __restrict__ part, int P, int E) {  // part [gridDim.z][BT][E] partial sums
-  const int bt = blockIdx.y;
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= E) return;
-  const int per = (P + gridDim.z - 1) / gridDim.z, p0 = blockIdx.z * per, p1 = p0 + per < P ? p0 + per : P;
-  float acc = 0.f;
-  for (int p = p0; p < p1; ++p) acc += src[((long)bt * P + p) * E + e];
-  part[((long)blockIdx.z * gridDim.y + bt) * E + e] = acc;
 }
 // hi = bf16(x), lo = bf16(x - hi): 8 elements per thread
 __global__ void split_bf16_kernel(const float* __restrict__ x, bf16* __restrict__ hi, bf16* __restrict__ lo, long n8) {
@@ -1249,44 +1197,9 @@ int dfot_op_gn_silu_fwd2(const float* x, const float* gamma, const float* beta, 
   DFOT_CHECK_HIP(hipGetLastError());
   return DFOT_OK;
 }
-// backward with saved statistics; dx += when accumulate_dx; dgamma / dbeta are written (deterministic two-stage sums)
-int dfot_op_gn_silu_bwd2(const float* x, const float* dy, const float* stats, const float* gamma, const float* beta, const void* film, float* dx,
-                         void* dfilm, float* dgamma, float* dbeta, int bt, int pixels, int channels, int accumulate_dx, void* stream) {
-  DFOT_REQUIRE(x && dy && stats && gamma && beta && dx && dgamma && dbeta, DFOT_ERR_ARG, "op_gn_silu_bwd2: null argument");
-  hipStream_t s = (hipStream_t)stream;
-  void* sums = nullptr;
-  int rc = op_scratch(4, (size_t)bt * 64 * sizeof(float), &sums);
-  if (rc) return rc;
-  return gn_silu_backward(x, dy, stats, gamma, beta, (const bf16*)film, (float*)sums, dx, (bf16*)dfilm, dgamma, dbeta, bt, pixels, channels,
-                          accumulate_dx != 0, s);
-}
-int dfot_op_gn_silu_bwd3(const float* x, const float* dy, const float* stats, const float* gamma, const float* beta, const void* film, float* dx,
-                         void* dfilm, float* dgamma, float* dbeta, int bt, int pixels, int channels, int accumulate_dx, int64_t dfilm_ld, void* stream) {
-  DFOT_REQUIRE(x && dy && stats && gamma && beta && dx && dgamma && dbeta && dfilm_ld >= 2 * channels && dfilm_ld % 4 == 0, DFOT_ERR_ARG,
-               "op_gn_silu_bwd3: bad argument");
-  hipStream_t s = (hipStream_t)stream;
-  void* sums = nullptr;
-  int rc = op_scratch(4, (size_t)bt * 64 * sizeof(float), &sums);
-  if (rc) return rc;
-  return gn_silu_backward(x, dy, stats, gamma, beta, (const bf16*)film, (float*)sums, dx, (bf16*)dfilm, dgamma, dbeta, bt, pixels, channels,
-                          accumulate_dx != 0, s, (long)dfilm_ld);
-}
-// the general form: dx = (dres ? dres : 0) + the norm's input gradient, written as fp32 (dx) and / or bf16 (dx_bf) -- the gradient that
-// only feeds a convolution's data / weight gradient is needed in bf16 alone, the one that continues down the residual stream in both
-int dfot_op_gn_silu_bwd4(const float* x, const float* dy, const float* stats, const float* gamma, const float* beta, const void* film, const float* dres,
-                         float* dx, void* dx_bf, void* dfilm, int64_t dfilm_ld, float* dgamma, float* dbeta, int bt, int pixels, int channels,
-                         void* stream) {
-  DFOT_REQUIRE(x && dy && stats && gamma && beta && (dx || dx_bf) && dgamma && dbeta && (!dres || dres != dx), DFOT_ERR_ARG,
-               "op_gn_silu_bwd4: null or aliased argument");
-  DFOT_REQUIRE(!dfilm || (dfilm_ld >= 2 * channels && dfilm_ld % 4 == 0), DFOT_ERR_ARG, "op_gn_silu_bwd4: bad dfilm row stride");
-  hipStream_t s = (hipStream_t)stream;
-  void* sums = nullptr;
-  int rc = op_scratch(4, (size_t)bt * 64 * sizeof(float), &sums);
-  if (rc) return rc;
-  return gn_silu_backward(x, dy, stats, gamma, beta, (const bf16*)film, (float*)sums, dx, (bf16*)dfilm, dgamma, dbeta, bt, pixels, channels,
-                          dres != nullptr, s, (long)dfilm_ld, dres, (bf16*)dx_bf);
-}
-// dfot_op_gn_silu_bwd4 with the upstream gradient in bf16 (what dfot_op_conv3x3_bwd2 leaves in dx_bf)
+// backward with saved statistics and the upstream gradient in bf16 (what dfot_op_conv3x3_bwd2 leaves in dx_bf): dx = (dres ? dres : 0) + the
+// norm's input gradient, written as fp32 (dx) and / or bf16 (dx_bf) -- the gradient that only feeds a convolution's data / weight gradient
+// is needed in bf16 alone, the one that continues down the residual stream in both; dgamma / dbeta are written (deterministic two-stage sums)
 int dfot_op_gn_silu_bwd5(const float* x, const void* dy_bf, const float* stats, const float* gamma, const float* beta, const void* film, const float* dres,
                          float* dx, void* dx_bf, void* dfilm, int64_t dfilm_ld, float* dgamma, float* dbeta, int bt, int pixels, int channels,
                          void* stream) {
@@ -1399,14 +1312,6 @@ int dfot_op_axpy(float* a, const float* b, float alpha, int64_t n, void* stream)
   DFOT_CHECK_HIP(hipGetLastError());
   return DFOT_OK;
 }
-int dfot_op_emb_combine(const void* pose, const float* nemb, const uint8_t* mask, void* out, int bt, int pixels, int e, int tokens, void* stream) {
-  DFOT_REQUIRE(e % 8 == 0, DFOT_ERR_SHAPE, "op_emb_combine: embedding width %d must be a multiple of 8", e);
-  const long total = (long)bt * pixels * (e / 8);
-  hipLaunchKernelGGL(emb_combine_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16*)pose, nemb, mask, (bf16*)out, total, pixels, e,
-                     tokens);
-  DFOT_CHECK_HIP(hipGetLastError());
-  return DFOT_OK;
-}
 int dfot_op_mul_cols(void* dst, int ldd, int dcol0, const void* mask, int64_t rows, int ncols, void* stream) {
   DFOT_REQUIRE(dst && mask && ncols % 8 == 0 && dcol0 % 8 == 0, DFOT_ERR_ARG, "op_mul_cols: bad argument");
   hipLaunchKernelGGL(mul_cols_kernel, dim3(cdiv((long)rows * (ncols / 8), 256)), dim3(256), 0, (hipStream_t)stream, (bf16*)dst, (long)ldd, dcol0,
@@ -1414,25 +1319,8 @@ int dfot_op_mul_cols(void* dst, int ldd, int dcol0, const void* mask, int64_t ro
   DFOT_CHECK_HIP(hipGetLastError());
   return DFOT_OK;
 }
-int dfot_op_masked_cast(const float* src, const uint8_t* mask, void* out, int64_t total, int64_t per_video, void* stream) {
-  DFOT_REQUIRE(total % 8 == 0 && per_video % 8 == 0, DFOT_ERR_SHAPE, "op_masked_cast: sizes must be multiples of 8");
-  hipLaunchKernelGGL(masked_cast_kernel, dim3(cdiv((long)total / 8, 256)), dim3(256), 0, (hipStream_t)stream, src, mask, (bf16*)out, (long)total / 8,
-                     (long)per_video);
-  DFOT_CHECK_HIP(hipGetLastError());
-  return DFOT_OK;
-}
 int dfot_op_emb_pyramid(const void* emb0, void* emb1, void* emb2, void* emb3, int bt, int r0, int e, void* stream) {
   return launch_emb_pyramid((const bf16*)emb0, (bf16*)emb1, (bf16*)emb2, (bf16*)emb3, bt, r0, e, (hipStream_t)stream);
-}
-int dfot_op_rows_sum(const float* src, float* out, int bt, int pixels, int e, void* stream) {
-  hipStream_t s = (hipStream_t)stream;
-  const int nz = pixels >= 2048 ? 64 : 1;
-  float* part = nullptr;  // deterministic: partial sums per pixel chunk, then a fixed-order sum
-  int rc = det_scratch(2, (size_t)nz * bt * e, &part);
-  if (rc) return rc;
-  hipLaunchKernelGGL(rows_sum_kernel, dim3(cdiv(e, 256), bt, nz), dim3(256), 0, s, src, part, pixels, e);
-  DFOT_CHECK_HIP(hipGetLastError());
-  return det_sum(part, (long)bt * e, nz, bt * e, out, false, s);
 }
 int dfot_op_cond_repack(const float* cond, void* a, int bt, int res, int cdim, int kpad, void* stream) {
   return launch_cond_repack(cond, (bf16*)a, bt, res, cdim, kpad, (hipStream_t)stream);

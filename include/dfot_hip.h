@@ -363,19 +363,13 @@ int dfot_op_attention_bwd_lse(const void* q, const void* k, const void* v, const
                               void* dq, void* dk, void* dv, int batch, int heads, int n, int d, void* stream);
 /* ResBlock / resampler / embedding pieces of the UViT training driver (channels-last fp32 streams, bf16 GEMM operands).
  * Shape contract of the vectorised kernels: GroupNorm entries take 128, 256, 512 or 1024 channels; pool2_bwd / upsample_bwd channels
- * % 4 == 0; emb_combine embedding width % 8 == 0; masked_cast total and per_video % 8 == 0 (anything else returns DFOT_ERR_SHAPE). */
+ * % 4 == 0; frame sums / split_bf16 lengths % 8 == 0 (anything else returns DFOT_ERR_SHAPE). */
 int dfot_op_gn_silu_fwd(const float* x, const float* gamma, const float* beta, const void* film, float eps, void* out, float* stats, int bt,
                         int pixels, int channels, void* stream);
-int dfot_op_gn_silu_bwd2(const float* x, const float* dy, const float* stats, const float* gamma, const float* beta, const void* film, float* dx,
-                         void* dfilm, float* dgamma, float* dbeta, int bt, int pixels, int channels, int accumulate_dx, void* stream);
-/* the same, dfilm written at row stride dfilm_ld (elements): a column block of a wider matrix */
-int dfot_op_gn_silu_bwd3(const float* x, const float* dy, const float* stats, const float* gamma, const float* beta, const void* film, float* dx,
-                         void* dfilm, float* dgamma, float* dbeta, int bt, int pixels, int channels, int accumulate_dx, int64_t dfilm_ld, void* stream);
-/* general form: dx = (dres ? dres : 0) + input gradient, as fp32 (dx) and / or bf16 (dx_bf); dfilm optional with its row stride */
-int dfot_op_gn_silu_bwd4(const float* x, const float* dy, const float* stats, const float* gamma, const float* beta, const void* film, const float* dres,
-                         float* dx, void* dx_bf, void* dfilm, int64_t dfilm_ld, float* dgamma, float* dbeta, int bt, int pixels, int channels,
-                         void* stream);
-/* dfot_op_gn_silu_bwd4 with the upstream gradient dy in bf16 [BT][P][C] (dx_bf of dfot_op_conv3x3_bwd2) */
+
+
+/* backward of GroupNorm (+ FiLM) + SiLU with saved statistics, the upstream gradient dy in bf16 [BT][P][C] (dx_bf of dfot_op_conv3x3_bwd2):
+ * dx = (dres ? dres : 0) + input gradient, as fp32 (dx) and / or bf16 (dx_bf); dfilm optional with its row stride dfilm_ld */
 int dfot_op_gn_silu_bwd5(const float* x, const void* dy_bf, const float* stats, const float* gamma, const float* beta, const void* film, const float* dres,
                          float* dx, void* dx_bf, void* dfilm, int64_t dfilm_ld, float* dgamma, float* dbeta, int bt, int pixels, int channels,
                          void* stream);
@@ -411,11 +405,8 @@ int dfot_op_sub_bf16(const float* a, const float* b, void* out, int64_t n, void*
 int dfot_op_upsample_add(const float* t, const float* skip, float* out, int bt, int h, int w, int c, void* stream);
 int dfot_op_upsample_bwd(const float* dy, float* ds, int bt, int h, int w, int c, void* stream);
 int dfot_op_axpy(float* a, const float* b, float alpha, int64_t n, void* stream);
-int dfot_op_emb_combine(const void* pose, const float* nemb, const uint8_t* mask, void* out, int bt, int pixels, int e, int tokens, void* stream);
 int dfot_op_mul_cols(void* dst, int ldd, int dcol0, const void* mask, int64_t rows, int ncols, void* stream);
-int dfot_op_masked_cast(const float* src, const uint8_t* mask, void* out, int64_t total, int64_t per_video, void* stream);
 int dfot_op_emb_pyramid(const void* emb0, void* emb1, void* emb2, void* emb3, int bt, int r0, int e, void* stream);
-int dfot_op_rows_sum(const float* src, float* out, int bt, int pixels, int e, void* stream);
 int dfot_op_cond_repack(const float* cond, void* a, int bt, int res, int cdim, int kpad, void* stream);
 int dfot_op_embed_input(const float* x, const float* w, const float* b, float* out, int bt, int res, int cin, int c0, void* stream);
 int dfot_op_embed_input_wgrad(const float* dx0, const float* x, float* dw, float* db, int bt, int res, int cin, int c0, int ps, void* stream);
