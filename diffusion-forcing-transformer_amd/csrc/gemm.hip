@@ -596,7 +596,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int tile_inde
           for (int p = 0; p < 2; ++p) {
             const int r = p * 8 + (lane >> 3);
             bf16x8 o;
-            if (AMODE == A_CONV3 && g.resid_bf) {  // (convolutions only: the dense 12-wave tiles have no register to spare) bf16 residual stream (ResBlock levels of the inference engine): same rows / pitch as the output, added
+            if ((AMODE == A_CONV3 || BN_T == 144) && g.resid_bf) {  // (convolutions and the 256x144 ring: the persistent dense 256x192 tiles have no register to spare) bf16 residual stream (ResBlock levels of the inference engine): same rows / pitch as the output, added
               // last (after an activation, if any), loaded here so that it is live for one row only (the 128-register budget of the 16-wave tiles)
               const bf16x8 rb = *reinterpret_cast<const bf16x8*>(g.resid_bf + (mw + r) * g.ldo + col);
 #pragma unroll
@@ -869,7 +869,7 @@ static int launch_v(int variant, const GemmArgs& g, hipStream_t s) {
       if constexpr (AMODE != A_DENSE) break;
       else return launch_t<256, 192, 64, 2, AMODE, EPI, true>(g, s);
     case GEMM_DMA3_256x144:  // (also the long-K Downsample / Upsample convolutions: run_down / run_up)
-      if constexpr (EPI != E_F32) break;
+      if constexpr (EPI != E_F32 && !(EPI == E_BF16 && AMODE == A_DENSE)) break;  // E_BF16: the level-2 out-projection onto the bf16 stream
       else {
         if (g.gn_part) break;
         return launch_t<256, 144, 64, 3, AMODE, EPI, true>(g, s);
@@ -957,7 +957,9 @@ int launch_gemm(int amode, int epi, int variant, const GemmArgs& g, hipStream_t 
                      !g.gn_part && g.K / BK >= 2 * g.ksplit, DFOT_ERR_ARG,
                  "gemm: split-K over workgroups needs the fp32 epilogue with an in-place residual (or none), no gate, and K >= %d", 2 * g.ksplit * BK);
   if (g.bias_rows) DFOT_REQUIRE((epi == E_F32 || epi == E_BF16) && g.bias, DFOT_ERR_ARG, "gemm: 2-D bias needs a plain epilogue");
-  if (g.resid_bf) DFOT_REQUIRE(epi == E_BF16 && amode == A_CONV3 && !g.resid, DFOT_ERR_ARG, "gemm: a bf16 residual needs a convolution with the bf16 epilogue");
+  if (g.resid_bf)
+    DFOT_REQUIRE(epi == E_BF16 && (amode == A_CONV3 || variant == GEMM_DMA3_256x144) && !g.resid, DFOT_ERR_ARG,
+                 "gemm: a bf16 residual needs the bf16 epilogue of a convolution or of the 256x144 ring");
   if (g.tr_rows) {
     DFOT_REQUIRE(epi == E_BF16 && !g.bias && !g.act && !g.gn_part && g.tr_rows % 4 == 0 && g.M % g.tr_rows == 0 && amode == A_DENSE,
                  DFOT_ERR_ARG, "gemm: transposed store needs the plain bf16 epilogue and tr_rows %% 4 == 0 dividing M");

@@ -37,7 +37,7 @@ int launch_gn_film_silu(const bf16* h, const float* stats, const float* gamma, c
                         hipStream_t s, const uint8_t* live = nullptr);
 // a residual stream whose last out-projection is still two or three K-slice partials: x += bias[c] + s0 + s1 (+ s2) (run_tr_block, uvit.hip)
 struct RmsPending {
-  float* x;
+  void* x;  // where the completed sum goes: fp32 (launch_rms_film) or bf16 (launch_rms_film_bf16), the type of the stream
   const float* bias;
   const float* s0;
   const float* s1;
@@ -45,6 +45,8 @@ struct RmsPending {
 };
 int launch_rms_film(const float* x, const float* w, const bf16* fcache, const float* sv, const uint8_t* cond_mask, bf16* out,
                     long m, int c, int rows_per_bt, int tokens, float eps, hipStream_t s, const RmsPending* pend = nullptr);
+int launch_rms_film_bf16(const bf16* x, const float* w, const bf16* fcache, const float* sv, const uint8_t* cond_mask, bf16* out,
+                         long m, int c, int rows_per_bt, int tokens, float eps, hipStream_t s, const RmsPending* pend = nullptr);
 
 // ---- resampling / skips ----
 int launch_pool2_bf16(const float* x, bf16* out, int bt, int h, int w, int c, hipStream_t s);

@@ -76,6 +76,18 @@ __device__ __forceinline__ float4v stream_ld4(const T* p) {
   }
 }
 template <typename T>
+__device__ __forceinline__ void stream_st8(T* p, const float (&v)[8]) {
+  if constexpr (sizeof(T) == 4) {
+    *reinterpret_cast<float4v*>(p) = float4v{v[0], v[1], v[2], v[3]};
+    *reinterpret_cast<float4v*>(p + 4) = float4v{v[4], v[5], v[6], v[7]};
+  } else {
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = f2bf(v[j]);
+    *reinterpret_cast<bf16x8*>(p) = o;
+  }
+}
+template <typename T>
 __device__ __forceinline__ void stream_st4(T* p, float4v v) {
   if constexpr (sizeof(T) == 4) {
     *reinterpret_cast<float4v*>(p) = v;
@@ -863,42 +875,42 @@ int launch_gn_film_silu(const bf16* h, const float* stats, const float* gamma, c
 // TransformerBlock: xn = RMSNorm(x) * w * (1 + scale) + shift, fp32 stream in -> bf16 out; one wave per token
 // PEND: the residual stream still lacks the previous block's out-projection, left as two K-slice partials: x += bias + s0 + s1 is
 // applied here (and written back) instead of in a pass of its own
-template <int MAXCH, bool PEND>
-__global__ __launch_bounds__(256) void rms_film_kernel(const float* x, const float* __restrict__ w,
+// TS: element type of the residual stream (fp32, or bf16: the value written back by PEND is then the bf16 rounding of the sum, and the
+// norm is taken of that rounded value -- what the next reader of the stream sees)
+template <int MAXCH, bool PEND, typename TS>
+__global__ __launch_bounds__(256) void rms_film_kernel(const TS* x, const float* __restrict__ w,
                                                        const bf16* __restrict__ fcache, const float* __restrict__ sv,
                                                        const uint8_t* __restrict__ cond_mask, bf16* __restrict__ out,
-                                                       long m, int c, int rows_per_bt, int tokens, float eps, float* xw,
+                                                       long m, int c, int rows_per_bt, int tokens, float eps, TS* xw,
                                                        const float* __restrict__ pbias, const float* __restrict__ p0,
                                                        const float* __restrict__ p1, const float* __restrict__ p2) {
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= m) return;
   const int lane = threadIdx.x & 63;
   const int nch = c / 8;
-  const float* src = x + row * c;
+  const TS* src = x + row * c;
   float v[MAXCH][8];
   float ss = 0.f;
 #pragma unroll
   for (int k = 0; k < MAXCH; ++k) {
     const int ch = lane + 64 * k;
     if (ch < nch) {
-      const float4v a = *reinterpret_cast<const float4v*>(src + ch * 8);
-      const float4v b = *reinterpret_cast<const float4v*>(src + ch * 8 + 4);
-      v[k][0] = a[0]; v[k][1] = a[1]; v[k][2] = a[2]; v[k][3] = a[3];
-      v[k][4] = b[0]; v[k][5] = b[1]; v[k][6] = b[2]; v[k][7] = b[3];
+      stream_ld8(src + ch * 8, v[k]);
       if constexpr (PEND) {
         const long o = row * c + ch * 8;
-        float4v lo = a, hi = b;
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
           float4v add = *reinterpret_cast<const float4v*>(pbias + ch * 8 + 4 * hf) + *reinterpret_cast<const float4v*>(p0 + o + 4 * hf) +
                         *reinterpret_cast<const float4v*>(p1 + o + 4 * hf);
           if (p2) add += *reinterpret_cast<const float4v*>(p2 + o + 4 * hf);
-          if (hf == 0) lo += add; else hi += add;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[k][4 * hf + j] += add[j];
         }
-        *reinterpret_cast<float4v*>(xw + o) = lo;
-        *reinterpret_cast<float4v*>(xw + o + 4) = hi;
-        v[k][0] = lo[0]; v[k][1] = lo[1]; v[k][2] = lo[2]; v[k][3] = lo[3];
-        v[k][4] = hi[0]; v[k][5] = hi[1]; v[k][6] = hi[2]; v[k][7] = hi[3];
+        stream_st8(xw + o, v[k]);
+        if constexpr (sizeof(TS) == 2) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[k][j] = bf2f(f2bf(v[k][j]));
+        }
       }
 #pragma unroll
       for (int j = 0; j < 8; ++j) ss += v[k][j] * v[k][j];
@@ -937,12 +949,13 @@ __global__ __launch_bounds__(256) void rms_film_kernel(const float* x, const flo
     }
   }
 }
-int launch_rms_film(const float* x, const float* w, const bf16* fcache, const float* sv, const uint8_t* cond_mask, bf16* out,
-                    long m, int c, int rows_per_bt, int tokens, float eps, hipStream_t s, const RmsPending* pend) {
+template <typename TS>
+static int launch_rms_film_t(const TS* x, const float* w, const bf16* fcache, const float* sv, const uint8_t* cond_mask, bf16* out,
+                             long m, int c, int rows_per_bt, int tokens, float eps, hipStream_t s, const RmsPending* pend) {
   DFOT_REQUIRE(c % 8 == 0 && c <= 8 * 64 * 3, DFOT_ERR_SHAPE, "rms_film: channels %d unsupported", c);
 #define RMS_CALL(MC, P)                                                                                                             \
-  hipLaunchKernelGGL((rms_film_kernel<MC, P>), dim3(cdiv(m, 4)), dim3(256), 0, s, x, w, fcache, sv, cond_mask, out, m, c, rows_per_bt, \
-                     tokens, eps, P ? pend->x : nullptr, P ? pend->bias : nullptr, P ? pend->s0 : nullptr, P ? pend->s1 : nullptr, P ? pend->s2 : nullptr)
+  hipLaunchKernelGGL((rms_film_kernel<MC, P, TS>), dim3(cdiv(m, 4)), dim3(256), 0, s, x, w, fcache, sv, cond_mask, out, m, c, rows_per_bt, \
+                     tokens, eps, P ? (TS*)pend->x : nullptr, P ? pend->bias : nullptr, P ? pend->s0 : nullptr, P ? pend->s1 : nullptr, P ? pend->s2 : nullptr)
   if (pend) {
     // x is read, x + bias + slices is normalised AND written to pend->x (the same buffer, or X[l] when the stream still sits in the skip tensor)
     DFOT_REQUIRE(pend->x && pend->bias && pend->s0 && pend->s1, DFOT_ERR_ARG, "rms_film: pending sum needs a target, a bias and two slices");
@@ -953,6 +966,15 @@ int launch_rms_film(const float* x, const float* w, const bf16* fcache, const fl
 #undef RMS_CALL
   DFOT_CHECK_HIP(hipGetLastError());
   return DFOT_OK;
+}
+int launch_rms_film(const float* x, const float* w, const bf16* fcache, const float* sv, const uint8_t* cond_mask, bf16* out,
+                    long m, int c, int rows_per_bt, int tokens, float eps, hipStream_t s, const RmsPending* pend) {
+  return launch_rms_film_t<float>(x, w, fcache, sv, cond_mask, out, m, c, rows_per_bt, tokens, eps, s, pend);
+}
+// the stream (x, and pend->x) in bf16
+int launch_rms_film_bf16(const bf16* x, const float* w, const bf16* fcache, const float* sv, const uint8_t* cond_mask, bf16* out,
+                         long m, int c, int rows_per_bt, int tokens, float eps, hipStream_t s, const RmsPending* pend) {
+  return launch_rms_film_t<bf16>(x, w, fcache, sv, cond_mask, out, m, c, rows_per_bt, tokens, eps, s, pend);
 }
 
 // --------------------------------------------------------------------------------------------

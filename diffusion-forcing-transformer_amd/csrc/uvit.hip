@@ -122,12 +122,15 @@ struct dfot_uvit_s {
   // where the residual stream of a level currently lives: X[l], or HSA[l-1] right after the Downsample convolution (its output is both
   // the skip tensor and the next level's input: the first block of the level reads it there and writes X[l], no copy)
   const float* xin[4] = {nullptr, nullptr, nullptr, nullptr};
-  // ResBlock levels (0, 1): the stream between blocks is bf16 (XB[l]) -- what torch.autocast(bf16) keeps there in the reference: every
+  // The residual stream between the blocks of a level is bf16 (XB[l]).  ResBlock levels (0, 1) -- what torch.autocast(bf16) keeps there in the reference: every
   // block's second convolution adds the residual in its bf16 epilogue.  A level is ENTERED from an fp32 tensor (level 1: the Downsample
   // output HSA[0], which stays fp32 as skip tensor) or from XB[l] itself (level 0: the patch embedding writes bf16; up path: upsample_add).
   // xin_bf[l]: the level's stream currently lives in XB[l] (xin[l] is then unused).
-  bf16* XB[2] = {nullptr, nullptr};
-  bool xin_bf[2] = {false, false};
+  // Transformer levels (2, 3): the same -- the out-projection adds the residual in its bf16 epilogue (level 2) or leaves K-slice
+  // partials that the next block's norm kernel adds into the bf16 stream (level 3); a level entered from the fp32 Downsample output is
+  // cast once.
+  bf16* XB[4] = {nullptr, nullptr, nullptr, nullptr};
+  bool xin_bf[4] = {false, false, false, false};
   int gemm_variant = GEMM_AUTO;
   int attn_variant = 2;
   bool attn_force_safe = false;  // level-2 attention: always the running-max kernel (what weights with a bound >= 64 get)
@@ -418,15 +421,26 @@ static int run_res_block(dfot_uvit_s* h, const ResW& w, int lvl, int bt, hipStre
   return DFOT_OK;
 }
 
-// x += bias + slice0 + slice1 (fp32, 4 elements per thread): the reduce pass of the two-slice out-projection
-__global__ void out_reduce_kernel(float* x, const float* xsrc, const float* __restrict__ bias, const float* __restrict__ s0,
-                                  const float* __restrict__ s1, const float* __restrict__ s2, long total4, int cq) {
+// x += bias + slice0 + slice1 (+ slice2) on the bf16 stream (fp32 sums, 4 elements per thread): the reduce pass of the K-sliced
+// out-projection where no norm kernel follows to do it (end of a level)
+__global__ void out_reduce_kernel(bf16* x, const float* __restrict__ bias, const float* __restrict__ s0, const float* __restrict__ s1,
+                                  const float* __restrict__ s2, long total4, int cq) {
   typedef __attribute__((ext_vector_type(4))) float f4;
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total4) return;
   f4 b = reinterpret_cast<const f4*>(bias)[i % cq] + reinterpret_cast<const f4*>(s0)[i] + reinterpret_cast<const f4*>(s1)[i];
   if (s2) b += reinterpret_cast<const f4*>(s2)[i];
-  reinterpret_cast<f4*>(x)[i] = reinterpret_cast<const f4*>(xsrc)[i] + b;
+  const bf16x4 xv = reinterpret_cast<const bf16x4*>(x)[i];
+  reinterpret_cast<bf16x4*>(x)[i] = bf16x4{f2bf(bf2f(xv[0]) + b[0]), f2bf(bf2f(xv[1]) + b[1]), f2bf(bf2f(xv[2]) + b[2]), f2bf(bf2f(xv[3]) + b[3])};
+}
+// x (bf16 stream) += y (fp32): the fallback of the out-projection when a forced GEMM tile form has no bf16 residual epilogue
+__global__ void add_f32_into_bf16_kernel(bf16* x, const float* __restrict__ y, long total4) {
+  typedef __attribute__((ext_vector_type(4))) float f4;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total4) return;
+  const f4 b = reinterpret_cast<const f4*>(y)[i];
+  const bf16x4 xv = reinterpret_cast<const bf16x4*>(x)[i];
+  reinterpret_cast<bf16x4*>(x)[i] = bf16x4{f2bf(bf2f(xv[0]) + b[0]), f2bf(bf2f(xv[1]) + b[1]), f2bf(bf2f(xv[2]) + b[2]), f2bf(bf2f(xv[3]) + b[3])};
 }
 
 static void swap_out_part(dfot_uvit_s* h) { h->pend_part = h->out_part; }
@@ -434,10 +448,9 @@ static void swap_out_part(dfot_uvit_s* h) { h->pend_part = h->out_part; }
 static int flush_pending(dfot_uvit_s* h, hipStream_t s) {
   if (!h->pend_bias) return DFOT_OK;
   const long total4 = h->pend_m * h->pend_c / 4;
-  hipLaunchKernelGGL(out_reduce_kernel, dim3(cdiv(total4, 256)), dim3(256), 0, s, h->X[h->pend_lvl], h->xin[h->pend_lvl], h->pend_bias, h->pend_part,
+  hipLaunchKernelGGL(out_reduce_kernel, dim3(cdiv(total4, 256)), dim3(256), 0, s, h->XB[h->pend_lvl], h->pend_bias, h->pend_part,
                      h->pend_part + h->pend_m * h->pend_c, h->pend_slices == 3 ? h->pend_part + 2 * h->pend_m * h->pend_c : nullptr, total4,
                      h->pend_c / 4);
-  h->xin[h->pend_lvl] = h->X[h->pend_lvl];
   h->pend_bias = nullptr;
   DFOT_CHECK_HIP(hipGetLastError());
   return DFOT_OK;
@@ -446,14 +459,17 @@ static int flush_pending(dfot_uvit_s* h, hipStream_t s) {
 static int run_tr_block(dfot_uvit_s* h, const TrW& w, int lvl, int batch, hipStream_t s) {
   const int c = w.c, rr = h->r[lvl], n = h->T * rr * rr, d = c / h->heads;
   const int m = batch * n;
-  float* x = h->X[lvl];
+  bf16* xb = h->XB[lvl];
   int rc = 0;
   if (h->pend_bias && (h->pend_lvl != lvl || h->pend_m != m || h->pend_c != c) && (rc = flush_pending(h, s))) return rc;
-  RmsPending pend{x, h->pend_bias, h->pend_part, h->pend_part + (long)m * c, h->pend_slices == 3 ? h->pend_part + 2L * m * c : nullptr};
-  if ((rc = launch_rms_film(h->xin[lvl], w.nw, w.fcache, h->sv + w.sv_off, h->have_mask ? h->cond_mask : nullptr, h->s1, m, c,
-                            rr * rr, h->T, h->cfg.eps, s, h->pend_bias ? &pend : nullptr)))
+  if (!h->xin_bf[lvl]) {  // the level is entered from the fp32 Downsample output (which stays fp32 as the skip tensor): one cast
+    if ((rc = launch_f32_to_bf16(h->xin[lvl], xb, (long)m * c, s))) return rc;
+    h->xin_bf[lvl] = true;
+  }
+  RmsPending pend{xb, h->pend_bias, h->pend_part, h->pend_part + (long)m * c, h->pend_slices == 3 ? h->pend_part + 2L * m * c : nullptr};
+  if ((rc = launch_rms_film_bf16(xb, w.nw, w.fcache, h->sv + w.sv_off, h->have_mask ? h->cond_mask : nullptr, h->s1, m, c, rr * rr, h->T,
+                                 h->cfg.eps, s, h->pend_bias ? &pend : nullptr)))
     return rc;
-  if (h->pend_bias) h->xin[lvl] = x;  // the pending sum was written to X[lvl]
   h->pend_bias = nullptr;
   GemmArgs p;
   p.A = h->s1; p.lda = c; p.W = w.w_fused; p.M = m; p.N = 7 * c; p.K = c; p.bias = w.b_fused;
@@ -472,8 +488,7 @@ static int run_tr_block(dfot_uvit_s* h, const TrW& w, int lvl, int batch, hipStr
   if ((rc = launch_attention(h->q, h->k, h->v, h->cat, 5 * c, batch, h->heads, n, d, av, s, &h->attn_scratch))) return rc;
   if (timed) DFOT_CHECK_HIP(hipEventRecord(h->ev_stop[h->ev_used++], s));
   GemmArgs o;
-  o.A = h->cat; o.lda = 5 * c; o.W = w.w_out; o.M = m; o.N = c; o.K = 5 * c; o.bias = w.b_out; o.out_f32 = x; o.resid = h->xin[lvl];
-  o.ldo = c;
+  o.A = h->cat; o.lda = 5 * c; o.W = w.w_out; o.M = m; o.N = c; o.K = 5 * c; o.bias = w.b_out; o.ldo = c;
   // level 3 at small model batch: 256x144 tiles give M/256 x N/144 = 128 workgroups for 256 CUs; two K slices into partial buffers
   // make it 256 on the THREE-stage 256x144 ring (150 KB of LDS: the long-K loop no longer waits on the single k-tile a two-stage loop
   // has in flight), and the slices + bias are added into the fp32 residual stream by the NEXT block's norm kernel (deferred: pend_*).
@@ -482,7 +497,7 @@ static int run_tr_block(dfot_uvit_s* h, const TrW& w, int lvl, int batch, hipStr
   if (h->gemm_variant == GEMM_AUTO && h->out_part && (size_t)2 * m * c <= h->out_part_elems && m % 256 == 0 && c % 144 == 0 &&
       (long)(m / 256) * (c / 144) * 2 <= 256 && (5 * c / 64) >= 8) {
     GemmArgs p2 = o;
-    p2.bias = nullptr; p2.resid = nullptr; p2.out_f32 = h->out_part; p2.ksplit = 2; p2.slice_stride = (long)m * c;
+    p2.bias = nullptr; p2.out_f32 = h->out_part; p2.ksplit = 2; p2.slice_stride = (long)m * c;
     if ((rc = launch_gemm(A_DENSE, E_F32, GEMM_DMA3_256x144, p2, s))) return rc;
     h->pend_bias = w.b_out;
     h->pend_lvl = lvl; h->pend_m = m; h->pend_c = c; h->pend_slices = 2;
@@ -493,12 +508,17 @@ static int run_tr_block(dfot_uvit_s* h, const TrW& w, int lvl, int batch, hipStr
   // (N = 4 x 144) are exactly 256, one per CU, at 92 instead of 110 FLOP per operand byte, on the three-stage ring (10.10 vs 10.00
   // frames/s, two rounds; the two-stage form was equal to the 256x192 tiles)
   if (h->gemm_variant == GEMM_AUTO && c % 144 == 0 && m % 256 == 0 && (long)(m / 256) * ((c + 191) / 192) < 256 &&
-      (long)(m / 256) * (c / 144) >= 200 && (long)(m / 256) * (c / 144) <= 256)
-    rc = launch_gemm(A_DENSE, E_F32, GEMM_DMA3_256x144, o, s);
-  else
-    rc = launch_gemm(A_DENSE, E_F32, h->gemm_variant, o, s);
-  h->xin[lvl] = x;
-  return rc;
+      (long)(m / 256) * (c / 144) >= 200 && (long)(m / 256) * (c / 144) <= 256) {
+    o.out_bf16 = xb;
+    o.resid_bf = xb;  // in place on the bf16 stream: a thread reads its elements before it writes them
+    return launch_gemm(A_DENSE, E_BF16, GEMM_DMA3_256x144, o, s);
+  }
+  // any other shape / a forced tile form: the plain fp32 epilogue into the level's fp32 scratch, then one pass adds it into the stream
+  o.out_f32 = h->X[lvl];
+  if ((rc = launch_gemm(A_DENSE, E_F32, h->gemm_variant, o, s))) return rc;
+  hipLaunchKernelGGL(add_f32_into_bf16_kernel, dim3(cdiv((long)m * c / 4, 256)), dim3(256), 0, s, xb, h->X[lvl], (long)m * c / 4);
+  DFOT_CHECK_HIP(hipGetLastError());
+  return DFOT_OK;
 }
 
 // (The block's two independent branches -- attention and MLP, u_vit_blocks.py:253-277 -- were run on two streams for a while; with
@@ -553,7 +573,7 @@ static int conv_between_levels(dfot_uvit_s* h, GemmArgs g, hipStream_t s) {
 static int run_down(dfot_uvit_s* h, int l, int bt, hipStream_t s, const uint8_t* live = nullptr) {
   const int rr = h->r[l], cin = h->ch[l], cout = h->ch[l + 1];
   int rc = 0;
-  if ((rc = (l < 2 && h->xin_bf[l]) ? launch_pool2_bf16_bf16in(h->XB[l], h->s1, bt, rr, rr, cin, s) : launch_pool2_bf16(h->xin[l], h->s1, bt, rr, rr, cin, s)))
+  if ((rc = h->xin_bf[l] ? launch_pool2_bf16_bf16in(h->XB[l], h->s1, bt, rr, rr, cin, s) : launch_pool2_bf16(h->xin[l], h->s1, bt, rr, rr, cin, s)))
     return rc;
   GemmArgs g;
   g.A = h->s1; g.W = h->down_conv[l].w; g.M = bt * (rr / 2) * (rr / 2); g.N = cout; g.K = 9 * cin; g.H = rr / 2; g.Wd = rr / 2;
@@ -566,7 +586,7 @@ static int run_down(dfot_uvit_s* h, int l, int bt, hipStream_t s, const uint8_t*
   if ((rc = conv_between_levels(h, g, s))) return rc;
   h->gn1_nblk = next_is_res ? g.gn_rows_per_bt / 64 : 0;
   h->xin[l + 1] = h->HSA[l];  // the skip tensor IS the next level's input: its first block reads it here and writes X[l + 1]
-  if (l + 1 < 2) h->xin_bf[l + 1] = false;
+  h->xin_bf[l + 1] = false;
   return DFOT_OK;
 }
 
@@ -574,8 +594,8 @@ static int run_up(dfot_uvit_s* h, int l, int bt, hipStream_t s, const uint8_t* l
   const int rr = h->r[l + 1], cin = h->ch[l + 1], cout = h->ch[l];
   const long n_in = (long)bt * rr * rr * cin;
   int rc = 0;
-  if ((rc = (l + 1 < 2 && h->xin_bf[l + 1]) ? launch_sub_bf16_bf16in(h->XB[l + 1], h->HSA[l], h->s1, n_in, s, live, (long)rr * rr * cin)
-                                             : launch_sub_bf16(h->xin[l + 1], h->HSA[l], h->s1, n_in, s, live, (long)rr * rr * cin)))
+  if ((rc = h->xin_bf[l + 1] ? launch_sub_bf16_bf16in(h->XB[l + 1], h->HSA[l], h->s1, n_in, s, live, (long)rr * rr * cin)
+                             : launch_sub_bf16(h->xin[l + 1], h->HSA[l], h->s1, n_in, s, live, (long)rr * rr * cin)))
     return rc;
   GemmArgs g;
   g.A = h->s1; g.W = h->up_conv[l].w; g.M = bt * rr * rr; g.N = cout; g.K = 9 * cin; g.H = rr; g.Wd = rr; g.Cin = cin;
@@ -584,16 +604,12 @@ static int run_up(dfot_uvit_s* h, int l, int bt, hipStream_t s, const uint8_t* l
   if (live && (rr * rr) % 256 == 0 && h->gemm_variant == GEMM_AUTO) g.live = live;
   if ((rc = conv_between_levels(h, g, s))) return rc;
   h->gn1_nblk = 0;  // X[l] is rewritten by an elementwise kernel: its statistics come from the standalone kernel
-  if (l < 2) {  // ResBlock level: the down path left its output in the bf16 stream; the sum goes back into it (elementwise, in place)
-    if (!h->xin_bf[l]) {
-      set_error("run_up: level %d stream is not in its bf16 buffer", l);
-      return DFOT_ERR_STATE;
-    }
-    return launch_upsample_add_bf16(h->tmp, h->XB[l], h->XB[l], bt, rr, rr, cout, s, live);
+  // the down path left the level's output in the bf16 stream; the sum goes back into it (elementwise, in place)
+  if (!h->xin_bf[l]) {
+    set_error("run_up: level %d stream is not in its bf16 buffer", l);
+    return DFOT_ERR_STATE;
   }
-  rc = launch_upsample_add(h->tmp, h->xin[l], h->X[l], bt, rr, rr, cout, s, live);
-  h->xin[l] = h->X[l];
-  return rc;
+  return launch_upsample_add_bf16(h->tmp, h->XB[l], h->XB[l], bt, rr, rr, cout, s, live);
 }
 
 }  // namespace dfot
@@ -725,11 +741,9 @@ int dfot_uvit_reserve(dfot_uvit_t h, int max_batch) {
   if ((rc = dev_alloc(h, &h->nemb, bt * h->E, true))) return rc;
   if ((rc = dev_alloc(h, &h->nhid, bt * h->E, true))) return rc;
   for (int l = 0; l < 4; ++l) {
-    if (l < 2) {
-      if ((rc = dev_alloc(h, &h->XB[l], bt * pix[l] * h->ch[l], true))) return rc;
-    } else if ((rc = dev_alloc(h, &h->X[l], bt * pix[l] * h->ch[l], true))) {
-      return rc;
-    }
+    if ((rc = dev_alloc(h, &h->XB[l], bt * pix[l] * h->ch[l], true))) return rc;
+    // fp32 scratch of a transformer level (the out-projection's fallback path, run_tr_block)
+    if (l >= 2 && (rc = dev_alloc(h, &h->X[l], bt * pix[l] * h->ch[l], true))) return rc;
     if ((rc = dev_alloc(h, &h->emb[l], bt * pix[l] * h->E, true))) return rc;
   }
   for (int l = 0; l < 3; ++l)
@@ -925,7 +939,7 @@ int dfot_uvit_forward_cached_masks(dfot_uvit_t h, const float* x, const float* n
   h->gn1_nblk = 0;
   for (int l = 0; l < 4; ++l) h->xin[l] = h->X[l];
   h->xin_bf[0] = true;
-  h->xin_bf[1] = false;
+  h->xin_bf[1] = h->xin_bf[2] = h->xin_bf[3] = false;
 
   // frames that are NOT fresh (fresh_frames[b * T + t] == 0): the caller states that this frame's input, noise level and conditioning
   // equal those of the previous forward of this handle (a clean context frame of the conditional branch across the DDIM steps of a
@@ -981,7 +995,7 @@ int dfot_uvit_read_tap(dfot_uvit_t h, const char* name, float* out, size_t capac
   const Tap taps[] = {
       {"pose_emb0", 0, h->E, nullptr, h->emb[0]}, {"down0", 1, h->ch[1], h->HSA[0], nullptr},
       {"down1", 2, h->ch[2], h->HSA[1], nullptr}, {"down2", 3, h->ch[3], h->HSA[2], nullptr},
-      {"mid", 3, h->ch[3], h->xin[3], nullptr}, {"up2", 2, h->ch[2], h->xin[2], nullptr},
+      {"mid", 3, h->ch[3], nullptr, h->XB[3]}, {"up2", 2, h->ch[2], nullptr, h->XB[2]},
       {"up1", 1, h->ch[1], nullptr, h->XB[1]}, {"up0", 0, h->ch[0], nullptr, h->XB[0]},
   };
   for (const Tap& t : taps) {
