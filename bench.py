@@ -698,7 +698,7 @@ def main():
         total_attn_flop = 4.0 * n2 * n2 * 64 * 9 * 12 * roofline_fwd
         achieved = total_attn_flop / (attn_ms * 1e-3) / 1e12 if attn_n else None
         traffic = traffic_source = None
-        pmc = next((f for f in (os.path.join(ROOT, "profiles", n) for n in ("r04_pmc_hbm_traffic_8f.json", "r03_pmc_hbm_traffic_8f.json")) if os.path.exists(f)), None)
+        pmc = next((f for f in (os.path.join(ROOT, "profiles", n) for n in ("r04_g_pmc_hbm_traffic_8f.json", "r03_pmc_hbm_traffic_8f.json")) if os.path.exists(f)), None)
         if pmc and res == 256 and not long_rollout:
             ks = [v for n, v in json.load(open(pmc))["kernels"].items() if "attn64_kernel_v5" in n]
             traffic = ks[0]["hbm_bytes_per_launch_corrected"] if ks else None
